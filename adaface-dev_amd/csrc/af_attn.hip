@@ -1,0 +1,373 @@
+// af_attn.hip -- fused attention core  O = softmax(Q K^T * scale + keybias) V  on MFMA,
+// without materialising the [b*h, N, L] score tensor (attention.py:181-202 does).
+//
+// Mapping (gfx950, wave64, v_mfma_f32_32x32x16_f16):
+//   * a workgroup = 4 waves = 128 queries of one (batch, head); each wave owns 32 queries and
+//     keeps the query on the MFMA *lane* from the first product to the store:
+//       S^T[key, query] = K . Q^T          (A = K tile rows from LDS, B = Q fragments in registers)
+//       O^T[d,   query] = V^T . P^T        (A = V^T rows from LDS,   B = exp(S^T) straight from
+//                                           the accumulator registers -- no LDS round trip, no
+//                                           cross-lane shuffle: the accumulator's row index is
+//                                           the next product's k index)
+//     so the online-softmax state (running max m, running sum l) is one scalar per lane, the
+//     two half-waves (which hold different keys of the same query) exchange one value per
+//     64-key stage, and rescaling O is a per-lane multiply;
+//   * head dims 40 / 80 / 160 (SD-1.5: C/8) are consumed in k-steps of 16 (d padded to 48 / 80 /
+//     160) and produce ceil(d/32) 32-row O^T tiles;
+//   * V arrives TRANSPOSED ([B, C, L], key index contiguous -- written that way by the
+//     projection GEMM's epilogue), so V^T fragments are two 8-byte LDS reads; LDS rows are
+//     padded (K: +16 B, V^T: 72 B) to keep ds_read_b128 / ds_read_b64 conflict-free;
+//   * K / V^T stages of 64 keys are double-buffered: global loads of stage t+1 are issued before
+//     the MFMAs of stage t and written to LDS after them (one barrier per stage);
+//   * masked keys (img_mask, attention.py:185-194) and the padding of L up to a stage boundary
+//     are both expressed as an additive per-key bias (-FLT_MAX / excluded), which reproduces
+//     masked_fill_(~mask, -finfo.max) exactly, including the all-masked (uniform) row.
+#include <float.h>
+
+#include "af_common.h"
+
+namespace {
+
+struct AttnArgs {
+  const half_t* q;
+  const half_t* k;
+  const half_t* vt;
+  half_t* o;
+  const float* kbias;
+  int B, Nq, L, heads, d;
+  int ldq, ldk, ldo, ldv, ldb;
+  float c;  // scale * log2(e)
+};
+
+constexpr int KB = 64;     // keys per stage
+constexpr int VST = 36;    // V^T LDS row stride in halves (72 B)
+
+template <int DS>
+__global__ __launch_bounds__(256) void af_attn_kernel(AttnArgs a) {
+  constexpr int DP = 16 * DS;         // padded head dim for the QK^T k-loop
+  constexpr int DT = (DS + 1) / 2;    // 32-row O^T tiles
+  constexpr int DV = 32 * DT;         // V^T rows staged
+  constexpr int KST = DP + 8;         // K LDS row stride (halves)
+  constexpr int KBUF = KB * KST;      // halves
+  constexpr int VBUF = 2 * DV * VST;  // halves
+  constexpr int STAGE = KBUF + VBUF;
+  constexpr int KCH = KB * (DP / 8);  // 16-byte chunks of a K stage
+  constexpr int NKC = (KCH + 255) / 256;
+  constexpr int VCH = DV * 8;  // 16-byte chunks of a V^T stage
+  constexpr int NVC = (VCH + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) char af_smem[];
+  half_t* lds = reinterpret_cast<half_t*>(af_smem);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int query = blockIdx.x * 128 + wave * 32 + r;
+  const int C = a.heads * a.d;
+
+  // ---- Q fragments (B operand of S^T = K Q^T): lane (r, hh) holds Q[query][16 s + 8 hh .. +7]
+  half8_t qf[DS];
+  const half8_t zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  {
+    const half_t* qp = a.q + ((size_t)b * a.Nq + (query < a.Nq ? query : 0)) * a.ldq + h * a.d;
+#pragma unroll
+    for (int s = 0; s < DS; ++s) {
+      const int dc = 16 * s + 8 * hh;
+      qf[s] = (query < a.Nq && dc < a.d) ? *reinterpret_cast<const half8_t*>(qp + dc) : zero8;
+    }
+  }
+
+  half8_t rk[NKC], rv[NVC];
+  auto load_stage = [&](int key0) {
+#pragma unroll
+    for (int j = 0; j < NKC; ++j) {
+      const int i = tid + 256 * j;
+      const int row = i / (DP / 8), ch = i - row * (DP / 8);
+      const int key = key0 + row;
+      const bool ok = i < KCH && key < a.L && ch * 8 < a.d;
+      rk[j] = ok ? *reinterpret_cast<const half8_t*>(a.k + ((size_t)b * a.L + key) * a.ldk + h * a.d + ch * 8) : zero8;
+    }
+#pragma unroll
+    for (int j = 0; j < NVC; ++j) {
+      const int i = tid + 256 * j;
+      const int row = i >> 3, ch = i & 7;
+      const int kk = key0 + ch * 8;
+      const bool ok = i < VCH && row < a.d && kk < a.L;
+      half8_t v = ok ? *reinterpret_cast<const half8_t*>(a.vt + ((size_t)b * C + h * a.d + row) * a.ldv + kk) : zero8;
+      if (ok && kk + 8 > a.L) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (kk + e >= a.L) v[e] = (half_t)0;
+      }
+      rv[j] = v;
+    }
+  };
+  auto store_stage = [&](int buf) {
+    half_t* Ks = lds + buf * STAGE;
+    half_t* Vs = Ks + KBUF;
+#pragma unroll
+    for (int j = 0; j < NKC; ++j) {
+      const int i = tid + 256 * j;
+      if (i < KCH) {
+        const int row = i / (DP / 8), ch = i - row * (DP / 8);
+        *reinterpret_cast<half8_t*>(Ks + row * KST + ch * 8) = rk[j];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NVC; ++j) {
+      const int i = tid + 256 * j;
+      if (i < VCH) {
+        const int row = i >> 3, ch = i & 7;
+        half_t* dst = Vs + ((ch >> 2) * DV + row) * VST + (ch & 3) * 8;
+        const half4_t lo = {rv[j][0], rv[j][1], rv[j][2], rv[j][3]};
+        const half4_t hi = {rv[j][4], rv[j][5], rv[j][6], rv[j][7]};
+        *reinterpret_cast<half4_t*>(dst) = lo;
+        *reinterpret_cast<half4_t*>(dst + 4) = hi;
+      }
+    }
+  };
+
+  floatx16 o[DT];
+#pragma unroll
+  for (int t = 0; t < DT; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[t][i] = 0.f;
+  float m = -FLT_MAX, l = 0.f;
+
+  const int nstage = (a.L + KB - 1) / KB;
+  load_stage(0);
+  store_stage(0);
+  __syncthreads();
+  for (int st = 0; st < nstage; ++st) {
+    const int key0 = st * KB;
+    const bool more = st + 1 < nstage;
+    if (more) load_stage(key0 + KB);
+
+    const half_t* Ks = lds + (st & 1) * STAGE;
+    const half_t* Vs = Ks + KBUF;
+    const int nsub = (key0 + 32 < a.L) ? 2 : 1;
+
+    // ---- S^T = K Q^T for up to two 32-key sub-tiles
+    floatx16 sT[2];
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) sT[sub][i] = 0.f;
+      if (sub < nsub) {
+#pragma unroll
+        for (int s = 0; s < DS; ++s) {
+          const half8_t kf = *reinterpret_cast<const half8_t*>(Ks + (sub * 32 + r) * KST + 16 * s + 8 * hh);
+          sT[sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], sT[sub], 0, 0, 0);
+        }
+      }
+    }
+    // ---- scale, bias, key-range mask; running max
+    float mx = -FLT_MAX;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      if (sub < nsub) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int kb = key0 + sub * 32 + 8 * g + 4 * hh;  // keys kb .. kb+3 live in regs 4g .. 4g+3
+          floatx4 bias = {0.f, 0.f, 0.f, 0.f};
+          if (a.kbias) bias = *reinterpret_cast<const floatx4*>(a.kbias + (size_t)b * a.ldb + kb);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float t = sT[sub][4 * g + e] * a.c + bias[e];
+            t = (kb + e < a.L) ? t : -INFINITY;
+            sT[sub][4 * g + e] = t;
+            mx = fmaxf(mx, t);
+          }
+        }
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m, mx);
+    const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+    m = m_new;
+    l *= alpha;
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) o[t][i] *= alpha;
+
+    // ---- P^T = exp2(S^T - m): accumulator registers become the B operand of the PV product
+    half8_t pf[2][2];
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      if (sub < nsub) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float p = __builtin_amdgcn_exp2f(sT[sub][8 * s2 + j] - m_new);
+            l += p;
+            pf[sub][s2][j] = (half_t)p;
+          }
+        }
+      } else {
+        pf[sub][0] = zero8;
+        pf[sub][1] = zero8;
+      }
+    }
+    // ---- O^T += V^T P^T
+#pragma unroll
+    for (int t = 0; t < DT; ++t) {
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub) {
+        if (sub < nsub) {
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+            const half_t* vp = Vs + (sub * DV + 32 * t + r) * VST + 16 * s2 + 4 * hh;
+            const half4_t lo = *reinterpret_cast<const half4_t*>(vp);
+            const half4_t hi = *reinterpret_cast<const half4_t*>(vp + 8);
+            const half8_t vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[sub][s2], o[t], 0, 0, 0);
+          }
+        }
+      }
+    }
+
+    if (more) store_stage((st + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- normalise and store: lane holds d rows {32t + 8g + 4hh + e} of its query
+  l += __shfl_xor(l, 32, 64);
+  const float inv = 1.0f / l;
+  if (query < a.Nq) {
+    half_t* op = a.o + ((size_t)b * a.Nq + query) * a.ldo + h * a.d;
+#pragma unroll
+    for (int t = 0; t < DT; ++t) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int dd = 32 * t + 8 * g + 4 * hh;
+        if (dd < a.d) {
+          const half4_t v = {(half_t)(o[t][4 * g + 0] * inv), (half_t)(o[t][4 * g + 1] * inv),
+                             (half_t)(o[t][4 * g + 2] * inv), (half_t)(o[t][4 * g + 3] * inv)};
+          *reinterpret_cast<half4_t*>(op + dd) = v;
+        }
+      }
+    }
+  }
+}
+
+template <int DS>
+int launch_attn(const AttnArgs& a, hipStream_t stream) {
+  constexpr int DP = 16 * DS, DT = (DS + 1) / 2, DV = 32 * DT;
+  constexpr size_t lds = (size_t)2 * (KB * (DP + 8) + 2 * DV * VST) * sizeof(half_t);
+  static bool attr_set = false;  // benign race: idempotent attribute
+  if (lds > 65536 && !attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&af_attn_kernel<DS>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return af_fail(AF_E_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
+    attr_set = true;
+  }
+  dim3 grid((a.Nq + 127) / 128, a.heads, a.B), block(256);
+  hipLaunchKernelGGL(af_attn_kernel<DS>, grid, block, lds, stream, a);
+  return af_check_launch("af_attention");
+}
+
+// explicit scores / probabilities for the capture path: one wave per (b, h, query) row, L <= 128
+__global__ __launch_bounds__(256) void af_scores_kernel(const half_t* __restrict__ q, const half_t* __restrict__ k,
+                                                        float* __restrict__ score, float* __restrict__ prob, int B, int Nq,
+                                                        int L, int heads, int d, float scale) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long nrows = (long)B * heads * Nq;
+  if (row >= nrows) return;
+  const int i = (int)(row % Nq);
+  const int h = (int)((row / Nq) % heads);
+  const int b = (int)(row / ((long)Nq * heads));
+  const int C = heads * d;
+  const half_t* qp = q + ((size_t)b * Nq + i) * C + h * d;
+  float s[2];
+#pragma unroll
+  for (int jj = 0; jj < 2; ++jj) {
+    const int j = lane + 64 * jj;
+    float acc = 0.f;
+    if (j < L) {
+      const half_t* kp = k + ((size_t)b * L + j) * C + h * d;
+      for (int c0 = 0; c0 < d; c0 += 8) {
+        const half8_t qv = *reinterpret_cast<const half8_t*>(qp + c0);
+        const half8_t kv = *reinterpret_cast<const half8_t*>(kp + c0);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc += (float)qv[e] * (float)kv[e];
+      }
+    }
+    s[jj] = j < L ? acc * scale : -INFINITY;
+  }
+  const float mx = af_wave_max(fmaxf(s[0], s[1]));
+  const float e0 = __expf(s[0] - mx), e1 = __expf(s[1] - mx);
+  const float inv = 1.0f / af_wave_sum(e0 + e1);
+  float* sp = score + (size_t)row * L;
+  float* pp = prob + (size_t)row * L;
+  if (lane < L) {
+    sp[lane] = s[0];
+    pp[lane] = e0 * inv;
+  }
+  if (lane + 64 < L) {
+    sp[lane + 64] = s[1];
+    pp[lane + 64] = e1 * inv;
+  }
+}
+
+}  // namespace
+
+extern "C" int af_attention(const void* q, const void* k, const void* vt, void* o, const void* keybias, int B, int Nq,
+                            int L, int heads, int d, int ldq, int ldk, int ldo, int ldv, int ldb, float scale,
+                            void* stream) {
+  AF_REQUIRE(q && k && vt && o, "af_attention: null pointer");
+  AF_REQUIRE(B > 0 && Nq > 0 && L > 0 && heads > 0 && d > 0, "af_attention: bad sizes");
+  AF_REQUIRE(d % 8 == 0, "af_attention: head dim must be a multiple of 8");
+  AF_SUPPORTED(d <= 160, "af_attention: head dim > 160");
+  AF_REQUIRE(heads <= 65535 && B <= 65535, "af_attention: grid limit");
+  const int C = heads * d;
+  AF_REQUIRE(ldq >= C && ldk >= C && ldo >= C && ldq % 8 == 0 && ldk % 8 == 0 && ldo % 4 == 0,
+             "af_attention: bad row strides");
+  AF_REQUIRE(ldv % 8 == 0 && ldv >= ((L + 7) / 8) * 8, "af_attention: ldv must be a multiple of 8 and >= roundup(L, 8)");
+  if (keybias) AF_REQUIRE(ldb >= ((L + KB - 1) / KB) * KB && ldb % 4 == 0, "af_attention: ldb must cover L rounded up to 64");
+  AttnArgs a;
+  a.q = (const half_t*)q;
+  a.k = (const half_t*)k;
+  a.vt = (const half_t*)vt;
+  a.o = (half_t*)o;
+  a.kbias = (const float*)keybias;
+  a.B = B;
+  a.Nq = Nq;
+  a.L = L;
+  a.heads = heads;
+  a.d = d;
+  a.ldq = ldq;
+  a.ldk = ldk;
+  a.ldo = ldo;
+  a.ldv = ldv;
+  a.ldb = ldb;
+  a.c = scale * 1.4426950408889634f;
+  AfLaunchScope scope(AF_FAM_ATTN, stream);
+  hipStream_t s = (hipStream_t)stream;
+  const int ds = (d + 15) / 16;
+  switch (ds) {
+    case 1: return launch_attn<1>(a, s);
+    case 2: return launch_attn<2>(a, s);
+    case 3: return launch_attn<3>(a, s);
+    case 4: return launch_attn<4>(a, s);
+    case 5: return launch_attn<5>(a, s);
+    case 6: return launch_attn<6>(a, s);
+    case 8: return launch_attn<8>(a, s);
+    case 10: return launch_attn<10>(a, s);
+    default: return af_fail(AF_E_UNSUPPORTED, "af_attention: unsupported head dim (need ceil(d/16) in {1,2,3,4,5,6,8,10})");
+  }
+}
+
+extern "C" int af_attention_scores(const void* q, const void* k, void* score, void* prob, int B, int Nq, int L, int heads,
+                                   int d, float scale, void* stream) {
+  AF_REQUIRE(q && k && score && prob, "af_attention_scores: null pointer");
+  AF_REQUIRE(B > 0 && Nq > 0 && L > 0 && heads > 0 && d > 0 && d % 8 == 0, "af_attention_scores: bad sizes");
+  AF_SUPPORTED(L <= 128, "af_attention_scores: L > 128 (capture path is for cross-attention only)");
+  const long rows = (long)B * heads * Nq;
+  dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  AfLaunchScope scope(AF_FAM_ATTN, stream);
+  hipLaunchKernelGGL(af_scores_kernel, grid, block, 0, (hipStream_t)stream, (const half_t*)q, (const half_t*)k,
+                     (float*)score, (float*)prob, B, Nq, L, heads, d, scale);
+  return af_check_launch("af_attention_scores");
+}

@@ -1,0 +1,56 @@
+// af_common.h -- shared device/host helpers for libadaface_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#include "../../include/adaface_hip.h"
+
+typedef _Float16 half_t;
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+#define AF_WAVE 64
+
+// ---- host side: error reporting + launch bracketing -------------------------------------
+void af_set_error(const std::string& msg);
+int af_fail(int code, const std::string& msg);
+
+// RAII bracket used by every launcher: records hipEvents around the launch when profiling
+// of `family` is enabled (bench.py roofline leg), and turns a failed launch into AF_E_HIP.
+struct AfLaunchScope {
+  int family;
+  hipStream_t stream;
+  int slot;
+  AfLaunchScope(int family, void* stream);
+  ~AfLaunchScope();
+};
+int af_check_launch(const char* what);
+
+#define AF_REQUIRE(cond, msg)                                      \
+  do {                                                             \
+    if (!(cond)) return af_fail(AF_E_BADARG, std::string(msg));    \
+  } while (0)
+#define AF_SUPPORTED(cond, msg)                                      \
+  do {                                                               \
+    if (!(cond)) return af_fail(AF_E_UNSUPPORTED, std::string(msg)); \
+  } while (0)
+
+// ---- device helpers ------------------------------------------------------------------------
+__device__ __forceinline__ float af_silu(float x) { return x / (1.0f + __expf(-x)); }
+// exact (erf) GELU as F.gelu default (attention.py:38)
+__device__ __forceinline__ float af_gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+__device__ __forceinline__ float af_wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ float af_wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  return v;
+}

@@ -1,0 +1,119 @@
+// af_elem.hip -- small element-wise kernels around the U-Net: timestep embedding, layout
+// conversion at the NCHW fp32 API boundary, classifier-free guidance + DDIM update, q_sample.
+#include "af_common.h"
+
+namespace {
+
+__global__ void temb_kernel(const int64_t* __restrict__ t, half_t* __restrict__ out, int B, int dim, float max_period) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int half_dim = dim / 2;
+  if (idx >= B * dim) return;
+  const int b = idx / dim, j = idx - b * dim;
+  float v = 0.f;
+  if (j < 2 * half_dim) {
+    const int kk = j < half_dim ? j : j - half_dim;
+    // freqs = exp(-ln(max_period) * k / half)   (util.py:165-167), args = t * freqs
+    const float f = expf(-logf(max_period) * (float)kk / (float)half_dim);
+    const float arg = (float)t[b] * f;
+    v = j < half_dim ? cosf(arg) : sinf(arg);
+  }
+  out[idx] = (half_t)v;
+}
+
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, half_t* __restrict__ y, int B, int C, int HW, int cpad) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long n = (long)B * HW * cpad;
+  if (idx >= n) return;
+  const int c = (int)(idx % cpad);
+  const long pix = idx / cpad;
+  const int b = (int)(pix / HW);
+  const int p = (int)(pix - (long)b * HW);
+  y[idx] = c < C ? (half_t)x[((long)b * C + c) * HW + p] : (half_t)0;
+}
+
+__global__ void nhwc_to_nchw_kernel(const half_t* __restrict__ x, float* __restrict__ y, int B, int C, int HW, int cstride) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long n = (long)B * C * HW;
+  if (idx >= n) return;
+  const int p = (int)(idx % HW);
+  const long bc = idx / HW;
+  const int c = (int)(bc % C);
+  const int b = (int)(bc / C);
+  y[idx] = (float)x[((long)b * HW + p) * cstride + c];
+}
+
+__global__ void cfg_ddim_kernel(const float* __restrict__ eps2, const float* __restrict__ x, float* __restrict__ x_prev,
+                                float* __restrict__ pred_x0, long n, int has_uncond, float g, float sqrt_one_minus_at,
+                                float sqrt_at, float sqrt_aprev, float dir_coef) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float e = eps2[i];
+  if (has_uncond) {
+    const float eu = eps2[n + i];
+    e = eu + g * (e - eu);
+  }
+  const float p0 = (x[i] - sqrt_one_minus_at * e) / sqrt_at;
+  if (pred_x0) pred_x0[i] = p0;
+  x_prev[i] = sqrt_aprev * p0 + dir_coef * e;
+}
+
+__global__ void q_sample_kernel(const float* __restrict__ x0, const float* __restrict__ noise, const float* __restrict__ sa,
+                                const float* __restrict__ sb, float* __restrict__ xt, int B, long per) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)B * per) return;
+  const int b = (int)(i / per);
+  xt[i] = sa[b] * x0[i] + sb[b] * noise[i];
+}
+
+inline dim3 grid1d(long n, int block = 256) { return dim3((unsigned)((n + block - 1) / block)); }
+
+}  // namespace
+
+extern "C" int af_timestep_embedding(const void* timesteps_i64, void* out, int B, int dim, float max_period, void* stream) {
+  AF_REQUIRE(timesteps_i64 && out && B > 0 && dim > 0, "af_timestep_embedding: bad argument");
+  AfLaunchScope scope(AF_FAM_ELEM, stream);
+  hipLaunchKernelGGL(temb_kernel, grid1d((long)B * dim), dim3(256), 0, (hipStream_t)stream, (const int64_t*)timesteps_i64,
+                     (half_t*)out, B, dim, max_period);
+  return af_check_launch("af_timestep_embedding");
+}
+
+extern "C" int af_nchw_f32_to_nhwc_f16(const void* x, void* y, int B, int C, int HW, int cpad, void* stream) {
+  AF_REQUIRE(x && y && B > 0 && C > 0 && HW > 0 && cpad >= C, "af_nchw_f32_to_nhwc_f16: bad argument");
+  AfLaunchScope scope(AF_FAM_ELEM, stream);
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, grid1d((long)B * HW * cpad), dim3(256), 0, (hipStream_t)stream, (const float*)x,
+                     (half_t*)y, B, C, HW, cpad);
+  return af_check_launch("af_nchw_f32_to_nhwc_f16");
+}
+
+extern "C" int af_nhwc_f16_to_nchw_f32(const void* x, void* y, int B, int C, int HW, int cstride, void* stream) {
+  AF_REQUIRE(x && y && B > 0 && C > 0 && HW > 0 && cstride >= C, "af_nhwc_f16_to_nchw_f32: bad argument");
+  AfLaunchScope scope(AF_FAM_ELEM, stream);
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, grid1d((long)B * C * HW), dim3(256), 0, (hipStream_t)stream, (const half_t*)x,
+                     (float*)y, B, C, HW, cstride);
+  return af_check_launch("af_nhwc_f16_to_nchw_f32");
+}
+
+extern "C" int af_cfg_ddim_step(const void* eps2, const void* x, void* x_prev, void* pred_x0, int64_t n, int has_uncond,
+                                float guidance, float a_t, float a_prev, void* stream) {
+  AF_REQUIRE(eps2 && x && x_prev && n > 0, "af_cfg_ddim_step: bad argument");
+  AF_REQUIRE(a_t > 0.f && a_t <= 1.f && a_prev > 0.f && a_prev <= 1.f, "af_cfg_ddim_step: alphas must be in (0, 1]");
+  // fp32 scalar arithmetic exactly as ddim.py:279-301 (torch.full(..., fp32).sqrt())
+  const float sqrt_one_minus_at = sqrtf(1.0f - a_t);
+  const float sqrt_at = sqrtf(a_t);
+  const float sqrt_aprev = sqrtf(a_prev);
+  const float dir_coef = sqrtf(1.0f - a_prev);
+  AfLaunchScope scope(AF_FAM_ELEM, stream);
+  hipLaunchKernelGGL(cfg_ddim_kernel, grid1d(n), dim3(256), 0, (hipStream_t)stream, (const float*)eps2, (const float*)x,
+                     (float*)x_prev, (float*)pred_x0, (long)n, has_uncond, guidance, sqrt_one_minus_at, sqrt_at, sqrt_aprev,
+                     dir_coef);
+  return af_check_launch("af_cfg_ddim_step");
+}
+
+extern "C" int af_q_sample(const void* x0, const void* noise, const void* sa, const void* sb, void* xt, int B, int64_t per,
+                           void* stream) {
+  AF_REQUIRE(x0 && noise && sa && sb && xt && B > 0 && per > 0, "af_q_sample: bad argument");
+  AfLaunchScope scope(AF_FAM_ELEM, stream);
+  hipLaunchKernelGGL(q_sample_kernel, grid1d((long)B * per), dim3(256), 0, (hipStream_t)stream, (const float*)x0,
+                     (const float*)noise, (const float*)sa, (const float*)sb, (float*)xt, B, (long)per);
+  return af_check_launch("af_q_sample");
+}

@@ -1,0 +1,366 @@
+// af_gemm.hip -- one MFMA kernel template for every matmul-shaped op of the U-Net:
+// 3x3 convolution as implicit GEMM over NHWC (stride 1/2, fused nearest-x2 upsample, fused
+// channel concat of two sources), 1x1 convolution and nn.Linear.
+//
+//   out[m, n] = epilogue( sum_k A[m, k] * Wt[n, k] )
+//
+// Layout / mapping (gfx950, wave64):
+//   * both operands are K-contiguous, so A (activations) and Wt (weights) fragments are
+//     16-byte rows for v_mfma_f32_16x16x32_f16;
+//   * the MFMA is issued "swapped" (Wt as the A operand, activations as the B operand) so the
+//     accumulator holds 4 CONSECUTIVE output channels per lane -> 8-byte epilogue stores and
+//     8-byte bias / residual loads along the contiguous dimension of the NHWC output;
+//   * block tile BM x BN x 64, 4 waves as 2(M) x 2(N); LDS tiles are [rows][64] fp16 with the
+//     16-byte chunk index XOR-swizzled by (row & 7) so ds_read_b128 fragment reads are
+//     conflict-free; global->register->LDS staging, double-buffered, one barrier per K step
+//     (the next tile's global loads are issued before the MFMAs of the current one);
+//   * workgroup ids are remapped so each XCD (private L2) walks a contiguous range of tiles.
+#include "af_common.h"
+
+namespace {
+
+struct GemmDev {
+  const half_t* a1;
+  const half_t* a2;
+  const half_t* wt;
+  const float* bias;
+  const half_t* rowbias;
+  const half_t* residual;
+  half_t* out;
+  half_t* out2;
+  int M, N, K, kpad;
+  int c1, c2, lda1, lda2;
+  int H, W, Ho, Wo, HoWo, Heff, Weff, stride, upsample;
+  int rows_per_batch, ld_rowbias, act_silu, ld_out, split_col, ld_out2;
+  int tiles_n;
+};
+
+constexpr int BK = 64;
+enum { EPI_STD = 0, EPI_GEGLU = 1, EPI_SPLIT_T = 2 };
+
+template <int BM, int BN, int TAPS, int EPI>
+__global__ __launch_bounds__(256, 2) void af_gemm_kernel(GemmDev p) {
+  constexpr int WM = BM / 2, WN = BN / 2;    // per-wave tile
+  constexpr int TM = WM / 16, TN = WN / 16;  // 16x16 MFMA tiles per wave
+  constexpr int AI = BM / 32, WI = BN / 32;  // 16-byte chunks per thread per K step
+  constexpr int STAGE = (BM + BN) * BK;      // halves per LDS buffer
+  extern __shared__ __attribute__((aligned(16))) char af_smem[];
+  half_t* lds = reinterpret_cast<half_t*>(af_smem);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 1, wn = wave >> 1;
+
+  // XCD-aware, bijective tile remap (blocks b and b+8 share an XCD / L2).
+  int tile_m, tile_n;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    tile_m = lid / p.tiles_n;
+    tile_n = lid - tile_m * p.tiles_n;
+  }
+
+  // ---- loader state: thread owns chunk column cc (8 halves) of rows rb + 32*i
+  const int cc = tid & 7, rb = tid >> 3;
+  const int Cin = p.c1 + p.c2;
+  int a_iy0[AI], a_ix0[AI], a_base[AI];
+#pragma unroll
+  for (int i = 0; i < AI; ++i) {
+    const int m = tile_m * BM + rb + 32 * i;
+    if (TAPS == 9) {
+      if (m < p.M) {
+        const int b = m / p.HoWo;
+        const int rem = m - b * p.HoWo;
+        const int oy = rem / p.Wo;
+        const int ox = rem - oy * p.Wo;
+        a_iy0[i] = oy * p.stride - 1;
+        a_ix0[i] = ox * p.stride - 1;
+        a_base[i] = b * p.H * p.W;
+      } else {
+        a_iy0[i] = -(1 << 20);
+        a_ix0[i] = 0;
+        a_base[i] = 0;
+      }
+    } else {
+      a_base[i] = (m < p.M) ? m : -1;
+      a_iy0[i] = a_ix0[i] = 0;
+    }
+  }
+  int tap = 0, c = cc * 8;  // TAPS==9: (tap, channel) of this thread's chunk in the current K step
+  if (TAPS == 9) {
+    while (c >= Cin) {
+      c -= Cin;
+      ++tap;
+    }
+  }
+
+  half8_t ra[AI], rw[WI];
+  const half8_t zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+  auto load_tile = [&](int kt) {
+    const half_t* wp = p.wt + (size_t)(tile_n * BN + rb) * p.kpad + kt * BK + cc * 8;
+#pragma unroll
+    for (int i = 0; i < WI; ++i) rw[i] = *reinterpret_cast<const half8_t*>(wp + (size_t)i * 32 * p.kpad);
+    if (TAPS == 9) {
+      const bool kval = tap < 9;
+      const int ky = tap / 3, kx = tap - ky * 3;
+      const half_t* src;
+      int cs, coff;
+      if (c < p.c1) {
+        src = p.a1;
+        cs = p.c1;
+        coff = c;
+      } else {
+        src = p.a2;
+        cs = p.c2;
+        coff = c - p.c1;
+      }
+#pragma unroll
+      for (int i = 0; i < AI; ++i) {
+        const int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
+        const bool ok = kval && (unsigned)iy < (unsigned)p.Heff && (unsigned)ix < (unsigned)p.Weff;
+        const int sy = p.upsample ? (iy >> 1) : iy, sx = p.upsample ? (ix >> 1) : ix;
+        const size_t off = ((size_t)(a_base[i] + sy * p.W + sx)) * cs + coff;
+        ra[i] = ok ? *reinterpret_cast<const half8_t*>(src + off) : zero8;
+      }
+      c += BK;
+      while (c >= Cin) {
+        c -= Cin;
+        ++tap;
+      }
+    } else {
+      const int k = kt * BK + cc * 8;
+      const bool kval = k < p.K;
+      const half_t* src;
+      int ld, koff;
+      if (k < p.c1) {
+        src = p.a1;
+        ld = p.lda1;
+        koff = k;
+      } else {
+        src = p.a2;
+        ld = p.lda2;
+        koff = k - p.c1;
+      }
+#pragma unroll
+      for (int i = 0; i < AI; ++i) {
+        const bool ok = kval && a_base[i] >= 0;
+        ra[i] = ok ? *reinterpret_cast<const half8_t*>(src + (size_t)a_base[i] * ld + koff) : zero8;
+      }
+    }
+  };
+
+  const int st_off = ((cc ^ (rb & 7)) * 8);  // swizzled chunk, identical for every row this thread writes
+  auto store_tile = [&](int buf) {
+    half_t* As = lds + buf * STAGE;
+    half_t* Ws = As + BM * BK;
+#pragma unroll
+    for (int i = 0; i < AI; ++i) *reinterpret_cast<half8_t*>(As + (rb + 32 * i) * BK + st_off) = ra[i];
+#pragma unroll
+    for (int i = 0; i < WI; ++i) *reinterpret_cast<half8_t*>(Ws + (rb + 32 * i) * BK + st_off) = rw[i];
+  };
+
+  floatx4 acc[TN][TM];
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) acc[tn][tm] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+  const int fr = lane & 15, fq = lane >> 4;
+  auto compute = [&](int buf) {
+    const half_t* As = lds + buf * STAGE;
+    const half_t* Ws = As + BM * BK;
+#pragma unroll
+    for (int ks = 0; ks < BK / 32; ++ks) {
+      const int sw = ((ks * 4 + fq) ^ (fr & 7)) * 8;
+      half8_t wf[TN], xf[TM];
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+        wf[tn] = *reinterpret_cast<const half8_t*>(Ws + (wn * WN + tn * 16 + fr) * BK + sw);
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+        xf[tm] = *reinterpret_cast<const half8_t*>(As + (wm * WM + tm * 16 + fr) * BK + sw);
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+          acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[tn], xf[tm], acc[tn][tm], 0, 0, 0);
+    }
+  };
+
+  const int nk = p.kpad / BK;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const bool more = kt + 1 < nk;
+    if (more) load_tile(kt + 1);
+    compute(kt & 1);
+    if (more) store_tile((kt + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds rows n0..n0+3 (consecutive output channels) of column m
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    const int m = tile_m * BM + wm * WM + tm * 16 + fr;
+    if (m >= p.M) continue;
+    const int bidx = (p.rowbias != nullptr || EPI == EPI_SPLIT_T) ? m / p.rows_per_batch : 0;
+#pragma unroll
+    for (int tn = 0; tn < TN; tn += (EPI == EPI_GEGLU ? 2 : 1)) {
+      const int nt = tile_n * BN + wn * WN + tn * 16;  // first row of this 16-row MFMA tile
+      const int n0 = nt + 4 * fq;
+      float v[4];
+      if (EPI == EPI_GEGLU) {
+        // Wt rows are interleaved [16 value rows | 16 gate rows]; output column = nt/2 + 4*fq + i
+        const int no = (nt >> 1) + 4 * fq;
+        if (no >= (p.N >> 1)) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float xv = acc[tn][tm][i], gv = acc[tn + 1][tm][i];
+          if (p.bias) {
+            xv += p.bias[n0 + i];
+            gv += p.bias[n0 + 16 + i];
+          }
+          v[i] = xv * af_gelu_erf(gv);
+        }
+        half4_t h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+        *reinterpret_cast<half4_t*>(p.out + (size_t)m * p.ld_out + no) = h;
+      } else {
+        if (n0 >= p.N) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = acc[tn][tm][i];
+        if (p.bias) {
+          const floatx4 bv = *reinterpret_cast<const floatx4*>(p.bias + n0);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] += bv[i];
+        }
+        if (p.rowbias) {
+          const half4_t rv = *reinterpret_cast<const half4_t*>(p.rowbias + (size_t)bidx * p.ld_rowbias + n0);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] += (float)rv[i];
+        }
+        if (p.act_silu) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = af_silu(v[i]);
+        }
+        if (EPI == EPI_SPLIT_T && n0 >= p.split_col) {
+          const int tok = m - bidx * p.rows_per_batch;
+          half_t* o2 = p.out2 + ((size_t)bidx * (p.N - p.split_col) + (n0 - p.split_col)) * p.ld_out2 + tok;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) o2[(size_t)i * p.ld_out2] = (half_t)v[i];
+        } else {
+          if (p.residual) {
+            const half4_t rv = *reinterpret_cast<const half4_t*>(p.residual + (size_t)m * p.N + n0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] += (float)rv[i];
+          }
+          half4_t h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+          *reinterpret_cast<half4_t*>(p.out + (size_t)m * p.ld_out + n0) = h;
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int TAPS, int EPI>
+int launch(const GemmDev& p0, hipStream_t stream) {
+  GemmDev p = p0;
+  const int tiles_m = (p.M + BM - 1) / BM;
+  p.tiles_n = (p.N + BN - 1) / BN;
+  const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(half_t);
+  dim3 grid(tiles_m * p.tiles_n), block(256);
+  hipLaunchKernelGGL((af_gemm_kernel<BM, BN, TAPS, EPI>), grid, block, lds, stream, p);
+  return af_check_launch("af_gemm");
+}
+
+template <int TAPS, int EPI>
+int launch_tile(const GemmDev& p, int tile, hipStream_t stream) {
+  if (tile == 1) return launch<128, 128, TAPS, EPI>(p, stream);
+  return launch<64, 64, TAPS, EPI>(p, stream);
+}
+
+}  // namespace
+
+extern "C" int af_gemm(const af_gemm_desc* d, void* stream) {
+  AF_REQUIRE(d != nullptr, "af_gemm: null descriptor");
+  AF_REQUIRE(d->a1 && d->wt && d->out, "af_gemm: a1/wt/out must be non-null");
+  AF_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "af_gemm: M, N, K must be positive");
+  AF_REQUIRE(d->taps == 1 || d->taps == 9, "af_gemm: taps must be 1 or 9");
+  AF_REQUIRE(d->kpad % BK == 0 && d->kpad >= d->K, "af_gemm: kpad must be a multiple of 64 and >= K");
+  AF_REQUIRE(d->N % 4 == 0, "af_gemm: N must be a multiple of 4");
+  AF_REQUIRE(d->c1 > 0 && d->c1 % 8 == 0 && d->c2 >= 0 && d->c2 % 8 == 0, "af_gemm: c1/c2 must be multiples of 8");
+  AF_REQUIRE(d->c2 == 0 || d->a2 != nullptr, "af_gemm: a2 is null but c2 > 0");
+  AF_REQUIRE(d->K == d->taps * (d->c1 + d->c2), "af_gemm: K != taps*(c1+c2)");
+  GemmDev p;
+  p.a1 = (const half_t*)d->a1;
+  p.a2 = (const half_t*)d->a2;
+  p.wt = (const half_t*)d->wt;
+  p.bias = (const float*)d->bias;
+  p.rowbias = (const half_t*)d->rowbias;
+  p.residual = (const half_t*)d->residual;
+  p.out = (half_t*)d->out;
+  p.out2 = (half_t*)d->out2;
+  p.M = d->M;
+  p.N = d->N;
+  p.K = d->K;
+  p.kpad = d->kpad;
+  p.c1 = d->c1;
+  p.c2 = d->c2;
+  p.lda1 = d->lda1 ? d->lda1 : d->c1;
+  p.lda2 = d->lda2 ? d->lda2 : d->c2;
+  p.stride = d->stride ? d->stride : 1;
+  p.upsample = d->upsample ? 1 : 0;
+  p.H = d->H;
+  p.W = d->W;
+  p.Ho = d->Ho;
+  p.Wo = d->Wo;
+  p.HoWo = d->Ho * d->Wo;
+  p.Heff = p.upsample ? 2 * d->H : d->H;
+  p.Weff = p.upsample ? 2 * d->W : d->W;
+  p.rows_per_batch = d->rows_per_batch > 0 ? d->rows_per_batch : d->M;
+  p.ld_rowbias = d->ld_rowbias;
+  p.act_silu = d->act == AF_ACT_SILU;
+  p.split_col = d->split_col;
+  p.ld_out2 = d->ld_out2;
+  p.tiles_n = 0;
+  if (d->taps == 9) {
+    AF_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Ho > 0 && d->Wo > 0, "af_gemm: conv geometry missing");
+    AF_REQUIRE(p.stride == 1 || p.stride == 2, "af_gemm: stride must be 1 or 2");
+    AF_REQUIRE(!(p.upsample && p.stride != 1), "af_gemm: upsample requires stride 1");
+    AF_REQUIRE(d->M == d->B * d->Ho * d->Wo, "af_gemm: M != B*Ho*Wo");
+    AF_REQUIRE(d->Ho == (p.Heff + 2 - 3) / p.stride + 1 && d->Wo == (p.Weff + 2 - 3) / p.stride + 1,
+               "af_gemm: Ho/Wo inconsistent with H/W/stride/upsample");
+  }
+  if (d->rowbias) AF_REQUIRE(d->ld_rowbias >= d->N, "af_gemm: ld_rowbias < N");
+  const bool geglu = d->act == AF_ACT_GEGLU;
+  if (geglu) {
+    AF_REQUIRE(d->N % 32 == 0, "af_gemm: GEGLU needs N % 32 == 0 (interleaved 16-row groups)");
+    AF_REQUIRE(d->out_mode == AF_OUT_NORMAL && !d->rowbias && !d->residual, "af_gemm: GEGLU epilogue is exclusive");
+    p.ld_out = d->ld_out ? d->ld_out : d->N / 2;
+  } else {
+    p.ld_out = d->ld_out ? d->ld_out : (d->out_mode == AF_OUT_SPLIT_T ? d->split_col : d->N);
+  }
+  if (d->out_mode == AF_OUT_SPLIT_T) {
+    AF_REQUIRE(d->out2 != nullptr, "af_gemm: AF_OUT_SPLIT_T needs out2");
+    AF_REQUIRE(d->split_col % 16 == 0 && d->split_col >= 0 && d->split_col < d->N, "af_gemm: bad split_col");
+    AF_REQUIRE(d->rows_per_batch > 0 && d->ld_out2 >= d->rows_per_batch, "af_gemm: bad ld_out2/rows_per_batch");
+    AF_REQUIRE(!d->residual, "af_gemm: residual unsupported with AF_OUT_SPLIT_T");
+  }
+  AF_REQUIRE(p.ld_out % 4 == 0, "af_gemm: ld_out must be a multiple of 4");
+
+  int tile = d->tile;
+  if (tile == 0) {
+    const long t128 = (long)((d->M + 127) / 128) * ((d->N + 127) / 128);
+    tile = (t128 >= 192 && d->N >= 96) ? 1 : 2;
+  }
+  AF_REQUIRE(tile == 1 || tile == 2, "af_gemm: tile must be 0, 1 or 2");
+
+  AfLaunchScope scope(AF_FAM_GEMM, stream);
+  hipStream_t s = (hipStream_t)stream;
+  if (geglu) return d->taps == 9 ? af_fail(AF_E_UNSUPPORTED, "af_gemm: GEGLU on a 3x3 conv")
+                                 : launch_tile<1, EPI_GEGLU>(p, tile, s);
+  if (d->out_mode == AF_OUT_SPLIT_T)
+    return d->taps == 9 ? af_fail(AF_E_UNSUPPORTED, "af_gemm: SPLIT_T on a 3x3 conv") : launch_tile<1, EPI_SPLIT_T>(p, tile, s);
+  return d->taps == 9 ? launch_tile<9, EPI_STD>(p, tile, s) : launch_tile<1, EPI_STD>(p, tile, s);
+}

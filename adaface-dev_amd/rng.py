@@ -1,0 +1,56 @@
+"""Counter-based synthetic weights and inputs.
+
+There is no network for SD-1.5 checkpoints, so benchmarks, fixtures and tests use
+seeded random weights.  Every tensor is drawn from its own Philox stream keyed by
+(seed, crc32(tensor name)), so the golden-fixture generator (which instantiates the
+*reference* module tree in the build container) and the GPU box (which instantiates
+this package's module tree) obtain bit-identical weights from names + shapes alone,
+without shipping gigabytes.
+
+The reference zero-initialises 39 tensors (``zero_module``: ResBlock ``out_layers.3``,
+SpatialTransformer ``proj_out``, final ``out.2`` -- openaimodel.py:230-232,689,
+attention.py:280); a random-weight network with those left at zero outputs exactly 0,
+so they are drawn like every other tensor here (SURVEY.md 8c caveat 1).
+"""
+import zlib
+
+import numpy as np
+import torch
+
+
+def _stream(seed: int, name: str) -> np.random.Generator:
+    return np.random.Generator(np.random.Philox(key=[int(seed) & 0xFFFFFFFFFFFFFFFF, zlib.crc32(name.encode())]))
+
+
+def synth_tensor(name: str, shape, seed: int = 0) -> torch.Tensor:
+    """One synthetic fp32 parameter. Rule is decided by the name suffix and rank."""
+    shape = tuple(int(s) for s in shape)
+    g = _stream(seed, name)
+    z = g.standard_normal(size=shape, dtype=np.float32)
+    if name.endswith(".bias"):
+        z *= 0.05
+    elif len(shape) == 1:  # GroupNorm / LayerNorm gamma
+        z = 1.0 + 0.1 * z
+    else:  # conv / linear weight: unit-gain fan-in scaling
+        fan_in = int(np.prod(shape[1:]))
+        z *= 1.0 / np.sqrt(fan_in)
+    return torch.from_numpy(np.ascontiguousarray(z, dtype=np.float32))
+
+
+def synth_state_dict(named_shapes, seed: int = 0):
+    """named_shapes: iterable of (name, shape). Returns {name: fp32 tensor}."""
+    return {name: synth_tensor(name, shape, seed) for name, shape in named_shapes}
+
+
+def load_synth_weights(module: torch.nn.Module, seed: int = 0) -> None:
+    """Overwrite every parameter of `module` in place with its synthetic value."""
+    with torch.no_grad():
+        for name, p in module.named_parameters():
+            p.copy_(synth_tensor(name, p.shape, seed).to(p.dtype))
+
+
+def synth_input(name: str, shape, seed: int = 0, scale: float = 1.0) -> torch.Tensor:
+    """Synthetic N(0, scale^2) activation-like input (latents, context, ID vectors)."""
+    g = _stream(seed, "input:" + name)
+    z = g.standard_normal(size=tuple(int(s) for s in shape), dtype=np.float32) * scale
+    return torch.from_numpy(z.astype(np.float32))

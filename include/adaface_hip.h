@@ -1,0 +1,158 @@
+/*
+ * adaface_hip.h -- C ABI of libadaface_hip.so: the MI355X (gfx950) kernels of AdaFace's
+ * denoising hot path (SD-1.5 U-Net epsilon-prediction).
+ *
+ * The reference (askerlee/AdaFace-dev) has no FFI layer: its seams are Python call
+ * signatures that bottom out in torch ops.  Each entry point below names the reference
+ * call site(s) (file:line relative to the reference tree) whose arithmetic it replaces;
+ * INTEGRATION.md shows the ctypes binding a reference maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (torch); the library
+ *     allocates nothing and keeps no global mutable state (re-entrant: forward thread and
+ *     autograd thread may call concurrently);
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
+ *     no call synchronises, so every call is hipGraph-capturable;
+ *   - activations are fp16 ("h"), NHWC / token-major [rows, channels]; accumulation,
+ *     statistics and softmax are fp32;
+ *   - return value: 0 = ok, <0 = AF_E_* ; af_last_error() gives the message (thread-local).
+ */
+#ifndef ADAFACE_HIP_H
+#define ADAFACE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AF_OK 0
+#define AF_E_BADARG (-1)      /* null pointer, negative size, misaligned dimension   */
+#define AF_E_UNSUPPORTED (-2) /* shape outside what the kernels are built for        */
+#define AF_E_HIP (-3)         /* launch failed; message holds hipGetErrorString      */
+
+const char* af_last_error(void);
+int af_version(void);
+/* number of HIP devices visible, or AF_E_HIP (used by smoke tests; does not create a context) */
+int af_device_count(void);
+
+/* ---- profiling hook (bench.py roofline leg): when enabled, every launch of the kernel
+ * family `family` is bracketed by hipEvents on its own stream; af_prof_read synchronises
+ * those events and returns the launch count and summed milliseconds since the last reset. */
+#define AF_FAM_GEMM 0   /* conv3x3 implicit-GEMM + linear/conv1x1 (one kernel template) */
+#define AF_FAM_ATTN 1
+#define AF_FAM_GNORM 2
+#define AF_FAM_LNORM 3
+#define AF_FAM_ELEM 4
+#define AF_FAM_COUNT 5
+int af_prof_enable(int on);
+int af_prof_reset(void);
+int af_prof_read(int family, int* launches, double* total_ms);
+
+/* ---- GEMM / implicit-GEMM convolution -------------------------------------------------
+ * out[M,N] = epilogue( sum_k A[m,k] * Wt[n,k] )          (Wt is [Npad, Kpad], K contiguous)
+ * Replaces: nn.Conv2d 3x3 / 1x1 (ldm/modules/diffusionmodules/util.py:214-224, called at
+ * openaimodel.py:202-242,108,152,523,689; attention.py:269,280) and nn.Linear
+ * (attention.py:34,54,156-162; openaimodel.py:511-515,221).
+ *
+ * A operand (activations, fp16):
+ *   taps == 1 : plain rows.  k <  k1 reads a1[m*lda1 + k], k >= k1 reads a2[m*lda2 + (k-k1)]
+ *               (a2 may be NULL when k1 == K): fuses torch.cat([h, skip], 1) (openaimodel.py:918).
+ *   taps == 9 : 3x3, pad 1, implicit im2col over an NHWC image [B, H, W, c1 (+c2)]:
+ *               k = tap*(c1+c2) + c ; stride 1|2 (Downsample, openaimodel.py:150-161);
+ *               upsample=1 reads the nearest-x2 upsampled image without materialising it
+ *               (Upsample, openaimodel.py:117-119).  M = B*Ho*Wo.
+ * Epilogue (fp32): + bias[n] ; + rowbias[(m / rows_per_batch)*ld_rowbias + n] (ResBlock time
+ *   embedding add, openaimodel.py:265-274) ; act ; + residual[m*N + n] ; -> fp16.
+ *   act: AF_ACT_NONE | AF_ACT_SILU | AF_ACT_GEGLU (Wt rows interleaved [16 x | 16 gate],
+ *   out has N/2 columns: a * gelu_erf(g), attention.py:36-38).
+ *   out_mode AF_OUT_SPLIT_T: columns n >= split_col are written TRANSPOSED to out2
+ *   ([B, N - split_col, ld_out2] with token index contiguous): V^T for the attention kernel.
+ */
+#define AF_ACT_NONE 0
+#define AF_ACT_SILU 1
+#define AF_ACT_GEGLU 2
+#define AF_OUT_NORMAL 0
+#define AF_OUT_SPLIT_T 1
+
+typedef struct af_gemm_desc {
+  const void* a1;       /* fp16 */
+  const void* a2;       /* fp16 or NULL */
+  const void* wt;       /* fp16 [Npad][Kpad], Npad % 128 == 0, Kpad % 64 == 0, zero padded */
+  const void* bias;     /* fp32 [N] or NULL */
+  const void* rowbias;  /* fp16 [B][ld_rowbias] or NULL */
+  const void* residual; /* fp16 [M][N] or NULL */
+  void* out;            /* fp16 [M][ld_out] */
+  void* out2;           /* fp16, AF_OUT_SPLIT_T only */
+  int32_t M, N, K;      /* logical sizes (K = taps*(c1+c2) for taps == 9) */
+  int32_t kpad;         /* row stride of wt in elements */
+  int32_t taps;         /* 1 or 9 */
+  int32_t c1, c2;       /* channels of a1 / a2 (taps==1: k1 = c1, k2 = c2) */
+  int32_t lda1, lda2;   /* taps==1 row strides in elements */
+  int32_t B, H, W;      /* taps==9 input image (before upsample) */
+  int32_t Ho, Wo;       /* taps==9 output image */
+  int32_t stride;       /* 1 | 2 */
+  int32_t upsample;     /* 0 | 1 */
+  int32_t rows_per_batch;
+  int32_t ld_rowbias;
+  int32_t act;
+  int32_t out_mode;
+  int32_t ld_out;       /* elements; 0 -> N (or N/2 for GEGLU) */
+  int32_t split_col;    /* AF_OUT_SPLIT_T */
+  int32_t ld_out2;      /* AF_OUT_SPLIT_T: tokens per batch item rounded up to 8 */
+  int32_t tile;         /* 0 = auto, 1 = 128x128, 2 = 64x64 */
+} af_gemm_desc;
+
+int af_gemm(const af_gemm_desc* d, void* stream);
+
+/* ---- GroupNorm(32) [+ SiLU], NHWC -----------------------------------------------------
+ * Replaces GroupNorm32 + nn.SiLU (util.py:195-212; openaimodel.py:202-233,686-690; eps 1e-5)
+ * and Normalize (attention.py:70-71; eps 1e-6).  x = concat(x1[.., c1], x2[.., c2]) along
+ * channels (x2 may be NULL).  Two launches: partial sums -> normalise.
+ * workspace: fp32, at least af_groupnorm_ws_floats(B) floats.                              */
+int af_groupnorm_ws_floats(int B);
+int af_groupnorm(const void* x1, const void* x2, int c1, int c2, const void* gamma, const void* beta,
+                 void* y, int B, int HW, int groups, float eps, int silu, void* workspace, void* stream);
+
+/* ---- LayerNorm over the last dim (nn.LayerNorm, attention.py:232-234; eps 1e-5) ------- */
+int af_layernorm(const void* x, const void* gamma, const void* beta, void* y, int rows, int C, float eps,
+                 void* stream);
+
+/* ---- fused attention core: softmax(q k^T * scale + keybias) v --------------------------
+ * Replaces attention.py:180-204 (CrossAttention.forward between the projections) and the
+ * explicit SDPA of adaface/diffusers_attn_lora_capture.py:79-139 without materialising
+ * the [b*h, N, L] score tensor.
+ *   q  [B, Nq, ldq]   k [B, L, ldk]   o [B, Nq, ldo]   (row strides in elements, >= heads*d:
+ *   q and k may be column slices of one fused projection output)
+ *   vt [B, heads*d, ldv] (V transposed, key index contiguous, ldv % 8 == 0)
+ *   keybias: fp32 [B, ldb] added to every score row (0 = keep, -FLT_MAX = masked key as
+ *   masked_fill_(~mask, -finfo.max) attention.py:188-194); NULL = none.  Keys >= L are
+ *   always excluded.  d % 8 == 0, d <= 160.                                                */
+int af_attention(const void* q, const void* k, const void* vt, void* o, const void* keybias, int B, int Nq,
+                 int L, int heads, int d, int ldq, int ldk, int ldo, int ldv, int ldb, float scale, void* stream);
+
+/* explicit score / probability capture for one cross-attention layer (attention.py:207-220):
+ * score[b,h,i,j] = q.k*scale, prob = softmax_j(score); fp32 outputs [B,heads,Nq,L].         */
+int af_attention_scores(const void* q, const void* k, void* score, void* prob, int B, int Nq, int L, int heads,
+                        int d, float scale, void* stream);
+
+/* ---- small element-wise kernels --------------------------------------------------------
+ * timestep embedding [cos | sin] (util.py:154-174) -> fp16 [B, dim]                        */
+int af_timestep_embedding(const void* timesteps_i64, void* out, int B, int dim, float max_period, void* stream);
+/* NCHW fp32 -> NHWC fp16 with channel padding to cpad (zeros) and back (NHWC fp16 -> NCHW fp32) */
+int af_nchw_f32_to_nhwc_f16(const void* x, void* y, int B, int C, int HW, int cpad, void* stream);
+int af_nhwc_f16_to_nchw_f32(const void* x, void* y, int B, int C, int HW, int cstride, void* stream);
+/* classifier-free guidance + DDIM update (ldm/models/diffusion/ddim.py:253-255, 279-301, sigma = 0):
+ * eps = e_u + g (e_c - e_u); pred_x0 = (x - sqrt(1-a_t) eps)/sqrt(a_t);
+ * x_prev = sqrt(a_prev) pred_x0 + sqrt(1-a_prev) eps.   eps2 = [e_c ; e_u] fp32 [2n];
+ * e_u == NULL (n_uncond = 0) means no guidance.  x, x_prev, pred_x0: fp32 [n].              */
+int af_cfg_ddim_step(const void* eps2, const void* x, void* x_prev, void* pred_x0, int64_t n, int has_uncond,
+                     float guidance, float a_t, float a_prev, void* stream);
+/* q_sample (ldm/models/diffusion/ddpm.py:395-398): x_t = sa[b] x0 + sb[b] noise, fp32, per-sample scalars */
+int af_q_sample(const void* x0, const void* noise, const void* sa, const void* sb, void* xt, int B, int64_t per,
+                void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ADAFACE_HIP_H */

@@ -1,0 +1,287 @@
+#!/usr/bin/env python
+"""Generate the golden vectors under tests/golden/ by running the REFERENCE modules.
+
+Run in the build container only (it imports /root/reference, which never travels to
+the GPU box):
+
+    python tests/golden/gen_golden.py [--skip-full]
+
+What is committed is data: seeded inputs are regenerated from ``adaface_dev_amd.rng`` on
+both sides, so the fixtures hold only expected outputs (plus small probes for the
+full-size network).  The reference has no tests / fixtures of its own, so
+these files are what pins the oracle (oracle/*.py) and, through it, the HIP path.
+"""
+import argparse
+import os
+import sys
+import time
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+REF = "/root/reference"
+
+
+def install_reference_stubs():
+    """Two import-time stubs the reference needs here: torchvision.utils and
+    omegaconf.listconfig.  transformers must be imported BEFORE the fake torchvision exists."""
+    import transformers  # noqa: F401
+    import transformers.models.clip.modeling_clip  # noqa: F401
+
+    if "torchvision" not in sys.modules:
+        tv = types.ModuleType("torchvision")
+        tvu = types.ModuleType("torchvision.utils")
+        tvu.make_grid = lambda *a, **k: None
+        tvu.draw_bounding_boxes = lambda *a, **k: None
+        tv.utils = tvu
+        sys.modules["torchvision"] = tv
+        sys.modules["torchvision.utils"] = tvu
+    if "omegaconf" not in sys.modules:
+        oc = types.ModuleType("omegaconf")
+        ocl = types.ModuleType("omegaconf.listconfig")
+
+        class ListConfig(list):
+            pass
+
+        ocl.ListConfig = ListConfig
+        oc.listconfig = ocl
+        sys.modules["omegaconf"] = oc
+        sys.modules["omegaconf.listconfig"] = ocl
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+
+
+def probes(t: torch.Tensor):
+    """Size-independent summary of a big tensor: mean, abs-mean, and 64 strided samples."""
+    f = t.detach().float().reshape(-1)
+    n = f.numel()
+    idx = (torch.arange(64, dtype=torch.int64) * 2654435761) % n
+    return np.concatenate([[f.mean().item(), f.abs().mean().item()], f[idx].numpy()]).astype(np.float32)
+
+
+def gen_unet_tiny(out):
+    from adaface_dev_amd import TINY_UNET_CONFIG, rng
+    from ldm.modules.diffusionmodules.openaimodel import UNetModel
+
+    torch.manual_seed(0)
+    m = UNetModel(**TINY_UNET_CONFIG).eval()
+    rng.load_synth_weights(m, seed=1)
+    x = rng.synth_input("tiny.x", (2, 4, 16, 16), seed=1)
+    ctx = rng.synth_input("tiny.ctx", (2, 77, 64), seed=1)
+    t = torch.tensor([10, 500], dtype=torch.int64)
+
+    blocks = {}
+    hooks = []
+    names = [(f"in{i}", b) for i, b in enumerate(m.input_blocks)] + [("mid", m.middle_block)] + [
+        (f"out{i}", b) for i, b in enumerate(m.output_blocks)
+    ]
+    for n, b in names:
+        hooks.append(b.register_forward_hook(lambda mod, a, o, n=n: blocks.__setitem__(n, o.detach().clone())))
+
+    res = {}
+    # (a) plain forward + gradients wrt x and context for a fixed cotangent
+    xg = x.clone().requires_grad_(True)
+    cg = ctx.clone().requires_grad_(True)
+    eps = m(xg, t, cg, extra_info={})
+    cot = rng.synth_input("tiny.cot", eps.shape, seed=1)
+    (eps * cot).sum().backward()
+    res["eps"] = eps.detach().numpy()
+    res["grad_x"] = xg.grad.numpy()
+    res["grad_ctx"] = cg.grad.numpy()
+    for n, o in blocks.items():
+        res["block_" + n] = o.numpy()
+    for h in hooks:
+        h.remove()
+
+    # (b) img_mask (self-attention key mask) + capture of cross-attn activations, layers 22-24
+    mask = torch.ones(2, 1, 16, 16)
+    mask[0, :, :, :5] = 0
+    mask[1, :, 9:, :] = 0
+    ei = {"img_mask": mask, "capture_ca_activations": True}
+    with torch.no_grad():
+        eps_m = m(x, t, ctx, extra_info=ei)
+    res["eps_masked"] = eps_m.numpy()
+    acts = ei["ca_layers_activations"]
+    for key in ("outfeat", "attn", "attnscore", "q", "attn_out"):
+        for li, v in acts[key].items():
+            res[f"cap_{key}_{li}"] = probes(v)
+            res[f"cap_{key}_{li}_shape"] = np.asarray(v.shape, dtype=np.int64)
+    # one capture kept in full (layer 24, smallest useful set)
+    res["cap_attn_24_full"] = acts["attn"][24].numpy().astype(np.float16)
+    res["cap_q_24_full"] = acts["q"][24].numpy()
+    res["cap_attn_out_24_full"] = acts["attn_out"][24].numpy()
+    np.savez_compressed(os.path.join(out, "unet_tiny.npz"), **res)
+    print("unet_tiny: eps absmean", float(np.abs(res["eps"]).mean()), "masked", float(np.abs(res["eps_masked"]).mean()))
+
+
+def gen_unet_full(out):
+    from adaface_dev_amd import SD15_UNET_CONFIG, rng
+    from ldm.modules.diffusionmodules.openaimodel import UNetModel
+
+    m = UNetModel(**SD15_UNET_CONFIG).eval()
+    nparams = sum(p.numel() for p in m.parameters())
+    ntens = len(list(m.state_dict().keys()))
+    rng.load_synth_weights(m, seed=0)
+    x = rng.synth_input("full.x", (1, 4, 64, 64), seed=0)
+    ctx = rng.synth_input("full.ctx", (1, 77, 768), seed=0)
+    t = torch.tensor([500], dtype=torch.int64)
+    res = {"nparams": np.int64(nparams), "ntensors": np.int64(ntens)}
+    hooks = []
+    names = [(f"in{i}", b) for i, b in enumerate(m.input_blocks)] + [("mid", m.middle_block)] + [
+        (f"out{i}", b) for i, b in enumerate(m.output_blocks)
+    ]
+    for n, b in names:
+        hooks.append(b.register_forward_hook(lambda mod, a, o, n=n: res.__setitem__("probe_" + n, probes(o))))
+    t0 = time.time()
+    with torch.no_grad():
+        eps = m(x, t, ctx, extra_info={})
+    dt = time.time() - t0
+    res["eps"] = eps.numpy()
+    res["ref_cpu_seconds"] = np.float64(dt)
+    np.savez_compressed(os.path.join(out, "unet_full.npz"), **res)
+    print(f"unet_full: {nparams} params, {ntens} tensors, fwd {dt:.1f}s, eps absmean {float(eps.abs().mean()):.4f}")
+
+
+def gen_blocks(out):
+    """Reference leaf/block modules at reduced widths, incl. the shapes the HIP kernels special-case."""
+    from adaface_dev_amd import rng
+    from ldm.modules.attention import BasicTransformerBlock, CrossAttention, SpatialTransformer
+    from ldm.modules.diffusionmodules.openaimodel import Downsample, ResBlock, Upsample
+    from ldm.modules.diffusionmodules.util import normalization, timestep_embedding
+
+    res = {}
+    # timestep embedding known answers
+    t = torch.tensor([0, 1, 21, 500, 981, 999], dtype=torch.int64)
+    res["temb_t"] = t.numpy()
+    res["temb_320"] = timestep_embedding(t, 320).numpy()
+
+    # GroupNorm32 + SiLU, eps 1e-5
+    gn = normalization(64)
+    rng.load_synth_weights(gn, seed=2)
+    x = rng.synth_input("blk.gn.x", (2, 64, 8, 8), seed=2, scale=2.0) + 0.5
+    res["gn_silu"] = torch.nn.functional.silu(gn(x)).detach().numpy()
+
+    # CrossAttention: self (masked / unmasked) and cross, head dim 40 like SD-1.5 at C=320 (scaled: 8 heads x 8)
+    for tag, qd, cd, heads, dh, n, l in (("self", 64, None, 8, 8, 64, 64), ("cross", 64, 48, 8, 8, 64, 77),
+                                         ("d40", 80, 96, 2, 40, 48, 77)):
+        ca = CrossAttention(query_dim=qd, context_dim=cd, heads=heads, dim_head=dh).eval()
+        rng.load_synth_weights(ca, seed=3)
+        xq = rng.synth_input(f"blk.ca.{tag}.x", (2, n, qd), seed=3)
+        cx = None if cd is None else rng.synth_input(f"blk.ca.{tag}.ctx", (2, l, cd), seed=3)
+        with torch.no_grad():
+            res[f"ca_{tag}"] = ca(xq, cx).numpy()
+            if cd is None:
+                mask = torch.ones(2, 1, 8, 8)
+                mask[0, :, :3] = 0
+                mask[1, :, :, 6:] = 0
+                res[f"ca_{tag}_masked"] = ca(xq, None, mask=mask).numpy()
+                res[f"ca_{tag}_allmasked"] = ca(xq, None, mask=torch.zeros(2, 1, 8, 8)).numpy()
+
+    # ResBlock with and without 1x1 skip
+    emb = rng.synth_input("blk.rb.emb", (2, 128), seed=4)
+    for tag, cin, cout in (("same", 64, 64), ("proj", 96, 64)):
+        rb = ResBlock(cin, 128, 0.0, out_channels=cout).eval()
+        rng.load_synth_weights(rb, seed=4)
+        x = rng.synth_input(f"blk.rb.{tag}.x", (2, cin, 8, 8), seed=4)
+        with torch.no_grad():
+            res[f"rb_{tag}"] = rb(x, emb).numpy()
+
+    # Down / Up sample
+    dn = Downsample(64, True, out_channels=64).eval()
+    up = Upsample(64, True, out_channels=64).eval()
+    rng.load_synth_weights(dn, seed=5)
+    rng.load_synth_weights(up, seed=5)
+    x = rng.synth_input("blk.ud.x", (2, 64, 8, 8), seed=5)
+    with torch.no_grad():
+        res["down"] = dn(x).numpy()
+        res["up"] = up(x).numpy()
+
+    # BasicTransformerBlock / SpatialTransformer
+    st = SpatialTransformer(64, 8, 8, depth=1, context_dim=48).eval()
+    rng.load_synth_weights(st, seed=6)
+    x = rng.synth_input("blk.st.x", (2, 64, 8, 8), seed=6)
+    cx = rng.synth_input("blk.st.ctx", (2, 77, 48), seed=6)
+    mask = torch.ones(2, 1, 16, 16)
+    mask[0, :, :6] = 0
+    with torch.no_grad():
+        res["st"] = st(x, cx).numpy()
+        res["st_masked"] = st(x, cx, mask=mask).numpy()
+    np.savez_compressed(os.path.join(out, "blocks.npz"), **res)
+    print("blocks:", sorted(res.keys()))
+
+
+def gen_schedule(out):
+    from ldm.models.diffusion.ddim import DDIMSampler
+    from ldm.modules.diffusionmodules.util import (make_beta_schedule, make_ddim_sampling_parameters,
+                                                   make_ddim_timesteps)
+
+    betas = make_beta_schedule("linear", 1000, linear_start=0.00085, linear_end=0.012)
+    ac = np.cumprod(1.0 - betas, axis=0)
+    ts = make_ddim_timesteps("uniform", 50, 1000, verbose=False)
+    ac32 = torch.tensor(ac, dtype=torch.float32)
+    sig, a, ap = make_ddim_sampling_parameters(ac32, ts, 0.0, verbose=False)
+    np.savez_compressed(
+        os.path.join(out, "schedule.npz"),
+        betas=betas, alphas_cumprod=ac, ddim_timesteps=ts,
+        ddim_alphas=np.asarray(a, dtype=np.float32), ddim_alphas_prev=np.asarray(ap, dtype=np.float32),
+        ddim_sigmas=np.asarray(sig, dtype=np.float32),
+        # in-code known answers, ldm/models/diffusion/ddim.py:265-270 (fp16-printed)
+        kat_alphas_first=np.asarray([0.9985, 0.9805, 0.9609, 0.9399, 0.9170], dtype=np.float32),
+        kat_alphas_last=np.asarray([0.0140, 0.0113, 0.0091, 0.0073, 0.0058], dtype=np.float32),
+    )
+
+    # One reference DDIM trajectory with a stand-in epsilon model (tests the sampler arithmetic,
+    # CFG ordering (cond, uncond) and guidance annealing -- ddim.py:133-302).
+    class FakeLDM:
+        num_timesteps = 1000
+        device = torch.device("cpu")
+
+        def __init__(self):
+            self.betas = torch.tensor(betas, dtype=torch.float32)
+            self.alphas_cumprod = ac32
+            self.alphas_cumprod_prev = torch.tensor(np.append(1.0, ac[:-1]), dtype=torch.float32)
+
+        def apply_model(self, x, t, c):
+            ctx = c[0] if isinstance(c, tuple) else c
+            return torch.tanh(x) * 0.7 + 0.05 * ctx.mean(dim=(1, 2)).reshape(-1, 1, 1, 1) + 1e-4 * t.reshape(-1, 1, 1, 1).float()
+
+    DDIMSampler.register_buffer = lambda self, name, attr: setattr(self, name, attr)
+    sampler = DDIMSampler(FakeLDM())
+    from adaface_dev_amd import rng
+    xT = rng.synth_input("ddim.xT", (2, 4, 8, 8), seed=7)
+    c = rng.synth_input("ddim.c", (2, 77, 16), seed=7)
+    uc = rng.synth_input("ddim.uc", (2, 77, 16), seed=7)
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+        x0, inter = sampler.sample(S=50, batch_size=2, shape=(4, 8, 8), conditioning=(c, ["a", "b"], {}),
+                                   verbose=False, x_T=xT, guidance_scale=(4.0, 1.0),
+                                   unconditional_conditioning=(uc, ["", ""], {}), log_every_t=10)
+    np.savez_compressed(os.path.join(out, "ddim_step.npz"), x_final=x0.numpy(),
+                        x_inter=np.stack([t.numpy() for t in inter["x_inter"]]))
+    print("schedule: ddim_timesteps[:3]", ts[:3], "alphas[:3]", np.asarray(a)[:3])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--skip-full", action="store_true")
+    ap.add_argument("--only", default=None)
+    args = ap.parse_args()
+    install_reference_stubs()
+    torch.set_num_threads(8)
+    out = HERE
+    jobs = {"blocks": gen_blocks, "schedule": gen_schedule, "unet_tiny": gen_unet_tiny, "unet_full": gen_unet_full}
+    for name, fn in jobs.items():
+        if args.only and name != args.only:
+            continue
+        if name == "unet_full" and args.skip_full:
+            continue
+        fn(out)
+
+
+if __name__ == "__main__":
+    main()
