@@ -1,0 +1,95 @@
+"""ctypes binding of csrc/libadaface_hip.so (C ABI declared in include/adaface_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a call fails, a
+RuntimeError is raised.  ``build()`` (re)compiles the library in-tree with hipcc for gfx950.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libadaface_hip.so")
+
+AF_OK, AF_E_BADARG, AF_E_UNSUPPORTED, AF_E_HIP = 0, -1, -2, -3
+AF_ACT_NONE, AF_ACT_SILU, AF_ACT_GEGLU = 0, 1, 2
+AF_OUT_NORMAL, AF_OUT_SPLIT_T = 0, 1
+AF_FAM_GEMM, AF_FAM_ATTN, AF_FAM_GNORM, AF_FAM_LNORM, AF_FAM_ELEM = 0, 1, 2, 3, 4
+
+# every symbol include/adaface_hip.h declares (tests check the .so exports exactly these)
+EXPORTS = (
+    "af_last_error", "af_version", "af_device_count", "af_prof_enable", "af_prof_reset", "af_prof_read",
+    "af_gemm", "af_groupnorm_ws_floats", "af_groupnorm", "af_layernorm", "af_attention", "af_attention_scores",
+    "af_timestep_embedding", "af_nchw_f32_to_nhwc_f16", "af_nhwc_f16_to_nchw_f32", "af_cfg_ddim_step", "af_q_sample",
+    "af_silu_f16",
+)
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [
+        ("a1", C.c_void_p), ("a2", C.c_void_p), ("wt", C.c_void_p), ("bias", C.c_void_p),
+        ("rowbias", C.c_void_p), ("residual", C.c_void_p), ("out", C.c_void_p), ("out2", C.c_void_p),
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("kpad", C.c_int32), ("taps", C.c_int32),
+        ("c1", C.c_int32), ("c2", C.c_int32), ("lda1", C.c_int32), ("lda2", C.c_int32),
+        ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32),
+        ("stride", C.c_int32), ("upsample", C.c_int32), ("rows_per_batch", C.c_int32), ("ld_rowbias", C.c_int32),
+        ("act", C.c_int32), ("out_mode", C.c_int32), ("ld_out", C.c_int32), ("split_col", C.c_int32),
+        ("ld_out2", C.c_int32), ("tile", C.c_int32),
+    ]
+
+
+def build(verbose: bool = False) -> str:
+    """Compile every HIP source for gfx950 into csrc/libadaface_hip.so (make, in-tree)."""
+    r = subprocess.run(["make", "-C", CSRC, "-j4"], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("building libadaface_hip.so failed:\n" + r.stdout + r.stderr)
+    if verbose:
+        print(r.stdout)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load (once) and return the library; raise loudly if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the HIP extension is required (no CPU fallback). "
+            "Run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C adaface-dev_amd/csrc`."
+        )
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
+    L.af_last_error.restype = C.c_char_p
+    L.af_last_error.argtypes = []
+    L.af_version.argtypes = []
+    L.af_device_count.argtypes = []
+    L.af_prof_enable.argtypes = [i32]
+    L.af_prof_reset.argtypes = []
+    L.af_prof_read.argtypes = [i32, C.POINTER(C.c_int), C.POINTER(C.c_double)]
+    L.af_gemm.argtypes = [C.POINTER(GemmDesc), vp]
+    L.af_groupnorm_ws_floats.argtypes = [i32]
+    L.af_groupnorm.argtypes = [vp, vp, i32, i32, vp, vp, vp, i32, i32, i32, f32, i32, vp, vp]
+    L.af_layernorm.argtypes = [vp, vp, vp, vp, i32, i32, f32, vp]
+    L.af_attention.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp]
+    L.af_attention_scores.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp]
+    L.af_timestep_embedding.argtypes = [vp, vp, i32, i32, f32, vp]
+    L.af_nchw_f32_to_nhwc_f16.argtypes = [vp, vp, i32, i32, i32, i32, vp]
+    L.af_nhwc_f16_to_nchw_f32.argtypes = [vp, vp, i32, i32, i32, i32, vp]
+    L.af_cfg_ddim_step.argtypes = [vp, vp, vp, vp, i64, i32, f32, f32, f32, vp]
+    L.af_q_sample.argtypes = [vp, vp, vp, vp, vp, i32, i64, vp]
+    L.af_silu_f16.argtypes = [vp, vp, i64, vp]
+    for name in EXPORTS:
+        if name != "af_last_error":
+            getattr(L, name).restype = C.c_int
+    _lib = L
+    return L
+
+
+def check(rc: int, what: str) -> None:
+    if rc < 0:
+        msg = lib().af_last_error().decode(errors="replace")
+        raise RuntimeError(f"{what} failed (code {rc}): {msg}")

@@ -65,6 +65,11 @@ __global__ void q_sample_kernel(const float* __restrict__ x0, const float* __res
   xt[i] = sa[b] * x0[i] + sb[b] * noise[i];
 }
 
+__global__ void silu_kernel(const half_t* __restrict__ x, half_t* __restrict__ y, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = (half_t)af_silu((float)x[i]);
+}
+
 inline dim3 grid1d(long n, int block = 256) { return dim3((unsigned)((n + block - 1) / block)); }
 
 }  // namespace
@@ -116,4 +121,11 @@ extern "C" int af_q_sample(const void* x0, const void* noise, const void* sa, co
   hipLaunchKernelGGL(q_sample_kernel, grid1d((long)B * per), dim3(256), 0, (hipStream_t)stream, (const float*)x0,
                      (const float*)noise, (const float*)sa, (const float*)sb, (float*)xt, B, (long)per);
   return af_check_launch("af_q_sample");
+}
+
+extern "C" int af_silu_f16(const void* x, void* y, int64_t n, void* stream) {
+  AF_REQUIRE(x && y && n > 0, "af_silu_f16: bad argument");
+  AfLaunchScope scope(AF_FAM_ELEM, stream);
+  hipLaunchKernelGGL(silu_kernel, grid1d((long)n), dim3(256), 0, (hipStream_t)stream, (const half_t*)x, (half_t*)y, (long)n);
+  return af_check_launch("af_silu_f16");
 }

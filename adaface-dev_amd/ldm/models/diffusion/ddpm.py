@@ -1,0 +1,102 @@
+"""Host-side mirror of the hot-path slice of the reference's ``ldm/models/diffusion/ddpm.py``:
+the noise schedule (``DDPM.register_schedule`` 294-345), ``q_sample`` /
+``predict_start_from_noise`` (389-398), ``LatentDiffusion.apply_model`` (1560-1569) and the
+U-Net wrapper contract ``self.model(x, t, cond_context, out_dtype)`` of
+``DiffusersUNetWrapper.forward`` (4187-4252).
+
+Out of scope here: Lightning glue, the loss zoo, prompt plumbing, VAE.  The
+class is a plain ``nn.Module`` so samplers and trainers written against the reference's
+``LatentDiffusion`` attribute surface (``num_timesteps``, ``alphas_cumprod``, ``betas``,
+``device``, ``q_sample``, ``apply_model``, ``model.diffusion_model``) keep working.
+"""
+from functools import partial
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .... import ops
+from ...modules.diffusionmodules.openaimodel import UNetModel
+from ...modules.diffusionmodules.util import extract_into_tensor, make_beta_schedule
+
+
+class UNetWrapper(nn.Module):
+    """``self.model`` of LatentDiffusion: forward(x, t, cond_context, out_dtype=float32) with
+    cond_context = (prompt_emb [b,L,768], prompt_in list[str], extra_info dict).  extra_info is
+    read (img_mask, capture_ca_activations) and written (ca_layers_activations), like the
+    reference wrapper (ddpm.py:4187-4252).  LoRA flags are accepted and must be off."""
+
+    def __init__(self, unet_config):
+        super().__init__()
+        self.diffusion_model = UNetModel(**unet_config)
+        self.use_attn_lora = False
+        self.use_ffn_lora = False
+        self.unet_lora_modules = nn.ModuleDict()
+
+    @property
+    def dtype(self):
+        return torch.float16
+
+    def load_unet_state_dict(self, unet_state_dict):
+        self.diffusion_model.load_state_dict(unet_state_dict)
+
+    def forward(self, x, t, cond_context, out_dtype=torch.float32):
+        prompt_emb, prompt_in, extra_info = cond_context
+        if extra_info is not None and (extra_info.get("use_attn_lora", False) or extra_info.get("use_ffn_lora", False)):
+            raise NotImplementedError("attention / FFN LoRA adapters are a later row of the scope table (SURVEY.md 8f rank 1)")
+        out = self.diffusion_model(x, t, prompt_emb, extra_info=extra_info)
+        return out.to(out_dtype)
+
+
+class LatentDiffusion(nn.Module):
+    def __init__(self, unet_config, timesteps=1000, beta_schedule="linear", linear_start=0.00085, linear_end=0.012,
+                 cosine_s=8e-3, parameterization="eps"):
+        super().__init__()
+        assert parameterization == "eps"
+        self.parameterization = parameterization
+        self.model = UNetWrapper(unet_config)
+        self.register_schedule(beta_schedule=beta_schedule, timesteps=timesteps, linear_start=linear_start,
+                               linear_end=linear_end, cosine_s=cosine_s)
+
+    @property
+    def device(self):
+        return self.betas.device
+
+    def register_schedule(self, given_betas=None, beta_schedule="linear", timesteps=1000, linear_start=1e-4,
+                          linear_end=2e-2, cosine_s=8e-3):
+        betas = given_betas if given_betas is not None else make_beta_schedule(
+            beta_schedule, timesteps, linear_start=linear_start, linear_end=linear_end, cosine_s=cosine_s)
+        alphas = 1.0 - betas
+        alphas_cumprod = np.cumprod(alphas, axis=0)
+        alphas_cumprod_prev = np.append(1.0, alphas_cumprod[:-1])
+        self.num_timesteps = int(betas.shape[0])
+        self.linear_start, self.linear_end = linear_start, linear_end
+        to_torch = partial(torch.tensor, dtype=torch.float32)
+        reg = lambda n, v: self.register_buffer(n, to_torch(v))
+        reg("betas", betas)
+        reg("alphas_cumprod", alphas_cumprod)
+        reg("alphas_cumprod_prev", alphas_cumprod_prev)
+        reg("sqrt_alphas_cumprod", np.sqrt(alphas_cumprod))
+        reg("sqrt_one_minus_alphas_cumprod", np.sqrt(1.0 - alphas_cumprod))
+        reg("log_one_minus_alphas_cumprod", np.log(1.0 - alphas_cumprod))
+        reg("sqrt_recip_alphas_cumprod", np.sqrt(1.0 / alphas_cumprod))
+        reg("sqrt_recipm1_alphas_cumprod", np.sqrt(1.0 / alphas_cumprod - 1))
+        posterior_variance = betas * (1.0 - alphas_cumprod_prev) / (1.0 - alphas_cumprod)
+        reg("posterior_variance", posterior_variance)
+        reg("posterior_log_variance_clipped", np.log(np.maximum(posterior_variance, 1e-20)))
+        reg("posterior_mean_coef1", betas * np.sqrt(alphas_cumprod_prev) / (1.0 - alphas_cumprod))
+        reg("posterior_mean_coef2", (1.0 - alphas_cumprod_prev) * np.sqrt(alphas) / (1.0 - alphas_cumprod))
+
+    def q_sample(self, x_start, t, noise=None):
+        noise = torch.randn_like(x_start) if noise is None else noise
+        return ops.q_sample(x_start, noise, self.sqrt_alphas_cumprod[t], self.sqrt_one_minus_alphas_cumprod[t])
+
+    def predict_start_from_noise(self, x_t, t, noise):
+        return (extract_into_tensor(self.sqrt_recip_alphas_cumprod, t, x_t.shape) * x_t
+                - extract_into_tensor(self.sqrt_recipm1_alphas_cumprod, t, x_t.shape) * noise)
+
+    def apply_model(self, x_noisy, t, cond_context, use_attn_lora=False, use_ffn_lora=False, ffn_lora_adapter_name=None):
+        cond_context[2]["use_attn_lora"] = use_attn_lora
+        cond_context[2]["use_ffn_lora"] = use_ffn_lora
+        cond_context[2]["ffn_lora_adapter_name"] = ffn_lora_adapter_name
+        return self.model(x_noisy, t, cond_context)

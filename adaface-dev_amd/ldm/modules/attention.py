@@ -1,0 +1,224 @@
+"""Host-side mirror of the reference's ``ldm/modules/attention.py`` (CrossAttention,
+BasicTransformerBlock, SpatialTransformer, FeedForward / GEGLU, Normalize) on MI355X kernels.
+
+Constructor arguments, attribute names (``save_cross_attn_vars``, ``cached_activations``,
+``infeat_size``), parameter names and ``forward`` signatures follow the reference
+(attention.py:31-58, 146-304).  What differs is the execution plan:
+
+* activations stay token-major fp16 ``[B*N, C]`` from ``proj_in`` to ``proj_out`` -- the NHWC
+  feature map *is* the token matrix, so the two ``rearrange(...).contiguous()`` copies of
+  attention.py:293,301 disappear;
+* self-attention uses ONE projection GEMM for q, k and v (weights concatenated at pack time);
+  cross-attention one for q and one for k|v; the v columns are written transposed by the GEMM
+  epilogue, which is the layout the fused attention kernel consumes;
+* softmax(QK^T)V is one flash-style kernel (no [b*h, N, L] score tensor, attention.py:181-202);
+* the residual adds of BasicTransformerBlock (attention.py:244-250) and SpatialTransformer
+  (attention.py:304) are fused into the epilogues of to_out / ff.net.2 / proj_out, and
+  GEGLU's ``x * gelu(gate)`` into the epilogue of its projection.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ... import ops
+from ...ops import AF_ACT_GEGLU, F16
+from .diffusionmodules.util import (Conv2d, GroupNorm32, LayerNorm, Linear, _PackCache, checkpoint, from_nhwc_f16,
+                                    to_nhwc_f16, zero_module)
+
+
+def exists(val):
+    return val is not None
+
+
+def default(val, d):
+    if exists(val):
+        return val
+    return d() if callable(d) else d
+
+
+def Normalize(in_channels):
+    """GroupNorm(32, eps=1e-6, affine) -- reference attention.py:70-71."""
+    return GroupNorm32(num_groups=32, num_channels=in_channels, eps=1e-6, affine=True)
+
+
+class GEGLU(nn.Module):
+    """proj: Linear(dim_in, 2*dim_out); forward = value * gelu(gate) (attention.py:31-38)."""
+
+    def __init__(self, dim_in, dim_out):
+        super().__init__()
+        self.proj = Linear(dim_in, dim_out * 2)
+        self._cache = _PackCache()
+
+    def packed(self):
+        def build():
+            wi, bi = ops.interleave_geglu(self.proj.weight.detach(), self.proj.bias.detach())
+            return ops.pack_matrix(wi, bi, self.proj.weight.device)
+
+        return self._cache.get((self.proj.weight, self.proj.bias), build)
+
+    def hip(self, x2d):
+        return ops.gemm(x2d, self.packed(), act=AF_ACT_GEGLU)
+
+    def forward(self, x):
+        y = self.hip(x.reshape(-1, x.shape[-1]).to(F16).contiguous())
+        y = y.reshape(*x.shape[:-1], y.shape[-1])
+        return y if x.dtype == F16 else y.to(x.dtype)
+
+
+class FeedForward(nn.Module):
+    def __init__(self, dim, dim_out=None, mult=4, glu=False, dropout=0.0):
+        super().__init__()
+        inner_dim = int(dim * mult)
+        dim_out = default(dim_out, dim)
+        if not glu:
+            raise NotImplementedError("FeedForward(glu=False) is not on the SD-1.5 path")
+        if dropout != 0.0:
+            raise NotImplementedError("dropout > 0 is not supported (SD-1.5 uses 0)")
+        self.net = nn.Sequential(GEGLU(dim, inner_dim), nn.Dropout(dropout), Linear(inner_dim, dim_out))
+
+    def hip(self, x2d, residual=None):
+        return self.net[2].hip(self.net[0].hip(x2d), residual=residual)
+
+    def forward(self, x):
+        y = self.hip(x.reshape(-1, x.shape[-1]).to(F16).contiguous()).reshape(x.shape[:-1] + (-1,))
+        return y if x.dtype == F16 else y.to(x.dtype)
+
+
+class CrossAttention(nn.Module):
+    """All SD-1.5 attention layers: 8 heads, head dim C/8 (attention.py:146-222)."""
+
+    def __init__(self, query_dim, context_dim=None, heads=8, dim_head=64, dropout=0.0):
+        super().__init__()
+        inner_dim = dim_head * heads
+        context_dim = default(context_dim, query_dim)
+        if dropout != 0.0:
+            raise NotImplementedError("dropout > 0 is not supported (SD-1.5 uses 0)")
+        self.scale = dim_head ** -0.5
+        self.heads = heads
+        self.dim_head = dim_head
+        self.inner_dim = inner_dim
+        self.to_q = Linear(query_dim, inner_dim, bias=False)
+        self.to_k = Linear(context_dim, inner_dim, bias=False)
+        self.to_v = Linear(context_dim, inner_dim, bias=False)
+        self.to_out = nn.Sequential(Linear(inner_dim, query_dim), nn.Dropout(dropout))
+        self.save_cross_attn_vars = False
+        self.cached_activations = None
+        self._qkv_cache = _PackCache()
+        self._kv_cache = _PackCache()
+
+    # fused projection weights (built once per device / weight version)
+    def _packed_qkv(self):
+        ws = (self.to_q.weight, self.to_k.weight, self.to_v.weight)
+        return self._qkv_cache.get(ws, lambda: ops.pack_matrix(torch.cat([w.detach() for w in ws], 0), None, ws[0].device))
+
+    def _packed_kv(self):
+        ws = (self.to_k.weight, self.to_v.weight)
+        return self._kv_cache.get(ws, lambda: ops.pack_matrix(torch.cat([w.detach() for w in ws], 0), None, ws[0].device))
+
+    def hip(self, x2d, B, N, context=None, keybias=None, residual=None):
+        """x2d [B*N, C] fp16; context [B, L, Cc] fp16 or None (self-attention); keybias fp32
+        [B, roundup(L,64)] or None; residual [B*N, C] added after to_out.  Returns [B*N, C]."""
+        Ci, h, d = self.inner_dim, self.heads, self.dim_head
+        if context is None:
+            if self.to_k.in_features != self.to_q.in_features:
+                raise RuntimeError("CrossAttention: context is required (context_dim != query_dim)")
+            L = N
+            qk, vt = ops.gemm(x2d, self._packed_qkv(), rows_per_batch=N, split_col=2 * Ci)
+            q, k, ldq, ldk = qk, qk[:, Ci:], 2 * Ci, 2 * Ci
+        else:
+            L = context.shape[1]
+            q = self.to_q.hip(x2d)
+            k, vt = ops.gemm(context.reshape(B * L, context.shape[-1]), self._packed_kv(), rows_per_batch=L, split_col=Ci)
+            ldq = ldk = Ci
+        o = ops.attention(q, k, vt, B=B, Nq=N, L=L, heads=h, d=d, ldq=ldq, ldk=ldk, keybias=keybias, scale=self.scale)
+        if self.save_cross_attn_vars:
+            # attention.py:207-220 -- explicit score / prob only on the (rare) capture path
+            out_plain = self.to_out[0].hip(o)
+            qc = q if context is not None else qk[:, :Ci].contiguous()
+            kc = k if context is not None else qk[:, Ci:].contiguous()
+            score, prob = ops.attention_scores(qc, kc, B=B, Nq=N, L=L, heads=h, d=d, scale=self.scale)
+            self.cached_activations = {
+                "q": (qc.reshape(B, N, Ci).permute(0, 2, 1).float() * math.sqrt(self.scale)).contiguous(),
+                "attn": prob,
+                "attnscore": score,
+                "attn_out": out_plain.reshape(B, N, -1).permute(0, 2, 1).float().contiguous(),
+            }
+            if residual is None:
+                return out_plain
+        return self.to_out[0].hip(o, residual=residual)
+
+    def forward(self, x, context=None, mask=None):
+        """x [b, n, C]; context [b, l, Cc] or None; mask [b, ...] (nonzero = keep) over keys."""
+        B, N, _ = x.shape
+        x2d = x.reshape(B * N, -1).to(F16).contiguous()
+        ctx = None if context is None else context.to(F16).contiguous()
+        L = N if ctx is None else ctx.shape[1]
+        kb = None if mask is None else ops.make_keybias(mask.reshape(B, -1), L)
+        y = self.hip(x2d, B, N, ctx, kb).reshape(B, N, -1)
+        return y if x.dtype == F16 else y.to(x.dtype)
+
+
+class BasicTransformerBlock(nn.Module):
+    def __init__(self, dim, n_heads, d_head, dropout=0.0, context_dim=None, gated_ff=True, checkpoint=True):
+        super().__init__()
+        self.attn1 = CrossAttention(query_dim=dim, heads=n_heads, dim_head=d_head, dropout=dropout)
+        self.ff = FeedForward(dim, dropout=dropout, glu=gated_ff)
+        self.attn2 = CrossAttention(query_dim=dim, context_dim=context_dim, heads=n_heads, dim_head=d_head, dropout=dropout)
+        self.norm1 = LayerNorm(dim)
+        self.norm2 = LayerNorm(dim)
+        self.norm3 = LayerNorm(dim)
+        self.checkpoint = checkpoint
+
+    def hip(self, x2d, B, N, context=None, keybias=None):
+        """attention.py:242-252 with the three residual adds fused into GEMM epilogues."""
+        x1 = self.attn1.hip(self.norm1.hip(x2d), B, N, None, keybias, residual=x2d)
+        x2 = self.attn2.hip(self.norm2.hip(x1), B, N, context, None, residual=x1)
+        return self.ff.hip(self.norm3.hip(x2), residual=x2)
+
+    def forward(self, x, context=None, mask=None):
+        return checkpoint(self._forward, (x, context, mask), self.parameters(), self.checkpoint)
+
+    def _forward(self, x, context=None, mask=None):
+        B, N, _ = x.shape
+        ctx = None if context is None else context.to(F16).contiguous()
+        kb = None if mask is None else ops.make_keybias(mask.reshape(B, -1), N)
+        y = self.hip(x.reshape(B * N, -1).to(F16).contiguous(), B, N, ctx, kb).reshape(B, N, -1)
+        return y if x.dtype == F16 else y.to(x.dtype)
+
+
+class SpatialTransformer(nn.Module):
+    """GroupNorm -> 1x1 conv -> transformer block(s) over the H*W tokens -> 1x1 conv -> + input
+    (attention.py:254-304)."""
+
+    def __init__(self, in_channels, n_heads, d_head, depth=1, dropout=0.0, context_dim=None):
+        super().__init__()
+        self.in_channels = in_channels
+        inner_dim = n_heads * d_head
+        self.norm = Normalize(in_channels)
+        self.proj_in = Conv2d(in_channels, inner_dim, kernel_size=1, stride=1, padding=0)
+        self.transformer_blocks = nn.ModuleList(
+            [BasicTransformerBlock(inner_dim, n_heads, d_head, dropout=dropout, context_dim=context_dim) for _ in range(depth)]
+        )
+        self.proj_out = zero_module(Conv2d(inner_dim, in_channels, kernel_size=1, stride=1, padding=0))
+
+    def hip(self, x, context=None, mask=None):
+        """x [B,H,W,C] fp16; context [B,L,Cc] fp16; mask [B,1,h0,w0] (nonzero = keep) or None."""
+        B, H, W, Cn = x.shape
+        N = H * W
+        y = self.norm.hip(x)
+        y = self.proj_in.hip(y).reshape(B * N, -1)
+        kb = None
+        if mask is not None:
+            m2 = F.interpolate(mask.float(), size=(H, W), mode="nearest")  # attention.py:298
+            kb = ops.make_keybias(m2.reshape(B, N), N)
+        for block in self.transformer_blocks:
+            block.attn2.infeat_size = (H, W)
+            y = block.hip(y, B, N, context, kb)
+        out = ops.gemm(y, self.proj_out.packed(), residual=x.reshape(B * N, Cn))
+        return out.reshape(B, H, W, Cn)
+
+    def forward(self, x, context=None, mask=None):
+        ctx = None if context is None else context.to(F16).contiguous()
+        return from_nhwc_f16(self.hip(to_nhwc_f16(x), ctx, mask), x.dtype)

@@ -1,0 +1,419 @@
+"""Host-side mirror of the reference's ``ldm/modules/diffusionmodules/openaimodel.py``:
+``UNetModel`` / ``ResBlock`` / ``TimestepEmbedSequential`` / ``Upsample`` / ``Downsample``
+with the reference constructor arguments, state-dict keys and ``forward`` contracts
+(openaimodel.py:73-161, 164-276, 414-952), executed by hand-written gfx950 kernels.
+
+Execution plan of one epsilon-prediction (what differs from the reference's op-by-op torch):
+
+* NCHW fp32 latents are converted once to NHWC fp16 (4 -> 8 channels zero-padded for 16-byte
+  loads) and back once at the end; everything in between is NHWC fp16 in HBM;
+* ResBlock = GroupNorm+SiLU kernel -> conv3x3 (bias + time-embedding add in the epilogue) ->
+  GroupNorm+SiLU -> conv3x3 (bias + skip add in the epilogue); the 1x1 skip conv, the nearest
+  upsample (openaimodel.py:117) and the ``torch.cat([h, hs.pop()], 1)`` of the decoder
+  (openaimodel.py:918) are fused into the operand loaders of the kernels that consume them;
+* the 22 per-ResBlock ``emb_layers`` Linear(SiLU(emb)) (openaimodel.py:219-225,265) are one
+  GEMM per forward (weights concatenated at pack time), SiLU fused into the epilogue of
+  ``time_embed.2``.
+"""
+from abc import abstractmethod
+
+import torch
+import torch.nn as nn
+
+from .... import ops
+from ....ops import AF_ACT_SILU, F16
+from ..attention import SpatialTransformer
+from .util import (Conv2d, _PackCache, checkpoint, conv_nd, from_nhwc_f16, linear, normalization, timestep_embedding,
+                   to_nhwc_f16, zero_module)
+
+
+class TimestepBlock(nn.Module):
+    @abstractmethod
+    def forward(self, x, emb):
+        """Apply the module to `x` given `emb` timestep embeddings."""
+
+
+class SkipCat(tuple):
+    """(h, skip): the decoder's channel concat, kept as two tensors so consumers read both
+    sources directly instead of materialising torch.cat (openaimodel.py:918)."""
+
+
+class EmbPack:
+    """Time embedding handed to ResBlocks inside UNetModel: SiLU(emb) plus, when available, the
+    batched output of every ResBlock's emb_layers projection."""
+
+    def __init__(self, silu_emb, all_out=None):
+        self.silu_emb = silu_emb  # [B, emb_ch] fp16
+        self.all_out = all_out    # [B, sum(Cout)] fp16 or None
+
+
+class TimestepEmbedSequential(nn.Sequential, TimestepBlock):
+    def hip(self, x, emb, context=None, mask=None):
+        for layer in self:
+            if isinstance(layer, TimestepBlock):
+                x = layer.hip(x, emb)
+            elif isinstance(layer, SpatialTransformer):
+                x = layer.hip(x, context, mask)
+            else:
+                x = layer.hip(x)
+        return x
+
+    def forward(self, x, emb, context=None, mask=None):
+        for layer in self:
+            if isinstance(layer, TimestepBlock):
+                x = layer(x, emb)
+            elif isinstance(layer, SpatialTransformer):
+                x = layer(x, context, mask=mask)
+            else:
+                x = layer(x)
+        return x
+
+
+class Upsample(nn.Module):
+    """Nearest x2 + optional 3x3 conv; the upsample is folded into the conv's input gather."""
+
+    def __init__(self, channels, use_conv, dims=2, out_channels=None, padding=1):
+        super().__init__()
+        self.channels = channels
+        self.out_channels = out_channels or channels
+        self.use_conv = use_conv
+        self.dims = dims
+        if not use_conv:
+            raise NotImplementedError("Upsample(use_conv=False) is not on the SD-1.5 path")
+        self.conv = conv_nd(dims, self.channels, self.out_channels, 3, padding=padding)
+
+    def hip(self, x):
+        assert x.shape[-1] == self.channels
+        return self.conv.hip(x, upsample=True)
+
+    def forward(self, x):
+        assert x.shape[1] == self.channels
+        return from_nhwc_f16(self.hip(to_nhwc_f16(x)), x.dtype)
+
+
+class Downsample(nn.Module):
+    def __init__(self, channels, use_conv, dims=2, out_channels=None, padding=1):
+        super().__init__()
+        self.channels = channels
+        self.out_channels = out_channels or channels
+        self.use_conv = use_conv
+        self.dims = dims
+        if not use_conv:
+            raise NotImplementedError("Downsample(use_conv=False) is not on the SD-1.5 path")
+        self.op = conv_nd(dims, self.channels, self.out_channels, 3, stride=2, padding=padding)
+
+    def hip(self, x):
+        assert x.shape[-1] == self.channels
+        return self.op.hip(x)
+
+    def forward(self, x):
+        assert x.shape[1] == self.channels
+        return from_nhwc_f16(self.hip(to_nhwc_f16(x)), x.dtype)
+
+
+class ResBlock(TimestepBlock):
+    def __init__(self, channels, emb_channels, dropout, out_channels=None, use_conv=False, use_scale_shift_norm=False,
+                 dims=2, use_checkpoint=False, up=False, down=False):
+        super().__init__()
+        if use_scale_shift_norm or up or down:
+            raise NotImplementedError("scale-shift norm / resblock_updown are not on the SD-1.5 path")
+        if dropout != 0:
+            raise NotImplementedError("dropout > 0 is not supported (SD-1.5 uses 0)")
+        self.channels = channels
+        self.emb_channels = emb_channels
+        self.dropout = dropout
+        self.out_channels = out_channels or channels
+        self.use_conv = use_conv
+        self.use_checkpoint = use_checkpoint
+        self.use_scale_shift_norm = use_scale_shift_norm
+        self.updown = False
+        self.in_layers = nn.Sequential(
+            normalization(channels), nn.SiLU(), conv_nd(dims, channels, self.out_channels, 3, padding=1)
+        )
+        self.h_upd = self.x_upd = nn.Identity()
+        self.emb_layers = nn.Sequential(nn.SiLU(), linear(emb_channels, self.out_channels))
+        self.out_layers = nn.Sequential(
+            normalization(self.out_channels), nn.SiLU(), nn.Dropout(p=dropout),
+            zero_module(conv_nd(dims, self.out_channels, self.out_channels, 3, padding=1)),
+        )
+        if self.out_channels == channels:
+            self.skip_connection = nn.Identity()
+        elif use_conv:
+            self.skip_connection = conv_nd(dims, channels, self.out_channels, 3, padding=1)
+        else:
+            self.skip_connection = conv_nd(dims, channels, self.out_channels, 1)
+        self._emb_slice = None  # (offset, width) into EmbPack.all_out, assigned by UNetModel
+
+    def hip(self, x, emb):
+        """x: [B,H,W,C] fp16 or SkipCat((h, skip)); emb: EmbPack or fp16 [B, emb_ch] (raw emb)."""
+        x1, x2 = (x[0], x[1]) if isinstance(x, SkipCat) else (x, None)
+        if isinstance(emb, EmbPack) and emb.all_out is not None and self._emb_slice is not None:
+            off, width = self._emb_slice
+            e = emb.all_out[:, off:off + width]          # [B, Cout] view, row stride = sum(Cout)
+        else:
+            se = emb.silu_emb if isinstance(emb, EmbPack) else ops.silu(emb.to(F16).contiguous())
+            e = self.emb_layers[1].hip(se)
+        h = self.in_layers[0].hip(x1, silu=True, x2=x2)
+        h = self.in_layers[2].hip(h, rowbias=e)
+        h = self.out_layers[0].hip(h, silu=True)
+        if isinstance(self.skip_connection, nn.Identity):
+            skip = x1 if x2 is None else torch.cat([x1, x2], dim=-1)
+        else:
+            skip = self.skip_connection.hip(x1, x2=x2)
+        return self.out_layers[3].hip(h, residual=skip)
+
+    def forward(self, x, emb):
+        return checkpoint(self._forward, (x, emb), self.parameters(), self.use_checkpoint)
+
+    def _forward(self, x, emb):
+        return from_nhwc_f16(self.hip(to_nhwc_f16(x), emb), x.dtype)
+
+
+class UNetModel(nn.Module):
+    """The SD-1.5 U-Net with the reference's constructor signature (openaimodel.py:444-469).
+    Only the options SD-1.5 uses are implemented; the others raise at construction."""
+
+    def __init__(self, in_channels, model_channels, out_channels, num_res_blocks, attention_resolutions, dropout=0,
+                 channel_mult=(1, 2, 4, 8), conv_resample=True, dims=2, num_classes=None, use_checkpoint=False,
+                 use_fp16=False, num_heads=-1, num_head_channels=-1, num_heads_upsample=-1, use_scale_shift_norm=False,
+                 resblock_updown=False, use_new_attention_order=False, use_spatial_transformer=False, transformer_depth=1,
+                 context_dim=None, n_embed=None, legacy=True):
+        super().__init__()
+        if not use_spatial_transformer or context_dim is None:
+            raise NotImplementedError("only the use_spatial_transformer=True / context_dim path (SD-1.x) is implemented")
+        if num_classes is not None or n_embed is not None or resblock_updown or use_scale_shift_norm or dims != 2:
+            raise NotImplementedError("class-conditional / codebook / resblock_updown / scale-shift variants are off the hot path")
+        if isinstance(context_dim, (list, tuple)) or type(context_dim).__name__ == "ListConfig":
+            context_dim = list(context_dim)[0]
+        if num_heads_upsample == -1:
+            num_heads_upsample = num_heads
+        if num_heads == -1 and num_head_channels == -1:
+            raise ValueError("Either num_heads or num_head_channels has to be set")
+
+        self.in_channels = in_channels
+        self.model_channels = model_channels
+        self.out_channels = out_channels
+        self.num_res_blocks = num_res_blocks
+        self.attention_resolutions = attention_resolutions
+        self.dropout = dropout
+        self.channel_mult = channel_mult
+        self.conv_resample = conv_resample
+        self.num_classes = num_classes
+        self.use_checkpoint = use_checkpoint
+        self.dtype = torch.float16 if use_fp16 else torch.float32
+        self.num_heads = num_heads
+        self.num_head_channels = num_head_channels
+        self.num_heads_upsample = num_heads_upsample
+        self.predict_codebook_ids = False
+        self.debug_attn = False
+        self.backup_vars = {"save_cross_attn_vars": False}
+
+        def heads_of(ch, nh):
+            if num_head_channels == -1:
+                return nh, ch // nh
+            return ch // num_head_channels, num_head_channels
+
+        def transformer(ch, nh):
+            n, d = heads_of(ch, nh)
+            return SpatialTransformer(ch, n, d, depth=transformer_depth, context_dim=context_dim)
+
+        time_embed_dim = model_channels * 4
+        self.time_embed = nn.Sequential(linear(model_channels, time_embed_dim), nn.SiLU(), linear(time_embed_dim, time_embed_dim))
+
+        conv_in = conv_nd(dims, in_channels, model_channels, 3, padding=1)
+        conv_in.cin_pad = ops.round_up(in_channels, 8)
+        self.input_blocks = nn.ModuleList([TimestepEmbedSequential(conv_in)])
+        input_block_chans = [model_channels]
+        ch = model_channels
+        ds = 1
+        for level, mult in enumerate(channel_mult):
+            for _ in range(num_res_blocks):
+                layers = [ResBlock(ch, time_embed_dim, dropout, out_channels=mult * model_channels, dims=dims,
+                                   use_checkpoint=use_checkpoint)]
+                ch = mult * model_channels
+                if ds in attention_resolutions:
+                    layers.append(transformer(ch, num_heads))
+                self.input_blocks.append(TimestepEmbedSequential(*layers))
+                input_block_chans.append(ch)
+            if level != len(channel_mult) - 1:
+                self.input_blocks.append(TimestepEmbedSequential(Downsample(ch, conv_resample, dims=dims, out_channels=ch)))
+                input_block_chans.append(ch)
+                ds *= 2
+
+        self.middle_block = TimestepEmbedSequential(
+            ResBlock(ch, time_embed_dim, dropout, dims=dims, use_checkpoint=use_checkpoint),
+            transformer(ch, num_heads),
+            ResBlock(ch, time_embed_dim, dropout, dims=dims, use_checkpoint=use_checkpoint),
+        )
+
+        self.output_blocks = nn.ModuleList([])
+        for level, mult in list(enumerate(channel_mult))[::-1]:
+            for i in range(num_res_blocks + 1):
+                ich = input_block_chans.pop()
+                layers = [ResBlock(ch + ich, time_embed_dim, dropout, out_channels=model_channels * mult, dims=dims,
+                                   use_checkpoint=use_checkpoint)]
+                ch = model_channels * mult
+                if ds in attention_resolutions:
+                    layers.append(transformer(ch, num_heads_upsample))
+                if level and i == num_res_blocks:
+                    layers.append(Upsample(ch, conv_resample, dims=dims, out_channels=ch))
+                    ds //= 2
+                self.output_blocks.append(TimestepEmbedSequential(*layers))
+
+        self.out = nn.Sequential(
+            normalization(ch), nn.SiLU(), zero_module(conv_nd(dims, model_channels, out_channels, 3, padding=1))
+        )
+
+        # batched emb_layers projection: slices assigned in module order
+        self._resblocks = [m for m in self.modules() if isinstance(m, ResBlock)]
+        off = 0
+        for rb in self._resblocks:
+            rb._emb_slice = (off, rb.out_channels)
+            off += ops.round_up(rb.out_channels, 8)
+        self._emb_total = off
+        self._emb_cache = _PackCache()
+
+    # ------------------------------------------------------------------ reference flag plumbing
+    ALL_CA_LAYER_INDICES = [1, 2, 4, 5, 7, 8, 12, 16, 17, 18, 19, 20, 21, 22, 23, 24]  # openaimodel.py:721
+
+    def _layer_blocks(self):
+        return list(self.input_blocks) + [self.middle_block] + list(self.output_blocks)
+
+    def set_cross_attn_flags(self, ca_flag_dict=None, ca_layer_indices=None, trans_flag_dict=None, trans_layer_indices=None):
+        """Set attributes on attn2 (ca_flag_dict) / the transformer block (trans_flag_dict) of the
+        selected cross-attention layers; returns the previous values (openaimodel.py:716-817).
+        The ':layerwise' / ':layerwise-dict' value forms of the reference are accepted."""
+        if ca_flag_dict is None and trans_flag_dict is None:
+            return None, None
+        l2ca = {li: i for i, li in enumerate(self.ALL_CA_LAYER_INDICES)}
+        blocks = self._layer_blocks()
+
+        def apply(flag_dict, indices, target):
+            if flag_dict is None or len(indices) == 0:
+                return None
+            old = {}
+            for k, v in flag_dict.items():
+                old[k] = self.backup_vars.get(k)
+                self.backup_vars[k] = v
+                key, lw_arr, lw_dict = k, False, False
+                if key.endswith(":layerwise"):
+                    key, lw_arr = key[: -len(":layerwise")], v is not None
+                if key.endswith(":layerwise-dict"):
+                    key, lw_dict = key[: -len(":layerwise-dict")], v is not None
+                for li in indices:
+                    if li >= len(blocks) or li not in l2ca:
+                        continue
+                    blk = blocks[li][1].transformer_blocks[0]
+                    if lw_arr:
+                        v2 = v[l2ca[li]]
+                    elif lw_dict:
+                        v2 = v.get(li, None) if hasattr(v, "get") else v
+                    else:
+                        v2 = v
+                    (blk.attn2 if target == "ca" else blk).__dict__[key] = v2
+            return old
+
+        ca_idx = self.ALL_CA_LAYER_INDICES if ca_layer_indices is None else ca_layer_indices
+        tr_idx = self.ALL_CA_LAYER_INDICES if trans_layer_indices is None else trans_layer_indices
+        return apply(ca_flag_dict, ca_idx, "ca"), apply(trans_flag_dict, tr_idx, "trans")
+
+    # ------------------------------------------------------------------ packing
+    def _packed_emb_all(self):
+        params = []
+        for rb in self._resblocks:
+            params += [rb.emb_layers[1].weight, rb.emb_layers[1].bias]
+
+        def build():
+            dev = params[0].device
+            K = self._resblocks[0].emb_channels
+            w = torch.zeros((self._emb_total, K), dtype=torch.float32, device=dev)
+            b = torch.zeros((self._emb_total,), dtype=torch.float32, device=dev)
+            for rb in self._resblocks:
+                off, width = rb._emb_slice
+                w[off:off + width] = rb.emb_layers[1].weight.detach().float()
+                b[off:off + width] = rb.emb_layers[1].bias.detach().float()
+            return ops.pack_matrix(w, b, dev)
+
+        return self._emb_cache.get(params, build)
+
+    def prepare(self):
+        """Pack every weight for the current device now (otherwise done lazily on first use)."""
+        for m in self.modules():
+            if hasattr(m, "packed"):
+                m.packed()
+            if hasattr(m, "_packed_qkv") and m.to_k.in_features == m.to_q.in_features:
+                m._packed_qkv()
+            if hasattr(m, "_packed_kv") and m.to_k.in_features != m.to_q.in_features:
+                m._packed_kv()
+        self._packed_emb_all()
+        return self
+
+    # ------------------------------------------------------------------ forward
+    def hip(self, x_nhwc, timesteps, context, img_mask=None, capture_layers=()):
+        """x_nhwc [B,H,W,8] fp16 (4 latent channels + zero pad), timesteps int64 [B],
+        context [B,L,ctx] fp16 -> (eps [B,H,W,out_channels] fp16, captured activations)."""
+        t_emb = timestep_embedding(timesteps, self.model_channels)
+        e0 = ops.gemm(t_emb, self.time_embed[0].packed(), act=AF_ACT_SILU)
+        semb = ops.gemm(e0, self.time_embed[2].packed(), act=AF_ACT_SILU)  # SiLU(emb): only consumer is emb_layers
+        emb = EmbPack(semb, ops.gemm(semb, self._packed_emb_all()))
+
+        acts = {}
+        hs = []
+        h = x_nhwc
+        layer_idx = 0
+
+        def collect(module, h):
+            attn2 = module[1].transformer_blocks[0].attn2
+            a = attn2.cached_activations
+            a["outfeat"] = from_nhwc_f16(h, torch.float32)
+            acts[layer_idx] = a
+            attn2.cached_activations = None
+
+        for module in self.input_blocks:
+            h = module.hip(h, emb, context, img_mask)
+            hs.append(h)
+            if layer_idx in capture_layers:
+                collect(module, h)
+            layer_idx += 1
+        h = self.middle_block.hip(h, emb, context, img_mask)
+        if layer_idx in capture_layers:
+            collect(self.middle_block, h)
+        layer_idx += 1
+        for module in self.output_blocks:
+            h = module.hip(SkipCat((h, hs.pop())), emb, context, img_mask)
+            if layer_idx in capture_layers:
+                collect(module, h)
+            layer_idx += 1
+        h = self.out[0].hip(h, silu=True)
+        return self.out[2].hip(h), acts
+
+    def forward(self, x, timesteps=None, context=None, y=None, context_in=None, extra_info=None, **kwargs):
+        """Reference contract (openaimodel.py:820-952): x [N,4,H,W], timesteps [N], context
+        [N,L,ctx]; ``extra_info`` carries ``img_mask`` / ``capture_ca_activations`` in and
+        receives ``ca_layers_activations`` out.  Returns eps [N,out_channels,H,W] in x.dtype."""
+        assert y is None, "must specify y if and only if the model is class-conditional"
+        capture = extra_info.get("capture_ca_activations", False) if extra_info is not None else False
+        img_mask = extra_info.get("img_mask", None) if extra_info is not None else None
+        captured = [22, 23, 24] if capture else []
+        old_flags = None
+        if capture:
+            old_flags, _ = self.set_cross_attn_flags(ca_flag_dict={"save_cross_attn_vars": True}, ca_layer_indices=captured)
+        try:
+            xh = to_nhwc_f16(x, ops.round_up(self.in_channels, 8))
+            ctx = context.to(F16).contiguous()
+            eps, acts = self.hip(xh, timesteps, ctx, img_mask, captured)
+        finally:
+            if capture:
+                self.set_cross_attn_flags(ca_flag_dict=old_flags, ca_layer_indices=captured)
+        if extra_info is not None:
+            extra_info["ca_layers_activations"] = {
+                key: {li: acts[li][key] for li in acts} for key in ("outfeat", "attn", "attnscore", "q", "attn_out")
+            }
+        return from_nhwc_f16(eps, x.dtype, self.out_channels)
+
+
+def unet_param_shapes(cfg):
+    """(name, shape) of every parameter of UNetModel(**cfg), without allocating them."""
+    with torch.device("meta"):
+        m = UNetModel(**cfg)
+    return [(n, tuple(p.shape)) for n, p in m.named_parameters()]

@@ -1,0 +1,304 @@
+"""Tensor-level wrappers over the C ABI (include/adaface_hip.h).
+
+torch is plumbing here: it owns device memory and the current HIP stream; every function
+below hands raw device pointers to ``libadaface_hip.so`` and raises ``RuntimeError`` on any
+failure.  There is no eager / CPU fallback.
+
+Activation convention: fp16, channels-last.  A feature map is a contiguous tensor
+``[B, H, W, C]`` (equivalently tokens ``[B, H*W, C]``).
+"""
+import ctypes as C
+import math
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import AF_ACT_GEGLU, AF_ACT_NONE, AF_ACT_SILU, AF_OUT_NORMAL, AF_OUT_SPLIT_T, GemmDesc
+
+F16 = torch.float16
+NEG_MAX = -torch.finfo(torch.float32).max
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _chk_f16(t: torch.Tensor, name: str):
+    if t.dtype != F16 or not t.is_cuda or not t.is_contiguous():
+        raise RuntimeError(f"{name}: expected a contiguous fp16 device tensor, got {t.dtype} {t.device} contiguous={t.is_contiguous()}")
+
+
+def round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+# ----------------------------------------------------------------------------- weights
+@dataclass
+class PackedWeight:
+    """fp16 [Npad, Kpad] K-contiguous weight (+ fp32 bias) laid out for af_gemm."""
+    wt: torch.Tensor
+    bias: Optional[torch.Tensor]
+    N: int
+    K: int
+    kpad: int
+    taps: int = 1
+    cin: int = 0  # channels per tap as seen by the kernel (after any channel padding)
+
+
+def pack_matrix(w2d: torch.Tensor, bias: Optional[torch.Tensor], device, taps: int = 1, cin: int = 0) -> PackedWeight:
+    """w2d: [N, K] (any float dtype, any device) -> zero-padded fp16 [roundup(N,128), roundup(K,64)]."""
+    N, K = w2d.shape
+    npad, kpad = round_up(N, 128), round_up(K, 64)
+    wt = torch.zeros((npad, kpad), dtype=F16, device=device)
+    wt[:N, :K] = w2d.detach().to(device=device, dtype=F16)
+    b = None if bias is None else bias.detach().to(device=device, dtype=torch.float32).contiguous()
+    return PackedWeight(wt, b, N, K, kpad, taps, cin if cin else K)
+
+
+def pack_conv3x3(w: torch.Tensor, bias: Optional[torch.Tensor], device, cin_pad: int = 0) -> PackedWeight:
+    """[Cout, Cin, 3, 3] -> [Cout, 9*Cin'] with K order (ky, kx, cin); Cin' = max(Cin, cin_pad)."""
+    cout, cin, kh, kw = w.shape
+    assert kh == 3 and kw == 3
+    w = w.detach().permute(0, 2, 3, 1)  # [Cout, 3, 3, Cin]
+    cinp = max(cin, cin_pad)
+    if cinp != cin:
+        w = torch.nn.functional.pad(w, (0, cinp - cin))
+    return pack_matrix(w.reshape(cout, 9 * cinp), bias, device, taps=9, cin=cinp)
+
+
+def interleave_geglu(w: torch.Tensor, b: torch.Tensor):
+    """GEGLU projection [2*inner, C]: rows [value | gate] -> 16-row groups [16 value, 16 gate, ...]
+    so value and gate of a channel land in the same lane / register of adjacent MFMA tiles."""
+    inner = w.shape[0] // 2
+    assert inner % 16 == 0
+    wv, wg = w[:inner].reshape(inner // 16, 16, -1), w[inner:].reshape(inner // 16, 16, -1)
+    wi = torch.stack([wv, wg], dim=1).reshape(2 * inner, -1)
+    bv, bg = b[:inner].reshape(inner // 16, 16), b[inner:].reshape(inner // 16, 16)
+    bi = torch.stack([bv, bg], dim=1).reshape(2 * inner)
+    return wi, bi
+
+
+# ----------------------------------------------------------------------------- gemm / conv
+def gemm(a1: torch.Tensor, pw: PackedWeight, *, a2: Optional[torch.Tensor] = None, rowbias: Optional[torch.Tensor] = None,
+         rows_per_batch: int = 0, residual: Optional[torch.Tensor] = None, act: int = AF_ACT_NONE,
+         split_col: int = 0, ld_out2: int = 0, tile: int = 0):
+    """Plain-rows GEMM: a1 [M, K1] (+ a2 [M, K2], concatenated along K) x pw.  Returns out
+    ([M, N], or [M, N/2] for GEGLU), or (out [M, split_col], out2 [B, N-split_col, ld_out2])."""
+    _chk_f16(a1, "gemm.a1")
+    M, k1 = a1.shape
+    k2 = 0
+    if a2 is not None:
+        _chk_f16(a2, "gemm.a2")
+        k2 = a2.shape[1]
+        assert a2.shape[0] == M
+    assert k1 + k2 == pw.K, f"gemm: K mismatch {k1}+{k2} vs {pw.K}"
+    d = GemmDesc()
+    d.a1, d.a2, d.wt, d.bias = _p(a1), _p(a2), _p(pw.wt), _p(pw.bias)
+    d.rowbias, d.residual = _p(rowbias), _p(residual)
+    d.M, d.N, d.K, d.kpad, d.taps = M, pw.N, pw.K, pw.kpad, 1
+    d.c1, d.c2, d.lda1, d.lda2 = k1, k2, k1, k2
+    d.rows_per_batch = rows_per_batch
+    d.ld_rowbias = 0 if rowbias is None else rowbias.stride(0)
+    d.act, d.tile = act, tile
+    out2 = None
+    if split_col:
+        assert rows_per_batch > 0 and M % rows_per_batch == 0
+        nb = M // rows_per_batch
+        ld_out2 = ld_out2 or round_up(rows_per_batch, 8)
+        out = torch.empty((M, split_col), dtype=F16, device=a1.device)
+        out2 = torch.empty((nb, pw.N - split_col, ld_out2), dtype=F16, device=a1.device)
+        d.out_mode, d.split_col, d.ld_out2, d.out2 = AF_OUT_SPLIT_T, split_col, ld_out2, _p(out2)
+    else:
+        n_out = pw.N // 2 if act == AF_ACT_GEGLU else pw.N
+        out = torch.empty((M, n_out), dtype=F16, device=a1.device)
+    if residual is not None:
+        _chk_f16(residual, "gemm.residual")
+        assert residual.shape == out.shape
+    d.out = _p(out)
+    _lib.check(_lib.lib().af_gemm(C.byref(d), _stream()), "af_gemm")
+    return (out, out2) if split_col else out
+
+
+def conv3x3(x: torch.Tensor, pw: PackedWeight, *, x2: Optional[torch.Tensor] = None, stride: int = 1, upsample: bool = False,
+            rowbias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, tile: int = 0) -> torch.Tensor:
+    """3x3 / pad 1 convolution as implicit GEMM.  x [B,H,W,C1] (+ x2 [B,H,W,C2] channel-concat)
+    -> [B,Ho,Wo,Cout].  rowbias [B, >=Cout] is added per batch item (time-embedding), residual
+    [B,Ho,Wo,Cout] after it."""
+    _chk_f16(x, "conv3x3.x")
+    B, H, W, c1 = x.shape
+    c2 = 0
+    if x2 is not None:
+        _chk_f16(x2, "conv3x3.x2")
+        assert x2.shape[:3] == x.shape[:3]
+        c2 = x2.shape[3]
+    assert pw.taps == 9 and pw.cin == c1 + c2, f"conv3x3: channel mismatch {c1}+{c2} vs {pw.cin}"
+    he, we = (2 * H, 2 * W) if upsample else (H, W)
+    ho, wo = (he + 2 - 3) // stride + 1, (we + 2 - 3) // stride + 1
+    out = torch.empty((B, ho, wo, pw.N), dtype=F16, device=x.device)
+    d = GemmDesc()
+    d.a1, d.a2, d.wt, d.bias = _p(x), _p(x2), _p(pw.wt), _p(pw.bias)
+    d.rowbias, d.residual, d.out = _p(rowbias), _p(residual), _p(out)
+    d.M, d.N, d.K, d.kpad, d.taps = B * ho * wo, pw.N, pw.K, pw.kpad, 9
+    d.c1, d.c2 = c1, c2
+    d.B, d.H, d.W, d.Ho, d.Wo = B, H, W, ho, wo
+    d.stride, d.upsample = stride, int(upsample)
+    d.rows_per_batch = ho * wo
+    d.ld_rowbias = 0 if rowbias is None else rowbias.stride(0)
+    d.tile = tile
+    if residual is not None:
+        _chk_f16(residual, "conv3x3.residual")
+        assert residual.shape == out.shape
+    _lib.check(_lib.lib().af_gemm(C.byref(d), _stream()), "af_gemm(conv3x3)")
+    return out
+
+
+# ----------------------------------------------------------------------------- norms
+_gn_ws = {}
+
+
+def _gn_workspace(device, B: int) -> torch.Tensor:
+    need = _lib.lib().af_groupnorm_ws_floats(max(B, 16))
+    ws = _gn_ws.get(device)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty((need,), dtype=torch.float32, device=device)
+        _gn_ws[device] = ws
+    return ws
+
+
+def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, silu: bool, *,
+              x2: Optional[torch.Tensor] = None, groups: int = 32) -> torch.Tensor:
+    """x [B, ..., C1] (+ x2 [B, ..., C2]) -> [B, ..., C1+C2] fp16; gamma/beta fp32 [C1+C2]."""
+    _chk_f16(x, "groupnorm.x")
+    B, c1 = x.shape[0], x.shape[-1]
+    hw = x.numel() // (B * c1)
+    c2 = 0
+    if x2 is not None:
+        _chk_f16(x2, "groupnorm.x2")
+        c2 = x2.shape[-1]
+    y = torch.empty(tuple(x.shape[:-1]) + (c1 + c2,), dtype=F16, device=x.device)
+    ws = _gn_workspace(x.device, B)
+    rc = _lib.lib().af_groupnorm(_p(x), _p(x2), c1, c2, _p(gamma), _p(beta), _p(y), B, hw, groups, float(eps), int(silu),
+                                 _p(ws), _stream())
+    _lib.check(rc, "af_groupnorm")
+    return y
+
+
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    _chk_f16(x, "layernorm.x")
+    Cn = x.shape[-1]
+    y = torch.empty_like(x)
+    _lib.check(_lib.lib().af_layernorm(_p(x), _p(gamma), _p(beta), _p(y), x.numel() // Cn, Cn, float(eps), _stream()),
+               "af_layernorm")
+    return y
+
+
+# ----------------------------------------------------------------------------- attention
+def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, *, B: int, Nq: int, L: int, heads: int, d: int,
+              ldq: int, ldk: int, keybias: Optional[torch.Tensor] = None, scale: Optional[float] = None) -> torch.Tensor:
+    """q [B*Nq, ldq-wide rows], k [B*L, ldk-wide rows], vt [B, heads*d, ldv] -> o [B*Nq, heads*d]."""
+    Cn = heads * d
+    o = torch.empty((B * Nq, Cn), dtype=F16, device=q.device)
+    scale = d ** -0.5 if scale is None else scale
+    ldb = 0 if keybias is None else keybias.stride(0)
+    rc = _lib.lib().af_attention(_p(q), _p(k), _p(vt), _p(o), _p(keybias), B, Nq, L, heads, d, ldq, ldk, Cn, vt.stride(1),
+                                 ldb, float(scale), _stream())
+    _lib.check(rc, "af_attention")
+    return o
+
+
+def attention_scores(q: torch.Tensor, k: torch.Tensor, *, B: int, Nq: int, L: int, heads: int, d: int,
+                     scale: Optional[float] = None):
+    """Explicit (score, prob) fp32 [B, heads, Nq, L] for the capture path; q [B*Nq, C], k [B*L, C] contiguous."""
+    _chk_f16(q, "attention_scores.q")
+    _chk_f16(k, "attention_scores.k")
+    score = torch.empty((B, heads, Nq, L), dtype=torch.float32, device=q.device)
+    prob = torch.empty_like(score)
+    scale = d ** -0.5 if scale is None else scale
+    _lib.check(_lib.lib().af_attention_scores(_p(q), _p(k), _p(score), _p(prob), B, Nq, L, heads, d, float(scale), _stream()),
+               "af_attention_scores")
+    return score, prob
+
+
+def make_keybias(mask: torch.Tensor, L: int) -> torch.Tensor:
+    """mask [B, L] (nonzero = keep) -> fp32 [B, roundup(L, 64)] additive bias: 0 / -FLT_MAX
+    (== masked_fill_(~mask, -finfo.max), attention.py:188-194)."""
+    B = mask.shape[0]
+    kb = torch.zeros((B, round_up(L, 64)), dtype=torch.float32, device=mask.device)
+    kb[:, :L] = torch.where(mask.bool(), 0.0, NEG_MAX)
+    return kb
+
+
+# ----------------------------------------------------------------------------- element-wise
+def timestep_embedding(timesteps: torch.Tensor, dim: int, max_period: float = 10000.0) -> torch.Tensor:
+    t = timesteps.to(dtype=torch.int64).contiguous()
+    out = torch.empty((t.shape[0], dim), dtype=F16, device=t.device)
+    _lib.check(_lib.lib().af_timestep_embedding(_p(t), _p(out), t.shape[0], dim, float(max_period), _stream()),
+               "af_timestep_embedding")
+    return out
+
+
+def nchw_f32_to_nhwc_f16(x: torch.Tensor, cpad: int = 0) -> torch.Tensor:
+    x = x.to(torch.float32).contiguous()
+    B, Cn, H, W = x.shape
+    cpad = max(cpad, Cn)
+    y = torch.empty((B, H, W, cpad), dtype=F16, device=x.device)
+    _lib.check(_lib.lib().af_nchw_f32_to_nhwc_f16(_p(x), _p(y), B, Cn, H * W, cpad, _stream()), "af_nchw_f32_to_nhwc_f16")
+    return y
+
+
+def nhwc_f16_to_nchw_f32(x: torch.Tensor, Cn: Optional[int] = None) -> torch.Tensor:
+    _chk_f16(x, "nhwc_f16_to_nchw_f32.x")
+    B, H, W, cs = x.shape
+    Cn = Cn or cs
+    y = torch.empty((B, Cn, H, W), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().af_nhwc_f16_to_nchw_f32(_p(x), _p(y), B, Cn, H * W, cs, _stream()), "af_nhwc_f16_to_nchw_f32")
+    return y
+
+
+def silu(x: torch.Tensor) -> torch.Tensor:
+    _chk_f16(x, "silu.x")
+    y = torch.empty_like(x)
+    _lib.check(_lib.lib().af_silu_f16(_p(x), _p(y), x.numel(), _stream()), "af_silu_f16")
+    return y
+
+
+def cfg_ddim_step(eps2: torch.Tensor, x: torch.Tensor, guidance: float, a_t: float, a_prev: float, has_uncond: bool = True):
+    """eps2 fp32 [2n or n] = [e_cond ; e_uncond], x fp32 [n] -> (x_prev, pred_x0), ddim.py:253-302 (sigma = 0)."""
+    assert eps2.dtype == torch.float32 and x.dtype == torch.float32 and eps2.is_contiguous() and x.is_contiguous()
+    n = x.numel()
+    assert eps2.numel() == (2 * n if has_uncond else n)
+    x_prev, pred_x0 = torch.empty_like(x), torch.empty_like(x)
+    _lib.check(_lib.lib().af_cfg_ddim_step(_p(eps2), _p(x), _p(x_prev), _p(pred_x0), n, int(has_uncond), float(guidance),
+                                           float(a_t), float(a_prev), _stream()), "af_cfg_ddim_step")
+    return x_prev, pred_x0
+
+
+def q_sample(x0: torch.Tensor, noise: torch.Tensor, sa: torch.Tensor, sb: torch.Tensor) -> torch.Tensor:
+    """x_t = sa[b] x0 + sb[b] noise (ddpm.py:395-398); fp32."""
+    x0, noise = x0.to(torch.float32).contiguous(), noise.to(torch.float32).contiguous()
+    sa, sb = sa.to(torch.float32).contiguous(), sb.to(torch.float32).contiguous()
+    B = x0.shape[0]
+    xt = torch.empty_like(x0)
+    _lib.check(_lib.lib().af_q_sample(_p(x0), _p(noise), _p(sa), _p(sb), _p(xt), B, x0.numel() // B, _stream()), "af_q_sample")
+    return xt
+
+
+# ----------------------------------------------------------------------------- profiling hook
+def prof_enable(on: bool):
+    _lib.check(_lib.lib().af_prof_enable(int(on)), "af_prof_enable")
+
+
+def prof_reset():
+    _lib.check(_lib.lib().af_prof_reset(), "af_prof_reset")
+
+
+def prof_read(family: int):
+    n, ms = C.c_int(0), C.c_double(0.0)
+    _lib.check(_lib.lib().af_prof_read(family, C.byref(n), C.byref(ms)), "af_prof_read")
+    return n.value, ms.value

@@ -1,0 +1,226 @@
+#!/usr/bin/env python
+"""bench.py -- denoise-steps/s of the AdaFace SD-1.5 hot path on MI355X.
+
+Workload (BASELINE.json configs[1], the one `metric` is quoted on): AdaFace txt2img DDIM
+inference, 512x512 (latent 64x64), bs = 4 images/GPU with classifier-free guidance, i.e. one
+*denoise step* = one U-Net epsilon-prediction on a batch of 8 (4 cond + 4 uncond, 77 context
+tokens) + guidance combine + DDIM update.  Synthetic latents / context, seeded random weights
+of the SD-1.5 architecture (no network for checkpoints).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+
+N > 1: one process per GPU, independent replicas (inference has no exchange step: SURVEY 8e),
+weak scaling; `value` = N*K steps / max-over-ranks time.
+
+The JSON line carries, besides the driver contract:
+  roofline     -- dominant kernel family (the MFMA GEMM / implicit-conv template): algorithmic
+                  FLOPs (conv3x3 400.33 + Linear 233.28 + conv1x1 43.62 GFLOP per
+                  U-Net sample at 77 tokens) / summed launch time measured with hipEvents on the
+                  launch stream in an instrumented pass of the same steps, against 2.5 PFLOP/s
+                  dense fp16 MFMA (MI355X_MICROARCH.md);
+  cpu_baseline -- the CPU oracle (torch-CPU fp32 restatement of the reference U-Net, "port")
+                  timed on this host: ONE U-Net sample (bs 1, 64x64 latent, 77 tokens) = 1/8 of a
+                  denoise step, all host threads.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+GEMM_GFLOP_PER_SAMPLE = 400.33 + 233.28 + 43.62   # SURVEY.md 8d / BASELINE.md section 2 (T = 77)
+ATTN_GFLOP_PER_SAMPLE = 122.49 + 3.56
+UNET_GFLOP_PER_SAMPLE = 803.27
+MFMA_PEAK_TFLOPS = 2500.0                          # dense fp16/bf16, MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=4, help="images per GPU (U-Net batch is 2x with CFG)")
+    ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying a hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from adaface_dev_amd import SD15_UNET_CONFIG, _lib, ops, rng
+    from adaface_dev_amd.ldm.models.diffusion.ddim import DDIMSampler
+    from adaface_dev_amd.ldm.models.diffusion.ddpm import LatentDiffusion
+
+    _lib.lib()  # no fallback: fail here if the HIP extension is absent
+    B = args.batch
+    ldm = LatentDiffusion(SD15_UNET_CONFIG)
+    unet = ldm.model.diffusion_model
+    rng.load_synth_weights(unet, seed=0)
+    ldm = ldm.to(dev).eval()
+    unet.prepare()
+    for p in unet.parameters():
+        p.requires_grad_(False)
+
+    seed = 42 + rank * 10 ** 8   # per-rank stream, as ldm/util.py:524-530
+    x = rng.synth_input("bench.x", (B, 4, 64, 64), seed=seed).to(dev)
+    c_c = rng.synth_input("bench.ctx", (B, 77, 768), seed=seed).to(dev)
+    c_u = rng.synth_input("bench.uctx", (B, 77, 768), seed=seed).to(dev)
+    sampler = DDIMSampler(ldm)
+    sampler.make_schedule(50, verbose=False)
+    ts_desc = sampler.ddim_timesteps[::-1].copy()     # 981 ... 1
+    scales = sampler.guide_scales(50, 4.0)
+
+    # static buffers of one denoise step
+    x_in = torch.empty((2 * B, 4, 64, 64), dtype=torch.float32, device=dev)
+    t_in = torch.empty((2 * B,), dtype=torch.int64, device=dev)
+    ctx2 = torch.cat([c_c, c_u]).to(torch.float16).contiguous()   # (cond, uncond) order, ddim.py:244
+    state = {"x": x.clone(), "eps": None, "graph": None}
+
+    def unet_eps():
+        return unet(x_in, t_in, ctx2, extra_info=None)
+
+    def step(i):
+        idx = i % 50
+        index = 50 - idx - 1
+        x_in[:B].copy_(state["x"])
+        x_in[B:].copy_(state["x"])
+        t_in.fill_(int(ts_desc[idx]))
+        if state["graph"] is not None:
+            state["graph"].replay()
+            eps = state["eps"]
+        else:
+            eps = unet_eps()
+        xp, _ = ops.cfg_ddim_step(eps, state["x"], scales[idx], float(sampler.ddim_alphas[index]),
+                                  float(sampler.ddim_alphas_prev[index]), True)
+        state["x"] = xp
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+
+    with torch.no_grad():
+        step(0)                      # eager warm-up: packs weights, sets kernel attributes
+        torch.cuda.synchronize()
+        if not args.no_graph:
+            g = torch.cuda.CUDAGraph()
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                unet_eps()
+            torch.cuda.current_stream().wait_stream(s)
+            with torch.cuda.graph(g):
+                state["eps"] = unet_eps()
+            state["graph"] = g
+        state["x"] = x.clone()
+        for i in range(args.warmup):
+            step(i)
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(args.warmup + i)
+        torch.cuda.synchronize()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        finite = bool(torch.isfinite(state["x"]).all())
+
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    roofline = None
+    if not args.no_roofline and rank == 0:
+        # instrumented pass: same steps, eager launches, hipEvents around every launch of each family
+        state["graph"] = None
+        with torch.no_grad():
+            ops.prof_reset()
+            ops.prof_enable(True)
+            nprof = min(args.steps, 5)
+            for i in range(nprof):
+                step(args.warmup + i)
+            torch.cuda.synchronize()
+            ops.prof_enable(False)
+        fam = {}
+        for name, f in (("gemm", _lib.AF_FAM_GEMM), ("attn", _lib.AF_FAM_ATTN), ("gnorm", _lib.AF_FAM_GNORM),
+                        ("lnorm", _lib.AF_FAM_LNORM), ("elem", _lib.AF_FAM_ELEM)):
+            n, ms = ops.prof_read(f)
+            fam[name] = {"launches_per_step": n / nprof, "ms_per_step": ms / nprof}
+        ops.prof_reset()
+        g_ms = fam["gemm"]["ms_per_step"]
+        g_n = fam["gemm"]["launches_per_step"]
+        flops_step = GEMM_GFLOP_PER_SAMPLE * 1e9 * 2 * B
+        achieved = flops_step / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
+        a_ms = fam["attn"]["ms_per_step"]
+        roofline = {
+            "kernel": "af_gemm_kernel (conv3x3 implicit GEMM + linear + conv1x1)",
+            "bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+            "flops_per_launch": flops_step / g_n if g_n else None,
+            "avg_launch_ms": g_ms / g_n if g_n else None,
+            "families_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in fam.items()},
+            "families_launches_per_step": {k: v["launches_per_step"] for k, v in fam.items()},
+            "attn_tflops": round(ATTN_GFLOP_PER_SAMPLE * 1e9 * 2 * B / (a_ms * 1e-3) / 1e12, 2) if a_ms > 0 else None,
+        }
+
+    cpu_baseline = None
+    if not args.no_cpu_baseline and rank == 0 and world == 1:
+        from oracle import unet_oracle as O
+        ncores = os.cpu_count() or 1
+        torch.set_num_threads(ncores)
+        sd = {k: v.detach().float().cpu() for k, v in unet.state_dict().items()}
+        xc = rng.synth_input("full.x", (1, 4, 64, 64), seed=0)
+        cc = rng.synth_input("full.ctx", (1, 77, 768), seed=0)
+        with torch.no_grad():
+            t1 = time.perf_counter()
+            O.unet_forward(sd, SD15_UNET_CONFIG, xc, torch.tensor([500]), cc, {})
+            dt = time.perf_counter() - t1
+        cpu_baseline = {
+            "value": round(1.0 / (dt * 2 * B), 5), "unit": "denoise-steps/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"1 U-Net sample fwd (bs 1, 64x64 latent, 77 tokens, fp32) = 1/{2 * B} of a denoise step, {dt:.2f} s; "
+                      "value = 1 / (8 x that)",
+        }
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        value = world * args.steps / elapsed
+        out = {
+            "metric": "denoise-steps/sec SD-1.5 U-Net 512px bs=4/GPU",
+            "value": round(value, 3), "unit": "denoise-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16", "data": "synthetic",
+            "config": {"workload": "adaface_txt2img_ddim: SD-1.5 U-Net eps-prediction + CFG + DDIM update, 512x512 (latent 64x64), "
+                                   f"bs={B}/GPU, U-Net batch {2 * B} (cond+uncond), 77 tokens, DDIM-50 timesteps, random-init weights",
+                       "parallelism": f"replicas x{world}", "hipgraph": not args.no_graph,
+                       "unet_samples_per_s": round(value * 2 * B, 2),
+                       "step_mfma_frac": round(UNET_GFLOP_PER_SAMPLE * 1e9 * 2 * B / (ms * 1e-3) / (MFMA_PEAK_TFLOPS * 1e12), 4),
+                       "finite": finite},
+            "roofline": roofline, "cpu_baseline": cpu_baseline,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -152,6 +152,9 @@ int af_cfg_ddim_step(const void* eps2, const void* x, void* x_prev, void* pred_x
 int af_q_sample(const void* x0, const void* noise, const void* sa, const void* sb, void* xt, int B, int64_t per,
                 void* stream);
 
+/* y = x * sigmoid(x), fp16 (nn.SiLU on the time embedding, openaimodel.py:219-220) */
+int af_silu_f16(const void* x, void* y, int64_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

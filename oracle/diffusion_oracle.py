@@ -15,7 +15,7 @@ import torch
 
 def make_beta_schedule_linear(n_timestep=1000, linear_start=0.00085, linear_end=0.012):
     """ldm/modules/diffusionmodules/util.py:21-25 ("linear" = linspace of sqrt, squared), fp64."""
-    return np.linspace(linear_start ** 0.5, linear_end ** 0.5, n_timestep, dtype=np.float64) ** 2
+    return (torch.linspace(linear_start ** 0.5, linear_end ** 0.5, n_timestep, dtype=torch.float64) ** 2).numpy()
 
 
 def register_schedule(betas):
@@ -77,7 +77,7 @@ def ddim_update(x, e_t, a_t, a_prev, sigma_t=0.0):
     torch.full((b,1,1,1), table[index]) in the reference."""
     a_t = torch.tensor(a_t, dtype=torch.float32)
     a_prev = torch.tensor(a_prev, dtype=torch.float32)
-    sqrt_one_minus_at = torch.sqrt(1.0 - a_t.double()).float()   # np.sqrt(1. - ddim_alphas): fp32 in, fp32 out
+    # np.sqrt(1. - ddim_alphas) on the fp32 table (ddim.py:62): fp32 in, fp32 out
     sqrt_one_minus_at = torch.tensor(np.sqrt(np.float32(1.0) - np.float32(a_t.item())), dtype=torch.float32)
     pred_x0 = (x - sqrt_one_minus_at * e_t) / a_t.sqrt()
     dir_xt = (1.0 - a_prev - sigma_t ** 2).sqrt() * e_t

@@ -1,0 +1,282 @@
+"""Per-kernel parity on a real MI355X: every C-ABI entry point against a plain fp32 CPU
+computation of the same op on the same (fp16-rounded) inputs.  `pytest -m gpu`.
+
+Tolerances (stated per test): the kernels read fp16, accumulate in fp32 and round the result
+to fp16 once, so the expected relative L2 error against an fp32 reference on identical inputs
+is ~3e-4 (one fp16 rounding, 2^-11 = 4.9e-4 max per element); 2e-3 is used as the bound.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-3
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from adaface_dev_amd import _lib
+    _lib.lib()  # fail loudly if the HIP library is missing
+    return torch.device("cuda:0")
+
+
+def rnd(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(torch.float16)
+
+
+# ------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M,N,K,tile", [
+    (256, 128, 64, 1), (256, 128, 64, 2), (1000, 320, 320, 0), (8, 1280, 320, 0), (616, 640, 768, 2),
+    (4096, 320, 1280, 1), (130, 4, 320, 2), (512, 1280, 2560, 0),
+])
+def test_gemm_bias_residual(dev, M, N, K, tile):
+    from adaface_dev_amd import ops
+    a, w = rnd((M, K), 1), rnd((N, K), 2, K ** -0.5)
+    b, r = torch.randn(N, generator=torch.Generator().manual_seed(3)), rnd((M, N), 4)
+    pw = ops.pack_matrix(w, b, dev)
+    out = ops.gemm(a.to(dev), pw, residual=r.to(dev), tile=tile)
+    ref = a.float() @ w.float().t() + b + r.float()
+    assert rel_l2(out.float().cpu().numpy(), ref.numpy()) < TOL
+
+
+def test_gemm_concat_k_and_silu(dev):
+    from adaface_dev_amd import ops
+    M, K1, K2, N = 300, 128, 64, 192
+    a1, a2, w = rnd((M, K1), 1), rnd((M, K2), 2), rnd((N, K1 + K2), 3, 0.1)
+    b = torch.randn(N, generator=torch.Generator().manual_seed(5))
+    pw = ops.pack_matrix(w, b, dev)
+    out = ops.gemm(a1.to(dev), pw, a2=a2.to(dev), act=ops.AF_ACT_SILU)
+    ref = F.silu(torch.cat([a1, a2], 1).float() @ w.float().t() + b)
+    assert rel_l2(out.float().cpu().numpy(), ref.numpy()) < TOL
+
+
+@pytest.mark.parametrize("tile", [1, 2])
+def test_gemm_geglu(dev, tile):
+    from adaface_dev_amd import ops
+    M, C = 520, 64
+    a, w = rnd((M, C), 1), rnd((8 * C, C), 2, C ** -0.5)
+    b = torch.randn(8 * C, generator=torch.Generator().manual_seed(3)) * 0.1
+    wi, bi = ops.interleave_geglu(w.float(), b)
+    out = ops.gemm(a.to(dev), ops.pack_matrix(wi, bi, dev), act=ops.AF_ACT_GEGLU, tile=tile)
+    h = a.float() @ w.float().t() + b
+    x, g = h.chunk(2, dim=-1)
+    ref = x * F.gelu(g)
+    assert out.shape == (M, 4 * C)
+    assert rel_l2(out.float().cpu().numpy(), ref.numpy()) < TOL
+
+
+@pytest.mark.parametrize("tokens,tile", [(77, 2), (64, 1), (256, 0)])
+def test_gemm_split_transposed(dev, tokens, tile):
+    from adaface_dev_amd import ops
+    B, C, K = 3, 64, 96
+    a, w = rnd((B * tokens, K), 1), rnd((3 * C, K), 2, K ** -0.5)
+    out, out2 = ops.gemm(a.to(dev), ops.pack_matrix(w, None, dev), rows_per_batch=tokens, split_col=2 * C, tile=tile)
+    ref = a.float() @ w.float().t()
+    assert rel_l2(out.float().cpu().numpy(), ref[:, :2 * C].numpy()) < TOL
+    vt = ref[:, 2 * C:].reshape(B, tokens, C).permute(0, 2, 1)
+    assert out2.shape[:2] == (B, C) and out2.shape[2] % 8 == 0
+    assert rel_l2(out2[:, :, :tokens].float().cpu().numpy(), vt.numpy()) < TOL
+
+
+# ------------------------------------------------------------------------------- conv 3x3
+@pytest.mark.parametrize("B,H,W,c1,c2,cout,stride,ups,tile", [
+    (2, 16, 16, 64, 0, 64, 1, False, 2), (2, 16, 16, 64, 0, 128, 1, False, 1), (1, 64, 64, 8, 0, 320, 1, False, 0),
+    (2, 16, 16, 64, 0, 64, 2, False, 2), (2, 15, 17, 32, 0, 64, 2, False, 2), (2, 8, 8, 64, 0, 64, 1, True, 2),
+    (2, 8, 8, 128, 64, 64, 1, False, 2), (1, 32, 32, 320, 0, 4, 1, False, 0), (2, 8, 8, 96, 32, 128, 1, False, 1),
+])
+def test_conv3x3(dev, B, H, W, c1, c2, cout, stride, ups, tile):
+    from adaface_dev_amd import ops
+    cin = c1 + c2
+    x1 = rnd((B, H, W, c1), 1)
+    x2 = rnd((B, H, W, c2), 2) if c2 else None
+    w = rnd((cout, cin, 3, 3), 3, (9 * cin) ** -0.5)
+    bias = torch.randn(cout, generator=torch.Generator().manual_seed(4))
+    rowb = rnd((B, cout), 5)
+    pw = ops.pack_conv3x3(w, bias, dev)
+    xin = x1 if x2 is None else torch.cat([x1, x2], -1)
+    xin = xin.float().permute(0, 3, 1, 2)
+    if ups:
+        xin = F.interpolate(xin, scale_factor=2, mode="nearest")
+    ref = F.conv2d(xin, w.float(), bias, stride=stride, padding=1) + rowb.float()[:, :, None, None]
+    res = rnd(tuple(ref.permute(0, 2, 3, 1).shape), 6)
+    ref = ref + res.float().permute(0, 3, 1, 2)
+    out = ops.conv3x3(x1.to(dev), pw, x2=None if x2 is None else x2.to(dev), stride=stride, upsample=ups,
+                      rowbias=rowb.to(dev), residual=res.to(dev), tile=tile)
+    assert rel_l2(out.float().cpu().permute(0, 3, 1, 2).numpy(), ref.numpy()) < TOL
+
+
+def test_conv3x3_padded_input_channels(dev):
+    """first U-Net conv: 4 latent channels zero-padded to 8 (weights padded to match)."""
+    from adaface_dev_amd import ops
+    x = torch.randn(2, 4, 16, 16, generator=torch.Generator().manual_seed(1))
+    w = rnd((64, 4, 3, 3), 2, 1 / 6.0)
+    bias = torch.randn(64, generator=torch.Generator().manual_seed(3))
+    xh = ops.nchw_f32_to_nhwc_f16(x.to(dev), 8)
+    assert xh.shape == (2, 16, 16, 8) and float(xh[..., 4:].abs().max()) == 0.0
+    out = ops.conv3x3(xh, ops.pack_conv3x3(w, bias, dev, cin_pad=8))
+    ref = F.conv2d(x.half().float(), w.float(), bias, padding=1)
+    assert rel_l2(ops.nhwc_f16_to_nchw_f32(out).cpu().numpy(), ref.numpy()) < TOL
+
+
+# ------------------------------------------------------------------------------- norms
+@pytest.mark.parametrize("B,HW,c1,c2,eps,silu", [
+    (2, 64, 320, 0, 1e-5, True), (2, 256, 1280, 640, 1e-5, True), (1, 64, 2560, 0, 1e-5, True), (3, 100, 32, 0, 1e-6, False),
+    (2, 4096, 320, 0, 1e-6, False), (2, 64, 640, 320, 1e-5, True), (2, 49, 64, 64, 1e-5, True),
+])
+def test_groupnorm(dev, B, HW, c1, c2, eps, silu):
+    from adaface_dev_amd import ops
+    C = c1 + c2
+    x1 = (rnd((B, HW, c1), 1, 2.0).float() + 0.7).half()
+    x2 = rnd((B, HW, c2), 2, 0.5) if c2 else None
+    g = torch.randn(C, generator=torch.Generator().manual_seed(3)) * 0.2 + 1
+    b = torch.randn(C, generator=torch.Generator().manual_seed(4)) * 0.2
+    y = ops.groupnorm(x1.to(dev), g.to(dev), b.to(dev), eps, silu, x2=None if x2 is None else x2.to(dev))
+    xc = x1 if x2 is None else torch.cat([x1, x2], -1)
+    ref = F.group_norm(xc.float().permute(0, 2, 1), 32, g, b, eps)
+    ref = (F.silu(ref) if silu else ref).permute(0, 2, 1)
+    assert y.shape == (B, HW, C)
+    assert rel_l2(y.float().cpu().numpy(), ref.numpy()) < TOL
+
+
+@pytest.mark.parametrize("rows,C", [(77, 320), (1000, 640), (513, 1280), (64, 32), (10, 2048)])
+def test_layernorm(dev, rows, C):
+    from adaface_dev_amd import ops
+    x = (rnd((rows, C), 1, 3.0).float() - 1.0).half()
+    g = torch.randn(C, generator=torch.Generator().manual_seed(3)) * 0.2 + 1
+    b = torch.randn(C, generator=torch.Generator().manual_seed(4)) * 0.2
+    y = ops.layernorm(x.to(dev), g.to(dev), b.to(dev), 1e-5)
+    ref = F.layer_norm(x.float(), (C,), g, b, 1e-5)
+    assert rel_l2(y.float().cpu().numpy(), ref.numpy()) < TOL
+
+
+# ------------------------------------------------------------------------------- attention
+def _attn_ref(q, k, v, heads, mask=None):
+    from oracle.unet_oracle import attention_core
+    return attention_core(q.float(), k.float(), v.float(), heads, mask)
+
+
+@pytest.mark.parametrize("B,N,L,heads,d,masked", [
+    (2, 64, 64, 8, 8, False), (2, 256, 256, 8, 40, False), (1, 200, 77, 8, 40, False), (2, 48, 77, 2, 40, False),
+    (1, 1024, 1024, 8, 80, False), (1, 256, 256, 8, 160, False), (2, 96, 97, 4, 64, False), (2, 64, 64, 8, 16, True),
+    (1, 300, 300, 8, 40, True), (2, 128, 77, 8, 32, False), (1, 4096, 4096, 2, 40, False),
+])
+def test_attention(dev, B, N, L, heads, d, masked):
+    from adaface_dev_amd import ops
+    C = heads * d
+    q, k, v = rnd((B, N, C), 1), rnd((B, L, C), 2), rnd((B, L, C), 3)
+    mask = None
+    kb = None
+    if masked:
+        mask = torch.rand(B, L, generator=torch.Generator().manual_seed(9)) > 0.4
+        mask[0, : L // 2] = False
+        kb = ops.make_keybias(mask.to(dev), L)
+    ldv = ops.round_up(L, 8)
+    vt = torch.full((B, C, ldv), float("nan"), dtype=torch.float16)  # padding must never be read as data
+    vt[:, :, :L] = v.permute(0, 2, 1)
+    o = ops.attention(q.reshape(B * N, C).to(dev), k.reshape(B * L, C).to(dev), vt.to(dev), B=B, Nq=N, L=L, heads=heads,
+                      d=d, ldq=C, ldk=C, keybias=kb)
+    ref = _attn_ref(q, k, v, heads, mask)
+    assert rel_l2(o.float().cpu().reshape(B, N, C).numpy(), ref.numpy()) < TOL
+
+
+def test_attention_all_keys_masked_is_uniform(dev):
+    """masked_fill(-finfo.max) on every key gives a uniform softmax, not NaN (attention.py:183-194)."""
+    from adaface_dev_amd import ops
+    B, N, heads, d = 1, 64, 8, 40
+    C = heads * d
+    q, k, v = rnd((B, N, C), 1), rnd((B, N, C), 2), rnd((B, N, C), 3)
+    kb = ops.make_keybias(torch.zeros(B, N, dtype=torch.bool, device=dev), N)
+    o = ops.attention(q.reshape(N, C).to(dev), k.reshape(N, C).to(dev), v.permute(0, 2, 1).contiguous().to(dev), B=B, Nq=N,
+                      L=N, heads=heads, d=d, ldq=C, ldk=C, keybias=kb)
+    ref = v.float().mean(dim=1, keepdim=True).expand(B, N, C)
+    assert torch.isfinite(o).all()
+    assert rel_l2(o.float().cpu().reshape(B, N, C).numpy(), ref.numpy()) < TOL
+
+
+def test_attention_online_softmax_rescale_branch(dev):
+    """Force the running max to jump late (a spiked key in the last stage) -- the rescale of the
+    O accumulator must be exact (cdna guide rule 26: rare data-dependent branch needs its own test)."""
+    from adaface_dev_amd import ops
+    B, N, heads, d = 1, 128, 2, 40
+    C = heads * d
+    L = 320
+    q, k, v = rnd((B, N, C), 1), rnd((B, L, C), 2, 0.3), rnd((B, L, C), 3)
+    k[0, L - 3] = (q[0, 5] * 4).half()  # large positive score against query 5 (and others) in the final stage
+    ldv = ops.round_up(L, 8)
+    vt = torch.zeros((B, C, ldv), dtype=torch.float16)
+    vt[:, :, :L] = v.permute(0, 2, 1)
+    o = ops.attention(q.reshape(N, C).to(dev), k.reshape(L, C).to(dev), vt.to(dev), B=B, Nq=N, L=L, heads=heads, d=d, ldq=C,
+                      ldk=C)
+    ref = _attn_ref(q, k, v, heads)
+    assert rel_l2(o.float().cpu().reshape(B, N, C).numpy(), ref.numpy()) < TOL
+
+
+def test_attention_scores_capture(dev):
+    from adaface_dev_amd import ops
+    B, N, L, heads, d = 2, 100, 77, 8, 40
+    C = heads * d
+    q, k = rnd((B, N, C), 1), rnd((B, L, C), 2)
+    score, prob = ops.attention_scores(q.reshape(B * N, C).to(dev), k.reshape(B * L, C).to(dev), B=B, Nq=N, L=L, heads=heads, d=d)
+    _, attn, sc = __import__("oracle.unet_oracle", fromlist=["x"]).attention_core(q.float(), k.float(), k.float(), heads, None, True)
+    assert rel_l2(score.cpu().numpy(), sc.numpy()) < 1e-5
+    assert rel_l2(prob.cpu().numpy(), attn.numpy()) < 1e-5
+
+
+# ------------------------------------------------------------------------------- element-wise
+def test_timestep_embedding(dev, golden_dir):
+    import os
+    from adaface_dev_amd import ops
+    g = np.load(os.path.join(golden_dir, "blocks.npz"))
+    out = ops.timestep_embedding(torch.from_numpy(g["temb_t"]).to(dev), 320)
+    # fp16 output of values in [-1, 1]: absolute tolerance 1e-3 (args up to 999 rad in fp32)
+    assert np.abs(out.float().cpu().numpy() - g["temb_320"]).max() < 1.5e-3
+
+
+def test_layout_roundtrip_and_silu(dev):
+    from adaface_dev_amd import ops
+    x = torch.randn(2, 5, 7, 9, generator=torch.Generator().manual_seed(1))
+    y = ops.nchw_f32_to_nhwc_f16(x.to(dev), 8)
+    back = ops.nhwc_f16_to_nchw_f32(y, 5)
+    assert torch.equal(back.cpu(), x.half().float())
+    s = ops.silu(y)
+    assert rel_l2(s.float().cpu().numpy(), F.silu(y.float().cpu()).numpy()) < TOL
+
+
+def test_cfg_ddim_step_and_q_sample(dev):
+    from adaface_dev_amd import ops
+    from oracle import diffusion_oracle as D
+    g = torch.Generator().manual_seed(0)
+    x, ec, eu = torch.randn(4, 4, 8, 8, generator=g), torch.randn(4, 4, 8, 8, generator=g), torch.randn(4, 4, 8, 8, generator=g)
+    a_t, a_prev = 0.5215, 0.5552
+    xp, p0 = ops.cfg_ddim_step(torch.cat([ec, eu]).to(dev), x.to(dev), 4.0, a_t, a_prev, True)
+    rx, rp = D.ddim_update(x, D.cfg_combine(ec, eu, 4.0), a_t, a_prev)
+    assert rel_l2(xp.cpu().numpy(), rx.numpy()) < 1e-6 and rel_l2(p0.cpu().numpy(), rp.numpy()) < 1e-6
+    xp1, _ = ops.cfg_ddim_step(ec.to(dev), x.to(dev), 1.0, a_t, a_prev, False)
+    rx1, _ = D.ddim_update(x, ec, a_t, a_prev)
+    assert rel_l2(xp1.cpu().numpy(), rx1.numpy()) < 1e-6
+    tabs = D.register_schedule(D.make_beta_schedule_linear())
+    t = torch.tensor([0, 10, 500, 999])
+    xt = ops.q_sample(x.to(dev), ec.to(dev), torch.from_numpy(tabs["sqrt_alphas_cumprod"])[t].to(dev),
+                      torch.from_numpy(tabs["sqrt_one_minus_alphas_cumprod"])[t].to(dev))
+    assert rel_l2(xt.cpu().numpy(), D.q_sample(tabs, x, t, ec).numpy()) < 1e-6
+
+
+def test_error_reporting(dev):
+    """Bad arguments come back as RuntimeError with the library's message (never abort, never fall back)."""
+    from adaface_dev_amd import ops
+    a = rnd((16, 24), 1).to(dev)
+    pw = ops.pack_matrix(rnd((8, 24), 2), None, dev)
+    pw.N = 6  # not a multiple of 4
+    with pytest.raises(RuntimeError, match="multiple of 4"):
+        ops.gemm(a, pw)
+    with pytest.raises(RuntimeError, match="head dim"):
+        ops.attention(a, a, a.reshape(1, 24, 16), B=1, Nq=16, L=16, heads=2, d=12, ldq=24, ldk=24)
