@@ -56,6 +56,9 @@ def lib() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # torch ships its own libamdhip64; it must be the HIP runtime of this process, so load it
+    # first (the .so then binds to the already-loaded runtime instead of a second copy).
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             f"{LIB_PATH} not found: the HIP extension is required (no CPU fallback). "
