@@ -33,6 +33,8 @@ struct GemmDev {
   int H, W, Ho, Wo, HoWo, Heff, Weff, stride, upsample;
   int rows_per_batch, ld_rowbias, act_silu, ld_out, split_col, ld_out2;
   int tiles_n;
+  int splits, kt_per_split;  // split-K: blockIdx.y owns K steps [y*kt_per_split, ...)
+  float* ws;                 // fp32 partials [splits][M][N] when splits > 1
 };
 
 constexpr int BK = 64;
@@ -86,12 +88,13 @@ __global__ __launch_bounds__(256, 2) void af_gemm_kernel(GemmDev p) {
       a_iy0[i] = a_ix0[i] = 0;
     }
   }
-  int tap = 0, c = cc * 8;  // TAPS==9: (tap, channel) of this thread's chunk in the current K step
+  const int nk_total = p.kpad / BK;
+  const int kt_begin = blockIdx.y * p.kt_per_split;
+  const int kt_end = min(nk_total, kt_begin + p.kt_per_split);
+  int tap = 0, c = kt_begin * BK + cc * 8;  // TAPS==9: (tap, channel) of this thread's chunk in the current K step
   if (TAPS == 9) {
-    while (c >= Cin) {
-      c -= Cin;
-      ++tap;
-    }
+    tap = c / Cin;
+    c -= tap * Cin;
   }
 
   half8_t ra[AI], rw[WI];
@@ -188,16 +191,32 @@ __global__ __launch_bounds__(256, 2) void af_gemm_kernel(GemmDev p) {
     }
   };
 
-  const int nk = p.kpad / BK;
-  load_tile(0);
+  load_tile(kt_begin);
   store_tile(0);
   __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const bool more = kt + 1 < nk;
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    const bool more = kt + 1 < kt_end;
+    const int buf = (kt - kt_begin) & 1;
     if (more) load_tile(kt + 1);
-    compute(kt & 1);
-    if (more) store_tile((kt + 1) & 1);
+    compute(buf);
+    if (more) store_tile(buf ^ 1);
     __syncthreads();
+  }
+
+  // ---- split-K: raw fp32 partial tile to the workspace; af_splitk_reduce applies the epilogue
+  if (EPI == EPI_STD && p.splits > 1) {
+    float* wsp = p.ws + (size_t)blockIdx.y * p.M * p.N;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      const int m = tile_m * BM + wm * WM + tm * 16 + fr;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        const int n0 = tile_n * BN + wn * WN + tn * 16 + 4 * fq;
+        if (n0 < p.N) *reinterpret_cast<floatx4*>(wsp + (size_t)m * p.N + n0) = acc[tn][tm];
+      }
+    }
+    return;
   }
 
   // ---- epilogue: lane holds rows n0..n0+3 (consecutive output channels) of column m
@@ -263,14 +282,50 @@ __global__ __launch_bounds__(256, 2) void af_gemm_kernel(GemmDev p) {
   }
 }
 
+// split-K second pass: sum the fp32 partials and apply the standard epilogue (4 channels per thread)
+__global__ __launch_bounds__(256) void af_splitk_reduce_kernel(GemmDev p) {
+  const long i4 = (long)blockIdx.x * 256 + threadIdx.x;
+  const int n4 = p.N >> 2;
+  if (i4 >= (long)p.M * n4) return;
+  const int m = (int)(i4 / n4);
+  const int n0 = (int)(i4 - (long)m * n4) * 4;
+  floatx4 v = {0.f, 0.f, 0.f, 0.f};
+  for (int sp = 0; sp < p.splits; ++sp) v += *reinterpret_cast<const floatx4*>(p.ws + ((size_t)sp * p.M + m) * p.N + n0);
+  if (p.bias) v += *reinterpret_cast<const floatx4*>(p.bias + n0);
+  if (p.rowbias) {
+    const half4_t rv = *reinterpret_cast<const half4_t*>(p.rowbias + (size_t)(m / p.rows_per_batch) * p.ld_rowbias + n0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] += (float)rv[i];
+  }
+  if (p.act_silu) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = af_silu(v[i]);
+  }
+  if (p.residual) {
+    const half4_t rv = *reinterpret_cast<const half4_t*>(p.residual + (size_t)m * p.N + n0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] += (float)rv[i];
+  }
+  const half4_t h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+  *reinterpret_cast<half4_t*>(p.out + (size_t)m * p.ld_out + n0) = h;
+}
+
 template <int BM, int BN, int TAPS, int EPI>
 int launch(const GemmDev& p0, hipStream_t stream) {
   GemmDev p = p0;
   const int tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + BN - 1) / BN;
+  const int nk = p.kpad / BK;
+  if (p.splits > nk) p.splits = nk;
+  p.kt_per_split = (nk + p.splits - 1) / p.splits;
+  p.splits = (nk + p.kt_per_split - 1) / p.kt_per_split;  // no empty split
   const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(half_t);
-  dim3 grid(tiles_m * p.tiles_n), block(256);
+  dim3 grid(tiles_m * p.tiles_n, p.splits), block(256);
   hipLaunchKernelGGL((af_gemm_kernel<BM, BN, TAPS, EPI>), grid, block, lds, stream, p);
+  if (EPI == EPI_STD && p.splits > 1) {
+    const long n = (long)p.M * (p.N >> 2);
+    hipLaunchKernelGGL(af_splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, p);
+  }
   return af_check_launch("af_gemm");
 }
 
@@ -324,6 +379,9 @@ extern "C" int af_gemm(const af_gemm_desc* d, void* stream) {
   p.split_col = d->split_col;
   p.ld_out2 = d->ld_out2;
   p.tiles_n = 0;
+  p.splits = d->splits > 1 ? d->splits : 1;
+  p.kt_per_split = 0;
+  p.ws = (float*)d->workspace;
   if (d->taps == 9) {
     AF_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Ho > 0 && d->Wo > 0, "af_gemm: conv geometry missing");
     AF_REQUIRE(p.stride == 1 || p.stride == 2, "af_gemm: stride must be 1 or 2");
@@ -348,6 +406,11 @@ extern "C" int af_gemm(const af_gemm_desc* d, void* stream) {
     AF_REQUIRE(!d->residual, "af_gemm: residual unsupported with AF_OUT_SPLIT_T");
   }
   AF_REQUIRE(p.ld_out % 4 == 0, "af_gemm: ld_out must be a multiple of 4");
+  if (p.splits > 1) {
+    AF_REQUIRE(!geglu && d->out_mode == AF_OUT_NORMAL, "af_gemm: split-K only with the standard epilogue");
+    AF_REQUIRE(d->workspace != nullptr && d->workspace_bytes >= (int64_t)p.splits * d->M * d->N * 4,
+               "af_gemm: split-K needs workspace >= splits*M*N*4 bytes");
+  }
 
   int tile = d->tile;
   if (tile == 0) {

@@ -84,10 +84,62 @@ def interleave_geglu(w: torch.Tensor, b: torch.Tensor):
     return wi, bi
 
 
+# ----------------------------------------------------------------------------- launch tuning
+# (tile, splits) per GEMM shape, measured on an MI355X by tools/autotune_gemm.py and committed as
+# tuning/gfx950_gemm.json; shapes not in the table use the library's heuristic (tile 0, no split).
+import json as _json
+import os as _os
+
+_TUNE_PATH = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "tuning", "gfx950_gemm.json")
+_tune_table = None
+_tune_recorder = None      # set by tools/autotune_gemm.py: callable(key, desc, device) -> (tile, splits)
+_splitk_ws = {}
+SPLITK_WS_BYTES = 192 << 20
+
+
+def tune_table():
+    global _tune_table
+    if _tune_table is None:
+        try:
+            with open(_TUNE_PATH) as f:
+                _tune_table = {k: tuple(v) for k, v in _json.load(f).items()}
+        except FileNotFoundError:
+            _tune_table = {}
+    return _tune_table
+
+
+def _splitk_workspace(device) -> torch.Tensor:
+    ws = _splitk_ws.get(device)
+    if ws is None:
+        ws = torch.empty((SPLITK_WS_BYTES // 4,), dtype=torch.float32, device=device)
+        _splitk_ws[device] = ws
+    return ws
+
+
+def _launch_gemm(d: "GemmDesc", device, what: str, tile: int = 0, splits: int = 0):
+    """Pick (tile, splits) -- explicit args > recorder (autotune) > table > heuristic -- and launch."""
+    if tile == 0 and splits == 0:
+        key = f"{d.taps},{d.M},{d.N},{d.K},{d.act},{d.out_mode},{d.stride},{d.upsample}"
+        if _tune_recorder is not None:
+            tile, splits = _tune_recorder(key, d, device)
+        else:
+            tile, splits = tune_table().get(key, (0, 1))
+    d.tile = tile
+    d.splits = max(1, splits)
+    if d.splits > 1:
+        if d.act == AF_ACT_GEGLU or d.out_mode != AF_OUT_NORMAL:
+            d.splits = 1
+        else:
+            ws = _splitk_workspace(device)
+            d.splits = max(1, min(d.splits, (ws.numel() * 4) // (d.M * d.N * 4)))
+            d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+    _lib.check(_lib.lib().af_gemm(C.byref(d), _stream()), what)
+
+
 # ----------------------------------------------------------------------------- gemm / conv
 def gemm(a1: torch.Tensor, pw: PackedWeight, *, a2: Optional[torch.Tensor] = None, rowbias: Optional[torch.Tensor] = None,
          rows_per_batch: int = 0, residual: Optional[torch.Tensor] = None, act: int = AF_ACT_NONE,
-         split_col: int = 0, ld_out2: int = 0, tile: int = 0):
+         split_col: int = 0, ld_out2: int = 0, tile: int = 0, splits: int = 0):
     """Plain-rows GEMM: a1 [M, K1] (+ a2 [M, K2], concatenated along K) x pw.  Returns out
     ([M, N], or [M, N/2] for GEGLU), or (out [M, split_col], out2 [B, N-split_col, ld_out2])."""
     _chk_f16(a1, "gemm.a1")
@@ -105,7 +157,7 @@ def gemm(a1: torch.Tensor, pw: PackedWeight, *, a2: Optional[torch.Tensor] = Non
     d.c1, d.c2, d.lda1, d.lda2 = k1, k2, k1, k2
     d.rows_per_batch = rows_per_batch
     d.ld_rowbias = 0 if rowbias is None else rowbias.stride(0)
-    d.act, d.tile = act, tile
+    d.act = act
     out2 = None
     if split_col:
         assert rows_per_batch > 0 and M % rows_per_batch == 0
@@ -121,12 +173,13 @@ def gemm(a1: torch.Tensor, pw: PackedWeight, *, a2: Optional[torch.Tensor] = Non
         _chk_f16(residual, "gemm.residual")
         assert residual.shape == out.shape
     d.out = _p(out)
-    _lib.check(_lib.lib().af_gemm(C.byref(d), _stream()), "af_gemm")
+    _launch_gemm(d, a1.device, "af_gemm", tile, splits)
     return (out, out2) if split_col else out
 
 
 def conv3x3(x: torch.Tensor, pw: PackedWeight, *, x2: Optional[torch.Tensor] = None, stride: int = 1, upsample: bool = False,
-            rowbias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, tile: int = 0) -> torch.Tensor:
+            rowbias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, tile: int = 0,
+            splits: int = 0) -> torch.Tensor:
     """3x3 / pad 1 convolution as implicit GEMM.  x [B,H,W,C1] (+ x2 [B,H,W,C2] channel-concat)
     -> [B,Ho,Wo,Cout].  rowbias [B, >=Cout] is added per batch item (time-embedding), residual
     [B,Ho,Wo,Cout] after it."""
@@ -150,11 +203,10 @@ def conv3x3(x: torch.Tensor, pw: PackedWeight, *, x2: Optional[torch.Tensor] = N
     d.stride, d.upsample = stride, int(upsample)
     d.rows_per_batch = ho * wo
     d.ld_rowbias = 0 if rowbias is None else rowbias.stride(0)
-    d.tile = tile
     if residual is not None:
         _chk_f16(residual, "conv3x3.residual")
         assert residual.shape == out.shape
-    _lib.check(_lib.lib().af_gemm(C.byref(d), _stream()), "af_gemm(conv3x3)")
+    _launch_gemm(d, x.device, "af_gemm(conv3x3)", tile, splits)
     return out
 
 

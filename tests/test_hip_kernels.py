@@ -48,6 +48,24 @@ def test_gemm_bias_residual(dev, M, N, K, tile):
     assert rel_l2(out.float().cpu().numpy(), ref.numpy()) < TOL
 
 
+@pytest.mark.parametrize("tile,splits", [(1, 2), (2, 3), (1, 8)])
+def test_gemm_and_conv_split_k(dev, tile, splits):
+    """split-K (fp32 partials + reduce/epilogue pass) == the single-pass result."""
+    from adaface_dev_amd import ops
+    M, N, K = 512, 192, 1280
+    a, w = rnd((M, K), 1), rnd((N, K), 2, K ** -0.5)
+    b, r = torch.randn(N, generator=torch.Generator().manual_seed(3)), rnd((M, N), 4)
+    out = ops.gemm(a.to(dev), ops.pack_matrix(w, b, dev), residual=r.to(dev), act=ops.AF_ACT_NONE, tile=tile, splits=splits)
+    ref = a.float() @ w.float().t() + b + r.float()
+    assert rel_l2(out.float().cpu().numpy(), ref.numpy()) < TOL
+    B, H, W, cin, cout = 2, 8, 8, 192, 128
+    x, wc = rnd((B, H, W, cin), 5), rnd((cout, cin, 3, 3), 6, (9 * cin) ** -0.5)
+    bias, rowb = torch.randn(cout, generator=torch.Generator().manual_seed(7)), rnd((B, cout), 8)
+    oc = ops.conv3x3(x.to(dev), ops.pack_conv3x3(wc, bias, dev), rowbias=rowb.to(dev), tile=tile, splits=splits)
+    refc = F.conv2d(x.float().permute(0, 3, 1, 2), wc.float(), bias, padding=1) + rowb.float()[:, :, None, None]
+    assert rel_l2(oc.float().cpu().permute(0, 3, 1, 2).numpy(), refc.numpy()) < TOL
+
+
 def test_gemm_concat_k_and_silu(dev):
     from adaface_dev_amd import ops
     M, K1, K2, N = 300, 128, 64, 192

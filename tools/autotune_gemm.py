@@ -1,0 +1,95 @@
+#!/usr/bin/env python
+"""In-situ autotune of af_gemm's (tile, split-K) per shape on an MI355X.
+
+Runs U-Net forwards at the benchmark shapes with a recorder hooked into ops._launch_gemm: the
+first time a GEMM shape is seen, every candidate (tile in {128x128, 64x64} x split-K in
+{1,2,3,4,6,8}) is timed on the live operands with HIP events, and the fastest is written to
+adaface-dev_amd/tuning/gfx950_gemm.json.  Usage (GPU box):
+
+    python tools/autotune_gemm.py [--batches 8,2]
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batches", default="8,2")
+    ap.add_argument("--reps", type=int, default=12)
+    ap.add_argument("--out", default=None)
+    args = ap.parse_args()
+    from adaface_dev_amd import SD15_UNET_CONFIG, _lib, ops, rng
+    from adaface_dev_amd.ldm.modules.diffusionmodules.openaimodel import UNetModel
+
+    dev = torch.device("cuda:0")
+    L = _lib.lib()
+    table, log = {}, []
+
+    def timed(d, device, tile, splits):
+        d.tile, d.splits = tile, splits
+        if splits > 1:
+            ws = ops._splitk_workspace(device)
+            if splits * d.M * d.N * 4 > ws.numel() * 4:
+                return None
+            d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+        st = torch.cuda.current_stream().cuda_stream
+        for _ in range(2):
+            if L.af_gemm(C.byref(d), st) < 0:
+                return None
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.reps):
+            L.af_gemm(C.byref(d), st)
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / args.reps
+
+    def recorder(key, d, device):
+        if key in table:
+            return table[key]
+        nk = d.kpad // 64
+        best, best_t, res = (0, 1), None, {}
+        for tile in (1, 2):
+            for splits in (1, 2, 3, 4, 6, 8):
+                if splits > 1 and (d.act == _lib.AF_ACT_GEGLU or d.out_mode != 0 or nk < 4 * splits):
+                    continue
+                t = timed(d, device, tile, splits)
+                if t is None:
+                    continue
+                res[f"{tile}x{splits}"] = round(t * 1e3, 1)
+                if best_t is None or t < best_t:
+                    best, best_t = (tile, splits), t
+        table[key] = best
+        gf = 2.0 * d.M * d.N * d.K / (best_t * 1e-3) / 1e12
+        log.append((key, best, round(best_t * 1e3, 1), round(gf, 1), res))
+        return best
+
+    unet = UNetModel(**SD15_UNET_CONFIG)
+    rng.load_synth_weights(unet, seed=0)
+    unet = unet.to(dev).eval()
+    ops._tune_recorder = recorder
+    with torch.no_grad():
+        for b in [int(v) for v in args.batches.split(",")]:
+            x = rng.synth_input("bench.x", (b, 4, 64, 64), seed=1).to(dev)
+            ctx = rng.synth_input("bench.ctx", (b, 77, 768), seed=1).to(dev)
+            unet(x, torch.full((b,), 500, device=dev), ctx, extra_info=None)
+            torch.cuda.synchronize()
+    ops._tune_recorder = None
+    out = args.out or ops._TUNE_PATH
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    with open(out, "w") as f:
+        json.dump({k: list(v) for k, v in sorted(table.items())}, f, indent=0)
+    for row in log:
+        print(row)
+    print(f"wrote {len(table)} entries to {out}")
+
+
+if __name__ == "__main__":
+    main()
