@@ -21,7 +21,9 @@ EXPORTS = (
     "af_last_error", "af_version", "af_device_count", "af_prof_enable", "af_prof_reset", "af_prof_read",
     "af_gemm", "af_groupnorm_ws_floats", "af_groupnorm", "af_layernorm", "af_attention", "af_attention_scores",
     "af_timestep_embedding", "af_nchw_f32_to_nhwc_f16", "af_nhwc_f16_to_nchw_f32", "af_cfg_ddim_step", "af_q_sample",
-    "af_silu_f16",
+    "af_silu_f16", "af_attention_lse", "af_groupnorm_stats", "af_attention_bwd_scratch_bytes", "af_attention_bwd",
+    "af_groupnorm_bwd", "af_layernorm_bwd", "af_geglu_fwd", "af_geglu_bwd", "af_sumpool2x2", "af_add_f16",
+    "af_transpose_tokens", "af_cadamw_step",
 )
 
 
@@ -86,9 +88,22 @@ def lib() -> C.CDLL:
     L.af_cfg_ddim_step.argtypes = [vp, vp, vp, vp, i64, i32, f32, f32, f32, vp]
     L.af_q_sample.argtypes = [vp, vp, vp, vp, vp, i32, i64, vp]
     L.af_silu_f16.argtypes = [vp, vp, i64, vp]
+    L.af_attention_lse.argtypes = [vp, vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp]
+    L.af_groupnorm_stats.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp, vp]
+    L.af_attention_bwd_scratch_bytes.argtypes = [i32, i32, i32, i32, i32]
+    L.af_attention_bwd.argtypes = [vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, i64] + [i32] * 14 + [f32, vp]
+    L.af_groupnorm_bwd.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]
+    L.af_layernorm_bwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, f32, vp]
+    L.af_geglu_fwd.argtypes = [vp, vp, i64, i32, vp]
+    L.af_geglu_bwd.argtypes = [vp, vp, vp, i64, i32, vp]
+    L.af_sumpool2x2.argtypes = [vp, vp, i32, i32, i32, i32, vp]
+    L.af_add_f16.argtypes = [vp, vp, vp, i64, vp]
+    L.af_transpose_tokens.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
+    L.af_cadamw_step.argtypes = [vp, vp, vp, vp, vp, i32, vp, f32, f32, f32, f32, f32, i32, i32, vp]
     for name in EXPORTS:
         if name != "af_last_error":
             getattr(L, name).restype = C.c_int
+    L.af_attention_bwd_scratch_bytes.restype = C.c_int64
     _lib = L
     return L
 

@@ -34,6 +34,8 @@ struct AttnArgs {
   const half_t* vt;
   half_t* o;
   const float* kbias;
+  float* lse2;
+  int ld_lse;
   int B, Nq, L, heads, d;
   int ldq, ldk, ldo, ldv, ldb;
   float c;  // scale * log2(e)
@@ -234,6 +236,7 @@ __global__ __launch_bounds__(256) void af_attn_kernel(AttnArgs a) {
   // ---- normalise and store: lane holds d rows {32t + 8g + 4hh + e} of its query
   l += __shfl_xor(l, 32, 64);
   const float inv = 1.0f / l;
+  if (a.lse2 && query < a.Nq && hh == 0) a.lse2[((size_t)b * a.heads + h) * a.ld_lse + query] = m + __builtin_amdgcn_logf(l);
   if (query < a.Nq) {
     half_t* op = a.o + ((size_t)b * a.Nq + query) * a.ldo + h * a.d;
 #pragma unroll
@@ -313,9 +316,9 @@ __global__ __launch_bounds__(256) void af_scores_kernel(const half_t* __restrict
 
 }  // namespace
 
-extern "C" int af_attention(const void* q, const void* k, const void* vt, void* o, const void* keybias, int B, int Nq,
-                            int L, int heads, int d, int ldq, int ldk, int ldo, int ldv, int ldb, float scale,
-                            void* stream) {
+extern "C" int af_attention_lse(const void* q, const void* k, const void* vt, void* o, void* lse2, int ld_lse,
+                                const void* keybias, int B, int Nq, int L, int heads, int d, int ldq, int ldk, int ldo,
+                                int ldv, int ldb, float scale, void* stream) {
   AF_REQUIRE(q && k && vt && o, "af_attention: null pointer");
   AF_REQUIRE(B > 0 && Nq > 0 && L > 0 && heads > 0 && d > 0, "af_attention: bad sizes");
   AF_REQUIRE(d % 8 == 0, "af_attention: head dim must be a multiple of 8");
@@ -332,6 +335,9 @@ extern "C" int af_attention(const void* q, const void* k, const void* vt, void* 
   a.vt = (const half_t*)vt;
   a.o = (half_t*)o;
   a.kbias = (const float*)keybias;
+  a.lse2 = (float*)lse2;
+  a.ld_lse = ld_lse;
+  if (lse2) AF_REQUIRE(ld_lse >= Nq, "af_attention: ld_lse < Nq");
   a.B = B;
   a.Nq = Nq;
   a.L = L;
@@ -357,6 +363,12 @@ extern "C" int af_attention(const void* q, const void* k, const void* vt, void* 
     case 10: return launch_attn<10>(a, s);
     default: return af_fail(AF_E_UNSUPPORTED, "af_attention: unsupported head dim (need ceil(d/16) in {1,2,3,4,5,6,8,10})");
   }
+}
+
+extern "C" int af_attention(const void* q, const void* k, const void* vt, void* o, const void* keybias, int B, int Nq,
+                            int L, int heads, int d, int ldq, int ldk, int ldo, int ldv, int ldb, float scale,
+                            void* stream) {
+  return af_attention_lse(q, k, vt, o, nullptr, 0, keybias, B, Nq, L, heads, d, ldq, ldk, ldo, ldv, ldb, scale, stream);
 }
 
 extern "C" int af_attention_scores(const void* q, const void* k, void* score, void* prob, int B, int Nq, int L, int heads,

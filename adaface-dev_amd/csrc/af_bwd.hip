@@ -1,0 +1,549 @@
+// af_bwd.hip -- backward-pass kernels that are not matmul-shaped (those reuse af_gemm with
+// transposed / flipped packed weights): GroupNorm(+SiLU) / LayerNorm / GEGLU input gradients,
+// the adjoint of nearest-x2 upsampling, token<->channel-major transposes for the attention
+// backward, gradient accumulation, and the fused cautious-AdamW step.
+//
+// The U-Net base weights are frozen in the reference (ddpm.py:4131-4132), so the backward is
+// activation-gradient only: no gamma/beta/weight gradients are produced here.
+#include "af_common.h"
+
+namespace {
+
+constexpr int GB_NBLK = 32;
+constexpr int GB_MAXG = 32;
+
+struct GnBwdArgs {
+  const half_t* x1;
+  const half_t* x2;
+  int c1, c2, C, CP;
+  const float* gamma;
+  const float* beta;
+  const float* stats;  // [B][groups][2] (mean, rstd) from the forward
+  const half_t* dy;    // [B][HW][C]
+  const half_t* add;   // optional [B][HW][C], added to dx
+  half_t* dx1;         // [B][HW][c1]
+  half_t* dx2;         // [B][HW][c2] (c2 > 0)
+  int B, HW, groups, cpg, silu;
+  float* ws;  // [B][GB_NBLK][GB_MAXG][2]
+  int ppb;
+};
+
+__device__ __forceinline__ half8_t gb_load(const GnBwdArgs& a, int b, int pix, int c0) {
+  const size_t row = (size_t)b * a.HW + pix;
+  if (c0 < a.c1) return *reinterpret_cast<const half8_t*>(a.x1 + row * a.c1 + c0);
+  return *reinterpret_cast<const half8_t*>(a.x2 + row * a.c2 + (c0 - a.c1));
+}
+
+// d/du [u * sigmoid(u)]
+__device__ __forceinline__ float silu_grad(float u) {
+  const float s = 1.0f / (1.0f + __expf(-u));
+  return s * (1.0f + u * (1.0f - s));
+}
+
+// per-thread constants for its 8 channels: xhat = x*ka + kb ; u = xhat*gamma + beta
+struct ChanConst {
+  float ka[8], kb[8], g[8], bt[8];
+};
+
+template <int CT>
+__device__ __forceinline__ void gb_consts(const GnBwdArgs& a, int b, int chunk0, ChanConst (&cc)[CT]) {
+#pragma unroll
+  for (int j = 0; j < CT; ++j) {
+    const int ch = chunk0 + 256 * j;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = min(ch * 8 + e, a.C - 1);
+      const int g = c / a.cpg;
+      const float mean = a.stats[((size_t)b * a.groups + g) * 2 + 0];
+      const float rstd = a.stats[((size_t)b * a.groups + g) * 2 + 1];
+      cc[j].ka[e] = rstd;
+      cc[j].kb[e] = -mean * rstd;
+      cc[j].g[e] = a.gamma[c];
+      cc[j].bt[e] = a.beta[c];
+    }
+  }
+}
+
+// pass 1: partial sums per group of  g = dy*act'(u)*gamma  and  g*xhat
+template <int CT>
+__global__ __launch_bounds__(256) void gn_bwd_partial_kernel(GnBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char af_smem[];
+  float* red = reinterpret_cast<float*>(af_smem);
+  const int t = threadIdx.x, b = blockIdx.y, blk = blockIdx.x;
+  const int slots = CT == 1 ? a.ppb : 1;
+  const int slot = CT == 1 ? t / a.CP : 0;
+  const int chunk0 = CT == 1 ? t - slot * a.CP : t;
+  const bool active = CT == 1 ? (slot < slots) : true;
+  const int per = (a.HW + GB_NBLK - 1) / GB_NBLK;
+  const int p0 = blk * per, p1 = min(a.HW, p0 + per);
+  ChanConst cc[CT];
+  gb_consts<CT>(a, b, chunk0, cc);
+  float s1[CT][8], s2[CT][8];
+#pragma unroll
+  for (int j = 0; j < CT; ++j)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s1[j][e] = s2[j][e] = 0.f;
+  if (active) {
+    for (int pix = p0 + slot; pix < p1; pix += slots) {
+#pragma unroll
+      for (int j = 0; j < CT; ++j) {
+        const int ch = chunk0 + 256 * j;
+        if (ch < a.CP) {
+          const half8_t xv = gb_load(a, b, pix, ch * 8);
+          const half8_t dv = *reinterpret_cast<const half8_t*>(a.dy + ((size_t)b * a.HW + pix) * a.C + ch * 8);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float xh = (float)xv[e] * cc[j].ka[e] + cc[j].kb[e];
+            float g = (float)dv[e] * cc[j].g[e];
+            if (a.silu) g *= silu_grad(xh * cc[j].g[e] + cc[j].bt[e]);
+            s1[j][e] += g;
+            s2[j][e] += g * xh;
+          }
+        }
+      }
+    }
+  }
+  float* r1 = red;
+  float* r2 = red + slots * a.C;
+  if (active) {
+#pragma unroll
+    for (int j = 0; j < CT; ++j) {
+      const int ch = chunk0 + 256 * j;
+      if (ch < a.CP) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          r1[slot * a.C + ch * 8 + e] = s1[j][e];
+          r2[slot * a.C + ch * 8 + e] = s2[j][e];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int c = t; c < a.C; c += 256) {
+    float u = 0.f, v = 0.f;
+    for (int sl = 0; sl < slots; ++sl) {
+      u += r1[sl * a.C + c];
+      v += r2[sl * a.C + c];
+    }
+    r1[c] = u;
+    r2[c] = v;
+  }
+  __syncthreads();
+  if (t < a.groups) {
+    float u = 0.f, v = 0.f;
+    for (int c = t * a.cpg; c < (t + 1) * a.cpg; ++c) {
+      u += r1[c];
+      v += r2[c];
+    }
+    float* w = a.ws + (((size_t)b * GB_NBLK + blk) * GB_MAXG + t) * 2;
+    w[0] = u;
+    w[1] = v;
+  }
+}
+
+// pass 2: dx = rstd * (g - mean(g) - xhat * mean(g*xhat)) + add
+template <int CT>
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GnBwdArgs a) {
+  __shared__ float mm[GB_MAXG][2];
+  const int t = threadIdx.x, b = blockIdx.y;
+  if (t < a.groups) {
+    float u = 0.f, v = 0.f;
+    for (int k = 0; k < GB_NBLK; ++k) {
+      const float* w = a.ws + (((size_t)b * GB_NBLK + k) * GB_MAXG + t) * 2;
+      u += w[0];
+      v += w[1];
+    }
+    const float inv_n = 1.0f / ((float)a.HW * (float)a.cpg);
+    mm[t][0] = u * inv_n;
+    mm[t][1] = v * inv_n;
+  }
+  __syncthreads();
+  const int slots = CT == 1 ? a.ppb : 1;
+  const int slot = CT == 1 ? t / a.CP : 0;
+  const int chunk0 = CT == 1 ? t - slot * a.CP : t;
+  if (CT == 1 && slot >= slots) return;
+  ChanConst cc[CT];
+  gb_consts<CT>(a, b, chunk0, cc);
+  float m1[CT][8], m2[CT][8];
+#pragma unroll
+  for (int j = 0; j < CT; ++j) {
+    const int ch = chunk0 + 256 * j;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int g = min(ch * 8 + e, a.C - 1) / a.cpg;
+      m1[j][e] = mm[g][0];
+      m2[j][e] = mm[g][1];
+    }
+  }
+  const int per = (a.HW + gridDim.x - 1) / gridDim.x;
+  const int p0 = blockIdx.x * per, p1 = min(a.HW, p0 + per);
+  for (int pix = p0 + slot; pix < p1; pix += slots) {
+#pragma unroll
+    for (int j = 0; j < CT; ++j) {
+      const int ch = chunk0 + 256 * j;
+      if (ch < a.CP) {
+        const size_t row = (size_t)b * a.HW + pix;
+        const half8_t xv = gb_load(a, b, pix, ch * 8);
+        const half8_t dv = *reinterpret_cast<const half8_t*>(a.dy + row * a.C + ch * 8);
+        half8_t av = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (a.add) av = *reinterpret_cast<const half8_t*>(a.add + row * a.C + ch * 8);
+        half8_t o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float xh = (float)xv[e] * cc[j].ka[e] + cc[j].kb[e];
+          float g = (float)dv[e] * cc[j].g[e];
+          if (a.silu) g *= silu_grad(xh * cc[j].g[e] + cc[j].bt[e]);
+          o[e] = (half_t)(cc[j].ka[e] * (g - m1[j][e] - xh * m2[j][e]) + (float)av[e]);
+        }
+        const int c0 = ch * 8;
+        if (c0 < a.c1)
+          *reinterpret_cast<half8_t*>(a.dx1 + row * a.c1 + c0) = o;
+        else
+          *reinterpret_cast<half8_t*>(a.dx2 + row * a.c2 + (c0 - a.c1)) = o;
+      }
+    }
+  }
+}
+
+// LayerNorm input gradient, one wave per row
+template <int CT>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const half_t* __restrict__ x, const float* __restrict__ gamma,
+                                                            const half_t* __restrict__ dy, const half_t* __restrict__ add,
+                                                            half_t* __restrict__ dx, int rows, int C, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int CP = C >> 3;
+  const size_t off = (size_t)row * C;
+  half8_t xv[CT], dv[CT];
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < CT; ++j) {
+    const int ch = lane + 64 * j;
+    if (ch < CP) {
+      xv[j] = *reinterpret_cast<const half8_t*>(x + off + ch * 8);
+      dv[j] = *reinterpret_cast<const half8_t*>(dy + off + ch * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += (float)xv[j][e];
+    }
+  }
+  const float mean = af_wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < CT; ++j)
+    if (lane + 64 * j < CP) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float d = (float)xv[j][e] - mean;
+        q += d * d;
+      }
+    }
+  const float rstd = rsqrtf(af_wave_sum(q) / (float)C + eps);
+  float g[CT][8], xh[CT][8];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int j = 0; j < CT; ++j) {
+    const int ch = lane + 64 * j;
+    if (ch < CP) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        xh[j][e] = ((float)xv[j][e] - mean) * rstd;
+        g[j][e] = (float)dv[j][e] * gamma[ch * 8 + e];
+        s1 += g[j][e];
+        s2 += g[j][e] * xh[j][e];
+      }
+    }
+  }
+  const float m1 = af_wave_sum(s1) / (float)C, m2 = af_wave_sum(s2) / (float)C;
+#pragma unroll
+  for (int j = 0; j < CT; ++j) {
+    const int ch = lane + 64 * j;
+    if (ch < CP) {
+      half8_t av = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (add) av = *reinterpret_cast<const half8_t*>(add + off + ch * 8);
+      half8_t o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (half_t)(rstd * (g[j][e] - m1 - xh[j][e] * m2) + (float)av[e]);
+      *reinterpret_cast<half8_t*>(dx + off + ch * 8) = o;
+    }
+  }
+}
+
+// GEGLU on the interleaved pre-activation hp [M][2I]: 32-column groups [16 value | 16 gate]
+__global__ __launch_bounds__(256) void geglu_fwd_kernel(const half_t* __restrict__ hp, half_t* __restrict__ out, long M, int I) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;  // one thread per 8 output channels
+  const int per_row = I >> 3;
+  if (idx >= M * per_row) return;
+  const long m = idx / per_row;
+  const int c0 = (int)(idx - m * per_row) * 8;             // output channel of element 0
+  const int col = (c0 >> 4) * 32 + (c0 & 15);             // its value column in hp
+  const half8_t xv = *reinterpret_cast<const half8_t*>(hp + m * 2 * I + col);
+  const half8_t gv = *reinterpret_cast<const half8_t*>(hp + m * 2 * I + col + 16);
+  half8_t o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)xv[e] * af_gelu_erf((float)gv[e]));
+  *reinterpret_cast<half8_t*>(out + m * I + c0) = o;
+}
+
+__global__ __launch_bounds__(256) void geglu_bwd_kernel(const half_t* __restrict__ hp, const half_t* __restrict__ dout,
+                                                        half_t* __restrict__ dhp, long M, int I) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const int per_row = I >> 3;
+  if (idx >= M * per_row) return;
+  const long m = idx / per_row;
+  const int c0 = (int)(idx - m * per_row) * 8;
+  const int col = (c0 >> 4) * 32 + (c0 & 15);
+  const half8_t xv = *reinterpret_cast<const half8_t*>(hp + m * 2 * I + col);
+  const half8_t gv = *reinterpret_cast<const half8_t*>(hp + m * 2 * I + col + 16);
+  const half8_t dv = *reinterpret_cast<const half8_t*>(dout + m * I + c0);
+  half8_t dxv, dgv;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float g = (float)gv[e], d = (float)dv[e];
+    const float cdf = 0.5f * (1.0f + erff(g * 0.70710678118654752f));
+    const float pdf = 0.3989422804014327f * __expf(-0.5f * g * g);
+    dxv[e] = (half_t)(d * g * cdf);                        // d/dvalue = gelu(gate)
+    dgv[e] = (half_t)(d * (float)xv[e] * (cdf + g * pdf)); // d/dgate  = value * gelu'(gate)
+  }
+  *reinterpret_cast<half8_t*>(dhp + m * 2 * I + col) = dxv;
+  *reinterpret_cast<half8_t*>(dhp + m * 2 * I + col + 16) = dgv;
+}
+
+// adjoint of nearest x2 upsampling: y[b,h,w,:] = sum of the 2x2 block of x[b,2h..,2w..,:]
+__global__ __launch_bounds__(256) void sumpool2x2_kernel(const half_t* __restrict__ x, half_t* __restrict__ y, int B, int H,
+                                                         int W, int C) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const int cp = C >> 3;
+  if (idx >= (long)B * H * W * cp) return;
+  const int ch = (int)(idx % cp);
+  const long pix = idx / cp;
+  const int w = (int)(pix % W);
+  const int h = (int)((pix / W) % H);
+  const int b = (int)(pix / ((long)W * H));
+  const half_t* base = x + (((size_t)b * 2 * H + 2 * h) * 2 * W + 2 * w) * C + ch * 8;
+  const half8_t v00 = *reinterpret_cast<const half8_t*>(base);
+  const half8_t v01 = *reinterpret_cast<const half8_t*>(base + C);
+  const half8_t v10 = *reinterpret_cast<const half8_t*>(base + (size_t)2 * W * C);
+  const half8_t v11 = *reinterpret_cast<const half8_t*>(base + (size_t)2 * W * C + C);
+  half8_t o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)v00[e] + (float)v01[e] + (float)v10[e] + (float)v11[e]);
+  *reinterpret_cast<half8_t*>(y + pix * C + ch * 8) = o;
+}
+
+__global__ __launch_bounds__(256) void add_f16_kernel(const half_t* __restrict__ a, const half_t* __restrict__ b,
+                                                      half_t* __restrict__ out, long n8) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n8) return;
+  const half8_t x = *reinterpret_cast<const half8_t*>(a + i * 8), y = *reinterpret_cast<const half8_t*>(b + i * 8);
+  half8_t o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)x[e] + (float)y[e]);
+  *reinterpret_cast<half8_t*>(out + i * 8) = o;
+}
+
+// x [B][N][ldx] (C columns) -> y [B][C][ldy] (token index contiguous), 64x64 LDS tiles
+__global__ __launch_bounds__(256) void transpose_tokens_kernel(const half_t* __restrict__ x, half_t* __restrict__ y, int N, int C,
+                                                               int ldx, int ldy) {
+  __shared__ half_t tile[64][66];
+  const int b = blockIdx.z, n0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
+  for (int r = ty; r < 64; r += 4) {
+    const int n = n0 + r, c = c0 + tx;
+    tile[r][tx] = (n < N && c < C) ? x[((size_t)b * N + n) * ldx + c] : (half_t)0;
+  }
+  __syncthreads();
+  for (int r = ty; r < 64; r += 4) {
+    const int c = c0 + r, n = n0 + tx;
+    if (c < C && n < ldy) y[((size_t)b * C + c) * ldy + n] = n < N ? tile[tx][r] : (half_t)0;
+  }
+}
+
+// ---- cautious AdamW (ldm/c_adamw.py:65-123) over a flat fp32 parameter buffer with per-tensor segments
+struct AdamArgs {
+  float* p;
+  const float* g;
+  float* m;
+  float* v;
+  const long* seg_off;  // [nseg + 1]
+  unsigned int* counts;  // [nseg] number of elements with m*g > 0
+  float lr, beta1, beta2, eps, wd, step_size;
+};
+
+__global__ __launch_bounds__(256) void cadamw_moments_kernel(AdamArgs a) {
+  const int seg = blockIdx.y;
+  const long lo = a.seg_off[seg], hi = a.seg_off[seg + 1];
+  unsigned int cnt = 0;
+  for (long i = lo + (long)blockIdx.x * 256 + threadIdx.x; i < hi; i += (long)gridDim.x * 256) {
+    const float g = a.g[i];
+    const float m = a.m[i] * a.beta1 + g * (1.0f - a.beta1);
+    const float v = a.v[i] * a.beta2 + g * g * (1.0f - a.beta2);
+    a.m[i] = m;
+    a.v[i] = v;
+    cnt += (m * g > 0.f) ? 1u : 0u;
+  }
+  // integer count: deterministic regardless of arrival order
+  for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+  if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(a.counts + seg, cnt);
+}
+
+__global__ __launch_bounds__(256) void cadamw_update_kernel(AdamArgs a) {
+  const int seg = blockIdx.y;
+  const long lo = a.seg_off[seg], hi = a.seg_off[seg + 1];
+  const float mean = fmaxf((float)a.counts[seg] / (float)(hi - lo), 1e-3f);  // mask.mean().clamp_(min=1e-3)
+  const float inv_mean = 1.0f / mean;
+  for (long i = lo + (long)blockIdx.x * 256 + threadIdx.x; i < hi; i += (long)gridDim.x * 256) {
+    float p = a.p[i];
+    if (a.wd > 0.f) p += p * (-a.lr * a.wd);
+    const float g = a.g[i], m = a.m[i];
+    const float mask = (m * g > 0.f) ? inv_mean : 0.f;
+    const float denom = sqrtf(a.v[i]) + a.eps;
+    a.p[i] = p - a.step_size * (m * mask) / denom;
+  }
+}
+
+inline dim3 g1(long n) { return dim3((unsigned)((n + 255) / 256)); }
+
+}  // namespace
+
+extern "C" int af_groupnorm_bwd(const void* x1, const void* x2, int c1, int c2, const void* gamma, const void* beta,
+                                const void* stats, const void* dy, const void* add, void* dx1, void* dx2, int B, int HW,
+                                int groups, int silu, void* workspace, void* stream) {
+  AF_REQUIRE(x1 && gamma && beta && stats && dy && dx1 && workspace, "af_groupnorm_bwd: null pointer");
+  AF_REQUIRE(B > 0 && HW > 0 && c1 > 0 && c2 >= 0 && c1 % 8 == 0 && c2 % 8 == 0, "af_groupnorm_bwd: bad sizes");
+  AF_REQUIRE(c2 == 0 || (x2 && dx2), "af_groupnorm_bwd: x2/dx2 required when c2 > 0");
+  const int C = c1 + c2;
+  AF_REQUIRE(groups > 0 && groups <= GB_MAXG && C % groups == 0, "af_groupnorm_bwd: groups must divide C and be <= 32");
+  AF_SUPPORTED(C <= 4096, "af_groupnorm_bwd: C > 4096");
+  GnBwdArgs a;
+  a.x1 = (const half_t*)x1;
+  a.x2 = (const half_t*)x2;
+  a.c1 = c1;
+  a.c2 = c2;
+  a.C = C;
+  a.CP = C / 8;
+  a.gamma = (const float*)gamma;
+  a.beta = (const float*)beta;
+  a.stats = (const float*)stats;
+  a.dy = (const half_t*)dy;
+  a.add = (const half_t*)add;
+  a.dx1 = (half_t*)dx1;
+  a.dx2 = (half_t*)dx2;
+  a.B = B;
+  a.HW = HW;
+  a.groups = groups;
+  a.cpg = C / groups;
+  a.silu = silu;
+  a.ws = (float*)workspace;
+  const int ct = (a.CP + 255) / 256;
+  a.ppb = ct == 1 ? 256 / a.CP : 1;
+  const int slots = ct == 1 ? a.ppb : 1;
+  const size_t lds = (size_t)2 * slots * C * sizeof(float);
+  hipStream_t s = (hipStream_t)stream;
+  AfLaunchScope scope(AF_FAM_GNORM, stream);
+  dim3 gp(GB_NBLK, B), blk(256);
+  int nb2 = (HW + slots - 1) / slots;
+  nb2 = nb2 > 64 ? 64 : nb2;
+  dim3 ga(nb2, B);
+  if (ct == 1) {
+    hipLaunchKernelGGL(gn_bwd_partial_kernel<1>, gp, blk, lds, s, a);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel<1>, ga, blk, 0, s, a);
+  } else {
+    hipLaunchKernelGGL(gn_bwd_partial_kernel<2>, gp, blk, lds, s, a);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel<2>, ga, blk, 0, s, a);
+  }
+  return af_check_launch("af_groupnorm_bwd");
+}
+
+extern "C" int af_layernorm_bwd(const void* x, const void* gamma, const void* dy, const void* add, void* dx, int rows, int C,
+                                float eps, void* stream) {
+  AF_REQUIRE(x && gamma && dy && dx, "af_layernorm_bwd: null pointer");
+  AF_REQUIRE(rows > 0 && C > 0 && C % 8 == 0, "af_layernorm_bwd: C must be a positive multiple of 8");
+  AF_SUPPORTED(C <= 1536, "af_layernorm_bwd: C > 1536");
+  const int ct = (C / 8 + 63) / 64;
+  dim3 grid((rows + 3) / 4), blk(256);
+  hipStream_t s = (hipStream_t)stream;
+  AfLaunchScope scope(AF_FAM_LNORM, stream);
+  const half_t* xx = (const half_t*)x;
+  const float* g = (const float*)gamma;
+  const half_t* d = (const half_t*)dy;
+  const half_t* ad = (const half_t*)add;
+  half_t* o = (half_t*)dx;
+  switch (ct) {
+    case 1: hipLaunchKernelGGL(layernorm_bwd_kernel<1>, grid, blk, 0, s, xx, g, d, ad, o, rows, C, eps); break;
+    case 2: hipLaunchKernelGGL(layernorm_bwd_kernel<2>, grid, blk, 0, s, xx, g, d, ad, o, rows, C, eps); break;
+    default: hipLaunchKernelGGL(layernorm_bwd_kernel<3>, grid, blk, 0, s, xx, g, d, ad, o, rows, C, eps); break;
+  }
+  return af_check_launch("af_layernorm_bwd");
+}
+
+extern "C" int af_geglu_fwd(const void* hp, void* out, int64_t M, int inner, void* stream) {
+  AF_REQUIRE(hp && out && M > 0 && inner > 0 && inner % 16 == 0, "af_geglu_fwd: inner must be a positive multiple of 16");
+  AfLaunchScope scope(AF_FAM_ELEM, stream);
+  hipLaunchKernelGGL(geglu_fwd_kernel, g1((long)M * (inner / 8)), dim3(256), 0, (hipStream_t)stream, (const half_t*)hp,
+                     (half_t*)out, (long)M, inner);
+  return af_check_launch("af_geglu_fwd");
+}
+
+extern "C" int af_geglu_bwd(const void* hp, const void* dout, void* dhp, int64_t M, int inner, void* stream) {
+  AF_REQUIRE(hp && dout && dhp && M > 0 && inner > 0 && inner % 16 == 0, "af_geglu_bwd: inner must be a positive multiple of 16");
+  AfLaunchScope scope(AF_FAM_ELEM, stream);
+  hipLaunchKernelGGL(geglu_bwd_kernel, g1((long)M * (inner / 8)), dim3(256), 0, (hipStream_t)stream, (const half_t*)hp,
+                     (const half_t*)dout, (half_t*)dhp, (long)M, inner);
+  return af_check_launch("af_geglu_bwd");
+}
+
+extern "C" int af_sumpool2x2(const void* x, void* y, int B, int H, int W, int C, void* stream) {
+  AF_REQUIRE(x && y && B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "af_sumpool2x2: bad argument");
+  AfLaunchScope scope(AF_FAM_ELEM, stream);
+  hipLaunchKernelGGL(sumpool2x2_kernel, g1((long)B * H * W * (C / 8)), dim3(256), 0, (hipStream_t)stream, (const half_t*)x,
+                     (half_t*)y, B, H, W, C);
+  return af_check_launch("af_sumpool2x2");
+}
+
+extern "C" int af_add_f16(const void* a, const void* b, void* out, int64_t n, void* stream) {
+  AF_REQUIRE(a && b && out && n > 0 && n % 8 == 0, "af_add_f16: n must be a positive multiple of 8");
+  AfLaunchScope scope(AF_FAM_ELEM, stream);
+  hipLaunchKernelGGL(add_f16_kernel, g1(n / 8), dim3(256), 0, (hipStream_t)stream, (const half_t*)a, (const half_t*)b,
+                     (half_t*)out, (long)(n / 8));
+  return af_check_launch("af_add_f16");
+}
+
+extern "C" int af_transpose_tokens(const void* x, void* y, int B, int N, int C, int ldx, int ldy, void* stream) {
+  AF_REQUIRE(x && y && B > 0 && N > 0 && C > 0 && ldx >= C && ldy >= N, "af_transpose_tokens: bad argument");
+  AfLaunchScope scope(AF_FAM_ELEM, stream);
+  dim3 grid((ldy + 63) / 64, (C + 63) / 64, B);
+  hipLaunchKernelGGL(transpose_tokens_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const half_t*)x, (half_t*)y, N, C,
+                     ldx, ldy);
+  return af_check_launch("af_transpose_tokens");
+}
+
+extern "C" int af_cadamw_step(void* p, const void* g, void* m, void* v, const void* seg_offsets, int nseg, void* counts,
+                              float lr, float beta1, float beta2, float eps, float weight_decay, int step, int correct_bias,
+                              void* stream) {
+  AF_REQUIRE(p && g && m && v && seg_offsets && counts && nseg > 0 && step > 0, "af_cadamw_step: bad argument");
+  AF_REQUIRE(nseg <= 65535, "af_cadamw_step: too many segments");
+  AdamArgs a;
+  a.p = (float*)p;
+  a.g = (const float*)g;
+  a.m = (float*)m;
+  a.v = (float*)v;
+  a.seg_off = (const long*)seg_offsets;
+  a.counts = (unsigned int*)counts;
+  a.lr = lr;
+  a.beta1 = beta1;
+  a.beta2 = beta2;
+  a.eps = eps;
+  a.wd = weight_decay;
+  double ss = lr;
+  if (correct_bias) ss = ss * sqrt(1.0 - pow((double)beta2, step)) / (1.0 - pow((double)beta1, step));
+  a.step_size = (float)ss;
+  hipStream_t s = (hipStream_t)stream;
+  AfLaunchScope scope(AF_FAM_ELEM, stream);
+  hipError_t e = hipMemsetAsync(counts, 0, sizeof(unsigned int) * nseg, s);
+  if (e != hipSuccess) return af_fail(AF_E_HIP, std::string("hipMemsetAsync: ") + hipGetErrorString(e));
+  dim3 grid(64, nseg), blk(256);
+  hipLaunchKernelGGL(cadamw_moments_kernel, grid, blk, 0, s, a);
+  hipLaunchKernelGGL(cadamw_update_kernel, grid, blk, 0, s, a);
+  return af_check_launch("af_cadamw_step");
+}

@@ -121,7 +121,8 @@ __global__ __launch_bounds__(256, 2) void af_gemm_kernel(GemmDev p) {
 #pragma unroll
       for (int i = 0; i < AI; ++i) {
         const int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
-        const bool ok = kval && (unsigned)iy < (unsigned)p.Heff && (unsigned)ix < (unsigned)p.Weff;
+        bool ok = kval && (unsigned)iy < (unsigned)p.Heff && (unsigned)ix < (unsigned)p.Weff;
+        if (p.upsample == 2) ok = ok && !((iy | ix) & 1);  // zero-insertion: only even positions carry data
         const int sy = p.upsample ? (iy >> 1) : iy, sx = p.upsample ? (ix >> 1) : ix;
         const size_t off = ((size_t)(a_base[i] + sy * p.W + sx)) * cs + coff;
         ra[i] = ok ? *reinterpret_cast<const half8_t*>(src + off) : zero8;
@@ -365,7 +366,7 @@ extern "C" int af_gemm(const af_gemm_desc* d, void* stream) {
   p.lda1 = d->lda1 ? d->lda1 : d->c1;
   p.lda2 = d->lda2 ? d->lda2 : d->c2;
   p.stride = d->stride ? d->stride : 1;
-  p.upsample = d->upsample ? 1 : 0;
+  p.upsample = d->upsample;
   p.H = d->H;
   p.W = d->W;
   p.Ho = d->Ho;
@@ -373,6 +374,10 @@ extern "C" int af_gemm(const af_gemm_desc* d, void* stream) {
   p.HoWo = d->Ho * d->Wo;
   p.Heff = p.upsample ? 2 * d->H : d->H;
   p.Weff = p.upsample ? 2 * d->W : d->W;
+  if (p.upsample == 2 && d->taps == 9) {  // zero-inserted image may be declared one short (odd forward input size)
+    p.Heff = d->Ho;
+    p.Weff = d->Wo;
+  }
   p.rows_per_batch = d->rows_per_batch > 0 ? d->rows_per_batch : d->M;
   p.ld_rowbias = d->ld_rowbias;
   p.act_silu = d->act == AF_ACT_SILU;
@@ -385,8 +390,12 @@ extern "C" int af_gemm(const af_gemm_desc* d, void* stream) {
   if (d->taps == 9) {
     AF_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Ho > 0 && d->Wo > 0, "af_gemm: conv geometry missing");
     AF_REQUIRE(p.stride == 1 || p.stride == 2, "af_gemm: stride must be 1 or 2");
+    AF_REQUIRE(p.upsample >= 0 && p.upsample <= 2, "af_gemm: upsample must be 0, 1 (nearest) or 2 (zero-insert)");
     AF_REQUIRE(!(p.upsample && p.stride != 1), "af_gemm: upsample requires stride 1");
     AF_REQUIRE(d->M == d->B * d->Ho * d->Wo, "af_gemm: M != B*Ho*Wo");
+    if (p.upsample == 2)
+      AF_REQUIRE((d->Ho == 2 * d->H || d->Ho == 2 * d->H - 1) && (d->Wo == 2 * d->W || d->Wo == 2 * d->W - 1),
+                 "af_gemm: zero-insert mode needs Ho in {2H, 2H-1}, Wo in {2W, 2W-1}");
     AF_REQUIRE(d->Ho == (p.Heff + 2 - 3) / p.stride + 1 && d->Wo == (p.Weff + 2 - 3) / p.stride + 1,
                "af_gemm: Ho/Wo inconsistent with H/W/stride/upsample");
   }

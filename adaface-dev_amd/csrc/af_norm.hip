@@ -29,6 +29,7 @@ struct GnArgs {
   float eps;
   int silu;
   float* ws;  // [B][GN_NBLK][GN_MAXG][2]
+  float* stats;  // optional out [B][groups][2] = (mean, rstd)
   int ppb;    // pixel slots per iteration (CT == 1)
 };
 
@@ -130,6 +131,10 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnArgs a) {
     const float var = fmaxf(qq * inv_n - mean * mean, 0.f);
     mr[t][0] = mean;
     mr[t][1] = rsqrtf(var + a.eps);
+    if (a.stats && blockIdx.x == 0) {
+      a.stats[((size_t)b * a.groups + t) * 2 + 0] = mean;
+      a.stats[((size_t)b * a.groups + t) * 2 + 1] = mr[t][1];
+    }
   }
   __syncthreads();
   const int slots = CT == 1 ? a.ppb : 1;
@@ -232,6 +237,12 @@ extern "C" int af_groupnorm_ws_floats(int B) { return B > 0 ? B * GN_NBLK * GN_M
 
 extern "C" int af_groupnorm(const void* x1, const void* x2, int c1, int c2, const void* gamma, const void* beta, void* y,
                             int B, int HW, int groups, float eps, int silu, void* workspace, void* stream) {
+  return af_groupnorm_stats(x1, x2, c1, c2, gamma, beta, y, nullptr, B, HW, groups, eps, silu, workspace, stream);
+}
+
+extern "C" int af_groupnorm_stats(const void* x1, const void* x2, int c1, int c2, const void* gamma, const void* beta,
+                                  void* y, void* stats, int B, int HW, int groups, float eps, int silu, void* workspace,
+                                  void* stream) {
   AF_REQUIRE(x1 && gamma && beta && y && workspace, "af_groupnorm: null pointer");
   AF_REQUIRE(B > 0 && HW > 0 && c1 > 0 && c2 >= 0, "af_groupnorm: bad sizes");
   AF_REQUIRE(c1 % 8 == 0 && c2 % 8 == 0, "af_groupnorm: c1/c2 must be multiples of 8");
@@ -256,6 +267,7 @@ extern "C" int af_groupnorm(const void* x1, const void* x2, int c1, int c2, cons
   a.eps = eps;
   a.silu = silu;
   a.ws = (float*)workspace;
+  a.stats = (float*)stats;
   const int ct = (a.CP + 255) / 256;
   a.ppb = ct == 1 ? 256 / a.CP : 1;
   const int slots = ct == 1 ? a.ppb : 1;

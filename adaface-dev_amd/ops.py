@@ -179,7 +179,7 @@ def gemm(a1: torch.Tensor, pw: PackedWeight, *, a2: Optional[torch.Tensor] = Non
 
 def conv3x3(x: torch.Tensor, pw: PackedWeight, *, x2: Optional[torch.Tensor] = None, stride: int = 1, upsample: bool = False,
             rowbias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, tile: int = 0,
-            splits: int = 0) -> torch.Tensor:
+            splits: int = 0, out_hw=None) -> torch.Tensor:
     """3x3 / pad 1 convolution as implicit GEMM.  x [B,H,W,C1] (+ x2 [B,H,W,C2] channel-concat)
     -> [B,Ho,Wo,Cout].  rowbias [B, >=Cout] is added per batch item (time-embedding), residual
     [B,Ho,Wo,Cout] after it."""
@@ -193,6 +193,9 @@ def conv3x3(x: torch.Tensor, pw: PackedWeight, *, x2: Optional[torch.Tensor] = N
     assert pw.taps == 9 and pw.cin == c1 + c2, f"conv3x3: channel mismatch {c1}+{c2} vs {pw.cin}"
     he, we = (2 * H, 2 * W) if upsample else (H, W)
     ho, wo = (he + 2 - 3) // stride + 1, (we + 2 - 3) // stride + 1
+    if int(upsample) == 2:      # zero-inserted image (stride-2 dgrad): output size = forward input size
+        ho, wo = out_hw if out_hw is not None else (2 * H, 2 * W)
+        assert ho in (2 * H, 2 * H - 1) and wo in (2 * W, 2 * W - 1)
     out = torch.empty((B, ho, wo, pw.N), dtype=F16, device=x.device)
     d = GemmDesc()
     d.a1, d.a2, d.wt, d.bias = _p(x), _p(x2), _p(pw.wt), _p(pw.bias)
@@ -252,16 +255,41 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
 
 # ----------------------------------------------------------------------------- attention
 def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, *, B: int, Nq: int, L: int, heads: int, d: int,
-              ldq: int, ldk: int, keybias: Optional[torch.Tensor] = None, scale: Optional[float] = None) -> torch.Tensor:
-    """q [B*Nq, ldq-wide rows], k [B*L, ldk-wide rows], vt [B, heads*d, ldv] -> o [B*Nq, heads*d]."""
+              ldq: int, ldk: int, keybias: Optional[torch.Tensor] = None, scale: Optional[float] = None,
+              want_lse: bool = False):
+    """q [B*Nq, ldq-wide rows], k [B*L, ldk-wide rows], vt [B, heads*d, ldv] -> o [B*Nq, heads*d]
+    (and, with want_lse, the base-2 log-sum-exp fp32 [B, heads, roundup(Nq,32)] for the backward)."""
     Cn = heads * d
     o = torch.empty((B * Nq, Cn), dtype=F16, device=q.device)
     scale = d ** -0.5 if scale is None else scale
     ldb = 0 if keybias is None else keybias.stride(0)
-    rc = _lib.lib().af_attention(_p(q), _p(k), _p(vt), _p(o), _p(keybias), B, Nq, L, heads, d, ldq, ldk, Cn, vt.stride(1),
-                                 ldb, float(scale), _stream())
+    lse = torch.empty((B, heads, round_up(Nq, 32)), dtype=torch.float32, device=q.device) if want_lse else None
+    rc = _lib.lib().af_attention_lse(_p(q), _p(k), _p(vt), _p(o), _p(lse), 0 if lse is None else lse.stride(1), _p(keybias),
+                                     B, Nq, L, heads, d, ldq, ldk, Cn, vt.stride(1), ldb, float(scale), _stream())
     _lib.check(rc, "af_attention")
-    return o
+    return (o, lse) if want_lse else o
+
+
+_attn_scratch = {}
+
+
+def attention_bwd(q, k, v, o, dout, lse, *, B: int, Nq: int, L: int, heads: int, d: int, ldq: int, ldk: int, ldv: int,
+                  dq: torch.Tensor, dk: torch.Tensor, dv: torch.Tensor, lddq: int, lddk: int, lddv: int,
+                  keybias: Optional[torch.Tensor] = None, scale: Optional[float] = None):
+    """Input gradients of `attention`.  q/k/v: row-major token tensors (views allowed: row strides ldq/ldk/ldv);
+    o, dout [B*Nq, heads*d] contiguous; dq/dk/dv are written in place with row strides lddq/lddk/lddv."""
+    Cn = heads * d
+    scale = d ** -0.5 if scale is None else scale
+    need = _lib.lib().af_attention_bwd_scratch_bytes(B, Nq, L, heads, d)
+    sc = _attn_scratch.get(q.device)
+    if sc is None or sc.numel() < need:
+        sc = torch.empty((max(need, 64 << 20),), dtype=torch.uint8, device=q.device)
+        _attn_scratch[q.device] = sc
+    ldb = 0 if keybias is None else keybias.stride(0)
+    rc = _lib.lib().af_attention_bwd(_p(q), _p(k), _p(v), _p(o), _p(dout), _p(lse), lse.stride(1), _p(keybias), _p(dq), _p(dk),
+                                     _p(dv), _p(sc), sc.numel(), B, Nq, L, heads, d, ldq, ldk, ldv, Cn, Cn, lddq, lddk, lddv,
+                                     ldb, float(scale), _stream())
+    _lib.check(rc, "af_attention_bwd")
 
 
 def attention_scores(q: torch.Tensor, k: torch.Tensor, *, B: int, Nq: int, L: int, heads: int, d: int,
@@ -339,6 +367,90 @@ def q_sample(x0: torch.Tensor, noise: torch.Tensor, sa: torch.Tensor, sb: torch.
     xt = torch.empty_like(x0)
     _lib.check(_lib.lib().af_q_sample(_p(x0), _p(noise), _p(sa), _p(sb), _p(xt), B, x0.numel() // B, _stream()), "af_q_sample")
     return xt
+
+
+# ----------------------------------------------------------------------------- backward ops
+def groupnorm_train(x, gamma, beta, eps, silu, *, x2=None, groups=32):
+    """groupnorm() that also returns the (mean, rstd) statistics fp32 [B, groups, 2] for the backward."""
+    _chk_f16(x, "groupnorm.x")
+    B, c1 = x.shape[0], x.shape[-1]
+    hw = x.numel() // (B * c1)
+    c2 = 0 if x2 is None else x2.shape[-1]
+    y = torch.empty(tuple(x.shape[:-1]) + (c1 + c2,), dtype=F16, device=x.device)
+    stats = torch.empty((B, groups, 2), dtype=torch.float32, device=x.device)
+    rc = _lib.lib().af_groupnorm_stats(_p(x), _p(x2), c1, c2, _p(gamma), _p(beta), _p(y), _p(stats), B, hw, groups, float(eps),
+                                       int(silu), _p(_gn_workspace(x.device, B)), _stream())
+    _lib.check(rc, "af_groupnorm_stats")
+    return y, stats
+
+
+def groupnorm_bwd(x, gamma, beta, stats, dy, silu, *, x2=None, add=None, groups=32):
+    """Input gradient of groupnorm(+SiLU): returns dx (or (dx1, dx2) when x2 is given)."""
+    B, c1 = x.shape[0], x.shape[-1]
+    hw = x.numel() // (B * c1)
+    c2 = 0 if x2 is None else x2.shape[-1]
+    _chk_f16(dy, "groupnorm_bwd.dy")
+    dx1 = torch.empty_like(x)
+    dx2 = None if x2 is None else torch.empty_like(x2)
+    rc = _lib.lib().af_groupnorm_bwd(_p(x), _p(x2), c1, c2, _p(gamma), _p(beta), _p(stats), _p(dy), _p(add), _p(dx1), _p(dx2), B,
+                                     hw, groups, int(silu), _p(_gn_workspace(x.device, B)), _stream())
+    _lib.check(rc, "af_groupnorm_bwd")
+    return dx1 if x2 is None else (dx1, dx2)
+
+
+def layernorm_bwd(x, gamma, dy, eps=1e-5, add=None):
+    dx = torch.empty_like(x)
+    Cn = x.shape[-1]
+    _lib.check(_lib.lib().af_layernorm_bwd(_p(x), _p(gamma), _p(dy), _p(add), _p(dx), x.numel() // Cn, Cn, float(eps), _stream()),
+               "af_layernorm_bwd")
+    return dx
+
+
+def geglu_fwd(hp):
+    M, two_i = hp.shape
+    out = torch.empty((M, two_i // 2), dtype=F16, device=hp.device)
+    _lib.check(_lib.lib().af_geglu_fwd(_p(hp), _p(out), M, two_i // 2, _stream()), "af_geglu_fwd")
+    return out
+
+
+def geglu_bwd(hp, dout):
+    dhp = torch.empty_like(hp)
+    _lib.check(_lib.lib().af_geglu_bwd(_p(hp), _p(dout), _p(dhp), hp.shape[0], hp.shape[1] // 2, _stream()), "af_geglu_bwd")
+    return dhp
+
+
+def sumpool2x2(x):
+    B, H2, W2, Cn = x.shape
+    y = torch.empty((B, H2 // 2, W2 // 2, Cn), dtype=F16, device=x.device)
+    _lib.check(_lib.lib().af_sumpool2x2(_p(x), _p(y), B, H2 // 2, W2 // 2, Cn, _stream()), "af_sumpool2x2")
+    return y
+
+
+def add(a, b):
+    _chk_f16(a, "add.a")
+    _chk_f16(b, "add.b")
+    assert a.shape == b.shape
+    out = torch.empty_like(a)
+    _lib.check(_lib.lib().af_add_f16(_p(a), _p(b), _p(out), a.numel(), _stream()), "af_add_f16")
+    return out
+
+
+def transpose_tokens(x, B, N, Cn, ldx):
+    """x: rows of a [B*N, ldx] token tensor (Cn columns from x's first column) -> [B, Cn, roundup(N, 8)]."""
+    ldy = round_up(N, 8)
+    y = torch.empty((B, Cn, ldy), dtype=F16, device=x.device)
+    _lib.check(_lib.lib().af_transpose_tokens(_p(x), _p(y), B, N, Cn, ldx, ldy, _stream()), "af_transpose_tokens")
+    return y
+
+
+def cadamw_step(p, g, m, v, seg_offsets, counts, *, lr, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.0, step=1, correct_bias=True):
+    """Fused cautious-AdamW step (c_adamw.py:65-123) on flat fp32 buffers; seg_offsets int64 [nseg+1] on the device."""
+    for t in (p, g, m, v):
+        assert t.dtype == torch.float32 and t.is_contiguous()
+    rc = _lib.lib().af_cadamw_step(_p(p), _p(g), _p(m), _p(v), _p(seg_offsets), seg_offsets.numel() - 1, _p(counts), float(lr),
+                                   float(betas[0]), float(betas[1]), float(eps), float(weight_decay), int(step), int(correct_bias),
+                                   _stream())
+    _lib.check(rc, "af_cadamw_step")
 
 
 # ----------------------------------------------------------------------------- profiling hook

@@ -61,7 +61,9 @@ int af_prof_read(int family, int* launches, double* total_ms);
  *   taps == 9 : 3x3, pad 1, implicit im2col over an NHWC image [B, H, W, c1 (+c2)]:
  *               k = tap*(c1+c2) + c ; stride 1|2 (Downsample, openaimodel.py:150-161);
  *               upsample=1 reads the nearest-x2 upsampled image without materialising it
- *               (Upsample, openaimodel.py:117-119).  M = B*Ho*Wo.
+ *               (Upsample, openaimodel.py:117-119); upsample=2 reads the ZERO-INSERTED x2 image of size
+ *               Ho x Wo (data at even positions): with flipped/transposed weights this is the input
+ *               gradient of the stride-2 convolution.  M = B*Ho*Wo.
  * Epilogue (fp32): + bias[n] ; + rowbias[(m / rows_per_batch)*ld_rowbias + n] (ResBlock time
  *   embedding add, openaimodel.py:265-274) ; act ; + residual[m*N + n] ; -> fp16.
  *   act: AF_ACT_NONE | AF_ACT_SILU | AF_ACT_GEGLU (Wt rows interleaved [16 x | 16 gate],
@@ -92,7 +94,7 @@ typedef struct af_gemm_desc {
   int32_t B, H, W;      /* taps==9 input image (before upsample) */
   int32_t Ho, Wo;       /* taps==9 output image */
   int32_t stride;       /* 1 | 2 */
-  int32_t upsample;     /* 0 | 1 */
+  int32_t upsample;     /* 0 | 1 (nearest x2) | 2 (zero-insert x2) */
   int32_t rows_per_batch;
   int32_t ld_rowbias;
   int32_t act;
@@ -119,6 +121,11 @@ int af_groupnorm(const void* x1, const void* x2, int c1, int c2, const void* gam
                  void* y, int B, int HW, int groups, float eps, int silu, void* workspace, void* stream);
 
 /* ---- LayerNorm over the last dim (nn.LayerNorm, attention.py:232-234; eps 1e-5) ------- */
+/* same, and also writes stats fp32 [B, groups, 2] = (mean, rstd) for af_groupnorm_bwd */
+int af_groupnorm_stats(const void* x1, const void* x2, int c1, int c2, const void* gamma, const void* beta,
+                       void* y, void* stats, int B, int HW, int groups, float eps, int silu, void* workspace,
+                       void* stream);
+
 int af_layernorm(const void* x, const void* gamma, const void* beta, void* y, int rows, int C, float eps,
                  void* stream);
 
@@ -134,6 +141,23 @@ int af_layernorm(const void* x, const void* gamma, const void* beta, void* y, in
  *   always excluded.  d % 8 == 0, d <= 160.                                                */
 int af_attention(const void* q, const void* k, const void* vt, void* o, const void* keybias, int B, int Nq,
                  int L, int heads, int d, int ldq, int ldk, int ldo, int ldv, int ldb, float scale, void* stream);
+/* same, and also writes lse2 fp32 [B, heads, Nq] = log2(sum_j exp(score_ij)) (base-2 log-sum-exp of the
+ * scaled+biased scores), which af_attention_bwd consumes. */
+int af_attention_lse(const void* q, const void* k, const void* vt, void* o, void* lse2, int ld_lse, const void* keybias,
+                     int B, int Nq, int L, int heads, int d, int ldq, int ldk, int ldo, int ldv, int ldb, float scale,
+                     void* stream);
+
+/* ---- attention backward (flash-style, recomputes P from q, k and lse2) -------------------
+ * Input gradients of af_attention for dO = `dout`: dq [B,Nq,lddq], dk [B,L,lddk], dv [B,L,lddv].
+ * q/k/v/o/dout are ROW-major token tensors (v is NOT transposed here) with row strides ld*;
+ * lse2 fp32 [B, heads, ld_lse] from af_attention_lse, ld_lse >= roundup(Nq, 32), % 4 == 0.
+ * scratch: >= af_attention_bwd_scratch_bytes(...) bytes (Q^T, K^T, dO^T copies and delta).
+ * Reference: autograd of attention.py:180-204 (the reference stores the full score tensor).   */
+int64_t af_attention_bwd_scratch_bytes(int B, int Nq, int L, int heads, int d);
+int af_attention_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const void* lse2,
+                     int ld_lse, const void* keybias, void* dq, void* dk, void* dv, void* scratch,
+                     int64_t scratch_bytes, int B, int Nq, int L, int heads, int d, int ldq, int ldk, int ldv,
+                     int ldo, int lddo, int lddq, int lddk, int lddv, int ldb, float scale, void* stream);
 
 /* explicit score / probability capture for one cross-attention layer (attention.py:207-220):
  * score[b,h,i,j] = q.k*scale, prob = softmax_j(score); fp32 outputs [B,heads,Nq,L].         */
@@ -158,6 +182,28 @@ int af_q_sample(const void* x0, const void* noise, const void* sa, const void* s
 
 /* y = x * sigmoid(x), fp16 (nn.SiLU on the time embedding, openaimodel.py:219-220) */
 int af_silu_f16(const void* x, void* y, int64_t n, void* stream);
+
+/* ---- backward-pass kernels (activation gradients only: U-Net base weights are frozen, ddpm.py:4131) ----
+ * GroupNorm(+SiLU) input gradient; x = concat(x1, x2) as in the forward, stats from af_groupnorm_stats,
+ * dy/add [B,HW,c1+c2] (add optional, summed into dx), dx written to dx1 [B,HW,c1] / dx2 [B,HW,c2].      */
+int af_groupnorm_bwd(const void* x1, const void* x2, int c1, int c2, const void* gamma, const void* beta,
+                     const void* stats, const void* dy, const void* add, void* dx1, void* dx2, int B, int HW,
+                     int groups, int silu, void* workspace, void* stream);
+/* LayerNorm input gradient (+ optional `add`) */
+int af_layernorm_bwd(const void* x, const void* gamma, const void* dy, const void* add, void* dx, int rows, int C,
+                     float eps, void* stream);
+/* un-fused GEGLU on the interleaved pre-activation hp [M, 2*inner] (training keeps hp): forward and input gradient */
+int af_geglu_fwd(const void* hp, void* out, int64_t M, int inner, void* stream);
+int af_geglu_bwd(const void* hp, const void* dout, void* dhp, int64_t M, int inner, void* stream);
+/* adjoint of nearest-x2 upsampling: y [B,H,W,C] = 2x2 block sums of x [B,2H,2W,C] */
+int af_sumpool2x2(const void* x, void* y, int B, int H, int W, int C, void* stream);
+int af_add_f16(const void* a, const void* b, void* out, int64_t n, void* stream);
+/* x [B,N,ldx] (C columns) -> y [B,C,ldy] with the token index contiguous (zero padded to ldy) */
+int af_transpose_tokens(const void* x, void* y, int B, int N, int C, int ldx, int ldy, void* stream);
+/* cautious AdamW (ldm/c_adamw.py:65-123) over a flat fp32 buffer; seg_offsets int64 [nseg+1] delimit the
+ * parameter tensors (the caution mask is renormalised per tensor); counts: uint32 [nseg] scratch.          */
+int af_cadamw_step(void* p, const void* g, void* m, void* v, const void* seg_offsets, int nseg, void* counts, float lr,
+                   float beta1, float beta2, float eps, float weight_decay, int step, int correct_bias, void* stream);
 
 #ifdef __cplusplus
 }

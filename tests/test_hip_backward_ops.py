@@ -1,0 +1,176 @@
+"""Backward kernels on a real MI355X against torch autograd (fp32, CPU) of the same op on the same
+fp16-rounded inputs.  `pytest -m gpu`.  Gradients are rounded to fp16 once on output: bound 3e-3 rel-L2
+(attention backward: 5e-3 -- P and dz are rounded to fp16 before the second MFMA product)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+TOL = 3e-3
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from adaface_dev_amd import _lib
+    _lib.lib()
+    return torch.device("cuda:0")
+
+
+def rnd(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(torch.float16)
+
+
+@pytest.mark.parametrize("B,HW,c1,c2,silu,with_add", [(2, 64, 320, 0, True, True), (2, 100, 640, 320, True, False),
+                                                        (1, 64, 2560, 0, True, True), (2, 256, 64, 0, False, True),
+                                                        (2, 49, 64, 64, True, True)])
+def test_groupnorm_bwd(dev, B, HW, c1, c2, silu, with_add):
+    from adaface_dev_amd import ops
+    C = c1 + c2
+    x1 = (rnd((B, HW, c1), 1, 2.0).float() + 0.5).half()
+    x2 = rnd((B, HW, c2), 2) if c2 else None
+    g = torch.randn(C, generator=torch.Generator().manual_seed(3)) * 0.2 + 1
+    b = torch.randn(C, generator=torch.Generator().manual_seed(4)) * 0.2
+    dy, add = rnd((B, HW, C), 5), (rnd((B, HW, C), 6) if with_add else None)
+    y, stats = ops.groupnorm_train(x1.to(dev), g.to(dev), b.to(dev), 1e-5, silu, x2=None if x2 is None else x2.to(dev))
+    res = ops.groupnorm_bwd(x1.to(dev), g.to(dev), b.to(dev), stats, dy.to(dev), silu, x2=None if x2 is None else x2.to(dev),
+                            add=None if add is None else add.to(dev))
+    xc = (x1 if x2 is None else torch.cat([x1, x2], -1)).float().requires_grad_(True)
+    ref = F.group_norm(xc.permute(0, 2, 1), 32, g, b, 1e-5)
+    ref = (F.silu(ref) if silu else ref).permute(0, 2, 1)
+    assert rel_l2(y.float().cpu().numpy(), ref.detach().numpy()) < TOL
+    ref.backward(dy.float())
+    gx = xc.grad + (add.float() if add is not None else 0)
+    got = res if x2 is None else torch.cat([res[0], res[1]], -1)
+    assert rel_l2(got.float().cpu().numpy(), gx.numpy()) < TOL
+
+
+@pytest.mark.parametrize("rows,C", [(77, 320), (300, 640), (130, 1280), (64, 64)])
+def test_layernorm_bwd(dev, rows, C):
+    from adaface_dev_amd import ops
+    x = (rnd((rows, C), 1, 2.0).float() - 0.3).half()
+    g = torch.randn(C, generator=torch.Generator().manual_seed(3)) * 0.2 + 1
+    b = torch.zeros(C)
+    dy, add = rnd((rows, C), 5), rnd((rows, C), 6)
+    dx = ops.layernorm_bwd(x.to(dev), g.to(dev), dy.to(dev), 1e-5, add=add.to(dev))
+    xr = x.float().requires_grad_(True)
+    F.layer_norm(xr, (C,), g, b, 1e-5).backward(dy.float())
+    assert rel_l2(dx.float().cpu().numpy(), (xr.grad + add.float()).numpy()) < TOL
+
+
+def test_geglu_fwd_bwd(dev):
+    from adaface_dev_amd import ops
+    M, I = 200, 128
+    h = rnd((M, 2 * I), 1)           # natural layout [value | gate]
+    dout = rnd((M, I), 2)
+    hv, hg = h[:, :I].reshape(M, I // 16, 16), h[:, I:].reshape(M, I // 16, 16)
+    hp = torch.stack([hv, hg], dim=2).reshape(M, 2 * I).contiguous()      # interleaved 16-col groups
+    out = ops.geglu_fwd(hp.to(dev))
+    dhp = ops.geglu_bwd(hp.to(dev), dout.to(dev))
+    hr = h.float().requires_grad_(True)
+    xv, gv = hr.chunk(2, dim=-1)
+    ref = xv * F.gelu(gv)
+    ref.backward(dout.float())
+    assert rel_l2(out.float().cpu().numpy(), ref.detach().numpy()) < TOL
+    dh = dhp.float().cpu().reshape(M, I // 16, 2, 16)
+    got = torch.cat([dh[:, :, 0].reshape(M, I), dh[:, :, 1].reshape(M, I)], -1)
+    assert rel_l2(got.numpy(), hr.grad.numpy()) < TOL
+
+
+def test_sumpool_add_transpose(dev):
+    from adaface_dev_amd import ops
+    x = rnd((2, 8, 6, 16), 1)
+    y = ops.sumpool2x2(x.to(dev))
+    ref = F.avg_pool2d(x.float().permute(0, 3, 1, 2), 2) * 4
+    assert rel_l2(y.float().cpu().permute(0, 3, 1, 2).numpy(), ref.numpy()) < TOL
+    a, b = rnd((3, 40), 2), rnd((3, 40), 3)
+    assert torch.equal(ops.add(a.to(dev), b.to(dev)).cpu(), (a.float() + b.float()).half())
+    t = rnd((2 * 77, 96), 4)
+    tt = ops.transpose_tokens(t.to(dev)[:, 32:], 2, 77, 64, 96)
+    assert tt.shape == (2, 64, 80)
+    assert torch.equal(tt[:, :, :77].cpu(), t[:, 32:].reshape(2, 77, 64).permute(0, 2, 1))
+    assert float(tt[:, :, 77:].abs().max()) == 0
+
+
+def test_conv_dgrad_via_transposed_weights(dev):
+    """conv3x3 input gradient = conv3x3 with spatially flipped, in/out-transposed weights (stride 1);
+    stride-2 forward: the same over the zero-inserted output gradient (upsample mode 2)."""
+    from adaface_dev_amd import ops
+    B, H, W, cin, cout = 2, 8, 8, 64, 128
+    x = rnd((B, H, W, cin), 1)
+    w = rnd((cout, cin, 3, 3), 2, (9 * cin) ** -0.5)
+    wd = w.flip(2, 3).permute(1, 0, 2, 3).contiguous()                       # [cin, cout, 3, 3]
+    for stride in (1, 2):
+        xr = x.float().permute(0, 3, 1, 2).requires_grad_(True)
+        yr = F.conv2d(xr, w.float(), None, stride=stride, padding=1)
+        dy = rnd(tuple(yr.permute(0, 2, 3, 1).shape), 3)
+        yr.backward(dy.float().permute(0, 3, 1, 2))
+        pw = ops.pack_conv3x3(wd, None, dev)
+        if stride == 1:
+            dx = ops.conv3x3(dy.to(dev), pw)
+        else:
+            dx = ops.conv3x3(dy.to(dev), pw, upsample=2, out_hw=(H, W))
+        assert rel_l2(dx.float().cpu().permute(0, 3, 1, 2).numpy(), xr.grad.numpy()) < TOL
+
+
+@pytest.mark.parametrize("B,N,L,heads,d,masked", [(2, 64, 64, 8, 8, False), (1, 200, 77, 8, 40, False), (2, 160, 160, 4, 40, True),
+                                                   (1, 256, 256, 2, 80, False), (1, 96, 96, 2, 160, False), (2, 70, 97, 4, 64, False),
+                                                   (1, 1024, 1024, 2, 40, False)])
+def test_attention_bwd(dev, B, N, L, heads, d, masked):
+    from adaface_dev_amd import ops
+    from oracle.unet_oracle import attention_core
+    C = heads * d
+    q, k, v, do = rnd((B, N, C), 1), rnd((B, L, C), 2), rnd((B, L, C), 3), rnd((B, N, C), 4)
+    mask, kb = None, None
+    if masked:
+        mask = torch.rand(B, L, generator=torch.Generator().manual_seed(9)) > 0.3
+        kb = ops.make_keybias(mask.to(dev), L)
+    qd, kd, vd = q.reshape(B * N, C).to(dev), k.reshape(B * L, C).to(dev), v.reshape(B * L, C).to(dev)
+    vt = ops.transpose_tokens(vd, B, L, C, C)
+    o, lse = ops.attention(qd, kd, vt, B=B, Nq=N, L=L, heads=heads, d=d, ldq=C, ldk=C, keybias=kb, want_lse=True)
+    dq, dk, dv = torch.empty_like(qd), torch.empty_like(kd), torch.empty_like(vd)
+    ops.attention_bwd(qd, kd, vd, o, do.reshape(B * N, C).to(dev), lse, B=B, Nq=N, L=L, heads=heads, d=d, ldq=C, ldk=C, ldv=C,
+                      dq=dq, dk=dk, dv=dv, lddq=C, lddk=C, lddv=C, keybias=kb)
+    qr, kr, vr = q.float().requires_grad_(True), k.float().requires_grad_(True), v.float().requires_grad_(True)
+    ref = attention_core(qr, kr, vr, heads, mask)
+    ref.backward(do.float())
+    assert rel_l2(o.float().cpu().reshape(B, N, C).numpy(), ref.detach().numpy()) < TOL
+    for name, got, want in (("dq", dq, qr.grad), ("dk", dk, kr.grad), ("dv", dv, vr.grad)):
+        err = rel_l2(got.float().cpu().reshape(want.shape).numpy(), want.numpy())
+        assert err < 5e-3, (name, err)
+
+
+def test_cadamw_step_matches_reference_trace(dev):
+    """3 steps of the fused kernel == a plain restatement of c_adamw.py:65-123 (two tensors, wd on)."""
+    from adaface_dev_amd import ops
+    torch.manual_seed(0)
+    shapes = [(37, 5), (130,)]
+    ps = [torch.randn(s) for s in shapes]
+    sizes = [p.numel() for p in ps]
+    off = torch.tensor([0, sizes[0], sizes[0] + sizes[1]], dtype=torch.int64)
+    flat = torch.cat([p.reshape(-1) for p in ps]).to(dev)
+    m, v = torch.zeros_like(flat), torch.zeros_like(flat)
+    counts = torch.zeros(2, dtype=torch.int32, device=dev)
+    rp = [p.clone() for p in ps]
+    rm, rv = [torch.zeros_like(p) for p in ps], [torch.zeros_like(p) for p in ps]
+    lr, b1, b2, eps, wd = 1e-2, 0.9, 0.995, 1e-6, 0.02
+    for step in range(1, 4):
+        gs = [torch.randn(s) for s in shapes]
+        gflat = torch.cat([g.reshape(-1) for g in gs]).to(dev)
+        ops.cadamw_step(flat, gflat, m, v, off.to(dev), counts, lr=lr, betas=(b1, b2), eps=eps, weight_decay=wd, step=step)
+        for p, g, em, ev in zip(rp, gs, rm, rv):
+            p.add_(p, alpha=-lr * wd)
+            em.mul_(b1).add_(g, alpha=1 - b1)
+            ev.mul_(b2).addcmul_(g, g, value=1 - b2)
+            denom = ev.sqrt().add_(eps)
+            ss = lr * (1 - b2 ** step) ** 0.5 / (1 - b1 ** step)
+            mask = (em * g > 0).to(g.dtype)
+            mask.div_(mask.mean().clamp_(min=1e-3))
+            p.add_((em * mask) / denom, alpha=-ss)
+    want = torch.cat([p.reshape(-1) for p in rp])
+    assert rel_l2(flat.cpu().numpy(), want.numpy()) < 1e-5
