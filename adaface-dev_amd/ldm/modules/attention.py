@@ -61,6 +61,23 @@ class GEGLU(nn.Module):
     def hip(self, x2d):
         return ops.gemm(x2d, self.packed(), act=AF_ACT_GEGLU)
 
+    def hip_train(self, x2d):
+        """Un-fused: keeps the (interleaved) pre-activation for the backward.  -> (out, hp)."""
+        hp = ops.gemm(x2d, self.packed())
+        return ops.geglu_fwd(hp), hp
+
+    def packed_bwd(self):
+        def build():
+            wi, _ = ops.interleave_geglu(self.proj.weight.detach(), self.proj.bias.detach())
+            return ops.pack_matrix(wi.t().contiguous(), None, self.proj.weight.device)
+
+        if not hasattr(self, "_cache_bwd"):
+            self._cache_bwd = _PackCache()
+        return self._cache_bwd.get((self.proj.weight,), build)
+
+    def hip_bwd(self, hp, dout):
+        return ops.gemm(ops.geglu_bwd(hp, dout), self.packed_bwd())
+
     def forward(self, x):
         y = self.hip(x.reshape(-1, x.shape[-1]).to(F16).contiguous())
         y = y.reshape(*x.shape[:-1], y.shape[-1])
@@ -80,6 +97,13 @@ class FeedForward(nn.Module):
 
     def hip(self, x2d, residual=None):
         return self.net[2].hip(self.net[0].hip(x2d), residual=residual)
+
+    def hip_train(self, x2d, residual=None):
+        g, hp = self.net[0].hip_train(x2d)
+        return self.net[2].hip(g, residual=residual), hp
+
+    def hip_bwd(self, hp, dy):
+        return self.net[0].hip_bwd(hp, self.net[2].hip_dgrad(dy))
 
     def forward(self, x):
         y = self.hip(x.reshape(-1, x.shape[-1]).to(F16).contiguous()).reshape(x.shape[:-1] + (-1,))
@@ -149,6 +173,55 @@ class CrossAttention(nn.Module):
                 return out_plain
         return self.to_out[0].hip(o, residual=residual)
 
+    # ---- training mode: row-major q|k|v kept for the flash backward
+    def _packed_qkv_bwd(self):
+        ws = (self.to_q.weight, self.to_k.weight, self.to_v.weight)
+        if not hasattr(self, "_qkv_cache_bwd"):
+            self._qkv_cache_bwd = _PackCache()
+        return self._qkv_cache_bwd.get(ws, lambda: ops.pack_matrix(torch.cat([w.detach() for w in ws], 0).t().contiguous(), None, ws[0].device))
+
+    def _packed_kv_bwd(self):
+        ws = (self.to_k.weight, self.to_v.weight)
+        if not hasattr(self, "_kv_cache_bwd"):
+            self._kv_cache_bwd = _PackCache()
+        return self._kv_cache_bwd.get(ws, lambda: ops.pack_matrix(torch.cat([w.detach() for w in ws], 0).t().contiguous(), None, ws[0].device))
+
+    def hip_train(self, x2d, B, N, context=None, keybias=None, residual=None):
+        """As hip(), returning (out, saved) where `saved` feeds hip_bwd."""
+        Ci, h, d = self.inner_dim, self.heads, self.dim_head
+        if context is None:
+            qkv = ops.gemm(x2d, self._packed_qkv())                                   # [M, 3C] row-major
+            vt = ops.transpose_tokens(qkv[:, 2 * Ci:], B, N, Ci, 3 * Ci)
+            o, lse = ops.attention(qkv, qkv[:, Ci:], vt, B=B, Nq=N, L=N, heads=h, d=d, ldq=3 * Ci, ldk=3 * Ci, keybias=keybias,
+                                   scale=self.scale, want_lse=True)
+            saved = ("self", qkv, o, lse, keybias, B, N, N)
+        else:
+            L = context.shape[1]
+            q = self.to_q.hip(x2d)
+            kv = ops.gemm(context.reshape(B * L, context.shape[-1]), self._packed_kv())  # [B*L, 2C]
+            vt = ops.transpose_tokens(kv[:, Ci:], B, L, Ci, 2 * Ci)
+            o, lse = ops.attention(q, kv, vt, B=B, Nq=N, L=L, heads=h, d=d, ldq=Ci, ldk=2 * Ci, scale=self.scale, want_lse=True)
+            saved = ("cross", q, kv, o, lse, B, N, L)
+        return self.to_out[0].hip(o, residual=residual), saved
+
+    def hip_bwd(self, saved, dy, dctx=None):
+        """dy [M, C] -> (dx [M, C], dctx [B*L, Cc] accumulated) -- activation gradients only."""
+        Ci, h, d = self.inner_dim, self.heads, self.dim_head
+        do = self.to_out[0].hip_dgrad(dy)
+        if saved[0] == "self":
+            _, qkv, o, lse, keybias, B, N, L = saved
+            dqkv = torch.empty_like(qkv)
+            ops.attention_bwd(qkv, qkv[:, Ci:], qkv[:, 2 * Ci:], o, do, lse, B=B, Nq=N, L=L, heads=h, d=d, ldq=3 * Ci, ldk=3 * Ci,
+                              ldv=3 * Ci, dq=dqkv, dk=dqkv[:, Ci:], dv=dqkv[:, 2 * Ci:], lddq=3 * Ci, lddk=3 * Ci, lddv=3 * Ci,
+                              keybias=keybias, scale=self.scale)
+            return ops.gemm(dqkv, self._packed_qkv_bwd()), dctx
+        _, q, kv, o, lse, B, N, L = saved
+        dq, dkv = torch.empty_like(q), torch.empty_like(kv)
+        ops.attention_bwd(q, kv, kv[:, Ci:], o, do, lse, B=B, Nq=N, L=L, heads=h, d=d, ldq=Ci, ldk=2 * Ci, ldv=2 * Ci, dq=dq,
+                          dk=dkv, dv=dkv[:, Ci:], lddq=Ci, lddk=2 * Ci, lddv=2 * Ci, scale=self.scale)
+        dctx = ops.gemm(dkv, self._packed_kv_bwd(), residual=dctx)
+        return self.to_q.hip_dgrad(dq), dctx
+
     def forward(self, x, context=None, mask=None):
         """x [b, n, C]; context [b, l, Cc] or None; mask [b, ...] (nonzero = keep) over keys."""
         B, N, _ = x.shape
@@ -176,6 +249,22 @@ class BasicTransformerBlock(nn.Module):
         x1 = self.attn1.hip(self.norm1.hip(x2d), B, N, None, keybias, residual=x2d)
         x2 = self.attn2.hip(self.norm2.hip(x1), B, N, context, None, residual=x1)
         return self.ff.hip(self.norm3.hip(x2), residual=x2)
+
+    def hip_train(self, x2d, B, N, context=None, keybias=None):
+        x1, s1 = self.attn1.hip_train(self.norm1.hip(x2d), B, N, None, keybias, residual=x2d)
+        x2, s2 = self.attn2.hip_train(self.norm2.hip(x1), B, N, context, None, residual=x1)
+        x3, hp = self.ff.hip_train(self.norm3.hip(x2), residual=x2)
+        return x3, (x2d, x1, x2, s1, s2, hp)
+
+    def hip_bwd(self, saved, dy, dctx=None):
+        """Reverse of attention.py:242-252; every residual add of the backward is fused into the LayerNorm
+        backward kernel's `add` input."""
+        x, x1, x2, s1, s2, hp = saved
+        dx2 = self.norm3.hip_bwd(x2, self.ff.hip_bwd(hp, dy), add=dy)
+        dn2, dctx = self.attn2.hip_bwd(s2, dx2, dctx)
+        dx1 = self.norm2.hip_bwd(x1, dn2, add=dx2)
+        dn1, _ = self.attn1.hip_bwd(s1, dx1, None)
+        return self.norm1.hip_bwd(x, dn1, add=dx1), dctx
 
     def forward(self, x, context=None, mask=None):
         return checkpoint(self._forward, (x, context, mask), self.parameters(), self.checkpoint)
@@ -218,6 +307,31 @@ class SpatialTransformer(nn.Module):
             y = block.hip(y, B, N, context, kb)
         out = ops.gemm(y, self.proj_out.packed(), residual=x.reshape(B * N, Cn))
         return out.reshape(B, H, W, Cn)
+
+    def hip_train(self, x, context=None, mask=None):
+        B, H, W, Cn = x.shape
+        N = H * W
+        y, st = self.norm.hip_train(x)
+        y = self.proj_in.hip(y).reshape(B * N, -1)
+        kb = None
+        if mask is not None:
+            kb = ops.make_keybias(F.interpolate(mask.float(), size=(H, W), mode="nearest").reshape(B, N), N)
+        bs = []
+        for block in self.transformer_blocks:
+            block.attn2.infeat_size = (H, W)
+            y, s = block.hip_train(y, B, N, context, kb)
+            bs.append(s)
+        out = ops.gemm(y, self.proj_out.packed(), residual=x.reshape(B * N, Cn))
+        return out.reshape(B, H, W, Cn), (x, st, bs)
+
+    def hip_bwd(self, saved, dy, dctx=None):
+        x, st, bs = saved
+        B, H, W, Cn = x.shape
+        d = ops.gemm(dy.reshape(B * H * W, Cn), self.proj_out.packed_bwd())
+        for block, s in zip(reversed(self.transformer_blocks), reversed(bs)):
+            d, dctx = block.hip_bwd(s, d, dctx)
+        dn = ops.gemm(d, self.proj_in.packed_bwd()).reshape(B, H, W, Cn)
+        return self.norm.hip_bwd(x, st, dn, silu=False, add=dy), dctx
 
     def forward(self, x, context=None, mask=None):
         ctx = None if context is None else context.to(F16).contiguous()

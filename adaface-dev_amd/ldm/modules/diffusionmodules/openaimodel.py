@@ -58,6 +58,27 @@ class TimestepEmbedSequential(nn.Sequential, TimestepBlock):
                 x = layer.hip(x)
         return x
 
+    def hip_train(self, x, emb, context=None, mask=None):
+        saved = []
+        for layer in self:
+            if isinstance(layer, TimestepBlock):
+                x, s = layer.hip_train(x, emb)
+            elif isinstance(layer, SpatialTransformer):
+                x, s = layer.hip_train(x, context, mask)
+            else:
+                x, s = layer.hip_train(x)
+            saved.append(s)
+        return x, saved
+
+    def hip_bwd(self, saved, dy, dctx=None):
+        """Reverse walk; returns (dx or (dx_h, dx_skip) for a SkipCat input, dctx)."""
+        for layer, s in zip(reversed(list(self)), reversed(saved)):
+            if isinstance(layer, SpatialTransformer):
+                dy, dctx = layer.hip_bwd(s, dy, dctx)
+            else:
+                dy = layer.hip_bwd(s, dy)
+        return dy, dctx
+
     def forward(self, x, emb, context=None, mask=None):
         for layer in self:
             if isinstance(layer, TimestepBlock):
@@ -86,6 +107,12 @@ class Upsample(nn.Module):
         assert x.shape[-1] == self.channels
         return self.conv.hip(x, upsample=True)
 
+    def hip_train(self, x):
+        return self.hip(x), None
+
+    def hip_bwd(self, saved, dy):
+        return self.conv.hip_dgrad(dy, upsampled=True)
+
     def forward(self, x):
         assert x.shape[1] == self.channels
         return from_nhwc_f16(self.hip(to_nhwc_f16(x)), x.dtype)
@@ -105,6 +132,12 @@ class Downsample(nn.Module):
     def hip(self, x):
         assert x.shape[-1] == self.channels
         return self.op.hip(x)
+
+    def hip_train(self, x):
+        return self.hip(x), (x.shape[1], x.shape[2])
+
+    def hip_bwd(self, saved, dy):
+        return self.op.hip_dgrad(dy, in_hw=saved)
 
     def forward(self, x):
         assert x.shape[1] == self.channels
@@ -161,6 +194,35 @@ class ResBlock(TimestepBlock):
         else:
             skip = self.skip_connection.hip(x1, x2=x2)
         return self.out_layers[3].hip(h, residual=skip)
+
+    def _emb_out(self, emb):
+        if isinstance(emb, EmbPack) and emb.all_out is not None and self._emb_slice is not None:
+            off, width = self._emb_slice
+            return emb.all_out[:, off:off + width]
+        se = emb.silu_emb if isinstance(emb, EmbPack) else ops.silu(emb.to(F16).contiguous())
+        return self.emb_layers[1].hip(se)
+
+    def hip_train(self, x, emb):
+        """hip() keeping what the activation-gradient backward needs: the block input(s), the conv1
+        output and the two GroupNorm statistics (GroupNorm outputs are only needed for weight gradients,
+        which do not exist here: base weights are frozen, ddpm.py:4131-4132)."""
+        x1, x2 = (x[0], x[1]) if isinstance(x, SkipCat) else (x, None)
+        a, st1 = self.in_layers[0].hip_train(x1, silu=True, x2=x2)
+        h1 = self.in_layers[2].hip(a, rowbias=self._emb_out(emb))
+        b, st2 = self.out_layers[0].hip_train(h1, silu=True)
+        if isinstance(self.skip_connection, nn.Identity):
+            skip = x1 if x2 is None else torch.cat([x1, x2], dim=-1)
+        else:
+            skip = self.skip_connection.hip(x1, x2=x2)
+        return self.out_layers[3].hip(b, residual=skip), (x1, x2, st1, h1, st2)
+
+    def hip_bwd(self, saved, dy):
+        """Reverse of openaimodel.py:256-276 (no gradient flows into the time embedding: it depends on t only)."""
+        x1, x2, st1, h1, st2 = saved
+        dh1 = self.out_layers[0].hip_bwd(h1, st2, self.out_layers[3].hip_dgrad(dy), silu=True)
+        da = self.in_layers[2].hip_dgrad(dh1)
+        dskip = dy if isinstance(self.skip_connection, nn.Identity) else self.skip_connection.hip_dgrad(dy)
+        return self.in_layers[0].hip_bwd(x1, st1, da, silu=True, x2=x2, add=dskip)
 
     def forward(self, x, emb):
         return checkpoint(self._forward, (x, emb), self.parameters(), self.use_checkpoint)
@@ -352,10 +414,7 @@ class UNetModel(nn.Module):
     def hip(self, x_nhwc, timesteps, context, img_mask=None, capture_layers=()):
         """x_nhwc [B,H,W,8] fp16 (4 latent channels + zero pad), timesteps int64 [B],
         context [B,L,ctx] fp16 -> (eps [B,H,W,out_channels] fp16, captured activations)."""
-        t_emb = timestep_embedding(timesteps, self.model_channels)
-        e0 = ops.gemm(t_emb, self.time_embed[0].packed(), act=AF_ACT_SILU)
-        semb = ops.gemm(e0, self.time_embed[2].packed(), act=AF_ACT_SILU)  # SiLU(emb): only consumer is emb_layers
-        emb = EmbPack(semb, ops.gemm(semb, self._packed_emb_all()))
+        emb = self._embed(timesteps)   # SiLU(emb) (its only consumers are the emb_layers) + all 22 projections
 
         acts = {}
         hs = []
@@ -387,6 +446,48 @@ class UNetModel(nn.Module):
         h = self.out[0].hip(h, silu=True)
         return self.out[2].hip(h), acts
 
+    def _embed(self, timesteps):
+        t_emb = timestep_embedding(timesteps, self.model_channels)
+        e0 = ops.gemm(t_emb, self.time_embed[0].packed(), act=AF_ACT_SILU)
+        semb = ops.gemm(e0, self.time_embed[2].packed(), act=AF_ACT_SILU)
+        return EmbPack(semb, ops.gemm(semb, self._packed_emb_all()))
+
+    def hip_train(self, x_nhwc, timesteps, context, img_mask=None):
+        """Forward that keeps the activations the backward needs.  -> (eps [B,H,W,out_channels], saved)."""
+        emb = self._embed(timesteps)
+        saved_in, saved_out, hs = [], [], []
+        h = x_nhwc
+        for module in self.input_blocks:
+            h, s = module.hip_train(h, emb, context, img_mask)
+            saved_in.append(s)
+            hs.append(h)
+        h, saved_mid = self.middle_block.hip_train(h, emb, context, img_mask)
+        for module in self.output_blocks:
+            h, s = module.hip_train(SkipCat((h, hs.pop())), emb, context, img_mask)
+            saved_out.append(s)
+        g, st = self.out[0].hip_train(h, silu=True)
+        return self.out[2].hip(g), (saved_in, saved_mid, saved_out, h, st, context.shape)
+
+    def hip_bwd(self, saved, deps_nhwc, need_dx=True):
+        """Activation-gradient backward: deps [B,H,W,roundup(out_channels,8)] fp16 (zero padded) ->
+        (dx [B,H,W,in_channels] or None, dcontext [B,L,ctx] fp16).  Skip-connection gradients from the
+        decoder are added to the encoder's output gradients as the walk reaches them."""
+        saved_in, saved_mid, saved_out, h_last, st, ctx_shape = saved
+        d = self.out[0].hip_bwd(h_last, st, self.out[2].hip_dgrad(deps_nhwc), silu=True)
+        dctx = None
+        dskips = []
+        for module, s in zip(reversed(self.output_blocks), reversed(saved_out)):
+            (d, dskip), dctx = module.hip_bwd(s, d, dctx)
+            dskips.append(dskip)   # the LAST decoder block consumed hs[0], so this appends d(hs[0]), d(hs[1]), ...
+        d, dctx = self.middle_block.hip_bwd(saved_mid, d, dctx)
+        n_in = len(self.input_blocks)
+        for i in range(n_in - 1, -1, -1):
+            d = ops.add(d, dskips[i])
+            if i == 0 and not need_dx:
+                return None, dctx.reshape(ctx_shape)
+            d, dctx = self.input_blocks[i].hip_bwd(saved_in[i], d, dctx)
+        return d, dctx.reshape(ctx_shape)
+
     def forward(self, x, timesteps=None, context=None, y=None, context_in=None, extra_info=None, **kwargs):
         """Reference contract (openaimodel.py:820-952): x [N,4,H,W], timesteps [N], context
         [N,L,ctx]; ``extra_info`` carries ``img_mask`` / ``capture_ca_activations`` in and
@@ -398,6 +499,10 @@ class UNetModel(nn.Module):
         old_flags = None
         if capture:
             old_flags, _ = self.set_cross_attn_flags(ca_flag_dict={"save_cross_attn_vars": True}, ca_layer_indices=captured)
+        if torch.is_grad_enabled() and (x.requires_grad or context.requires_grad):
+            if capture:
+                raise NotImplementedError("capture_ca_activations together with gradients (Stage-2 losses) is SURVEY.md 8f rank 4")
+            return _UNetFunction.apply(self, x, timesteps, context, img_mask)
         try:
             xh = to_nhwc_f16(x, ops.round_up(self.in_channels, 8))
             ctx = context.to(F16).contiguous()
@@ -410,6 +515,29 @@ class UNetModel(nn.Module):
                 key: {li: acts[li][key] for li in acts} for key in ("outfeat", "attn", "attnscore", "q", "attn_out")
             }
         return from_nhwc_f16(eps, x.dtype, self.out_channels)
+
+
+class _UNetFunction(torch.autograd.Function):
+    """One autograd node for the whole U-Net: forward = UNetModel.hip_train, backward = the manual
+    activation-gradient walk UNetModel.hip_bwd (gradients w.r.t. x and context; the base weights are
+    frozen as in the reference, ddpm.py:4131-4132, so no weight gradients exist on this path)."""
+
+    @staticmethod
+    def forward(ctx, unet, x, timesteps, context, img_mask):
+        xh = to_nhwc_f16(x.detach(), ops.round_up(unet.in_channels, 8))
+        eps, saved = unet.hip_train(xh, timesteps, context.detach().to(F16).contiguous(), img_mask)
+        ctx.unet, ctx.saved = unet, saved
+        ctx.need_dx, ctx.x_dtype, ctx.c_dtype = x.requires_grad, x.dtype, context.dtype
+        return from_nhwc_f16(eps, x.dtype, unet.out_channels)
+
+    @staticmethod
+    def backward(ctx, deps):
+        unet = ctx.unet
+        dh = to_nhwc_f16(deps.contiguous(), ops.round_up(unet.out_channels, 8))
+        dx, dctx = unet.hip_bwd(ctx.saved, dh, need_dx=ctx.need_dx)
+        ctx.saved = None
+        gx = from_nhwc_f16(dx, ctx.x_dtype, unet.in_channels) if dx is not None else None
+        return None, gx, None, dctx.to(ctx.c_dtype), None
 
 
 def unet_param_shapes(cfg):

@@ -93,6 +93,41 @@ class Conv2d(nn.Conv2d):
         out = ops.gemm(x.reshape(B * H * W, c1), pw, a2=a2, rowbias=rowbias, rows_per_batch=H * W, residual=res)
         return out.reshape(B, H, W, -1)
 
+    def packed_bwd(self) -> ops.PackedWeight:
+        """Weights of the input-gradient convolution: spatially flipped, in/out channels swapped
+        (3x3) or the plain transpose (1x1).  No bias."""
+        _require_cuda(self.weight, "Conv2d")
+
+        def build():
+            w = self.weight.detach()
+            if self.kernel_size == (3, 3):
+                wd = w.flip(2, 3).permute(1, 0, 2, 3).contiguous()       # [Cin, Cout, 3, 3]
+                return ops.pack_conv3x3(wd, None, w.device, ops.round_up(self.out_channels, 8))
+            return ops.pack_matrix(w.reshape(self.out_channels, self.in_channels).t().contiguous(), None, w.device)
+
+        if not hasattr(self, "_cache_bwd"):
+            self._cache_bwd = _PackCache()
+        return self._cache_bwd.get((self.weight,), build)
+
+    # layer protocol used by TimestepEmbedSequential.hip_train / hip_bwd (bare conv = first input block)
+    def hip_train(self, x):
+        return self.hip(x), (x.shape[1], x.shape[2])
+
+    def hip_bwd(self, saved, dy):
+        return self.hip_dgrad(dy, in_hw=saved)
+
+    def hip_dgrad(self, dy, in_hw=None, upsampled=False):
+        """dy [B,Ho,Wo,Cout] -> dx [B,H,W,Cin].  in_hw: forward input size (needed for stride 2);
+        upsampled: the forward ran on the nearest-x2 upsampled input (Upsample) -> 2x2 block sums."""
+        pw = self.packed_bwd()
+        if self.kernel_size == (3, 3):
+            if self.stride[0] == 2:
+                return ops.conv3x3(dy, pw, upsample=2, out_hw=in_hw)
+            dx = ops.conv3x3(dy, pw)
+            return ops.sumpool2x2(dx) if upsampled else dx
+        B, H, W, c = dy.shape
+        return ops.gemm(dy.reshape(B * H * W, c), pw).reshape(B, H, W, -1)
+
     def forward(self, x):
         y = self.hip(to_nhwc_f16(x, self.cin_pad))
         return from_nhwc_f16(y, x.dtype)
@@ -112,6 +147,16 @@ class Linear(nn.Linear):
     def hip(self, x2d, residual=None, act=ops.AF_ACT_NONE, a2=None):
         return ops.gemm(x2d, self.packed(), residual=residual, act=act, a2=a2)
 
+    def packed_bwd(self) -> ops.PackedWeight:
+        _require_cuda(self.weight, "Linear")
+        if not hasattr(self, "_cache_bwd"):
+            self._cache_bwd = _PackCache()
+        return self._cache_bwd.get((self.weight,), lambda: ops.pack_matrix(self.weight.detach().t().contiguous(), None, self.weight.device))
+
+    def hip_dgrad(self, dy2d, residual=None):
+        """dy [M, N] -> dx [M, K] (+ residual)."""
+        return ops.gemm(dy2d, self.packed_bwd(), residual=residual)
+
     def forward(self, x):
         x2d = x.reshape(-1, x.shape[-1]).to(F16).contiguous()
         y = self.hip(x2d).reshape(*x.shape[:-1], self.out_features)
@@ -125,6 +170,14 @@ class GroupNorm32(nn.GroupNorm):
         _require_cuda(self.weight, "GroupNorm32")
         return ops.groupnorm(x, self.weight, self.bias, self.eps, silu, x2=x2, groups=self.num_groups)
 
+    def hip_train(self, x, silu=False, x2=None):
+        """-> (y, stats) with stats = per-(batch, group) (mean, rstd) kept for hip_bwd."""
+        _require_cuda(self.weight, "GroupNorm32")
+        return ops.groupnorm_train(x, self.weight, self.bias, self.eps, silu, x2=x2, groups=self.num_groups)
+
+    def hip_bwd(self, x, stats, dy, silu=False, x2=None, add=None):
+        return ops.groupnorm_bwd(x, self.weight, self.bias, stats, dy, silu, x2=x2, add=add, groups=self.num_groups)
+
     def forward(self, x):
         return from_nhwc_f16(self.hip(to_nhwc_f16(x)), x.dtype)
 
@@ -133,6 +186,9 @@ class LayerNorm(nn.LayerNorm):
     def hip(self, x2d):
         _require_cuda(self.weight, "LayerNorm")
         return ops.layernorm(x2d, self.weight, self.bias, self.eps)
+
+    def hip_bwd(self, x2d, dy, add=None):
+        return ops.layernorm_bwd(x2d, self.weight, dy, self.eps, add=add)
 
     def forward(self, x):
         y = self.hip(x.reshape(-1, x.shape[-1]).to(F16).contiguous()).reshape(x.shape)
