@@ -9,15 +9,18 @@ class is a plain ``nn.Module`` so samplers and trainers written against the refe
 ``LatentDiffusion`` attribute surface (``num_timesteps``, ``alphas_cumprod``, ``betas``,
 ``device``, ``q_sample``, ``apply_model``, ``model.diffusion_model``) keep working.
 """
+import copy
 from functools import partial
 
 import numpy as np
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from .... import ops
 from ...modules.diffusionmodules.openaimodel import UNetModel
 from ...modules.diffusionmodules.util import extract_into_tensor, make_beta_schedule
+from ...util import calc_recon_loss
 
 
 class UNetWrapper(nn.Module):
@@ -55,6 +58,8 @@ class LatentDiffusion(nn.Module):
         assert parameterization == "eps"
         self.parameterization = parameterization
         self.model = UNetWrapper(unet_config)
+        self.uncond_context = None   # (uncond_emb [1,L,768], [""], {}) when guided_denoise runs with cfg_scale > 1
+        self.unet_teacher = None     # adaface.unet_teachers.UNetTeacher (frozen)
         self.register_schedule(beta_schedule=beta_schedule, timesteps=timesteps, linear_start=linear_start,
                                linear_end=linear_end, cosine_s=cosine_s)
 
@@ -100,3 +105,65 @@ class LatentDiffusion(nn.Module):
         cond_context[2]["use_ffn_lora"] = use_ffn_lora
         cond_context[2]["ffn_lora_adapter_name"] = ffn_lora_adapter_name
         return self.model(x_noisy, t, cond_context)
+
+    # ------------------------------------------------------------------ Stage-1 distillation (ddpm.py:1597-1750, 2984-3184)
+    unet_distill_weight = 8          # ddpm.py:2367
+    res_hidden_states_gradscale = 1
+
+    def guided_denoise(self, x_start, noise, t, cond_context, uncond_emb=None, img_mask=None, subj_indices=None,
+                       normalize_cross_attn=False, mix_sc_mc_attn=False, batch_part_has_grad="all", do_pixel_recon=False,
+                       cfg_scale=-1, capture_ca_activations=False, res_hidden_states_gradscale=1, use_attn_lora=False,
+                       use_ffn_lora=False, ffn_lora_adapter_name=None):
+        """q_sample -> U-Net (with or without gradient) -> optional no-grad unconditional pass and CFG combine
+        eps = eps_c * s - eps_u * (s - 1) -> optional x0 (reference ddpm.py:1597-1750; the 'subject-compos'
+        batch partition belongs to Stage-2)."""
+        x_noisy = self.q_sample(x_start, t, noise)
+        extra_info = cond_context[2]
+        extra_info["capture_ca_activations"] = capture_ca_activations
+        extra_info["res_hidden_states_gradscale"] = res_hidden_states_gradscale
+        extra_info["img_mask"] = img_mask
+        extra_info["normalize_cross_attn"] = normalize_cross_attn
+        extra_info["subj_indices"] = subj_indices
+        if batch_part_has_grad == "none":
+            with torch.no_grad():
+                noise_pred = self.apply_model(x_noisy, t, cond_context, use_attn_lora=use_attn_lora, use_ffn_lora=use_ffn_lora,
+                                              ffn_lora_adapter_name=ffn_lora_adapter_name)
+        elif batch_part_has_grad == "all":
+            noise_pred = self.apply_model(x_noisy, t, cond_context, use_attn_lora=use_attn_lora, use_ffn_lora=use_ffn_lora,
+                                          ffn_lora_adapter_name=ffn_lora_adapter_name)
+        else:
+            raise NotImplementedError("batch_part_has_grad='subject-compos' is the Stage-2 partition (SURVEY.md 8f rank 4)")
+        ca_layers_activations = extra_info.get("ca_layers_activations") if capture_ca_activations else None
+        if cfg_scale > 1:
+            if uncond_emb is None:
+                uncond_emb = self.uncond_context[0].repeat(x_noisy.shape[0], 1, 1)
+            uncond_context = (uncond_emb, self.uncond_context[1] * x_noisy.shape[0], copy.copy(self.uncond_context[2]))
+            with torch.no_grad():
+                noise_pred_uncond = self.apply_model(x_noisy, t, uncond_context, use_attn_lora=False, use_ffn_lora=use_ffn_lora,
+                                                     ffn_lora_adapter_name=ffn_lora_adapter_name)
+            noise_pred = noise_pred * cfg_scale - noise_pred_uncond * (cfg_scale - 1)
+        x_recon = self.predict_start_from_noise(x_noisy, t=t, noise=noise_pred) if do_pixel_recon else None
+        return noise_pred, x_recon, ca_layers_activations
+
+    def calc_unet_distill_loss(self, x_start, noise, subj_context, teacher_context, img_mask, fg_mask,
+                               num_unet_denoising_steps, t=None, recon_bg_pixel_weight=0, presampled=None):
+        """Teacher multi-step epsilon targets, student epsilon per step, fg-masked MSE, sum / sqrt(steps)
+        (reference ddpm.py:2984-3184 without the logging decodes / pure-noise priming, which SURVEY.md section 3.1
+        identifies as pure overhead for throughput).  FFN-LoRA 'unet_distill' is SURVEY.md 8f rank 1."""
+        if t is None:
+            t = torch.randint(int(self.num_timesteps * 0.7), int(self.num_timesteps * 0.9), (x_start.shape[0],),
+                              device=x_start.device).long()
+        with torch.no_grad():
+            t_preds, t_x_starts, t_noises, all_t = self.unet_teacher(self, x_start, noise, t, teacher_context,
+                                                                     num_denoising_steps=num_unet_denoising_steps,
+                                                                     force_uses_cfg=False, presampled=presampled)
+        losses = []
+        for s in range(num_unet_denoising_steps):
+            noise_pred_s, _, _ = self.guided_denoise(t_x_starts[s].to(x_start.dtype), t_noises[s].to(x_start.dtype), all_t[s],
+                                                     subj_context, img_mask=None, batch_part_has_grad="all",
+                                                     do_pixel_recon=True, cfg_scale=self.unet_teacher.cfg_scale,
+                                                     res_hidden_states_gradscale=self.res_hidden_states_gradscale)
+            loss_s, _ = calc_recon_loss(F.mse_loss, noise_pred_s, t_preds[s].to(noise_pred_s.dtype), img_mask, fg_mask,
+                                        instance_weights=None, fg_pixel_weight=1, bg_pixel_weight=recon_bg_pixel_weight)
+            losses.append(loss_s)
+        return sum(losses) / np.sqrt(num_unet_denoising_steps)

@@ -266,6 +266,45 @@ def gen_schedule(out):
     print("schedule: ddim_timesteps[:3]", ts[:3], "alphas[:3]", np.asarray(a)[:3])
 
 
+def gen_train(out):
+    """Training-step pieces that ARE importable from the reference: calc_recon_loss (ldm/util.py:1678),
+    CAdamW (ldm/c_adamw.py) and the LR schedule (ldm/modules/lr_scheduler.py)."""
+    import torch.nn.functional as F
+    from adaface_dev_amd import rng
+    from ldm.c_adamw import AdamW as CAdamW   # the reference names the class AdamW (c_adamw.py:13)
+    from ldm.modules.lr_scheduler import LambdaWarmUpCosineScheduler
+    from ldm.util import calc_recon_loss
+
+    res = {}
+    pred = rng.synth_input("train.pred", (3, 4, 16, 16), seed=8)
+    gt = rng.synth_input("train.gt", (3, 4, 16, 16), seed=8)
+    fg = (rng.synth_input("train.fg", (3, 1, 16, 16), seed=8) > 0.2).float()
+    im = torch.ones(3, 1, 16, 16)
+    im[1, :, :, :4] = 0
+    res["recon_plain"] = calc_recon_loss(F.mse_loss, pred, gt, None, None)[0].numpy()
+    res["recon_fg0"] = calc_recon_loss(F.mse_loss, pred, gt, im, fg, fg_pixel_weight=1, bg_pixel_weight=0)[0].numpy()
+    res["recon_fg_half"] = calc_recon_loss(F.mse_loss, pred, gt, im, fg, fg_pixel_weight=1, bg_pixel_weight=0.5)[0].numpy()
+    res["recon_inst"] = calc_recon_loss(F.mse_loss, pred, gt, im, fg, instance_weights=torch.tensor([1.0, 0.0, 2.0]),
+                                        fg_pixel_weight=1, bg_pixel_weight=0.1)[0].numpy()
+
+    # CAdamW trace: two tensors, weight decay on, 4 steps (betas of the yaml: 0.9, 0.995; eps 1e-6)
+    ps = [torch.nn.Parameter(rng.synth_input("train.p0", (37, 5), seed=8)), torch.nn.Parameter(rng.synth_input("train.p1", (130,), seed=8))]
+    opt = CAdamW([{"params": [ps[0]], "weight_decay": 0.02}, {"params": [ps[1]], "weight_decay": 0.0}], lr=1e-2, betas=(0.9, 0.995), eps=1e-6)
+    for step in range(4):
+        for i, p in enumerate(ps):
+            p.grad = rng.synth_input(f"train.g{i}.{step}", p.shape, seed=8)
+        opt.step()
+        res[f"cadamw_p0_step{step}"] = ps[0].detach().numpy().copy()
+        res[f"cadamw_p1_step{step}"] = ps[1].detach().numpy().copy()
+
+    sch = LambdaWarmUpCosineScheduler(warm_up_steps=500, lr_min=0.1, lr_max=1.0, lr_start=0.01, max_decay_steps=60000)
+    ns = np.asarray([0, 1, 250, 499, 500, 501, 1000, 30000, 59999, 60000, 90000], dtype=np.int64)
+    res["lr_n"] = ns
+    res["lr_mult"] = np.asarray([sch(int(n)) for n in ns], dtype=np.float64)
+    np.savez_compressed(os.path.join(out, "train.npz"), **res)
+    print("train:", {k: (float(v) if v.ndim == 0 else v.shape) for k, v in res.items() if k.startswith("recon")})
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-full", action="store_true")
@@ -274,7 +313,7 @@ def main():
     install_reference_stubs()
     torch.set_num_threads(8)
     out = HERE
-    jobs = {"blocks": gen_blocks, "schedule": gen_schedule, "unet_tiny": gen_unet_tiny, "unet_full": gen_unet_full}
+    jobs = {"blocks": gen_blocks, "schedule": gen_schedule, "train": gen_train, "unet_tiny": gen_unet_tiny, "unet_full": gen_unet_full}
     for name, fn in jobs.items():
         if args.only and name != args.only:
             continue
