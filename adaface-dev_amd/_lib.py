@@ -12,7 +12,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libadaface_hip.so")
 
 AF_OK, AF_E_BADARG, AF_E_UNSUPPORTED, AF_E_HIP = 0, -1, -2, -3
-AF_ACT_NONE, AF_ACT_SILU, AF_ACT_GEGLU = 0, 1, 2
+AF_ACT_NONE, AF_ACT_SILU, AF_ACT_GEGLU, AF_ACT_QUICKGELU = 0, 1, 2, 3
 AF_OUT_NORMAL, AF_OUT_SPLIT_T = 0, 1
 AF_FAM_GEMM, AF_FAM_ATTN, AF_FAM_GNORM, AF_FAM_LNORM, AF_FAM_ELEM = 0, 1, 2, 3, 4
 
@@ -23,7 +23,7 @@ EXPORTS = (
     "af_timestep_embedding", "af_nchw_f32_to_nhwc_f16", "af_nhwc_f16_to_nchw_f32", "af_cfg_ddim_step", "af_q_sample",
     "af_silu_f16", "af_attention_lse", "af_groupnorm_stats", "af_attention_bwd_scratch_bytes", "af_attention_bwd",
     "af_groupnorm_bwd", "af_layernorm_bwd", "af_geglu_fwd", "af_geglu_bwd", "af_sumpool2x2", "af_add_f16",
-    "af_transpose_tokens", "af_cadamw_step",
+    "af_transpose_tokens", "af_cadamw_step", "af_attention_ex",
 )
 
 
@@ -89,6 +89,7 @@ def lib() -> C.CDLL:
     L.af_q_sample.argtypes = [vp, vp, vp, vp, vp, i32, i64, vp]
     L.af_silu_f16.argtypes = [vp, vp, i64, vp]
     L.af_attention_lse.argtypes = [vp, vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp]
+    L.af_attention_ex.argtypes = [vp, vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp]
     L.af_groupnorm_stats.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp, vp]
     L.af_attention_bwd_scratch_bytes.argtypes = [i32, i32, i32, i32, i32]
     L.af_attention_bwd.argtypes = [vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, i64] + [i32] * 14 + [f32, vp]

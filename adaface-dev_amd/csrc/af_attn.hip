@@ -36,6 +36,7 @@ struct AttnArgs {
   const float* kbias;
   float* lse2;
   int ld_lse;
+  int causal_m;  // > 0: key j is visible to query i iff j / causal_m <= i (CLIP causal mask, m keys per token)
   int B, Nq, L, heads, d;
   int ldq, ldk, ldo, ldv, ldb;
   float c;  // scale * log2(e)
@@ -175,7 +176,9 @@ __global__ __launch_bounds__(256) void af_attn_kernel(AttnArgs a) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             float t = sT[sub][4 * g + e] * a.c + bias[e];
-            t = (kb + e < a.L) ? t : -INFINITY;
+            bool vis = kb + e < a.L;
+            if (a.causal_m > 0) vis = vis && ((kb + e) / a.causal_m <= query);
+            t = vis ? t : -INFINITY;
             sT[sub][4 * g + e] = t;
             mx = fmaxf(mx, t);
           }
@@ -319,6 +322,12 @@ __global__ __launch_bounds__(256) void af_scores_kernel(const half_t* __restrict
 extern "C" int af_attention_lse(const void* q, const void* k, const void* vt, void* o, void* lse2, int ld_lse,
                                 const void* keybias, int B, int Nq, int L, int heads, int d, int ldq, int ldk, int ldo,
                                 int ldv, int ldb, float scale, void* stream) {
+  return af_attention_ex(q, k, vt, o, lse2, ld_lse, keybias, 0, B, Nq, L, heads, d, ldq, ldk, ldo, ldv, ldb, scale, stream);
+}
+
+extern "C" int af_attention_ex(const void* q, const void* k, const void* vt, void* o, void* lse2, int ld_lse,
+                               const void* keybias, int causal_m, int B, int Nq, int L, int heads, int d, int ldq, int ldk,
+                               int ldo, int ldv, int ldb, float scale, void* stream) {
   AF_REQUIRE(q && k && vt && o, "af_attention: null pointer");
   AF_REQUIRE(B > 0 && Nq > 0 && L > 0 && heads > 0 && d > 0, "af_attention: bad sizes");
   AF_REQUIRE(d % 8 == 0, "af_attention: head dim must be a multiple of 8");
@@ -337,6 +346,8 @@ extern "C" int af_attention_lse(const void* q, const void* k, const void* vt, vo
   a.kbias = (const float*)keybias;
   a.lse2 = (float*)lse2;
   a.ld_lse = ld_lse;
+  a.causal_m = causal_m;
+  AF_REQUIRE(causal_m >= 0, "af_attention: causal_m < 0");
   if (lse2) AF_REQUIRE(ld_lse >= Nq, "af_attention: ld_lse < Nq");
   a.B = B;
   a.Nq = Nq;

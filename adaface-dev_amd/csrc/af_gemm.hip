@@ -31,7 +31,7 @@ struct GemmDev {
   int M, N, K, kpad;
   int c1, c2, lda1, lda2;
   int H, W, Ho, Wo, HoWo, Heff, Weff, stride, upsample;
-  int rows_per_batch, ld_rowbias, act_silu, ld_out, split_col, ld_out2;
+  int rows_per_batch, ld_rowbias, act_silu, ld_out, split_col, ld_out2;  // act_silu: 0 none, 1 SiLU, 3 quick-GELU
   int tiles_n;
   int splits, kt_per_split;  // split-K: blockIdx.y owns K steps [y*kt_per_split, ...)
   float* ws;                 // fp32 partials [splits][M][N] when splits > 1
@@ -260,9 +260,12 @@ __global__ __launch_bounds__(256, 2) void af_gemm_kernel(GemmDev p) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) v[i] += (float)rv[i];
         }
-        if (p.act_silu) {
+        if (p.act_silu == 1) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) v[i] = af_silu(v[i]);
+        } else if (p.act_silu == 3) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = v[i] / (1.0f + __expf(-1.702f * v[i]));  // x * sigmoid(1.702 x)
         }
         if (EPI == EPI_SPLIT_T && n0 >= p.split_col) {
           const int tok = m - bidx * p.rows_per_batch;
@@ -298,9 +301,12 @@ __global__ __launch_bounds__(256) void af_splitk_reduce_kernel(GemmDev p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] += (float)rv[i];
   }
-  if (p.act_silu) {
+  if (p.act_silu == 1) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] = af_silu(v[i]);
+  } else if (p.act_silu == 3) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = v[i] / (1.0f + __expf(-1.702f * v[i]));
   }
   if (p.residual) {
     const half4_t rv = *reinterpret_cast<const half4_t*>(p.residual + (size_t)m * p.N + n0);
@@ -380,7 +386,7 @@ extern "C" int af_gemm(const af_gemm_desc* d, void* stream) {
   }
   p.rows_per_batch = d->rows_per_batch > 0 ? d->rows_per_batch : d->M;
   p.ld_rowbias = d->ld_rowbias;
-  p.act_silu = d->act == AF_ACT_SILU;
+  p.act_silu = d->act == AF_ACT_SILU ? 1 : (d->act == AF_ACT_QUICKGELU ? 3 : 0);
   p.split_col = d->split_col;
   p.ld_out2 = d->ld_out2;
   p.tiles_n = 0;

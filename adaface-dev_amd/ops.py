@@ -15,7 +15,7 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import AF_ACT_GEGLU, AF_ACT_NONE, AF_ACT_SILU, AF_OUT_NORMAL, AF_OUT_SPLIT_T, GemmDesc
+from ._lib import AF_ACT_GEGLU, AF_ACT_NONE, AF_ACT_QUICKGELU, AF_ACT_SILU, AF_OUT_NORMAL, AF_OUT_SPLIT_T, GemmDesc
 
 F16 = torch.float16
 NEG_MAX = -torch.finfo(torch.float32).max
@@ -256,7 +256,7 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
 # ----------------------------------------------------------------------------- attention
 def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, *, B: int, Nq: int, L: int, heads: int, d: int,
               ldq: int, ldk: int, keybias: Optional[torch.Tensor] = None, scale: Optional[float] = None,
-              want_lse: bool = False):
+              want_lse: bool = False, causal_m: int = 0):
     """q [B*Nq, ldq-wide rows], k [B*L, ldk-wide rows], vt [B, heads*d, ldv] -> o [B*Nq, heads*d]
     (and, with want_lse, the base-2 log-sum-exp fp32 [B, heads, roundup(Nq,32)] for the backward)."""
     Cn = heads * d
@@ -264,8 +264,8 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, *, B: int, Nq:
     scale = d ** -0.5 if scale is None else scale
     ldb = 0 if keybias is None else keybias.stride(0)
     lse = torch.empty((B, heads, round_up(Nq, 32)), dtype=torch.float32, device=q.device) if want_lse else None
-    rc = _lib.lib().af_attention_lse(_p(q), _p(k), _p(vt), _p(o), _p(lse), 0 if lse is None else lse.stride(1), _p(keybias),
-                                     B, Nq, L, heads, d, ldq, ldk, Cn, vt.stride(1), ldb, float(scale), _stream())
+    rc = _lib.lib().af_attention_ex(_p(q), _p(k), _p(vt), _p(o), _p(lse), 0 if lse is None else lse.stride(1), _p(keybias),
+                                    int(causal_m), B, Nq, L, heads, d, ldq, ldk, Cn, vt.stride(1), ldb, float(scale), _stream())
     _lib.check(rc, "af_attention")
     return (o, lse) if want_lse else o
 

@@ -74,6 +74,7 @@ int af_prof_read(int family, int* launches, double* total_ms);
 #define AF_ACT_NONE 0
 #define AF_ACT_SILU 1
 #define AF_ACT_GEGLU 2
+#define AF_ACT_QUICKGELU 3 /* x * sigmoid(1.702 x): CLIP text MLP (transformers QuickGELUActivation) */
 #define AF_OUT_NORMAL 0
 #define AF_OUT_SPLIT_T 1
 
@@ -146,6 +147,12 @@ int af_attention(const void* q, const void* k, const void* vt, void* o, const vo
 int af_attention_lse(const void* q, const void* k, const void* vt, void* o, void* lse2, int ld_lse, const void* keybias,
                      int B, int Nq, int L, int heads, int d, int ldq, int ldk, int ldo, int ldv, int ldb, float scale,
                      void* stream);
+
+/* general form: causal_m > 0 adds CLIP's causal mask with `causal_m` keys per token (key j visible to query i
+ * iff j / causal_m <= i): adaface/arc2face_models.py:145-231 (CLIPAttentionMKV, K/V widened x m). */
+int af_attention_ex(const void* q, const void* k, const void* vt, void* o, void* lse2, int ld_lse, const void* keybias,
+                    int causal_m, int B, int Nq, int L, int heads, int d, int ldq, int ldk, int ldo, int ldv, int ldb,
+                    float scale, void* stream);
 
 /* ---- attention backward (flash-style, recomputes P from q, k and lse2) -------------------
  * Input gradients of af_attention for dO = `dout`: dq [B,Nq,lddq], dk [B,L,lddk], dv [B,L,lddv].

@@ -305,6 +305,67 @@ def gen_train(out):
     print("train:", {k: (float(v) if v.ndim == 0 else v.shape) for k, v in res.items() if k.startswith("recon")})
 
 
+CLIP_SMALL = dict(hidden=128, heads=2, layers=3, inter=512, vocab=1000, max_pos=77)
+
+
+def gen_clip(out):
+    """(a) the reference's own CLIPAttentionMKV (m = 1, 2); (b) transformers' CLIPTextModel (third-party layer arithmetic,
+    version recorded) on a reduced config.  Extra import-time stubs: diffusers / ConsistentID names that
+    adaface/arc2face_models.py and adaface/util.py import at module top but the attention class never touches."""
+    import transformers
+    from transformers import CLIPTextConfig, CLIPTextModel
+    from adaface_dev_amd import rng
+
+    def stub(name, **attrs):
+        m = types.ModuleType(name)
+        m.__path__ = []
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        sys.modules.setdefault(name, m)
+
+    D = lambda n: type(n, (), {})
+    stub("diffusers", StableDiffusionPipeline=D("a"), UNet2DConditionModel=D("b"), DDIMScheduler=D("c"))
+    stub("diffusers.models")
+    stub("diffusers.models.unets")
+    stub("diffusers.models.unets.unet_2d_condition", UNet2DConditionOutput=D("d"))
+    stub("ConsistentID")
+    stub("ConsistentID.lib")
+    stub("ConsistentID.lib.pipeline_ConsistentID", ConsistentIDPipeline=D("e"))
+    import warnings
+    warnings.simplefilter("ignore")
+    from adaface.arc2face_models import CLIPAttentionMKV
+    from transformers.modeling_attn_mask_utils import AttentionMaskConverter
+
+    c = CLIP_SMALL
+    cfg = CLIPTextConfig(vocab_size=c["vocab"], hidden_size=c["hidden"], intermediate_size=c["inter"], num_hidden_layers=c["layers"],
+                         num_attention_heads=c["heads"], max_position_embeddings=c["max_pos"], hidden_act="quick_gelu")
+    res = {"transformers_version": np.asarray(transformers.__version__)}
+    for m in (1, 2):
+        att = CLIPAttentionMKV(cfg, multiplier=m).eval()
+        with torch.no_grad():
+            for n, p in att.named_parameters():
+                p.copy_(rng.synth_tensor(f"mkv{m}." + n, p.shape, seed=20))
+        for T in (22, 77):
+            h = rng.synth_input(f"clip.h{T}", (2, T, c["hidden"]), seed=20)
+            cm = AttentionMaskConverter._make_causal_mask((2, T), torch.float32, device=h.device)
+            with torch.no_grad():
+                res[f"mkv_m{m}_T{T}"] = att(h, None, cm)[0].numpy()
+    model = CLIPTextModel(cfg).eval()
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            key = n if n.startswith("text_model.") else "text_model." + n      # transformers-4 key layout
+            p.copy_(rng.synth_tensor(key, p.shape, seed=21))
+    ids = torch.randint(0, c["vocab"], (2, 77), generator=torch.Generator().manual_seed(3))
+    with torch.no_grad():
+        o = model(input_ids=ids, output_hidden_states=True)
+    res["text_ids"] = ids.numpy()
+    res["text_last"] = o.last_hidden_state.numpy()
+    res["text_hidden_m3"] = o.hidden_states[-3].numpy()
+    res["text_hidden_0"] = o.hidden_states[0].numpy()
+    np.savez_compressed(os.path.join(out, "clip.npz"), **res)
+    print("clip:", {k: v.shape for k, v in res.items()}, len(o.hidden_states))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-full", action="store_true")
@@ -313,7 +374,7 @@ def main():
     install_reference_stubs()
     torch.set_num_threads(8)
     out = HERE
-    jobs = {"blocks": gen_blocks, "schedule": gen_schedule, "train": gen_train, "unet_tiny": gen_unet_tiny, "unet_full": gen_unet_full}
+    jobs = {"blocks": gen_blocks, "schedule": gen_schedule, "train": gen_train, "clip": gen_clip, "unet_tiny": gen_unet_tiny, "unet_full": gen_unet_full}
     for name, fn in jobs.items():
         if args.only and name != args.only:
             continue

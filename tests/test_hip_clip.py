@@ -1,0 +1,116 @@
+"""Face -> prompt encoder stack on a real MI355X (`pytest -m gpu`): CLIPAttentionMKV against the REFERENCE module's
+outputs, the CLIP text transformer against transformers' CLIPTextModel (tests/golden/clip.npz), and the Arc2Face ID ->
+image-prompt -> AdaFace-embedding chain (full CLIP-L size) against the CPU oracle.  fp16 activations: 5e-3 rel-L2 per
+module, 1e-2 through the 2 x 12-layer chain."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, rel_l2
+from test_clip_oracle import CLIP_SMALL, small_clip_shapes
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from adaface_dev_amd import _lib
+    _lib.lib()
+    return torch.device("cuda:0")
+
+
+def small_cfg():
+    from adaface_dev_amd.adaface.arc2face_models import clip_text_config
+    c = CLIP_SMALL
+    return clip_text_config(hidden_size=c["hidden"], num_attention_heads=c["heads"], num_hidden_layers=c["layers"],
+                            intermediate_size=c["inter"], vocab_size=c["vocab"], max_position_embeddings=c["max_pos"])
+
+
+def test_mkv_attention_module_vs_reference(dev):
+    from adaface_dev_amd import rng
+    from adaface_dev_amd.adaface.arc2face_models import CLIPAttentionMKV
+    g = np.load(os.path.join(GOLDEN, "clip.npz"))
+    for m in (1, 2):
+        att = CLIPAttentionMKV(small_cfg(), multiplier=m)
+        with torch.no_grad():
+            for n, p in att.named_parameters():
+                p.copy_(rng.synth_tensor(f"mkv{m}." + n, p.shape, seed=20))
+        att = att.to(dev)
+        for T in (22, 77):
+            h = rng.synth_input(f"clip.h{T}", (2, T, CLIP_SMALL["hidden"]), seed=20).to(dev)
+            out, _ = att(h, None, causal_attention_mask=True)
+            assert rel_l2(out.cpu().numpy(), g[f"mkv_m{m}_T{T}"]) < 5e-3, (m, T)
+
+
+def _small_model(dev, seed=21, multipliers=None):
+    from adaface_dev_amd import rng
+    from adaface_dev_amd.adaface.arc2face_models import CLIPTextModelWrapper
+    m = CLIPTextModelWrapper(small_cfg())
+    if multipliers:
+        for li, mult in enumerate(multipliers):
+            if mult > 1:
+                m.extend_clip_attention_MKV_multiplier(li, li, mult, perturb_std=0.0)
+    rng.load_synth_weights(m, seed=seed)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    return m.to(dev).eval(), sd
+
+
+def test_clip_text_model_vs_transformers(dev):
+    g = np.load(os.path.join(GOLDEN, "clip.npz"))
+    m, _ = _small_model(dev)
+    ids = torch.from_numpy(g["text_ids"]).to(dev)
+    with torch.no_grad():
+        last, pooled, hidden = m(input_ids=ids, output_hidden_states=True)
+    assert last.dtype == torch.float32 and pooled.shape == (2, CLIP_SMALL["hidden"]) and len(hidden) == CLIP_SMALL["layers"] + 1
+    assert rel_l2(hidden[-3].float().cpu().numpy(), g["text_hidden_m3"]) < 5e-3
+    assert rel_l2(last.cpu().numpy(), g["text_last"]) < 5e-3
+
+
+def test_small_encoder_chain_with_mkv_and_layer_weights_vs_oracle(dev):
+    from adaface_dev_amd import rng
+    from oracle import clip_oracle as CO
+    mult = [1, 2, 1]
+    m, sd = _small_model(dev, seed=22, multipliers=mult)
+    assert sd["text_model.encoder.layers.1.self_attn.k_proj.weight"].shape[0] == 2 * CLIP_SMALL["hidden"]
+    ids = torch.randint(0, CLIP_SMALL["vocab"], (3, 77), generator=torch.Generator().manual_seed(5))
+    tok = rng.synth_input("clip.tok", (3, 77, CLIP_SMALL["hidden"]), seed=22, scale=0.3)
+    w = torch.tensor([[1.0], [2.0], [4.0]])
+    with torch.no_grad():
+        last = m(input_ids=ids.to(dev), input_token_embs=tok.to(dev), hidden_state_layer_weights=w.to(dev))[0]
+    ref = CO.clip_text_forward(sd, CLIP_SMALL, ids, tok, w, mult)[0]
+    assert rel_l2(last.cpu().numpy(), ref.numpy()) < 5e-3
+
+
+def test_arc2face_id_to_adaface_embeddings_full_size_vs_oracle(dev):
+    """ID [B,512] -> Arc2Face CLIP encoder (22 tokens, ID token injected) -> [B,16,768] -> SubjBasisGenerator
+    (77-token template, slots 4:20 replaced, last-3-layer mix [1,2,4]) -> AdaFace embeddings [B,16,768]."""
+    from adaface_dev_amd import rng
+    from adaface_dev_amd.adaface.face_id_to_ada_prompt import Arc2Face_ID2AdaPrompt
+    from adaface_dev_amd.adaface.subj_basis_generator import template_ids
+    from oracle import clip_oracle as CO
+    enc = Arc2Face_ID2AdaPrompt()
+    rng.load_synth_weights(enc.text_to_image_prompt_encoder, seed=30)
+    rng.load_synth_weights(enc.subj_basis_generator.prompt2token_proj, seed=31)
+    sd_a = {k: v.detach().clone() for k, v in enc.text_to_image_prompt_encoder.state_dict().items()}
+    sd_s = {k: v.detach().clone() for k, v in enc.subj_basis_generator.prompt2token_proj.state_dict().items()}
+    enc = enc.to(dev).eval()
+    ids512 = torch.nn.functional.normalize(rng.synth_input("id.embs", (3, 512), seed=30), dim=-1)
+    with torch.no_grad():
+        ada, img_prompt, lens = enc.generate_adaface_embeddings(face_id_embs=ids512.to(dev), avg_at_stage=None)
+    assert ada.shape == (3, 16, 768) and img_prompt.shape == (3, 16, 768) and lens == [16]
+    cfg = dict(hidden=768, heads=12, layers=12)
+    ref_img = CO.id_to_img_prompt(sd_a, cfg, template_ids(["photo", "of", "a", "id", "person"], 22).repeat(3, 1), 4, ids512)
+    assert rel_l2(img_prompt.float().cpu().numpy(), ref_img.numpy()) < 1e-2
+    ref_ada = CO.inverse_img_prompt(sd_s, cfg, template_ids(["photo", "of", "a"] + [","] * 18, 77).repeat(3, 1), ref_img,
+                                    torch.tensor([[1.0], [2.0], [4.0]]))
+    err = rel_l2(ada.float().cpu().numpy(), ref_ada.numpy())
+    print(f"AdaFace embeddings rel-L2 vs oracle: {err:.3e}")
+    assert err < 1e-2
+    # averaging at the id_emb stage returns one subject's [16, 768]
+    with torch.no_grad():
+        ada1, _, _ = enc.generate_adaface_embeddings(face_id_embs=ids512.to(dev), avg_at_stage="id_emb")
+    assert ada1.shape == (16, 768)
