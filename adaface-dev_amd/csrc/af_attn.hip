@@ -45,7 +45,12 @@ struct AttnArgs {
 constexpr int KB = 64;     // keys per stage
 constexpr int VST = 36;    // V^T LDS row stride in halves (72 B)
 
-template <int DS>
+// ONES: the padded V^T tile has a spare row (32*DT > d); its LAST row is set to 1 for every valid key, so the row
+// sum l = sum_j p_ij falls out of the PV MFMA (accumulator o[DT-1][15] of the upper half-wave) instead of 32 VALU
+// adds per stage, and is rescaled together with O.  At d = 40 the softmax bookkeeping, not the MFMA, bounds this kernel.
+// GENERAL = false: no key bias, no causal mask and L % 64 == 0 -- every self-attention of the U-Net -- compiles to a
+// stage body with no per-score work besides max / sub / exp2 / cvt.
+template <int DS, bool ONES, bool GENERAL>
 __global__ __launch_bounds__(256) void af_attn_kernel(AttnArgs a) {
   constexpr int DP = 16 * DS;         // padded head dim for the QK^T k-loop
   constexpr int DT = (DS + 1) / 2;    // 32-row O^T tiles
@@ -63,11 +68,20 @@ __global__ __launch_bounds__(256) void af_attn_kernel(AttnArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, hh = lane >> 5;
-  const int b = blockIdx.z, h = blockIdx.y;
-  const int query = blockIdx.x * 128 + wave * 32 + r;
+  // XCD-aware block mapping: workgroups are dealt round-robin over the 8 XCDs (private 4 MB L2s).  All query
+  // blocks of one (batch, head) share its K / V, so they are placed on the SAME XCD (bid % 8) and walked
+  // consecutively there: each L2 then holds the K/V of the few (batch, head) groups it is working on instead of
+  // every XCD streaming every group from the Infinity Cache.  Speed only; any placement is correct.
+  const int qblocks = (a.Nq + 127) / 128;
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int bh = (idx / qblocks) * 8 + xcd;
+  if (bh >= a.B * a.heads) return;
+  const int b = bh / a.heads, h = bh - b * a.heads;
+  const int query = (idx % qblocks) * 128 + wave * 32 + r;
   const int C = a.heads * a.d;
 
-  // ---- Q fragments (B operand of S^T = K Q^T): lane (r, hh) holds Q[query][16 s + 8 hh .. +7]
+  // ---- Q fragments (B operand of S^T = K Q^T), pre-multiplied by scale*log2(e): lane (r, hh) holds
+  //      Q[query][16 s + 8 hh .. +7]
   half8_t qf[DS];
   const half8_t zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
   {
@@ -75,36 +89,64 @@ __global__ __launch_bounds__(256) void af_attn_kernel(AttnArgs a) {
 #pragma unroll
     for (int s = 0; s < DS; ++s) {
       const int dc = 16 * s + 8 * hh;
-      qf[s] = (query < a.Nq && dc < a.d) ? *reinterpret_cast<const half8_t*>(qp + dc) : zero8;
+      half8_t v = (query < a.Nq && dc < a.d) ? *reinterpret_cast<const half8_t*>(qp + dc) : zero8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] * a.c);
+      qf[s] = v;
     }
   }
 
   half8_t rk[NKC], rv[NVC];
+  // per-thread staging sources are fixed up to the stage's key offset: hoist the address arithmetic out of the loop
+  const half_t* kptr[NKC];
+  bool kok[NKC];
+#pragma unroll
+  for (int j = 0; j < NKC; ++j) {
+    const int i = tid + 256 * j;
+    const int row = i / (DP / 8), ch = i - row * (DP / 8);
+    kok[j] = i < KCH && ch * 8 < a.d;
+    kptr[j] = a.k + ((size_t)b * a.L + row) * a.ldk + h * a.d + ch * 8;
+  }
+  const half_t* vptr[NVC];
+  bool vok[NVC], vones[NVC];
+#pragma unroll
+  for (int j = 0; j < NVC; ++j) {
+    const int i = tid + 256 * j;
+    const int row = i >> 3, ch = i & 7;
+    vok[j] = i < VCH && row < a.d;
+    vones[j] = ONES && i < VCH && row == DV - 1;
+    vptr[j] = a.vt + ((size_t)b * C + h * a.d + (row < a.d ? row : 0)) * a.ldv + ch * 8;
+  }
+  const half8_t ones8 = {1, 1, 1, 1, 1, 1, 1, 1};
   auto load_stage = [&](int key0) {
 #pragma unroll
     for (int j = 0; j < NKC; ++j) {
-      const int i = tid + 256 * j;
-      const int row = i / (DP / 8), ch = i - row * (DP / 8);
-      const int key = key0 + row;
-      const bool ok = i < KCH && key < a.L && ch * 8 < a.d;
-      rk[j] = ok ? *reinterpret_cast<const half8_t*>(a.k + ((size_t)b * a.L + key) * a.ldk + h * a.d + ch * 8) : zero8;
+      const int row = (tid + 256 * j) / (DP / 8);
+      const bool ok = kok[j] && (!GENERAL || key0 + row < a.L);
+      rk[j] = ok ? *reinterpret_cast<const half8_t*>(kptr[j] + (size_t)key0 * a.ldk) : zero8;
     }
 #pragma unroll
     for (int j = 0; j < NVC; ++j) {
-      const int i = tid + 256 * j;
-      const int row = i >> 3, ch = i & 7;
-      const int kk = key0 + ch * 8;
-      const bool ok = i < VCH && row < a.d && kk < a.L;
-      half8_t v = ok ? *reinterpret_cast<const half8_t*>(a.vt + ((size_t)b * C + h * a.d + row) * a.ldv + kk) : zero8;
-      if (ok && kk + 8 > a.L) {
+      const int kk = key0 + ((tid + 256 * j) & 7) * 8;
+      const bool ok = vok[j] && (!GENERAL || kk < a.L);
+      // The fill value must not depend on the loaded data: any VALU touch of the destination right after the load
+      // makes the compiler wait for it here (vmcnt(0)) and the prefetch turns synchronous.  Tail masking of a
+      // partially valid chunk (L % 8 != 0) therefore happens in store_stage, after the stage's compute.
+      half8_t fill = zero8;
+      if (ONES) {
+        if (GENERAL) {
+          if (vones[j]) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e)
-          if (kk + e >= a.L) v[e] = (half_t)0;
+            for (int e = 0; e < 8; ++e) fill[e] = (kk + e < a.L) ? (half_t)1 : (half_t)0;
+          }
+        } else {
+          fill = vones[j] ? ones8 : zero8;
+        }
       }
-      rv[j] = v;
+      rv[j] = ok ? *reinterpret_cast<const half8_t*>(vptr[j] + key0) : fill;
     }
   };
-  auto store_stage = [&](int buf) {
+  auto store_stage = [&](int buf, int key0_store) {
     half_t* Ks = lds + buf * STAGE;
     half_t* Vs = Ks + KBUF;
 #pragma unroll
@@ -121,6 +163,14 @@ __global__ __launch_bounds__(256) void af_attn_kernel(AttnArgs a) {
       if (i < VCH) {
         const int row = i >> 3, ch = i & 7;
         half_t* dst = Vs + ((ch >> 2) * DV + row) * VST + (ch & 3) * 8;
+        if (GENERAL) {   // keys >= L inside a partially valid chunk carry whatever the padding holds: zero them
+          const int kk = key0_store + ch * 8;
+          if (kk + 8 > a.L) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              if (kk + e >= a.L) rv[j][e] = (half_t)0;
+          }
+        }
         const half4_t lo = {rv[j][0], rv[j][1], rv[j][2], rv[j][3]};
         const half4_t hi = {rv[j][4], rv[j][5], rv[j][6], rv[j][7]};
         *reinterpret_cast<half4_t*>(dst) = lo;
@@ -138,7 +188,7 @@ __global__ __launch_bounds__(256) void af_attn_kernel(AttnArgs a) {
 
   const int nstage = (a.L + KB - 1) / KB;
   load_stage(0);
-  store_stage(0);
+  store_stage(0, 0);
   __syncthreads();
   for (int st = 0; st < nstage; ++st) {
     const int key0 = st * KB;
@@ -147,14 +197,17 @@ __global__ __launch_bounds__(256) void af_attn_kernel(AttnArgs a) {
 
     const half_t* Ks = lds + (st & 1) * STAGE;
     const half_t* Vs = Ks + KBUF;
-    const int nsub = (key0 + 32 < a.L) ? 2 : 1;
+    const int nsub = GENERAL ? ((key0 + 32 < a.L) ? 2 : 1) : 2;
 
-    // ---- S^T = K Q^T for up to two 32-key sub-tiles
+    // ---- S^T = K Q^T (already in the base-2 softmax domain) for up to two 32-key sub-tiles.
+    // Mask-free kernel: the accumulator starts at -m (row constant as the MFMA's C operand), so the MFMA
+    // delivers S^T - m and exp2 applies directly; only when some lane's max grew is a correction subtracted.
     floatx16 sT[2];
+    const float cinit = (GENERAL || st == 0) ? 0.f : -m;
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) sT[sub][i] = 0.f;
+      for (int i = 0; i < 16; ++i) sT[sub][i] = cinit;
       if (sub < nsub) {
 #pragma unroll
         for (int s = 0; s < DS; ++s) {
@@ -163,37 +216,67 @@ __global__ __launch_bounds__(256) void af_attn_kernel(AttnArgs a) {
         }
       }
     }
-    // ---- scale, bias, key-range mask; running max
     float mx = -FLT_MAX;
+    if (GENERAL) {
+      // ---- bias, causal / key-range mask
 #pragma unroll
-    for (int sub = 0; sub < 2; ++sub) {
-      if (sub < nsub) {
+      for (int sub = 0; sub < 2; ++sub) {
+        if (sub < nsub) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int kb = key0 + sub * 32 + 8 * g + 4 * hh;  // keys kb .. kb+3 live in regs 4g .. 4g+3
-          floatx4 bias = {0.f, 0.f, 0.f, 0.f};
-          if (a.kbias) bias = *reinterpret_cast<const floatx4*>(a.kbias + (size_t)b * a.ldb + kb);
+          for (int g = 0; g < 4; ++g) {
+            const int kb = key0 + sub * 32 + 8 * g + 4 * hh;  // keys kb .. kb+3 live in regs 4g .. 4g+3
+            floatx4 bias = {0.f, 0.f, 0.f, 0.f};
+            if (a.kbias) bias = *reinterpret_cast<const floatx4*>(a.kbias + (size_t)b * a.ldb + kb);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float t = sT[sub][4 * g + e] * a.c + bias[e];
-            bool vis = kb + e < a.L;
-            if (a.causal_m > 0) vis = vis && ((kb + e) / a.causal_m <= query);
-            t = vis ? t : -INFINITY;
-            sT[sub][4 * g + e] = t;
-            mx = fmaxf(mx, t);
+            for (int e = 0; e < 4; ++e) {
+              float t = sT[sub][4 * g + e] + bias[e];
+              bool vis = kb + e < a.L;
+              if (a.causal_m > 0) vis = vis && ((kb + e) / a.causal_m <= query);
+              t = vis ? t : -INFINITY;
+              sT[sub][4 * g + e] = t;
+              mx = fmaxf(mx, t);
+            }
           }
         }
       }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; i += 2) {   // v_max3_f32 chains: 16 instructions for 32 scores
+        mx = fmaxf(fmaxf(mx, sT[0][i]), sT[0][i + 1]);
+        mx = fmaxf(fmaxf(mx, sT[1][i]), sT[1][i + 1]);
+      }
     }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m, mx);
-    const float alpha = __builtin_amdgcn_exp2f(m - m_new);
-    m = m_new;
-    l *= alpha;
+    if (GENERAL) {
+      // ---- rescale only when some lane's running max grew (wave-uniform branch; exact, not a threshold)
+      if (__builtin_amdgcn_ballot_w64(mx > m) != 0) {
+        const float m_new = fmaxf(m, mx);
+        const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+        m = m_new;
+        if (!ONES) l *= alpha;
 #pragma unroll
-    for (int t = 0; t < DT; ++t)
+        for (int t = 0; t < DT; ++t)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) o[t][i] *= alpha;
+          for (int i = 0; i < 16; ++i) o[t][i] *= alpha;
+      }
+      sT[0] = sT[0] - m;
+      sT[1] = sT[1] - m;
+    } else if (st == 0) {
+      m = mx;                       // first stage: scores are absolute, O and l are still zero
+      sT[0] = sT[0] - m;
+      sT[1] = sT[1] - m;
+    } else if (__builtin_amdgcn_ballot_w64(mx > 0.f) != 0) {
+      const float delta = fmaxf(mx, 0.f);   // scores are relative to m: the max grew by delta on these lanes
+      const float alpha = __builtin_amdgcn_exp2f(-delta);
+      m += delta;
+      if (!ONES) l *= alpha;
+#pragma unroll
+      for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[t][i] *= alpha;
+      sT[0] = sT[0] - delta;
+      sT[1] = sT[1] - delta;
+    }
 
     // ---- P^T = exp2(S^T - m): accumulator registers become the B operand of the PV product
     half8_t pf[2][2];
@@ -204,8 +287,8 @@ __global__ __launch_bounds__(256) void af_attn_kernel(AttnArgs a) {
         for (int s2 = 0; s2 < 2; ++s2) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
-            const float p = __builtin_amdgcn_exp2f(sT[sub][8 * s2 + j] - m_new);
-            l += p;
+            const float p = __builtin_amdgcn_exp2f(sT[sub][8 * s2 + j]);
+            if (!ONES) l += p;
             pf[sub][s2][j] = (half_t)p;
           }
         }
@@ -232,12 +315,19 @@ __global__ __launch_bounds__(256) void af_attn_kernel(AttnArgs a) {
       }
     }
 
-    if (more) store_stage((st + 1) & 1);
+    if (more) store_stage((st + 1) & 1, key0 + KB);
     __syncthreads();
   }
 
   // ---- normalise and store: lane holds d rows {32t + 8g + 4hh + e} of its query
-  l += __shfl_xor(l, 32, 64);
+  if (ONES) {
+    // row DV-1 of O^T (the ones row) lives in register 15 of the last tile on the upper half-wave
+    const float mine = o[DT - 1][15];
+    const float other = __shfl_xor(mine, 32, 64);
+    l = hh ? mine : other;
+  } else {
+    l += __shfl_xor(l, 32, 64);
+  }
   const float inv = 1.0f / l;
   if (a.lse2 && query < a.Nq && hh == 0) a.lse2[((size_t)b * a.heads + h) * a.ld_lse + query] = m + __builtin_amdgcn_logf(l);
   if (query < a.Nq) {
@@ -257,20 +347,29 @@ __global__ __launch_bounds__(256) void af_attn_kernel(AttnArgs a) {
   }
 }
 
-template <int DS>
-int launch_attn(const AttnArgs& a, hipStream_t stream) {
+template <int DS, bool ONES, bool GENERAL>
+int launch_attn2(const AttnArgs& a, hipStream_t stream) {
   constexpr int DP = 16 * DS, DT = (DS + 1) / 2, DV = 32 * DT;
   constexpr size_t lds = (size_t)2 * (KB * (DP + 8) + 2 * DV * VST) * sizeof(half_t);
   static bool attr_set = false;  // benign race: idempotent attribute
   if (lds > 65536 && !attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&af_attn_kernel<DS>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&af_attn_kernel<DS, ONES, GENERAL>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return af_fail(AF_E_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
     attr_set = true;
   }
-  dim3 grid((a.Nq + 127) / 128, a.heads, a.B), block(256);
-  hipLaunchKernelGGL(af_attn_kernel<DS>, grid, block, lds, stream, a);
+  const int qblocks = (a.Nq + 127) / 128, bh8 = (a.B * a.heads + 7) / 8 * 8;
+  dim3 grid(qblocks * bh8), block(256);
+  hipLaunchKernelGGL((af_attn_kernel<DS, ONES, GENERAL>), grid, block, lds, stream, a);
   return af_check_launch("af_attention");
+}
+
+template <int DS>
+int launch_attn(const AttnArgs& a, hipStream_t stream) {
+  constexpr int DV = 32 * ((DS + 1) / 2);
+  const bool general = a.kbias != nullptr || a.causal_m > 0 || a.L % KB != 0;
+  if (DV > a.d) return general ? launch_attn2<DS, true, true>(a, stream) : launch_attn2<DS, true, false>(a, stream);
+  return general ? launch_attn2<DS, false, true>(a, stream) : launch_attn2<DS, false, false>(a, stream);
 }
 
 // explicit scores / probabilities for the capture path: one wave per (b, h, query) row, L <= 128
@@ -332,7 +431,6 @@ extern "C" int af_attention_ex(const void* q, const void* k, const void* vt, voi
   AF_REQUIRE(B > 0 && Nq > 0 && L > 0 && heads > 0 && d > 0, "af_attention: bad sizes");
   AF_REQUIRE(d % 8 == 0, "af_attention: head dim must be a multiple of 8");
   AF_SUPPORTED(d <= 160, "af_attention: head dim > 160");
-  AF_REQUIRE(heads <= 65535 && B <= 65535, "af_attention: grid limit");
   const int C = heads * d;
   AF_REQUIRE(ldq >= C && ldk >= C && ldo >= C && ldq % 8 == 0 && ldk % 8 == 0 && ldo % 4 == 0,
              "af_attention: bad row strides");

@@ -98,13 +98,9 @@ __device__ __forceinline__ void load_tr(half8_t (&r)[NC], const half_t* base, in
     const int row = i >> 2, ch = i & 3;
     const int tk = tok0 + ch * 8;
     const bool ok = i < CH && row < d && tk < ntok;
-    half8_t v = ok ? *reinterpret_cast<const half8_t*>(base + (size_t)row * ld + tk) : zero8;
-    if (ok && tk + 8 > ntok) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e)
-        if (tk + e >= ntok) v[e] = (half_t)0;
-    }
-    r[j] = v;
+    // no VALU touch of the loaded chunk here (it would force a vmcnt(0) wait at the load); the transposed sources are
+    // produced by transpose_heads_kernel, which zero-fills tokens >= ntok up to the row stride, so no tail mask is needed
+    r[j] = ok ? *reinterpret_cast<const half8_t*>(base + (size_t)row * ld + tk) : zero8;
   }
 }
 template <int DV, int NC>

@@ -1,0 +1,71 @@
+#!/usr/bin/env python
+"""Micro-benchmark of one kernel shape on the GPU box (also the target of rocprofv3 --pmc runs).
+    python tools/bench_kernel.py attn  B N L heads d [reps]
+    python tools/bench_kernel.py gemm  M N K [tile] [splits] [reps]
+    python tools/bench_kernel.py conv  B H W Cin Cout [tile] [splits] [reps]
+    python tools/bench_kernel.py gn    B HW C [reps]
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+
+def timeit(fn, reps):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def main():
+    from adaface_dev_amd import ops
+    kind = sys.argv[1]
+    a = [int(v) for v in sys.argv[2:]]
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(0)
+    rnd = lambda *s: torch.randn(*s, generator=g).half().to(dev)
+    if kind == "attn":
+        B, N, L, H, d = a[:5]
+        reps = a[5] if len(a) > 5 else 20
+        C = H * d
+        q, k, v = rnd(B * N, C), rnd(B * L, C), rnd(B * L, C)
+        vt = ops.transpose_tokens(v, B, L, C, C)
+        ms = timeit(lambda: ops.attention(q, k, vt, B=B, Nq=N, L=L, heads=H, d=d, ldq=C, ldk=C), reps)
+        fl = 4.0 * B * H * N * L * d
+        print(f"attn B{B} N{N} L{L} H{H} d{d}: {ms * 1e3:.1f} us  {fl / ms / 1e9:.1f} TFLOP/s")
+    elif kind == "gemm":
+        M, N, K = a[:3]
+        tile, splits = (a[3] if len(a) > 3 else 0), (a[4] if len(a) > 4 else 0)
+        reps = a[5] if len(a) > 5 else 20
+        x, w = rnd(M, K), rnd(N, K)
+        pw = ops.pack_matrix(w, None, dev)
+        ms = timeit(lambda: ops.gemm(x, pw, tile=tile, splits=splits), reps)
+        print(f"gemm M{M} N{N} K{K} tile{tile} splits{splits}: {ms * 1e3:.1f} us  {2.0 * M * N * K / ms / 1e9:.1f} TFLOP/s")
+    elif kind == "conv":
+        B, H, W, ci, co = a[:5]
+        tile, splits = (a[5] if len(a) > 5 else 0), (a[6] if len(a) > 6 else 0)
+        reps = a[7] if len(a) > 7 else 20
+        x, w = rnd(B, H, W, ci), rnd(co, ci, 3, 3)
+        pw = ops.pack_conv3x3(w, None, dev)
+        ms = timeit(lambda: ops.conv3x3(x, pw, tile=tile, splits=splits), reps)
+        print(f"conv B{B} {H}x{W} {ci}->{co} tile{tile} splits{splits}: {ms * 1e3:.1f} us  {2.0 * B * H * W * co * 9 * ci / ms / 1e9:.1f} TFLOP/s")
+    elif kind == "gn":
+        B, HW, C = a[:3]
+        reps = a[3] if len(a) > 3 else 20
+        x = rnd(B, HW, C)
+        gm, bt = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+        ms = timeit(lambda: ops.groupnorm(x, gm, bt, 1e-5, True), reps)
+        print(f"gn B{B} HW{HW} C{C}: {ms * 1e3:.1f} us  {3.0 * B * HW * C * 2 / ms / 1e6:.1f} GB/s (2R+1W)")
+
+
+if __name__ == "__main__":
+    main()
