@@ -37,7 +37,7 @@ class GemmDesc(C.Structure):
         ("stride", C.c_int32), ("upsample", C.c_int32), ("rows_per_batch", C.c_int32), ("ld_rowbias", C.c_int32),
         ("act", C.c_int32), ("out_mode", C.c_int32), ("ld_out", C.c_int32), ("split_col", C.c_int32),
         ("ld_out2", C.c_int32), ("tile", C.c_int32), ("splits", C.c_int32),
-        ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64), ("zeros", C.c_void_p),
     ]
 
 

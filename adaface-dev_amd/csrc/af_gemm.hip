@@ -15,6 +15,8 @@
 //     conflict-free; global->register->LDS staging, double-buffered, one barrier per K step
 //     (the next tile's global loads are issued before the MFMAs of the current one);
 //   * workgroup ids are remapped so each XCD (private L2) walks a contiguous range of tiles.
+#include <stdlib.h>
+
 #include "af_common.h"
 
 namespace {
@@ -40,7 +42,12 @@ struct GemmDev {
 constexpr int BK = 64;
 enum { EPI_STD = 0, EPI_GEGLU = 1, EPI_SPLIT_T = 2 };
 
-template <int BM, int BN, int TAPS, int EPI>
+// FAST (3x3 only): both channel counts are multiples of 64 and there is no upsampling, so one 64-wide K step lies
+// inside ONE tap and ONE source for the whole workgroup: tap, channel offset and source are scalar (SGPR) values,
+// and a thread only needs a precomputed per-row centre-pixel offset and a 9-bit mask of in-bounds taps.  This
+// replaces ~170 VALU/SALU instructions of im2col address generation per K step (more than the 32 MFMAs cost)
+// with ~4 VALU per row.
+template <int BM, int BN, int TAPS, int EPI, bool FAST = false>
 __global__ __launch_bounds__(256, 2) void af_gemm_kernel(GemmDev p) {
   constexpr int WM = BM / 2, WN = BN / 2;    // per-wave tile
   constexpr int TM = WM / 16, TN = WN / 16;  // 16x16 MFMA tiles per wave
@@ -88,6 +95,22 @@ __global__ __launch_bounds__(256, 2) void af_gemm_kernel(GemmDev p) {
       a_iy0[i] = a_ix0[i] = 0;
     }
   }
+  // FAST loader state: a_base[i] = linear index of the centre input pixel (or -1), a_mask[i] = in-bounds taps
+  unsigned a_mask[AI];
+  if (FAST) {
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      unsigned mk = 0;
+      const int cy = a_iy0[i] + 1, cx = a_ix0[i] + 1;
+#pragma unroll
+      for (int t9 = 0; t9 < 9; ++t9) {
+        const int iy = cy + t9 / 3 - 1, ix = cx + t9 % 3 - 1;
+        if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) mk |= 1u << t9;
+      }
+      a_mask[i] = a_iy0[i] < -1000 ? 0u : mk;
+      a_base[i] = a_base[i] + cy * p.W + cx;
+    }
+  }
   const int nk_total = p.kpad / BK;
   const int kt_begin = blockIdx.y * p.kt_per_split;
   const int kt_end = min(nk_total, kt_begin + p.kt_per_split);
@@ -104,7 +127,22 @@ __global__ __launch_bounds__(256, 2) void af_gemm_kernel(GemmDev p) {
     const half_t* wp = p.wt + (size_t)(tile_n * BN + rb) * p.kpad + kt * BK + cc * 8;
 #pragma unroll
     for (int i = 0; i < WI; ++i) rw[i] = *reinterpret_cast<const half8_t*>(wp + (size_t)i * 32 * p.kpad);
-    if (TAPS == 9) {
+    if (TAPS == 9 && FAST) {
+      // workgroup-uniform: tap and channel offset of this K step (k = kt*64 is a multiple of 64 | Cin)
+      const int k0 = kt * BK;
+      const int tp = k0 / Cin;
+      const int c0 = k0 - tp * Cin;
+      const bool first = c0 < p.c1;
+      const half_t* src = first ? p.a1 : p.a2;
+      const int cs = first ? p.c1 : p.c2;
+      const int coff = (first ? c0 : c0 - p.c1) + cc * 8;
+      const int dpix = (tp / 3 - 1) * p.W + (tp % 3 - 1);
+#pragma unroll
+      for (int i = 0; i < AI; ++i) {
+        const bool ok = (a_mask[i] >> tp) & 1u;   // tp >= 9 (K padding) -> no bit set
+        ra[i] = ok ? *reinterpret_cast<const half8_t*>(src + (size_t)(a_base[i] + dpix) * cs + coff) : zero8;
+      }
+    } else if (TAPS == 9) {
       const bool kval = tap < 9;
       const int ky = tap / 3, kx = tap - ky * 3;
       const half_t* src;
@@ -317,7 +355,7 @@ __global__ __launch_bounds__(256) void af_splitk_reduce_kernel(GemmDev p) {
   *reinterpret_cast<half4_t*>(p.out + (size_t)m * p.ld_out + n0) = h;
 }
 
-template <int BM, int BN, int TAPS, int EPI>
+template <int BM, int BN, int TAPS, int EPI, bool FAST = false>
 int launch(const GemmDev& p0, hipStream_t stream) {
   GemmDev p = p0;
   const int tiles_m = (p.M + BM - 1) / BM;
@@ -328,7 +366,7 @@ int launch(const GemmDev& p0, hipStream_t stream) {
   p.splits = (nk + p.kt_per_split - 1) / p.kt_per_split;  // no empty split
   const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(half_t);
   dim3 grid(tiles_m * p.tiles_n, p.splits), block(256);
-  hipLaunchKernelGGL((af_gemm_kernel<BM, BN, TAPS, EPI>), grid, block, lds, stream, p);
+  hipLaunchKernelGGL((af_gemm_kernel<BM, BN, TAPS, EPI, FAST>), grid, block, lds, stream, p);
   if (EPI == EPI_STD && p.splits > 1) {
     const long n = (long)p.M * (p.N >> 2);
     hipLaunchKernelGGL(af_splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, p);
@@ -338,11 +376,20 @@ int launch(const GemmDev& p0, hipStream_t stream) {
 
 template <int TAPS, int EPI>
 int launch_tile(const GemmDev& p, int tile, hipStream_t stream) {
+  static const bool no_fast = getenv("AF_NO_FASTCONV") != nullptr;   // A/B switch for profiling
+  if (!no_fast && TAPS == 9 && EPI == EPI_STD && !p.upsample && p.c1 % BK == 0 && p.c2 % BK == 0) {
+    if (tile == 1) return launch<128, 128, TAPS, EPI, true>(p, stream);
+    return launch<64, 64, TAPS, EPI, true>(p, stream);
+  }
   if (tile == 1) return launch<128, 128, TAPS, EPI>(p, stream);
   return launch<64, 64, TAPS, EPI>(p, stream);
 }
 
 }  // namespace
+
+// af_gemm3.hip
+int af_gemm3_try_launch(const af_gemm_desc* d, int splits, int wide, hipStream_t stream);
+int af_gemm3_effective_splits(const af_gemm_desc* d, int splits);
 
 extern "C" int af_gemm(const af_gemm_desc* d, void* stream) {
   AF_REQUIRE(d != nullptr, "af_gemm: null descriptor");
@@ -432,10 +479,23 @@ extern "C" int af_gemm(const af_gemm_desc* d, void* stream) {
     const long t128 = (long)((d->M + 127) / 128) * ((d->N + 127) / 128);
     tile = (t128 >= 192 && d->N >= 96) ? 1 : 2;
   }
-  AF_REQUIRE(tile == 1 || tile == 2, "af_gemm: tile must be 0, 1 or 2");
+  AF_REQUIRE(tile >= 1 && tile <= 4, "af_gemm: tile must be 0 .. 4");
 
   AfLaunchScope scope(AF_FAM_GEMM, stream);
   hipStream_t s = (hipStream_t)stream;
+  if (tile >= 3) {
+    const int eff = af_gemm3_effective_splits(d, p.splits);
+    const int rc3 = af_gemm3_try_launch(d, p.splits, tile == 4, s);
+    if (rc3 == 0) return af_check_launch("af_gemm(tile 3)");
+    if (rc3 == 2) {
+      p.splits = eff;
+      p.ld_out = d->ld_out ? d->ld_out : d->N;
+      const long n = (long)p.M * (p.N >> 2);
+      hipLaunchKernelGGL(af_splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p);
+      return af_check_launch("af_gemm(tile 3, split-K)");
+    }
+    tile = 1;  // outside the pipelined kernel's scope
+  }
   if (geglu) return d->taps == 9 ? af_fail(AF_E_UNSUPPORTED, "af_gemm: GEGLU on a 3x3 conv")
                                  : launch_tile<1, EPI_GEGLU>(p, tile, s);
   if (d->out_mode == AF_OUT_SPLIT_T)

@@ -1,0 +1,388 @@
+// af_gemm3.hip -- pipelined variant of the GEMM / implicit-conv kernel ("tile 3"):
+// operands go HBM -> LDS by LDS-DMA (global_load_lds_dwordx4, no VGPR round trip, no ds_write) into a
+// 4-slot ring of 128 x 32 (A) + 128 x 32 (W) fp16 tiles, three K-steps ahead of the MFMAs; a wave waits
+// only for its own oldest stage with a COUNTED s_waitcnt vmcnt(8) and one raw s_barrier per K-step publishes
+// it to the other waves.  The rocprofv3 PMC profile of the register-staged kernel (af_gemm.hip) showed the
+// MFMA pipe ~33 % busy with both resident waves parked on the per-K-step chain
+// {global-load latency -> vmcnt(0) -> 8 x ds_write_b128 -> barrier -> ds_read latency}; this structure takes
+// the load latency and the LDS writes off that chain.
+//
+// LDS image: rows of 32 halves (64 B).  One LDS-DMA wave-instruction writes 1 KiB = 16 rows x 4 chunks of 16 B,
+// lane-linear (lane -> row lane>>2, physical chunk lane&3), so the XOR swizzle that makes the MFMA fragment
+// reads (ds_read_b128, 16 rows x one chunk) conflict-free is applied on the SOURCE side: the lane that fills
+// physical chunk p of row r fetches logical chunk p ^ PI[(r>>2)&3], PI = {0,2,3,1}; the reader applies the same
+// involution.  Halo / out-of-range lanes fetch from a 16-byte zero page.
+//
+// Scope: standard epilogue (bias, per-batch row bias, SiLU / quick-GELU, residual, split-K partials); plain rows or
+// 3x3 taps with channel counts that are multiples of 32 and no upsampling.  Everything else stays on af_gemm.hip.
+#include <stdlib.h>
+
+#include "af_common.h"
+
+namespace {
+
+struct Gemm3Dev {
+  const half_t* a1;
+  const half_t* a2;
+  const half_t* wt;
+  const half_t* zeros;
+  const float* bias;
+  const half_t* rowbias;
+  const half_t* residual;
+  half_t* out;
+  half_t* out2;
+  int split_col, ld_out2;
+  int M, N, K, kpad, npad;
+  int c1, c2, lda1, lda2;
+  int H, W, Ho, Wo, HoWo, stride;
+  int rows_per_batch, ld_rowbias, act, ld_out;
+  int tiles_n, splits, kt_per_split;
+  float* ws;
+  int ablate;  // profiling only (AF_GEMM3_ABLATE): 1 = no DMA after the prologue, 2 = fragments read once, 4 = no barrier
+};
+
+constexpr int BK3 = 32;
+constexpr int NST = 4;                 // ring slots
+
+
+// PI = {0, 2, 3, 1} packed two bits per entry: 0b01'11'10'00 = 0x78, PI[g] = (0x78 >> 2g) & 3
+
+__device__ __forceinline__ void glds16(const half_t* src, char* lds_dst) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+// Tile shape: NWM x NWN waves, each wave 64 (M) x 16*TN (N).  Two instantiations:
+//   <2, 2, 4>: 128 x 128, 4 waves, 2 workgroups per CU             (64 FLOP per operand byte)
+//   <2, 4, 5>: 128 x 320, 8 waves, 1 workgroup per CU              (91 FLOP per operand byte)
+// The ablation in profiles/r01d_gemm_ablation.txt shows the 128 x 128 kernel is bound by L2 -> CU operand
+// traffic (no-DMA build: 555 -> 900 TFLOP/s; no-LDS-read build: unchanged), and every channel count of SD-1.5 is a
+// multiple of 320, so the wide tile raises the intensity AND tiles N exactly (M = 32768, N = 320 -> 256 tiles).
+// Every wave issues exactly 4 LDS-DMA pieces per stage in both shapes (2 A + 2 W, or 1 A + 3 W with the W pieces
+// padded from 20 to 24; padding pieces fetch the zero page), so the counted waits are the same constants.
+enum { E3_STD = 0, E3_GEGLU = 1, E3_SPLIT_T = 2 };
+
+template <int TAPS, int NWM, int NWN, int TN, int EPI>
+__global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void af_gemm3_kernel(Gemm3Dev p) {
+  constexpr int TM = 4;
+  constexpr int NW = NWM * NWN;
+  constexpr int BM = NWM * 64, BN = NWN * TN * 16;
+  constexpr int APW = (BM / 16) / NW;                 // A pieces (16 rows) per wave per stage
+  constexpr int WPW = (BN / 16 + NW - 1) / NW;        // W pieces per wave per stage
+  constexpr int DPS = APW + WPW;                      // DMA pieces per wave per stage (3 or 4)
+  static_assert(APW * NW * 16 == BM && (DPS == 3 || DPS == 4), "every wave must issue DPS DMA pieces per stage");
+  constexpr int WROWS = WPW * NW * 16;                // W rows held per stage (>= BN)
+  constexpr int STAGE = (BM + WROWS) * 64;            // bytes
+  extern __shared__ __attribute__((aligned(16))) char af_smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave % NWM, wn = wave / NWM;
+
+  int tile_m, tile_n;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    tile_m = lid / p.tiles_n;
+    tile_n = lid - tile_m * p.tiles_n;
+  }
+
+  // ---- loader state: wave w fills A pieces {w*APW + j} and W pieces {w + NW*j}
+  const int lrow = lane >> 2;                                     // row inside a 16-row piece
+  const int lc = (lane & 3) ^ ((0x78 >> (2 * (lane >> 4))) & 3);  // logical chunk this lane fetches (source-side swizzle)
+  const int Cin = p.c1 + p.c2;
+  int a_base[APW];
+  unsigned a_mask[APW];
+  const half_t* wptr[WPW];
+  bool wok[WPW];
+#pragma unroll
+  for (int j = 0; j < APW; ++j) {
+    const int m = tile_m * BM + (wave * APW + j) * 16 + lrow;
+    if (TAPS == 9) {
+      unsigned mk = 0;
+      int base = 0;
+      if (m < p.M) {
+        const int b = m / p.HoWo;
+        const int rem = m - b * p.HoWo;
+        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        const int cy = oy * p.stride, cx = ox * p.stride;
+#pragma unroll
+        for (int t9 = 0; t9 < 9; ++t9) {
+          const int iy = cy + t9 / 3 - 1, ix = cx + t9 % 3 - 1;
+          if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) mk |= 1u << t9;
+        }
+        base = (b * p.H + cy) * p.W + cx;
+      }
+      a_mask[j] = mk;
+      a_base[j] = base;
+    } else {
+      a_mask[j] = m < p.M ? 1u : 0u;
+      a_base[j] = m;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < WPW; ++j) {
+    const int piece = wave + NW * j;
+    const int n = tile_n * BN + piece * 16 + lrow;
+    wok[j] = piece * 16 < BN && n < p.npad;            // padding pieces / rows beyond the packed weight -> zero page
+    wptr[j] = p.wt + (size_t)(wok[j] ? n : 0) * p.kpad + lc * 8;
+  }
+
+  auto issue_stage = [&](int kt, int slot) {
+    char* As = af_smem + slot * STAGE;
+    char* Ws = As + BM * 64;
+    const int k0 = kt * BK3;
+    if (TAPS == 9) {
+      const int tp = k0 / Cin;                      // workgroup-uniform (32 | c1, c2)
+      const int c0 = k0 - tp * Cin;
+      const bool first = c0 < p.c1;
+      const half_t* src = first ? p.a1 : p.a2;
+      const int cs = first ? p.c1 : p.c2;
+      const int coff = (first ? c0 : c0 - p.c1) + lc * 8;
+      const int dpix = (tp / 3 - 1) * p.W + (tp % 3 - 1);
+#pragma unroll
+      for (int j = 0; j < APW; ++j) {
+        const bool ok = (a_mask[j] >> tp) & 1u;     // tp >= 9 (K padding): no bit set
+        const half_t* g = ok ? src + (size_t)(a_base[j] + dpix) * cs + coff : p.zeros;
+        glds16(g, As + (wave * APW + j) * 1024);
+      }
+    } else {
+      const bool first = k0 < p.c1;                 // uniform: 32 | c1
+      const half_t* src = first ? p.a1 : p.a2;
+      const int ld = first ? p.lda1 : p.lda2;
+      const int koff = (first ? k0 : k0 - p.c1) + lc * 8;
+      const bool kval = k0 + lc * 8 < p.K;
+#pragma unroll
+      for (int j = 0; j < APW; ++j) {
+        const bool ok = kval && a_mask[j];
+        const half_t* g = ok ? src + (size_t)a_base[j] * ld + koff : p.zeros;
+        glds16(g, As + (wave * APW + j) * 1024);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < WPW; ++j) glds16(wok[j] ? wptr[j] + k0 : p.zeros, Ws + (wave + NW * j) * 1024);
+  };
+
+  floatx4 acc[TN][TM];
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) acc[tn][tm] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+  const int fr = lane & 15, fq = lane >> 4;
+  const int rd_off = fr * 64 + ((fq ^ ((0x78 >> (2 * ((fr >> 2) & 3))) & 3)) * 16);   // swizzled fragment offset inside a 16-row piece
+
+  const int nk_total = p.kpad / BK3;
+  const int kt_begin = blockIdx.y * p.kt_per_split;
+  const int kt_end = min(nk_total, kt_begin + p.kt_per_split);
+  const int nk = kt_end - kt_begin;
+
+  // prologue: three stages in flight
+#pragma unroll
+  for (int s = 0; s < NST - 1; ++s)
+    if (s < nk) issue_stage(kt_begin + s, s);
+
+  half8_t wf[TN], xf[TM];
+  for (int i = 0; i < nk; ++i) {
+    // my own pieces of stage i have landed when at most the (up to two) younger stages' 8 DMAs are still in flight
+    if (i + 2 < nk) {
+      if (DPS == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else if (i + 1 < nk) {
+      if (DPS == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    if (!(p.ablate & 4)) __builtin_amdgcn_s_barrier();   // every wave's pieces of stage i are in LDS; everyone is done reading slot (i-1)%4
+    if (i + NST - 1 < nk && !(p.ablate & 1)) issue_stage(kt_begin + i + NST - 1, (i + NST - 1) % NST);
+
+    const char* As = af_smem + (i % NST) * STAGE;
+    const char* Ws = As + BM * 64;
+    if (!(p.ablate & 2) || i == 0) {
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) wf[tn] = *reinterpret_cast<const half8_t*>(Ws + (wn * TN * 16 + tn * 16) * 64 + rd_off);
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) xf[tm] = *reinterpret_cast<const half8_t*>(As + (wm * 64 + tm * 16) * 64 + rd_off);
+    }
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+        acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[tn], xf[tm], acc[tn][tm], 0, 0, 0);
+  }
+
+  // ---- epilogue (identical arithmetic to af_gemm.hip's standard epilogue)
+  if (p.splits > 1) {
+    float* wsp = p.ws + (size_t)blockIdx.y * p.M * p.N;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      const int m = tile_m * BM + wm * 64 + tm * 16 + fr;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        const int n0 = tile_n * BN + wn * TN * 16 + tn * 16 + 4 * fq;
+        if (n0 < p.N) *reinterpret_cast<floatx4*>(wsp + (size_t)m * p.N + n0) = acc[tn][tm];
+      }
+    }
+    return;
+  }
+  if (EPI == E3_GEGLU) {
+    // W rows interleaved [16 value | 16 gate]: adjacent MFMA n-tiles pair up in the same lane / register
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      const int m = tile_m * BM + wm * 64 + tm * 16 + fr;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int tn = 0; tn + 1 < TN; tn += 2) {
+        const int nt = tile_n * BN + wn * TN * 16 + tn * 16;
+        const int n0 = nt + 4 * fq, no = (nt >> 1) + 4 * fq;
+        if (no >= (p.N >> 1)) continue;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float xv = acc[tn][tm][e], gv = acc[tn + 1][tm][e];
+          if (p.bias) {
+            xv += p.bias[n0 + e];
+            gv += p.bias[n0 + 16 + e];
+          }
+          v[e] = xv * af_gelu_erf(gv);
+        }
+        const half4_t h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+        *reinterpret_cast<half4_t*>(p.out + (size_t)m * p.ld_out + no) = h;
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    const int m = tile_m * BM + wm * 64 + tm * 16 + fr;
+    if (m >= p.M) continue;
+    const int bidx = (p.rowbias || EPI == E3_SPLIT_T) ? m / p.rows_per_batch : 0;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const int n0 = tile_n * BN + wn * TN * 16 + tn * 16 + 4 * fq;
+      if (n0 >= p.N) continue;
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = acc[tn][tm][e];
+      if (p.bias) {
+        const floatx4 bv = *reinterpret_cast<const floatx4*>(p.bias + n0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += bv[e];
+      }
+      if (p.rowbias) {
+        const half4_t rv = *reinterpret_cast<const half4_t*>(p.rowbias + (size_t)bidx * p.ld_rowbias + n0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
+      }
+      if (p.act == 1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = af_silu(v[e]);
+      } else if (p.act == 3) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] / (1.0f + __expf(-1.702f * v[e]));
+      }
+      if (EPI == E3_SPLIT_T && n0 >= p.split_col) {   // V columns: written transposed [B][N - split_col][ld_out2]
+        const int tok = m - bidx * p.rows_per_batch;
+        half_t* o2 = p.out2 + ((size_t)bidx * (p.N - p.split_col) + (n0 - p.split_col)) * p.ld_out2 + tok;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o2[(size_t)e * p.ld_out2] = (half_t)v[e];
+        continue;
+      }
+      if (p.residual) {
+        const half4_t rv = *reinterpret_cast<const half4_t*>(p.residual + (size_t)m * p.N + n0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
+      }
+      const half4_t h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+      *reinterpret_cast<half4_t*>(p.out + (size_t)m * p.ld_out + n0) = h;
+    }
+  }
+}
+
+template <int TAPS, int NWM, int NWN, int TN, int EPI = E3_STD>
+void launch3(const Gemm3Dev& p0, hipStream_t stream) {
+  Gemm3Dev p = p0;
+  constexpr int NW = NWM * NWN, BM = NWM * 64, BN = NWN * TN * 16;
+  constexpr int WROWS = ((BN / 16 + NW - 1) / NW) * NW * 16;
+  constexpr size_t lds = (size_t)NST * (BM + WROWS) * 64;
+  p.tiles_n = (p.N + BN - 1) / BN;
+  const int tiles_m = (p.M + BM - 1) / BM;
+  static bool attr_set = false;
+  if (lds > 65536 && !attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&af_gemm3_kernel<TAPS, NWM, NWN, TN, EPI>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  dim3 grid(tiles_m * p.tiles_n, p.splits), block(64 * NW);
+  hipLaunchKernelGGL((af_gemm3_kernel<TAPS, NWM, NWN, TN, EPI>), grid, block, lds, stream, p);
+}
+
+}  // namespace
+
+// Called by af_gemm (af_gemm.hip) for tile == 3 after the common argument validation.  Returns 1 if the shape is
+// outside this kernel's scope (caller falls back), 0 after a launch.
+int af_gemm3_try_launch(const af_gemm_desc* d, int splits, int wide, hipStream_t stream) {
+  const bool geglu = d->act == AF_ACT_GEGLU, split_t = d->out_mode == AF_OUT_SPLIT_T;
+  if (d->upsample || d->c1 % BK3 != 0 || d->c2 % BK3 != 0 || d->zeros == nullptr) return 1;
+  if ((geglu || split_t) && (d->taps != 1 || splits > 1)) return 1;
+  if (geglu && (!wide || d->N % 256 != 0)) return 1;          // GEGLU: 128 x 256 tile only
+  if (!geglu && wide && d->N % 320 != 0) return 1;
+  Gemm3Dev p;
+  p.a1 = (const half_t*)d->a1;
+  p.a2 = (const half_t*)d->a2;
+  p.wt = (const half_t*)d->wt;
+  p.zeros = (const half_t*)d->zeros;
+  p.bias = (const float*)d->bias;
+  p.rowbias = (const half_t*)d->rowbias;
+  p.residual = (const half_t*)d->residual;
+  p.out = (half_t*)d->out;
+  p.out2 = (half_t*)d->out2;
+  p.split_col = d->split_col;
+  p.ld_out2 = d->ld_out2;
+  p.M = d->M;
+  p.N = d->N;
+  p.K = d->K;
+  p.kpad = d->kpad;
+  p.npad = (d->N + 127) / 128 * 128;   // rows present in the packed weight
+  p.c1 = d->c1;
+  p.c2 = d->c2;
+  p.lda1 = d->lda1 ? d->lda1 : d->c1;
+  p.lda2 = d->lda2 ? d->lda2 : d->c2;
+  p.H = d->H;
+  p.W = d->W;
+  p.Ho = d->Ho;
+  p.Wo = d->Wo;
+  p.HoWo = d->Ho * d->Wo;
+  p.stride = d->stride ? d->stride : 1;
+  p.rows_per_batch = d->rows_per_batch > 0 ? d->rows_per_batch : d->M;
+  p.ld_rowbias = d->ld_rowbias;
+  p.act = d->act == AF_ACT_SILU ? 1 : (d->act == AF_ACT_QUICKGELU ? 3 : 0);
+  p.ld_out = d->ld_out ? d->ld_out : (geglu ? d->N / 2 : (split_t ? d->split_col : d->N));
+  p.tiles_n = 0;
+  const int nk = p.kpad / BK3;
+  p.splits = splits > 1 ? splits : 1;
+  if (p.splits > nk) p.splits = nk;
+  p.kt_per_split = (nk + p.splits - 1) / p.splits;
+  p.splits = (nk + p.kt_per_split - 1) / p.kt_per_split;
+  p.ws = (float*)d->workspace;
+  static const int ablate = getenv("AF_GEMM3_ABLATE") ? atoi(getenv("AF_GEMM3_ABLATE")) : 0;
+  p.ablate = ablate;
+  if (geglu) {
+    launch3<1, 2, 4, 4, E3_GEGLU>(p, stream);
+  } else if (split_t) {
+    if (wide) launch3<1, 2, 4, 5, E3_SPLIT_T>(p, stream); else launch3<1, 2, 2, 4, E3_SPLIT_T>(p, stream);
+  } else if (wide) {
+    if (d->taps == 9) launch3<9, 2, 4, 5>(p, stream); else launch3<1, 2, 4, 5>(p, stream);
+  } else {
+    if (d->taps == 9) launch3<9, 2, 2, 4>(p, stream); else launch3<1, 2, 2, 4>(p, stream);
+  }
+  return p.splits > 1 ? 2 : 0;   // 2: caller must run the split-K reduce pass with p.splits
+}
+
+int af_gemm3_effective_splits(const af_gemm_desc* d, int splits) {
+  const int nk = d->kpad / BK3;
+  int s = splits > 1 ? splits : 1;
+  if (s > nk) s = nk;
+  const int per = (nk + s - 1) / s;
+  return (nk + per - 1) / per;
+}

@@ -108,6 +108,17 @@ def tune_table():
     return _tune_table
 
 
+_zero_pages = {}
+
+
+def _zero_page(device) -> torch.Tensor:
+    z = _zero_pages.get(device)
+    if z is None:
+        z = torch.zeros(64, dtype=F16, device=device)
+        _zero_pages[device] = z
+    return z
+
+
 def _splitk_workspace(device) -> torch.Tensor:
     ws = _splitk_ws.get(device)
     if ws is None:
@@ -125,6 +136,7 @@ def _launch_gemm(d: "GemmDesc", device, what: str, tile: int = 0, splits: int = 
         else:
             tile, splits = tune_table().get(key, (0, 1))
     d.tile = tile
+    d.zeros = _zero_page(device).data_ptr()
     d.splits = max(1, splits)
     if d.splits > 1:
         if d.act == AF_ACT_GEGLU or d.out_mode != AF_OUT_NORMAL:

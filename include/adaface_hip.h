@@ -103,11 +103,14 @@ typedef struct af_gemm_desc {
   int32_t ld_out;       /* elements; 0 -> N (or N/2 for GEGLU) */
   int32_t split_col;    /* AF_OUT_SPLIT_T */
   int32_t ld_out2;      /* AF_OUT_SPLIT_T: tokens per batch item rounded up to 8 */
-  int32_t tile;         /* 0 = auto, 1 = 128x128, 2 = 64x64 */
+  int32_t tile;         /* 0 = auto, 1 = 128x128, 2 = 64x64 (register-staged), 3 = 128x128 and 4 = 128x320 LDS-DMA
+                           pipelined ring (standard epilogue, channel counts % 32 == 0, no upsample, tile 4: N % 320
+                           == 0; otherwise falls back to 1) */
   int32_t splits;       /* split-K factor (<=1: none).  >1 needs the standard epilogue and a workspace:
                            each split writes an fp32 partial [M][N], a second launch reduces + applies the epilogue */
   void* workspace;      /* fp32, >= splits*M*N*4 bytes when splits > 1 */
   int64_t workspace_bytes;
+  const void* zeros;    /* >= 16 bytes of zeros, 16-byte aligned: source of halo / out-of-range lanes (tile 3) */
 } af_gemm_desc;
 
 int af_gemm(const af_gemm_desc* d, void* stream);

@@ -66,6 +66,65 @@ def test_gemm_and_conv_split_k(dev, tile, splits):
     assert rel_l2(oc.float().cpu().permute(0, 3, 1, 2).numpy(), refc.numpy()) < TOL
 
 
+@pytest.mark.parametrize("M,N,K,splits", [(256, 128, 64, 1), (1000, 320, 320, 1), (616, 640, 768, 2), (4096, 320, 1280, 1), (130, 4, 320, 1),
+                                            (512, 1280, 2560, 4), (77, 64, 32, 1)])
+def test_gemm_tile3_pipelined(dev, M, N, K, splits):
+    """LDS-DMA ring kernel (tile 3): same results as the reference matmul, incl. ragged M/N, K tails and split-K."""
+    from adaface_dev_amd import ops
+    a, w = rnd((M, K), 1), rnd((N, K), 2, K ** -0.5)
+    b, r = torch.randn(N, generator=torch.Generator().manual_seed(3)), rnd((M, N), 4)
+    out = ops.gemm(a.to(dev), ops.pack_matrix(w, b, dev), residual=r.to(dev), tile=3, splits=splits)
+    ref = a.float() @ w.float().t() + b + r.float()
+    assert rel_l2(out.float().cpu().numpy(), ref.numpy()) < TOL
+
+
+@pytest.mark.parametrize("B,H,W,c1,c2,cout,stride,splits", [(2, 16, 16, 64, 0, 64, 1, 1), (2, 16, 16, 64, 0, 128, 1, 2), (2, 15, 17, 32, 0, 64, 2, 1),
+                                                            (2, 8, 8, 128, 64, 64, 1, 1), (1, 32, 32, 320, 0, 4, 1, 1), (2, 8, 8, 96, 32, 128, 1, 3),
+                                                            (1, 64, 64, 320, 0, 320, 1, 1)])
+def test_conv3x3_tile3_pipelined(dev, B, H, W, c1, c2, cout, stride, splits):
+    from adaface_dev_amd import ops
+    cin = c1 + c2
+    x1 = rnd((B, H, W, c1), 1)
+    x2 = rnd((B, H, W, c2), 2) if c2 else None
+    w = rnd((cout, cin, 3, 3), 3, (9 * cin) ** -0.5)
+    bias, rowb = torch.randn(cout, generator=torch.Generator().manual_seed(4)), rnd((B, cout), 5)
+    xin = (x1 if x2 is None else torch.cat([x1, x2], -1)).float().permute(0, 3, 1, 2)
+    ref = F.conv2d(xin, w.float(), bias, stride=stride, padding=1) + rowb.float()[:, :, None, None]
+    res = rnd(tuple(ref.permute(0, 2, 3, 1).shape), 6)
+    ref = ref + res.float().permute(0, 3, 1, 2)
+    out = ops.conv3x3(x1.to(dev), ops.pack_conv3x3(w, bias, dev), x2=None if x2 is None else x2.to(dev), stride=stride,
+                      rowbias=rowb.to(dev), residual=res.to(dev), tile=3, splits=splits)
+    assert rel_l2(out.float().cpu().permute(0, 3, 1, 2).numpy(), ref.numpy()) < TOL
+
+
+@pytest.mark.parametrize("M,N,K,splits", [(300, 320, 320, 1), (4096, 640, 1280, 2), (130, 960, 64, 1)])
+def test_gemm_tile4_wide(dev, M, N, K, splits):
+    """128 x 320 / 8-wave variant of the LDS-DMA ring kernel (N % 320 == 0)."""
+    from adaface_dev_amd import ops
+    a, w = rnd((M, K), 1), rnd((N, K), 2, K ** -0.5)
+    b, r = torch.randn(N, generator=torch.Generator().manual_seed(3)), rnd((M, N), 4)
+    out = ops.gemm(a.to(dev), ops.pack_matrix(w, b, dev), residual=r.to(dev), act=ops.AF_ACT_SILU * 0, tile=4, splits=splits)
+    ref = a.float() @ w.float().t() + b + r.float()
+    assert rel_l2(out.float().cpu().numpy(), ref.numpy()) < TOL
+
+
+@pytest.mark.parametrize("B,H,W,c1,c2,cout,stride,splits", [(1, 32, 32, 320, 0, 320, 1, 1), (2, 16, 16, 640, 320, 640, 1, 2), (2, 16, 16, 320, 0, 320, 2, 1)])
+def test_conv3x3_tile4_wide(dev, B, H, W, c1, c2, cout, stride, splits):
+    from adaface_dev_amd import ops
+    cin = c1 + c2
+    x1 = rnd((B, H, W, c1), 1)
+    x2 = rnd((B, H, W, c2), 2) if c2 else None
+    w = rnd((cout, cin, 3, 3), 3, (9 * cin) ** -0.5)
+    bias, rowb = torch.randn(cout, generator=torch.Generator().manual_seed(4)), rnd((B, cout), 5)
+    xin = (x1 if x2 is None else torch.cat([x1, x2], -1)).float().permute(0, 3, 1, 2)
+    ref = F.conv2d(xin, w.float(), bias, stride=stride, padding=1) + rowb.float()[:, :, None, None]
+    res = rnd(tuple(ref.permute(0, 2, 3, 1).shape), 6)
+    ref = ref + res.float().permute(0, 3, 1, 2)
+    out = ops.conv3x3(x1.to(dev), ops.pack_conv3x3(w, bias, dev), x2=None if x2 is None else x2.to(dev), stride=stride,
+                      rowbias=rowb.to(dev), residual=res.to(dev), tile=4, splits=splits)
+    assert rel_l2(out.float().cpu().permute(0, 3, 1, 2).numpy(), ref.numpy()) < TOL
+
+
 def test_gemm_concat_k_and_silu(dev):
     from adaface_dev_amd import ops
     M, K1, K2, N = 300, 128, 64, 192
@@ -77,7 +136,18 @@ def test_gemm_concat_k_and_silu(dev):
     assert rel_l2(out.float().cpu().numpy(), ref.numpy()) < TOL
 
 
-@pytest.mark.parametrize("tile", [1, 2])
+def test_gemm_split_transposed_wide_tile4(dev):
+    from adaface_dev_amd import ops
+    B, C, K, tokens = 2, 320, 320, 100
+    a, w = rnd((B * tokens, K), 1), rnd((3 * C, K), 2, K ** -0.5)
+    out, out2 = ops.gemm(a.to(dev), ops.pack_matrix(w, None, dev), rows_per_batch=tokens, split_col=2 * C, tile=4)
+    ref = a.float() @ w.float().t()
+    assert rel_l2(out.float().cpu().numpy(), ref[:, :2 * C].numpy()) < TOL
+    vt = ref[:, 2 * C:].reshape(B, tokens, C).permute(0, 2, 1)
+    assert rel_l2(out2[:, :, :tokens].float().cpu().numpy(), vt.numpy()) < TOL
+
+
+@pytest.mark.parametrize("tile", [1, 2, 4])
 def test_gemm_geglu(dev, tile):
     from adaface_dev_amd import ops
     M, C = 520, 64
@@ -92,7 +162,7 @@ def test_gemm_geglu(dev, tile):
     assert rel_l2(out.float().cpu().numpy(), ref.numpy()) < TOL
 
 
-@pytest.mark.parametrize("tokens,tile", [(77, 2), (64, 1), (256, 0)])
+@pytest.mark.parametrize("tokens,tile", [(77, 2), (64, 1), (256, 0), (77, 3), (256, 3)])
 def test_gemm_split_transposed(dev, tokens, tile):
     from adaface_dev_amd import ops
     B, C, K = 3, 64, 96

@@ -2,8 +2,8 @@
 """In-situ autotune of af_gemm's (tile, split-K) per shape on an MI355X.
 
 Runs U-Net forwards at the benchmark shapes with a recorder hooked into ops._launch_gemm: the
-first time a GEMM shape is seen, every candidate (tile in {128x128, 64x64} x split-K in
-{1,2,3,4,6,8}) is timed on the live operands with HIP events, and the fastest is written to
+first time a GEMM shape is seen, every candidate (tile in {128x128, 64x64 register-staged; 128x128, 128x320
+LDS-DMA ring} x split-K in {1..16}) is timed on the live operands with HIP events, and the fastest is written to
 adaface-dev_amd/tuning/gfx950_gemm.json.  Usage (GPU box):
 
     python tools/autotune_gemm.py [--batches 8,2]
@@ -34,6 +34,7 @@ def main():
 
     def timed(d, device, tile, splits):
         d.tile, d.splits = tile, splits
+        d.zeros = ops._zero_page(device).data_ptr()
         if splits > 1:
             ws = ops._splitk_workspace(device)
             if splits * d.M * d.N * 4 > ws.numel() * 4:
@@ -56,8 +57,8 @@ def main():
             return table[key]
         nk = d.kpad // 64
         best, best_t, res = (0, 1), None, {}
-        for tile in (1, 2):
-            for splits in (1, 2, 3, 4, 6, 8):
+        for tile in (1, 2, 3, 4):
+            for splits in (1, 2, 3, 4, 6, 8, 12, 16):
                 if splits > 1 and (d.act == _lib.AF_ACT_GEGLU or d.out_mode != 0 or nk < 4 * splits):
                     continue
                 t = timed(d, device, tile, splits)
