@@ -16,6 +16,7 @@ from types import SimpleNamespace
 import torch
 import torch.nn as nn
 
+from .. import autograd_ops as ag
 from .. import ops
 from ..ldm.modules.diffusionmodules.util import LayerNorm, Linear
 from ..ops import AF_ACT_QUICKGELU, F16
@@ -85,6 +86,15 @@ class CLIPAttentionMKV(nn.Module):
                           causal_m=m if causal else 0)
         return self.out_proj.hip(o, residual=residual)
 
+    def hip_autograd(self, x2d, B, T, residual=None, causal=True):
+        """Same as `hip`, built from autograd nodes so the projection weights receive gradients."""
+        E, m = self.embed_dim, self.multiplier
+        q = ag.linear(self.q_proj, x2d)
+        k = ag.linear(self.k_proj, x2d).reshape(B * T * m, E)
+        v = ag.linear(self.v_proj, x2d).reshape(B * T * m, E)
+        o = ag.AttentionFn.apply(q, k, v, B, T, m, self.num_heads, self.scale, causal)
+        return ag.linear(self.out_proj, o, residual=residual)
+
     def forward(self, hidden_states, attention_mask=None, causal_attention_mask=None, output_attentions=False):
         if attention_mask is not None or output_attentions:
             raise NotImplementedError("padding masks / attention outputs are not used on the AdaFace path")
@@ -103,6 +113,9 @@ class CLIPMLP(nn.Module):
     def hip(self, x2d, residual=None):
         return self.fc2.hip(self.fc1.hip(x2d, act=AF_ACT_QUICKGELU), residual=residual)
 
+    def hip_autograd(self, x2d, residual=None):
+        return ag.linear(self.fc2, ag.QuickGeluFn.apply(ag.linear(self.fc1, x2d)), residual=residual)
+
 
 class CLIPEncoderLayer(nn.Module):
     def __init__(self, config):
@@ -115,6 +128,10 @@ class CLIPEncoderLayer(nn.Module):
     def hip(self, h, B, T):
         h = self.self_attn.hip(self.layer_norm1.hip(h), B, T, residual=h)
         return self.mlp.hip(self.layer_norm2.hip(h), residual=h)
+
+    def hip_autograd(self, h, B, T):
+        h = self.self_attn.hip_autograd(ag.layer_norm(self.layer_norm1, h), B, T, residual=h)
+        return self.mlp.hip_autograd(ag.layer_norm(self.layer_norm2, h), residual=h)
 
 
 class CLIPTextEmbeddings(nn.Module):
@@ -176,8 +193,11 @@ class CLIPTextModelWrapper(nn.Module):
         out_dtype = h0.dtype
         h = h0.reshape(B * T, E).to(F16).contiguous()
         hs = [h]
+        # training: any encoder weight (or the input embeddings) wants a gradient -> autograd-node execution
+        train = torch.is_grad_enabled() and (h0.requires_grad or any(p.requires_grad for p in tm.encoder.parameters())
+                                             or tm.final_layer_norm.weight.requires_grad)
         for layer in tm.encoder.layers:
-            h = layer.hip(h, B, T)
+            h = layer.hip_autograd(h, B, T) if train else layer.hip(h, B, T)
             if want_hidden:
                 hs.append(h)
         if hidden_state_layer_weights is None:
@@ -187,7 +207,7 @@ class CLIPTextModelWrapper(nn.Module):
             w = hidden_state_layer_weights.to(torch.float32)
             w = (w / w.sum(dim=0, keepdim=True)).unsqueeze(1)                       # [k, 1, 1 | E]  (reference :296-300)
             last = (torch.stack([t.float() for t in hs[-k:]], dim=0) * w).sum(dim=0).to(F16).contiguous()
-        last = tm.final_layer_norm.hip(last).reshape(B, T, E)
+        last = (ag.layer_norm(tm.final_layer_norm, last) if train else tm.final_layer_norm.hip(last)).reshape(B, T, E)
         last = last if out_dtype == F16 else last.to(out_dtype)
         if tm.eos_token_id == 2:
             pos = input_ids.to(torch.int).argmax(dim=-1)

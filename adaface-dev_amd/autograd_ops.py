@@ -1,0 +1,125 @@
+"""torch.autograd nodes of the TRAINABLE part of the hot path: the CLIP text transformer inside SubjBasisGenerator
+(``prompt2token_proj``, the only weights the Arc2Face-distillation stage updates besides the 3 layer-mix weights;
+reference ddpm.py:4120-4170 collects them, subj_basis_generator.py:841-853 freezes the embeddings).
+
+Every node's forward and backward is one or a few launches of this package's gfx950 kernels through the C ABI:
+
+  LinearFn     y = x W^T + b (+ residual)     fwd af_gemm; dx af_gemm on the transposed pack; dW = dy^T x as af_gemm
+                                              over token-transposed operands (af_transpose_tokens); db af_colsum
+  LayerNormFn  af_layernorm / af_layernorm_bwd; dgamma = colsum(dy * x_hat), dbeta = colsum(dy)
+  QuickGeluFn  af_quickgelu_fwd / af_quickgelu_bwd
+  AttentionFn  causal (multi-key-per-token) flash attention forward with log-sum-exp / af_attention_bwd
+
+Activations and activation gradients are fp16, so callers scale the loss (ldm/trainer.py LossScaler) exactly like
+fp16 AMP does in the reference (`precision: 16` Lightning runs); parameter gradients are returned in the parameter's
+dtype (fp32 master weights) still multiplied by that scale and are unscaled in the flat gradient arena."""
+import torch
+
+from . import _lib, ops
+from .ops import F16, round_up
+
+
+def wgrad(dy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """dW [N, K] = dy^T [N, M] @ x [M, K] through af_gemm: both operands are token-transposed so the reduction (M) is the
+    K-contiguous axis the GEMM kernels want; pads are zero-filled."""
+    M, N = dy.shape
+    K = x.shape[1]
+    m64 = round_up(M, 64)
+    dev = dy.device
+    dyt = torch.empty((N, m64), dtype=F16, device=dev)                         # the transpose zero-fills columns M..m64
+    k128 = round_up(K, 128)
+    xt = (torch.empty if k128 == K else torch.zeros)((k128, m64), dtype=F16, device=dev)
+    L = _lib.lib()
+    _lib.check(L.af_transpose_tokens(ops._p(dy), ops._p(dyt), 1, M, N, N, m64, ops._stream()), "af_transpose_tokens")
+    _lib.check(L.af_transpose_tokens(ops._p(x), ops._p(xt), 1, M, K, K, m64, ops._stream()), "af_transpose_tokens")
+    pw = ops.PackedWeight(xt, None, K, m64, m64, 1, m64)
+    return ops.gemm(dyt, pw)
+
+
+class LinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, mod):
+        ctx.save_for_backward(x)
+        ctx.mod = mod
+        ctx.has_res = residual is not None
+        return ops.gemm(x, mod.packed(), residual=residual)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, = ctx.saved_tensors
+        mod = ctx.mod
+        dy = dy.contiguous()
+        need = ctx.needs_input_grad
+        dx = ops.gemm(dy, mod.packed_bwd()) if need[0] else None
+        dw = wgrad(dy, x).to(mod.weight.dtype) if need[1] else None
+        db = ops.colsum(dy).to(mod.bias.dtype) if need[2] and mod.bias is not None else None
+        return dx, dw, db, (dy if ctx.has_res and need[3] else None), None
+
+
+class LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        g32, b32 = gamma.detach().float(), beta.detach().float()
+        ctx.save_for_backward(x, g32)
+        ctx.eps = eps
+        ctx.pdtype = gamma.dtype
+        return ops.layernorm(x, g32, b32, eps)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, g32 = ctx.saved_tensors
+        dy = dy.contiguous()
+        need = ctx.needs_input_grad
+        dx = ops.layernorm_bwd(x, g32, dy, ctx.eps) if need[0] else None
+        dg = db = None
+        if need[1]:
+            xhat = ops.layernorm(x, torch.ones_like(g32), torch.zeros_like(g32), ctx.eps)
+            dg = ops.colsum(dy, xhat).to(ctx.pdtype)
+        if need[2]:
+            db = ops.colsum(dy).to(ctx.pdtype)
+        return dx, dg, db, None
+
+
+class QuickGeluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return ops.quickgelu_fwd(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, = ctx.saved_tensors
+        return ops.quickgelu_bwd(x, dy.contiguous())
+
+
+class AttentionFn(torch.autograd.Function):
+    """q [B*T, E], k / v [B*T*m, E] (token-major, m keys per token) -> [B*T, E]."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, B, T, m, heads, scale, causal):
+        E = q.shape[1]
+        d = E // heads
+        vt = ops.transpose_tokens(v, B, T * m, E, E)
+        o, lse = ops.attention(q, k, vt, B=B, Nq=T, L=T * m, heads=heads, d=d, ldq=E, ldk=E, scale=scale, want_lse=True,
+                               causal_m=m if causal else 0)
+        ctx.save_for_backward(q, k, v, o, lse)
+        ctx.cfg = (B, T, m, heads, d, scale, causal)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, o, lse = ctx.saved_tensors
+        B, T, m, heads, d, scale, causal = ctx.cfg
+        E = heads * d
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        ops.attention_bwd(q, k, v, o, do.contiguous(), lse, B=B, Nq=T, L=T * m, heads=heads, d=d, ldq=E, ldk=E, ldv=E,
+                          dq=dq, dk=dk, dv=dv, lddq=E, lddk=E, lddv=E, scale=scale, causal_m=m if causal else 0)
+        return dq, dk, dv, None, None, None, None, None, None
+
+
+def linear(mod, x, residual=None):
+    return LinearFn.apply(x, mod.weight, mod.bias, residual, mod)
+
+
+def layer_norm(mod, x):
+    return LayerNormFn.apply(x, mod.weight, mod.bias, mod.eps)

@@ -38,6 +38,7 @@ struct BwdArgs {
   half_t* dv;         // [B, L, lddv]
   int B, Nq, L, heads, d;
   int ldq, ldk, ldv, ldo, ldqt, ldkt, lddq, lddk, lddv, ldb, nqpad, ld_lse;
+  int causal_m;  // > 0: key j visible to query i iff j / causal_m <= i
   float c;      // scale * log2(e)
   float scale;
 };
@@ -205,7 +206,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(BwdArgs a) {
       for (int e = 0; e < 4; ++e) {
         const int i = 4 * g + e;
         const float t = sT[i] * a.c + bias[e];
-        const float p = (kk + e < a.L) ? __builtin_amdgcn_exp2f(t - lse) : 0.f;
+        bool vis = kk + e < a.L;
+        if (a.causal_m > 0) vis = vis && ((kk + e) / a.causal_m <= query);
+        const float p = vis ? __builtin_amdgcn_exp2f(t - lse) : 0.f;
         zf[i >> 3][i & 7] = (half_t)(p * (pT[i] - delta));
       }
     }
@@ -314,7 +317,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(BwdArgs a) {
       for (int e = 0; e < 4; ++e) {
         const int i = 4 * g + e;
         const float t = s[i] * a.c + kbias;
-        const bool ok = key_ok && qq + e < a.Nq;   // padding rows of lse/delta may hold anything: select, never multiply
+        bool ok = key_ok && qq + e < a.Nq;   // padding rows of lse/delta may hold anything: select, never multiply
+        if (a.causal_m > 0) ok = ok && (key / a.causal_m <= qq + e);
         const float p = ok ? __builtin_amdgcn_exp2f(t - lse[e]) : 0.f;
         pf[i >> 3][i & 7] = (half_t)p;
         zf[i >> 3][i & 7] = (half_t)(ok ? p * (dp[i] - del[e]) : 0.f);
@@ -383,7 +387,7 @@ extern "C" int64_t af_attention_bwd_scratch_bytes(int B, int Nq, int L, int head
 }
 
 extern "C" int af_attention_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const void* lse2,
-                                int ld_lse, const void* keybias, void* dq, void* dk, void* dv, void* scratch, int64_t scratch_bytes, int B,
+                                int ld_lse, const void* keybias, int causal_m, void* dq, void* dk, void* dv, void* scratch, int64_t scratch_bytes, int B,
                                 int Nq, int L, int heads, int d, int ldq, int ldk, int ldv, int ldo, int lddo, int lddq, int lddk,
                                 int lddv, int ldb, float scale, void* stream) {
   AF_REQUIRE(q && k && v && o && dout && lse2 && dq && dk && dv && scratch, "af_attention_bwd: null pointer");
@@ -439,6 +443,7 @@ extern "C" int af_attention_bwd(const void* q, const void* k, const void* v, con
   a.ldb = ldb;
   a.nqpad = nq64;
   a.ld_lse = ld_lse;
+  a.causal_m = causal_m;
   a.c = scale * 1.4426950408889634f;
   a.scale = scale;
   const int ds = (d + 15) / 16;

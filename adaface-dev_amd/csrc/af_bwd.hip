@@ -402,6 +402,60 @@ __global__ __launch_bounds__(256) void cadamw_update_kernel(AdamArgs a) {
   }
 }
 
+// out[c] (+)= sum_r a[r,c] * b[r,c]; one block per 64 columns, 4 waves stride over rows, LDS fold
+__global__ __launch_bounds__(256) void colsum_kernel(const half_t* __restrict__ a, const half_t* __restrict__ b,
+                                                     float* __restrict__ out, int rows, int C, int accumulate) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  float s = 0.f;
+  if (c < C) {
+    for (int r = w; r < rows; r += 4) {
+      const float av = (float)a[(size_t)r * C + c];
+      s += b ? av * (float)b[(size_t)r * C + c] : av;
+    }
+  }
+  red[w][lane] = s;
+  __syncthreads();
+  if (w == 0 && c < C) {
+    const float t = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+    out[c] = accumulate ? out[c] + t : t;
+  }
+}
+
+__global__ __launch_bounds__(256) void quickgelu_fwd_kernel(const half_t* __restrict__ x, half_t* __restrict__ y, long n8) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n8) return;
+  const half8_t v = *reinterpret_cast<const half8_t*>(x + i * 8);
+  half8_t o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float f = (float)v[e];
+    o[e] = (half_t)(f / (1.0f + __expf(-1.702f * f)));
+  }
+  *reinterpret_cast<half8_t*>(y + i * 8) = o;
+}
+
+__global__ __launch_bounds__(256) void quickgelu_bwd_kernel(const half_t* __restrict__ x, const half_t* __restrict__ dy,
+                                                            half_t* __restrict__ dx, long n8) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n8) return;
+  const half8_t v = *reinterpret_cast<const half8_t*>(x + i * 8), g = *reinterpret_cast<const half8_t*>(dy + i * 8);
+  half8_t o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float f = (float)v[e];
+    const float sg = 1.0f / (1.0f + __expf(-1.702f * f));
+    o[e] = (half_t)((float)g[e] * sg * (1.0f + 1.702f * f * (1.0f - sg)));
+  }
+  *reinterpret_cast<half8_t*>(dx + i * 8) = o;
+}
+
+__global__ __launch_bounds__(256) void scale_f32_kernel(float* __restrict__ a, float s, long n) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) a[i] *= s;
+}
+
 inline dim3 g1(long n) { return dim3((unsigned)((n + 255) / 256)); }
 
 }  // namespace
@@ -546,4 +600,34 @@ extern "C" int af_cadamw_step(void* p, const void* g, void* m, void* v, const vo
   hipLaunchKernelGGL(cadamw_moments_kernel, grid, blk, 0, s, a);
   hipLaunchKernelGGL(cadamw_update_kernel, grid, blk, 0, s, a);
   return af_check_launch("af_cadamw_step");
+}
+
+extern "C" int af_colsum(const void* a, const void* b, void* out, int rows, int C, int accumulate, void* stream) {
+  AF_REQUIRE(a && out && rows > 0 && C > 0, "af_colsum: bad argument");
+  AfLaunchScope scope(AF_FAM_ELEM, stream);
+  hipLaunchKernelGGL(colsum_kernel, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)stream, (const half_t*)a, (const half_t*)b,
+                     (float*)out, rows, C, accumulate);
+  return af_check_launch("af_colsum");
+}
+
+extern "C" int af_quickgelu_fwd(const void* x, void* y, int64_t n, void* stream) {
+  AF_REQUIRE(x && y && n > 0 && n % 8 == 0, "af_quickgelu_fwd: n must be a positive multiple of 8");
+  AfLaunchScope scope(AF_FAM_ELEM, stream);
+  hipLaunchKernelGGL(quickgelu_fwd_kernel, g1(n / 8), dim3(256), 0, (hipStream_t)stream, (const half_t*)x, (half_t*)y, (long)(n / 8));
+  return af_check_launch("af_quickgelu_fwd");
+}
+
+extern "C" int af_quickgelu_bwd(const void* x, const void* dy, void* dx, int64_t n, void* stream) {
+  AF_REQUIRE(x && dy && dx && n > 0 && n % 8 == 0, "af_quickgelu_bwd: n must be a positive multiple of 8");
+  AfLaunchScope scope(AF_FAM_ELEM, stream);
+  hipLaunchKernelGGL(quickgelu_bwd_kernel, g1(n / 8), dim3(256), 0, (hipStream_t)stream, (const half_t*)x, (const half_t*)dy,
+                     (half_t*)dx, (long)(n / 8));
+  return af_check_launch("af_quickgelu_bwd");
+}
+
+extern "C" int af_scale_f32(void* a, float s, int64_t n, void* stream) {
+  AF_REQUIRE(a && n > 0, "af_scale_f32: bad argument");
+  AfLaunchScope scope(AF_FAM_ELEM, stream);
+  hipLaunchKernelGGL(scale_f32_kernel, g1(n), dim3(256), 0, (hipStream_t)stream, (float*)a, s, (long)n);
+  return af_check_launch("af_scale_f32");
 }

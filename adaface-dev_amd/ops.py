@@ -287,7 +287,7 @@ _attn_scratch = {}
 
 def attention_bwd(q, k, v, o, dout, lse, *, B: int, Nq: int, L: int, heads: int, d: int, ldq: int, ldk: int, ldv: int,
                   dq: torch.Tensor, dk: torch.Tensor, dv: torch.Tensor, lddq: int, lddk: int, lddv: int,
-                  keybias: Optional[torch.Tensor] = None, scale: Optional[float] = None):
+                  keybias: Optional[torch.Tensor] = None, scale: Optional[float] = None, causal_m: int = 0):
     """Input gradients of `attention`.  q/k/v: row-major token tensors (views allowed: row strides ldq/ldk/ldv);
     o, dout [B*Nq, heads*d] contiguous; dq/dk/dv are written in place with row strides lddq/lddk/lddv."""
     Cn = heads * d
@@ -298,7 +298,7 @@ def attention_bwd(q, k, v, o, dout, lse, *, B: int, Nq: int, L: int, heads: int,
         sc = torch.empty((max(need, 64 << 20),), dtype=torch.uint8, device=q.device)
         _attn_scratch[q.device] = sc
     ldb = 0 if keybias is None else keybias.stride(0)
-    rc = _lib.lib().af_attention_bwd(_p(q), _p(k), _p(v), _p(o), _p(dout), _p(lse), lse.stride(1), _p(keybias), _p(dq), _p(dk),
+    rc = _lib.lib().af_attention_bwd(_p(q), _p(k), _p(v), _p(o), _p(dout), _p(lse), lse.stride(1), _p(keybias), int(causal_m), _p(dq), _p(dk),
                                      _p(dv), _p(sc), sc.numel(), B, Nq, L, heads, d, ldq, ldk, ldv, Cn, Cn, lddq, lddk, lddv,
                                      ldb, float(scale), _stream())
     _lib.check(rc, "af_attention_bwd")
@@ -463,6 +463,32 @@ def cadamw_step(p, g, m, v, seg_offsets, counts, *, lr, betas=(0.9, 0.999), eps=
                                    float(betas[0]), float(betas[1]), float(eps), float(weight_decay), int(step), int(correct_bias),
                                    _stream())
     _lib.check(rc, "af_cadamw_step")
+
+
+def colsum(a, b=None, out=None, accumulate=False):
+    """fp32 [C] = sum over rows of a (* b): bias / LayerNorm-gamma gradients."""
+    rows, Cn = a.shape
+    if out is None:
+        out = torch.empty((Cn,), dtype=torch.float32, device=a.device)
+    _lib.check(_lib.lib().af_colsum(_p(a), _p(b), _p(out), rows, Cn, int(accumulate), _stream()), "af_colsum")
+    return out
+
+
+def quickgelu_fwd(x):
+    y = torch.empty_like(x)
+    _lib.check(_lib.lib().af_quickgelu_fwd(_p(x), _p(y), x.numel(), _stream()), "af_quickgelu_fwd")
+    return y
+
+
+def quickgelu_bwd(x, dy):
+    dx = torch.empty_like(x)
+    _lib.check(_lib.lib().af_quickgelu_bwd(_p(x), _p(dy), _p(dx), x.numel(), _stream()), "af_quickgelu_bwd")
+    return dx
+
+
+def scale_f32_(a, s):
+    _lib.check(_lib.lib().af_scale_f32(_p(a), float(s), a.numel(), _stream()), "af_scale_f32")
+    return a
 
 
 # ----------------------------------------------------------------------------- profiling hook

@@ -165,7 +165,7 @@ int af_attention_ex(const void* q, const void* k, const void* vt, void* o, void*
  * Reference: autograd of attention.py:180-204 (the reference stores the full score tensor).   */
 int64_t af_attention_bwd_scratch_bytes(int B, int Nq, int L, int heads, int d);
 int af_attention_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const void* lse2,
-                     int ld_lse, const void* keybias, void* dq, void* dk, void* dv, void* scratch,
+                     int ld_lse, const void* keybias, int causal_m, void* dq, void* dk, void* dv, void* scratch,
                      int64_t scratch_bytes, int B, int Nq, int L, int heads, int d, int ldq, int ldk, int ldv,
                      int ldo, int lddo, int lddq, int lddk, int lddv, int ldb, float scale, void* stream);
 
@@ -214,6 +214,16 @@ int af_transpose_tokens(const void* x, void* y, int B, int N, int C, int ldx, in
  * parameter tensors (the caution mask is renormalised per tensor); counts: uint32 [nseg] scratch.          */
 int af_cadamw_step(void* p, const void* g, void* m, void* v, const void* seg_offsets, int nseg, void* counts, float lr,
                    float beta1, float beta2, float eps, float weight_decay, int step, int correct_bias, void* stream);
+
+/* ---- parameter-gradient helpers of the (trainable) CLIP text encoder -------------------------------
+ * out fp32 [C] (+)= sum_rows a[r,c] * (b ? b[r,c] : 1): bias gradients (b = NULL) and LayerNorm gamma gradients
+ * (a = dy, b = x_hat).  accumulate != 0 adds to `out`.                                                      */
+int af_colsum(const void* a, const void* b, void* out, int rows, int C, int accumulate, void* stream);
+/* quick-GELU x*sigmoid(1.702x) (CLIP MLP) and its input gradient, fp16 element-wise */
+int af_quickgelu_fwd(const void* x, void* y, int64_t n, void* stream);
+int af_quickgelu_bwd(const void* x, const void* dy, void* dx, int64_t n, void* stream);
+/* y = a * s (fp32), used to unscale the loss-scaled gradient arena before the optimizer step */
+int af_scale_f32(void* a, float s, int64_t n, void* stream);
 
 #ifdef __cplusplus
 }

@@ -114,3 +114,43 @@ def test_arc2face_id_to_adaface_embeddings_full_size_vs_oracle(dev):
     with torch.no_grad():
         ada1, _, _ = enc.generate_adaface_embeddings(face_id_embs=ids512.to(dev), avg_at_stage="id_emb")
     assert ada1.shape == (16, 768)
+
+
+def test_small_encoder_weight_gradients_vs_oracle_autograd(dev):
+    """Training path (autograd nodes over the HIP kernels): every encoder weight / bias / LayerNorm gradient, the
+    layer-mix weight gradient and the input-embedding gradient against torch autograd through the fp32 CPU oracle."""
+    from adaface_dev_amd import rng
+    from oracle import clip_oracle as CO
+    mult = [1, 2, 1]
+    m, sd = _small_model(dev, seed=23, multipliers=mult)
+    ids = torch.randint(0, CLIP_SMALL["vocab"], (3, 77), generator=torch.Generator().manual_seed(6))
+    tok = rng.synth_input("clip.tok.g", (3, 77, CLIP_SMALL["hidden"]), seed=23, scale=0.3)
+    R = rng.synth_input("clip.R", (3, 77, CLIP_SMALL["hidden"]), seed=23)
+    w = torch.tensor([[1.0], [2.0], [4.0]])
+    S = 64.0
+    tok_d = tok.to(dev).requires_grad_(True)
+    w_d = w.to(dev).requires_grad_(True)
+    last = m(input_ids=ids.to(dev), input_token_embs=tok_d, hidden_state_layer_weights=w_d)[0]
+    ((last * R.to(dev)).sum() * S).backward()
+    sd_r = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    tok_r, w_r = tok.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    ref = CO.clip_text_forward(sd_r, CLIP_SMALL, ids, tok_r, w_r, mult)[0]
+    (ref * R).sum().backward()
+    assert rel_l2(last.detach().cpu().numpy(), ref.detach().numpy()) < 5e-3
+    worst = 0.0
+    for n, p in m.named_parameters():
+        if "token_embedding" in n:
+            continue
+        assert p.grad is not None, n
+        qb = sd_r[n.replace("k_proj", "q_proj")].grad.norm().item()
+        if n.endswith("k_proj.bias") and sd_r[n].grad.norm().item() < 1e-4 * qb:
+            # m = 1: a key bias shifts every score of a query by the same amount, so its true gradient is 0 (softmax
+            # shift invariance; the reference's value is fp32 round-off) -- compare against the q-bias gradient's size
+            assert (p.grad / S).norm().item() < 2e-2 * qb, n
+            continue
+        e = rel_l2((p.grad / S).cpu().numpy(), sd_r[n].grad.numpy())
+        worst = max(worst, e)
+        assert e < 1e-2, (n, e)
+    assert rel_l2((tok_d.grad / S).cpu().numpy(), tok_r.grad.numpy()) < 1e-2
+    assert rel_l2((w_d.grad / S).cpu().numpy(), w_r.grad.numpy()) < 1e-2
+    print(f"worst encoder parameter-gradient rel-L2 vs oracle autograd: {worst:.3e}")
