@@ -1,0 +1,175 @@
+"""Stage-1 (Arc2Face -> AdaFace) U-Net distillation training step, the data-parallel hot loop of BASELINE configs 3/4
+(reference ``DDPM.training_step`` ddpm.py:434-503, ``shared_step``/``forward`` :936-1355 for the ``do_unet_distill``
+iteration type, ``p_losses`` :2355-2368, ``configure_optimizers`` :3855-4020; Lightning ``strategy="ddp"``,
+``accumulate_grad_batches: 2`` main.py:618,911-915).
+
+What one micro-batch does (everything below the Python control flow is a HIP kernel launch through the C ABI):
+
+  face IDs [B,512] --Arc2Face CLIP (frozen, no grad)--> image-prompt embs [B,16,768]                     (F2)
+      --SubjBasisGenerator CLIP (TRAINABLE, autograd nodes)--> AdaFace token embs [B,16,768]             (F3-F6)
+      --patched into the subject slots of the prompt's token embeddings--> frozen CLIP text encoder
+        (activation-gradient only) --> subj_context [B,T,768]                                           (8f rank 2, minimal)
+  teacher: "photo of a" prefix (4 tokens) ++ image-prompt embs -> multi-step Arc2Face U-Net (no grad)    (D5)
+  student: per step eps-prediction of the frozen SD-1.5 U-Net under subj_context, fg-masked MSE x 8      (D4, D6)
+  backward: whole-U-Net activation-gradient node -> text encoder dgrad -> SubjBasisGenerator weights
+  every `accumulate_grad_batches`-th micro-batch: bucketed RCCL all-reduce overlapped with the backward
+  (GradReducer), unscale, cautious AdamW on the flat fp32 arena, warm-up/cosine LR.
+
+Like the reference's do_unet_distill iterations the batch is cut to HALF_BS = ceil(BS / steps) instances when
+`num_unet_denoising_steps` > 1 (ddpm.py:1283-1311) and the step count cycles 2,3,4 deterministically so every rank runs
+the same graph (ddpm.py:1266-1270).
+
+fp16 activation gradients need loss scaling (the reference trains with fp16 autocast + GradScaler through Lightning
+`precision: 16`): `LossScaler` is the usual dynamic scheme (x2 every `growth_interval` clean steps, /2 and skip on
+inf/nan), with the overflow flag all-reduced so ranks skip together."""
+import contextlib
+import math
+
+import torch
+import torch.distributed as dist
+
+from .. import ops
+from ..adaface.subj_basis_generator import template_ids
+from ..distributed import GradReducer
+from .c_adamw import AdamW as CAdamW
+from .modules.lr_scheduler import LambdaWarmUpCosineScheduler
+from .util import set_seed_per_rank_and_batch
+
+
+class LossScaler:
+    def __init__(self, init_scale=2.0 ** 14, growth_interval=200, min_scale=1.0, max_scale=2.0 ** 24):
+        self.scale = float(init_scale)
+        self.growth_interval = growth_interval
+        self.min_scale, self.max_scale = min_scale, max_scale
+        self._good = 0
+
+    def update(self, overflow: bool):
+        if overflow:
+            self.scale = max(self.min_scale, self.scale / 2)
+            self._good = 0
+        else:
+            self._good += 1
+            if self._good % self.growth_interval == 0:
+                self.scale = min(self.max_scale, self.scale * 2)
+
+
+class DistillTrainer:
+    """Owns the optimizer state, the gradient reducer and the iteration bookkeeping; the models are passed in.
+
+    ldm            LatentDiffusion with `.unet_teacher` set (frozen student U-Net + Arc2Face teacher U-Net)
+    id2ada         Arc2Face_ID2AdaPrompt (frozen Arc2Face encoder + trainable SubjBasisGenerator)
+    text_encoder   CLIPTextModelWrapper holding the frozen SD-1.5 text encoder weights
+    """
+
+    unet_distill_weight = 8                                                     # ddpm.py:2367
+
+    def __init__(self, ldm, id2ada, text_encoder, base_lr=2e-6, batch_size=4, accumulate_grad_batches=2,
+                 betas=(0.9, 0.995), eps=1e-6, weight_decay=0.0, warm_up_steps=500, max_decay_steps=60000,
+                 bucket_bytes=32 << 20, loss_scaler=None, prompt_len=77, subj_slot=4, process_group=None):
+        self.ldm, self.id2ada, self.text_encoder = ldm, id2ada, text_encoder
+        for p in text_encoder.parameters():
+            p.requires_grad_(False)
+        self.accum = accumulate_grad_batches
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
+        self.pg = process_group
+        # lr = accumulate_grad_batches * ngpu * bs * base_lr (main.py:911-915)
+        self.learning_rate = accumulate_grad_batches * self.world * batch_size * base_lr
+        params = [p for p in id2ada.subj_basis_generator.parameters() if p.requires_grad]
+        self.optimizer = CAdamW(params, lr=self.learning_rate, betas=betas, eps=eps, weight_decay=weight_decay)
+        self.arena = self.optimizer.arena(0)
+        self.reducer = GradReducer([self.arena], bucket_bytes=bucket_bytes, process_group=process_group)
+        self.lr_lambda = LambdaWarmUpCosineScheduler(warm_up_steps, 0.1, 1.0, 0.01, max_decay_steps)
+        self.scaler = loss_scaler or LossScaler()
+        self.global_step = 0                                                   # optimizer steps
+        self.unet_distill_iters_count = 0
+        self.skipped_steps = 0
+        self.prompt_len, self.subj_slot = prompt_len, subj_slot
+        self._micro = 0
+        self._overflow = None
+
+    # ------------------------------------------------------------------ conditioning
+    def prompt_ids(self, bs, device):
+        """"a photo of z_0_0 ... z_0_15" with the 16 subject tokens at slots subj_slot.. (adaface_wrapper.py:491-532
+        rewrites the prompt the same way); the placeholder ids are irrelevant because their embeddings are replaced."""
+        n_id = self.id2ada.subj_basis_generator.N_ID
+        return template_ids(["a", "photo", "of"] + [","] * n_id, self.prompt_len, device).repeat(bs, 1)
+
+    def get_text_conditioning(self, adaface_embs, input_ids=None):
+        """AdaFace token embeddings -> prompt embeddings [B, T, 768] through the frozen text encoder (the minimal form of
+        reference get_text_conditioning ddpm.py:739-853 + EmbeddingManager token patching embedding_manager.py:236-421)."""
+        bs = adaface_embs.shape[0]
+        te = self.text_encoder
+        ids = self.prompt_ids(bs, adaface_embs.device) if input_ids is None else input_ids
+        s, n = self.subj_slot, adaface_embs.shape[1]
+        with torch.no_grad():
+            tok = te(input_ids=ids, return_token_embs=True).to(adaface_embs.dtype)
+        tok = torch.cat([tok[:, :s], adaface_embs, tok[:, s + n:]], dim=1)
+        return te(input_ids=ids, input_token_embs=tok)[0]
+
+    def teacher_context(self, id2img_prompt_embs):
+        """[BS, 4 + 16, 768]: "photo of a" prefix embeddings ++ image-prompt embeddings (ddpm.py:2925-2931)."""
+        enc = self.id2ada.text_to_image_prompt_encoder
+        bs = id2img_prompt_embs.shape[0]
+        if getattr(self, "_prefix", None) is None:
+            with torch.no_grad():
+                ids = template_ids(["photo", "of", "a"], 22, id2img_prompt_embs.device)
+                self._prefix = enc(input_ids=ids)[0][:, :4].to(id2img_prompt_embs.dtype)
+        return torch.cat([self._prefix.repeat(bs, 1, 1), id2img_prompt_embs], dim=1)
+
+    # ------------------------------------------------------------------ one micro-batch
+    def shared_step(self, batch, num_unet_denoising_steps=None, t=None, presampled=None):
+        """batch: dict with 'x_start' [B,4,h,w] latents, 'face_id_embs' [B,512], optional 'fg_mask'/'img_mask' [B,1,h,w]
+        and 'noise'.  Returns the (unscaled) loss tensor."""
+        x_start = batch["x_start"]
+        BS = x_start.shape[0]
+        steps = num_unet_denoising_steps or (self.unet_distill_iters_count % 3 + 2)      # ddpm.py:1270
+        half = math.ceil(BS / steps) if steps > 1 else BS                                # == arange(BS).chunk(steps)[0]
+        sel = slice(0, half)
+        x_start = x_start[sel]
+        fg_mask = batch.get("fg_mask")
+        img_mask = batch.get("img_mask")
+        fg_mask = None if fg_mask is None else fg_mask[sel]
+        img_mask = None if img_mask is None else img_mask[sel]
+        noise = batch["noise"][sel] if "noise" in batch else torch.randn_like(x_start)
+        with torch.no_grad():
+            _, _, id2img = self.id2ada.get_img_prompt_embs(batch["face_id_embs"][sel], id_batch_size=half)[:3]
+        id2img = id2img.float()
+        ada = self.id2ada.subj_basis_generator(id2img, out_id_embs_cfg_scale=self.id2ada.out_id_embs_cfg_scale, is_face=True)
+        ctx = self.get_text_conditioning(ada.float())
+        cond = (ctx, ["a photo of z"] * half, {})
+        loss = self.ldm.calc_unet_distill_loss(x_start, noise, cond, self.teacher_context(id2img), img_mask, fg_mask, steps,
+                                               t=t, presampled=presampled)
+        return loss * self.unet_distill_weight
+
+    def training_step(self, batch, batch_idx, epoch=0, **kw):
+        """One micro-batch: forward, scaled backward (with the gradient exchange overlapped on the last micro-batch of an
+        accumulation window), and on window end: unscale, optimizer step, LR schedule.  Returns the loss (detached)."""
+        set_seed_per_rank_and_batch(self.rank, epoch, batch_idx)                        # ddpm.py:442
+        self.unet_distill_iters_count += 1
+        last = (batch_idx + 1) % self.accum == 0
+        sync = contextlib.nullcontext() if last else self.reducer.no_sync()
+        loss = self.shared_step(batch, **kw)
+        with sync:
+            (loss * (self.scaler.scale / self.accum)).backward()
+        if last:
+            self.optimizer_step()
+        return loss.detach()
+
+    def optimizer_step(self):
+        self.reducer.finish()                                     # wait for the in-flight buckets; sums -> means
+        g = self.arena.flat_g
+        bad = (~torch.isfinite(g.sum())).float()                  # one reduction; inf/nan anywhere poisons the sum
+        if self.world > 1:
+            dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=self.pg)
+        overflow = bool(bad.item() > 0)
+        if not overflow:
+            ops.scale_f32_(g, 1.0 / self.scaler.scale)
+            for group in self.optimizer.param_groups:
+                group["lr"] = self.learning_rate * self.lr_lambda(self.global_step)
+            self.optimizer.step()
+            self.global_step += 1
+        else:
+            self.skipped_steps += 1
+        self.scaler.update(overflow)
+        self.optimizer.zero_grad()

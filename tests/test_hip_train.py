@@ -84,3 +84,129 @@ def test_unet_distill_loss_and_context_grad_vs_oracle(dev, steps):
     print(f"steps={steps}: loss {float(loss):.5f} vs {float(ref):.5f} (rel {el:.2e}); dcontext rel-L2 {eg:.2e}")
     # chained fp16 U-Nets (teacher x0 feeds the next step): 5e-3 on the loss, 1e-2 on the gradient (measured 1e-4 / 2.6e-3)
     assert el < 5e-3 and eg < 1e-2
+
+
+def _trainer_setup(dev, accum=1):
+    """Reduced-width replica of the whole Stage-1 stack: CLIP encoders hidden 128 / 3 layers, U-Nets model_channels 64."""
+    from adaface_dev_amd import rng
+    from adaface_dev_amd.adaface.arc2face_models import CLIPTextModelWrapper, clip_text_config
+    from adaface_dev_amd.adaface.face_id_to_ada_prompt import Arc2Face_ID2AdaPrompt
+    from adaface_dev_amd.adaface.unet_teachers import Arc2FaceTeacher
+    from adaface_dev_amd.ldm.models.diffusion.ddpm import LatentDiffusion
+    from adaface_dev_amd.ldm.modules.diffusionmodules.openaimodel import UNetModel
+    from adaface_dev_amd.ldm.trainer import DistillTrainer, LossScaler
+    ccfg = clip_text_config(hidden_size=128, num_attention_heads=2, num_hidden_layers=3, intermediate_size=512)
+    ucfg = dict(CFG, context_dim=128)
+    ld = LatentDiffusion(ucfg)
+    rng.load_synth_weights(ld.model.diffusion_model, seed=41)
+    teacher_unet = UNetModel(**ucfg)
+    rng.load_synth_weights(teacher_unet, seed=42)
+    id2ada = Arc2Face_ID2AdaPrompt(clip_config=ccfg)
+    rng.load_synth_weights(id2ada.text_to_image_prompt_encoder, seed=43)
+    rng.load_synth_weights(id2ada.subj_basis_generator.prompt2token_proj, seed=44)
+    text_enc = CLIPTextModelWrapper(ccfg)
+    rng.load_synth_weights(text_enc, seed=45)
+    sds = dict(student=ld.model.diffusion_model.state_dict(), teacher=teacher_unet.state_dict(),
+               arc2face=id2ada.text_to_image_prompt_encoder.state_dict(),
+               sbg=id2ada.subj_basis_generator.prompt2token_proj.state_dict(), text=text_enc.state_dict())
+    sds = {k: {n: v.detach().clone() for n, v in sd.items()} for k, sd in sds.items()}
+    ld = ld.to(dev)
+    ld.unet_teacher = Arc2FaceTeacher(teacher_unet.to(dev))
+    tr = DistillTrainer(ld, id2ada.to(dev), text_enc.to(dev), accumulate_grad_batches=accum, warm_up_steps=0,
+                        loss_scaler=LossScaler(init_scale=2.0 ** 10))
+    return tr, sds, ucfg
+
+
+def _oracle_distill(sds, ucfg, ids512, x0, noise, t, fg, steps, pres, sbg_sd=None):
+    from adaface_dev_amd.adaface.subj_basis_generator import template_ids
+    from oracle import clip_oracle as CO
+    from oracle import diffusion_oracle as D
+    from oracle import train_oracle as T
+    from oracle import unet_oracle as O
+    cc = dict(hidden=128, heads=2, layers=3)
+    B = x0.shape[0]
+    sbg = sbg_sd if sbg_sd is not None else {k: v.clone().requires_grad_(True) for k, v in sds["sbg"].items()}
+    lw = torch.tensor([[1.0], [2.0], [4.0]], requires_grad=True)
+    with torch.no_grad():
+        idn = torch.nn.functional.normalize(ids512, dim=-1)
+        id2img = CO.id_to_img_prompt(sds["arc2face"], cc, template_ids(["photo", "of", "a", "id", "person"], 22).repeat(B, 1), 4, idn[:, :128])
+        prefix = CO.clip_text_forward(sds["arc2face"], cc, template_ids(["photo", "of", "a"], 22))[0][:, :4]
+    ada = CO.inverse_img_prompt(sbg, cc, template_ids(["photo", "of", "a"] + [","] * 18, 77).repeat(B, 1), id2img, lw)
+    pid = template_ids(["a", "photo", "of"] + [","] * 16, 77).repeat(B, 1)
+    tok = sds["text"]["text_model.embeddings.token_embedding.weight"][pid].clone()
+    tok = torch.cat([tok[:, :4], ada, tok[:, 20:]], dim=1)
+    ctx = CO.clip_text_forward(sds["text"], cc, pid, tok)[0]
+    tctx = torch.cat([prefix.repeat(B, 1, 1), id2img], dim=1)
+    tabs = D.register_schedule(D.make_beta_schedule_linear())
+    loss = 8 * T.unet_distill_loss(lambda x, tt, c: O.unet_forward(sds["student"], ucfg, x, tt, c, {}),
+                                   lambda x, tt, c: O.unet_forward(sds["teacher"], ucfg, x, tt, c, {}),
+                                   tabs, x0, noise, t, ctx, tctx, fg, steps, pres)
+    return loss, sbg, lw
+
+
+def test_distill_trainer_micro_batch_loss_and_weight_gradients_vs_oracle(dev):
+    """face IDs -> Arc2Face encoder -> trainable SubjBasisGenerator -> frozen text encoder -> student/teacher U-Nets ->
+    loss; the gradients of every SubjBasisGenerator weight (flat arena) against autograd through the fp32 CPU oracles."""
+    from adaface_dev_amd import rng
+    tr, sds, ucfg = _trainer_setup(dev)
+    BS, steps = 4, 2                        # HALF_BS = 2 (ddpm.py:1283-1289)
+    ids512 = rng.synth_input("tr.ids", (BS, 512), seed=46)
+    x0 = rng.synth_input("tr.x0", (BS, 4, 32, 32), seed=46)
+    noise = rng.synth_input("tr.noise", (BS, 4, 32, 32), seed=46)
+    fg = (rng.synth_input("tr.fg", (BS, 1, 32, 32), seed=46) > -0.3).float()
+    t = torch.tensor([760, 850])
+    pres = [(torch.rand(2, generator=torch.Generator().manual_seed(3)), rng.synth_input("tr.n1", (2, 4, 32, 32), seed=46))]
+    batch = dict(x_start=x0.to(dev), face_id_embs=ids512.to(dev), fg_mask=fg.to(dev), noise=noise.to(dev))
+    tr.optimizer.zero_grad()
+    loss = tr.shared_step(batch, num_unet_denoising_steps=steps, t=t.to(dev), presampled=[(r.to(dev), n.to(dev)) for r, n in pres])
+    S = tr.scaler.scale
+    (loss * S).backward()
+    ref, sbg, lw = _oracle_distill(sds, ucfg, ids512[:2], x0[:2], noise[:2], t, fg[:2], steps, pres)
+    ref.backward()
+    el = abs(float(loss) - float(ref)) / abs(float(ref))
+    assert el < 5e-3, (float(loss), float(ref))
+    worst, n_checked = 0.0, 0
+    sb = tr.id2ada.subj_basis_generator
+    for n, p in sb.prompt2token_proj.named_parameters():
+        if not p.requires_grad:
+            assert "embeddings" in n
+            continue
+        gref = sbg[n].grad
+        if n.endswith("k_proj.bias"):
+            continue                         # true gradient is 0 (softmax shift invariance)
+        e = rel_l2((p.grad / S).cpu().numpy(), gref.numpy())
+        worst = max(worst, e)
+        n_checked += 1
+        assert e < 3e-2, (n, e)
+    e_w = rel_l2((sb.hidden_state_layer_weights.grad / S).cpu().numpy(), 5.0 * lw.grad.numpy())      # x5 grad scaler (:716)
+    print(f"trainer micro-batch: loss rel err {el:.2e}; worst weight-gradient rel-L2 over {n_checked} tensors {worst:.2e}; layer-mix {e_w:.2e}")
+    assert e_w < 3e-2
+
+
+def test_distill_trainer_accumulate_and_step(dev):
+    """Two micro-batches with accumulate_grad_batches=2: one optimizer step, lr from the warm-up/cosine schedule, update
+    direction -lr*sign(g) at step 1 of cautious AdamW on (almost) every element, gradients zeroed afterwards."""
+    from adaface_dev_amd import rng
+    tr, sds, ucfg = _trainer_setup(dev, accum=2)
+    p0 = tr.arena.flat_p.clone()
+    BS = 4
+    batches = []
+    for i in range(2):
+        batches.append(dict(x_start=rng.synth_input(f"ts.x{i}", (BS, 4, 32, 32), seed=47).to(dev),
+                            face_id_embs=rng.synth_input(f"ts.id{i}", (BS, 512), seed=47).to(dev),
+                            fg_mask=torch.ones(BS, 1, 32, 32, device=dev)))
+    l0 = tr.training_step(batches[0], 0)
+    assert tr.global_step == 0 and float(tr.arena.flat_g.abs().sum()) > 0
+    g_after_first = tr.arena.flat_g.clone()
+    l1 = tr.training_step(batches[1], 1)
+    assert tr.global_step == 1 and tr.skipped_steps == 0
+    assert torch.isfinite(l0) and torch.isfinite(l1)
+    assert float(tr.arena.flat_g.abs().sum()) == 0.0
+    dp = tr.arena.flat_p - p0
+    lr = tr.learning_rate * tr.lr_lambda(0)
+    moved = dp != 0
+    assert moved.float().mean() > 0.95
+    # first cautious-AdamW step: |dp| <= lr / mask_mean-ish, sign opposite to the accumulated gradient
+    assert float(dp.abs().max()) <= lr * 1.01 / 0.999
+    assert g_after_first.shape == dp.shape
+    assert tr.unet_distill_iters_count == 2
