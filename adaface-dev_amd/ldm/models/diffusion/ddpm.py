@@ -108,6 +108,7 @@ class LatentDiffusion(nn.Module):
 
     # ------------------------------------------------------------------ Stage-1 distillation (ddpm.py:1597-1750, 2984-3184)
     unet_distill_weight = 8          # ddpm.py:2367
+    batch_student_steps = True       # one student U-Net call for all denoising steps of a micro-batch
     res_hidden_states_gradscale = 1
 
     def guided_denoise(self, x_start, noise, t, cond_context, uncond_emb=None, img_mask=None, subj_indices=None,
@@ -158,12 +159,29 @@ class LatentDiffusion(nn.Module):
                                                                      num_denoising_steps=num_unet_denoising_steps,
                                                                      force_uses_cfg=False, presampled=presampled)
         losses = []
-        for s in range(num_unet_denoising_steps):
-            noise_pred_s, _, _ = self.guided_denoise(t_x_starts[s].to(x_start.dtype), t_noises[s].to(x_start.dtype), all_t[s],
-                                                     subj_context, img_mask=None, batch_part_has_grad="all",
-                                                     do_pixel_recon=True, cfg_scale=self.unet_teacher.cfg_scale,
-                                                     res_hidden_states_gradscale=self.res_hidden_states_gradscale)
-            loss_s, _ = calc_recon_loss(F.mse_loss, noise_pred_s, t_preds[s].to(noise_pred_s.dtype), img_mask, fg_mask,
+        n, bs = num_unet_denoising_steps, x_start.shape[0]
+        if self.batch_student_steps and n > 1:
+            # The student's per-step passes are independent once the teacher's trajectory exists (the reference loops over
+            # them, ddpm.py:3103-3176): run them as ONE U-Net call on the steps*BS batch -- same arithmetic per sample
+            # (GroupNorm, attention and the masked MSE are per instance), larger GEMM M, one backward node.
+            ctx, prompts, extra = subj_context
+            cat_context = (ctx.repeat(n, 1, 1), list(prompts) * n, extra)
+            pred_all, _, _ = self.guided_denoise(torch.cat([x.to(x_start.dtype) for x in t_x_starts[:n]]),
+                                                 torch.cat([z.to(x_start.dtype) for z in t_noises[:n]]), torch.cat(list(all_t[:n])),
+                                                 cat_context, img_mask=None, batch_part_has_grad="all", do_pixel_recon=True,
+                                                 cfg_scale=self.unet_teacher.cfg_scale,
+                                                 res_hidden_states_gradscale=self.res_hidden_states_gradscale)
+            preds = pred_all.split(bs)
+        else:
+            preds = []
+            for s in range(n):
+                noise_pred_s, _, _ = self.guided_denoise(t_x_starts[s].to(x_start.dtype), t_noises[s].to(x_start.dtype), all_t[s],
+                                                         subj_context, img_mask=None, batch_part_has_grad="all",
+                                                         do_pixel_recon=True, cfg_scale=self.unet_teacher.cfg_scale,
+                                                         res_hidden_states_gradscale=self.res_hidden_states_gradscale)
+                preds.append(noise_pred_s)
+        for s in range(n):
+            loss_s, _ = calc_recon_loss(F.mse_loss, preds[s], t_preds[s].to(preds[s].dtype), img_mask, fg_mask,
                                         instance_weights=None, fg_pixel_weight=1, bg_pixel_weight=recon_bg_pixel_weight)
             losses.append(loss_s)
         return sum(losses) / np.sqrt(num_unet_denoising_steps)

@@ -42,6 +42,105 @@ MFMA_PEAK_TFLOPS = 2500.0                          # dense fp16/bf16, MI355X_MIC
 HBM_PEAK_GBS = 8000.0
 
 
+def main_train(args):
+    """Secondary bench (not the driver's line): BASELINE configs[2] (1 GPU) / configs[3] (DDP).  One *step* = one training
+    micro-batch of bs images/GPU: face IDs -> Arc2Face encoder -> trainable SubjBasisGenerator -> frozen text encoder ->
+    teacher multi-step targets + student eps per step (HALF_BS = ceil(bs/steps) instances, steps cycling 2,3,4 as
+    ddpm.py:1270-1289) -> masked MSE -> backward to the 85 M SubjBasisGenerator weights; every 2nd micro-batch the
+    bucketed gradient all-reduce (overlapped with the backward), unscale and fused CAdamW.  Full-size models: 2 x SD-1.5
+    U-Net (student, teacher) + 3 x CLIP-L text transformers, seeded random weights."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    from adaface_dev_amd import SD15_UNET_CONFIG, _lib, ops, rng
+    from adaface_dev_amd.adaface.arc2face_models import CLIPTextModelWrapper
+    from adaface_dev_amd.adaface.face_id_to_ada_prompt import Arc2Face_ID2AdaPrompt
+    from adaface_dev_amd.adaface.unet_teachers import Arc2FaceTeacher
+    from adaface_dev_amd.ldm.models.diffusion.ddpm import LatentDiffusion
+    from adaface_dev_amd.ldm.modules.diffusionmodules.openaimodel import UNetModel
+    from adaface_dev_amd.ldm.trainer import DistillTrainer
+
+    _lib.lib()
+    B = args.batch
+    ldm = LatentDiffusion(SD15_UNET_CONFIG)
+    rng.load_synth_weights(ldm.model.diffusion_model, seed=0)
+    teacher = UNetModel(**SD15_UNET_CONFIG)
+    rng.load_synth_weights(teacher, seed=1)
+    id2ada = Arc2Face_ID2AdaPrompt()
+    rng.load_synth_weights(id2ada.text_to_image_prompt_encoder, seed=2)
+    rng.load_synth_weights(id2ada.subj_basis_generator.prompt2token_proj, seed=3)
+    text_enc = CLIPTextModelWrapper()
+    rng.load_synth_weights(text_enc, seed=4)
+    ldm = ldm.to(dev)
+    for p in ldm.model.diffusion_model.parameters():
+        p.requires_grad_(False)
+    ldm.unet_teacher = Arc2FaceTeacher(teacher.to(dev))
+    tr = DistillTrainer(ldm, id2ada.to(dev), text_enc.to(dev), batch_size=B, accumulate_grad_batches=2)
+    n_train = tr.arena.numel
+
+    def batch(i):
+        seed = 42 + i + rank * 10 ** 8
+        return dict(x_start=rng.synth_input(f"tb.x{i % 4}", (B, 4, 64, 64), seed=seed).to(dev),
+                    face_id_embs=rng.synth_input(f"tb.id{i % 4}", (B, 512), seed=seed).to(dev),
+                    fg_mask=torch.ones(B, 1, 64, 64, device=dev))
+    batches = [batch(i) for i in range(4)]
+    steps = args.steps + (args.steps % 2)            # whole accumulation windows
+    warm = max(2, args.warmup + (args.warmup % 2))
+    losses = []
+    for i in range(warm):
+        tr.training_step(batches[i % 4], i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        losses.append(tr.training_step(batches[i % 4], warm + i))
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    fam = None
+    if rank == 0 and not args.no_roofline:
+        ops.prof_reset()
+        ops.prof_enable(True)
+        for i in range(6):                             # one full 2,3,4-step cycle twice over (6 micro-batches)
+            tr.training_step(batches[i % 4], warm + steps + i)
+        torch.cuda.synchronize()
+        ops.prof_enable(False)
+        fam = {}
+        for name, f in (("gemm", _lib.AF_FAM_GEMM), ("attn", _lib.AF_FAM_ATTN), ("gnorm", _lib.AF_FAM_GNORM),
+                        ("lnorm", _lib.AF_FAM_LNORM), ("elem", _lib.AF_FAM_ELEM)):
+            n, ms = ops.prof_read(f)
+            fam[name] = {"launches_per_step": round(n / 6, 1), "ms_per_step": round(ms / 6, 3)}
+        ops.prof_reset()
+    if rank == 0:
+        ms = elapsed / steps * 1e3
+        out = {"metric": "train-images/sec Stage-1 Arc2Face distillation bs=4/GPU", "value": round(world * B * steps / elapsed, 3),
+               "unit": "images/s", "n_gpus": world, "steps": steps, "warmup": warm, "ms_per_step": round(ms, 3),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+               "config": {"workload": f"stage1_unet_distill micro-batch: bs={B}/GPU, 512x512 (latent 64x64), denoising steps cycle 2,3,4 "
+                                      "with HALF_BS=ceil(bs/steps), teacher+student SD-1.5 U-Nets, 3 CLIP-L encoders, "
+                                      f"{n_train} trainable fp32 params, accumulate_grad_batches=2, CAdamW",
+                          "parallelism": f"dp{world} (RCCL bucketed all-reduce overlapped with backward)" if world > 1 else "single GPU",
+                          "optimizer_steps": tr.global_step, "skipped_steps": tr.skipped_steps, "loss_scale": tr.scaler.scale,
+                          "last_loss": float(losses[-1]), "finite": bool(all(torch.isfinite(l) for l in losses))},
+               "families_per_micro_batch": fam}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -51,7 +150,12 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--mode", choices=["denoise", "train"], default="denoise",
+                    help="denoise: BASELINE configs[1] (the headline metric, default); train: configs[2]/[3], the Stage-1 "
+                         "distillation micro-batch (fwd + bwd + overlapped RCCL gradient exchange + CAdamW every 2nd)")
     args = ap.parse_args()
+    if args.mode == "train":
+        return main_train(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

@@ -6,7 +6,11 @@ first time a GEMM shape is seen, every candidate (tile in {128x128, 64x64 regist
 LDS-DMA ring} x split-K in {1..16}) is timed on the live operands with HIP events, and the fastest is written to
 adaface-dev_amd/tuning/gfx950_gemm.json.  Usage (GPU box):
 
-    python tools/autotune_gemm.py [--batches 8,2]
+    python tools/autotune_gemm.py [--batches 8,2] [--train] [--fresh]
+
+--train additionally runs three Stage-1 distillation micro-batches (denoising steps 2, 3, 4: teacher batches 1-2, the
+batched student pass at 4-6 samples, the whole backward and the CLIP encoders' forward/dgrad/wgrad GEMMs) so the
+training shapes are tuned as well.  Existing entries are kept unless --fresh is given.
 """
 import argparse
 import ctypes as C
@@ -24,6 +28,8 @@ def main():
     ap.add_argument("--batches", default="8,2")
     ap.add_argument("--reps", type=int, default=12)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--train", action="store_true")
+    ap.add_argument("--fresh", action="store_true", help="ignore the existing table instead of extending it")
     args = ap.parse_args()
     from adaface_dev_amd import SD15_UNET_CONFIG, _lib, ops, rng
     from adaface_dev_amd.ldm.modules.diffusionmodules.openaimodel import UNetModel
@@ -31,6 +37,10 @@ def main():
     dev = torch.device("cuda:0")
     L = _lib.lib()
     table, log = {}, []
+    if not args.fresh and os.path.exists(ops._TUNE_PATH):
+        with open(ops._TUNE_PATH) as f:
+            table = {k: tuple(v) for k, v in json.load(f).items()}
+        print(f"extending {len(table)} existing entries")
 
     def timed(d, device, tile, splits):
         d.tile, d.splits = tile, splits
@@ -81,6 +91,29 @@ def main():
             x = rng.synth_input("bench.x", (b, 4, 64, 64), seed=1).to(dev)
             ctx = rng.synth_input("bench.ctx", (b, 77, 768), seed=1).to(dev)
             unet(x, torch.full((b,), 500, device=dev), ctx, extra_info=None)
+            torch.cuda.synchronize()
+    if args.train:
+        from adaface_dev_amd.adaface.arc2face_models import CLIPTextModelWrapper
+        from adaface_dev_amd.adaface.face_id_to_ada_prompt import Arc2Face_ID2AdaPrompt
+        from adaface_dev_amd.adaface.unet_teachers import Arc2FaceTeacher
+        from adaface_dev_amd.ldm.models.diffusion.ddpm import LatentDiffusion
+        from adaface_dev_amd.ldm.trainer import DistillTrainer
+        ldm = LatentDiffusion(SD15_UNET_CONFIG)
+        rng.load_synth_weights(ldm.model.diffusion_model, seed=0)
+        id2ada = Arc2Face_ID2AdaPrompt()
+        rng.load_synth_weights(id2ada.text_to_image_prompt_encoder, seed=2)
+        rng.load_synth_weights(id2ada.subj_basis_generator.prompt2token_proj, seed=3)
+        text_enc = CLIPTextModelWrapper()
+        rng.load_synth_weights(text_enc, seed=4)
+        ldm = ldm.to(dev)
+        for p in ldm.model.diffusion_model.parameters():
+            p.requires_grad_(False)
+        ldm.unet_teacher = Arc2FaceTeacher(unet)                      # shapes only: the teacher can share the tuned U-Net
+        tr = DistillTrainer(ldm, id2ada.to(dev), text_enc.to(dev), batch_size=4, accumulate_grad_batches=2)
+        for i in range(4):
+            b = dict(x_start=rng.synth_input("tb.x", (4, 4, 64, 64), seed=5).to(dev),
+                     face_id_embs=rng.synth_input("tb.id", (4, 512), seed=5).to(dev), fg_mask=torch.ones(4, 1, 64, 64, device=dev))
+            tr.training_step(b, i)
             torch.cuda.synchronize()
     ops._tune_recorder = None
     out = args.out or ops._TUNE_PATH
