@@ -8,6 +8,7 @@ import pytest
 import torch
 
 from conftest import GOLDEN, rel_l2
+from trainer_util import trainer_setup
 
 pytestmark = pytest.mark.gpu
 
@@ -86,37 +87,6 @@ def test_unet_distill_loss_and_context_grad_vs_oracle(dev, steps):
     assert el < 5e-3 and eg < 1e-2
 
 
-def _trainer_setup(dev, accum=1):
-    """Reduced-width replica of the whole Stage-1 stack: CLIP encoders hidden 128 / 3 layers, U-Nets model_channels 64."""
-    from adaface_dev_amd import rng
-    from adaface_dev_amd.adaface.arc2face_models import CLIPTextModelWrapper, clip_text_config
-    from adaface_dev_amd.adaface.face_id_to_ada_prompt import Arc2Face_ID2AdaPrompt
-    from adaface_dev_amd.adaface.unet_teachers import Arc2FaceTeacher
-    from adaface_dev_amd.ldm.models.diffusion.ddpm import LatentDiffusion
-    from adaface_dev_amd.ldm.modules.diffusionmodules.openaimodel import UNetModel
-    from adaface_dev_amd.ldm.trainer import DistillTrainer, LossScaler
-    ccfg = clip_text_config(hidden_size=128, num_attention_heads=2, num_hidden_layers=3, intermediate_size=512)
-    ucfg = dict(CFG, context_dim=128)
-    ld = LatentDiffusion(ucfg)
-    rng.load_synth_weights(ld.model.diffusion_model, seed=41)
-    teacher_unet = UNetModel(**ucfg)
-    rng.load_synth_weights(teacher_unet, seed=42)
-    id2ada = Arc2Face_ID2AdaPrompt(clip_config=ccfg)
-    rng.load_synth_weights(id2ada.text_to_image_prompt_encoder, seed=43)
-    rng.load_synth_weights(id2ada.subj_basis_generator.prompt2token_proj, seed=44)
-    text_enc = CLIPTextModelWrapper(ccfg)
-    rng.load_synth_weights(text_enc, seed=45)
-    sds = dict(student=ld.model.diffusion_model.state_dict(), teacher=teacher_unet.state_dict(),
-               arc2face=id2ada.text_to_image_prompt_encoder.state_dict(),
-               sbg=id2ada.subj_basis_generator.prompt2token_proj.state_dict(), text=text_enc.state_dict())
-    sds = {k: {n: v.detach().clone() for n, v in sd.items()} for k, sd in sds.items()}
-    ld = ld.to(dev)
-    ld.unet_teacher = Arc2FaceTeacher(teacher_unet.to(dev))
-    tr = DistillTrainer(ld, id2ada.to(dev), text_enc.to(dev), accumulate_grad_batches=accum, warm_up_steps=0,
-                        loss_scaler=LossScaler(init_scale=2.0 ** 10))
-    return tr, sds, ucfg
-
-
 def _oracle_distill(sds, ucfg, ids512, x0, noise, t, fg, steps, pres, sbg_sd=None):
     from adaface_dev_amd.adaface.subj_basis_generator import template_ids
     from oracle import clip_oracle as CO
@@ -148,7 +118,7 @@ def test_distill_trainer_micro_batch_loss_and_weight_gradients_vs_oracle(dev):
     """face IDs -> Arc2Face encoder -> trainable SubjBasisGenerator -> frozen text encoder -> student/teacher U-Nets ->
     loss; the gradients of every SubjBasisGenerator weight (flat arena) against autograd through the fp32 CPU oracles."""
     from adaface_dev_amd import rng
-    tr, sds, ucfg = _trainer_setup(dev)
+    tr, sds, ucfg = trainer_setup(dev)
     BS, steps = 4, 2                        # HALF_BS = 2 (ddpm.py:1283-1289)
     ids512 = rng.synth_input("tr.ids", (BS, 512), seed=46)
     x0 = rng.synth_input("tr.x0", (BS, 4, 32, 32), seed=46)
@@ -187,7 +157,7 @@ def test_distill_trainer_accumulate_and_step(dev):
     """Two micro-batches with accumulate_grad_batches=2: one optimizer step, lr from the warm-up/cosine schedule, update
     direction -lr*sign(g) at step 1 of cautious AdamW on (almost) every element, gradients zeroed afterwards."""
     from adaface_dev_amd import rng
-    tr, sds, ucfg = _trainer_setup(dev, accum=2)
+    tr, sds, ucfg = trainer_setup(dev, accum=2)
     p0 = tr.arena.flat_p.clone()
     BS = 4
     batches = []
@@ -210,3 +180,34 @@ def test_distill_trainer_accumulate_and_step(dev):
     assert float(dp.abs().max()) <= lr * 1.01 / 0.999
     assert g_after_first.shape == dp.shape
     assert tr.unet_distill_iters_count == 2
+
+
+def test_data_parallel_step_two_ranks_equals_accumulated_single_process(dev, tmp_path):
+    """world_size 2 (two processes sharing this GPU, gloo transport -- RCCL refuses two ranks on one device), one micro-batch
+    per rank, bucketed all-reduce from the backward hooks  ==  one process accumulating the same two micro-batches:
+    identical mean gradient, identical lr (accum * world * bs * base_lr), identical parameters after the CAdamW step."""
+    import subprocess
+    import sys
+    from adaface_dev_amd import rng
+    out = tmp_path / "ddp_params.pt"
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", PYTHONPATH=os.path.dirname(here) + os.pathsep + here)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29617", os.path.join(here, "ddp_train_worker.py"), str(out)], env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    got = torch.load(out)
+    tr, _, _ = trainer_setup(dev, accum=2)
+    t = torch.tensor([760, 850, 800, 720], device=dev)
+    for i in range(2):
+        b = dict(x_start=rng.synth_input(f"dp.x{i}", (4, 4, 32, 32), seed=48).to(dev), face_id_embs=rng.synth_input(f"dp.id{i}", (4, 512), seed=48).to(dev),
+                 fg_mask=torch.ones(4, 1, 32, 32, device=dev), noise=rng.synth_input(f"dp.n{i}", (4, 4, 32, 32), seed=48).to(dev))
+        tr.training_step(b, i, num_unet_denoising_steps=1, t=t)
+    assert tr.global_step == 1 and got["global_step"] == 1 and got["world"] == 2
+    assert abs(got["lr"] - tr.learning_rate) < 1e-12
+    ref = tr.arena.flat_p.cpu()
+    # gradients agree to fp32 summation order; the sign-like first CAdamW step turns the few near-zero elements whose sign
+    # flips into +-lr outliers, so compare the update direction on (almost) all elements and the mean gradient exactly-ish
+    same = ((got["flat_p"] - got["p0"]).sign() == (ref - got["p0"]).sign()).float().mean()
+    assert same > 0.999, float(same)
+    assert rel_l2(got["mean_grad"].numpy(), got["mean_grad_expected_from_rank_sums"].numpy()) < 1e-5

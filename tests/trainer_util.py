@@ -1,0 +1,36 @@
+"""Shared by tests/test_hip_train.py and tests/ddp_train_worker.py: a reduced-width replica of the whole Stage-1 stack."""
+import torch
+
+CFG = dict(in_channels=4, model_channels=64, out_channels=4, num_res_blocks=2, attention_resolutions=[4, 2, 1],
+           channel_mult=[1, 2, 4, 4], num_heads=8, use_spatial_transformer=True, transformer_depth=1, context_dim=64, legacy=False)
+
+
+def trainer_setup(dev, accum=1, process_group=None):
+    """Reduced-width replica of the whole Stage-1 stack: CLIP encoders hidden 128 / 3 layers, U-Nets model_channels 64."""
+    from adaface_dev_amd import rng
+    from adaface_dev_amd.adaface.arc2face_models import CLIPTextModelWrapper, clip_text_config
+    from adaface_dev_amd.adaface.face_id_to_ada_prompt import Arc2Face_ID2AdaPrompt
+    from adaface_dev_amd.adaface.unet_teachers import Arc2FaceTeacher
+    from adaface_dev_amd.ldm.models.diffusion.ddpm import LatentDiffusion
+    from adaface_dev_amd.ldm.modules.diffusionmodules.openaimodel import UNetModel
+    from adaface_dev_amd.ldm.trainer import DistillTrainer, LossScaler
+    ccfg = clip_text_config(hidden_size=128, num_attention_heads=2, num_hidden_layers=3, intermediate_size=512)
+    ucfg = dict(CFG, context_dim=128)
+    ld = LatentDiffusion(ucfg)
+    rng.load_synth_weights(ld.model.diffusion_model, seed=41)
+    teacher_unet = UNetModel(**ucfg)
+    rng.load_synth_weights(teacher_unet, seed=42)
+    id2ada = Arc2Face_ID2AdaPrompt(clip_config=ccfg)
+    rng.load_synth_weights(id2ada.text_to_image_prompt_encoder, seed=43)
+    rng.load_synth_weights(id2ada.subj_basis_generator.prompt2token_proj, seed=44)
+    text_enc = CLIPTextModelWrapper(ccfg)
+    rng.load_synth_weights(text_enc, seed=45)
+    sds = dict(student=ld.model.diffusion_model.state_dict(), teacher=teacher_unet.state_dict(),
+               arc2face=id2ada.text_to_image_prompt_encoder.state_dict(),
+               sbg=id2ada.subj_basis_generator.prompt2token_proj.state_dict(), text=text_enc.state_dict())
+    sds = {k: {n: v.detach().clone() for n, v in sd.items()} for k, sd in sds.items()}
+    ld = ld.to(dev)
+    ld.unet_teacher = Arc2FaceTeacher(teacher_unet.to(dev))
+    tr = DistillTrainer(ld, id2ada.to(dev), text_enc.to(dev), accumulate_grad_batches=accum, warm_up_steps=0,
+                        loss_scaler=LossScaler(init_scale=2.0 ** 10), process_group=process_group)
+    return tr, sds, ucfg
