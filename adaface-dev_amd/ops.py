@@ -491,6 +491,37 @@ def scale_f32_(a, s):
     return a
 
 
+# ----------------------------------------------------------------------------- ArcFace ResNetFace encoder
+def affine_prelu(x, scale=None, shift=None, slope=None):
+    """y = prelu(x * scale[c] + shift[c]) over the last (channel) axis; any of the two stages may be absent."""
+    Cn = x.shape[-1]
+    y = torch.empty_like(x)
+    _lib.check(_lib.lib().af_affine_prelu(_p(x), _p(scale), _p(shift), _p(slope), _p(y), x.numel() // Cn, Cn, _stream()), "af_affine_prelu")
+    return y
+
+
+def maxpool2x2(x):
+    B, H2, W2, Cn = x.shape
+    y = torch.empty((B, H2 // 2, W2 // 2, Cn), dtype=F16, device=x.device)
+    _lib.check(_lib.lib().af_maxpool2x2(_p(x), _p(y), B, H2 // 2, W2 // 2, Cn, _stream()), "af_maxpool2x2")
+    return y
+
+
+def global_avgpool(x):
+    B, H, W, Cn = x.shape
+    out = torch.empty((B, Cn), dtype=F16, device=x.device)
+    _lib.check(_lib.lib().af_global_avgpool(_p(x), _p(out), B, H * W, Cn, _stream()), "af_global_avgpool")
+    return out
+
+
+def se_residual_prelu(x, se_logits, residual, slope):
+    B, H, W, Cn = x.shape
+    y = torch.empty_like(x)
+    _lib.check(_lib.lib().af_se_residual_prelu(_p(x), _p(se_logits), _p(residual), _p(slope), _p(y), B, H * W, Cn, _stream()),
+               "af_se_residual_prelu")
+    return y
+
+
 # ----------------------------------------------------------------------------- profiling hook
 def prof_enable(on: bool):
     _lib.check(_lib.lib().af_prof_enable(int(on)), "af_prof_enable")

@@ -54,3 +54,23 @@ def synth_input(name: str, shape, seed: int = 0, scale: float = 1.0) -> torch.Te
     g = _stream(seed, "input:" + name)
     z = g.standard_normal(size=tuple(int(s) for s in shape), dtype=np.float32) * scale
     return torch.from_numpy(z.astype(np.float32))
+
+
+def synth_face_state_dict(state_dict, seed: int = 0):
+    """Synthetic values for every entry of a ResNetFace state dict (parameters AND BatchNorm buffers) from names + shapes:
+    running_var > 0, PReLU slopes around 0.25, everything else by `synth_tensor`'s rules."""
+    out = {}
+    for name, t in state_dict.items():
+        shape = tuple(t.shape)
+        if name.endswith("num_batches_tracked"):
+            out[name] = torch.zeros(shape, dtype=t.dtype)
+            continue
+        z = synth_tensor(name, shape if shape else (1,), seed)
+        if name.endswith("running_var"):
+            z = 0.6 + 0.4 * z.abs()
+        elif name.endswith("running_mean"):
+            z = (z - 1.0)                                    # 1-D rule gives 1 + 0.1 z -> 0.1 z
+        elif t.numel() == 1:                                  # nn.PReLU() slope
+            z = 0.25 + 0.5 * (z - 1.0)
+        out[name] = z.reshape(shape).to(torch.float32)
+    return out

@@ -225,6 +225,18 @@ int af_quickgelu_bwd(const void* x, const void* dy, void* dx, int64_t n, void* s
 /* y = a * s (fp32), used to unscale the loss-scaled gradient arena before the optimizer step */
 int af_scale_f32(void* a, float s, int64_t n, void* stream);
 
+/* ---- ArcFace ResNetFace-18 IR-SE face encoder (reference evaluation/arcface_resnet.py:62-97, 139-154, 157-217) ----
+ * NHWC fp16 activations, C % 8 == 0.  Convolutions / FCs are af_gemm calls with eval-mode BatchNorm folded on the host.
+ * y = prelu(x * scale[c] + shift[c]); scale/shift fp32 [C] or both NULL; slope fp32 [1] device pointer or NULL (no PReLU) */
+int af_affine_prelu(const void* x, const void* scale, const void* shift, const void* slope, void* y, int64_t rows, int C, void* stream);
+/* x [B, 2Ho, 2Wo, C] -> y [B, Ho, Wo, C] (nn.MaxPool2d(2, 2), arcface_resnet.py:165) */
+int af_maxpool2x2(const void* x, void* y, int B, int Ho, int Wo, int C, void* stream);
+/* x [B, HW, C] -> out fp16 [B, C] (AdaptiveAvgPool2d(1), arcface_resnet.py:142) */
+int af_global_avgpool(const void* x, void* out, int B, int HW, int C, void* stream);
+/* y = prelu(x * sigmoid(se_logits[b, c]) + residual); se_logits fp16 [B, C] or NULL (use_se = False) (arcface_resnet.py:88-95,153) */
+int af_se_residual_prelu(const void* x, const void* se_logits, const void* residual, const void* slope, void* y, int B, int HW, int C,
+                         void* stream);
+
 #ifdef __cplusplus
 }
 #endif

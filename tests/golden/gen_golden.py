@@ -366,6 +366,28 @@ def gen_clip(out):
     print("clip:", {k: v.shape for k, v in res.items()}, len(o.hidden_states))
 
 
+def gen_arcface(out):
+    """ResNetFace-18 IR-SE (evaluation/arcface_resnet.py:337-339) in eval mode on seeded weights AND BatchNorm statistics:
+    the 512-d embedding and the four stage outputs' probes for 3 grey 128x128 crops."""
+    from evaluation.arcface_resnet import resnet_face18
+    from adaface_dev_amd import rng
+    m = resnet_face18(use_se=True).eval()
+    m.load_state_dict(rng.synth_face_state_dict(m.state_dict(), seed=50))
+    x = rng.synth_input("face.x", (3, 1, 128, 128), seed=50)
+    feats = []
+    hooks = [getattr(m, f"layer{i}").register_forward_hook(lambda mod, inp, o: feats.append(o.detach())) for i in range(1, 5)]
+    with torch.no_grad():
+        y = m(x)
+    for h in hooks:
+        h.remove()
+    d = {"emb": y.numpy()}
+    for i, f in enumerate(feats):
+        d[f"layer{i + 1}_probes"] = probes(f)
+    d["layer4"] = feats[3].numpy()
+    np.savez_compressed(os.path.join(out, "arcface.npz"), **d)
+    print("arcface.npz", y.shape, float(y.abs().mean()))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-full", action="store_true")
@@ -374,7 +396,7 @@ def main():
     install_reference_stubs()
     torch.set_num_threads(8)
     out = HERE
-    jobs = {"blocks": gen_blocks, "schedule": gen_schedule, "train": gen_train, "clip": gen_clip, "unet_tiny": gen_unet_tiny, "unet_full": gen_unet_full}
+    jobs = {"blocks": gen_blocks, "schedule": gen_schedule, "train": gen_train, "clip": gen_clip, "arcface": gen_arcface, "unet_tiny": gen_unet_tiny, "unet_full": gen_unet_full}
     for name, fn in jobs.items():
         if args.only and name != args.only:
             continue
