@@ -1,0 +1,63 @@
+"""AdaFaceWrapper host logic (reference adaface_wrapper.py:414-532): placeholder-token registration, token-table patching and
+prompt rewriting -- pure host code, CPU only.  Expected strings are worked out by hand from the reference's regexes."""
+import torch
+
+from adaface_dev_amd import TINY_UNET_CONFIG
+from adaface_dev_amd.adaface.adaface_wrapper import AdaFaceWrapper, WordTokenizer
+from adaface_dev_amd.adaface.arc2face_models import clip_text_config
+
+TOKS = " ".join(f"z_0_{j}" for j in range(16))
+
+
+def _wrapper():
+    cc = clip_text_config(hidden_size=64, num_attention_heads=1, num_hidden_layers=1, intermediate_size=128)
+    return AdaFaceWrapper(clip_config=cc, unet_config=dict(TINY_UNET_CONFIG), device="cpu")
+
+
+def test_token_registration_and_embedding_resize():
+    w = _wrapper()
+    assert w.all_placeholder_tokens == [f"z_0_{j}" for j in range(16)]
+    assert w.placeholder_token_ids == list(range(49408, 49424)) and len(w.tokenizer) == 49424
+    assert w.text_encoder.text_model.embeddings.token_embedding.weight.shape == (49424, 64)
+    assert w.all_null_placeholder_tokens_str == " ".join([", "] * 16)
+    try:
+        AdaFaceWrapper(clip_config=w.text_encoder.config, unet_config=dict(TINY_UNET_CONFIG), device="cpu", tokenizer=w.tokenizer)
+    except ValueError as e:
+        assert "already contains" in str(e)
+    else:
+        raise AssertionError("re-registering the same placeholder tokens must fail like the reference (:440-444)")
+
+
+def test_update_prompt_matches_reference_rules():
+    w = _wrapper()
+    assert w.update_prompt("portrait of a z, in a garden") == "portrait of  in a garden " + TOKS
+    assert w.update_prompt("z") == " " + TOKS
+    assert w.update_prompt(None) == " " + TOKS
+    assert w.update_prompt("the z at the beach", placeholder_tokens_pos="prepend") == TOKS + "  at the beach"
+    assert w.update_prompt("zebra z") == "zebra  " + TOKS                               # \bz\b only
+    nul = " ".join([", "] * 16)
+    assert w.update_prompt("a woman z", use_null_placeholders=True) == "a woman  " + nul
+    assert w.update_prompt("z on a chair", use_null_placeholders=True) == " on a chair person " + nul
+    assert w.update_prompt("x", repeat_prompt_for_each_encoder=False) == "x " + TOKS
+
+
+def test_update_text_encoder_subj_embeddings_and_tokenisation():
+    w = _wrapper()
+    embs = torch.arange(16 * 64, dtype=torch.float32).reshape(16, 64)
+    w.update_text_encoder_subj_embeddings(embs, [16])
+    table = w.text_encoder.text_model.embeddings.token_embedding.weight
+    assert torch.equal(table[49408:49424], embs)
+    assert w.updated_tokens_str == TOKS
+    ids = w.tokenizer([w.update_prompt("a photo of z")], max_length=77).input_ids
+    assert ids.shape == (1, 77) and ids[0, 0] == 49406 and ids[0, 4:20].tolist() == list(range(49408, 49424)) and ids[0, 20] == 49407
+    # static-suffix-disabled case: fewer embeddings than registered tokens
+    w.update_text_encoder_subj_embeddings(embs[:4] + 1, [4])
+    assert w.updated_tokens_str == "z_0_0 z_0_1 z_0_2 z_0_3" and torch.equal(table[49408:49412], embs[:4] + 1)
+
+
+def test_word_tokenizer_protocol():
+    t = WordTokenizer()
+    assert t.add_tokens(["z_0_0", "z_0_1"]) == 2 and t.add_tokens(["z_0_0"]) == 0
+    assert t.convert_tokens_to_ids("z_0_1") == 49409 and t.convert_tokens_to_ids(["photo", ","]) == [1125, 267]
+    ids = t(["A photo, z_0_0"], max_length=8).input_ids[0].tolist()
+    assert ids == [49406, 320, 1125, 267, 49408, 49407, 49407, 49407]

@@ -154,3 +154,41 @@ def test_small_encoder_weight_gradients_vs_oracle_autograd(dev):
     assert rel_l2((tok_d.grad / S).cpu().numpy(), tok_r.grad.numpy()) < 1e-2
     assert rel_l2((w_d.grad / S).cpu().numpy(), w_r.grad.numpy()) < 1e-2
     print(f"worst encoder parameter-gradient rel-L2 vs oracle autograd: {worst:.3e}")
+
+
+def test_adaface_wrapper_end_to_end_reduced_width(dev):
+    """AdaFaceWrapper (config-2 API): face IDs -> AdaFace token embeddings -> token table -> rewritten prompt -> text encoder ->
+    5-step DDIM with CFG on a reduced-width U-Net; the result equals the same sampler driven by hand with embeddings from
+    `encode_prompt`, and the prompt embedding equals the CPU oracle's text-encoder output for the patched token table."""
+    from adaface_dev_amd import TINY_UNET_CONFIG, rng
+    from adaface_dev_amd.adaface.adaface_wrapper import AdaFaceWrapper
+    from adaface_dev_amd.adaface.arc2face_models import clip_text_config
+    from adaface_dev_amd.ldm.models.diffusion.ddim import DDIMSampler
+    from oracle import clip_oracle as CO
+    cc = clip_text_config(hidden_size=128, num_attention_heads=2, num_hidden_layers=3, intermediate_size=512)
+    w = AdaFaceWrapper(clip_config=cc, unet_config=dict(TINY_UNET_CONFIG, model_channels=64, context_dim=128), device=dev, num_inference_steps=5)
+    rng.load_synth_weights(w.text_encoder, seed=60)
+    rng.load_synth_weights(w.id2ada_prompt_encoder.text_to_image_prompt_encoder, seed=61)
+    rng.load_synth_weights(w.id2ada_prompt_encoder.subj_basis_generator.prompt2token_proj, seed=62)
+    rng.load_synth_weights(w.ldm.model.diffusion_model, seed=63)
+    w = w.to(dev)
+    ids512 = rng.synth_input("w.ids", (2, 512), seed=60).to(dev)
+    embs = w.prepare_adaface_embeddings(None, face_id_embs=ids512, avg_at_stage="id_emb")
+    assert embs.shape == (16, 128)
+    table = w.text_encoder.text_model.embeddings.token_embedding.weight
+    assert torch.equal(table[49408:49424].float(), embs.float().to(table.dtype).float())
+    pe, ne, _, _ = w.encode_prompt("portrait of a z, in a garden", device=dev)
+    assert pe.shape == (1, 77, 128) and ne.shape == (1, 77, 128)
+    sd = {k: v.detach().float().cpu() for k, v in w.text_encoder.state_dict().items()}
+    tok_ids = w.tokenizer([w.update_prompt("portrait of a z, in a garden")], max_length=77).input_ids
+    ref = CO.clip_text_forward(sd, dict(hidden=128, heads=2, layers=3), tok_ids)[0]
+    assert rel_l2(pe.float().cpu().numpy(), ref.numpy()) < 5e-3
+    noise = rng.synth_input("w.noise", (3, 4, 16, 16), seed=60)
+    lat = w(noise, "portrait of a z, in a garden", guidance_scale=4.0, out_image_count=3)
+    assert lat.shape == (3, 4, 16, 16) and bool(torch.isfinite(lat).all())
+    sampler = DDIMSampler(w.ldm)
+    man, _ = sampler.sample(5, 3, (4, 16, 16), conditioning=(pe.repeat(3, 1, 1), [""] * 3, {}), x_T=noise.to(dev), verbose=False,
+                            guidance_scale=4.0, unconditional_conditioning=(ne.repeat(3, 1, 1), [""] * 3, {}))
+    assert torch.equal(lat, man)
+    lat2 = w(noise, None, prompt_embeds=(pe, ne), guidance_scale=4.0, out_image_count=3)
+    assert torch.equal(lat, lat2)
