@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Micro-benchmark of one kernel shape on the GPU box (also the target of rocprofv3 --pmc runs).
     python tools/bench_kernel.py attn  B N L heads d [reps]
-    python tools/bench_kernel.py gemm  M N K [tile] [splits] [reps]
+    python tools/bench_kernel.py gemm  M N K [tile] [splits] [reps] [act]      (act 2 = GEGLU, 3 = quick-GELU, 1 = SiLU)
     python tools/bench_kernel.py conv  B H W Cin Cout [tile] [splits] [reps]
     python tools/bench_kernel.py gn    B HW C [reps]
 """
@@ -46,10 +46,11 @@ def main():
         M, N, K = a[:3]
         tile, splits = (a[3] if len(a) > 3 else 0), (a[4] if len(a) > 4 else 0)
         reps = a[5] if len(a) > 5 else 20
+        act = a[6] if len(a) > 6 else 0
         x, w = rnd(M, K), rnd(N, K)
-        pw = ops.pack_matrix(w, None, dev)
-        ms = timeit(lambda: ops.gemm(x, pw, tile=tile, splits=splits), reps)
-        print(f"gemm M{M} N{N} K{K} tile{tile} splits{splits}: {ms * 1e3:.1f} us  {2.0 * M * N * K / ms / 1e9:.1f} TFLOP/s")
+        pw = ops.pack_matrix(w, torch.zeros(N), dev)
+        ms = timeit(lambda: ops.gemm(x, pw, tile=tile, splits=splits, act=act), reps)
+        print(f"gemm M{M} N{N} K{K} tile{tile} splits{splits} act{act}: {ms * 1e3:.1f} us  {2.0 * M * N * K / ms / 1e9:.1f} TFLOP/s")
     elif kind == "conv":
         B, H, W, ci, co = a[:5]
         tile, splits = (a[5] if len(a) > 5 else 0), (a[6] if len(a) > 6 else 0)
