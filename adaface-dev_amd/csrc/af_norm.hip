@@ -15,7 +15,7 @@
 
 namespace {
 
-constexpr int GN_NBLK = 32;    // statistic partial blocks per batch item
+constexpr int GN_NBLK = 128;   // max statistic partial blocks per batch item (the launch uses a.nblk <= GN_NBLK)
 constexpr int GN_MAXG = 32;
 
 struct GnArgs {
@@ -31,6 +31,7 @@ struct GnArgs {
   float* ws;  // [B][GN_NBLK][GN_MAXG][2]
   float* stats;  // optional out [B][groups][2] = (mean, rstd)
   int ppb;    // pixel slots per iteration (CT == 1)
+  int nblk;   // partial blocks per batch item in this launch
 };
 
 __device__ __forceinline__ half8_t gn_load(const GnArgs& a, int b, int pix, int c0) {
@@ -49,7 +50,7 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(GnArgs a) {
   const int slot = CT == 1 ? t / a.CP : 0;
   const int chunk0 = CT == 1 ? t - slot * a.CP : t;
   const bool active = CT == 1 ? (slot < slots) : true;
-  const int per = (a.HW + GN_NBLK - 1) / GN_NBLK;
+  const int per = (a.HW + a.nblk - 1) / a.nblk;
   const int p0 = blk * per, p1 = min(a.HW, p0 + per);
 
   float s[CT][8], q[CT][8];
@@ -59,20 +60,28 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(GnArgs a) {
     for (int e = 0; e < 8; ++e) s[j][e] = q[j][e] = 0.f;
 
   if (active) {
-    for (int pix = p0 + slot; pix < p1; pix += slots) {
+    // PF pixels per thread in flight: the loop is pure load -> fma, so bytes in flight per CU are what sets the rate
+    constexpr int PF = CT == 1 ? 4 : 2;
+    for (int pix = p0 + slot; pix < p1; pix += slots * PF) {
+      half8_t v[PF][CT];
 #pragma unroll
-      for (int j = 0; j < CT; ++j) {
-        const int ch = chunk0 + 256 * j;
-        if (ch < a.CP) {
-          const half8_t v = gn_load(a, b, pix, ch * 8);
+      for (int u = 0; u < PF; ++u)
+#pragma unroll
+        for (int j = 0; j < CT; ++j) {
+          const int ch = chunk0 + 256 * j;
+          const int px = pix + u * slots;
+          v[u][j] = (px < p1 && ch < a.CP) ? gn_load(a, b, px, ch * 8) : half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+#pragma unroll
+      for (int u = 0; u < PF; ++u)
+#pragma unroll
+        for (int j = 0; j < CT; ++j)
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
-            const float f = (float)v[e];
+            const float f = (float)v[u][j][e];
             s[j][e] += f;
             q[j][e] += f * f;
           }
-        }
-      }
     }
   }
   float* rs = red;
@@ -118,13 +127,28 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(GnArgs a) {
 template <int CT>
 __global__ __launch_bounds__(256) void gn_apply_kernel(GnArgs a) {
   __shared__ float mr[GN_MAXG][2];
+  __shared__ float fold[8][GN_MAXG][2];
   const int t = threadIdx.x, b = blockIdx.y;
+  {
+    // 8 lanes of partial blocks x 32 groups: every thread folds nblk / 8 partials, then 8 -> 1 through LDS
+    const int g = t & 31, kl = t >> 5;
+    float ss = 0.f, qq = 0.f;
+    if (g < a.groups)
+      for (int k = kl; k < a.nblk; k += 8) {
+        const float* w = a.ws + (((size_t)b * GN_NBLK + k) * GN_MAXG + g) * 2;
+        ss += w[0];
+        qq += w[1];
+      }
+    fold[kl][g][0] = ss;
+    fold[kl][g][1] = qq;
+  }
+  __syncthreads();
   if (t < a.groups) {
     float ss = 0.f, qq = 0.f;
-    for (int k = 0; k < GN_NBLK; ++k) {
-      const float* w = a.ws + (((size_t)b * GN_NBLK + k) * GN_MAXG + t) * 2;
-      ss += w[0];
-      qq += w[1];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      ss += fold[k][t][0];
+      qq += fold[k][t][1];
     }
     const float inv_n = 1.0f / ((float)a.HW * (float)a.cpg);
     const float mean = ss * inv_n;
@@ -157,22 +181,34 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnArgs a) {
   }
   const int per = (a.HW + gridDim.x - 1) / gridDim.x;
   const int p0 = blockIdx.x * per, p1 = min(a.HW, p0 + per);
-  for (int pix = p0 + slot; pix < p1; pix += slots) {
+  constexpr int PF = CT == 1 ? 4 : 2;
+  for (int pix = p0 + slot; pix < p1; pix += slots * PF) {
+    half8_t v[PF][CT];
 #pragma unroll
-    for (int j = 0; j < CT; ++j) {
-      const int ch = chunk0 + 256 * j;
-      if (ch < a.CP) {
-        const half8_t v = gn_load(a, b, pix, ch * 8);
-        half8_t o;
+    for (int u = 0; u < PF; ++u)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float f = (float)v[e] * sc[j][e] + sh[j][e];
-          if (a.silu) f = af_silu(f);
-          o[e] = (half_t)f;
-        }
-        *reinterpret_cast<half8_t*>(a.y + ((size_t)b * a.HW + pix) * a.C + ch * 8) = o;
+      for (int j = 0; j < CT; ++j) {
+        const int ch = chunk0 + 256 * j;
+        const int px = pix + u * slots;
+        if (px < p1 && ch < a.CP) v[u][j] = gn_load(a, b, px, ch * 8);
       }
-    }
+#pragma unroll
+    for (int u = 0; u < PF; ++u)
+#pragma unroll
+      for (int j = 0; j < CT; ++j) {
+        const int ch = chunk0 + 256 * j;
+        const int px = pix + u * slots;
+        if (px < p1 && ch < a.CP) {
+          half8_t o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float f = (float)v[u][j][e] * sc[j][e] + sh[j][e];
+            if (a.silu) f = af_silu(f);
+            o[e] = (half_t)f;
+          }
+          *reinterpret_cast<half8_t*>(a.y + ((size_t)b * a.HW + px) * a.C + ch * 8) = o;
+        }
+      }
   }
 }
 
@@ -274,9 +310,15 @@ extern "C" int af_groupnorm_stats(const void* x1, const void* x2, int c1, int c2
   const size_t lds = (size_t)2 * slots * C * sizeof(float);
   hipStream_t s = (hipStream_t)stream;
   AfLaunchScope scope(AF_FAM_GNORM, stream);
-  dim3 g1(GN_NBLK, B), blk(256);
-  int nb2 = (HW + slots - 1) / slots;
-  nb2 = nb2 > 64 ? 64 : nb2;
+  // enough workgroups to keep >= 4 per CU streaming (B * nblk >= 1024 when the tensor is large enough), each thread with
+  // several 16-byte loads in flight; small levels keep >= 4 pixel iterations per thread
+  const int iters = (HW + slots - 1) / slots;          // pixel iterations if one block took a whole batch item
+  int nblk = (iters + 7) / 8;
+  nblk = nblk < 1 ? 1 : (nblk > GN_NBLK ? GN_NBLK : nblk);
+  a.nblk = nblk;
+  dim3 g1(nblk, B), blk(256);
+  int nb2 = (iters + 7) / 8;
+  nb2 = nb2 < 1 ? 1 : (nb2 > 256 ? 256 : nb2);
   dim3 g2(nb2, B);
   if (ct == 1) {
     hipLaunchKernelGGL(gn_partial_kernel<1>, g1, blk, lds, s, a);
