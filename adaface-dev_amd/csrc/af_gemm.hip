@@ -18,6 +18,16 @@
 #include <stdlib.h>
 
 #include "af_common.h"
+#include <stdlib.h>
+
+// Which operand an XCD's contiguous tile range should share in its private 4 MB L2: every XCD streams the operand it does NOT
+// share in full, so share the bigger one.  Weights (N x K) beat activations (M x Cin) on the 16x16 / 8x8 levels, where the
+// default M-major mapping made all 8 XCDs fetch the whole 29.5 MB filter of a 1280 -> 1280 conv (FETCH_SIZE, profiles/r01g).
+int af_gemm_n_major(int M, int N, int K, int cin) {
+  static const int force = getenv("AF_GEMM_NMAJOR") ? atoi(getenv("AF_GEMM_NMAJOR")) : -1;
+  if (force >= 0) return force;
+  return (long)N * K > (long)M * cin ? 1 : 0;
+}
 
 namespace {
 
@@ -34,7 +44,7 @@ struct GemmDev {
   int c1, c2, lda1, lda2;
   int H, W, Ho, Wo, HoWo, Heff, Weff, stride, upsample;
   int rows_per_batch, ld_rowbias, act_silu, ld_out, split_col, ld_out2;  // act_silu: 0 none, 1 SiLU, 3 quick-GELU
-  int tiles_n;
+  int tiles_n, tiles_m, n_major;
   int splits, kt_per_split;  // split-K: blockIdx.y owns K steps [y*kt_per_split, ...)
   float* ws;                 // fp32 partials [splits][M][N] when splits > 1
 };
@@ -65,8 +75,13 @@ __global__ __launch_bounds__(256, 2) void af_gemm_kernel(GemmDev p) {
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
     const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    tile_m = lid / p.tiles_n;
-    tile_n = lid - tile_m * p.tiles_n;
+    if (p.n_major) {           // weights outweigh activations: an XCD's contiguous tile range shares W columns, not A rows
+      tile_n = lid / p.tiles_m;
+      tile_m = lid - tile_n * p.tiles_m;
+    } else {
+      tile_m = lid / p.tiles_n;
+      tile_n = lid - tile_m * p.tiles_n;
+    }
   }
 
   // ---- loader state: thread owns chunk column cc (8 halves) of rows rb + 32*i
@@ -360,6 +375,8 @@ int launch(const GemmDev& p0, hipStream_t stream) {
   GemmDev p = p0;
   const int tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + BN - 1) / BN;
+  p.tiles_m = tiles_m;
+  p.n_major = af_gemm_n_major(p.M, p.N, p.K, TAPS == 9 ? p.c1 + p.c2 : p.K);
   const int nk = p.kpad / BK;
   if (p.splits > nk) p.splits = nk;
   p.kt_per_split = (nk + p.splits - 1) / p.splits;

@@ -19,6 +19,8 @@
 
 #include "af_common.h"
 
+int af_gemm_n_major(int M, int N, int K, int cin);   // af_gemm.hip
+
 namespace {
 
 struct Gemm3Dev {
@@ -36,7 +38,7 @@ struct Gemm3Dev {
   int c1, c2, lda1, lda2;
   int H, W, Ho, Wo, HoWo, stride;
   int rows_per_batch, ld_rowbias, act, ld_out;
-  int tiles_n, splits, kt_per_split;
+  int tiles_n, tiles_m, n_major, splits, kt_per_split;
   float* ws;
   int ablate;  // profiling only (AF_GEMM3_ABLATE): 1 = no DMA after the prologue, 2 = fragments read once, 4 = no barrier
 };
@@ -83,8 +85,13 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void af_gem
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
     const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    tile_m = lid / p.tiles_n;
-    tile_n = lid - tile_m * p.tiles_n;
+    if (p.n_major) {           // weights outweigh activations: an XCD's contiguous tile range shares W columns, not A rows
+      tile_n = lid / p.tiles_m;
+      tile_m = lid - tile_n * p.tiles_m;
+    } else {
+      tile_m = lid / p.tiles_n;
+      tile_n = lid - tile_m * p.tiles_n;
+    }
   }
 
   // ---- loader state: wave w fills A pieces {w*APW + j} and W pieces {w + NW*j}
@@ -307,6 +314,8 @@ void launch3(const Gemm3Dev& p0, hipStream_t stream) {
   constexpr size_t lds = (size_t)NST * (BM + WROWS) * 64;
   p.tiles_n = (p.N + BN - 1) / BN;
   const int tiles_m = (p.M + BM - 1) / BM;
+  p.tiles_m = tiles_m;
+  p.n_major = af_gemm_n_major(p.M, p.N, p.K, TAPS == 9 ? p.c1 + p.c2 : p.K);
   static bool attr_set = false;
   if (lds > 65536 && !attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&af_gemm3_kernel<TAPS, NWM, NWN, TN, EPI>),
