@@ -275,10 +275,18 @@ def main():
         flops_step = GEMM_GFLOP_PER_SAMPLE * 1e9 * 2 * B
         achieved = flops_step / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
         a_ms = fam["attn"]["ms_per_step"]
+        # HBM bytes per launch of the GEMM family: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
+        # (separate passes, gfx950 x2 fetch correction; tools/pmc_traffic.py), committed under profiles/ -- counters cannot be
+        # read from inside the process, so the latest committed measurement is reported (null if absent)
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01g_hbm_traffic.json")
+        if os.path.exists(tpath) and B == 4:
+            with open(tpath) as f:
+                traffic = round(json.load(f)["gemm"]["bytes_per_step"] / g_n, 1) if g_n else None   # per af_gemm call, like `achieved`
         roofline = {
             "kernel": "af_gemm_kernel (conv3x3 implicit GEMM + linear + conv1x1)",
             "bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+            "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
             "flops_per_launch": flops_step / g_n if g_n else None,
             "avg_launch_ms": g_ms / g_n if g_n else None,
             "families_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in fam.items()},

@@ -2,7 +2,7 @@
 """HBM traffic per kernel family from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; rocpd sqlite output).
 Units and the gfx950 correction follow MI355X_MICROARCH.md (HBM section): both counters are in KiB; FETCH_SIZE counts 128-B
 requests at 64 B on gfx950, so it is doubled; WRITE_SIZE is exact for 16-B-per-lane stores.
-    python tools/pmc_traffic.py fetch.db write.db [--json out.json]"""
+    python tools/pmc_traffic.py fetch.db write.db --steps N [--json out.json]       (N = denoise steps the traced run executed)"""
 import json
 import sqlite3
 import sys
@@ -25,13 +25,15 @@ def per_family(db, counter):
 
 def main():
     fe, wr = per_family(sys.argv[1], "FETCH_SIZE"), per_family(sys.argv[2], "WRITE_SIZE")
-    res = {}
+    steps = int(sys.argv[sys.argv.index("--steps") + 1])
+    res = {"steps_traced": steps}
     for f, _ in FAMILIES:
         n = fe[f][0]
         assert n == wr[f][0], (f, n, wr[f][0])
         rd = 2.0 * fe[f][1] * 1024.0          # gfx950: FETCH_SIZE reports half of a wide streaming read
         w = wr[f][1] * 1024.0
-        res[f] = {"launches": n, "read_bytes_per_launch": rd / n, "write_bytes_per_launch": w / n, "bytes_per_launch": (rd + w) / n}
+        res[f] = {"kernel_dispatches_per_step": n / steps, "read_bytes_per_step": rd / steps, "write_bytes_per_step": w / steps,
+                  "bytes_per_step": (rd + w) / steps}
         print(f"{f:6s} launches {n:6d}  read {rd / n / 1e6:9.3f} MB/launch  write {w / n / 1e6:9.3f} MB/launch  total {(rd + w) / n / 1e6:9.3f} MB/launch")
     if "--json" in sys.argv:
         with open(sys.argv[sys.argv.index("--json") + 1], "w") as f:
