@@ -342,6 +342,17 @@ __global__ __launch_bounds__(256) void add_f16_kernel(const half_t* __restrict__
   *reinterpret_cast<half8_t*>(out + i * 8) = o;
 }
 
+__global__ __launch_bounds__(256) void axpy_f16_kernel(const half_t* __restrict__ a, const half_t* __restrict__ b, float alpha,
+                                                       half_t* __restrict__ out, long n8) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n8) return;
+  const half8_t x = *reinterpret_cast<const half8_t*>(a + i * 8), y = *reinterpret_cast<const half8_t*>(b + i * 8);
+  half8_t o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)x[e] + alpha * (float)y[e]);
+  *reinterpret_cast<half8_t*>(out + i * 8) = o;
+}
+
 // x [B][N][ldx] (C columns) -> y [B][C][ldy] (token index contiguous), 64x64 LDS tiles
 __global__ __launch_bounds__(256) void transpose_tokens_kernel(const half_t* __restrict__ x, half_t* __restrict__ y, int N, int C,
                                                                int ldx, int ldy) {
@@ -561,6 +572,14 @@ extern "C" int af_add_f16(const void* a, const void* b, void* out, int64_t n, vo
   hipLaunchKernelGGL(add_f16_kernel, g1(n / 8), dim3(256), 0, (hipStream_t)stream, (const half_t*)a, (const half_t*)b,
                      (half_t*)out, (long)(n / 8));
   return af_check_launch("af_add_f16");
+}
+
+extern "C" int af_axpy_f16(const void* a, const void* b, float alpha, void* out, int64_t n, void* stream) {
+  AF_REQUIRE(a && b && out && n > 0 && n % 8 == 0, "af_axpy_f16: n must be a positive multiple of 8");
+  AfLaunchScope scope(AF_FAM_ELEM, stream);
+  hipLaunchKernelGGL(axpy_f16_kernel, g1(n / 8), dim3(256), 0, (hipStream_t)stream, (const half_t*)a, (const half_t*)b, alpha,
+                     (half_t*)out, (long)(n / 8));
+  return af_check_launch("af_axpy_f16");
 }
 
 extern "C" int af_transpose_tokens(const void* x, void* y, int B, int N, int C, int ldx, int ldy, void* stream) {

@@ -109,7 +109,7 @@ class LatentDiffusion(nn.Module):
     # ------------------------------------------------------------------ Stage-1 distillation (ddpm.py:1597-1750, 2984-3184)
     unet_distill_weight = 8          # ddpm.py:2367
     batch_student_steps = True       # one student U-Net call for all denoising steps of a micro-batch
-    res_hidden_states_gradscale = 1
+    res_hidden_states_gradscale = 0.5   # reference ctor default (ddpm.py:140): gradient scale of the decoder's skip inputs
 
     def guided_denoise(self, x_start, noise, t, cond_context, uncond_emb=None, img_mask=None, subj_indices=None,
                        normalize_cross_attn=False, mix_sc_mc_attn=False, batch_part_has_grad="all", do_pixel_recon=False,

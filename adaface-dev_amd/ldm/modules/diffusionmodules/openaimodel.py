@@ -468,10 +468,12 @@ class UNetModel(nn.Module):
         g, st = self.out[0].hip_train(h, silu=True)
         return self.out[2].hip(g), (saved_in, saved_mid, saved_out, h, st, context.shape)
 
-    def hip_bwd(self, saved, deps_nhwc, need_dx=True):
+    def hip_bwd(self, saved, deps_nhwc, need_dx=True, res_gradscale=1.0):
         """Activation-gradient backward: deps [B,H,W,roundup(out_channels,8)] fp16 (zero padded) ->
         (dx [B,H,W,in_channels] or None, dcontext [B,L,ctx] fp16).  Skip-connection gradients from the
-        decoder are added to the encoder's output gradients as the walk reaches them."""
+        decoder are added to the encoder's output gradients as the walk reaches them; `res_gradscale` multiplies the
+        gradient of the skips consumed by output blocks >= num_res_blocks + 1 (the live path's
+        res_hidden_states_gradscale on diffusers up_blocks[1:], diffusers_attn_lora_capture.py:382-396, 606-609)."""
         saved_in, saved_mid, saved_out, h_last, st, ctx_shape = saved
         d = self.out[0].hip_bwd(h_last, st, self.out[2].hip_dgrad(deps_nhwc), silu=True)
         dctx = None
@@ -481,8 +483,10 @@ class UNetModel(nn.Module):
             dskips.append(dskip)   # the LAST decoder block consumed hs[0], so this appends d(hs[0]), d(hs[1]), ...
         d, dctx = self.middle_block.hip_bwd(saved_mid, d, dctx)
         n_in = len(self.input_blocks)
+        n_out = len(self.output_blocks)
         for i in range(n_in - 1, -1, -1):
-            d = ops.add(d, dskips[i])
+            scaled = res_gradscale != 1.0 and (n_out - 1 - i) >= self.num_res_blocks + 1     # hs[i] fed output block n_out-1-i
+            d = ops.axpy(d, dskips[i], res_gradscale) if scaled else ops.add(d, dskips[i])
             if i == 0 and not need_dx:
                 return None, dctx.reshape(ctx_shape)
             d, dctx = self.input_blocks[i].hip_bwd(saved_in[i], d, dctx)
@@ -502,7 +506,8 @@ class UNetModel(nn.Module):
         if torch.is_grad_enabled() and (x.requires_grad or context.requires_grad):
             if capture:
                 raise NotImplementedError("capture_ca_activations together with gradients (Stage-2 losses) is SURVEY.md 8f rank 4")
-            return _UNetFunction.apply(self, x, timesteps, context, img_mask)
+            gs = float((extra_info or {}).get("res_hidden_states_gradscale", 1) or 1)
+            return _UNetFunction.apply(self, x, timesteps, context, img_mask, gs)
         try:
             xh = to_nhwc_f16(x, ops.round_up(self.in_channels, 8))
             ctx = context.to(F16).contiguous()
@@ -523,7 +528,8 @@ class _UNetFunction(torch.autograd.Function):
     frozen as in the reference, ddpm.py:4131-4132, so no weight gradients exist on this path)."""
 
     @staticmethod
-    def forward(ctx, unet, x, timesteps, context, img_mask):
+    def forward(ctx, unet, x, timesteps, context, img_mask, res_gradscale=1.0):
+        ctx.res_gradscale = res_gradscale
         xh = to_nhwc_f16(x.detach(), ops.round_up(unet.in_channels, 8))
         eps, saved = unet.hip_train(xh, timesteps, context.detach().to(F16).contiguous(), img_mask)
         ctx.unet, ctx.saved = unet, saved
@@ -539,10 +545,10 @@ class _UNetFunction(torch.autograd.Function):
         amax = deps.detach().abs().amax().float().clamp_min(1e-30)
         scale = torch.exp2(torch.floor(torch.log2(256.0 / amax)))
         dh = to_nhwc_f16((deps * scale).contiguous(), ops.round_up(unet.out_channels, 8))
-        dx, dctx = unet.hip_bwd(ctx.saved, dh, need_dx=ctx.need_dx)
+        dx, dctx = unet.hip_bwd(ctx.saved, dh, need_dx=ctx.need_dx, res_gradscale=ctx.res_gradscale)
         ctx.saved = None
         gx = (from_nhwc_f16(dx, torch.float32, unet.in_channels) / scale).to(ctx.x_dtype) if dx is not None else None
-        return None, gx, None, (dctx.float() / scale).to(ctx.c_dtype), None
+        return None, gx, None, (dctx.float() / scale).to(ctx.c_dtype), None, None
 
 
 def unet_param_shapes(cfg):

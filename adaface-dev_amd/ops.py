@@ -447,6 +447,16 @@ def add(a, b):
     return out
 
 
+def axpy(a, b, alpha):
+    """a + alpha * b (fp16)."""
+    _chk_f16(a, "axpy.a")
+    _chk_f16(b, "axpy.b")
+    assert a.shape == b.shape
+    out = torch.empty_like(a)
+    _lib.check(_lib.lib().af_axpy_f16(_p(a), _p(b), float(alpha), _p(out), a.numel(), _stream()), "af_axpy_f16")
+    return out
+
+
 def transpose_tokens(x, B, N, Cn, ldx):
     """x: rows of a [B*N, ldx] token tensor (Cn columns from x's first column) -> [B, Cn, roundup(N, 8)]."""
     ldy = round_up(N, 8)

@@ -208,6 +208,9 @@ int af_geglu_bwd(const void* hp, const void* dout, void* dhp, int64_t M, int inn
 /* adjoint of nearest-x2 upsampling: y [B,H,W,C] = 2x2 block sums of x [B,2H,2W,C] */
 int af_sumpool2x2(const void* x, void* y, int B, int H, int W, int C, void* stream);
 int af_add_f16(const void* a, const void* b, void* out, int64_t n, void* stream);
+/* out = a + alpha * b: the decoder's skip-connection gradients joining the encoder's, scaled by res_hidden_states_gradscale
+ * (adaface/diffusers_attn_lora_capture.py:23-42 ScaleGrad, :382-396) */
+int af_axpy_f16(const void* a, const void* b, float alpha, void* out, int64_t n, void* stream);
 /* x [B,N,ldx] (C columns) -> y [B,C,ldy] with the token index contiguous (zero padded to ldy) */
 int af_transpose_tokens(const void* x, void* y, int B, int N, int C, int ldx, int ldy, void* stream);
 /* cautious AdamW (ldm/c_adamw.py:65-123) over a flat fp32 buffer; seg_offsets int64 [nseg+1] delimit the

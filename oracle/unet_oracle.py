@@ -217,8 +217,14 @@ def unet_forward(sd, cfg, x, timesteps, context, extra_info=None):
         layer_idx += 1
     h = run_block(middle, h, layer_idx)
     layer_idx += 1
-    for layers in outputs:
-        h = torch.cat([h, hs.pop()], dim=1)                                         # :916-918
+    gs = float(extra_info.get("res_hidden_states_gradscale", 1) or 1)
+    for oi, layers in enumerate(outputs):
+        skip = hs.pop()
+        if gs != 1 and oi >= 3:
+            # live path only (diffusers_attn_lora_capture.py:366-446, set_lora_and_capture_flags :606-609): the GRADIENT of
+            # the skip tensors entering up_blocks[1:] (= LDM output_blocks 3..11) is scaled; forward values are unchanged
+            skip = skip * gs + (skip * (1 - gs)).detach()
+        h = torch.cat([h, skip], dim=1)                                             # :916-918
         h = run_block(layers, h, layer_idx)
         layer_idx += 1
 

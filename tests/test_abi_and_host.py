@@ -48,7 +48,7 @@ def test_bad_arguments_return_codes_without_a_gpu(lib):
     d = lib.GemmDesc()
     assert L.af_gemm(ctypes.byref(d), None) == lib.AF_E_BADARG
     assert L.af_layernorm(None, None, None, None, 4, 320, 1e-5, None) == lib.AF_E_BADARG
-    assert L.af_groupnorm_ws_floats(8) == 8 * 32 * 32 * 2
+    assert L.af_groupnorm_ws_floats(8) == 8 * 128 * 32 * 2        # [B][<=128 partial blocks][32 groups][sum, sumsq]
 
 
 def test_gemm_desc_matches_c_struct(lib, tmp_path):

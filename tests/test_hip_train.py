@@ -77,7 +77,8 @@ def test_unet_distill_loss_and_context_grad_vs_oracle(dev, steps):
 
     tabs = D.register_schedule(D.make_beta_schedule_linear())
     sr = sctx.clone().requires_grad_(True)
-    ref = T.unet_distill_loss(lambda x, tt, c: O.unet_forward(sd_s, CFG, x, tt, c, {}), lambda x, tt, c: O.unet_forward(sd_t, CFG, x, tt, c, {}),
+    ref = T.unet_distill_loss(lambda x, tt, c: O.unet_forward(sd_s, CFG, x, tt, c, {"res_hidden_states_gradscale": 0.5}),
+                              lambda x, tt, c: O.unet_forward(sd_t, CFG, x, tt, c, {}),
                               tabs, x0, noise, t, sr, tctx, fg, steps, pres)
     ref.backward()
     el = abs(float(loss) - float(ref)) / abs(float(ref))
@@ -108,7 +109,7 @@ def _oracle_distill(sds, ucfg, ids512, x0, noise, t, fg, steps, pres, sbg_sd=Non
     ctx = CO.clip_text_forward(sds["text"], cc, pid, tok)[0]
     tctx = torch.cat([prefix.repeat(B, 1, 1), id2img], dim=1)
     tabs = D.register_schedule(D.make_beta_schedule_linear())
-    loss = 8 * T.unet_distill_loss(lambda x, tt, c: O.unet_forward(sds["student"], ucfg, x, tt, c, {}),
+    loss = 8 * T.unet_distill_loss(lambda x, tt, c: O.unet_forward(sds["student"], ucfg, x, tt, c, {"res_hidden_states_gradscale": 0.5}),
                                    lambda x, tt, c: O.unet_forward(sds["teacher"], ucfg, x, tt, c, {}),
                                    tabs, x0, noise, t, ctx, tctx, fg, steps, pres)
     return loss, sbg, lw

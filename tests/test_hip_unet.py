@@ -185,6 +185,33 @@ def test_unet_reduced_width_backward_vs_oracle_autograd(dev):
     assert rel_l2(cg.grad.cpu().numpy(), cr.grad.numpy()) < 2e-2 or img_mask is not None
 
 
+def test_unet_backward_skip_gradient_scale_vs_oracle(dev):
+    """res_hidden_states_gradscale (live path: adaface/diffusers_attn_lora_capture.py:382-396, 606-609): the gradient of the skip
+    tensors entering output blocks 3..11 is scaled (0.5 in Stage 1), forward values unchanged.  Both dx and dcontext change and
+    must match autograd through the oracle with the same scaler; scale 1 reproduces the unscaled gradient."""
+    from adaface_dev_amd import rng
+    from oracle import unet_oracle as O
+    m, sd = _build(GPU_TINY_CONFIG, 11, dev)
+    x = rng.synth_input("t64.x", (2, 4, 32, 32), seed=11)
+    ctx = rng.synth_input("t64.ctx", (2, 77, 64), seed=11)
+    cot = rng.synth_input("t64.cot", (2, 4, 32, 32), seed=11)
+    t = torch.tensor([10, 500])
+    grads = {}
+    for gs in (1.0, 0.5, 0.2):
+        xg, cg = x.clone().to(dev).requires_grad_(True), ctx.clone().to(dev).requires_grad_(True)
+        eps = m(xg, t.to(dev), cg, extra_info={"res_hidden_states_gradscale": gs})
+        (eps * cot.to(dev)).sum().backward()
+        xr, cr = x.clone().requires_grad_(True), ctx.clone().requires_grad_(True)
+        ref = O.unet_forward(sd, GPU_TINY_CONFIG, xr, t, cr, {"res_hidden_states_gradscale": gs})
+        (ref * cot).sum().backward()
+        assert rel_l2(eps.detach().cpu().numpy(), ref.detach().numpy()) < NET_TOL
+        ex, ec = rel_l2(xg.grad.cpu().numpy(), xr.grad.numpy()), rel_l2(cg.grad.cpu().numpy(), cr.grad.numpy())
+        print(f"gradscale {gs}: dx {ex:.3e} dcontext {ec:.3e}")
+        assert ex < 2e-2 and ec < 2e-2
+        grads[gs] = (xr.grad.clone(), cr.grad.clone())
+    assert rel_l2(grads[0.5][1].numpy(), grads[1.0][1].numpy()) > 0.05          # the scaler really changes the gradient
+
+
 @pytest.fixture(scope="module")
 def full_model(dev):
     from adaface_dev_amd import SD15_UNET_CONFIG
