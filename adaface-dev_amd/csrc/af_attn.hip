@@ -23,6 +23,7 @@
 //     are both expressed as an additive per-key bias (-FLT_MAX / excluded), which reproduces
 //     masked_fill_(~mask, -finfo.max) exactly, including the all-masked (uniform) row.
 #include <float.h>
+#include <stdlib.h>
 
 #include "af_common.h"
 
@@ -347,6 +348,224 @@ __global__ __launch_bounds__(256) void af_attn_kernel(AttnArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Short-key variant (L <= 128, no key bias, no causal mask): the U-Net's cross-attention cores (77 context tokens).
+// These launches are HBM/latency bound (76 FLOP per algorithmic byte at C = 320): the flash kernel above spends its time
+// re-staging the same 77 keys for every 128-query workgroup (2 x 64-key stages with barriers) on the ragged-L path.
+// Here the K and V^T of one (batch, head) are staged into LDS ONCE per workgroup, then every wave streams 32-query groups
+// with no further barrier: S^T for all keys at once (<= 4 sub-tiles of 32 keys), one plain softmax (no running max /
+// rescale), O^T = V^T P^T, store; the next group's Q fragments are fetched under the current group's arithmetic.
+template <int DS, bool ONES>
+__global__ __launch_bounds__(256) void af_xattn_kernel(AttnArgs a, int groups_per_wave, int nchunk) {
+  constexpr int DP = 16 * DS, DT = (DS + 1) / 2, DV = 32 * DT;
+  constexpr int KST = DP + 8;
+  constexpr int LP = 128;                     // keys staged (zero beyond L)
+  constexpr int KCH = LP * (DP / 8);          // 16-byte chunks of K
+  constexpr int VCH = DV * (LP / 8);          // 16-byte chunks of V^T
+  extern __shared__ __attribute__((aligned(16))) char af_smem[];
+  half_t* Ks = reinterpret_cast<half_t*>(af_smem);
+  half_t* Vs = Ks + LP * KST;                 // [4 sub][DV][VST]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int bh = (idx / nchunk) * 8 + xcd;
+  if (bh >= a.B * a.heads) return;
+  const int chunk = idx % nchunk;
+  const int b = bh / a.heads, h = bh - b * a.heads;
+  const int C = a.heads * a.d;
+  const int nsub = (a.L + 31) >> 5;
+  const half8_t zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+  // ---- first Q group (issued before the staging so its latency overlaps it)
+  const int group0 = (chunk * 4 + wave) * groups_per_wave;          // this wave's first 32-query group
+  auto load_q = [&](int grp, half8_t (&qf)[DS]) {
+    const int query = grp * 32 + r;
+    const half_t* qp = a.q + ((size_t)b * a.Nq + (query < a.Nq ? query : 0)) * a.ldq + h * a.d;
+#pragma unroll
+    for (int s2 = 0; s2 < DS; ++s2) {
+      const int dc = 16 * s2 + 8 * hh;
+      qf[s2] = (query < a.Nq && dc < a.d) ? *reinterpret_cast<const half8_t*>(qp + dc) : zero8;
+    }
+  };
+  half8_t qraw[DS], qnext[DS];
+  load_q(group0, qraw);
+
+  // ---- stage K [LP][KST] and V^T [4][DV][VST] once.  All global loads are issued before the first LDS store (two
+  //      phases over register arrays): a load -> store loop serialises one memory round trip per iteration, which was the
+  //      whole cost of these small launches (10.9 us at N = 64).
+  {
+    constexpr int NKC = (KCH + 255) / 256, NVC = (VCH + 255) / 256;
+    half8_t rk[NKC], rv[NVC];
+#pragma unroll
+    for (int j = 0; j < NKC; ++j) {
+      const int i = tid + 256 * j;
+      const int row = i / (DP / 8), ch = i - row * (DP / 8);
+      rk[j] = (i < KCH && row < a.L && ch * 8 < a.d)
+                  ? *reinterpret_cast<const half8_t*>(a.k + ((size_t)b * a.L + row) * a.ldk + h * a.d + ch * 8) : zero8;
+    }
+#pragma unroll
+    for (int j = 0; j < NVC; ++j) {
+      const int i = tid + 256 * j;
+      const int row = i >> 4, kk = (i & 15) * 8;
+      rv[j] = (i < VCH && row < a.d && kk < a.L)
+                  ? *reinterpret_cast<const half8_t*>(a.vt + ((size_t)b * C + h * a.d + row) * a.ldv + kk) : zero8;
+    }
+#pragma unroll
+    for (int j = 0; j < NKC; ++j) {
+      const int i = tid + 256 * j;
+      const int row = i / (DP / 8), ch = i - row * (DP / 8);
+      if (i < KCH) *reinterpret_cast<half8_t*>(Ks + row * KST + ch * 8) = rk[j];
+    }
+#pragma unroll
+    for (int j = 0; j < NVC; ++j) {
+      const int i = tid + 256 * j;
+      if (i < VCH) {
+        const int row = i >> 4, ch = i & 15, kk = ch * 8;
+        half8_t v = rv[j];
+        if (row < a.d) {
+          if (kk < a.L && kk + 8 > a.L) {        // the padding of V^T rows beyond L holds anything: zero it
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              if (kk + e >= a.L) v[e] = (half_t)0;
+          }
+        } else if (ONES && row == DV - 1) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = (kk + e < a.L) ? (half_t)1 : (half_t)0;
+        }
+        half_t* dst = Vs + ((ch >> 2) * DV + row) * VST + (ch & 3) * 8;
+        const half4_t lo = {v[0], v[1], v[2], v[3]}, hi = {v[4], v[5], v[6], v[7]};
+        *reinterpret_cast<half4_t*>(dst) = lo;
+        *reinterpret_cast<half4_t*>(dst + 4) = hi;
+      }
+    }
+  }
+  __syncthreads();
+
+  for (int gi = 0; gi < groups_per_wave; ++gi) {
+    const int grp = group0 + gi;
+    if (grp * 32 >= a.Nq) break;
+    const int query = grp * 32 + r;
+    if (gi + 1 < groups_per_wave) load_q(grp + 1, qnext);
+    half8_t qf[DS];
+#pragma unroll
+    for (int s2 = 0; s2 < DS; ++s2)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) qf[s2][e] = (half_t)((float)qraw[s2][e] * a.c);
+
+    // ---- S^T for all keys
+    floatx16 sT[4];
+#pragma unroll
+    for (int sub = 0; sub < 4; ++sub) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) sT[sub][i] = 0.f;
+      if (sub < nsub) {
+#pragma unroll
+        for (int s2 = 0; s2 < DS; ++s2) {
+          const half8_t kf = *reinterpret_cast<const half8_t*>(Ks + (sub * 32 + r) * KST + 16 * s2 + 8 * hh);
+          sT[sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s2], sT[sub], 0, 0, 0);
+        }
+      }
+    }
+    // ---- keys >= L (only the last sub-tile can hold some) -> -inf; row max
+    float mx = -FLT_MAX;
+#pragma unroll
+    for (int sub = 0; sub < 4; ++sub) {
+      if (sub < nsub) {
+        if (sub == nsub - 1) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int key = sub * 32 + 8 * (i >> 2) + 4 * hh + (i & 3);
+            if (key >= a.L) sT[sub][i] = -INFINITY;
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 16; i += 2) mx = fmaxf(fmaxf(mx, sT[sub][i]), sT[sub][i + 1]);
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    // ---- P^T = exp2(S^T - m), O^T = V^T P^T
+    floatx16 o[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) o[t][i] = 0.f;
+    float l = 0.f;
+#pragma unroll
+    for (int sub = 0; sub < 4; ++sub) {
+      if (sub < nsub) {
+        half8_t pf[2];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float pv = __builtin_amdgcn_exp2f(sT[sub][8 * s2 + j] - mx);
+            if (!ONES) l += pv;
+            pf[s2][j] = (half_t)pv;
+          }
+#pragma unroll
+        for (int t = 0; t < DT; ++t)
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+            const half_t* vp = Vs + (sub * DV + 32 * t + r) * VST + 16 * s2 + 4 * hh;
+            const half4_t lo = *reinterpret_cast<const half4_t*>(vp);
+            const half4_t hi = *reinterpret_cast<const half4_t*>(vp + 8);
+            const half8_t vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[s2], o[t], 0, 0, 0);
+          }
+      }
+    }
+    if (ONES) {
+      const float mine = o[DT - 1][15];
+      const float other = __shfl_xor(mine, 32, 64);
+      l = hh ? mine : other;
+    } else {
+      l += __shfl_xor(l, 32, 64);
+    }
+    const float inv = 1.0f / l;
+    if (a.lse2 && query < a.Nq && hh == 0) a.lse2[((size_t)b * a.heads + h) * a.ld_lse + query] = mx + __builtin_amdgcn_logf(l);
+    if (query < a.Nq) {
+      half_t* op = a.o + ((size_t)b * a.Nq + query) * a.ldo + h * a.d;
+#pragma unroll
+      for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int dd = 32 * t + 8 * g + 4 * hh;
+          if (dd < a.d) {
+            const half4_t v = {(half_t)(o[t][4 * g + 0] * inv), (half_t)(o[t][4 * g + 1] * inv),
+                               (half_t)(o[t][4 * g + 2] * inv), (half_t)(o[t][4 * g + 3] * inv)};
+            *reinterpret_cast<half4_t*>(op + dd) = v;
+          }
+        }
+    }
+    if (gi + 1 < groups_per_wave) {
+#pragma unroll
+      for (int s2 = 0; s2 < DS; ++s2) qraw[s2] = qnext[s2];
+    }
+  }
+}
+
+template <int DS, bool ONES>
+int launch_xattn(const AttnArgs& a, hipStream_t stream) {
+  constexpr int DP = 16 * DS, DT = (DS + 1) / 2, DV = 32 * DT;
+  constexpr size_t lds = (size_t)(128 * (DP + 8) + 4 * DV * VST) * sizeof(half_t);
+  static bool attr_set = false;
+  if (lds > 65536 && !attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&af_xattn_kernel<DS, ONES>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return af_fail(AF_E_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
+    attr_set = true;
+  }
+  const int groups = (a.Nq + 31) / 32;                       // 32-query groups per (batch, head)
+  // a workgroup = 4 waves x groups_per_wave groups; aim at >= 512 workgroups while K / V^T staging stays amortised
+  int gpw = groups / 32;                                      // N = 4096 -> 4 groups per wave, 8 workgroups per (b, h)
+  gpw = gpw < 1 ? 1 : (gpw > 8 ? 8 : gpw);
+  const int nchunk = (groups + 4 * gpw - 1) / (4 * gpw);
+  const int bh8 = (a.B * a.heads + 7) / 8 * 8;
+  hipLaunchKernelGGL((af_xattn_kernel<DS, ONES>), dim3(nchunk * bh8), dim3(256), lds, stream, a, gpw, nchunk);
+  return af_check_launch("af_attention(short-key)");
+}
+
 template <int DS, bool ONES, bool GENERAL>
 int launch_attn2(const AttnArgs& a, hipStream_t stream) {
   constexpr int DP = 16 * DS, DT = (DS + 1) / 2, DV = 32 * DT;
@@ -367,6 +586,9 @@ int launch_attn2(const AttnArgs& a, hipStream_t stream) {
 template <int DS>
 int launch_attn(const AttnArgs& a, hipStream_t stream) {
   constexpr int DV = 32 * ((DS + 1) / 2);
+  static const bool no_short = getenv("AF_NO_XATTN") != nullptr;     // A/B switch for profiling
+  if (a.kbias == nullptr && a.causal_m == 0 && a.L <= 128 && !no_short)
+    return DV > a.d ? launch_xattn<DS, true>(a, stream) : launch_xattn<DS, false>(a, stream);
   const bool general = a.kbias != nullptr || a.causal_m > 0 || a.L % KB != 0;
   if (DV > a.d) return general ? launch_attn2<DS, true, true>(a, stream) : launch_attn2<DS, true, false>(a, stream);
   return general ? launch_attn2<DS, false, true>(a, stream) : launch_attn2<DS, false, false>(a, stream);
@@ -458,7 +680,7 @@ extern "C" int af_attention_ex(const void* q, const void* k, const void* vt, voi
   a.ldv = ldv;
   a.ldb = ldb;
   a.c = scale * 1.4426950408889634f;
-  AfLaunchScope scope(AF_FAM_ATTN, stream);
+  AfLaunchScope scope(L < Nq ? AF_FAM_XATTN : AF_FAM_ATTN, stream);
   hipStream_t s = (hipStream_t)stream;
   const int ds = (d + 15) / 16;
   switch (ds) {

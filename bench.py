@@ -40,6 +40,9 @@ ATTN_GFLOP_PER_SAMPLE = 122.49 + 3.56
 UNET_GFLOP_PER_SAMPLE = 803.27
 MFMA_PEAK_TFLOPS = 2500.0                          # dense fp16/bf16, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
+# cross-attention core algorithmic bytes per U-Net sample (fp16): 2 B * (q + o: 2 N C, k + v: 2 T C) per layer,
+# layers: 5 x (N 4096, C 320), 5 x (1024, 640), 5 x (256, 1280), 1 x (64, 1280); T = 77
+XATTN_BYTES_PER_SAMPLE = 2 * sum(n_l * (2 * N * C + 2 * 77 * C) for n_l, N, C in ((5, 4096, 320), (5, 1024, 640), (5, 256, 1280), (1, 64, 1280)))
 
 
 def main_train(args):
@@ -266,7 +269,7 @@ def main():
             ops.prof_enable(False)
         fam = {}
         for name, f in (("gemm", _lib.AF_FAM_GEMM), ("attn", _lib.AF_FAM_ATTN), ("gnorm", _lib.AF_FAM_GNORM),
-                        ("lnorm", _lib.AF_FAM_LNORM), ("elem", _lib.AF_FAM_ELEM)):
+                        ("lnorm", _lib.AF_FAM_LNORM), ("elem", _lib.AF_FAM_ELEM), ("xattn", _lib.AF_FAM_XATTN)):
             n, ms = ops.prof_read(f)
             fam[name] = {"launches_per_step": n / nprof, "ms_per_step": ms / nprof}
         ops.prof_reset()
@@ -275,6 +278,7 @@ def main():
         flops_step = GEMM_GFLOP_PER_SAMPLE * 1e9 * 2 * B
         achieved = flops_step / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
         a_ms = fam["attn"]["ms_per_step"]
+        x_ms = fam["xattn"]["ms_per_step"]
         # HBM bytes per launch of the GEMM family: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
         # (separate passes, gfx950 x2 fetch correction; tools/pmc_traffic.py), committed under profiles/ -- counters cannot be
         # read from inside the process, so the latest committed measurement is reported (null if absent)
@@ -291,7 +295,16 @@ def main():
             "avg_launch_ms": g_ms / g_n if g_n else None,
             "families_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in fam.items()},
             "families_launches_per_step": {k: v["launches_per_step"] for k, v in fam.items()},
-            "attn_tflops": round(ATTN_GFLOP_PER_SAMPLE * 1e9 * 2 * B / (a_ms * 1e-3) / 1e12, 2) if a_ms > 0 else None,
+            "self_attn_tflops": round(122.49e9 * 2 * B / (a_ms * 1e-3) / 1e12, 2) if a_ms > 0 else None,
+            # U-Net cross-attention CORE (QK^T + softmax + PV over 77 keys, 16 layers): HBM-bound by construction (76 FLOP per
+            # algorithmic byte at C = 320), so it is priced against BOTH roofs; kernel boundary = af_attention only
+            # (the q / kv / out projections run in the GEMM family)
+            "cross_attn_core": None if x_ms <= 0 else {
+                "ms_per_step": round(x_ms, 4), "launches_per_step": fam["xattn"]["launches_per_step"],
+                "tflops": round(3.56e9 * 2 * B / (x_ms * 1e-3) / 1e12, 2),
+                "mfma_frac": round(3.56e9 * 2 * B / (x_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
+                "algorithmic_GBps": round(XATTN_BYTES_PER_SAMPLE * 2 * B / (x_ms * 1e-3) / 1e9, 1),
+                "hbm_frac": round(XATTN_BYTES_PER_SAMPLE * 2 * B / (x_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
         }
 
     cpu_baseline = None

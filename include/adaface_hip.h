@@ -44,7 +44,8 @@ int af_device_count(void);
 #define AF_FAM_GNORM 2
 #define AF_FAM_LNORM 3
 #define AF_FAM_ELEM 4
-#define AF_FAM_COUNT 5
+#define AF_FAM_XATTN 5  /* af_attention launches with fewer keys than queries: the U-Net's cross-attention cores */
+#define AF_FAM_COUNT 6
 int af_prof_enable(int on);
 int af_prof_reset(void);
 int af_prof_read(int family, int* launches, double* total_ms);

@@ -14,13 +14,25 @@ import torch  # noqa: E402
 
 
 def timeit(fn, reps):
+    """Average device time of fn(): `reps` calls captured into ONE hipGraph and replayed (so the host's launch rate -- ~10 us per
+    Python/ctypes call -- does not floor the measurement of short kernels)."""
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        fn()
+    torch.cuda.current_stream().wait_stream(s)
+    with torch.cuda.graph(g):
+        for _ in range(reps):
+            fn()
+    g.replay()
+    torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(reps):
-        fn()
+    g.replay()
     e1.record()
     e1.synchronize()
     return e0.elapsed_time(e1) / reps
@@ -42,6 +54,11 @@ def main():
         ms = timeit(lambda: ops.attention(q, k, vt, B=B, Nq=N, L=L, heads=H, d=d, ldq=C, ldk=C), reps)
         fl = 4.0 * B * H * N * L * d
         print(f"attn B{B} N{N} L{L} H{H} d{d}: {ms * 1e3:.1f} us  {fl / ms / 1e9:.1f} TFLOP/s")
+    elif kind == "add":           # calibration: a trivial element-wise kernel on n halves (per-node floor of the timing harness)
+        n = a[0]
+        x, y = rnd(n), rnd(n)
+        ms = timeit(lambda: ops.add(x, y), a[1] if len(a) > 1 else 50)
+        print(f"add n{n}: {ms * 1e3:.2f} us")
     elif kind == "gemm":
         M, N, K = a[:3]
         tile, splits = (a[3] if len(a) > 3 else 0), (a[4] if len(a) > 4 else 0)
