@@ -453,67 +453,63 @@ __global__ __launch_bounds__(256) void af_xattn_kernel(AttnArgs a, int groups_pe
 #pragma unroll
       for (int e = 0; e < 8; ++e) qf[s2][e] = (half_t)((float)qraw[s2][e] * a.c);
 
-    // ---- S^T for all keys
-    floatx16 sT[4];
+    // ---- two rolled passes over the <= 4 sub-tiles of 32 keys (S^T is recomputed in the second: these launches are
+    //      latency bound, the MFMA is idle anyway, and the rolled form keeps the code ~3x smaller than four unrolled
+    //      sub-tiles -- instruction fetch is part of a cold 10 us launch)
+    auto score_tile = [&](int sub) {
+      floatx16 sc;
 #pragma unroll
-    for (int sub = 0; sub < 4; ++sub) {
+      for (int i = 0; i < 16; ++i) sc[i] = 0.f;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) sT[sub][i] = 0.f;
-      if (sub < nsub) {
+      for (int s2 = 0; s2 < DS; ++s2) {
+        const half8_t kf = *reinterpret_cast<const half8_t*>(Ks + (sub * 32 + r) * KST + 16 * s2 + 8 * hh);
+        sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s2], sc, 0, 0, 0);
+      }
+      if (sub == nsub - 1) {                     // keys >= L (only the last sub-tile can hold some) -> -inf
 #pragma unroll
-        for (int s2 = 0; s2 < DS; ++s2) {
-          const half8_t kf = *reinterpret_cast<const half8_t*>(Ks + (sub * 32 + r) * KST + 16 * s2 + 8 * hh);
-          sT[sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s2], sT[sub], 0, 0, 0);
+        for (int i = 0; i < 16; ++i) {
+          const int key = sub * 32 + 8 * (i >> 2) + 4 * hh + (i & 3);
+          if (key >= a.L) sc[i] = -INFINITY;
         }
       }
-    }
-    // ---- keys >= L (only the last sub-tile can hold some) -> -inf; row max
+      return sc;
+    };
     float mx = -FLT_MAX;
+#pragma unroll 1
+    for (int sub = 0; sub < nsub; ++sub) {
+      const floatx16 sc = score_tile(sub);
 #pragma unroll
-    for (int sub = 0; sub < 4; ++sub) {
-      if (sub < nsub) {
-        if (sub == nsub - 1) {
-#pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            const int key = sub * 32 + 8 * (i >> 2) + 4 * hh + (i & 3);
-            if (key >= a.L) sT[sub][i] = -INFINITY;
-          }
-        }
-#pragma unroll
-        for (int i = 0; i < 16; i += 2) mx = fmaxf(fmaxf(mx, sT[sub][i]), sT[sub][i + 1]);
-      }
+      for (int i = 0; i < 16; i += 2) mx = fmaxf(fmaxf(mx, sc[i]), sc[i + 1]);
     }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    // ---- P^T = exp2(S^T - m), O^T = V^T P^T
     floatx16 o[DT];
 #pragma unroll
     for (int t = 0; t < DT; ++t)
 #pragma unroll
       for (int i = 0; i < 16; ++i) o[t][i] = 0.f;
     float l = 0.f;
+#pragma unroll 1
+    for (int sub = 0; sub < nsub; ++sub) {
+      const floatx16 sc = score_tile(sub);
+      half8_t pf[2];
 #pragma unroll
-    for (int sub = 0; sub < 4; ++sub) {
-      if (sub < nsub) {
-        half8_t pf[2];
+      for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
+        for (int j = 0; j < 8; ++j) {
+          const float pv = __builtin_amdgcn_exp2f(sc[8 * s2 + j] - mx);
+          if (!ONES) l += pv;
+          pf[s2][j] = (half_t)pv;
+        }
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const float pv = __builtin_amdgcn_exp2f(sT[sub][8 * s2 + j] - mx);
-            if (!ONES) l += pv;
-            pf[s2][j] = (half_t)pv;
-          }
+      for (int t = 0; t < DT; ++t)
 #pragma unroll
-        for (int t = 0; t < DT; ++t)
-#pragma unroll
-          for (int s2 = 0; s2 < 2; ++s2) {
-            const half_t* vp = Vs + (sub * DV + 32 * t + r) * VST + 16 * s2 + 4 * hh;
-            const half4_t lo = *reinterpret_cast<const half4_t*>(vp);
-            const half4_t hi = *reinterpret_cast<const half4_t*>(vp + 8);
-            const half8_t vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[s2], o[t], 0, 0, 0);
-          }
-      }
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const half_t* vp = Vs + (sub * DV + 32 * t + r) * VST + 16 * s2 + 4 * hh;
+          const half4_t lo = *reinterpret_cast<const half4_t*>(vp);
+          const half4_t hi = *reinterpret_cast<const half4_t*>(vp + 8);
+          const half8_t vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[s2], o[t], 0, 0, 0);
+        }
     }
     if (ONES) {
       const float mine = o[DT - 1][15];
