@@ -45,6 +45,7 @@ struct AttnArgs {
 
 constexpr int KB = 64;     // keys per stage
 constexpr int VST = 36;    // V^T LDS row stride in halves (72 B)
+constexpr float kLazy = 8.0f;  // log2 of the largest p the mask-free kernel tolerates before it moves the softmax reference
 
 // ONES: the padded V^T tile has a spare row (32*DT > d); its LAST row is set to 1 for every valid key, so the row
 // sum l = sum_j p_ij falls out of the PV MFMA (accumulator o[DT-1][15] of the upper half-wave) instead of 32 VALU
@@ -266,8 +267,13 @@ __global__ __launch_bounds__(256) void af_attn_kernel(AttnArgs a) {
       m = mx;                       // first stage: scores are absolute, O and l are still zero
       sT[0] = sT[0] - m;
       sT[1] = sT[1] - m;
-    } else if (__builtin_amdgcn_ballot_w64(mx > 0.f) != 0) {
-      const float delta = fmaxf(mx, 0.f);   // scores are relative to m: the max grew by delta on these lanes
+    } else if (__builtin_amdgcn_ballot_w64(mx > kLazy) != 0) {
+      // LAZY reference: m is a softmax reference, not necessarily the running max.  It is only moved when some lane's new
+      // scores exceed it by more than 2^kLazy; until then p = exp2(s - m) may be as large as 2^kLazy, which fp16 P and the
+      // fp32 accumulators hold without loss, and the final O / l is unchanged (softmax is shift invariant).  With the exact
+      // running max the wave-uniform branch below was taken on ~70 % of the stages for random data (any of 32 queries
+      // seeing a new maximum): 32 v_sub + 16 v_pk_mul of the 151 VALU instructions per stage of a VALU-issue-bound kernel.
+      const float delta = fmaxf(mx, 0.f);   // scores are relative to m: these lanes move their reference up by delta
       const float alpha = __builtin_amdgcn_exp2f(-delta);
       m += delta;
       if (!ONES) l *= alpha;
