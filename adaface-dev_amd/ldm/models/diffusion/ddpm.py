@@ -27,7 +27,10 @@ class UNetWrapper(nn.Module):
     """``self.model`` of LatentDiffusion: forward(x, t, cond_context, out_dtype=float32) with
     cond_context = (prompt_emb [b,L,768], prompt_in list[str], extra_info dict).  extra_info is
     read (img_mask, capture_ca_activations) and written (ca_layers_activations), like the
-    reference wrapper (ddpm.py:4187-4252).  LoRA flags are accepted and must be off."""
+    reference wrapper (ddpm.py:4187-4252).  ``use_attn_lora`` / ``use_ffn_lora`` / ``ffn_lora_adapter_name`` select DoRA adapters
+    (``load_unet_loras``), which on this path are MERGED into the layer weights when the requested set changes and un-merged
+    when it is switched off (adaface/lora.py): inference only -- with gradients enabled they raise (training-time DoRA is
+    SURVEY.md 8f rank 1)."""
 
     def __init__(self, unet_config):
         super().__init__()
@@ -35,18 +38,49 @@ class UNetWrapper(nn.Module):
         self.use_attn_lora = False
         self.use_ffn_lora = False
         self.unet_lora_modules = nn.ModuleDict()
+        self.unet_lora_state_dict = None
+        self._merged = (None, False)          # (ffn adapter name | None, attention LoRA on)
+        self._merge_saved = {}
 
     @property
     def dtype(self):
         return torch.float16
 
     def load_unet_state_dict(self, unet_state_dict):
+        self._set_loras((None, False))
         self.diffusion_model.load_state_dict(unet_state_dict)
+
+    def load_unet_loras(self, lora_state_dict):
+        """peft-style state dict with diffusers layer names (``up_blocks.3.resnets.1.conv1.lora_A.unet_distill.weight`` ...)."""
+        self._set_loras((None, False))
+        self.unet_lora_state_dict = dict(lora_state_dict)
+
+    def _set_loras(self, want):
+        if want == self._merged:
+            return
+        from ....adaface import lora
+        if self._merge_saved:
+            lora.unmerge_unet_loras(self.diffusion_model, self._merge_saved)
+            self._merge_saved = {}
+        if want != (None, False):
+            if self.unet_lora_state_dict is None:
+                raise RuntimeError("use_attn_lora / use_ffn_lora requested but no adapters are loaded (UNetWrapper.load_unet_loras)")
+            if want[0] is not None:
+                self._merge_saved.update(lora.merge_unet_loras(self.diffusion_model, self.unet_lora_state_dict, want[0],
+                                                               use_ffn_lora=True, use_attn_lora=False))
+            if want[1]:
+                self._merge_saved.update(lora.merge_unet_loras(self.diffusion_model, self.unet_lora_state_dict, "default",
+                                                               use_ffn_lora=False, use_attn_lora=True))
+        self._merged = want
 
     def forward(self, x, t, cond_context, out_dtype=torch.float32):
         prompt_emb, prompt_in, extra_info = cond_context
-        if extra_info is not None and (extra_info.get("use_attn_lora", False) or extra_info.get("use_ffn_lora", False)):
-            raise NotImplementedError("attention / FFN LoRA adapters are a later row of the scope table (SURVEY.md 8f rank 1)")
+        ei = extra_info or {}
+        want = (ei.get("ffn_lora_adapter_name") if ei.get("use_ffn_lora", False) else None, bool(ei.get("use_attn_lora", False)))
+        if want != (None, False) and torch.is_grad_enabled() and (x.requires_grad or prompt_emb.requires_grad):
+            raise NotImplementedError("training through DoRA adapters (dropout branch, gradients to A / B / m) is a later row of "
+                                      "the scope table (SURVEY.md 8f rank 1)")
+        self._set_loras(want)
         out = self.diffusion_model(x, t, prompt_emb, extra_info=extra_info)
         return out.to(out_dtype)
 

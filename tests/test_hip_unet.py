@@ -298,3 +298,49 @@ def test_latent_diffusion_apply_model_contract(dev):
     assert ld.num_timesteps == 1000 and abs(float(ld.alphas_cumprod[0]) - 0.99915) < 1e-5
     xt = ld.q_sample(x, torch.tensor([0, 999], device=dev), noise=torch.zeros_like(x))
     assert rel_l2(xt[0].cpu().numpy(), (x[0] * ld.sqrt_alphas_cumprod[0]).cpu().numpy()) < 1e-6
+
+
+def test_unet_wrapper_ffn_lora_flags_merge_and_restore(dev):
+    """apply_model(use_ffn_lora=True, ffn_lora_adapter_name=...) runs the U-Net with the DoRA adapters of the six
+    up_blocks.3 conv layers merged in (adaface/lora.py; merged weight == peft's branch form is pinned on CPU in
+    tests/test_lora_host.py), switching the flag off restores the base weights bit-exactly, and training through adapters
+    is refused loudly."""
+    from adaface_dev_amd import rng
+    from adaface_dev_amd.adaface import lora as L
+    from adaface_dev_amd.ldm.models.diffusion.ddpm import LatentDiffusion
+    ld = LatentDiffusion(GPU_TINY_CONFIG)
+    rng.load_synth_weights(ld.model.diffusion_model, seed=11)
+    ld = ld.to(dev)
+    unet = ld.model.diffusion_model
+    sd = {}
+    for dname, lpath in L.FFN_LORA_TARGETS.items():
+        w = L._get(unet, lpath).weight
+        sd[f"{dname}.lora_A.unet_distill.weight"] = rng.synth_input(dname + "A", (8,) + tuple(w.shape[1:]), seed=72, scale=0.3)
+        sd[f"{dname}.lora_B.unet_distill.weight"] = rng.synth_input(dname + "B", (w.shape[0], 8, 1, 1), seed=72, scale=0.3)
+        sd[f"{dname}.lora_magnitude_vector.unet_distill.weight"] = 1.0 + 0.3 * rng.synth_input(dname + "m", (w.shape[0],), seed=72).abs()
+    x = rng.synth_input("t64.x", (2, 4, 32, 32), seed=11).to(dev)
+    ctx = rng.synth_input("t64.ctx", (2, 77, 64), seed=11).to(dev)
+    t = torch.tensor([10, 500], device=dev)
+    with torch.no_grad():
+        base = ld.apply_model(x, t, (ctx, ["a"] * 2, {}))
+        try:
+            ld.apply_model(x, t, (ctx, ["a"] * 2, {}), use_ffn_lora=True, ffn_lora_adapter_name="unet_distill")
+        except RuntimeError as e:
+            assert "no adapters are loaded" in str(e)
+        else:
+            raise AssertionError("LoRA flags without adapters must fail loudly")
+        ld.model.load_unet_loras(sd)
+        lora_out = ld.apply_model(x, t, (ctx, ["a"] * 2, {}), use_ffn_lora=True, ffn_lora_adapter_name="unet_distill")
+        assert rel_l2(lora_out.cpu().numpy(), base.cpu().numpy()) > 1e-2                    # the adapters really act
+        # reference: a second U-Net whose six conv weights are merged by hand
+        import copy
+        ref_unet = copy.deepcopy(unet)
+        L.unmerge_unet_loras(ref_unet, ld.model._merge_saved)
+        L.merge_unet_loras(ref_unet, sd, "unet_distill")
+        ref = ref_unet(x, t, ctx, extra_info={})
+        assert torch.equal(lora_out, ref)
+        again = ld.apply_model(x, t, (ctx, ["a"] * 2, {}))                                  # flags off -> base weights restored
+        assert torch.equal(again, base)
+    cg = ctx.clone().requires_grad_(True)
+    with pytest.raises(NotImplementedError):
+        ld.apply_model(x, t, (cg, ["a"] * 2, {}), use_ffn_lora=True, ffn_lora_adapter_name="unet_distill")

@@ -1,0 +1,67 @@
+"""DoRA weight merge (adaface/lora.py) against the branch-form oracle (oracle/lora_oracle.py), and the name mapping / merge /
+unmerge bookkeeping on a reduced-width U-Net.  CPU only (merging is host-side weight arithmetic; the merged U-Net runs on the same
+HIP path as any other weights)."""
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_l2
+from adaface_dev_amd import TINY_UNET_CONFIG, rng
+from adaface_dev_amd.adaface import lora as L
+from oracle import lora_oracle as LO
+
+
+def _rand(name, shape, scale=1.0):
+    return rng.synth_input(name, shape, seed=70, scale=scale)
+
+
+def test_merged_conv_equals_dora_branch_form():
+    for k, pad in ((3, 1), (1, 0)):
+        w, b = _rand(f"w{k}", (24, 16, k, k), 0.1), _rand(f"b{k}", (24,), 0.1)
+        A, Bm = _rand(f"A{k}", (6, 16, k, k), 0.2), _rand(f"B{k}", (24, 6, 1, 1), 0.2)
+        m = 1.0 + 0.3 * _rand(f"m{k}", (24,)).abs()
+        x = _rand(f"x{k}", (2, 16, 9, 9))
+        ref = LO.dora_conv2d(x, w, b, A, Bm, m, 16 / 192 * 7, 1, pad)
+        got = F.conv2d(x, L.dora_merged_weight(w, A, Bm, m, 16 / 192 * 7), b, 1, pad)
+        assert rel_l2(got.numpy(), ref.numpy()) < 1e-5
+        plain = F.conv2d(x, L.dora_merged_weight(w, A, Bm, None, 0.5), b, 1, pad)            # plain LoRA: W + scaling * BA
+        assert rel_l2(plain.numpy(), (F.conv2d(x, w, b, 1, pad) + 0.5 * F.conv2d(F.conv2d(x, A, None, 1, pad), Bm)).numpy()) < 1e-5
+
+
+def test_merged_linear_equals_dora_branch_form_and_identity_at_init():
+    w, b = _rand("lw", (40, 24), 0.1), _rand("lb", (40,), 0.1)
+    A, Bm, m = _rand("lA", (8, 24), 0.2), _rand("lB", (40, 8), 0.2), 1.0 + 0.3 * _rand("lm", (40,)).abs()
+    x = _rand("lx", (5, 24))
+    ref = LO.dora_linear(x, w, b, A, Bm, m, 24 / 192)
+    assert rel_l2(F.linear(x, L.dora_merged_weight(w, A, Bm, m, 24 / 192), b).numpy(), ref.numpy()) < 1e-5
+    a0, b0, m0 = L.init_dora_adapter(w, rank=8, generator=torch.Generator().manual_seed(0))
+    assert torch.allclose(L.dora_merged_weight(w, a0, b0, m0, 16 / 192), w, atol=1e-6)       # B = 0, m = ||W||: no change
+
+
+def test_merge_and_unmerge_on_unet_module_tree():
+    from adaface_dev_amd.ldm.modules.diffusionmodules.openaimodel import UNetModel
+    unet = UNetModel(**dict(TINY_UNET_CONFIG))
+    rng.load_synth_weights(unet, seed=71)
+    sd = {}
+    for dname, lpath in list(L.FFN_LORA_TARGETS.items()) + list(L.ATTN_LORA_TARGETS.items()):
+        layer = L._get(unet, lpath)
+        assert hasattr(layer, "weight"), (dname, lpath)                 # output blocks 10/11 have 1x1 skip convs (960/640 -> 320)
+        w = layer.weight
+        r = 4
+        sd[f"{dname}.lora_A.unet_distill.weight"] = _rand(dname + "A", (r,) + tuple(w.shape[1:]), 0.2)
+        sd[f"{dname}.lora_B.unet_distill.weight"] = _rand(dname + "B", (w.shape[0], r) + (1,) * (w.dim() - 2), 0.2)
+        sd[f"{dname}.lora_magnitude_vector.unet_distill.weight"] = 1.0 + 0.2 * _rand(dname + "m", (w.shape[0],)).abs()
+    before = {k: v.detach().clone() for k, v in unet.state_dict().items()}
+    saved = L.merge_unet_loras(unet, sd, "unet_distill", use_ffn_lora=True, use_attn_lora=False, ffn_lora_alpha=2)
+    assert set(saved) == set(L.FFN_LORA_TARGETS.values())
+    changed = {k for k, v in unet.state_dict().items() if not torch.equal(v, before[k])}
+    assert changed == {p + ".weight" for p in L.FFN_LORA_TARGETS.values()}
+    conv = L._get(unet, "output_blocks.11.0.in_layers.2")
+    want = L.dora_merged_weight(before["output_blocks.11.0.in_layers.2.weight"], sd["up_blocks.3.resnets.2.conv1.lora_A.unet_distill.weight"],
+                                sd["up_blocks.3.resnets.2.conv1.lora_B.unet_distill.weight"],
+                                sd["up_blocks.3.resnets.2.conv1.lora_magnitude_vector.unet_distill.weight"], 2 / 4)
+    assert torch.allclose(conv.weight, want, atol=1e-6)
+    assert L.merge_unet_loras(unet, sd, "recon_loss") == {}                                  # adapter not in the state dict: no-op
+    L.unmerge_unet_loras(unet, saved)
+    assert all(torch.equal(v, before[k]) for k, v in unet.state_dict().items())
+    saved2 = L.merge_unet_loras(unet, sd, "unet_distill", use_ffn_lora=False, use_attn_lora=True)
+    assert set(saved2) == set(L.ATTN_LORA_TARGETS.values())
