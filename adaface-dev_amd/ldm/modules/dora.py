@@ -1,0 +1,124 @@
+"""Trainable DoRA adapters on convolutions of the U-Net: the reference attaches peft DoRA ``Conv2d``
+adapters (rank 192, ``lora_alpha`` 16, dropout 0.1, three adapter names) to ``up_blocks.3.resnets.{1,2}.{conv1,conv2,conv_shortcut}``
+(``adaface/diffusers_attn_lora_capture.py:541-591``) and ALWAYS enables the ``unet_distill`` one in Stage-1 distillation
+(``ddpm.py:3130-3134``).
+
+peft (third party, absent here, unpinned in the reference) computes, with ``xd = dropout(x)``, ``scaling = alpha / r`` and
+``s_c = m_c / ||W + scaling * B A||_c`` (norm detached):
+
+    y = base(x) + (s - 1) * conv(xd, W) + s * scaling * B(A(xd))                       (DoraConv2dLayer.forward)
+
+This module runs that forward and its backward on the gfx950 kernels: the three convolutions and their input gradients are ``af_gemm``
+launches (A: 3x3 or 1x1 Cin -> r; B: 1x1 r -> Cout), the combination is ``af_dora_combine``, dropout is ``af_mul_f16`` with a
+pre-drawn mask, the weight gradients are GEMMs over pixels: dB = d(lb)^T . t,  dA = d(t)^T . im2col(xd)  (``af_im2col3x3`` +
+``autograd_ops.wgrad``), dm = colsum(dy * (c2 + scaling * lb)) / norm.  Parameters are named like peft's so reference checkpoints map
+one to one (``adaface/lora.py::extract_adapter``)."""
+import torch
+import torch.nn as nn
+
+from ... import ops
+from ...autograd_ops import wgrad
+from ...ops import F16
+
+
+class DoRAConvAdapter(nn.Module):
+    def __init__(self, conv, rank=192, lora_alpha=16, lora_dropout=0.1, generator=None):
+        super().__init__()
+        from ...adaface.lora import init_dora_adapter
+        a, b, m = init_dora_adapter(conv.weight, rank, generator)
+        self.lora_A = nn.Parameter(a)                        # [r, Cin, k, k]
+        self.lora_B = nn.Parameter(b)                        # [Cout, r, 1, 1]   (zero: the adapter starts as the identity)
+        self.lora_magnitude_vector = nn.Parameter(m)         # [Cout]            (||W|| per output channel)
+        self.rank, self.scaling, self.p = rank, lora_alpha / rank, lora_dropout
+        self.k = conv.kernel_size[0]
+
+    # ---- packs (rebuilt when the parameters change: once per optimizer step)
+    def _packs(self):
+        key = (self.lora_A._version, self.lora_B._version, self.lora_A.data_ptr(), self.lora_B.data_ptr())
+        if getattr(self, "_pack_key", None) != key:
+            dev = self.lora_A.device
+            A, Bm = self.lora_A.detach(), self.lora_B.detach().flatten(1)
+            if self.k == 3:
+                pa = ops.pack_conv3x3(A, None, dev)
+                pa_t = ops.pack_conv3x3(A.flip(2, 3).permute(1, 0, 2, 3).contiguous(), None, dev, ops.round_up(self.rank, 8))
+            else:
+                pa = ops.pack_matrix(A.flatten(1), None, dev)
+                pa_t = ops.pack_matrix(A.flatten(1).t().contiguous(), None, dev)
+            self._pk = (pa, pa_t, ops.pack_matrix(Bm, None, dev), ops.pack_matrix(Bm.t().contiguous(), None, dev))
+            self._pack_key = key
+        return self._pk
+
+    def scales(self, conv):
+        """(u = s - 1, v = s * scaling, norm) fp32 [Cout]; s = m / ||W + scaling * B A|| with the norm detached (peft)."""
+        w = conv.weight.detach().float()
+        delta = (self.lora_B.detach().float().flatten(1) @ self.lora_A.detach().float().flatten(1)).reshape(w.shape)
+        norm = (w + self.scaling * delta).flatten(1).norm(dim=1)
+        s = self.lora_magnitude_vector.detach().float() / norm
+        return (s - 1).contiguous(), (s * self.scaling).contiguous(), norm
+
+    def draw_mask(self, shape, device, generator=None):
+        """Dropout mask with values 0 or 1 / (1 - p) (None in eval mode / p = 0)."""
+        if not self.training or self.p == 0:
+            return None
+        keep = torch.rand(shape, device=device, generator=generator) >= self.p
+        return (keep.to(torch.float32) / (1 - self.p)).to(F16)
+
+
+def _conv_nobias(conv, x):
+    pw = conv.packed()
+    pw0 = ops.PackedWeight(pw.wt, None, pw.N, pw.K, pw.kpad, pw.taps, pw.cin)
+    if conv.kernel_size == (3, 3):
+        return ops.conv3x3(x, pw0, stride=conv.stride[0])
+    B, H, W, c = x.shape
+    return ops.gemm(x.reshape(B * H * W, c), pw0).reshape(B, H, W, -1)
+
+
+def dora_conv_fwd(conv, ad, x, x2=None, rowbias=None, residual=None, mask=None):
+    """y = base(x) + (s - 1) * conv(xd, W) + s * scaling * B(A(xd)).  x (+ x2 concatenated along channels) NHWC fp16;
+    rowbias / residual are fused into the base convolution exactly as without adapters.  Returns (y, saved)."""
+    xin = x if x2 is None else torch.cat([x, x2], dim=-1)
+    y0 = conv.hip(x, x2=x2, rowbias=rowbias, residual=residual)
+    xd = xin if mask is None else ops.mul(xin, mask)
+    pa, _, pb, _ = ad._packs()
+    c2 = _conv_nobias(conv, xd)
+    Bn, H, W, _ = xd.shape
+    if ad.k == 3:
+        t = ops.conv3x3(xd, pa, stride=conv.stride[0])
+    else:
+        t = ops.gemm(xd.reshape(Bn * H * W, -1), pa).reshape(Bn, H, W, -1)
+    M = t.shape[0] * t.shape[1] * t.shape[2]
+    lb = ops.gemm(t.reshape(M, ad.rank), pb).reshape(c2.shape)
+    u, v, norm = ad.scales(conv)
+    y = ops.dora_combine(y0, c2, lb, u, v)
+    return y, (xd, c2, lb, t, mask, u, v, norm)
+
+
+def dora_conv_bwd(conv, ad, saved, dy):
+    """-> (dx [B,H,W,Cin] w.r.t. the (concatenated) input, {lora_A, lora_B, lora_magnitude_vector: fp32 gradients})."""
+    xd, c2, lb, t, mask, u, v, norm = saved
+    Bn, Ho, Wo, cout = dy.shape
+    M = Bn * Ho * Wo
+    zeros = torch.zeros_like(u)
+    _, pa_t, _, pb_t = ad._packs()
+    dy2 = dy.reshape(M, cout)
+    dc2 = ops.affine_prelu(dy, u, zeros)
+    dlb = ops.affine_prelu(dy, v, zeros).reshape(M, cout)
+    dt = ops.gemm(dlb, pb_t)                                               # [M, r]
+    if ad.k == 3:
+        dxa = ops.conv3x3(dt.reshape(Bn, Ho, Wo, ad.rank), pa_t)
+    else:
+        dxa = ops.gemm(dt, pa_t).reshape(Bn, Ho, Wo, -1)
+    dxd = ops.add(conv.hip_dgrad(dc2), dxa)
+    if mask is not None:
+        dxd = ops.mul(dxd, mask)
+    dx = ops.add(conv.hip_dgrad(dy), dxd)
+    # ---- parameter gradients
+    t2 = t.reshape(M, ad.rank)
+    dB = wgrad(dlb, t2).float().reshape(ad.lora_B.shape)
+    if ad.k == 3:
+        cin = xd.shape[-1]
+        dA = wgrad(dt, ops.im2col3x3(xd, conv.stride[0])).float().reshape(ad.rank, 3, 3, cin).permute(0, 3, 1, 2).contiguous()
+    else:
+        dA = wgrad(dt, xd.reshape(M, -1)).float().reshape(ad.lora_A.shape)
+    dm = (ops.colsum(dy2, c2.reshape(M, cout)) + ad.scaling * ops.colsum(dy2, lb.reshape(M, cout))) / norm
+    return dx, {"lora_A": dA, "lora_B": dB, "lora_magnitude_vector": dm}

@@ -501,6 +501,33 @@ def scale_f32_(a, s):
     return a
 
 
+# ----------------------------------------------------------------------------- trainable DoRA adapters
+def dora_combine(y0, c2, lb, u, v):
+    """y0 + u[c] * c2 + v[c] * lb over the last (channel) axis; u, v fp32 [C]."""
+    Cn = y0.shape[-1]
+    out = torch.empty_like(y0)
+    _lib.check(_lib.lib().af_dora_combine(_p(y0), _p(c2), _p(lb), _p(u), _p(v), _p(out), y0.numel() // Cn, Cn, _stream()), "af_dora_combine")
+    return out
+
+
+def mul(a, b):
+    _chk_f16(a, "mul.a")
+    _chk_f16(b, "mul.b")
+    assert a.shape == b.shape
+    out = torch.empty_like(a)
+    _lib.check(_lib.lib().af_mul_f16(_p(a), _p(b), _p(out), a.numel(), _stream()), "af_mul_f16")
+    return out
+
+
+def im2col3x3(x, stride=1):
+    """x [B,H,W,C] fp16 -> [B*Ho*Wo, 9*C], column order (ky, kx, c)."""
+    B, H, W, Cn = x.shape
+    Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
+    out = torch.empty((B * Ho * Wo, 9 * Cn), dtype=F16, device=x.device)
+    _lib.check(_lib.lib().af_im2col3x3(_p(x), _p(out), B, H, W, Cn, stride, _stream()), "af_im2col3x3")
+    return out
+
+
 # ----------------------------------------------------------------------------- ArcFace ResNetFace encoder
 def affine_prelu(x, scale=None, shift=None, slope=None):
     """y = prelu(x * scale[c] + shift[c]) over the last (channel) axis; any of the two stages may be absent."""

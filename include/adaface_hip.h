@@ -241,6 +241,17 @@ int af_global_avgpool(const void* x, void* out, int B, int HW, int C, void* stre
 int af_se_residual_prelu(const void* x, const void* se_logits, const void* residual, const void* slope, void* y, int B, int HW, int C,
                          void* stream);
 
+/* ---- trainable DoRA adapters on the U-Net's up_blocks.3 convolutions (adaface/diffusers_attn_lora_capture.py:541-591; peft
+ * DoraConv2dLayer.forward: y = base(x) + (s - 1) * conv(xd, W) + s * scaling * B(A(xd)), xd = dropout(x)) ---------------------
+ * out = y0 + u[c] * c2 + v[c] * lb   (fp16 [rows, C]; u = s - 1, v = s * scaling, fp32 [C]) */
+int af_dora_combine(const void* y0, const void* c2, const void* lb, const void* u, const void* v, void* out, int64_t rows, int C,
+                    void* stream);
+/* out = a * b, fp16 (dropout: b holds 0 or 1 / (1 - p)) */
+int af_mul_f16(const void* a, const void* b, void* out, int64_t n, void* stream);
+/* x [B,H,W,C] fp16 -> out [B*Ho*Wo, 9*C] with column order (ky, kx, c), zero halo, pad 1: the explicit operand of a 3x3 conv's
+ * weight gradient (a GEMM over pixels) */
+int af_im2col3x3(const void* x, void* out, int B, int H, int W, int C, int stride, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

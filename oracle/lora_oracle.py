@@ -21,3 +21,14 @@ def dora_linear(x, weight, bias, lora_A, lora_B, magnitude, scaling):
     s = (magnitude / weight_norm).view(1, -1)
     base = F.linear(x, weight, bias)
     return base + (s - 1) * F.linear(x, weight) + s * F.linear(F.linear(x, lora_A), lora_B) * scaling
+
+
+def dora_conv2d_train(x, weight, bias, lora_A, lora_B, magnitude, scaling, mask=None, stride=1, padding=1):
+    """Training-mode branch form with an explicit dropout mask (values 0 or 1 / (1 - p)) on the adapter branch: peft's
+    ``result = base_layer(x); x = dropout(x); result += dora(x)`` with dora(x) = (s - 1) * conv(x, W) + s * scaling * B(A(x))."""
+    lora_weight = (lora_B.flatten(1) @ lora_A.flatten(1)).reshape(weight.shape)
+    weight_norm = (weight + scaling * lora_weight.detach()).norm(p=2, dim=(1, 2, 3), keepdim=True).transpose(1, 0).detach()
+    s = magnitude.reshape(1, -1, 1, 1) / weight_norm
+    xd = x if mask is None else x * mask
+    base = F.conv2d(x, weight, bias, stride, padding)
+    return base + (s - 1) * F.conv2d(xd, weight, None, stride, padding) + s * F.conv2d(F.conv2d(xd, lora_A, None, stride, padding), lora_B) * scaling

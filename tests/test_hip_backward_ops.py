@@ -174,3 +174,56 @@ def test_cadamw_step_matches_reference_trace(dev):
             p.add_((em * mask) / denom, alpha=-ss)
     want = torch.cat([p.reshape(-1) for p in rp])
     assert rel_l2(flat.cpu().numpy(), want.numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("k,cin,cout,r", [(3, 96, 64, 32), (1, 96, 64, 32), (3, 64, 64, 192)])
+def test_dora_conv_forward_backward_vs_oracle_autograd(dev, k, cin, cout, r):
+    """Trainable DoRA adapter on a conv (3x3 and the 1x1 shortcut), with a dropout mask, fused rowbias + residual on the base
+    conv and a two-source (concatenated) input: y, dx and the gradients of lora_A / lora_B / magnitude against autograd through
+    the branch-form oracle (peft's DoraConv2dLayer restated; parity unpinned)."""
+    from adaface_dev_amd import ops, rng
+    from adaface_dev_amd.ldm.modules.diffusionmodules.util import Conv2d
+    from adaface_dev_amd.ldm.modules.dora import DoRAConvAdapter, dora_conv_bwd, dora_conv_fwd
+    from oracle import lora_oracle as LO
+    B, H, W = 2, 12, 10
+    conv = Conv2d(cin, cout, k, padding=k // 2)
+    with torch.no_grad():
+        conv.weight.copy_(rng.synth_input(f"dc.w{k}", conv.weight.shape, seed=80, scale=(cin * k * k) ** -0.5))
+        conv.bias.copy_(rng.synth_input(f"dc.b{k}", (cout,), seed=80, scale=0.1))
+    ad = DoRAConvAdapter(conv, rank=r, lora_alpha=16, lora_dropout=0.1)
+    with torch.no_grad():
+        ad.lora_A.copy_(rng.synth_input(f"dc.A{k}", ad.lora_A.shape, seed=80, scale=0.05))
+        ad.lora_B.copy_(rng.synth_input(f"dc.B{k}", ad.lora_B.shape, seed=80, scale=0.2))
+        ad.lora_magnitude_vector.mul_(1.0 + 0.2 * rng.synth_input(f"dc.m{k}", (cout,), seed=80).abs())
+    c1 = cin // 3 * 2 // 8 * 8
+    x = rng.synth_input(f"dc.x{k}", (B, cin, H, W), seed=80)
+    rowb = rng.synth_input(f"dc.rb{k}", (B, cout), seed=80, scale=0.3)
+    res = rng.synth_input(f"dc.res{k}", (B, cout, H, W), seed=80)
+    cot = rng.synth_input(f"dc.cot{k}", (B, cout, H, W), seed=80)
+    keep = (torch.rand((B, cin, H, W), generator=torch.Generator().manual_seed(9)) >= 0.1).float() / 0.9
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().half().to(dev)
+    conv, ad = conv.to(dev), ad.to(dev).train()
+    xh = nhwc(x)
+    y, saved = dora_conv_fwd(conv, ad, xh[..., :c1].contiguous(), x2=xh[..., c1:].contiguous(), rowbias=rowb.half().to(dev),
+                             residual=nhwc(res), mask=nhwc(keep))
+    dx, grads = dora_conv_bwd(conv, ad, saved, nhwc(cot))
+    # oracle (fp32, on the fp16-rounded inputs)
+    xr = xh.float().cpu().permute(0, 3, 1, 2).requires_grad_(True)
+    P = {n: p.detach().float().cpu().requires_grad_(True) for n, p in ad.named_parameters()}
+    ref = LO.dora_conv2d_train(xr, conv.weight.detach().float().cpu(), conv.bias.detach().float().cpu(), P["lora_A"], P["lora_B"],
+                               P["lora_magnitude_vector"], 16 / r, nhwc(keep).float().cpu().permute(0, 3, 1, 2), 1, k // 2)
+    ref = ref + rowb.half().float()[:, :, None, None] + nhwc(res).float().cpu().permute(0, 3, 1, 2)
+    (ref * nhwc(cot).float().cpu().permute(0, 3, 1, 2)).sum().backward()
+    tol = 5e-3
+    assert rel_l2(y.float().cpu().permute(0, 3, 1, 2).numpy(), ref.detach().numpy()) < tol
+    assert rel_l2(dx.float().cpu().permute(0, 3, 1, 2).numpy(), xr.grad.numpy()) < tol
+    for n in ("lora_A", "lora_B", "lora_magnitude_vector"):
+        e = rel_l2(grads[n].cpu().numpy(), P[n].grad.numpy())
+        assert e < tol, (n, e)
+    # eval mode / no mask: equals the merged-weight convolution
+    from adaface_dev_amd.adaface.lora import dora_merged_weight
+    y_eval, _ = dora_conv_fwd(conv, ad.eval(), xh)
+    wm = dora_merged_weight(conv.weight.detach().cpu(), ad.lora_A.detach().cpu(), ad.lora_B.detach().cpu(),
+                            ad.lora_magnitude_vector.detach().cpu(), 16 / r)
+    ref_eval = F.conv2d(xh.float().cpu().permute(0, 3, 1, 2), wm, conv.bias.detach().float().cpu(), 1, k // 2)
+    assert rel_l2(y_eval.float().cpu().permute(0, 3, 1, 2).numpy(), ref_eval.numpy()) < tol
