@@ -434,6 +434,35 @@ __global__ __launch_bounds__(256) void colsum_kernel(const half_t* __restrict__ 
   }
 }
 
+// tall matrices (rows >> columns: per-pixel gradients of the DoRA magnitudes): grid (C / 64, chunks), each workgroup folds its row
+// range into partial[chunk][c]; colsum_reduce_kernel folds the chunks in a fixed order (deterministic, no atomics)
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const half_t* __restrict__ a, const half_t* __restrict__ b,
+                                                             float* __restrict__ partial, int rows, int C, int rows_per_chunk) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  const int r0 = blockIdx.y * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
+  float s = 0.f;
+  if (c < C) {
+    for (int r = r0 + w; r < r1; r += 4) {
+      const float av = (float)a[(size_t)r * C + c];
+      s += b ? av * (float)b[(size_t)r * C + c] : av;
+    }
+  }
+  red[w][lane] = s;
+  __syncthreads();
+  if (w == 0 && c < C) partial[(size_t)blockIdx.y * C + c] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+}
+
+__global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out, int chunks, int C,
+                                                            int accumulate) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int k = 0; k < chunks; ++k) s += partial[(size_t)k * C + c];
+  out[c] = accumulate ? out[c] + s : s;
+}
+
 __global__ __launch_bounds__(256) void quickgelu_fwd_kernel(const half_t* __restrict__ x, half_t* __restrict__ y, long n8) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n8) return;
@@ -627,6 +656,18 @@ extern "C" int af_colsum(const void* a, const void* b, void* out, int rows, int 
   hipLaunchKernelGGL(colsum_kernel, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)stream, (const half_t*)a, (const half_t*)b,
                      (float*)out, rows, C, accumulate);
   return af_check_launch("af_colsum");
+}
+
+extern "C" int af_colsum_tall(const void* a, const void* b, void* partial, void* out, int rows, int C, int chunks, int accumulate,
+                              void* stream) {
+  AF_REQUIRE(a && partial && out && rows > 0 && C > 0 && chunks > 0 && chunks <= 65535, "af_colsum_tall: bad argument");
+  AfLaunchScope scope(AF_FAM_ELEM, stream);
+  const int rpc = (rows + chunks - 1) / chunks;
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3((C + 63) / 64, chunks), dim3(256), 0, (hipStream_t)stream, (const half_t*)a,
+                     (const half_t*)b, (float*)partial, rows, C, rpc);
+  hipLaunchKernelGGL(colsum_reduce_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)partial, (float*)out,
+                     chunks, C, accumulate);
+  return af_check_launch("af_colsum_tall");
 }
 
 extern "C" int af_quickgelu_fwd(const void* x, void* y, int64_t n, void* stream) {

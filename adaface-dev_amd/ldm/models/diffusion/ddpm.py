@@ -39,6 +39,7 @@ class UNetWrapper(nn.Module):
         self.use_ffn_lora = False
         self.unet_lora_modules = nn.ModuleDict()
         self.unet_lora_state_dict = None
+        self.ffn_lora = None                  # modules/dora.py::UNetLoRA (trainable adapters), see set_up_ffn_loras
         self._merged = (None, False)          # (ffn adapter name | None, attention LoRA on)
         self._merge_saved = {}
 
@@ -54,6 +55,17 @@ class UNetWrapper(nn.Module):
         """peft-style state dict with diffusers layer names (``up_blocks.3.resnets.1.conv1.lora_A.unet_distill.weight`` ...)."""
         self._set_loras((None, False))
         self.unet_lora_state_dict = dict(lora_state_dict)
+
+    def set_up_ffn_loras(self, adapter_names=("recon_loss", "unet_distill", "comp_distill"), lora_rank=192, lora_alpha=16,
+                         lora_dropout=0.1):
+        """Reference ``set_up_ffn_loras`` (diffusers_attn_lora_capture.py:541-591): create the trainable DoRA adapters.  Call after
+        the U-Net is on its device."""
+        from ...modules.dora import UNetLoRA
+        self.ffn_lora = UNetLoRA(self.diffusion_model, adapter_names, lora_rank, lora_alpha, lora_dropout)
+        dev = next(self.diffusion_model.parameters()).device
+        self.ffn_lora.to(dev)
+        self.unet_lora_modules = self.ffn_lora.adapters
+        return self.ffn_lora
 
     def _set_loras(self, want):
         if want == self._merged:
@@ -77,10 +89,34 @@ class UNetWrapper(nn.Module):
         prompt_emb, prompt_in, extra_info = cond_context
         ei = extra_info or {}
         want = (ei.get("ffn_lora_adapter_name") if ei.get("use_ffn_lora", False) else None, bool(ei.get("use_attn_lora", False)))
-        if want != (None, False) and torch.is_grad_enabled() and (x.requires_grad or prompt_emb.requires_grad):
-            raise NotImplementedError("training through DoRA adapters (dropout branch, gradients to A / B / m) is a later row of "
-                                      "the scope table (SURVEY.md 8f rank 1)")
-        self._set_loras(want)
+        training_pass = torch.is_grad_enabled() and (x.requires_grad or prompt_emb.requires_grad or
+                                                     (self.ffn_lora is not None and any(p.requires_grad for p in self.ffn_lora.parameters())))
+        if want != (None, False) and training_pass:
+            # TRAINING through the adapters: un-merged base weights + the DoRA branch with gradients (modules/dora.py)
+            if want[1]:
+                raise NotImplementedError("training the attention LoRAs is not built (Stage 1 never enables them, ddpm.py:3130-3132)")
+            if self.ffn_lora is None:
+                raise RuntimeError("use_ffn_lora requested in a training pass but no trainable adapters exist (UNetWrapper.set_up_ffn_loras)")
+            self._set_loras((None, False))
+            extra_info["_ffn_lora_adapters"] = self.ffn_lora.active(want[0])
+            try:
+                out = self.diffusion_model(x, t, prompt_emb, extra_info=extra_info)
+            finally:
+                extra_info.pop("_ffn_lora_adapters", None)
+            return out.to(out_dtype)
+        if want != (None, False) and self.ffn_lora is not None and self.unet_lora_state_dict is None:
+            key = tuple(p._version for p in self.ffn_lora.parameters())        # inference with the module-held adapters: merge them
+            if key != getattr(self, "_merged_from_key", None):
+                self._set_loras((None, False))
+                self._module_sd = self.ffn_lora.peft_state_dict()
+                self._merged_from_key = key
+            self.unet_lora_state_dict, keep = self._module_sd, True
+            try:
+                self._set_loras(want)
+            finally:
+                self.unet_lora_state_dict = None
+        else:
+            self._set_loras(want)
         out = self.diffusion_model(x, t, prompt_emb, extra_info=extra_info)
         return out.to(out_dtype)
 
@@ -204,7 +240,9 @@ class LatentDiffusion(nn.Module):
                                                  torch.cat([z.to(x_start.dtype) for z in t_noises[:n]]), torch.cat(list(all_t[:n])),
                                                  cat_context, img_mask=None, batch_part_has_grad="all", do_pixel_recon=True,
                                                  cfg_scale=self.unet_teacher.cfg_scale,
-                                                 res_hidden_states_gradscale=self.res_hidden_states_gradscale)
+                                                 res_hidden_states_gradscale=self.res_hidden_states_gradscale,
+                                                 # ** Always enable ffn LoRAs on unet distillation (ddpm.py:3130-3134) when they exist
+                                                 use_ffn_lora=self.model.ffn_lora is not None, ffn_lora_adapter_name="unet_distill")
             preds = pred_all.split(bs)
         else:
             preds = []
@@ -212,7 +250,9 @@ class LatentDiffusion(nn.Module):
                 noise_pred_s, _, _ = self.guided_denoise(t_x_starts[s].to(x_start.dtype), t_noises[s].to(x_start.dtype), all_t[s],
                                                          subj_context, img_mask=None, batch_part_has_grad="all",
                                                          do_pixel_recon=True, cfg_scale=self.unet_teacher.cfg_scale,
-                                                         res_hidden_states_gradscale=self.res_hidden_states_gradscale)
+                                                         res_hidden_states_gradscale=self.res_hidden_states_gradscale,
+                                                 # ** Always enable ffn LoRAs on unet distillation (ddpm.py:3130-3134) when they exist
+                                                 use_ffn_lora=self.model.ffn_lora is not None, ffn_lora_adapter_name="unet_distill")
                 preds.append(noise_pred_s)
         for s in range(n):
             loss_s, _ = calc_recon_loss(F.mse_loss, preds[s], t_preds[s].to(preds[s].dtype), img_mask, fg_mask,

@@ -202,26 +202,60 @@ class ResBlock(TimestepBlock):
         se = emb.silu_emb if isinstance(emb, EmbPack) else ops.silu(emb.to(F16).contiguous())
         return self.emb_layers[1].hip(se)
 
+    _lora = None      # {"conv1" | "conv2" | "conv_shortcut": DoRAConvAdapter}: set by _UNetFunction around hip_train (modules/dora.py)
+
     def hip_train(self, x, emb):
         """hip() keeping what the activation-gradient backward needs: the block input(s), the conv1
         output and the two GroupNorm statistics (GroupNorm outputs are only needed for weight gradients,
-        which do not exist here: base weights are frozen, ddpm.py:4131-4132)."""
+        which do not exist here: base weights are frozen, ddpm.py:4131-4132).  With trainable DoRA adapters attached
+        (`_lora`) the three convolutions run through modules/dora.py, which keeps its own operands."""
+        from ..dora import dora_conv_fwd
+        lora = self._lora or {}
         x1, x2 = (x[0], x[1]) if isinstance(x, SkipCat) else (x, None)
         a, st1 = self.in_layers[0].hip_train(x1, silu=True, x2=x2)
-        h1 = self.in_layers[2].hip(a, rowbias=self._emb_out(emb))
+        s1 = s2 = ssc = None
+        if "conv1" in lora:
+            ad = lora["conv1"]
+            h1, s1 = dora_conv_fwd(self.in_layers[2], ad, a, rowbias=self._emb_out(emb), mask=ad.draw_mask(a.shape, a.device))
+        else:
+            h1 = self.in_layers[2].hip(a, rowbias=self._emb_out(emb))
         b, st2 = self.out_layers[0].hip_train(h1, silu=True)
         if isinstance(self.skip_connection, nn.Identity):
             skip = x1 if x2 is None else torch.cat([x1, x2], dim=-1)
+        elif "conv_shortcut" in lora:
+            ad = lora["conv_shortcut"]
+            cin = x1.shape[-1] + (0 if x2 is None else x2.shape[-1])
+            skip, ssc = dora_conv_fwd(self.skip_connection, ad, x1, x2=x2, mask=ad.draw_mask(x1.shape[:-1] + (cin,), x1.device))
         else:
             skip = self.skip_connection.hip(x1, x2=x2)
-        return self.out_layers[3].hip(b, residual=skip), (x1, x2, st1, h1, st2)
+        if "conv2" in lora:
+            ad = lora["conv2"]
+            out, s2 = dora_conv_fwd(self.out_layers[3], ad, b, residual=skip, mask=ad.draw_mask(b.shape, b.device))
+        else:
+            out = self.out_layers[3].hip(b, residual=skip)
+        return out, (x1, x2, st1, h1, st2, (lora, s1, s2, ssc, {}) if lora else None)
 
     def hip_bwd(self, saved, dy):
-        """Reverse of openaimodel.py:256-276 (no gradient flows into the time embedding: it depends on t only)."""
-        x1, x2, st1, h1, st2 = saved
-        dh1 = self.out_layers[0].hip_bwd(h1, st2, self.out_layers[3].hip_dgrad(dy), silu=True)
-        da = self.in_layers[2].hip_dgrad(dh1)
-        dskip = dy if isinstance(self.skip_connection, nn.Identity) else self.skip_connection.hip_dgrad(dy)
+        """Reverse of openaimodel.py:256-276 (no gradient flows into the time embedding: it depends on t only).  Adapter
+        parameter gradients are left in the dict at the end of `saved`."""
+        from ..dora import dora_conv_bwd
+        x1, x2, st1, h1, st2, ls = saved
+        lora, s1, s2, ssc, grads = ls if ls is not None else ({}, None, None, None, None)
+        if s2 is not None:
+            db, grads["conv2"] = dora_conv_bwd(self.out_layers[3], lora["conv2"], s2, dy)
+        else:
+            db = self.out_layers[3].hip_dgrad(dy)
+        dh1 = self.out_layers[0].hip_bwd(h1, st2, db, silu=True)
+        if s1 is not None:
+            da, grads["conv1"] = dora_conv_bwd(self.in_layers[2], lora["conv1"], s1, dh1)
+        else:
+            da = self.in_layers[2].hip_dgrad(dh1)
+        if isinstance(self.skip_connection, nn.Identity):
+            dskip = dy
+        elif ssc is not None:
+            dskip, grads["conv_shortcut"] = dora_conv_bwd(self.skip_connection, lora["conv_shortcut"], ssc, dy)
+        else:
+            dskip = self.skip_connection.hip_dgrad(dy)
         return self.in_layers[0].hip_bwd(x1, st1, da, silu=True, x2=x2, add=dskip)
 
     def forward(self, x, emb):
@@ -503,11 +537,12 @@ class UNetModel(nn.Module):
         old_flags = None
         if capture:
             old_flags, _ = self.set_cross_attn_flags(ca_flag_dict={"save_cross_attn_vars": True}, ca_layer_indices=captured)
-        if torch.is_grad_enabled() and (x.requires_grad or context.requires_grad):
+        if torch.is_grad_enabled() and (x.requires_grad or context.requires_grad or (extra_info or {}).get("_ffn_lora_adapters")):
             if capture:
                 raise NotImplementedError("capture_ca_activations together with gradients (Stage-2 losses) is SURVEY.md 8f rank 4")
             gs = float((extra_info or {}).get("res_hidden_states_gradscale", 1) or 1)
-            return _UNetFunction.apply(self, x, timesteps, context, img_mask, gs)
+            lora = (extra_info or {}).get("_ffn_lora_adapters")           # set by UNetWrapper when use_ffn_lora is on
+            return _UNetFunction.apply(self, x, timesteps, context, img_mask, gs, lora, *[t[3] for t in lora_param_order(lora)])
         try:
             xh = to_nhwc_f16(x, ops.round_up(self.in_channels, 8))
             ctx = context.to(F16).contiguous()
@@ -528,10 +563,19 @@ class _UNetFunction(torch.autograd.Function):
     frozen as in the reference, ddpm.py:4131-4132, so no weight gradients exist on this path)."""
 
     @staticmethod
-    def forward(ctx, unet, x, timesteps, context, img_mask, res_gradscale=1.0):
+    def forward(ctx, unet, x, timesteps, context, img_mask, res_gradscale=1.0, lora=None, *lora_params):
+        """lora: {output-block index: {"conv1" | "conv2" | "conv_shortcut": DoRAConvAdapter}} or None; lora_params: the adapters'
+        parameters in `lora_param_order(lora)` order (passed so that autograd routes their gradients)."""
         ctx.res_gradscale = res_gradscale
+        ctx.lora = lora
         xh = to_nhwc_f16(x.detach(), ops.round_up(unet.in_channels, 8))
-        eps, saved = unet.hip_train(xh, timesteps, context.detach().to(F16).contiguous(), img_mask)
+        try:
+            for bi, ads in (lora or {}).items():
+                unet.output_blocks[bi][0]._lora = ads
+            eps, saved = unet.hip_train(xh, timesteps, context.detach().to(F16).contiguous(), img_mask)
+        finally:
+            for bi in (lora or {}):
+                unet.output_blocks[bi][0]._lora = None
         ctx.unet, ctx.saved = unet, saved
         ctx.need_dx, ctx.x_dtype, ctx.c_dtype = x.requires_grad, x.dtype, context.dtype
         return from_nhwc_f16(eps, x.dtype, unet.out_channels)
@@ -545,10 +589,25 @@ class _UNetFunction(torch.autograd.Function):
         amax = deps.detach().abs().amax().float().clamp_min(1e-30)
         scale = torch.exp2(torch.floor(torch.log2(256.0 / amax)))
         dh = to_nhwc_f16((deps * scale).contiguous(), ops.round_up(unet.out_channels, 8))
+        saved_out = ctx.saved[2]
         dx, dctx = unet.hip_bwd(ctx.saved, dh, need_dx=ctx.need_dx, res_gradscale=ctx.res_gradscale)
+        lora_grads = []
+        for bi, key, pname, p in lora_param_order(ctx.lora):
+            g = saved_out[bi][0][5][4][key][pname]             # ResBlock saved -> (lora, s1, s2, ssc, grads)
+            lora_grads.append((g / scale).to(p.dtype))
         ctx.saved = None
         gx = (from_nhwc_f16(dx, torch.float32, unet.in_channels) / scale).to(ctx.x_dtype) if dx is not None else None
-        return None, gx, None, (dctx.float() / scale).to(ctx.c_dtype), None, None
+        return (None, gx, None, (dctx.float() / scale).to(ctx.c_dtype), None, None, None) + tuple(lora_grads)
+
+
+def lora_param_order(lora):
+    """Deterministic flattening of {block: {conv key: adapter}} -> [(block, key, parameter name, parameter)]."""
+    out = []
+    for bi in sorted(lora or {}):
+        for key in sorted(lora[bi]):
+            for pname in ("lora_A", "lora_B", "lora_magnitude_vector"):
+                out.append((bi, key, pname, getattr(lora[bi][key], pname)))
+    return out
 
 
 def unet_param_shapes(cfg):

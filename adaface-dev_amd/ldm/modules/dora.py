@@ -122,3 +122,61 @@ def dora_conv_bwd(conv, ad, saved, dy):
         dA = wgrad(dt, xd.reshape(M, -1)).float().reshape(ad.lora_A.shape)
     dm = (ops.colsum(dy2, c2.reshape(M, cout)) + ad.scaling * ops.colsum(dy2, lb.reshape(M, cout))) / norm
     return dx, {"lora_A": dA, "lora_B": dB, "lora_magnitude_vector": dm}
+
+
+class UNetLoRA(nn.Module):
+    """The FFN DoRA adapters of one U-Net: for every adapter name, one DoRAConvAdapter on conv1 / conv2 / conv_shortcut of the last
+    two output blocks' ResBlocks (diffusers ``up_blocks.3.resnets.{1,2}``; reference ``set_up_ffn_loras``,
+    diffusers_attn_lora_capture.py:541-591: three adapters ``recon_loss`` / ``unet_distill`` / ``comp_distill``)."""
+
+    CONVS = (("conv1", lambda rb: rb.in_layers[2]), ("conv2", lambda rb: rb.out_layers[3]), ("conv_shortcut", lambda rb: rb.skip_connection))
+
+    def __init__(self, unet, adapter_names=("recon_loss", "unet_distill", "comp_distill"), rank=192, lora_alpha=16, lora_dropout=0.1):
+        super().__init__()
+        n_out = len(unet.output_blocks)
+        self.blocks = (n_out - 2, n_out - 1)
+        self.adapters = nn.ModuleDict()
+        for name in adapter_names:
+            d = nn.ModuleDict()
+            for ri, bi in enumerate(self.blocks, start=1):
+                rb = unet.output_blocks[bi][0]
+                for key, get in self.CONVS:
+                    conv = get(rb)
+                    if isinstance(conv, nn.Conv2d):
+                        d[f"up_blocks_3_resnets_{ri}_{key}"] = DoRAConvAdapter(conv, rank, lora_alpha, lora_dropout)
+            self.adapters[name] = d
+
+    def active(self, adapter_name):
+        """{output-block index: {conv key: adapter}} of one adapter name (what _UNetFunction consumes)."""
+        out = {}
+        for k, ad in self.adapters[adapter_name].items():
+            ri, key = int(k.split("_")[4]), k.split("_", 5)[5]
+            out.setdefault(self.blocks[ri - 1], {})[key] = ad
+        return out
+
+    def peft_state_dict(self, adapter_name=None):
+        """peft / diffusers naming: ``up_blocks.3.resnets.1.conv1.lora_A.<adapter>.weight`` ..."""
+        sd = {}
+        for name, d in self.adapters.items():
+            if adapter_name is not None and name != adapter_name:
+                continue
+            for k, ad in d.items():
+                parts = k.split("_", 5)
+                target = f"up_blocks.3.resnets.{parts[4]}.{parts[5]}"
+                sd[f"{target}.lora_A.{name}.weight"] = ad.lora_A.detach()
+                sd[f"{target}.lora_B.{name}.weight"] = ad.lora_B.detach()
+                sd[f"{target}.lora_magnitude_vector.{name}.weight"] = ad.lora_magnitude_vector.detach()
+        return sd
+
+    @torch.no_grad()
+    def load_peft_state_dict(self, sd):
+        for name, d in self.adapters.items():
+            for k, ad in d.items():
+                parts = k.split("_", 5)
+                target = f"up_blocks.3.resnets.{parts[4]}.{parts[5]}"
+                for pname in ("lora_A", "lora_B", "lora_magnitude_vector"):
+                    key = f"{target}.{pname}.{name}.weight"
+                    if key not in sd and pname == "lora_magnitude_vector":
+                        key = f"{target}.{pname}.{name}"
+                    if key in sd:
+                        getattr(ad, pname).copy_(sd[key].reshape(getattr(ad, pname).shape))

@@ -64,7 +64,7 @@ class DistillTrainer:
     unet_distill_weight = 8                                                     # ddpm.py:2367
 
     def __init__(self, ldm, id2ada, text_encoder, base_lr=2e-6, batch_size=4, accumulate_grad_batches=2,
-                 betas=(0.9, 0.995), eps=1e-6, weight_decay=0.0, warm_up_steps=500, max_decay_steps=60000,
+                 betas=(0.9, 0.995), eps=1e-6, weight_decay=0.0, lora_weight_decay=0.02, warm_up_steps=500, max_decay_steps=60000,
                  bucket_bytes=32 << 20, loss_scaler=None, prompt_len=77, subj_slot=4, process_group=None):
         self.ldm, self.id2ada, self.text_encoder = ldm, id2ada, text_encoder
         for p in text_encoder.parameters():
@@ -76,9 +76,18 @@ class DistillTrainer:
         # lr = accumulate_grad_batches * ngpu * bs * base_lr (main.py:911-915)
         self.learning_rate = accumulate_grad_batches * self.world * batch_size * base_lr
         params = [p for p in id2ada.subj_basis_generator.parameters() if p.requires_grad]
-        self.optimizer = CAdamW(params, lr=self.learning_rate, betas=betas, eps=eps, weight_decay=weight_decay)
-        self.arena = self.optimizer.arena(0)
-        self.reducer = GradReducer([self.arena], bucket_bytes=bucket_bytes, process_group=process_group)
+        groups = [{"params": params, "weight_decay": weight_decay}]
+        # second group: the U-Net's `unet_distill` FFN DoRA adapters when they exist (embedding_manager.optimized_parameters gives
+        # them their own weight decay, ddpm.py:143 lora_weight_decay = 0.02); the other adapter names are not touched in Stage 1
+        self.ffn_lora = getattr(ldm.model, "ffn_lora", None)
+        if self.ffn_lora is not None:
+            for n, p in self.ffn_lora.named_parameters():
+                p.requires_grad_(n.startswith("adapters.unet_distill."))
+            groups.append({"params": [p for p in self.ffn_lora.parameters() if p.requires_grad], "weight_decay": lora_weight_decay})
+        self.optimizer = CAdamW(groups, lr=self.learning_rate, betas=betas, eps=eps, weight_decay=weight_decay)
+        self.arenas = [self.optimizer.arena(i) for i in range(len(groups))]
+        self.arena = self.arenas[0]
+        self.reducer = GradReducer(self.arenas, bucket_bytes=bucket_bytes, process_group=process_group)
         self.lr_lambda = LambdaWarmUpCosineScheduler(warm_up_steps, 0.1, 1.0, 0.01, max_decay_steps)
         self.scaler = loss_scaler or LossScaler()
         self.global_step = 0                                                   # optimizer steps
@@ -158,13 +167,13 @@ class DistillTrainer:
 
     def optimizer_step(self):
         self.reducer.finish()                                     # wait for the in-flight buckets; sums -> means
-        g = self.arena.flat_g
-        bad = (~torch.isfinite(g.sum())).float()                  # one reduction; inf/nan anywhere poisons the sum
+        bad = sum((~torch.isfinite(a.flat_g.sum())).float() for a in self.arenas)   # one reduction per arena; inf/nan poisons the sum
         if self.world > 1:
             dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=self.pg)
         overflow = bool(bad.item() > 0)
         if not overflow:
-            ops.scale_f32_(g, 1.0 / self.scaler.scale)
+            for a in self.arenas:
+                ops.scale_f32_(a.flat_g, 1.0 / self.scaler.scale)
             for group in self.optimizer.param_groups:
                 group["lr"] = self.learning_rate * self.lr_lambda(self.global_step)
             self.optimizer.step()

@@ -480,6 +480,11 @@ def colsum(a, b=None, out=None, accumulate=False):
     rows, Cn = a.shape
     if out is None:
         out = torch.empty((Cn,), dtype=torch.float32, device=a.device)
+    if rows >= 2048:                                           # tall: spread the rows over workgroups (two deterministic passes)
+        chunks = min(256, (rows + 255) // 256)
+        partial = torch.empty((chunks, Cn), dtype=torch.float32, device=a.device)
+        _lib.check(_lib.lib().af_colsum_tall(_p(a), _p(b), _p(partial), _p(out), rows, Cn, chunks, int(accumulate), _stream()), "af_colsum_tall")
+        return out
     _lib.check(_lib.lib().af_colsum(_p(a), _p(b), _p(out), rows, Cn, int(accumulate), _stream()), "af_colsum")
     return out
 

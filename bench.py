@@ -85,8 +85,10 @@ def main_train(args):
     for p in ldm.model.diffusion_model.parameters():
         p.requires_grad_(False)
     ldm.unet_teacher = Arc2FaceTeacher(teacher.to(dev))
+    if not args.no_ffn_lora:
+        ldm.model.set_up_ffn_loras()         # rank-192 DoRA on up_blocks.3 convs; 'unet_distill' is always on in Stage 1 (ddpm.py:3130-3134)
     tr = DistillTrainer(ldm, id2ada.to(dev), text_enc.to(dev), batch_size=B, accumulate_grad_batches=2)
-    n_train = tr.arena.numel
+    n_train = sum(a.numel for a in tr.arenas)
 
     def batch(i):
         seed = 42 + i + rank * 10 ** 8
@@ -153,6 +155,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-ffn-lora", action="store_true", help="train mode: without the U-Net's trainable FFN DoRA adapters")
     ap.add_argument("--mode", choices=["denoise", "train"], default="denoise",
                     help="denoise: BASELINE configs[1] (the headline metric, default); train: configs[2]/[3], the Stage-1 "
                          "distillation micro-batch (fwd + bwd + overlapped RCCL gradient exchange + CAdamW every 2nd)")

@@ -223,6 +223,9 @@ int af_cadamw_step(void* p, const void* g, void* m, void* v, const void* seg_off
  * out fp32 [C] (+)= sum_rows a[r,c] * (b ? b[r,c] : 1): bias gradients (b = NULL) and LayerNorm gamma gradients
  * (a = dy, b = x_hat).  accumulate != 0 adds to `out`.                                                      */
 int af_colsum(const void* a, const void* b, void* out, int rows, int C, int accumulate, void* stream);
+/* same for tall inputs (rows >> C): `chunks` row ranges are folded by separate workgroups into partial (fp32 [chunks, C],
+ * caller-owned) and then reduced in a fixed order -- deterministic, no atomics */
+int af_colsum_tall(const void* a, const void* b, void* partial, void* out, int rows, int C, int chunks, int accumulate, void* stream);
 /* quick-GELU x*sigmoid(1.702x) (CLIP MLP) and its input gradient, fp16 element-wise */
 int af_quickgelu_fwd(const void* x, void* y, int64_t n, void* stream);
 int af_quickgelu_bwd(const void* x, const void* dy, void* dx, int64_t n, void* stream);

@@ -117,16 +117,28 @@ def spatial_transformer(sd, p, x, context, mask, heads, capture=None):
     return y + x_in
 
 
-def res_block(sd, p, x, emb):
-    """ResBlock._forward, openaimodel.py:256-276 (no up/down, no scale-shift)."""
+def res_block(sd, p, x, emb, lora=None):
+    """ResBlock._forward, openaimodel.py:256-276 (no up/down, no scale-shift).  lora: optional {"conv1" | "conv2" |
+    "conv_shortcut": (lora_A, lora_B, magnitude, scaling, mask | None)} -- DoRA adapters on the block's convolutions as the live
+    path attaches them (oracle/lora_oracle.py::dora_conv2d_train; diffusers_attn_lora_capture.py:541-591)."""
+    from . import lora_oracle as LO
+    lora = lora or {}
+
+    def conv(h, wname, key, padding=1):
+        w, b = sd[p + wname + ".weight"], sd[p + wname + ".bias"]
+        if key in lora:
+            A, Bm, m, scaling, mask = lora[key]
+            return LO.dora_conv2d_train(h, w, b, A, Bm, m, scaling, mask, 1, padding)
+        return conv2d(h, w, b, padding=padding)
+
     h = group_norm(x, sd[p + "in_layers.0.weight"], sd[p + "in_layers.0.bias"], 1e-5, silu=True)
-    h = conv2d(h, sd[p + "in_layers.2.weight"], sd[p + "in_layers.2.bias"])
+    h = conv(h, "in_layers.2", "conv1")
     e = F.linear(F.silu(emb), sd[p + "emb_layers.1.weight"], sd[p + "emb_layers.1.bias"])
     h = h + e[:, :, None, None]
     h = group_norm(h, sd[p + "out_layers.0.weight"], sd[p + "out_layers.0.bias"], 1e-5, silu=True)
-    h = conv2d(h, sd[p + "out_layers.3.weight"], sd[p + "out_layers.3.bias"])
+    h = conv(h, "out_layers.3", "conv2")
     if (p + "skip_connection.weight") in sd:
-        x = conv2d(x, sd[p + "skip_connection.weight"], sd[p + "skip_connection.bias"], padding=0)
+        x = conv(x, "skip_connection", "conv_shortcut", padding=0)
     return x + h
 
 
@@ -194,7 +206,7 @@ def unet_forward(sd, cfg, x, timesteps, context, extra_info=None):
             if kind == "conv_in":
                 h = conv2d(h, sd[p + "weight"], sd[p + "bias"])
             elif kind == "res":
-                h = res_block(sd, p, h, emb)
+                h = res_block(sd, p, h, emb, (extra_info.get("ffn_lora") or {}).get(p))
             elif kind == "attn":
                 cap = {} if (capture_on and layer_idx in CAPTURED_LAYERS) else None
                 h = spatial_transformer(sd, p, h, context, img_mask, heads, cap)

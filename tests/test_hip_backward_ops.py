@@ -227,3 +227,19 @@ def test_dora_conv_forward_backward_vs_oracle_autograd(dev, k, cin, cout, r):
                             ad.lora_magnitude_vector.detach().cpu(), 16 / r)
     ref_eval = F.conv2d(xh.float().cpu().permute(0, 3, 1, 2), wm, conv.bias.detach().float().cpu(), 1, k // 2)
     assert rel_l2(y_eval.float().cpu().permute(0, 3, 1, 2).numpy(), ref_eval.numpy()) < tol
+
+
+@pytest.mark.parametrize("rows,C", [(300, 72), (5000, 72), (24576, 320), (70000, 8)])
+def test_colsum_small_and_tall_vs_torch(dev, rows, C):
+    """Column sums (bias / LayerNorm gamma / DoRA magnitude gradients): the single-workgroup-per-64-columns form and the tall
+    two-pass form (rows >= 2048), with and without the element-wise second operand and accumulation."""
+    from adaface_dev_amd import ops
+    g = torch.Generator().manual_seed(rows)
+    a = torch.randn(rows, C, generator=g).half()
+    b = torch.randn(rows, C, generator=g).half()
+    out = ops.colsum(a.to(dev))
+    assert rel_l2(out.cpu().numpy(), a.float().sum(0).numpy()) < 1e-4 + 2e-3 * (rows > 20000)
+    acc = torch.ones(C, device=dev)
+    ops.colsum(a.to(dev), b.to(dev), out=acc, accumulate=True)
+    assert rel_l2(acc.cpu().numpy(), (1.0 + (a.float() * b.float()).sum(0)).numpy()) < 1e-4
+    assert torch.equal(ops.colsum(a.to(dev), b.to(dev)), ops.colsum(a.to(dev), b.to(dev)))       # deterministic

@@ -88,7 +88,7 @@ def test_unet_distill_loss_and_context_grad_vs_oracle(dev, steps):
     assert el < 5e-3 and eg < 1e-2
 
 
-def _oracle_distill(sds, ucfg, ids512, x0, noise, t, fg, steps, pres, sbg_sd=None):
+def _oracle_distill(sds, ucfg, ids512, x0, noise, t, fg, steps, pres, sbg_sd=None, ffn_lora=None):
     from adaface_dev_amd.adaface.subj_basis_generator import template_ids
     from oracle import clip_oracle as CO
     from oracle import diffusion_oracle as D
@@ -109,7 +109,7 @@ def _oracle_distill(sds, ucfg, ids512, x0, noise, t, fg, steps, pres, sbg_sd=Non
     ctx = CO.clip_text_forward(sds["text"], cc, pid, tok)[0]
     tctx = torch.cat([prefix.repeat(B, 1, 1), id2img], dim=1)
     tabs = D.register_schedule(D.make_beta_schedule_linear())
-    loss = 8 * T.unet_distill_loss(lambda x, tt, c: O.unet_forward(sds["student"], ucfg, x, tt, c, {"res_hidden_states_gradscale": 0.5}),
+    loss = 8 * T.unet_distill_loss(lambda x, tt, c: O.unet_forward(sds["student"], ucfg, x, tt, c, {"res_hidden_states_gradscale": 0.5, "ffn_lora": ffn_lora}),
                                    lambda x, tt, c: O.unet_forward(sds["teacher"], ucfg, x, tt, c, {}),
                                    tabs, x0, noise, t, ctx, tctx, fg, steps, pres)
     return loss, sbg, lw
@@ -212,3 +212,129 @@ def test_data_parallel_step_two_ranks_equals_accumulated_single_process(dev, tmp
     same = ((got["flat_p"] - got["p0"]).sign() == (ref - got["p0"]).sign()).float().mean()
     assert same > 0.999, float(same)
     assert rel_l2(got["mean_grad"].numpy(), got["mean_grad_expected_from_rank_sums"].numpy()) < 1e-5
+
+
+def test_unet_ffn_dora_training_gradients_vs_oracle(dev):
+    """Stage-1 student pass with the `unet_distill` FFN DoRA adapters ON (ddpm.py:3130-3134): eps, d/dcontext and the gradients
+    of all 18 adapter tensors (A, B, magnitude of conv1 / conv2 / conv_shortcut of the last two output blocks) against autograd
+    through the CPU oracle with the same adapters and the same dropout masks."""
+    from adaface_dev_amd import rng
+    from adaface_dev_amd.ldm.models.diffusion.ddpm import LatentDiffusion
+    from adaface_dev_amd.ldm.modules import dora as DR
+    from oracle import unet_oracle as O
+    ld = LatentDiffusion(CFG)
+    rng.load_synth_weights(ld.model.diffusion_model, seed=11)
+    sd = {k: v.detach().clone() for k, v in ld.model.diffusion_model.state_dict().items()}
+    ld = ld.to(dev)
+    lora = ld.model.set_up_ffn_loras(lora_rank=16, lora_dropout=0.1)
+    with torch.no_grad():
+        for n, p in lora.named_parameters():
+            if "lora_B" in n:
+                p.copy_(rng.synth_input(n, p.shape, seed=81, scale=0.3))
+            elif "magnitude" in n:
+                p.mul_(1.0 + 0.2 * rng.synth_input(n, p.shape, seed=81).abs().to(dev))
+    lora.train()
+    B = 2
+    x = rng.synth_input("t64.x", (B, 4, 32, 32), seed=11)
+    ctx = rng.synth_input("t64.ctx", (B, 77, 64), seed=11)
+    cot = rng.synth_input("t64.cot", (B, 4, 32, 32), seed=11)
+    t = torch.tensor([10, 500])
+    # fixed dropout masks shared with the oracle: patch draw_mask of every active adapter
+    masks = {}
+    act = lora.active("unet_distill")
+    for bi, ads in act.items():
+        for key, ad in ads.items():
+            def draw(shape, device, generator=None, _k=(bi, key)):
+                g = torch.Generator().manual_seed(hash(_k) % 1000)
+                m = ((torch.rand(shape, generator=g) >= 0.1).float() / 0.9).half()
+                masks[_k] = m
+                return m.to(device)
+            ad.draw_mask = draw
+    cg = ctx.clone().to(dev).requires_grad_(True)
+    eps = ld.apply_model(x.to(dev), t.to(dev), (cg, ["a"] * B, {}), use_ffn_lora=True, ffn_lora_adapter_name="unet_distill")
+    (eps * cot.to(dev)).sum().backward()
+    # oracle
+    P = {}
+    ffn = {}
+    for bi, ads in act.items():
+        pre = f"output_blocks.{bi}.0."
+        ffn[pre] = {}
+        for key, ad in ads.items():
+            A, Bm, m = (getattr(ad, n).detach().float().cpu().requires_grad_(True) for n in ("lora_A", "lora_B", "lora_magnitude_vector"))
+            P[(bi, key)] = (A, Bm, m)
+            ffn[pre][key] = (A, Bm, m, ad.scaling, masks[(bi, key)].float().permute(0, 3, 1, 2))
+    cr = ctx.clone().requires_grad_(True)
+    ref = O.unet_forward(sd, CFG, x, t, cr, {"ffn_lora": ffn, "res_hidden_states_gradscale": 1})
+    (ref * cot).sum().backward()
+    assert rel_l2(eps.detach().cpu().numpy(), ref.detach().numpy()) < 5e-3
+    assert rel_l2(cg.grad.cpu().numpy(), cr.grad.numpy()) < 2e-2
+    worst = 0.0
+    for (bi, key), (A, Bm, m) in P.items():
+        ad = act[bi][key]
+        for got, want, nm in ((ad.lora_A.grad, A.grad, "A"), (ad.lora_B.grad, Bm.grad, "B"), (ad.lora_magnitude_vector.grad, m.grad, "m")):
+            assert got is not None, (bi, key, nm)
+            e = rel_l2(got.cpu().numpy(), want.numpy())
+            worst = max(worst, e)
+            assert e < 2e-2, (bi, key, nm, e)
+    print(f"FFN DoRA: eps {rel_l2(eps.detach().cpu().numpy(), ref.detach().numpy()):.2e}; worst adapter-gradient rel-L2 over {3 * len(P)} tensors {worst:.2e}")
+    # inactive adapters received nothing; inference with the module-held adapters goes through the merged weights
+    assert all(p.grad is None for p in lora.adapters["recon_loss"].parameters())
+    lora.eval()
+    with torch.no_grad():
+        e_merge = ld.apply_model(x.to(dev), t.to(dev), (ctx.to(dev), ["a"] * B, {}), use_ffn_lora=True, ffn_lora_adapter_name="unet_distill")
+        e_base = ld.apply_model(x.to(dev), t.to(dev), (ctx.to(dev), ["a"] * B, {}))
+    ffn_eval = {pre: {k: v[:4] + (None,) for k, v in d.items()} for pre, d in ffn.items()}
+    with torch.no_grad():
+        ref_eval = O.unet_forward(sd, CFG, x, t, ctx, {"ffn_lora": ffn_eval})
+    assert rel_l2(e_merge.cpu().numpy(), ref_eval.numpy()) < 5e-3 and rel_l2(e_base.cpu().numpy(), ref_eval.numpy()) > 1e-2
+
+
+def test_distill_trainer_with_ffn_dora_param_group(dev):
+    """The Stage-1 micro-batch with the U-Net's `unet_distill` FFN DoRA adapters trainable next to the SubjBasisGenerator (two
+    parameter groups / arenas, the adapters' with weight decay 0.02): loss and the adapter gradients against the oracle, then one
+    accumulated optimizer step moves both groups and leaves the inactive adapters alone."""
+    from adaface_dev_amd import rng
+    tr, sds, ucfg = trainer_setup(dev, accum=2, ffn_lora=True)
+    assert len(tr.arenas) == 2 and tr.optimizer.param_groups[1]["weight_decay"] == 0.02
+    lora = tr.ffn_lora
+    BS, steps = 4, 2
+    ids512 = rng.synth_input("tr.ids", (BS, 512), seed=46)
+    x0 = rng.synth_input("tr.x0", (BS, 4, 32, 32), seed=46)
+    noise = rng.synth_input("tr.noise", (BS, 4, 32, 32), seed=46)
+    fg = (rng.synth_input("tr.fg", (BS, 1, 32, 32), seed=46) > -0.3).float()
+    t = torch.tensor([760, 850])
+    pres = [(torch.rand(2, generator=torch.Generator().manual_seed(3)), rng.synth_input("tr.n1", (2, 4, 32, 32), seed=46))]
+    batch = dict(x_start=x0.to(dev), face_id_embs=ids512.to(dev), fg_mask=fg.to(dev), noise=noise.to(dev))
+    tr.optimizer.zero_grad()
+    loss = tr.shared_step(batch, num_unet_denoising_steps=steps, t=t.to(dev), presampled=[(r.to(dev), n.to(dev)) for r, n in pres])
+    S = tr.scaler.scale
+    (loss * S).backward()
+    act = lora.active("unet_distill")
+    P, ffn = {}, {}
+    for bi, ads in act.items():
+        pre = f"output_blocks.{bi}.0."
+        ffn[pre] = {}
+        for key, ad in ads.items():
+            A, Bm, m = (getattr(ad, n).detach().float().cpu().requires_grad_(True) for n in ("lora_A", "lora_B", "lora_magnitude_vector"))
+            P[(bi, key)] = (A, Bm, m)
+            ffn[pre][key] = (A, Bm, m, ad.scaling, None)
+    ref, _, _ = _oracle_distill(sds, ucfg, ids512[:2], x0[:2], noise[:2], t, fg[:2], steps, pres, ffn_lora=ffn)
+    ref.backward()
+    assert abs(float(loss) - float(ref)) / abs(float(ref)) < 5e-3
+    worst = 0.0
+    for (bi, key), (A, Bm, m) in P.items():
+        ad = act[bi][key]
+        for got, want in ((ad.lora_A.grad, A.grad), (ad.lora_B.grad, Bm.grad), (ad.lora_magnitude_vector.grad, m.grad)):
+            e = rel_l2((got / S).cpu().numpy(), want.numpy())
+            worst = max(worst, e)
+            assert e < 3e-2, (bi, key, e)
+    print(f"trainer with FFN DoRA: loss {float(loss):.5f} vs {float(ref):.5f}; worst adapter-gradient rel-L2 {worst:.2e}")
+    # one accumulated optimizer step
+    tr.optimizer.zero_grad()
+    p_sbg, p_lora = tr.arenas[0].flat_p.clone(), tr.arenas[1].flat_p.clone()
+    other = [p.detach().clone() for p in lora.adapters["recon_loss"].parameters()]
+    for i in range(2):
+        tr.training_step(batch, i, num_unet_denoising_steps=steps, t=t.to(dev), presampled=[(r.to(dev), n.to(dev)) for r, n in pres])
+    assert tr.global_step == 1 and tr.skipped_steps == 0
+    assert float((tr.arenas[0].flat_p - p_sbg).abs().max()) > 0 and float((tr.arenas[1].flat_p - p_lora).abs().max()) > 0
+    assert all(torch.equal(a, b.detach()) for a, b in zip(other, lora.adapters["recon_loss"].parameters()))

@@ -5,7 +5,7 @@ CFG = dict(in_channels=4, model_channels=64, out_channels=4, num_res_blocks=2, a
            channel_mult=[1, 2, 4, 4], num_heads=8, use_spatial_transformer=True, transformer_depth=1, context_dim=64, legacy=False)
 
 
-def trainer_setup(dev, accum=1, process_group=None):
+def trainer_setup(dev, accum=1, process_group=None, ffn_lora=False):
     """Reduced-width replica of the whole Stage-1 stack: CLIP encoders hidden 128 / 3 layers, U-Nets model_channels 64."""
     from adaface_dev_amd import rng
     from adaface_dev_amd.adaface.arc2face_models import CLIPTextModelWrapper, clip_text_config
@@ -31,6 +31,12 @@ def trainer_setup(dev, accum=1, process_group=None):
     sds = {k: {n: v.detach().clone() for n, v in sd.items()} for k, sd in sds.items()}
     ld = ld.to(dev)
     ld.unet_teacher = Arc2FaceTeacher(teacher_unet.to(dev))
+    if ffn_lora:
+        lora = ld.model.set_up_ffn_loras(lora_rank=16, lora_dropout=0.0)
+        with torch.no_grad():
+            for n, p in lora.named_parameters():
+                if "lora_B" in n:
+                    p.copy_(rng.synth_input(n, p.shape, seed=82, scale=0.3))
     tr = DistillTrainer(ld, id2ada.to(dev), text_enc.to(dev), accumulate_grad_batches=accum, warm_up_steps=0,
                         loss_scaler=LossScaler(init_scale=2.0 ** 10), process_group=process_group)
     return tr, sds, ucfg
