@@ -109,6 +109,7 @@ def main():
         for p in ldm.model.diffusion_model.parameters():
             p.requires_grad_(False)
         ldm.unet_teacher = Arc2FaceTeacher(unet)                      # shapes only: the teacher can share the tuned U-Net
+        ldm.model.set_up_ffn_loras()                                  # the FFN DoRA adapters' GEMM shapes as well
         tr = DistillTrainer(ldm, id2ada.to(dev), text_enc.to(dev), batch_size=4, accumulate_grad_batches=2)
         for i in range(4):
             b = dict(x_start=rng.synth_input("tb.x", (4, 4, 64, 64), seed=5).to(dev),
