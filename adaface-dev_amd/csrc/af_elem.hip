@@ -20,6 +20,52 @@ __global__ void temb_kernel(const int64_t* __restrict__ t, half_t* __restrict__ 
   out[idx] = (half_t)v;
 }
 
+// row softmax of an explicit fp16 score matrix (the VAE decoder's single-head 512-dim attention, model.py:179-189, runs as
+// GEMM -> softmax -> GEMM: its head dim is beyond the flash kernel's register budget and it is one layer at N = 4096).
+// One wave per row, 16-byte accesses; rows up to 64 x 8 x RS elements are held in registers between the passes.
+template <int RS>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const half_t* __restrict__ x, half_t* __restrict__ y, long rows, int L) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const half_t* xr = x + row * L;
+  half8_t v[RS];
+  float mx = -3.0e38f;
+#pragma unroll
+  for (int j = 0; j < RS; ++j) {
+    const int c = (lane + 64 * j) * 8;
+    if (c < L) {
+      v[j] = *reinterpret_cast<const half8_t*>(xr + c);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) mx = fmaxf(mx, (float)v[j][e]);
+    }
+  }
+  mx = af_wave_max(mx);
+  float sum = 0.f;
+  float p[RS][8];
+#pragma unroll
+  for (int j = 0; j < RS; ++j) {
+    const int c = (lane + 64 * j) * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      p[j][e] = c < L ? __expf((float)v[j][e] - mx) : 0.f;
+      sum += p[j][e];
+    }
+  }
+  const float inv = 1.0f / af_wave_sum(sum);
+  half_t* yr = y + row * L;
+#pragma unroll
+  for (int j = 0; j < RS; ++j) {
+    const int c = (lane + 64 * j) * 8;
+    if (c < L) {
+      half8_t o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (half_t)(p[j][e] * inv);
+      *reinterpret_cast<half8_t*>(yr + c) = o;
+    }
+  }
+}
+
 __global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, half_t* __restrict__ y, int B, int C, int HW, int cpad) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long n = (long)B * HW * cpad;
@@ -121,6 +167,19 @@ extern "C" int af_q_sample(const void* x0, const void* noise, const void* sa, co
   hipLaunchKernelGGL(q_sample_kernel, grid1d((long)B * per), dim3(256), 0, (hipStream_t)stream, (const float*)x0,
                      (const float*)noise, (const float*)sa, (const float*)sb, (float*)xt, B, (long)per);
   return af_check_launch("af_q_sample");
+}
+
+extern "C" int af_softmax_rows(const void* x, void* y, int64_t rows, int L, void* stream) {
+  AF_REQUIRE(x && y && rows > 0 && L > 0 && L % 8 == 0, "af_softmax_rows: L must be a positive multiple of 8");
+  AF_SUPPORTED(L <= 64 * 8 * 8, "af_softmax_rows: L > 4096");
+  AfLaunchScope scope(AF_FAM_ELEM, stream);
+  dim3 grid((unsigned)((rows + 3) / 4)), blk(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (L <= 512) hipLaunchKernelGGL(softmax_rows_kernel<1>, grid, blk, 0, s, (const half_t*)x, (half_t*)y, (long)rows, L);
+  else if (L <= 1024) hipLaunchKernelGGL(softmax_rows_kernel<2>, grid, blk, 0, s, (const half_t*)x, (half_t*)y, (long)rows, L);
+  else if (L <= 2048) hipLaunchKernelGGL(softmax_rows_kernel<4>, grid, blk, 0, s, (const half_t*)x, (half_t*)y, (long)rows, L);
+  else hipLaunchKernelGGL(softmax_rows_kernel<8>, grid, blk, 0, s, (const half_t*)x, (half_t*)y, (long)rows, L);
+  return af_check_launch("af_softmax_rows");
 }
 
 extern "C" int af_silu_f16(const void* x, void* y, int64_t n, void* stream) {

@@ -129,6 +129,8 @@ class LatentDiffusion(nn.Module):
         self.parameterization = parameterization
         self.model = UNetWrapper(unet_config)
         self.uncond_context = None   # (uncond_emb [1,L,768], [""], {}) when guided_denoise runs with cfg_scale > 1
+        self.first_stage_model = None   # AutoencoderKLDecoder (instantiate_first_stage); VAE scale factor of SD-1.5:
+        self.scale_factor = 0.18215
         self.unet_teacher = None     # adaface.unet_teachers.UNetTeacher (frozen)
         self.register_schedule(beta_schedule=beta_schedule, timesteps=timesteps, linear_start=linear_start,
                                linear_end=linear_end, cosine_s=cosine_s)
@@ -161,6 +163,21 @@ class LatentDiffusion(nn.Module):
         reg("posterior_log_variance_clipped", np.log(np.maximum(posterior_variance, 1e-20)))
         reg("posterior_mean_coef1", betas * np.sqrt(alphas_cumprod_prev) / (1.0 - alphas_cumprod))
         reg("posterior_mean_coef2", (1.0 - alphas_cumprod_prev) * np.sqrt(alphas) / (1.0 - alphas_cumprod))
+
+    def instantiate_first_stage(self, ddconfig=None, embed_dim=4):
+        """The decoder half of the first-stage VAE (reference instantiate_first_stage ddpm.py:698-704; frozen, eval)."""
+        from ...modules.diffusionmodules.model import AutoencoderKLDecoder
+        self.first_stage_model = AutoencoderKLDecoder(ddconfig, embed_dim).eval()
+        for p in self.first_stage_model.parameters():
+            p.requires_grad_(False)
+        return self.first_stage_model
+
+    @torch.no_grad()
+    def decode_first_stage(self, z):
+        """latent -> image, roughly [-1, 1] (reference ddpm.py:889-896: z / scaling_factor, then vae.decode)."""
+        if self.first_stage_model is None:
+            raise RuntimeError("no first-stage decoder: call instantiate_first_stage() and load its weights")
+        return self.first_stage_model.decode(z / self.scale_factor)
 
     def q_sample(self, x_start, t, noise=None):
         noise = torch.randn_like(x_start) if noise is None else noise

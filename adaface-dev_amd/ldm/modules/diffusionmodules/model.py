@@ -1,0 +1,218 @@
+"""Host-side mirror of the decoder half of the reference's ``ldm/modules/diffusionmodules/model.py`` -- the SD-1.5 KL-f8 VAE decoder
+that turns the denoised latent into the image (BASELINE configs[1] ends with it): ``Normalize`` (:39-40),
+``Upsample`` (:43-58), ``ResnetBlock`` (:83-142), ``AttnBlock`` (:151-243, the mask-free branch), ``Decoder`` (:502-608), plus the
+``post_quant_conv`` + decoder wrapper of ``ldm/models/autoencoder.py:29,56-59``.  Same module tree and parameter names
+(``decoder.conv_in``, ``decoder.mid.block_1.norm1``, ``decoder.mid.attn_1.q``, ``decoder.up.3.block.0.conv1``,
+``decoder.up.1.upsample.conv``, ``decoder.norm_out``, ``decoder.conv_out``, ``post_quant_conv``) so ``first_stage_model.*`` checkpoint
+keys load with ``load_state_dict``.
+
+Execution is NHWC fp16 through the C ABI, with the kernels the U-Net already uses: GroupNorm(32, eps 1e-6)+swish fused, 3x3 convs as
+implicit GEMM (the nearest x2 upsample folded into the following conv's gather, the residual / 1x1 ``nin_shortcut`` in the epilogue), and
+the one attention layer (single head, 512 channels, 4096 tokens at 512x512) as  q.k^T GEMM -> ``af_softmax_rows`` -> P.v GEMM per
+image: its head dim is beyond the flash kernel's register budget and the layer is ~2 % of the decoder.  Inference only (the reference
+decodes under no_grad: ddpm.py:889-896); the encoder half / masked attention (training-time image encoding) is not built."""
+import torch
+import torch.nn as nn
+
+from .... import ops
+from ....ops import F16
+from .util import Conv2d, GroupNorm32, _require_cuda, from_nhwc_f16, to_nhwc_f16
+
+
+def Normalize(in_channels, num_groups=32):
+    return GroupNorm32(num_groups, in_channels, eps=1e-6, affine=True)
+
+
+class Upsample(nn.Module):
+    def __init__(self, in_channels, with_conv):
+        super().__init__()
+        self.with_conv = with_conv
+        if not with_conv:
+            raise NotImplementedError("Upsample without conv is not used by the SD VAE")
+        self.conv = Conv2d(in_channels, in_channels, kernel_size=3, stride=1, padding=1)
+
+    def hip(self, x):
+        return self.conv.hip(x, upsample=True)
+
+
+class ResnetBlock(nn.Module):
+    def __init__(self, *, in_channels, out_channels=None, conv_shortcut=False, dropout=0.0, temb_channels=512):
+        super().__init__()
+        if temb_channels > 0 or dropout != 0:
+            raise NotImplementedError("the VAE's ResnetBlocks have no time embedding and no dropout")
+        out_channels = in_channels if out_channels is None else out_channels
+        self.in_channels, self.out_channels, self.use_conv_shortcut = in_channels, out_channels, conv_shortcut
+        self.norm1 = Normalize(in_channels)
+        self.conv1 = Conv2d(in_channels, out_channels, kernel_size=3, stride=1, padding=1)
+        self.norm2 = Normalize(out_channels)
+        self.dropout = nn.Dropout(dropout)
+        self.conv2 = Conv2d(out_channels, out_channels, kernel_size=3, stride=1, padding=1)
+        if in_channels != out_channels:
+            if conv_shortcut:
+                self.conv_shortcut = Conv2d(in_channels, out_channels, kernel_size=3, stride=1, padding=1)
+            else:
+                self.nin_shortcut = Conv2d(in_channels, out_channels, kernel_size=1, stride=1, padding=0)
+
+    def hip(self, x):
+        h = self.conv1.hip(self.norm1.hip(x, silu=True))
+        h = self.norm2.hip(h, silu=True)
+        if self.in_channels != self.out_channels:
+            x = self.conv_shortcut.hip(x) if self.use_conv_shortcut else self.nin_shortcut.hip(x)
+        return self.conv2.hip(h, residual=x)
+
+
+class AttnBlock(nn.Module):
+    def __init__(self, in_channels):
+        super().__init__()
+        self.in_channels = in_channels
+        self.norm = Normalize(in_channels)
+        self.q = Conv2d(in_channels, in_channels, kernel_size=1, stride=1, padding=0)
+        self.k = Conv2d(in_channels, in_channels, kernel_size=1, stride=1, padding=0)
+        self.v = Conv2d(in_channels, in_channels, kernel_size=1, stride=1, padding=0)
+        self.proj_out = Conv2d(in_channels, in_channels, kernel_size=1, stride=1, padding=0)
+        self._qs_key, self._qs = None, None
+
+    def _q_scaled_pack(self):
+        """q projection with the c^-0.5 score scale folded in (model.py:187)."""
+        key = (self.q.weight._version, self.q.bias._version, self.q.weight.data_ptr())
+        if key != self._qs_key:
+            sc = float(self.in_channels) ** -0.5
+            self._qs = ops.pack_matrix(self.q.weight.detach().float().reshape(self.in_channels, -1) * sc, self.q.bias.detach().float() * sc,
+                                       self.q.weight.device)
+            self._qs_key = key
+        return self._qs
+
+    def hip(self, x):
+        B, H, W, C = x.shape
+        N = H * W
+        if N % 8 != 0 or N > 4096:
+            raise NotImplementedError(f"VAE attention over {N} tokens (af_softmax_rows holds rows up to 4096)")
+        hn = self.norm.hip(x).reshape(B * N, C)
+        q = ops.gemm(hn, self._q_scaled_pack())
+        k = ops.gemm(hn, self.k.packed())
+        v = ops.gemm(hn, self.v.packed())
+        vt = ops.transpose_tokens(v, B, N, C, C)                                  # [B, C, N]: the P.v GEMM's K-contiguous operand
+        kp, cp = ops.round_up(C, 64), ops.round_up(C, 128)
+        if kp != C or N % 128 != 0 or vt.shape[2] % 64 != 0 or cp != C:
+            raise NotImplementedError("VAE attention operands must already be tile aligned (C % 128 == 0, tokens % 128 == 0)")
+        out = torch.empty((B * N, C), dtype=F16, device=x.device)
+        for b in range(B):                                                        # one image at a time: [N, N] scores = 32 MB at 64x64
+            kb = ops.PackedWeight(k[b * N:(b + 1) * N], None, N, C, C, 1, C)      # keys as the "weight" [N, C], K-contiguous
+            p = ops.softmax_rows(ops.gemm(q[b * N:(b + 1) * N], kb))
+            vb = ops.PackedWeight(vt[b], None, C, N, N, 1, N)                     # V^T [C, N]
+            out[b * N:(b + 1) * N] = ops.gemm(p, vb)
+        y = ops.gemm(out, self.proj_out.packed(), residual=x.reshape(B * N, C))
+        return y.reshape(B, H, W, C)
+
+
+class Decoder(nn.Module):
+    def __init__(self, *, ch, out_ch, ch_mult=(1, 2, 4, 8), num_res_blocks, attn_resolutions, dropout=0.0, resamp_with_conv=True,
+                 in_channels, resolution, z_channels, give_pre_end=False, tanh_out=False, use_linear_attn=False, attn_type="vanilla",
+                 **ignorekwargs):
+        super().__init__()
+        if use_linear_attn or attn_type != "vanilla" or give_pre_end or tanh_out:
+            raise NotImplementedError("only the vanilla-attention SD VAE decoder is built")
+        self.ch, self.temb_ch = ch, 0
+        self.num_resolutions, self.num_res_blocks = len(ch_mult), num_res_blocks
+        self.resolution, self.in_channels, self.out_ch = resolution, in_channels, out_ch
+        block_in = ch * ch_mult[self.num_resolutions - 1]
+        curr_res = resolution // 2 ** (self.num_resolutions - 1)
+        self.z_shape = (1, z_channels, curr_res, curr_res)
+        self.conv_in = Conv2d(z_channels, block_in, kernel_size=3, stride=1, padding=1)
+        self.conv_in.cin_pad = ops.round_up(z_channels, 8)
+        self.mid = nn.Module()
+        self.mid.block_1 = ResnetBlock(in_channels=block_in, out_channels=block_in, temb_channels=0, dropout=dropout)
+        self.mid.attn_1 = AttnBlock(block_in)
+        self.mid.block_2 = ResnetBlock(in_channels=block_in, out_channels=block_in, temb_channels=0, dropout=dropout)
+        self.up = nn.ModuleList()
+        for i_level in reversed(range(self.num_resolutions)):
+            block, attn = nn.ModuleList(), nn.ModuleList()
+            block_out = ch * ch_mult[i_level]
+            for _ in range(num_res_blocks + 1):
+                block.append(ResnetBlock(in_channels=block_in, out_channels=block_out, temb_channels=0, dropout=dropout))
+                block_in = block_out
+                if curr_res in attn_resolutions:
+                    attn.append(AttnBlock(block_in))
+            up = nn.Module()
+            up.block, up.attn = block, attn
+            if i_level != 0:
+                up.upsample = Upsample(block_in, resamp_with_conv)
+                curr_res *= 2
+            self.up.insert(0, up)
+        self.norm_out = Normalize(block_in)
+        self.conv_out = Conv2d(block_in, out_ch, kernel_size=3, stride=1, padding=1)
+        self._out_key, self._out_pack = None, None
+
+    def _conv_out_pack(self):
+        """conv_out with its 3 output channels zero padded to 8 (the GEMM epilogue stores 8-byte groups)."""
+        c = self.conv_out
+        key = (c.weight._version, c.bias._version, c.weight.data_ptr())
+        if key != self._out_key:
+            n8 = ops.round_up(self.out_ch, 8)
+            w = torch.zeros((n8,) + tuple(c.weight.shape[1:]), device=c.weight.device)
+            b = torch.zeros((n8,), device=c.weight.device)
+            w[:self.out_ch], b[:self.out_ch] = c.weight.detach().float(), c.bias.detach().float()
+            self._out_pack = ops.pack_conv3x3(w, b, c.weight.device)
+            self._out_key = key
+        return self._out_pack
+
+    def hip(self, z):
+        """z [B, h, w, roundup(z_channels, 8)] fp16 -> [B, 8h, 8w, roundup(out_ch, 8)] fp16."""
+        h = self.conv_in.hip(z)
+        h = self.mid.block_1.hip(h)
+        h = self.mid.attn_1.hip(h)
+        h = self.mid.block_2.hip(h)
+        for i_level in reversed(range(self.num_resolutions)):
+            for i_block in range(self.num_res_blocks + 1):
+                h = self.up[i_level].block[i_block].hip(h)
+                if len(self.up[i_level].attn) > 0:
+                    h = self.up[i_level].attn[i_block].hip(h)
+            if i_level != 0:
+                h = self.up[i_level].upsample.hip(h)
+        h = self.norm_out.hip(h, silu=True)
+        return ops.conv3x3(h, self._conv_out_pack())
+
+    def forward(self, z):
+        _require_cuda(self.conv_in.weight, "VAE Decoder")
+        y = self.hip(to_nhwc_f16(z, ops.round_up(z.shape[1], 8)))
+        return from_nhwc_f16(y, z.dtype, self.out_ch)
+
+
+class AutoencoderKLDecoder(nn.Module):
+    """``first_stage_model`` restricted to what inference needs: ``decode(z) = decoder(post_quant_conv(z))``
+    (ldm/models/autoencoder.py:29, 56-59).  SD-1.5: embed_dim 4, ddconfig below."""
+
+    SD15_DDCONFIG = dict(double_z=True, z_channels=4, resolution=256, in_channels=3, out_ch=3, ch=128, ch_mult=(1, 2, 4, 4), num_res_blocks=2,
+                         attn_resolutions=[], dropout=0.0)
+
+    def __init__(self, ddconfig=None, embed_dim=4):
+        super().__init__()
+        ddconfig = dict(ddconfig or self.SD15_DDCONFIG)
+        ddconfig.pop("double_z", None)
+        self.decoder = Decoder(**ddconfig)
+        self.post_quant_conv = Conv2d(embed_dim, ddconfig["z_channels"], 1)
+        self.embed_dim = embed_dim
+        self._pq_key, self._pq = None, None
+
+    def _pq_pack(self):
+        """post_quant_conv on the channel-padded latent: [4 -> 4] embedded in an [8 -> 8] matrix."""
+        c = self.post_quant_conv
+        key = (c.weight._version, c.bias._version, c.weight.data_ptr())
+        if key != self._pq_key:
+            n8, k8 = ops.round_up(c.out_channels, 8), ops.round_up(c.in_channels, 8)
+            w = torch.zeros((n8, k8), device=c.weight.device)
+            b = torch.zeros((n8,), device=c.weight.device)
+            w[:c.out_channels, :c.in_channels] = c.weight.detach().float().reshape(c.out_channels, c.in_channels)
+            b[:c.out_channels] = c.bias.detach().float()
+            self._pq = ops.pack_matrix(w, b, c.weight.device)
+            self._pq_key = key
+        return self._pq
+
+    @torch.no_grad()
+    def decode(self, z):
+        """z [B, 4, h, w] (already divided by the 0.18215 scale factor) -> image [B, 3, 8h, 8w] in z.dtype, roughly [-1, 1]."""
+        _require_cuda(self.post_quant_conv.weight, "AutoencoderKLDecoder")
+        zh = to_nhwc_f16(z, ops.round_up(z.shape[1], 8))
+        B, H, W, c8 = zh.shape
+        zq = ops.gemm(zh.reshape(B * H * W, c8), self._pq_pack()).reshape(B, H, W, -1)
+        return from_nhwc_f16(self.decoder.hip(zq), z.dtype, self.decoder.out_ch)

@@ -506,6 +506,15 @@ def scale_f32_(a, s):
     return a
 
 
+def softmax_rows(x):
+    """Row softmax of an fp16 [rows, L] score matrix (fp32 inside)."""
+    _chk_f16(x, "softmax_rows.x")
+    rows, L = x.shape
+    y = torch.empty_like(x)
+    _lib.check(_lib.lib().af_softmax_rows(_p(x), _p(y), rows, L, _stream()), "af_softmax_rows")
+    return y
+
+
 # ----------------------------------------------------------------------------- trainable DoRA adapters
 def dora_combine(y0, c2, lb, u, v):
     """y0 + u[c] * c2 + v[c] * lb over the last (channel) axis; u, v fp32 [C]."""

@@ -232,6 +232,10 @@ int af_quickgelu_bwd(const void* x, const void* dy, void* dx, int64_t n, void* s
 /* y = a * s (fp32), used to unscale the loss-scaled gradient arena before the optimizer step */
 int af_scale_f32(void* a, float s, int64_t n, void* stream);
 
+/* ---- VAE decoder (ldm/modules/diffusionmodules/model.py:151-243 AttnBlock): row softmax of an explicit fp16 score matrix
+ * [rows, L], L % 8 == 0, L <= 4096 (single-head 512-dim attention runs as af_gemm -> af_softmax_rows -> af_gemm) */
+int af_softmax_rows(const void* x, void* y, int64_t rows, int L, void* stream);
+
 /* ---- ArcFace ResNetFace-18 IR-SE face encoder (reference evaluation/arcface_resnet.py:62-97, 139-154, 157-217) ----
  * NHWC fp16 activations, C % 8 == 0.  Convolutions / FCs are af_gemm calls with eval-mode BatchNorm folded on the host.
  * y = prelu(x * scale[c] + shift[c]); scale/shift fp32 [C] or both NULL; slope fp32 [1] device pointer or NULL (no PReLU) */

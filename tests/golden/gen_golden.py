@@ -388,6 +388,40 @@ def gen_arcface(out):
     print("arcface.npz", y.shape, float(y.abs().mean()))
 
 
+VAE_SMALL = dict(ch=32, out_ch=3, ch_mult=(1, 2, 4, 4), num_res_blocks=2, attn_resolutions=[], dropout=0.0, in_channels=3, resolution=128, z_channels=4)
+
+
+def gen_vae(out):
+    """The REFERENCE's VAE Decoder (ldm/modules/diffusionmodules/model.py:502-608) at reduced width (ch 32 -> 128 channels at the
+    latent level, 16x16 latent -> 128x128 image, 256-token mid attention): full output + the mid / first-up-level features, and the
+    full-size SD-1.5 decoder (ch 128, 64x64 latent -> 512x512) as probes + a 3x64x64 crop."""
+    from ldm.modules.diffusionmodules.model import Decoder
+    from adaface_dev_amd import rng
+    d = {}
+    for tag, cfg, zhw in (("small", VAE_SMALL, 16), ("full", dict(VAE_SMALL, ch=128, resolution=256), 64)):
+        m = Decoder(**cfg).eval()
+        with torch.no_grad():
+            for n, p in m.named_parameters():
+                p.copy_(rng.synth_tensor("decoder." + n, p.shape, seed=90))
+        z = rng.synth_input(f"vae.z.{tag}", (2 if tag == "small" else 1, 4, zhw, zhw), seed=90)
+        feats = {}
+        hooks = [m.mid.attn_1.register_forward_hook(lambda mod, i, o: feats.__setitem__("attn", o.detach())),
+                 m.up[3].register_forward_hook(lambda mod, i, o: None)]
+        with torch.no_grad():
+            y = m(z)
+        for h in hooks:
+            h.remove()
+        if tag == "small":
+            d["small_out"] = y.numpy()
+            d["small_attn"] = feats["attn"].numpy()
+        else:
+            d["full_probes"] = probes(y)
+            d["full_crop"] = y[0, :, 200:264, 300:364].numpy()
+            d["full_attn_probes"] = probes(feats["attn"])
+        print("vae", tag, tuple(y.shape), float(y.abs().mean()))
+    np.savez_compressed(os.path.join(out, "vae.npz"), **d)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-full", action="store_true")
@@ -396,7 +430,7 @@ def main():
     install_reference_stubs()
     torch.set_num_threads(8)
     out = HERE
-    jobs = {"blocks": gen_blocks, "schedule": gen_schedule, "train": gen_train, "clip": gen_clip, "arcface": gen_arcface, "unet_tiny": gen_unet_tiny, "unet_full": gen_unet_full}
+    jobs = {"blocks": gen_blocks, "schedule": gen_schedule, "train": gen_train, "clip": gen_clip, "arcface": gen_arcface, "vae": gen_vae, "unet_tiny": gen_unet_tiny, "unet_full": gen_unet_full}
     for name, fn in jobs.items():
         if args.only and name != args.only:
             continue
