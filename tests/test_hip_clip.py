@@ -192,3 +192,16 @@ def test_adaface_wrapper_end_to_end_reduced_width(dev):
     assert torch.equal(lat, man)
     lat2 = w(noise, None, prompt_embeds=(pe, ne), guidance_scale=4.0, out_image_count=3)
     assert torch.equal(lat, lat2)
+    # with a first-stage decoder attached the wrapper returns PIL images, like the reference pipeline (adaface_wrapper.py:800-809)
+    from adaface_dev_amd.ldm.modules.diffusionmodules.model import AutoencoderKLDecoder
+    vae = AutoencoderKLDecoder(dict(ch=32, out_ch=3, ch_mult=(1, 2, 4, 4), num_res_blocks=2, attn_resolutions=[], dropout=0.0, in_channels=3,
+                                    resolution=128, z_channels=4))
+    with torch.no_grad():
+        for n, p in vae.named_parameters():
+            p.copy_(rng.synth_tensor(n, p.shape, seed=64))
+    w.vae = vae.to(dev).eval()
+    imgs = w(noise, "portrait of a z, in a garden", guidance_scale=4.0, out_image_count=3)
+    assert len(imgs) == 3 and imgs[0].size == (128, 128) and imgs[0].mode == "RGB"
+    ref_img = w.vae.decode(lat / 0.18215)
+    a0 = ((ref_img[0].float() / 2 + 0.5).clamp(0, 1) * 255).round().to(torch.uint8).permute(1, 2, 0).cpu().numpy()
+    assert (np.asarray(imgs[0]) == a0).all()

@@ -8,7 +8,7 @@ adaface-dev_amd/tuning/gfx950_gemm.json.  Usage (GPU box):
 
     python tools/autotune_gemm.py [--batches 8,2] [--train] [--fresh]
 
---train additionally runs three Stage-1 distillation micro-batches (denoising steps 2, 3, 4: teacher batches 1-2, the
+--vae additionally runs the VAE decoder; --train additionally runs three Stage-1 distillation micro-batches (denoising steps 2, 3, 4: teacher batches 1-2, the
 batched student pass at 4-6 samples, the whole backward and the CLIP encoders' forward/dgrad/wgrad GEMMs) so the
 training shapes are tuned as well.  Existing entries are kept unless --fresh is given.
 """
@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--reps", type=int, default=12)
     ap.add_argument("--out", default=None)
     ap.add_argument("--train", action="store_true")
+    ap.add_argument("--vae", action="store_true", help="also tune the VAE decoder's shapes (batch 4 and 1, 64x64 latent)")
     ap.add_argument("--fresh", action="store_true", help="ignore the existing table instead of extending it")
     args = ap.parse_args()
     from adaface_dev_amd import SD15_UNET_CONFIG, _lib, ops, rng
@@ -115,6 +116,16 @@ def main():
             b = dict(x_start=rng.synth_input("tb.x", (4, 4, 64, 64), seed=5).to(dev),
                      face_id_embs=rng.synth_input("tb.id", (4, 512), seed=5).to(dev), fg_mask=torch.ones(4, 1, 64, 64, device=dev))
             tr.training_step(b, i)
+            torch.cuda.synchronize()
+    if args.vae:
+        from adaface_dev_amd.ldm.modules.diffusionmodules.model import AutoencoderKLDecoder
+        ae = AutoencoderKLDecoder()
+        with torch.no_grad():
+            for n, p in ae.named_parameters():
+                p.copy_(rng.synth_tensor(n, p.shape, seed=90))
+        ae = ae.to(dev).eval()
+        for b in (4, 1):
+            ae.decode(rng.synth_input("vae.bench", (b, 4, 64, 64), seed=1).to(dev))
             torch.cuda.synchronize()
     ops._tune_recorder = None
     out = args.out or ops._TUNE_PATH
