@@ -303,8 +303,8 @@ def test_latent_diffusion_apply_model_contract(dev):
 def test_unet_wrapper_ffn_lora_flags_merge_and_restore(dev):
     """apply_model(use_ffn_lora=True, ffn_lora_adapter_name=...) runs the U-Net with the DoRA adapters of the six
     up_blocks.3 conv layers merged in (adaface/lora.py; merged weight == peft's branch form is pinned on CPU in
-    tests/test_lora_host.py), switching the flag off restores the base weights bit-exactly, and training through adapters
-    is refused loudly."""
+    tests/test_lora_host.py), switching the flag off restores the base weights bit-exactly, and a training pass without trainable
+    adapter modules (or with attention LoRAs) is refused loudly."""
     from adaface_dev_amd import rng
     from adaface_dev_amd.adaface import lora as L
     from adaface_dev_amd.ldm.models.diffusion.ddpm import LatentDiffusion
@@ -341,6 +341,9 @@ def test_unet_wrapper_ffn_lora_flags_merge_and_restore(dev):
         assert torch.equal(lora_out, ref)
         again = ld.apply_model(x, t, (ctx, ["a"] * 2, {}))                                  # flags off -> base weights restored
         assert torch.equal(again, base)
+    # a TRAINING pass needs the trainable adapter modules (set_up_ffn_loras; covered in test_hip_train.py), not a merged state dict
     cg = ctx.clone().requires_grad_(True)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(RuntimeError, match="no trainable adapters"):
         ld.apply_model(x, t, (cg, ["a"] * 2, {}), use_ffn_lora=True, ffn_lora_adapter_name="unet_distill")
+    with pytest.raises(NotImplementedError):
+        ld.apply_model(x, t, (cg, ["a"] * 2, {}), use_attn_lora=True)
