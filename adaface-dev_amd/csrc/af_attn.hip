@@ -40,6 +40,7 @@ struct AttnArgs {
   int causal_m;  // > 0: key j is visible to query i iff j / causal_m <= i (CLIP causal mask, m keys per token)
   int B, Nq, L, heads, d;
   int ldq, ldk, ldo, ldv, ldb;
+  long vbs;  // elements between consecutive batch items of vt (heads*d*ldv when vt is its own [B, C, ldv] tensor)
   float c;  // scale * log2(e)
 };
 
@@ -80,7 +81,7 @@ __global__ __launch_bounds__(256) void af_attn_kernel(AttnArgs a) {
   if (bh >= a.B * a.heads) return;
   const int b = bh / a.heads, h = bh - b * a.heads;
   const int query = (idx % qblocks) * 128 + wave * 32 + r;
-  const int C = a.heads * a.d;
+
 
   // ---- Q fragments (B operand of S^T = K Q^T), pre-multiplied by scale*log2(e): lane (r, hh) holds
   //      Q[query][16 s + 8 hh .. +7]
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(256) void af_attn_kernel(AttnArgs a) {
     const int row = i >> 3, ch = i & 7;
     vok[j] = i < VCH && row < a.d;
     vones[j] = ONES && i < VCH && row == DV - 1;
-    vptr[j] = a.vt + ((size_t)b * C + h * a.d + (row < a.d ? row : 0)) * a.ldv + ch * 8;
+    vptr[j] = a.vt + (size_t)b * a.vbs + (size_t)(h * a.d + (row < a.d ? row : 0)) * a.ldv + ch * 8;
   }
   const half8_t ones8 = {1, 1, 1, 1, 1, 1, 1, 1};
   auto load_stage = [&](int key0) {
@@ -379,7 +380,7 @@ __global__ __launch_bounds__(256) void af_xattn_kernel(AttnArgs a, int groups_pe
   if (bh >= a.B * a.heads) return;
   const int chunk = idx % nchunk;
   const int b = bh / a.heads, h = bh - b * a.heads;
-  const int C = a.heads * a.d;
+
   const int nsub = (a.L + 31) >> 5;
   const half8_t zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 
@@ -415,7 +416,7 @@ __global__ __launch_bounds__(256) void af_xattn_kernel(AttnArgs a, int groups_pe
       const int i = tid + 256 * j;
       const int row = i >> 4, kk = (i & 15) * 8;
       rv[j] = (i < VCH && row < a.d && kk < a.L)
-                  ? *reinterpret_cast<const half8_t*>(a.vt + ((size_t)b * C + h * a.d + row) * a.ldv + kk) : zero8;
+                  ? *reinterpret_cast<const half8_t*>(a.vt + (size_t)b * a.vbs + (size_t)(h * a.d + row) * a.ldv + kk) : zero8;
     }
 #pragma unroll
     for (int j = 0; j < NKC; ++j) {
@@ -648,10 +649,22 @@ extern "C" int af_attention_lse(const void* q, const void* k, const void* vt, vo
   return af_attention_ex(q, k, vt, o, lse2, ld_lse, keybias, 0, B, Nq, L, heads, d, ldq, ldk, ldo, ldv, ldb, scale, stream);
 }
 
+extern "C" int af_attention_strided(const void* q, const void* k, const void* vt, void* o, void* lse2, int ld_lse, const void* keybias,
+                                    int causal_m, int B, int Nq, int L, int heads, int d, int ldq, int ldk, int ldo, int ldv, int ldb,
+                                    int64_t vt_batch_stride, float scale, void* stream);
+
 extern "C" int af_attention_ex(const void* q, const void* k, const void* vt, void* o, void* lse2, int ld_lse,
                                const void* keybias, int causal_m, int B, int Nq, int L, int heads, int d, int ldq, int ldk,
                                int ldo, int ldv, int ldb, float scale, void* stream) {
+  return af_attention_strided(q, k, vt, o, lse2, ld_lse, keybias, causal_m, B, Nq, L, heads, d, ldq, ldk, ldo, ldv, ldb,
+                              (int64_t)heads * d * ldv, scale, stream);
+}
+
+extern "C" int af_attention_strided(const void* q, const void* k, const void* vt, void* o, void* lse2, int ld_lse, const void* keybias,
+                                    int causal_m, int B, int Nq, int L, int heads, int d, int ldq, int ldk, int ldo, int ldv, int ldb,
+                                    int64_t vt_batch_stride, float scale, void* stream) {
   AF_REQUIRE(q && k && vt && o, "af_attention: null pointer");
+  AF_REQUIRE(vt_batch_stride >= (int64_t)heads * d * ldv && vt_batch_stride % 8 == 0, "af_attention: vt_batch_stride must cover heads*d rows of ldv and keep 16-byte alignment");
   AF_REQUIRE(B > 0 && Nq > 0 && L > 0 && heads > 0 && d > 0, "af_attention: bad sizes");
   AF_REQUIRE(d % 8 == 0, "af_attention: head dim must be a multiple of 8");
   AF_SUPPORTED(d <= 160, "af_attention: head dim > 160");
@@ -681,6 +694,7 @@ extern "C" int af_attention_ex(const void* q, const void* k, const void* vt, voi
   a.ldo = ldo;
   a.ldv = ldv;
   a.ldb = ldb;
+  a.vbs = vt_batch_stride;
   a.c = scale * 1.4426950408889634f;
   AfLaunchScope scope(L < Nq ? AF_FAM_XATTN : AF_FAM_ATTN, stream);
   hipStream_t s = (hipStream_t)stream;

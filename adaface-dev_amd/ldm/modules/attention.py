@@ -129,6 +129,7 @@ class CrossAttention(nn.Module):
         self.to_out = nn.Sequential(Linear(inner_dim, query_dim), nn.Dropout(dropout))
         self.save_cross_attn_vars = False
         self.cached_activations = None
+        self._kv_pre = None
         self._qkv_cache = _PackCache()
         self._kv_cache = _PackCache()
 
@@ -154,14 +155,17 @@ class CrossAttention(nn.Module):
         else:
             L = context.shape[1]
             q = self.to_q.hip(x2d)
-            k, vt = ops.gemm(context.reshape(B * L, context.shape[-1]), self._packed_kv(), rows_per_batch=L, split_col=Ci)
             ldq = ldk = Ci
+            if self._kv_pre is not None:                     # projected for all layers at once by UNetModel._project_context_all
+                k, vt, ldk = self._kv_pre
+            else:
+                k, vt = ops.gemm(context.reshape(B * L, context.shape[-1]), self._packed_kv(), rows_per_batch=L, split_col=Ci)
         o = ops.attention(q, k, vt, B=B, Nq=N, L=L, heads=h, d=d, ldq=ldq, ldk=ldk, keybias=keybias, scale=self.scale)
         if self.save_cross_attn_vars:
             # attention.py:207-220 -- explicit score / prob only on the (rare) capture path
             out_plain = self.to_out[0].hip(o)
             qc = q if context is not None else qk[:, :Ci].contiguous()
-            kc = k if context is not None else qk[:, Ci:].contiguous()
+            kc = k.contiguous() if context is not None else qk[:, Ci:].contiguous()
             score, prob = ops.attention_scores(qc, kc, B=B, Nq=N, L=L, heads=h, d=d, scale=self.scale)
             self.cached_activations = {
                 "q": (qc.reshape(B, N, Ci).permute(0, 2, 1).float() * math.sqrt(self.scale)).contiguous(),

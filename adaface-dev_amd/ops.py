@@ -276,8 +276,9 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, *, B: int, Nq:
     scale = d ** -0.5 if scale is None else scale
     ldb = 0 if keybias is None else keybias.stride(0)
     lse = torch.empty((B, heads, round_up(Nq, 32)), dtype=torch.float32, device=q.device) if want_lse else None
-    rc = _lib.lib().af_attention_ex(_p(q), _p(k), _p(vt), _p(o), _p(lse), 0 if lse is None else lse.stride(1), _p(keybias),
-                                    int(causal_m), B, Nq, L, heads, d, ldq, ldk, Cn, vt.stride(1), ldb, float(scale), _stream())
+    rc = _lib.lib().af_attention_strided(_p(q), _p(k), _p(vt), _p(o), _p(lse), 0 if lse is None else lse.stride(1), _p(keybias),
+                                         int(causal_m), B, Nq, L, heads, d, ldq, ldk, Cn, vt.stride(1), ldb, vt.stride(0), float(scale),
+                                         _stream())
     _lib.check(rc, "af_attention")
     return (o, lse) if want_lse else o
 

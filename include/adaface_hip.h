@@ -157,6 +157,11 @@ int af_attention_lse(const void* q, const void* k, const void* vt, void* o, void
 int af_attention_ex(const void* q, const void* k, const void* vt, void* o, void* lse2, int ld_lse, const void* keybias,
                     int causal_m, int B, int Nq, int L, int heads, int d, int ldq, int ldk, int ldo, int ldv, int ldb,
                     float scale, void* stream);
+/* same with an explicit element stride between the batch items of vt (>= heads*d*ldv): lets vt be a row slice of a larger
+ * [B, sum_C, ldv] tensor -- the U-Net computes the K / V^T projections of ALL its cross-attention layers in one GEMM */
+int af_attention_strided(const void* q, const void* k, const void* vt, void* o, void* lse2, int ld_lse, const void* keybias, int causal_m,
+                         int B, int Nq, int L, int heads, int d, int ldq, int ldk, int ldo, int ldv, int ldb, int64_t vt_batch_stride,
+                         float scale, void* stream);
 
 /* ---- attention backward (flash-style, recomputes P from q, k and lse2) -------------------
  * Input gradients of af_attention for dO = `dout`: dq [B,Nq,lddq], dk [B,L,lddk], dv [B,L,lddv].
