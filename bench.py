@@ -169,7 +169,8 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    launched = "RANK" in os.environ and "MASTER_PORT" in os.environ     # under torch.distributed.run (also with one rank)
+    if world > 1 or launched:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -222,7 +223,7 @@ def main():
         state["x"] = xp
 
     def barrier():
-        if world > 1:
+        if world > 1 or launched:
             import torch.distributed as dist
             dist.barrier()
 
@@ -236,7 +237,8 @@ def main():
             with torch.cuda.stream(s):
                 unet_eps()
             torch.cuda.current_stream().wait_stream(s)
-            with torch.cuda.graph(g):
+            # thread_local: with N > 1 the RCCL watchdog thread may touch the HIP runtime while this thread captures
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 state["eps"] = unet_eps()
             state["graph"] = g
         state["x"] = x.clone()
@@ -252,7 +254,7 @@ def main():
         elapsed = time.perf_counter() - t0
         finite = bool(torch.isfinite(state["x"]).all())
 
-    if world > 1:
+    if world > 1 or launched:
         import torch.distributed as dist
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -350,7 +352,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or launched:
         import torch.distributed as dist
         dist.destroy_process_group()
 
