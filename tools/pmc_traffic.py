@@ -7,7 +7,7 @@ import json
 import sqlite3
 import sys
 
-FAMILIES = (("gemm", ("af_gemm", "af_splitk_reduce")), ("attn", ("af_attn",)), ("gnorm", ("gn_partial", "gn_apply")),
+FAMILIES = (("gemm", ("af_gemm", "af_splitk_reduce")), ("attn", ("af_attn", "af_xattn")), ("gnorm", ("gn_partial", "gn_apply")),
             ("lnorm", ("layernorm_kernel",)))
 
 
