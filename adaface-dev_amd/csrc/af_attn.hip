@@ -356,6 +356,258 @@ __global__ __launch_bounds__(256) void af_attn_kernel(AttnArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Two-chain variant of the mask-free flash kernel (no key bias, no causal mask, L % 64 == 0: the U-Net's self-attention).
+// PMC (profiles/r01c, r01f): the one-chain kernel is VALU-issue bound at d = 40 and, inside a wave, its MFMA and VALU phases
+// alternate (S^T MFMAs -> softmax VALU -> PV MFMAs), so the two pipes overlap only across waves.  Here every wave carries
+// TWO independent 32-query chains (a workgroup = 256 queries) and orders a stage as
+//     S^T(A), S^T(B) [MFMA]  ->  softmax(A) [VALU, under S^T(B)]  ->  PV(A) [MFMA]  ->  softmax(B) [VALU, under PV(A)]  ->  PV(B)
+// so an MFMA batch of one chain is always in flight under the other chain's softmax, and the K / V^T fragments read from LDS are
+// shared by both chains (half the LDS reads per query: the LDS pipe was ~54 % busy).
+template <int DS, bool ONES>
+__global__ __launch_bounds__(256) void af_attn2_kernel(AttnArgs a) {
+  constexpr int DP = 16 * DS, DT = (DS + 1) / 2, DV = 32 * DT;
+  constexpr int KST = DP + 8, KBUF = KB * KST, VBUF = 2 * DV * VST, STAGE = KBUF + VBUF;
+  constexpr int KCH = KB * (DP / 8), NKC = (KCH + 255) / 256, VCH = DV * 8, NVC = (VCH + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) char af_smem[];
+  half_t* lds = reinterpret_cast<half_t*>(af_smem);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const int qblocks = (a.Nq + 255) / 256;
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int bh = (idx / qblocks) * 8 + xcd;
+  if (bh >= a.B * a.heads) return;
+  const int b = bh / a.heads, h = bh - b * a.heads;
+  const int q0 = (idx % qblocks) * 256 + wave * 64 + r;          // chain c handles query q0 + 32 c
+  const half8_t zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+  half8_t qf[2][DS];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const int query = q0 + 32 * c;
+    const half_t* qp = a.q + ((size_t)b * a.Nq + (query < a.Nq ? query : 0)) * a.ldq + h * a.d;
+#pragma unroll
+    for (int s = 0; s < DS; ++s) {
+      const int dc = 16 * s + 8 * hh;
+      half8_t v = (query < a.Nq && dc < a.d) ? *reinterpret_cast<const half8_t*>(qp + dc) : zero8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] * a.c);
+      qf[c][s] = v;
+    }
+  }
+
+  half8_t rk[NKC], rv[NVC];
+  const half_t* kptr[NKC];
+  bool kok[NKC];
+#pragma unroll
+  for (int j = 0; j < NKC; ++j) {
+    const int i = tid + 256 * j;
+    const int row = i / (DP / 8), ch = i - row * (DP / 8);
+    kok[j] = i < KCH && ch * 8 < a.d;
+    kptr[j] = a.k + ((size_t)b * a.L + row) * a.ldk + h * a.d + ch * 8;
+  }
+  const half_t* vptr[NVC];
+  bool vok[NVC], vones[NVC];
+#pragma unroll
+  for (int j = 0; j < NVC; ++j) {
+    const int i = tid + 256 * j;
+    const int row = i >> 3, ch = i & 7;
+    vok[j] = i < VCH && row < a.d;
+    vones[j] = ONES && i < VCH && row == DV - 1;
+    vptr[j] = a.vt + (size_t)b * a.vbs + (size_t)(h * a.d + (row < a.d ? row : 0)) * a.ldv + ch * 8;
+  }
+  const half8_t ones8 = {1, 1, 1, 1, 1, 1, 1, 1};
+  auto load_stage = [&](int key0) {
+#pragma unroll
+    for (int j = 0; j < NKC; ++j) rk[j] = kok[j] ? *reinterpret_cast<const half8_t*>(kptr[j] + (size_t)key0 * a.ldk) : zero8;
+#pragma unroll
+    for (int j = 0; j < NVC; ++j) rv[j] = vok[j] ? *reinterpret_cast<const half8_t*>(vptr[j] + key0) : (vones[j] ? ones8 : zero8);
+  };
+  auto store_stage = [&](int buf) {
+    half_t* Ks = lds + buf * STAGE;
+    half_t* Vs = Ks + KBUF;
+#pragma unroll
+    for (int j = 0; j < NKC; ++j) {
+      const int i = tid + 256 * j;
+      if (i < KCH) {
+        const int row = i / (DP / 8), ch = i - row * (DP / 8);
+        *reinterpret_cast<half8_t*>(Ks + row * KST + ch * 8) = rk[j];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NVC; ++j) {
+      const int i = tid + 256 * j;
+      if (i < VCH) {
+        const int row = i >> 3, ch = i & 7;
+        half_t* dst = Vs + ((ch >> 2) * DV + row) * VST + (ch & 3) * 8;
+        const half4_t lo = {rv[j][0], rv[j][1], rv[j][2], rv[j][3]};
+        const half4_t hi = {rv[j][4], rv[j][5], rv[j][6], rv[j][7]};
+        *reinterpret_cast<half4_t*>(dst) = lo;
+        *reinterpret_cast<half4_t*>(dst + 4) = hi;
+      }
+    }
+  };
+
+  floatx16 o[2][DT];
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) o[c][t][i] = 0.f;
+  float m[2] = {-FLT_MAX, -FLT_MAX}, l[2] = {0.f, 0.f};
+
+  // softmax of one chain's 64 scores of this stage (scores arrive relative to m[c] except in stage 0) -> P^T fragments
+  auto softmax = [&](int c, int st, floatx16 (&sT)[2], half8_t (&pf)[2][2]) {
+    float mx = -FLT_MAX;
+#pragma unroll
+    for (int i = 0; i < 16; i += 2) {
+      mx = fmaxf(fmaxf(mx, sT[0][i]), sT[0][i + 1]);
+      mx = fmaxf(fmaxf(mx, sT[1][i]), sT[1][i + 1]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    if (st == 0) {
+      m[c] = mx;
+      sT[0] = sT[0] - mx;
+      sT[1] = sT[1] - mx;
+    } else if (__builtin_amdgcn_ballot_w64(mx > kLazy) != 0) {       // lazy reference, see af_attn_kernel
+      const float delta = fmaxf(mx, 0.f);
+      const float alpha = __builtin_amdgcn_exp2f(-delta);
+      m[c] += delta;
+      if (!ONES) l[c] *= alpha;
+#pragma unroll
+      for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[c][t][i] *= alpha;
+      sT[0] = sT[0] - delta;
+      sT[1] = sT[1] - delta;
+    }
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float p = __builtin_amdgcn_exp2f(sT[sub][8 * s2 + j]);
+          if (!ONES) l[c] += p;
+          pf[sub][s2][j] = (half_t)p;
+        }
+  };
+
+  const int nstage = a.L / KB;
+  load_stage(0);
+  store_stage(0);
+  __syncthreads();
+  for (int st = 0; st < nstage; ++st) {
+    const bool more = st + 1 < nstage;
+    if (more) load_stage((st + 1) * KB);
+    const half_t* Ks = lds + (st & 1) * STAGE;
+    const half_t* Vs = Ks + KBUF;
+
+    // ---- S^T of both chains from shared K fragments
+    floatx16 sA[2], sB[2];
+    const float ca = st == 0 ? 0.f : -m[0], cb = st == 0 ? 0.f : -m[1];
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        sA[sub][i] = ca;
+        sB[sub][i] = cb;
+      }
+    }
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int s = 0; s < DS; ++s) {
+        const half8_t kf = *reinterpret_cast<const half8_t*>(Ks + (sub * 32 + r) * KST + 16 * s + 8 * hh);
+        sA[sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[0][s], sA[sub], 0, 0, 0);
+      }
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int s = 0; s < DS; ++s) {
+        const half8_t kf = *reinterpret_cast<const half8_t*>(Ks + (sub * 32 + r) * KST + 16 * s + 8 * hh);
+        sB[sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[1][s], sB[sub], 0, 0, 0);
+      }
+    // ---- chain A softmax (its scores are done first; chain B's MFMAs are still running)
+    half8_t pA[2][2], pB[2][2];
+    softmax(0, st, sA, pA);
+    // ---- PV(A) in flight under chain B's softmax
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const half_t* vp = Vs + (sub * DV + 32 * t + r) * VST + 16 * s2 + 4 * hh;
+          const half4_t lo = *reinterpret_cast<const half4_t*>(vp);
+          const half4_t hi = *reinterpret_cast<const half4_t*>(vp + 8);
+          const half8_t vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          o[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pA[sub][s2], o[0][t], 0, 0, 0);
+        }
+    softmax(1, st, sB, pB);
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const half_t* vp = Vs + (sub * DV + 32 * t + r) * VST + 16 * s2 + 4 * hh;
+          const half4_t lo = *reinterpret_cast<const half4_t*>(vp);
+          const half4_t hi = *reinterpret_cast<const half4_t*>(vp + 8);
+          const half8_t vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          o[1][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pB[sub][s2], o[1][t], 0, 0, 0);
+        }
+    if (more) store_stage((st + 1) & 1);
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const int query = q0 + 32 * c;
+    float lc = l[c];
+    if (ONES) {
+      const float mine = o[c][DT - 1][15];
+      const float other = __shfl_xor(mine, 32, 64);
+      lc = hh ? mine : other;
+    } else {
+      lc += __shfl_xor(lc, 32, 64);
+    }
+    const float inv = 1.0f / lc;
+    if (a.lse2 && query < a.Nq && hh == 0) a.lse2[((size_t)b * a.heads + h) * a.ld_lse + query] = m[c] + __builtin_amdgcn_logf(lc);
+    if (query < a.Nq) {
+      half_t* op = a.o + ((size_t)b * a.Nq + query) * a.ldo + h * a.d;
+#pragma unroll
+      for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int dd = 32 * t + 8 * g + 4 * hh;
+          if (dd < a.d) {
+            const half4_t v = {(half_t)(o[c][t][4 * g + 0] * inv), (half_t)(o[c][t][4 * g + 1] * inv),
+                               (half_t)(o[c][t][4 * g + 2] * inv), (half_t)(o[c][t][4 * g + 3] * inv)};
+            *reinterpret_cast<half4_t*>(op + dd) = v;
+          }
+        }
+    }
+  }
+}
+
+template <int DS, bool ONES>
+int launch_attn2chain(const AttnArgs& a, hipStream_t stream) {
+  constexpr int DP = 16 * DS, DT = (DS + 1) / 2, DV = 32 * DT;
+  constexpr size_t lds = (size_t)2 * (KB * (DP + 8) + 2 * DV * VST) * sizeof(half_t);
+  static bool attr_set = false;
+  if (lds > 65536 && !attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&af_attn2_kernel<DS, ONES>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return af_fail(AF_E_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
+    attr_set = true;
+  }
+  const int qblocks = (a.Nq + 255) / 256, bh8 = (a.B * a.heads + 7) / 8 * 8;
+  hipLaunchKernelGGL((af_attn2_kernel<DS, ONES>), dim3(qblocks * bh8), dim3(256), lds, stream, a);
+  return af_check_launch("af_attention(two-chain)");
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Short-key variant (L <= 128, no key bias, no causal mask): the U-Net's cross-attention cores (77 context tokens).
 // These launches are HBM/latency bound (76 FLOP per algorithmic byte at C = 320): the flash kernel above spends its time
 // re-staging the same 77 keys for every 128-query workgroup (2 x 64-key stages with barriers) on the ragged-L path.
@@ -593,6 +845,10 @@ int launch_attn(const AttnArgs& a, hipStream_t stream) {
   if (a.kbias == nullptr && a.causal_m == 0 && a.L <= 128 && !no_short)
     return DV > a.d ? launch_xattn<DS, true>(a, stream) : launch_xattn<DS, false>(a, stream);
   const bool general = a.kbias != nullptr || a.causal_m > 0 || a.L % KB != 0;
+  static const int two_chain = getenv("AF_ATTN_TWO_CHAIN") ? atoi(getenv("AF_ATTN_TWO_CHAIN")) : 1;
+  if constexpr (DS <= 3) {      // d <= 48: two chains fit the register file at 2 waves per SIMD
+    if (!general && two_chain && a.Nq >= 512) return DV > a.d ? launch_attn2chain<DS, true>(a, stream) : launch_attn2chain<DS, false>(a, stream);
+  }
   if (DV > a.d) return general ? launch_attn2<DS, true, true>(a, stream) : launch_attn2<DS, true, false>(a, stream);
   return general ? launch_attn2<DS, false, true>(a, stream) : launch_attn2<DS, false, false>(a, stream);
 }

@@ -256,6 +256,7 @@ def _attn_ref(q, k, v, heads, mask=None):
     (2, 64, 64, 8, 8, False), (2, 256, 256, 8, 40, False), (1, 200, 77, 8, 40, False), (2, 48, 77, 2, 40, False),
     (1, 1024, 1024, 8, 80, False), (1, 256, 256, 8, 160, False), (2, 96, 97, 4, 64, False), (2, 64, 64, 8, 16, True),
     (1, 300, 300, 8, 40, True), (2, 128, 77, 8, 32, False), (1, 4096, 4096, 2, 40, False),
+    (2, 640, 192, 3, 40, False), (1, 520, 128, 2, 24, False), (3, 1024, 1024, 1, 48, False),      # two-chain kernel incl. ragged query tails
 ])
 def test_attention(dev, B, N, L, heads, d, masked):
     from adaface_dev_amd import ops
@@ -290,11 +291,13 @@ def test_attention_all_keys_masked_is_uniform(dev):
     assert rel_l2(o.float().cpu().reshape(B, N, C).numpy(), ref.numpy()) < TOL
 
 
-def test_attention_online_softmax_rescale_branch(dev):
-    """Force the running max to jump late (a spiked key in the last stage) -- the rescale of the
-    O accumulator must be exact (cdna guide rule 26: rare data-dependent branch needs its own test)."""
+@pytest.mark.parametrize("N", [128, 512])
+def test_attention_online_softmax_rescale_branch(dev, N):
+    """Force the running max to jump late (a spiked key in the last stage, far beyond the 2^8 lazy-reference margin) -- the
+    rescale of the O accumulator must be exact (cdna guide rule 26: rare data-dependent branch needs its own test).
+    N = 128: one-chain kernel; N = 512: two-chain kernel."""
     from adaface_dev_amd import ops
-    B, N, heads, d = 1, 128, 2, 40
+    B, heads, d = 1, 2, 40
     C = heads * d
     L = 320
     q, k, v = rnd((B, N, C), 1), rnd((B, L, C), 2, 0.3), rnd((B, L, C), 3)
