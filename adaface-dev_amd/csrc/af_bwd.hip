@@ -491,6 +491,11 @@ __global__ __launch_bounds__(256) void quickgelu_bwd_kernel(const half_t* __rest
   *reinterpret_cast<half8_t*>(dx + i * 8) = o;
 }
 
+__global__ __launch_bounds__(256) void clamp_f32_kernel(float* __restrict__ a, float lo, float hi, long n) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) a[i] = fminf(fmaxf(a[i], lo), hi);       // NaN stays NaN (the overflow check runs before the clip)
+}
+
 __global__ __launch_bounds__(256) void scale_f32_kernel(float* __restrict__ a, float s, long n) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i < n) a[i] *= s;
@@ -683,6 +688,13 @@ extern "C" int af_quickgelu_bwd(const void* x, const void* dy, void* dx, int64_t
   hipLaunchKernelGGL(quickgelu_bwd_kernel, g1(n / 8), dim3(256), 0, (hipStream_t)stream, (const half_t*)x, (const half_t*)dy,
                      (half_t*)dx, (long)(n / 8));
   return af_check_launch("af_quickgelu_bwd");
+}
+
+extern "C" int af_clamp_f32(void* a, float lo, float hi, int64_t n, void* stream) {
+  AF_REQUIRE(a && n > 0 && lo <= hi, "af_clamp_f32: bad argument");
+  AfLaunchScope scope(AF_FAM_ELEM, stream);
+  hipLaunchKernelGGL(clamp_f32_kernel, g1(n), dim3(256), 0, (hipStream_t)stream, (float*)a, lo, hi, (long)n);
+  return af_check_launch("af_clamp_f32");
 }
 
 extern "C" int af_scale_f32(void* a, float s, int64_t n, void* stream) {

@@ -12,6 +12,7 @@ What one micro-batch does (everything below the Python control flow is a HIP ker
   teacher: "photo of a" prefix (4 tokens) ++ image-prompt embs -> multi-step Arc2Face U-Net (no grad)    (D5)
   student: per step eps-prediction of the frozen SD-1.5 U-Net under subj_context, fg-masked MSE x 8      (D4, D6)
   backward: whole-U-Net activation-gradient node -> text encoder dgrad -> SubjBasisGenerator weights
+  after every backward: gradient clipping by value (+-0.01, the yaml's Lightning setting) on the flat arena;
   every `accumulate_grad_batches`-th micro-batch: bucketed RCCL all-reduce overlapped with the backward
   (GradReducer), unscale, cautious AdamW on the flat fp32 arena, warm-up/cosine LR.
 
@@ -65,7 +66,8 @@ class DistillTrainer:
 
     def __init__(self, ldm, id2ada, text_encoder, base_lr=2e-6, batch_size=4, accumulate_grad_batches=2,
                  betas=(0.9, 0.995), eps=1e-6, weight_decay=0.0, lora_weight_decay=0.02, warm_up_steps=500, max_decay_steps=60000,
-                 bucket_bytes=32 << 20, loss_scaler=None, prompt_len=77, subj_slot=4, process_group=None):
+                 bucket_bytes=32 << 20, loss_scaler=None, prompt_len=77, subj_slot=4, process_group=None,
+                 gradient_clip_val=0.01, gradient_clip_algorithm="value"):
         self.ldm, self.id2ada, self.text_encoder = ldm, id2ada, text_encoder
         for p in text_encoder.parameters():
             p.requires_grad_(False)
@@ -94,8 +96,12 @@ class DistillTrainer:
         self.unet_distill_iters_count = 0
         self.skipped_steps = 0
         self.prompt_len, self.subj_slot = prompt_len, subj_slot
-        self._micro = 0
-        self._overflow = None
+        # Lightning trainer settings of the reference yaml (v1-distill-arc2face-ada.yaml:150-152), applied after every backward as
+        # DDPM.training_step does (ddpm.py:494-497)
+        if gradient_clip_algorithm != "value":
+            raise NotImplementedError("only gradient_clip_algorithm='value' (the reference's setting) is built")
+        self.gradient_clip_val = gradient_clip_val
+        self._bad = None                                                        # device flag: a non-finite gradient was seen
 
     # ------------------------------------------------------------------ conditioning
     def prompt_ids(self, bs, device):
@@ -162,12 +168,20 @@ class DistillTrainer:
         with sync:
             (loss * (self.scaler.scale / self.accum)).backward()
         if last:
+            self.reducer.finish()                                 # wait for the in-flight buckets; sums -> means
+        # overflow check BEFORE the clip (a clamp would hide an inf), accumulated on the device across the window
+        bad = sum((~torch.isfinite(a.flat_g.sum())).float() for a in self.arenas)       # inf/nan anywhere poisons the sum
+        self._bad = bad if self._bad is None else self._bad + bad
+        if self.gradient_clip_val:
+            lim = self.gradient_clip_val * self.scaler.scale                            # gradients are still loss-scaled
+            for a in self.arenas:
+                ops.clamp_f32_(a.flat_g, -lim, lim)
+        if last:
             self.optimizer_step()
         return loss.detach()
 
     def optimizer_step(self):
-        self.reducer.finish()                                     # wait for the in-flight buckets; sums -> means
-        bad = sum((~torch.isfinite(a.flat_g.sum())).float() for a in self.arenas)   # one reduction per arena; inf/nan poisons the sum
+        bad, self._bad = self._bad, None
         if self.world > 1:
             dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=self.pg)
         overflow = bool(bad.item() > 0)

@@ -502,6 +502,11 @@ def quickgelu_bwd(x, dy):
     return dx
 
 
+def clamp_f32_(a, lo, hi):
+    _lib.check(_lib.lib().af_clamp_f32(_p(a), float(lo), float(hi), a.numel(), _stream()), "af_clamp_f32")
+    return a
+
+
 def scale_f32_(a, s):
     _lib.check(_lib.lib().af_scale_f32(_p(a), float(s), a.numel(), _stream()), "af_scale_f32")
     return a

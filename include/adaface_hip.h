@@ -236,6 +236,9 @@ int af_quickgelu_fwd(const void* x, void* y, int64_t n, void* stream);
 int af_quickgelu_bwd(const void* x, const void* dy, void* dx, int64_t n, void* stream);
 /* y = a * s (fp32), used to unscale the loss-scaled gradient arena before the optimizer step */
 int af_scale_f32(void* a, float s, int64_t n, void* stream);
+/* a = clamp(a, lo, hi): gradient clipping by VALUE over the flat gradient arena (Lightning `gradient_clip_algorithm: 'value'`,
+ * `gradient_clip_val: 0.01` in configs/stable-diffusion/v1-distill-arc2face-ada.yaml:150-152; ddpm.py:496-497) */
+int af_clamp_f32(void* a, float lo, float hi, int64_t n, void* stream);
 
 /* ---- VAE decoder (ldm/modules/diffusionmodules/model.py:151-243 AttnBlock): row softmax of an explicit fp16 score matrix
  * [rows, L], L % 8 == 0, L <= 4096 (single-head 512-dim attention runs as af_gemm -> af_softmax_rows -> af_gemm) */

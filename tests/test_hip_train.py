@@ -169,6 +169,8 @@ def test_distill_trainer_accumulate_and_step(dev):
     l0 = tr.training_step(batches[0], 0)
     assert tr.global_step == 0 and float(tr.arena.flat_g.abs().sum()) > 0
     g_after_first = tr.arena.flat_g.clone()
+    # gradient clipping by value after every backward (yaml gradient_clip_val 0.01, 'value'), on the loss-scaled arena
+    assert float(g_after_first.abs().max()) <= 0.01 * tr.scaler.scale * (1 + 1e-6)
     l1 = tr.training_step(batches[1], 1)
     assert tr.global_step == 1 and tr.skipped_steps == 0
     assert torch.isfinite(l0) and torch.isfinite(l1)
