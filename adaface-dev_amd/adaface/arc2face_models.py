@@ -217,6 +217,22 @@ class CLIPTextModelWrapper(nn.Module):
         hidden = tuple(t.reshape(B, T, E) for t in hs) if want_hidden else None
         return (last, pooled) + ((hidden,) if hidden is not None else ())
 
+    @torch.no_grad()
+    def extend_position_embeddings(self, max_length):
+        """[77, E] -> [max_length, E] by appending copies of the last (max_length - 77) rows, as the reference's hooked text encoder
+        does for `--clip_prompt_max_length 97` (ldm/modules/encoders/modules.py:373-382, main.py:272)."""
+        emb = self.text_model.embeddings.position_embedding
+        old = emb.num_embeddings
+        if max_length <= old:
+            return
+        el = max_length - old
+        new = nn.Embedding(max_length, emb.embedding_dim).to(device=emb.weight.device, dtype=emb.weight.dtype)
+        new.weight[:old] = emb.weight
+        new.weight[old:] = emb.weight[-el:]
+        new.weight.requires_grad_(emb.weight.requires_grad)
+        self.text_model.embeddings.position_embedding = new
+        self.config.max_position_embeddings = max_length
+
     def extend_clip_attention_MKV_multiplier(self, begin_layer_idx=-1, end_layer_idx=-1, multiplier=2, perturb_std=0.1,
                                              perturb_std_is_relative=True, perturb_keep_norm=False, verbose=False):
         """Widen K/V of encoder layers [begin, end] (reference arc2face_models.py:343-382)."""

@@ -81,13 +81,14 @@ def main_train(args):
     rng.load_synth_weights(id2ada.subj_basis_generator.prompt2token_proj, seed=3)
     text_enc = CLIPTextModelWrapper()
     rng.load_synth_weights(text_enc, seed=4)
+    text_enc.extend_position_embeddings(97)          # --clip_prompt_max_length 97: the training context length (main.py:272)
     ldm = ldm.to(dev)
     for p in ldm.model.diffusion_model.parameters():
         p.requires_grad_(False)
     ldm.unet_teacher = Arc2FaceTeacher(teacher.to(dev))
     if not args.no_ffn_lora:
         ldm.model.set_up_ffn_loras()         # rank-192 DoRA on up_blocks.3 convs; 'unet_distill' is always on in Stage 1 (ddpm.py:3130-3134)
-    tr = DistillTrainer(ldm, id2ada.to(dev), text_enc.to(dev), batch_size=B, accumulate_grad_batches=2)
+    tr = DistillTrainer(ldm, id2ada.to(dev), text_enc.to(dev), batch_size=B, accumulate_grad_batches=2, prompt_len=97)
     n_train = sum(a.numel for a in tr.arenas)
 
     def batch(i):
@@ -134,7 +135,7 @@ def main_train(args):
         out = {"metric": "train-images/sec Stage-1 Arc2Face distillation bs=4/GPU", "value": round(world * B * steps / elapsed, 3),
                "unit": "images/s", "n_gpus": world, "steps": steps, "warmup": warm, "ms_per_step": round(ms, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-               "config": {"workload": f"stage1_unet_distill micro-batch: bs={B}/GPU, 512x512 (latent 64x64), denoising steps cycle 2,3,4 "
+               "config": {"workload": f"stage1_unet_distill micro-batch: bs={B}/GPU, 512x512 (latent 64x64), 97 context tokens, denoising steps cycle 2,3,4 "
                                       "with HALF_BS=ceil(bs/steps), teacher+student SD-1.5 U-Nets, 3 CLIP-L encoders, "
                                       f"{n_train} trainable fp32 params, accumulate_grad_batches=2, CAdamW",
                           "parallelism": f"dp{world} (RCCL bucketed all-reduce overlapped with backward)" if world > 1 else "single GPU",

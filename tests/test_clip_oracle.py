@@ -56,3 +56,15 @@ def test_text_model_vs_transformers():
     # pre-computed token embeddings path == input_ids path
     tok = sd["text_model.embeddings.token_embedding.weight"][ids]
     assert rel_l2(CO.clip_text_forward(sd, CLIP_SMALL, ids, tok)[0].numpy(), g["text_last"]) < 1e-6
+
+
+def test_extend_position_embeddings_like_reference():
+    """77 -> 97 positions by repeating the last 20 rows (ldm/modules/encoders/modules.py:373-382)."""
+    from adaface_dev_amd.adaface.arc2face_models import CLIPTextModelWrapper, clip_text_config
+    m = CLIPTextModelWrapper(clip_text_config(hidden_size=32, num_attention_heads=2, num_hidden_layers=1, intermediate_size=64, vocab_size=100))
+    w0 = m.text_model.embeddings.position_embedding.weight.detach().clone()
+    m.extend_position_embeddings(97)
+    w1 = m.text_model.embeddings.position_embedding.weight
+    assert w1.shape == (97, 32) and torch.equal(w1[:77], w0) and torch.equal(w1[77:], w0[-20:])
+    m.extend_position_embeddings(80)                           # never shrinks
+    assert m.text_model.embeddings.position_embedding.weight.shape == (97, 32)
