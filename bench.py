@@ -144,6 +144,7 @@ def main_train(args):
                "families_per_micro_batch": fam}
         print(json.dumps(out))
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 
@@ -355,6 +356,7 @@ def main():
         print(json.dumps(out))
     if world > 1 or launched:
         import torch.distributed as dist
+        dist.barrier()                  # rank 0 may still be in its instrumented pass: leave together
         dist.destroy_process_group()
 
 
