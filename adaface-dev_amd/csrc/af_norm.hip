@@ -11,6 +11,8 @@
 //     (<= 21 MB at batch 8) stays in the 256 MB Infinity Cache between the two passes;
 //   * the channel concat of the U-Net skip connections (openaimodel.py:918) is fused: the
 //     input is read from two sources, the output is one tensor.
+#include <stdlib.h>
+
 #include "af_common.h"
 
 namespace {
@@ -212,6 +214,77 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Small-tensor GroupNorm in ONE launch: one workgroup per (batch item, group) holds the group's HW x cpg elements in registers
+// (statistics, then normalise: 1 read + 1 write, no workspace, no second launch).  Used for the 16x16 / 8x8 levels, where a
+// GroupNorm call is two ~7 us latency-bound launches over a few MB; needs the group's channels to be whole 16-byte chunks
+// (cpg % 8 == 0: C = 1280 / 2560) that lie in ONE of the two sources, and HW * cpg / 8 <= 256 * GS_IT chunks.
+constexpr int GS_IT = 10;
+
+__global__ __launch_bounds__(256) void gn_small_kernel(GnArgs a) {
+  __shared__ float red[2][4];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int g = blockIdx.x, b = blockIdx.y;
+  const int cpb = a.cpg >> 3;                          // 16-byte chunks per pixel in this group
+  const int c0 = g * a.cpg;
+  const half_t* src = c0 < a.c1 ? a.x1 + c0 : a.x2 + (c0 - a.c1);
+  const int ld = c0 < a.c1 ? a.c1 : a.c2;
+  const int items = a.HW * cpb;
+  half8_t v[GS_IT];
+  float s = 0.f, q = 0.f;
+#pragma unroll
+  for (int u = 0; u < GS_IT; ++u) {
+    const int i = t + 256 * u;
+    if (i < items) {
+      const int pix = i / cpb, ch = i - pix * cpb;
+      v[u] = *reinterpret_cast<const half8_t*>(src + ((size_t)b * a.HW + pix) * ld + ch * 8);
+    } else {
+      v[u] = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < GS_IT; ++u)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float f = (float)v[u][e];
+      s += f;
+      q += f * f;
+    }
+  s = af_wave_sum(s);
+  q = af_wave_sum(q);
+  if (lane == 0) {
+    red[0][w] = s;
+    red[1][w] = q;
+  }
+  __syncthreads();
+  s = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+  q = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  const float inv_n = 1.0f / ((float)a.HW * (float)a.cpg);
+  const float mean = s * inv_n;
+  const float rstd = rsqrtf(fmaxf(q * inv_n - mean * mean, 0.f) + a.eps);
+  if (a.stats && t == 0) {
+    a.stats[((size_t)b * a.groups + g) * 2 + 0] = mean;
+    a.stats[((size_t)b * a.groups + g) * 2 + 1] = rstd;
+  }
+#pragma unroll
+  for (int u = 0; u < GS_IT; ++u) {
+    const int i = t + 256 * u;
+    if (i < items) {
+      const int pix = i / cpb, ch = i - pix * cpb;
+      const int c = c0 + ch * 8;
+      half8_t o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float k = rstd * a.gamma[c + e];
+        float f = (float)v[u][e] * k + (a.beta[c + e] - mean * k);
+        if (a.silu) f = af_silu(f);
+        o[e] = (half_t)f;
+      }
+      *reinterpret_cast<half8_t*>(a.y + ((size_t)b * a.HW + pix) * a.C + c) = o;
+    }
+  }
+}
+
 // LayerNorm: one wave per row, row held in registers (two-pass mean / variance).
 template <int CT>
 __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict__ x, const float* __restrict__ gamma,
@@ -310,6 +383,12 @@ extern "C" int af_groupnorm_stats(const void* x1, const void* x2, int c1, int c2
   const size_t lds = (size_t)2 * slots * C * sizeof(float);
   hipStream_t s = (hipStream_t)stream;
   AfLaunchScope scope(AF_FAM_GNORM, stream);
+  // small tensors: one launch, one workgroup per (batch item, group)
+  static const bool no_small = getenv("AF_GN_NO_SMALL") != nullptr;      // A/B switch
+  if (!no_small && a.cpg % 8 == 0 && (c2 == 0 || c1 % a.cpg == 0) && (long)HW * (a.cpg / 8) <= 256L * GS_IT) {
+    hipLaunchKernelGGL(gn_small_kernel, dim3(groups, B), dim3(256), 0, s, a);
+    return af_check_launch("af_groupnorm(small)");
+  }
   // enough workgroups to keep >= 4 per CU streaming (B * nblk >= 1024 when the tensor is large enough), each thread with
   // several 16-byte loads in flight; small levels keep >= 4 pixel iterations per thread
   const int iters = (HW + slots - 1) / slots;          // pixel iterations if one block took a whole batch item
