@@ -220,6 +220,7 @@ def test_conv3x3_padded_input_channels(dev):
     (2, 64, 320, 0, 1e-5, True), (2, 256, 1280, 640, 1e-5, True), (1, 64, 2560, 0, 1e-5, True), (3, 100, 32, 0, 1e-6, False),
     (2, 4096, 320, 0, 1e-6, False), (2, 64, 640, 320, 1e-5, True), (2, 49, 64, 64, 1e-5, True),
     (8, 256, 1280, 0, 1e-5, True), (3, 256, 1280, 1280, 1e-5, True), (2, 64, 1280, 1280, 1e-6, False), (2, 144, 1280, 0, 1e-5, False),   # single-launch path
+    (8, 1024, 640, 0, 1e-5, True), (3, 256, 1280, 640, 1e-5, True), (9, 256, 640, 0, 1e-6, False), (2, 1024, 320, 320, 1e-5, True),   # pair-granularity path
 ])
 def test_groupnorm(dev, B, HW, c1, c2, eps, silu):
     from adaface_dev_amd import ops
