@@ -6,6 +6,11 @@ failure.  There is no eager / CPU fallback.
 
 Activation convention: fp16, channels-last.  A feature map is a contiguous tensor
 ``[B, H, W, C]`` (equivalently tokens ``[B, H*W, C]``).
+
+Concurrency: launches go to ``torch.cuda.current_stream()``.  The caller-owned scratch the C ABI asks for (GroupNorm partials,
+split-K slabs, attention-backward copies, the zero page) is cached here PER DEVICE, not per stream: the hot path is
+single-stream by design (one process per GPU, one HIP stream, the hipGraph replays on it), so two streams of one process must
+not run these wrappers concurrently.
 """
 import ctypes as C
 import math
