@@ -17,7 +17,6 @@ adapters therefore cost NOTHING at run time: ``merge_*`` rewrites the layer's we
 the next call because the parameter version changes) and returns what is needed to restore it.  Training-time DoRA (dropout on the
 adapter branch, gradients to A / B / m) is the next row.  peft itself is not available offline: the formula
 above is restated from peft's published DoRA layer and is "parity unpinned" (oracle: ``oracle/lora_oracle.py``)."""
-import re
 
 import torch
 

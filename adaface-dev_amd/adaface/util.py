@@ -2,7 +2,6 @@
 ensemble (:174-248).  Small host-level tensor glue."""
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 
 def perturb_tensor(ts, perturb_std, perturb_std_is_relative=True, keep_norm=False, std_dim=-1, norm_dim=-1, verbose=False):

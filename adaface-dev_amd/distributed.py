@@ -19,7 +19,6 @@ Works on any torch.distributed backend (tests run it with gloo / world_size 2 on
 import contextlib
 from typing import List
 
-import torch
 import torch.distributed as dist
 
 

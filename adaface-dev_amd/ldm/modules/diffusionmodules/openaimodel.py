@@ -23,7 +23,7 @@ import torch.nn as nn
 from .... import ops
 from ....ops import AF_ACT_SILU, F16
 from ..attention import SpatialTransformer
-from .util import (Conv2d, _PackCache, checkpoint, conv_nd, from_nhwc_f16, linear, normalization, timestep_embedding,
+from .util import (_PackCache, checkpoint, conv_nd, from_nhwc_f16, linear, normalization, timestep_embedding,
                    to_nhwc_f16, zero_module)
 
 

@@ -12,7 +12,6 @@ Same public names and argument meaning (``timestep_embedding``, ``normalization`
 * weights are re-laid once per device into the K-contiguous fp16 matrices ``af_gemm`` consumes
   (``packed()``), and re-packed automatically when a parameter is modified or moved.
 """
-import math
 
 import numpy as np
 import torch

@@ -13,7 +13,6 @@ single-stream by design (one process per GPU, one HIP stream, the hipGraph repla
 not run these wrappers concurrently.
 """
 import ctypes as C
-import math
 from dataclasses import dataclass
 from typing import Optional
 

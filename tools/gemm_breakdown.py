@@ -2,7 +2,6 @@
 """Per-shape breakdown of the GEMM family in one denoise step (U-Net batch 8): launches, time at the tuned (tile, splits),
 TFLOP/s, share of the family.  GPU box:  python tools/gemm_breakdown.py [--batch 8]"""
 import argparse
-import copy
 import ctypes as C
 import os
 import sys
