@@ -39,6 +39,7 @@ class GemmDesc(C.Structure):
         ("act", C.c_int32), ("out_mode", C.c_int32), ("ld_out", C.c_int32), ("split_col", C.c_int32),
         ("ld_out2", C.c_int32), ("tile", C.c_int32), ("splits", C.c_int32),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64), ("zeros", C.c_void_p),
+        ("tap_shift", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 

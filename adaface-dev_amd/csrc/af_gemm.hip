@@ -45,6 +45,7 @@ struct GemmDev {
   int H, W, Ho, Wo, HoWo, Heff, Weff, stride, upsample;
   int rows_per_batch, ld_rowbias, act_silu, ld_out, split_col, ld_out2;  // act_silu: 0 none, 1 SiLU, 3 quick-GELU
   int tiles_n, tiles_m, n_major;
+  int tap_shift;   // 0: padding 1 all round; 1: taps shifted by +1 (padding (0,1,0,1))
   int splits, kt_per_split;  // split-K: blockIdx.y owns K steps [y*kt_per_split, ...)
   float* ws;                 // fp32 partials [splits][M][N] when splits > 1
 };
@@ -97,8 +98,8 @@ __global__ __launch_bounds__(256, 2) void af_gemm_kernel(GemmDev p) {
         const int rem = m - b * p.HoWo;
         const int oy = rem / p.Wo;
         const int ox = rem - oy * p.Wo;
-        a_iy0[i] = oy * p.stride - 1;
-        a_ix0[i] = ox * p.stride - 1;
+        a_iy0[i] = oy * p.stride - 1 + p.tap_shift;
+        a_ix0[i] = ox * p.stride - 1 + p.tap_shift;
         a_base[i] = b * p.H * p.W;
       } else {
         a_iy0[i] = -(1 << 20);
@@ -454,6 +455,7 @@ extern "C" int af_gemm(const af_gemm_desc* d, void* stream) {
   p.split_col = d->split_col;
   p.ld_out2 = d->ld_out2;
   p.tiles_n = 0;
+  p.tap_shift = d->taps == 9 ? d->tap_shift : 0;
   p.splits = d->splits > 1 ? d->splits : 1;
   p.kt_per_split = 0;
   p.ws = (float*)d->workspace;
@@ -500,6 +502,8 @@ extern "C" int af_gemm(const af_gemm_desc* d, void* stream) {
 
   AfLaunchScope scope(AF_FAM_GEMM, stream);
   hipStream_t s = (hipStream_t)stream;
+  AF_REQUIRE(d->tap_shift == 0 || (d->tap_shift == 1 && d->taps == 9 && !p.upsample), "af_gemm: tap_shift is 0 or 1 (3x3, no upsample)");
+  if (tile >= 3 && d->tap_shift) tile = 1;          // the ring kernel keeps the symmetric-padding loader only
   if (tile >= 3) {
     const int eff = af_gemm3_effective_splits(d, p.splits);
     const int rc3 = af_gemm3_try_launch(d, p.splits, tile == 4, s);

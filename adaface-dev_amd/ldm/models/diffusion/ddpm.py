@@ -165,9 +165,9 @@ class LatentDiffusion(nn.Module):
         reg("posterior_mean_coef2", (1.0 - alphas_cumprod_prev) * np.sqrt(alphas) / (1.0 - alphas_cumprod))
 
     def instantiate_first_stage(self, ddconfig=None, embed_dim=4):
-        """The decoder half of the first-stage VAE (reference instantiate_first_stage ddpm.py:698-704; frozen, eval)."""
-        from ...modules.diffusionmodules.model import AutoencoderKLDecoder
-        self.first_stage_model = AutoencoderKLDecoder(ddconfig, embed_dim).eval()
+        """The first-stage VAE (reference instantiate_first_stage ddpm.py:698-704; frozen, eval): encoder + decoder."""
+        from ...modules.diffusionmodules.model import AutoencoderKL
+        self.first_stage_model = AutoencoderKL(ddconfig, embed_dim).eval()
         for p in self.first_stage_model.parameters():
             p.requires_grad_(False)
         return self.first_stage_model
@@ -178,6 +178,19 @@ class LatentDiffusion(nn.Module):
         if self.first_stage_model is None:
             raise RuntimeError("no first-stage decoder: call instantiate_first_stage() and load its weights")
         return self.first_stage_model.decode(z / self.scale_factor)
+
+    @torch.no_grad()
+    def encode_first_stage(self, x, mask=None):
+        """image [B,3,H,W] in [-1, 1] -> posterior parameters (mean, logvar) of the latent (reference ddpm.py:875-887 / autoencoder.py:30-34)."""
+        if self.first_stage_model is None:
+            raise RuntimeError("no first-stage model: call instantiate_first_stage() and load its weights")
+        return self.first_stage_model.encode(x, mask)
+
+    def get_first_stage_encoding(self, encoder_posterior, generator=None):
+        """sample the DiagonalGaussian posterior and apply the latent scale factor (reference ddpm.py:718-727)."""
+        mean, logvar = encoder_posterior
+        z = mean + torch.exp(0.5 * logvar) * torch.randn(mean.shape, device=mean.device, dtype=mean.dtype, generator=generator)
+        return self.scale_factor * z
 
     def q_sample(self, x_start, t, noise=None):
         noise = torch.randn_like(x_start) if noise is None else noise

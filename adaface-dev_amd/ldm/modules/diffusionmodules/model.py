@@ -35,6 +35,26 @@ class Upsample(nn.Module):
         return self.conv.hip(x, upsample=True)
 
 
+class Downsample(nn.Module):
+    """3x3 stride-2 conv on the input padded (0, 1, 0, 1) (model.py:61-80): the asymmetric padding is a +1 shift of the taps in the
+    implicit-GEMM loader (``tap_shift``), not a padded copy."""
+
+    def __init__(self, in_channels, with_conv):
+        super().__init__()
+        self.with_conv = with_conv
+        if not with_conv:
+            raise NotImplementedError("Downsample without conv (avg_pool) is not used by the SD VAE")
+        self.conv = nn.Conv2d(in_channels, in_channels, kernel_size=3, stride=2, padding=0)
+        self._key, self._pack = None, None
+
+    def hip(self, x):
+        c = self.conv
+        key = (c.weight._version, c.bias._version, c.weight.data_ptr())
+        if key != self._key:
+            self._pack, self._key = ops.pack_conv3x3(c.weight, c.bias, c.weight.device), key
+        return ops.conv3x3(x, self._pack, stride=2, tap_shift=1)
+
+
 class ResnetBlock(nn.Module):
     def __init__(self, *, in_channels, out_channels=None, conv_shortcut=False, dropout=0.0, temb_channels=512):
         super().__init__()
@@ -178,6 +198,70 @@ class Decoder(nn.Module):
         return from_nhwc_f16(y, z.dtype, self.out_ch)
 
 
+class Encoder(nn.Module):
+    """Reference ``Encoder`` (model.py:408-500) without attention masks: image [B,3,H,W] -> moments [B, 2*z_channels, H/8, W/8]."""
+
+    def __init__(self, *, ch, out_ch, ch_mult=(1, 2, 4, 8), num_res_blocks, attn_resolutions, dropout=0.0, resamp_with_conv=True,
+                 in_channels, resolution, z_channels, double_z=True, use_linear_attn=False, attn_type="vanilla", **ignore_kwargs):
+        super().__init__()
+        if use_linear_attn or attn_type != "vanilla":
+            raise NotImplementedError("only the vanilla-attention SD VAE encoder is built")
+        self.ch, self.temb_ch = ch, 0
+        self.num_resolutions, self.num_res_blocks = len(ch_mult), num_res_blocks
+        self.resolution, self.in_channels = resolution, in_channels
+        self.conv_in = Conv2d(in_channels, ch, kernel_size=3, stride=1, padding=1)
+        self.conv_in.cin_pad = ops.round_up(in_channels, 8)
+        curr_res = resolution
+        in_ch_mult = (1,) + tuple(ch_mult)
+        self.down = nn.ModuleList()
+        block_in = ch
+        for i_level in range(self.num_resolutions):
+            block, attn = nn.ModuleList(), nn.ModuleList()
+            block_in, block_out = ch * in_ch_mult[i_level], ch * ch_mult[i_level]
+            for _ in range(num_res_blocks):
+                block.append(ResnetBlock(in_channels=block_in, out_channels=block_out, temb_channels=0, dropout=dropout))
+                block_in = block_out
+                if curr_res in attn_resolutions:
+                    attn.append(AttnBlock(block_in))
+            down = nn.Module()
+            down.block, down.attn = block, attn
+            if i_level != self.num_resolutions - 1:
+                down.downsample = Downsample(block_in, resamp_with_conv)
+                curr_res //= 2
+            self.down.append(down)
+        self.mid = nn.Module()
+        self.mid.block_1 = ResnetBlock(in_channels=block_in, out_channels=block_in, temb_channels=0, dropout=dropout)
+        self.mid.attn_1 = AttnBlock(block_in)
+        self.mid.block_2 = ResnetBlock(in_channels=block_in, out_channels=block_in, temb_channels=0, dropout=dropout)
+        self.norm_out = Normalize(block_in)
+        self.out_channels = 2 * z_channels if double_z else z_channels
+        self.conv_out = Conv2d(block_in, self.out_channels, kernel_size=3, stride=1, padding=1)
+
+    def hip(self, x):
+        """x [B,H,W,roundup(in_channels,8)] fp16 -> [B,H/8,W/8,out_channels] fp16 (out_channels % 8 == 0 for double_z z=4)."""
+        h = self.conv_in.hip(x)
+        for i_level in range(self.num_resolutions):
+            for i_block in range(self.num_res_blocks):
+                h = self.down[i_level].block[i_block].hip(h)
+                if len(self.down[i_level].attn) > 0:
+                    h = self.down[i_level].attn[i_block].hip(h)
+            if i_level != self.num_resolutions - 1:
+                h = self.down[i_level].downsample.hip(h)
+        h = self.mid.block_1.hip(h)
+        h = self.mid.attn_1.hip(h)
+        h = self.mid.block_2.hip(h)
+        return self.conv_out.hip(self.norm_out.hip(h, silu=True))
+
+    def forward(self, x, mask=None):
+        if mask is not None:
+            raise NotImplementedError("masked encoder attention (fg / aug masks, model.py:191-209) is not built")
+        _require_cuda(self.conv_in.weight, "VAE Encoder")
+        if self.out_channels % 8 != 0:
+            raise NotImplementedError("encoder output channels must be a multiple of 8 (double_z with z_channels = 4)")
+        y = self.hip(to_nhwc_f16(x, ops.round_up(x.shape[1], 8)))
+        return from_nhwc_f16(y, x.dtype, self.out_channels)
+
+
 class AutoencoderKLDecoder(nn.Module):
     """``first_stage_model`` restricted to what inference needs: ``decode(z) = decoder(post_quant_conv(z))``
     (ldm/models/autoencoder.py:29, 56-59).  SD-1.5: embed_dim 4, ddconfig below."""
@@ -216,3 +300,21 @@ class AutoencoderKLDecoder(nn.Module):
         B, H, W, c8 = zh.shape
         zq = ops.gemm(zh.reshape(B * H * W, c8), self._pq_pack()).reshape(B, H, W, -1)
         return from_nhwc_f16(self.decoder.hip(zq), z.dtype, self.decoder.out_ch)
+
+
+class AutoencoderKL(AutoencoderKLDecoder):
+    """``first_stage_model`` with both halves: ``encode(x)`` -> DiagonalGaussian moments (mean, logvar) through ``quant_conv``
+    (ldm/models/autoencoder.py:9, 30-34) and ``decode(z)``.  ``encode`` returns (mean, logvar) in fp32; sampling
+    ``mean + exp(0.5 logvar) * eps`` and the 0.18215 scale are the caller's (``LatentDiffusion.get_first_stage_encoding``)."""
+
+    def __init__(self, ddconfig=None, embed_dim=4):
+        super().__init__(ddconfig, embed_dim)
+        ddconfig = dict(ddconfig or self.SD15_DDCONFIG)
+        self.encoder = Encoder(**ddconfig)
+        self.quant_conv = Conv2d(2 * ddconfig["z_channels"], 2 * embed_dim, 1)
+
+    @torch.no_grad()
+    def encode(self, x, mask=None):
+        moments = self.quant_conv(self.encoder(x, mask).float())          # quant_conv: 8 -> 8 channels, 1x1 (plain af_gemm)
+        mean, logvar = torch.chunk(moments.float(), 2, dim=1)
+        return mean, torch.clamp(logvar, -30.0, 20.0)

@@ -195,8 +195,8 @@ def gemm(a1: torch.Tensor, pw: PackedWeight, *, a2: Optional[torch.Tensor] = Non
 
 def conv3x3(x: torch.Tensor, pw: PackedWeight, *, x2: Optional[torch.Tensor] = None, stride: int = 1, upsample: bool = False,
             rowbias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, tile: int = 0,
-            splits: int = 0, out_hw=None) -> torch.Tensor:
-    """3x3 / pad 1 convolution as implicit GEMM.  x [B,H,W,C1] (+ x2 [B,H,W,C2] channel-concat)
+            splits: int = 0, out_hw=None, tap_shift: int = 0) -> torch.Tensor:
+    """3x3 / pad 1 convolution as implicit GEMM (tap_shift=1: padding (0, 1, 0, 1) instead, the VAE encoder's Downsample).  x [B,H,W,C1] (+ x2 [B,H,W,C2] channel-concat)
     -> [B,Ho,Wo,Cout].  rowbias [B, >=Cout] is added per batch item (time-embedding), residual
     [B,Ho,Wo,Cout] after it."""
     _chk_f16(x, "conv3x3.x")
@@ -219,7 +219,7 @@ def conv3x3(x: torch.Tensor, pw: PackedWeight, *, x2: Optional[torch.Tensor] = N
     d.M, d.N, d.K, d.kpad, d.taps = B * ho * wo, pw.N, pw.K, pw.kpad, 9
     d.c1, d.c2 = c1, c2
     d.B, d.H, d.W, d.Ho, d.Wo = B, H, W, ho, wo
-    d.stride, d.upsample = stride, int(upsample)
+    d.stride, d.upsample, d.tap_shift = stride, int(upsample), int(tap_shift)
     d.rows_per_batch = ho * wo
     d.ld_rowbias = 0 if rowbias is None else rowbias.stride(0)
     if residual is not None:

@@ -112,6 +112,9 @@ typedef struct af_gemm_desc {
   void* workspace;      /* fp32, >= splits*M*N*4 bytes when splits > 1 */
   int64_t workspace_bytes;
   const void* zeros;    /* >= 16 bytes of zeros, 16-byte aligned: source of halo / out-of-range lanes (tile 3) */
+  int32_t tap_shift;    /* 3x3 only: 0 = padding 1 on every side; 1 = taps shifted by +1 pixel, i.e. padding (0, 1, 0, 1) as the VAE
+                           encoder's Downsample pads before its stride-2 conv (ldm/modules/diffusionmodules/model.py:73-77) */
+  int32_t reserved0;
 } af_gemm_desc;
 
 int af_gemm(const af_gemm_desc* d, void* stream);

@@ -419,6 +419,15 @@ def gen_vae(out):
             d["full_crop"] = y[0, :, 200:264, 300:364].numpy()
             d["full_attn_probes"] = probes(feats["attn"])
         print("vae", tag, tuple(y.shape), float(y.abs().mean()))
+    # Encoder (model.py:408-500), reduced width: 2 x 3 x 128 x 128 image -> moments [2, 8, 16, 16]; asymmetric-padding Downsample
+    from ldm.modules.diffusionmodules.model import Encoder
+    e = Encoder(**dict(VAE_SMALL, double_z=True)).eval()
+    with torch.no_grad():
+        for n, p in e.named_parameters():
+            p.copy_(rng.synth_tensor("encoder." + n, p.shape, seed=90))
+        img = rng.synth_input("vae.img.small", (2, 3, 128, 128), seed=90)
+        d["enc_small_out"] = e(img).numpy()
+    print("vae encoder", d["enc_small_out"].shape, float(np.abs(d["enc_small_out"]).mean()))
     np.savez_compressed(os.path.join(out, "vae.npz"), **d)
 
 

@@ -80,3 +80,50 @@ def test_vae_decoder_sd15_size_vs_reference_and_decode_vs_oracle(dev):
         img = ae.decode(z2.to(dev)).cpu()
         ref = VO.decode(sd, z2)
     assert rel_l2(img.numpy(), ref.numpy()) < 1e-2
+
+
+def test_vae_encoder_vs_reference_and_encode_decode_roundtrip_shapes(dev):
+    """Encoder (asymmetric-padding stride-2 Downsample = +1 tap shift in the conv loader) against the REFERENCE module's output;
+    AutoencoderKL.encode -> (mean, logvar) against the oracle; decode(encode(x).mean) has the image's shape."""
+    from adaface_dev_amd import rng
+    from adaface_dev_amd.ldm.modules.diffusionmodules.model import AutoencoderKL, Encoder
+    from oracle import vae_oracle as VO
+    g = np.load(os.path.join(GOLDEN, "vae.npz"))
+    e = Encoder(**dict(VAE_SMALL, double_z=True))
+    with torch.no_grad():
+        for n, p in e.named_parameters():
+            p.copy_(rng.synth_tensor("encoder." + n, p.shape, seed=90))
+    e = e.to(dev).eval()
+    img = rng.synth_input("vae.img.small", (2, 3, 128, 128), seed=90)
+    with torch.no_grad():
+        y = e(img.to(dev))
+    err = rel_l2(y.cpu().numpy(), g["enc_small_out"])
+    print(f"VAE encoder (reduced width) rel-L2 vs reference: {err:.3e}")
+    assert y.shape == (2, 8, 16, 16) and err < 1e-2
+    ae = AutoencoderKL(dict(VAE_SMALL, double_z=True))
+    with torch.no_grad():
+        for n, p in ae.named_parameters():
+            p.copy_(rng.synth_tensor(n, p.shape, seed=92))
+    sd = {k: v.detach().float().clone() for k, v in ae.state_dict().items()}
+    ae = ae.to(dev).eval()
+    mean, logvar = ae.encode(img.to(dev))
+    rm, rl = VO.encode(sd, img)
+    assert rel_l2(mean.cpu().numpy(), rm.numpy()) < 1e-2 and rel_l2(logvar.cpu().numpy(), rl.numpy()) < 1e-2
+    rec = ae.decode(mean)
+    assert rec.shape == img.shape and bool(torch.isfinite(rec).all())
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout", [(2, 16, 16, 64, 64), (1, 32, 30, 128, 96), (2, 9, 11, 32, 64)])
+def test_conv3x3_tap_shift_is_asymmetric_padding(dev, B, H, W, cin, cout):
+    """ops.conv3x3(stride=2, tap_shift=1) == F.conv2d(F.pad(x, (0,1,0,1)), w, stride=2) incl. odd sizes."""
+    import torch.nn.functional as F
+    from adaface_dev_amd import ops, rng
+    x = rng.synth_input("ts.x", (B, cin, H, W), seed=93)
+    w = rng.synth_input("ts.w", (cout, cin, 3, 3), seed=93, scale=(cin * 9) ** -0.5)
+    b = rng.synth_input("ts.b", (cout,), seed=93, scale=0.1)
+    xh = x.permute(0, 2, 3, 1).contiguous().half().to(dev)
+    # the op derives Ho from the symmetric formula; for odd sizes the reference's padded conv gives floor((H + 1 - 3) / 2) + 1
+    ref = F.conv2d(F.pad(xh.float().cpu().permute(0, 3, 1, 2), (0, 1, 0, 1)), w.half().float(), b, 2, 0)
+    y = ops.conv3x3(xh, ops.pack_conv3x3(w, b, dev), stride=2, tap_shift=1)
+    y = y[:, :ref.shape[2], :ref.shape[3]]
+    assert rel_l2(y.float().cpu().permute(0, 3, 1, 2).numpy(), ref.numpy()) < 2e-3

@@ -61,3 +61,15 @@ def test_host_mirror_layout_and_no_cpu_fallback():
         assert "MI355X" in str(e) or "no CPU" in str(e)
     else:
         raise AssertionError("the VAE decoder ran on the CPU: there must be no fallback path")
+
+
+def test_vae_encoder_oracle_vs_reference_reduced_width():
+    from adaface_dev_amd.ldm.modules.diffusionmodules.model import Encoder
+    g = np.load(os.path.join(GOLDEN, "vae.npz"))
+    with torch.device("meta"):
+        m = Encoder(**dict(VAE_SMALL, double_z=True))
+    sd = {"encoder." + n: rng.synth_tensor("encoder." + n, p.shape, seed=90) for n, p in m.named_parameters()}
+    img = rng.synth_input("vae.img.small", (2, 3, 128, 128), seed=90)
+    with torch.no_grad():
+        y = VO.encoder(sd, img)
+    assert y.shape == (2, 8, 16, 16) and rel_l2(y.numpy(), g["enc_small_out"]) < 1e-5
