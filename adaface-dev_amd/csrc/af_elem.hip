@@ -66,6 +66,21 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const half_t* __restr
   }
 }
 
+// the VAE encoder's masked attention (model.py:191-209): AFTER the softmax, weights between tokens of different classes are zeroed
+// (no renormalisation): p[i][j] *= ((cls[i] & cls[j]) != 0), cls bit 0 = foreground (fg*aug != 0), bit 1 = background ((1-fg)*aug != 0)
+__global__ __launch_bounds__(256) void mask_pairs_kernel(half_t* __restrict__ p, const unsigned char* __restrict__ cls, int N, long n8) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n8) return;
+  const int per_row = N >> 3;
+  const int row = (int)(i / per_row), c0 = (int)(i - (long)row * per_row) * 8;
+  const unsigned char ci = cls[row];
+  half8_t v = *reinterpret_cast<half8_t*>(p + i * 8);
+#pragma unroll
+  for (int e = 0; e < 8; ++e)
+    if ((cls[c0 + e] & ci) == 0) v[e] = (half_t)0;
+  *reinterpret_cast<half8_t*>(p + i * 8) = v;
+}
+
 __global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, half_t* __restrict__ y, int B, int C, int HW, int cpad) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long n = (long)B * HW * cpad;
@@ -180,6 +195,15 @@ extern "C" int af_softmax_rows(const void* x, void* y, int64_t rows, int L, void
   else if (L <= 2048) hipLaunchKernelGGL(softmax_rows_kernel<4>, grid, blk, 0, s, (const half_t*)x, (half_t*)y, (long)rows, L);
   else hipLaunchKernelGGL(softmax_rows_kernel<8>, grid, blk, 0, s, (const half_t*)x, (half_t*)y, (long)rows, L);
   return af_check_launch("af_softmax_rows");
+}
+
+extern "C" int af_mask_pairs(void* p, const void* cls, int N, void* stream) {
+  AF_REQUIRE(p && cls && N > 0 && N % 8 == 0, "af_mask_pairs: N must be a positive multiple of 8");
+  AfLaunchScope scope(AF_FAM_ELEM, stream);
+  const long n8 = (long)N * (N / 8);
+  hipLaunchKernelGGL(mask_pairs_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (half_t*)p,
+                     (const unsigned char*)cls, N, n8);
+  return af_check_launch("af_mask_pairs");
 }
 
 extern "C" int af_silu_f16(const void* x, void* y, int64_t n, void* stream) {

@@ -102,9 +102,24 @@ class AttnBlock(nn.Module):
             self._qs_key = key
         return self._qs
 
-    def hip(self, x):
+    @staticmethod
+    def pair_classes(mask, H, W):
+        """mask dict {'aug_mask', 'fg_mask'} ([B,1,h,w] or None) -> uint8 [B, H*W]: bit 0 = fg*aug != 0, bit 1 = (1-fg)*aug != 0,
+        nearest-resized to the feature map (model.py:192-201); None when fg_mask is absent (the reference then ignores masks)."""
+        if mask is None or mask.get("fg_mask") is None:
+            return None
+        import torch.nn.functional as F
+        fg = F.interpolate(mask["fg_mask"].float(), size=(H, W), mode="nearest")
+        aug = mask.get("aug_mask")
+        aug = torch.ones_like(fg) if aug is None else F.interpolate(aug.float(), size=(H, W), mode="nearest")
+        # the reference tests fg_i*fg_j != 0 or bg_i*bg_j != 0 per pair: (cls_i & cls_j) != 0 with these two bits
+        cls = (fg * aug != 0).to(torch.uint8) + 2 * ((1 - fg) * aug != 0).to(torch.uint8)
+        return cls.reshape(cls.shape[0], H * W).to(torch.uint8).contiguous()
+
+    def hip(self, x, mask=None):
         B, H, W, C = x.shape
         N = H * W
+        cls = self.pair_classes(mask, H, W)
         if N % 8 != 0 or N > 4096:
             raise NotImplementedError(f"VAE attention over {N} tokens (af_softmax_rows holds rows up to 4096)")
         hn = self.norm.hip(x).reshape(B * N, C)
@@ -119,6 +134,8 @@ class AttnBlock(nn.Module):
         for b in range(B):                                                        # one image at a time: [N, N] scores = 32 MB at 64x64
             kb = ops.PackedWeight(k[b * N:(b + 1) * N], None, N, C, C, 1, C)      # keys as the "weight" [N, C], K-contiguous
             p = ops.softmax_rows(ops.gemm(q[b * N:(b + 1) * N], kb))
+            if cls is not None:
+                ops.mask_pairs_(p, cls[b].to(x.device))
             vb = ops.PackedWeight(vt[b], None, C, N, N, 1, N)                     # V^T [C, N]
             out[b * N:(b + 1) * N] = ops.gemm(p, vb)
         y = ops.gemm(out, self.proj_out.packed(), residual=x.reshape(B * N, C))
@@ -199,7 +216,7 @@ class Decoder(nn.Module):
 
 
 class Encoder(nn.Module):
-    """Reference ``Encoder`` (model.py:408-500) without attention masks: image [B,3,H,W] -> moments [B, 2*z_channels, H/8, W/8]."""
+    """Reference ``Encoder`` (model.py:408-500) incl. the fg / aug attention masks of the mid block: image [B,3,H,W] -> moments [B, 2*z_channels, H/8, W/8]."""
 
     def __init__(self, *, ch, out_ch, ch_mult=(1, 2, 4, 8), num_res_blocks, attn_resolutions, dropout=0.0, resamp_with_conv=True,
                  in_channels, resolution, z_channels, double_z=True, use_linear_attn=False, attn_type="vanilla", **ignore_kwargs):
@@ -237,28 +254,26 @@ class Encoder(nn.Module):
         self.out_channels = 2 * z_channels if double_z else z_channels
         self.conv_out = Conv2d(block_in, self.out_channels, kernel_size=3, stride=1, padding=1)
 
-    def hip(self, x):
+    def hip(self, x, mask=None):
         """x [B,H,W,roundup(in_channels,8)] fp16 -> [B,H/8,W/8,out_channels] fp16 (out_channels % 8 == 0 for double_z z=4)."""
         h = self.conv_in.hip(x)
         for i_level in range(self.num_resolutions):
             for i_block in range(self.num_res_blocks):
                 h = self.down[i_level].block[i_block].hip(h)
                 if len(self.down[i_level].attn) > 0:
-                    h = self.down[i_level].attn[i_block].hip(h)
+                    h = self.down[i_level].attn[i_block].hip(h, mask)
             if i_level != self.num_resolutions - 1:
                 h = self.down[i_level].downsample.hip(h)
         h = self.mid.block_1.hip(h)
-        h = self.mid.attn_1.hip(h)
+        h = self.mid.attn_1.hip(h, mask)
         h = self.mid.block_2.hip(h)
         return self.conv_out.hip(self.norm_out.hip(h, silu=True))
 
     def forward(self, x, mask=None):
-        if mask is not None:
-            raise NotImplementedError("masked encoder attention (fg / aug masks, model.py:191-209) is not built")
         _require_cuda(self.conv_in.weight, "VAE Encoder")
         if self.out_channels % 8 != 0:
             raise NotImplementedError("encoder output channels must be a multiple of 8 (double_z with z_channels = 4)")
-        y = self.hip(to_nhwc_f16(x, ops.round_up(x.shape[1], 8)))
+        y = self.hip(to_nhwc_f16(x, ops.round_up(x.shape[1], 8)), mask)
         return from_nhwc_f16(y, x.dtype, self.out_channels)
 
 

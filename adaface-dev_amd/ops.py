@@ -525,6 +525,13 @@ def softmax_rows(x):
     return y
 
 
+def mask_pairs_(p, cls):
+    """In place: p [N, N] fp16 *= ((cls[i] & cls[j]) != 0); cls uint8 [N] (bit 0 foreground, bit 1 background)."""
+    assert p.shape[0] == p.shape[1] == cls.numel() and cls.dtype == torch.uint8
+    _lib.check(_lib.lib().af_mask_pairs(_p(p), _p(cls), p.shape[0], _stream()), "af_mask_pairs")
+    return p
+
+
 # ----------------------------------------------------------------------------- trainable DoRA adapters
 def dora_combine(y0, c2, lb, u, v):
     """y0 + u[c] * c2 + v[c] * lb over the last (channel) axis; u, v fp32 [C]."""

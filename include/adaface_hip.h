@@ -246,6 +246,8 @@ int af_clamp_f32(void* a, float lo, float hi, int64_t n, void* stream);
 /* ---- VAE decoder (ldm/modules/diffusionmodules/model.py:151-243 AttnBlock): row softmax of an explicit fp16 score matrix
  * [rows, L], L % 8 == 0, L <= 4096 (single-head 512-dim attention runs as af_gemm -> af_softmax_rows -> af_gemm) */
 int af_softmax_rows(const void* x, void* y, int64_t rows, int L, void* stream);
+/* masked VAE-encoder attention (model.py:191-209): p fp16 [N, N] (post-softmax) *= ((cls[i] & cls[j]) != 0); cls uint8 [N]: bit 0 fg*aug != 0, bit 1 (1-fg)*aug != 0 */
+int af_mask_pairs(void* p, const void* cls, int N, void* stream);
 
 /* ---- ArcFace ResNetFace-18 IR-SE face encoder (reference evaluation/arcface_resnet.py:62-97, 139-154, 157-217) ----
  * NHWC fp16 activations, C % 8 == 0.  Convolutions / FCs are af_gemm calls with eval-mode BatchNorm folded on the host.

@@ -391,6 +391,17 @@ def gen_arcface(out):
 VAE_SMALL = dict(ch=32, out_ch=3, ch_mult=(1, 2, 4, 4), num_res_blocks=2, attn_resolutions=[], dropout=0.0, in_channels=3, resolution=128, z_channels=4)
 
 
+def vae_test_masks(r):
+    """Deterministic fg / aug masks for the masked-encoder vectors (also used by the tests)."""
+    import torch
+    fg = torch.zeros(2, 1, r, r)
+    fg[0, :, r // 4: 3 * r // 4, r // 4: 3 * r // 4] = 1
+    fg[1, :, :, : r // 2] = 1
+    aug = torch.ones(2, 1, r, r)
+    aug[1, :, : r // 8] = 0
+    return fg, aug
+
+
 def gen_vae(out):
     """The REFERENCE's VAE Decoder (ldm/modules/diffusionmodules/model.py:502-608) at reduced width (ch 32 -> 128 channels at the
     latent level, 16x16 latent -> 128x128 image, 256-token mid attention): full output + the mid / first-up-level features, and the
@@ -427,7 +438,12 @@ def gen_vae(out):
             p.copy_(rng.synth_tensor("encoder." + n, p.shape, seed=90))
         img = rng.synth_input("vae.img.small", (2, 3, 128, 128), seed=90)
         d["enc_small_out"] = e(img).numpy()
-    print("vae encoder", d["enc_small_out"].shape, float(np.abs(d["enc_small_out"]).mean()))
+        # masked mid-block attention (model.py:191-232): fg / aug masks built by tests/trainer_util-free arithmetic below
+        fg, aug = vae_test_masks(128)
+        d["enc_small_masked_out"] = e(img, {"fg_mask": fg, "aug_mask": aug}).numpy()
+        d["enc_small_fgonly_out"] = e(img, {"fg_mask": fg, "aug_mask": None}).numpy()
+    print("vae encoder", d["enc_small_out"].shape, float(np.abs(d["enc_small_out"]).mean()),
+          "masked delta", float(np.abs(d["enc_small_masked_out"] - d["enc_small_out"]).mean()))
     np.savez_compressed(os.path.join(out, "vae.npz"), **d)
 
 

@@ -127,3 +127,34 @@ def test_conv3x3_tap_shift_is_asymmetric_padding(dev, B, H, W, cin, cout):
     y = ops.conv3x3(xh, ops.pack_conv3x3(w, b, dev), stride=2, tap_shift=1)
     y = y[:, :ref.shape[2], :ref.shape[3]]
     assert rel_l2(y.float().cpu().permute(0, 3, 1, 2).numpy(), ref.numpy()) < 2e-3
+
+
+def test_encoder_masked_attention_vs_reference(dev):
+    """fg / aug masks zero the post-softmax weights between foreground and background tokens (model.py:191-232): af_mask_pairs on
+    the [N, N] probabilities, against the REFERENCE Encoder's masked outputs; fractional masks against the oracle."""
+    from adaface_dev_amd import rng
+    from adaface_dev_amd.ldm.modules.diffusionmodules.model import Encoder
+    from oracle import vae_oracle as VO
+    from test_vae_oracle import vae_test_masks
+    g = np.load(os.path.join(GOLDEN, "vae.npz"))
+    e = Encoder(**dict(VAE_SMALL, double_z=True))
+    with torch.no_grad():
+        for n, p in e.named_parameters():
+            p.copy_(rng.synth_tensor("encoder." + n, p.shape, seed=90))
+    sd = {"encoder." + n: p.detach().clone() for n, p in e.named_parameters()}
+    e = e.to(dev).eval()
+    img = rng.synth_input("vae.img.small", (2, 3, 128, 128), seed=90)
+    fg, aug = vae_test_masks(128)
+    with torch.no_grad():
+        ym = e(img.to(dev), {"fg_mask": fg.to(dev), "aug_mask": aug.to(dev)}).cpu().numpy()
+        yf = e(img.to(dev), {"fg_mask": fg, "aug_mask": None}).cpu().numpy()
+        yn = e(img.to(dev), {"fg_mask": None, "aug_mask": aug}).cpu().numpy()
+    errs = rel_l2(ym, g["enc_small_masked_out"]), rel_l2(yf, g["enc_small_fgonly_out"]), rel_l2(yn, g["enc_small_out"])
+    print("masked VAE encoder rel-L2 vs reference (fg+aug, fg only, aug only):", ["%.2e" % v for v in errs])
+    assert max(errs) < 1e-2 and rel_l2(ym, g["enc_small_out"]) > 1e-2
+    # fractional masks: a pixel with 0 < fg < 1 is both foreground and background (bit mask 3)
+    fgf = torch.rand(2, 1, 128, 128, generator=torch.Generator().manual_seed(3)).round(decimals=0) * 0.5 + fg * 0.5
+    with torch.no_grad():
+        want = VO.encoder(sd, img, mask={"fg_mask": fgf, "aug_mask": aug})
+        got = e(img.to(dev), {"fg_mask": fgf, "aug_mask": aug}).cpu().numpy()
+    assert rel_l2(got, want.numpy()) < 1e-2

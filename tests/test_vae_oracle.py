@@ -12,6 +12,16 @@ from oracle import vae_oracle as VO
 VAE_SMALL = dict(ch=32, out_ch=3, ch_mult=(1, 2, 4, 4), num_res_blocks=2, attn_resolutions=[], dropout=0.0, in_channels=3, resolution=128, z_channels=4)
 
 
+def vae_test_masks(r):
+    """The masks tests/golden/gen_golden.py::vae_test_masks built the masked-encoder vectors with."""
+    fg = torch.zeros(2, 1, r, r)
+    fg[0, :, r // 4: 3 * r // 4, r // 4: 3 * r // 4] = 1
+    fg[1, :, :, : r // 2] = 1
+    aug = torch.ones(2, 1, r, r)
+    aug[1, :, : r // 8] = 0
+    return fg, aug
+
+
 def _probes(t):
     f = t.detach().float().reshape(-1)
     idx = (torch.arange(64, dtype=torch.int64) * 2654435761) % f.numel()
@@ -73,3 +83,12 @@ def test_vae_encoder_oracle_vs_reference_reduced_width():
     with torch.no_grad():
         y = VO.encoder(sd, img)
     assert y.shape == (2, 8, 16, 16) and rel_l2(y.numpy(), g["enc_small_out"]) < 1e-5
+    # masked mid-block attention (model.py:191-232), pinned on the reference Encoder's own masked outputs
+    fg, aug = vae_test_masks(128)
+    with torch.no_grad():
+        ym = VO.encoder(sd, img, mask={"fg_mask": fg, "aug_mask": aug})
+        yf = VO.encoder(sd, img, mask={"fg_mask": fg, "aug_mask": None})
+        yn = VO.encoder(sd, img, mask={"fg_mask": None, "aug_mask": aug})           # no fg mask: the reference ignores aug
+    assert rel_l2(ym.numpy(), g["enc_small_masked_out"]) < 1e-5
+    assert rel_l2(yf.numpy(), g["enc_small_fgonly_out"]) < 1e-5
+    assert rel_l2(ym.numpy(), g["enc_small_out"]) > 1e-2 and torch.equal(yn, y)
