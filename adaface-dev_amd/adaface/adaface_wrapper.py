@@ -67,18 +67,18 @@ class WordTokenizer:
     def _lower_keep_added(self, text):
         return " ".join(w if w in self.added else w.lower() for w in text.split())
 
-    def __call__(self, texts, padding="max_length", max_length=77, truncation=True, return_tensors="pt"):
+    def __call__(self, texts, padding="max_length", max_length=77, truncation=True, return_tensors="pt", **unused):
         texts = [texts] if isinstance(texts, str) else list(texts)
         rows = []
         for t in texts:
             ids = [CLIP_BOS] + [self._id(w) for w in self.tokenize(t)][:max_length - 2] + [CLIP_EOS]
             rows.append(ids + [CLIP_EOS] * (max_length - len(ids)))
+        return _Encoding(input_ids=torch.tensor(rows, dtype=torch.long))
 
-        class _Out:
-            pass
-        out = _Out()
-        out.input_ids = torch.tensor(rows, dtype=torch.long)
-        return out
+
+class _Encoding(dict):
+    """transformers' BatchEncoding protocol: enc["input_ids"] and enc.input_ids."""
+    __getattr__ = dict.__getitem__
 
 
 class AdaFaceWrapper(nn.Module):

@@ -233,18 +233,43 @@ class CLIPTextModelWrapper(nn.Module):
         self.text_model.embeddings.position_embedding = new
         self.config.max_position_embeddings = max_length
 
-    def extend_clip_attention_MKV_multiplier(self, begin_layer_idx=-1, end_layer_idx=-1, multiplier=2, perturb_std=0.1,
-                                             perturb_std_is_relative=True, perturb_keep_norm=False, verbose=False):
-        """Widen K/V of encoder layers [begin, end] (reference arc2face_models.py:343-382)."""
+    def extend_clip_attention_MKV_multiplier(self, prompt2token_proj_attention_multipliers=None, perturb_std=0.1,
+                                             perturb_std_is_relative=True, perturb_keep_norm=False, verbose=False,
+                                             begin_layer_idx=None, end_layer_idx=None, multiplier=None):
+        """Widen K/V of every encoder layer whose entry in the per-layer list is not 1 (reference arc2face_models.py:343-360).
+        ``begin_layer_idx / end_layer_idx / multiplier`` build that list for an inclusive layer range."""
         layers = self.text_model.encoder.layers
         n = len(layers)
-        if begin_layer_idx < 0:
-            begin_layer_idx += n
-        if end_layer_idx < 0:
-            end_layer_idx += n
-        for i in range(begin_layer_idx, end_layer_idx + 1):
+        mults = prompt2token_proj_attention_multipliers
+        if mults is None:
+            b = 0 if begin_layer_idx in (None, -1) else begin_layer_idx % n
+            e = n - 1 if end_layer_idx in (None, -1) else end_layer_idx % n
+            mults = [multiplier if b <= i <= e else 1 for i in range(n)]
+        extended = 0
+        for i, m in enumerate(mults):
+            if m == 1:
+                continue
             old = layers[i].self_attn
             new = CLIPAttentionMKV(self.config, multiplier=old.multiplier).to(device=old.q_proj.weight.device)
-            new.extend_weights(old, i, multiplier, perturb_std, perturb_std_is_relative, perturb_keep_norm, verbose)
+            new.extend_weights(old, i, m, perturb_std, perturb_std_is_relative, perturb_keep_norm, verbose)
             layers[i].self_attn = new
-        return n
+            extended += 1
+        return extended
+
+    def squeeze_clip_attention_MKV_divisor(self, prompt2token_proj_attention_divisors):
+        """Inverse of the extension: average groups of K/V copies (reference arc2face_models.py:365-382)."""
+        layers = self.text_model.encoder.layers
+        squeezed = 0
+        for i, dv in enumerate(prompt2token_proj_attention_divisors):
+            if dv == 1:
+                continue
+            old = layers[i].self_attn
+            new = CLIPAttentionMKV(self.config, multiplier=old.multiplier).to(device=old.q_proj.weight.device)
+            with torch.no_grad():
+                for nm in ("q_proj", "out_proj"):
+                    getattr(new, nm).weight.data = getattr(old, nm).weight.data.clone()
+                    getattr(new, nm).bias.data = getattr(old, nm).bias.data.clone()
+            new.squeeze_weights(old, dv)
+            layers[i].self_attn = new
+            squeezed += 1
+        return squeezed

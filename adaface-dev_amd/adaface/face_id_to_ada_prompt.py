@@ -18,8 +18,13 @@ class Arc2Face_ID2AdaPrompt(nn.Module):
     name = "arc2face"
 
     def __init__(self, subj_basis_generator=None, text_to_image_prompt_encoder=None, out_id_embs_cfg_scale=1.0,
-                 num_static_img_suffix_embs=0, clip_config=None, tokenizer=None):
+                 num_static_img_suffix_embs=0, clip_config=None, tokenizer=None, subject_string="z", adaface_ckpt_path=None,
+                 extend_prompt2token_proj_attention_multiplier=1, prompt2token_proj_ext_attention_perturb_ratio=0.1):
         super().__init__()
+        self.subject_string = subject_string
+        self.output_dim = 768
+        self.extend_prompt2token_proj_attention_multiplier = extend_prompt2token_proj_attention_multiplier
+        self.prompt2token_proj_ext_attention_perturb_ratio = prompt2token_proj_ext_attention_perturb_ratio
         self.num_id_vecs = self.num_id_vecs0 = 16
         self.id_img_prompt_max_length = 22
         self.num_static_img_suffix_embs = num_static_img_suffix_embs
@@ -33,6 +38,46 @@ class Arc2Face_ID2AdaPrompt(nn.Module):
             p.requires_grad_(False)
         self.subj_basis_generator = subj_basis_generator or SubjBasisGenerator(
             num_id_vecs=self.num_id_vecs, num_static_img_suffix_embs=num_static_img_suffix_embs, clip_config=cfg, tokenizer=tokenizer)
+
+        if adaface_ckpt_path is not None:
+            self.load_adaface_ckpt(adaface_ckpt_path)
+
+    def load_adaface_ckpt(self, adaface_ckpt_path):
+        """Load ``subj_basis_generator`` from an ``embeddings_gs-N.pt`` checkpoint (reference :109-162): the K/V widths of the
+        checkpointed prompt2token_proj are reproduced first, then the state dict is copied, then the configured extra widening."""
+        from .ckpt import load_adaface_ckpt_file, module_state_dict
+        if isinstance(adaface_ckpt_path, (list, tuple)):
+            adaface_ckpt_path = adaface_ckpt_path[0]
+        ckpt = load_adaface_ckpt_file(adaface_ckpt_path.split(":")[0])
+        gens = ckpt["string_to_subj_basis_generator_dict"]
+        if self.subject_string not in gens:
+            raise KeyError(f"Subject '{self.subject_string}' not found in {adaface_ckpt_path}")
+        g = gens[self.subject_string]
+        if isinstance(g, (nn.ModuleList, list, tuple)):
+            g = g[{"consistentID": 0, "arc2face": 1}[self.name]]
+        sd = dict(module_state_dict(g))
+        sbg = self.subj_basis_generator
+        n_layers = len(sbg.prompt2token_proj.text_model.encoder.layers)
+        mults = getattr(g, "prompt2token_proj_attention_multipliers", None)
+        if mults is None:                                   # plain state dict: read the widths off the k_proj shapes
+            e = sbg.prompt2token_proj.config.hidden_size
+            mults = [sd[f"prompt2token_proj.text_model.encoder.layers.{i}.self_attn.k_proj.weight"].shape[0] // e
+                     for i in range(n_layers)]
+        rel = [int(m) // int(c) for m, c in zip(mults, sbg.prompt2token_proj_attention_multipliers)]
+        sbg.extend_prompt2token_proj_attention(rel, -1, -1, 1, perturb_std=0)
+        if sbg.N_SFX == 0:
+            sd.pop("static_img_suffix_embs", None)
+        elif "static_img_suffix_embs" in sd and sd["static_img_suffix_embs"].shape[1] != sbg.N_SFX:
+            n = min(sd["static_img_suffix_embs"].shape[1], sbg.N_SFX)       # reference initialize_static_img_suffix_embs: keep the overlap
+            new = sbg.static_img_suffix_embs.detach().clone()
+            new[:, :n] = sd["static_img_suffix_embs"][:, :n]
+            sd["static_img_suffix_embs"] = new
+        ret = sbg.load_state_dict(sd, strict=False)
+        if self.extend_prompt2token_proj_attention_multiplier > 1:
+            sbg.extend_prompt2token_proj_attention(None, -1, -1, self.extend_prompt2token_proj_attention_multiplier,
+                                                   perturb_std=self.prompt2token_proj_ext_attention_perturb_ratio)
+        sbg.freeze_prompt2token_proj()
+        return ret
 
     @property
     def dtype(self):

@@ -70,6 +70,36 @@ class SubjBasisGenerator(nn.Module):
         for p in self.prompt2token_proj.text_model.embeddings.parameters():
             p.requires_grad_(False)
 
+    def extend_prompt2token_proj_attention(self, prompt2token_proj_attention_multipliers=None, begin_layer_idx=-1, end_layer_idx=-1,
+                                           multiplier=1, perturb_std=0.1):
+        """Widen the K/V projections of prompt2token_proj layers (reference :791-815); multipliers are relative to the current state."""
+        n = len(self.prompt2token_proj.text_model.encoder.layers)
+        b = 0 if begin_layer_idx == -1 else begin_layer_idx
+        e = n - 1 if end_layer_idx == -1 else end_layer_idx
+        if prompt2token_proj_attention_multipliers is None:
+            if multiplier == 1:
+                return 0
+            prompt2token_proj_attention_multipliers = [multiplier if b <= i <= e else 1 for i in range(n)]
+        done = self.prompt2token_proj.extend_clip_attention_MKV_multiplier(list(prompt2token_proj_attention_multipliers), perturb_std)
+        for i in range(b, e + 1):
+            self.prompt2token_proj_attention_multipliers[i] *= prompt2token_proj_attention_multipliers[i]
+        return done
+
+    def squeeze_prompt2token_proj_attention(self, prompt2token_proj_attention_divisors=None, begin_layer_idx=-1, end_layer_idx=-1,
+                                            divisor=1):
+        """Reference :817-841."""
+        n = len(self.prompt2token_proj.text_model.encoder.layers)
+        b = 0 if begin_layer_idx == -1 else begin_layer_idx
+        e = n - 1 if end_layer_idx == -1 else end_layer_idx
+        if prompt2token_proj_attention_divisors is None:
+            if divisor == 1:
+                return 0
+            prompt2token_proj_attention_divisors = [divisor if b <= i <= e else 1 for i in range(n)]
+        done = self.prompt2token_proj.squeeze_clip_attention_MKV_divisor(list(prompt2token_proj_attention_divisors))
+        for i in range(b, e + 1):
+            self.prompt2token_proj_attention_multipliers[i] //= prompt2token_proj_attention_divisors[i]
+        return done
+
     def _template(self, bs, device):
         if self.tokenizer is not None:
             ids = self.tokenizer(["photo of a " + ", " * (self.N_ID + 2)] * bs, truncation=True, padding="max_length",

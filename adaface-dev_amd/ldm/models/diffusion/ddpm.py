@@ -132,6 +132,10 @@ class LatentDiffusion(nn.Module):
         self.first_stage_model = None   # AutoencoderKLDecoder (instantiate_first_stage); VAE scale factor of SD-1.5:
         self.scale_factor = 0.18215
         self.unet_teacher = None     # adaface.unet_teachers.UNetTeacher (frozen)
+        self.cond_stage_model = None    # FrozenCLIPEmbedder (instantiate_cond_stage)
+        self.embedding_manager = None   # EmbeddingManager (instantiate_embedding_manager)
+        self.iter_flags = {"do_comp_feat_distill": False, "do_unet_distill": False}
+        self.num_id_vecs, self.num_static_img_suffix_embs = 16, 0
         self.register_schedule(beta_schedule=beta_schedule, timesteps=timesteps, linear_start=linear_start,
                                linear_end=linear_end, cosine_s=cosine_s)
 
@@ -163,6 +167,72 @@ class LatentDiffusion(nn.Module):
         reg("posterior_log_variance_clipped", np.log(np.maximum(posterior_variance, 1e-20)))
         reg("posterior_mean_coef1", betas * np.sqrt(alphas_cumprod_prev) / (1.0 - alphas_cumprod))
         reg("posterior_mean_coef2", (1.0 - alphas_cumprod_prev) * np.sqrt(alphas) / (1.0 - alphas_cumprod))
+
+    # ------------------------------------------------------------------ text conditioning
+    def instantiate_cond_stage(self, config=None):
+        """The hooked, frozen CLIP text encoder (reference ddpm.py:705-710, 612-617).  ``config``: a ``FrozenCLIPEmbedder`` or its
+        constructor kwargs (the yaml's ``cond_stage_config.params``)."""
+        from ...modules.encoders.modules import FrozenCLIPEmbedder
+        m = config if isinstance(config, nn.Module) else FrozenCLIPEmbedder(**(config or {}))
+        m.initialize_hooks()
+        m.eval()
+        for p in m.parameters():
+            p.requires_grad_(False)
+        self.cond_stage_model = m
+        return m
+
+    def instantiate_embedding_manager(self, config=None, text_embedder=None):
+        """Reference ddpm.py:712-733: the manager shares the U-Net's LoRA modules for checkpointing / parameter groups."""
+        from ...modules.embedding_manager import EmbeddingManager
+        text_embedder = text_embedder or self.cond_stage_model
+        if text_embedder is None:
+            raise RuntimeError("instantiate_cond_stage() first: the embedding manager needs the text encoder's tokenizer")
+        if isinstance(config, nn.Module):
+            m = config
+        else:
+            kw = dict(config or {})
+            kw.setdefault("subject_strings", ["z"])
+            kw.setdefault("unet_lora_modules", self.model.unet_lora_modules if len(self.model.unet_lora_modules) > 0 else None)
+            m = EmbeddingManager(text_embedder, **kw)
+        self.embedding_manager = m
+        self.num_id_vecs = m.id2ada_prompt_encoder.num_id_vecs
+        self.num_static_img_suffix_embs = m.id2ada_prompt_encoder.num_static_img_suffix_embs
+        return m
+
+    def get_text_conditioning(self, cond_in, subj_id2img_prompt_embs=None, clip_bg_features=None, randomize_clip_weights=False,
+                              return_prompt_embs_type="text", text_conditioning_iter_type=None, real_batch_size=-1):
+        """list of prompts -> cond_context ``(prompt_embeddings [B,T,768], cond_in, extra_info)`` (reference ddpm.py:739-853): the
+        embedding manager patches the subject tokens inside the text encoder's embedding step; in training, class strings found
+        in class prompts are merged into one token so that they line up with the subject token of the paired prompt."""
+        from ...util import merge_cls_token_embeddings
+        if self.cond_stage_model is None or self.embedding_manager is None:
+            raise RuntimeError("instantiate_cond_stage() and instantiate_embedding_manager() first")
+        self.cond_stage_model.device = self.device
+        if randomize_clip_weights:
+            self.cond_stage_model.sample_last_layers_skip_weights()
+        if text_conditioning_iter_type is None:
+            text_conditioning_iter_type = ("compos_distill_iter" if self.iter_flags["do_comp_feat_distill"] else
+                                           "unet_distill_iter" if self.iter_flags["do_unet_distill"] else "recon_iter")
+        em = self.embedding_manager
+        em.set_image_prompts_and_iter_type(subj_id2img_prompt_embs, clip_bg_features, text_conditioning_iter_type, real_batch_size)
+        prompt_embeddings = self.cond_stage_model.encode(cond_in, embedding_manager=em)
+        if self.training:
+            prompt_embeddings = merge_cls_token_embeddings(prompt_embeddings, em.cls_delta_string_indices)
+        if return_prompt_embs_type in ("id", "text_id"):
+            if text_conditioning_iter_type == "plain_text_iter" and subj_id2img_prompt_embs is None:
+                subj_id2img_prompt_embs = (prompt_embeddings[:, :self.num_id_vecs] if return_prompt_embs_type == "id"
+                                           else prompt_embeddings[:, -self.num_id_vecs:])
+            elif subj_id2img_prompt_embs is not None:
+                assert subj_id2img_prompt_embs.shape[1] == self.num_id_vecs + self.num_static_img_suffix_embs
+                subj_id2img_prompt_embs = subj_id2img_prompt_embs.repeat(len(cond_in) // subj_id2img_prompt_embs.shape[0], 1, 1)
+            if return_prompt_embs_type == "id":
+                prompt_embeddings = subj_id2img_prompt_embs
+            else:
+                prompt_embeddings = torch.cat([prompt_embeddings, subj_id2img_prompt_embs.to(prompt_embeddings.dtype)], dim=1)
+        extra_info = {"placeholder2indices": copy.copy(em.placeholder2indices), "prompt_emb_mask": copy.copy(em.prompt_emb_mask),
+                      "prompt_pad_mask": copy.copy(em.prompt_pad_mask), "capture_ca_activations": False, "use_attn_lora": False,
+                      "use_ffn_lora": False}
+        return (prompt_embeddings, cond_in, extra_info)
 
     def instantiate_first_stage(self, ddconfig=None, embed_dim=4):
         """The first-stage VAE (reference instantiate_first_stage ddpm.py:698-704; frozen, eval): encoder + decoder."""

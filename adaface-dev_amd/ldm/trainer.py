@@ -110,6 +110,12 @@ class DistillTrainer:
         n_id = self.id2ada.subj_basis_generator.N_ID
         return template_ids(["a", "photo", "of"] + [","] * n_id, self.prompt_len, device).repeat(bs, 1)
 
+    def subject_prompt(self, subject_string="z", filler=","):
+        """"a photo of z, , , ..." -- the subject token followed by K - 1 filler tokens, as the reference's dataset writes its
+        captions (ldm/data/personalized.py) so that the embedding manager finds K slots."""
+        n_id = self.id2ada.subj_basis_generator.N_ID
+        return "a photo of " + subject_string + (filler + " ") * (n_id - 1)
+
     def get_text_conditioning(self, adaface_embs, input_ids=None):
         """AdaFace token embeddings -> prompt embeddings [B, T, 768] through the frozen text encoder (the minimal form of
         reference get_text_conditioning ddpm.py:739-853 + EmbeddingManager token patching embedding_manager.py:236-421)."""
@@ -150,9 +156,21 @@ class DistillTrainer:
         with torch.no_grad():
             _, _, id2img = self.id2ada.get_img_prompt_embs(batch["face_id_embs"][sel], id_batch_size=half)[:3]
         id2img = id2img.float()
-        ada = self.id2ada.subj_basis_generator(id2img, out_id_embs_cfg_scale=self.id2ada.out_id_embs_cfg_scale, is_face=True)
-        ctx = self.get_text_conditioning(ada.float())
-        cond = (ctx, ["a photo of z"] * half, {})
+        em = getattr(self.ldm, "embedding_manager", None)
+        if em is not None:
+            # the reference's conditioning path (ddpm.py:739-853): prompts -> hooked text encoder, the embedding manager generates
+            # the ada embeddings inside the embedding step and patches them over "z, , , ..." (last-2-layers skip weights included)
+            if em.id2ada_prompt_encoder is not self.id2ada:
+                raise RuntimeError("the embedding manager must wrap the trainer's ID->prompt encoder (its parameters are the ones optimised)")
+            prompts = batch.get("caption")
+            prompts = list(prompts[sel]) if prompts is not None else [self.subject_prompt()] * half
+            self.ldm.iter_flags["do_unet_distill"] = True
+            cond = self.ldm.get_text_conditioning(prompts, subj_id2img_prompt_embs=id2img, text_conditioning_iter_type="unet_distill_iter",
+                                                  real_batch_size=half)
+        else:
+            ada = self.id2ada.subj_basis_generator(id2img, out_id_embs_cfg_scale=self.id2ada.out_id_embs_cfg_scale, is_face=True)
+            ctx = self.get_text_conditioning(ada.float())
+            cond = (ctx, ["a photo of z"] * half, {})
         loss = self.ldm.calc_unet_distill_loss(x_start, noise, cond, self.teacher_context(id2img), img_mask, fg_mask, steps,
                                                t=t, presampled=presampled)
         return loss * self.unet_distill_weight

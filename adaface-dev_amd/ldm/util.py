@@ -46,3 +46,118 @@ def set_seed_per_rank_and_batch(rank, epoch, iteration, base_seed=42):
     np.random.seed(seed + 1)
     random.seed(seed + 2)
     return seed
+
+
+# ----------------------------------------------------------------------------- prompt-token bookkeeping (embedding manager)
+# Host-side index arithmetic on [B, 77] token-id tensors: restated from the reference helpers with the same results; the
+# reference's ``breakpoint()`` guards are ValueErrors here.
+def split_indices_by_instance(indices, as_dict=False):
+    """(B idx, N idx) -> per-instance groups, instances in ascending order (reference ldm/util.py:1051-1058)."""
+    b, n = indices
+    groups = [(int(u), b == u) for u in torch.unique(b)]
+    if as_dict:
+        return {u: n[sel] for u, sel in groups}
+    return [(b[sel], n[sel]) for _, sel in groups]
+
+
+def extract_first_index_in_each_instance(token_indices):
+    """Keep the first occurrence of a token in every instance that has it (reference ldm/util.py:1384-1394)."""
+    b, n = token_indices
+    order = torch.argsort(b, stable=True)
+    bs, ns = b[order], n[order]
+    first = torch.ones_like(bs, dtype=torch.bool)
+    first[1:] = bs[1:] != bs[:-1]
+    return bs[first], ns[first]
+
+
+def scan_cls_delta_strings(tokenized_text, placeholder_indices_1st, subj_name_to_cls_delta_tokens, MAX_SEARCH_SPAN=5):
+    """In a batch whose first half holds the subject token and whose second half holds class prompts, find where the class
+    string (e.g. "young woman": 2 tokens) starts in every class prompt, searching MAX_SEARCH_SPAN tokens from the slot of the
+    paired subject token.  -> [(batch_i, start_N, num_tokens, subj_name)]  (reference ldm/util.py:616-678)."""
+    if not subj_name_to_cls_delta_tokens:
+        return []
+    ph_b, ph_n = placeholder_indices_1st
+    if len(torch.unique(ph_b)) != len(ph_b):
+        raise ValueError("scan_cls_delta_strings: more than one first-occurrence index per instance")
+    BS = tokenized_text.shape[0]
+    if len(ph_b) == BS:
+        return []
+    half = BS // 2
+    if len(ph_b) != half or (ph_b != torch.arange(half, device=tokenized_text.device)).any():
+        raise ValueError("scan_cls_delta_strings: the subject token must occur in exactly the first half of the batch")
+    rows = tokenized_text.tolist()
+    found = []
+    for i in range(half, BS):
+        start0 = int(ph_n[i - half])
+        hit = None
+        for j in range(MAX_SEARCH_SPAN + 1):
+            s = start0 + j
+            for name, toks in subj_name_to_cls_delta_tokens.items():
+                toks = toks.tolist() if torch.is_tensor(toks) else list(toks)
+                if rows[i][s:s + len(toks)] == toks:
+                    hit = (i, s, len(toks), name)
+                    break
+            if hit:
+                break
+        if hit:
+            found.append(hit)
+    return found
+
+
+def merge_cls_token_embeddings(prompt_embedding, cls_delta_string_indices):
+    """Sum the M embeddings of a class string into its first slot and shift the rest of the prompt left by M - 1, so the class
+    token lines up with the subject token of the paired instance (reference ldm/util.py:683-741).  The vacated tail keeps its old
+    values, as in the reference."""
+    if not cls_delta_string_indices:
+        return prompt_embedding
+    out = prompt_embedding.clone()
+    shift = {}
+    for bi, start, M, _name in sorted(cls_delta_string_indices, key=lambda x: (x[0], x[1])):
+        off = shift.get(bi, 0)
+        out[bi, start - off] = prompt_embedding[bi, start:start + M].sum(dim=0)
+        red = off + M - 1
+        if red > 0:
+            out[bi, start - off + 1: -red] = prompt_embedding[bi, start + M:]
+        shift[bi] = red
+    return out
+
+
+def get_clip_tokens_for_string(clip_tokenizer, string, force_single_token=False):
+    """Token ids of `string` without BOS / EOS padding (reference ldm/util.py:867-887)."""
+    enc = clip_tokenizer(string, truncation=True, max_length=77, padding="max_length", return_tensors="pt")
+    tokens = enc["input_ids"] if isinstance(enc, dict) or hasattr(enc, "__getitem__") else enc.input_ids
+    count = int(torch.count_nonzero(tokens - 49407)) - 1
+    if count < 1:
+        raise ValueError(f"No token found in string '{string}'")
+    if force_single_token and count != 1:
+        raise ValueError(f"String '{string}' maps to more than a single token. Please use another string")
+    return tokens[0, 1:1 + count]
+
+
+def get_embeddings_for_clip_tokens(embedder, tokens):
+    """embedder: the text model's embedding module; -> [N, 768] (reference ldm/util.py:898-902)."""
+    return embedder(tokens)[0]
+
+
+def anneal_value(training_percent, final_percent, value_range):
+    """Reference ldm/util.py:1242-1251."""
+    if not -1e-6 <= training_percent <= 1 + 1e-6:
+        raise ValueError("training_percent must lie in [0, 1]")
+    v0, v1 = value_range
+    return v0 + (v1 - v0) * training_percent if training_percent < final_percent else v1
+
+
+def anneal_perturb_embedding(embeddings, training_percent, begin_noise_std_range, end_noise_std_range, perturb_prob,
+                             perturb_std_is_relative=True, keep_norm=False, std_dim=-1, norm_dim=-1, verbose=False):
+    """With probability perturb_prob add Gaussian noise whose (relative) std is drawn uniformly from the annealed range
+    (reference ldm/util.py:1569-1585).  Consumes the global torch RNG in the reference's order: rand(1), rand(1), randn_like."""
+    from ..adaface.util import perturb_tensor
+    if torch.rand(1) > perturb_prob:
+        return embeddings
+    if end_noise_std_range is not None:
+        lb = anneal_value(training_percent, 1, (begin_noise_std_range[0], end_noise_std_range[0]))
+        ub = anneal_value(training_percent, 1, (begin_noise_std_range[1], end_noise_std_range[1]))
+    else:
+        lb, ub = begin_noise_std_range
+    std = torch.rand(1).item() * (ub - lb) + lb
+    return perturb_tensor(embeddings, std, perturb_std_is_relative, keep_norm, std_dim=std_dim, norm_dim=norm_dim)

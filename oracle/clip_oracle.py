@@ -87,3 +87,14 @@ def inverse_img_prompt(sd, cfg, input_ids, face_prompt_embs, layer_weights, n_id
     tok = sd["text_model.embeddings.token_embedding.weight"][input_ids].clone()
     tok[:, 4:4 + n_id] = face_prompt_embs
     return clip_text_forward(sd, cfg, input_ids, tok, layer_weights)[0][:, 4:4 + n_id]
+
+
+def frozen_clip_embedder_forward(sd, cfg, input_ids, token_embs=None, last_layers_skip_weights=(0.5, 0.5)):
+    """The hooked text encoder of the LDM side, ldm/modules/encoders/modules.py: ``embeddings_forward`` (:180-208: token embeddings,
+    possibly patched by the embedding manager, + positions), ``encoder_forward`` (:212-259: all encoder states kept),
+    ``text_model_forward`` (:264-341): ``final_layer_norm(sum_k w_k * states[-K + k])`` with w normalised to sum 1 by
+    ``set_last_layers_skip_weights`` (:424-428); the last weight belongs to the last layer.  None = plain last state."""
+    if last_layers_skip_weights is None:
+        return clip_text_forward(sd, cfg, input_ids, token_embs)[0]
+    w = torch.as_tensor(last_layers_skip_weights, dtype=torch.float32).reshape(-1, 1)
+    return clip_text_forward(sd, cfg, input_ids, token_embs, w / w.sum())[0]

@@ -391,6 +391,71 @@ def gen_arcface(out):
 VAE_SMALL = dict(ch=32, out_ch=3, ch_mult=(1, 2, 4, 4), num_res_blocks=2, attn_resolutions=[], dropout=0.0, in_channels=3, resolution=128, z_channels=4)
 
 
+def gen_embedding_manager(out):
+    """The REFERENCE EmbeddingManager (ldm/modules/embedding_manager.py) and its ldm.util helpers on the prompt cases of
+    tests/em_fixture_util.py.  The manager imports ``adaface.face_id_to_ada_prompt`` (diffusers / insightface: absent), of which it
+    only uses the encoder factory; the factory is replaced by one returning the fixture's fake encoder -- the code under test
+    (token search, slot placement, class-string scan, masks, RNG consumption of the training perturbation) is the reference's."""
+    import types
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import em_fixture_util as U
+    from adaface_dev_amd.adaface.adaface_wrapper import WordTokenizer
+    install_reference_stubs()
+    fake_mod = types.ModuleType("adaface.face_id_to_ada_prompt")
+    holder = {}
+    fake_mod.create_id2ada_prompt_encoder = lambda *a, **k: holder["enc"]
+    pkg = types.ModuleType("adaface")
+    pkg.__path__ = []
+    sys.modules.setdefault("adaface", pkg)
+    sys.modules["adaface.face_id_to_ada_prompt"] = fake_mod
+    import contextlib
+    import io
+    from ldm.modules.embedding_manager import EmbeddingManager
+    import ldm.util as RU
+    d = {}
+    table = U.token_table()
+    for name, (iter_type, subj_names, prompts, id_bs, K, real_bs, training) in U.CASES.items():
+        tok = WordTokenizer()
+        holder["enc"] = U.FakeID2AdaPromptEncoder(num_id_vecs=K)
+        with contextlib.redirect_stdout(io.StringIO()):
+            em = EmbeddingManager(U.text_embedder(tok, table), ["z"], subj_name_to_cls_delta_string={"alice": "young woman", "bob": "man"},
+                                  out_emb_dim=U.E, cls_delta_string="person", adaface_encoder_types=["arc2face"],
+                                  training_perturb_std_range=(0.05, 0.1) if name == "perturbed" else None,
+                                  training_perturb_prob={"unet_distill_iter": 0.6} if name == "perturbed" else None)
+            em.train(training)
+            em.set_curr_batch_subject_names(subj_names)
+            em.set_image_prompts_and_iter_type(None if id_bs is None else U.id_embs(id_bs, K, 5), None, iter_type, real_bs)
+        ids = tok(prompts, max_length=77)["input_ids"]
+        torch.manual_seed(123)
+        patched = em(ids, table[ids])
+        d[name + ".ids"] = ids.numpy()
+        d[name + ".patched"] = patched.numpy()
+        d[name + ".emb_mask"] = em.prompt_emb_mask.numpy()
+        d[name + ".pad_mask"] = em.prompt_pad_mask.numpy()
+        d[name + ".rng_after"] = torch.rand(4).numpy()                       # the perturbation consumed the global RNG identically
+        for k, v in U.flatten_indices(em.placeholder2indices).items():
+            d[f"{name}.p2i.{k}"] = np.zeros((0,)) if v is None else v.numpy()
+        d[name + ".p2i_keys"] = np.array(sorted(em.placeholder2indices.keys()), dtype="U8")
+        cls = em.cls_delta_string_indices
+        d[name + ".cls"] = np.array([[b, s, m] for b, s, m, _ in cls], dtype=np.int64).reshape(-1, 3)
+        d[name + ".cls_names"] = np.array([n for *_, n in cls], dtype="U16")
+        d[name + ".merged"] = RU.merge_cls_token_embeddings(patched, cls).numpy()
+        d[name + ".span"] = np.array(em.CLS_DELTA_STRING_MAX_SEARCH_SPAN)
+        d[name + ".cls_w"] = em.cls_delta_token_weights.numpy()
+        print("embedding_manager", name, ids.shape, "cls", cls, "p2i", {k: (None if v is None else v[0].shape) for k, v in em.placeholder2indices.items()})
+    # helpers on inputs the manager cases do not reach
+    g = torch.Generator().manual_seed(3)
+    b = torch.randint(0, 6, (40,), generator=g)
+    n = torch.randint(0, 77, (40,), generator=g)
+    fb, fn = RU.extract_first_index_in_each_instance((b, n))
+    d["first.b"], d["first.n"], d["first.fb"], d["first.fn"] = b.numpy(), n.numpy(), fb.numpy(), fn.numpy()
+    emb = torch.randn(3, 20, 8, generator=g)
+    multi = [(1, 9, 3, "x"), (1, 3, 2, "y"), (2, 5, 1, "x"), (0, 2, 4, "y")]
+    d["merge.in"], d["merge.out"] = emb.numpy(), RU.merge_cls_token_embeddings(emb, multi).numpy()
+    d["merge.idx"] = np.array([m[:3] for m in multi], dtype=np.int64)
+    np.savez_compressed(os.path.join(out, "embedding_manager.npz"), **d)
+
+
 def vae_test_masks(r):
     """Deterministic fg / aug masks for the masked-encoder vectors (also used by the tests)."""
     import torch
@@ -455,7 +520,7 @@ def main():
     install_reference_stubs()
     torch.set_num_threads(8)
     out = HERE
-    jobs = {"blocks": gen_blocks, "schedule": gen_schedule, "train": gen_train, "clip": gen_clip, "arcface": gen_arcface, "vae": gen_vae, "unet_tiny": gen_unet_tiny, "unet_full": gen_unet_full}
+    jobs = {"embedding_manager": gen_embedding_manager, "blocks": gen_blocks, "schedule": gen_schedule, "train": gen_train, "clip": gen_clip, "arcface": gen_arcface, "vae": gen_vae, "unet_tiny": gen_unet_tiny, "unet_full": gen_unet_full}
     for name, fn in jobs.items():
         if args.only and name != args.only:
             continue

@@ -1,0 +1,166 @@
+"""EmbeddingManager mirror + ldm.util token bookkeeping against fixtures produced by the REFERENCE EmbeddingManager
+(tests/golden/gen_golden.py::gen_embedding_manager): bit-exact for indices / masks / patched embeddings (pure copies), and for the
+training perturbation too because the global RNG is consumed in the reference's order.  CPU only (no kernel is involved)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import em_fixture_util as U
+from conftest import GOLDEN
+
+
+@pytest.fixture(scope="module")
+def golden():
+    return np.load(os.path.join(GOLDEN, "embedding_manager.npz"))
+
+
+def _manager(name, K, table):
+    from adaface_dev_amd.adaface.adaface_wrapper import WordTokenizer
+    from adaface_dev_amd.ldm.modules.embedding_manager import EmbeddingManager
+    tok = WordTokenizer()
+    em = EmbeddingManager(U.text_embedder(tok, table), ["z"], subj_name_to_cls_delta_string={"alice": "young woman", "bob": "man"},
+                          out_emb_dim=U.E, cls_delta_string="person", adaface_encoder_types=["arc2face"],
+                          training_perturb_std_range=(0.05, 0.1) if name == "perturbed" else None,
+                          training_perturb_prob={"unet_distill_iter": 0.6} if name == "perturbed" else None,
+                          id2ada_prompt_encoder=U.FakeID2AdaPromptEncoder(num_id_vecs=K))
+    return tok, em
+
+
+@pytest.mark.parametrize("name", list(U.CASES))
+def test_manager_matches_reference(golden, name):
+    iter_type, subj_names, prompts, id_bs, K, real_bs, training = U.CASES[name]
+    table = U.token_table()
+    tok, em = _manager(name, K, table)
+    em.train(training)
+    em.set_curr_batch_subject_names(subj_names)
+    em.set_image_prompts_and_iter_type(None if id_bs is None else U.id_embs(id_bs, K, 5), None, iter_type, real_bs)
+    ids = tok(prompts, max_length=77)["input_ids"]
+    assert np.array_equal(ids.numpy(), golden[name + ".ids"])
+    torch.manual_seed(123)
+    patched = em(ids, table[ids])
+    assert np.array_equal(patched.numpy(), golden[name + ".patched"])
+    assert np.array_equal(em.prompt_emb_mask.numpy(), golden[name + ".emb_mask"])
+    assert np.array_equal(em.prompt_pad_mask.numpy(), golden[name + ".pad_mask"])
+    assert np.array_equal(torch.rand(4).numpy(), golden[name + ".rng_after"])
+    assert sorted(em.placeholder2indices.keys()) == list(golden[name + ".p2i_keys"])
+    for k, v in U.flatten_indices(em.placeholder2indices).items():
+        assert np.array_equal(v.numpy(), golden[f"{name}.p2i.{k}"])
+    cls = em.cls_delta_string_indices
+    assert np.array_equal(np.array([[b, s, m] for b, s, m, _ in cls], dtype=np.int64).reshape(-1, 3), golden[name + ".cls"])
+    assert [n for *_, n in cls] == list(golden[name + ".cls_names"])
+    from adaface_dev_amd.ldm.util import merge_cls_token_embeddings
+    assert np.array_equal(merge_cls_token_embeddings(patched, cls).numpy(), golden[name + ".merged"])
+    assert int(golden[name + ".span"]) == em.CLS_DELTA_STRING_MAX_SEARCH_SPAN
+    assert np.allclose(em.cls_delta_token_weights.numpy(), golden[name + ".cls_w"])
+    if name == "distill":       # the encoder was asked for the static suffix only in a unet-distill iteration, without dropout in eval
+        assert em.id2ada_prompt_encoder.calls == [dict(bs=2, p_dropout=0, sfx=True)]
+    if name == "compos":        # one subject for the whole batch: the first ID embedding only, repeated over the 2 subject prompts
+        assert em.id2ada_prompt_encoder.calls[0]["bs"] == 1 and em.id2ada_prompt_encoder.calls[0]["sfx"] is False
+
+
+def test_helpers_match_reference(golden):
+    from adaface_dev_amd.ldm.util import extract_first_index_in_each_instance, merge_cls_token_embeddings, split_indices_by_instance
+    b, n = torch.from_numpy(golden["first.b"]), torch.from_numpy(golden["first.n"])
+    fb, fn = extract_first_index_in_each_instance((b, n))                    # unsorted input
+    assert np.array_equal(fb.numpy(), golden["first.fb"]) and np.array_equal(fn.numpy(), golden["first.fn"])
+    groups = split_indices_by_instance((b, n))
+    assert [int(g[0][0]) for g in groups] == sorted(set(b.tolist())) and sum(len(g[0]) for g in groups) == len(b)
+    multi = [tuple(r) + (nm,) for r, nm in zip(golden["merge.idx"].tolist(), ["x", "y", "x", "y"])]
+    out = merge_cls_token_embeddings(torch.from_numpy(golden["merge.in"]), multi)
+    assert np.array_equal(out.numpy(), golden["merge.out"])
+    assert merge_cls_token_embeddings(out, []) is out
+
+
+def test_guards_raise_instead_of_breakpoint():
+    from adaface_dev_amd.ldm.util import get_clip_tokens_for_string, scan_cls_delta_strings
+    from adaface_dev_amd.adaface.adaface_wrapper import WordTokenizer
+    tok = WordTokenizer()
+    with pytest.raises(ValueError):
+        get_clip_tokens_for_string(tok, "young woman", force_single_token=True)
+    with pytest.raises(ValueError):
+        get_clip_tokens_for_string(tok, "")
+    ids = tok(["a z", "a z", "a man", "a man"])["input_ids"]
+    toks = {"bob": get_clip_tokens_for_string(tok, "man")}
+    with pytest.raises(ValueError):       # subject token in instances 0 and 2: not "the first half"
+        scan_cls_delta_strings(ids, (torch.tensor([0, 2]), torch.tensor([2, 2])), toks, 2)
+    assert scan_cls_delta_strings(ids, (torch.tensor([0, 1]), torch.tensor([2, 2])), toks, 2) == [(2, 2, 1, "bob"), (3, 2, 1, "bob")]
+    table = U.token_table()
+    tok, em = _manager("x", 4, table)
+    em.set_image_prompts_and_iter_type(U.id_embs(1, 4, 5), None, "recon_iter", 1)
+    ids = tok(["z , ,"])["input_ids"]                                        # 3 slots for 4 embeddings
+    with pytest.raises(ValueError):
+        em(ids, table[ids])
+
+
+def test_checkpoint_roundtrip_and_reference_class_paths(tmp_path):
+    """save() writes the reference's dict layout; load() restores generator weights, placeholder strings (with the from-to mapping)
+    and the LoRA state dict filters.  A checkpoint whose pickled classes live under the reference's module paths
+    (adaface.subj_basis_generator.*), which are not importable here, loads through the class map of adaface/ckpt.py."""
+    import sys
+    import types
+    import torch.nn as nn
+    from adaface_dev_amd.adaface.ckpt import ShellModule, load_adaface_ckpt_file, module_state_dict
+    table = U.token_table()
+    tok, em = _manager("x", 4, table)
+    loras = nn.ModuleDict({"up_blocks_3_resnets_1_conv1": nn.ModuleDict({"lora_A": nn.ModuleDict({"unet_distill": nn.Linear(4, 2, bias=False),
+                                                                                                "recon_loss": nn.Linear(4, 2, bias=False)})})})
+    em.unet_lora_modules = loras
+    path = str(tmp_path / "embeddings_gs-10.pt")
+    em.save(path)
+    ck = load_adaface_ckpt_file(path)
+    assert set(ck) == {"string_to_subj_basis_generator_dict", "placeholder_strings", "subject_strings", "unet_lora_modules"}
+    assert ck["placeholder_strings"] == ["z"] and list(ck["string_to_subj_basis_generator_dict"].keys()) == ["z"]
+    # load into a fresh manager: LoRA filter keeps only the requested adapter
+    tok2, em2 = _manager("x", 4, table)
+    loras2 = nn.ModuleDict({"up_blocks_3_resnets_1_conv1": nn.ModuleDict({"lora_A": nn.ModuleDict({"unet_distill": nn.Linear(4, 2, bias=False),
+                                                                                                 "recon_loss": nn.Linear(4, 2, bias=False)})})})
+    before = loras2.state_dict()["up_blocks_3_resnets_1_conv1.lora_A.recon_loss.weight"].clone()
+    em2.unet_lora_modules = loras2
+    em2.load([path + ":z-y"], unet_ffn_adapters_to_load=["unet_distill"])
+    assert em2.subject_strings == ["y"] and em2.placeholder_strings == ["y"] and "y" in em2.string_to_token_dict
+    assert em2.id2ada_prompt_encoder.loaded == path + ":z-y"
+    sd1, sd2 = loras.state_dict(), loras2.state_dict()
+    assert torch.equal(sd1["up_blocks_3_resnets_1_conv1.lora_A.unet_distill.weight"], sd2["up_blocks_3_resnets_1_conv1.lora_A.unet_distill.weight"])
+    assert torch.equal(before, sd2["up_blocks_3_resnets_1_conv1.lora_A.recon_loss.weight"])          # filtered out: untouched
+    groups = em2.optimized_parameters(1e-4, 0.0, 2e-4, 0.02)
+    assert len(groups) == 2 and groups[1]["weight_decay"] == 0.02 and len(groups[1]["params"]) == 2
+
+    # a checkpoint pickled from classes under the reference's module names, which disappear before loading
+    pkg, mod = types.ModuleType("adaface"), types.ModuleType("adaface.subj_basis_generator")
+    other = types.ModuleType("adaface.not_mirrored")
+
+    class SubjBasisGenerator(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.N_ID, self.prompt2token_proj_attention_multipliers = 16, [1, 2]
+            self.hidden_state_layer_weights = nn.Parameter(torch.tensor([[1.0], [2.0], [5.0]]))
+            self.helper = Helper()
+
+    class Helper(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = nn.Parameter(torch.arange(3.0))
+
+    SubjBasisGenerator.__module__, SubjBasisGenerator.__qualname__ = "adaface.subj_basis_generator", "SubjBasisGenerator"
+    Helper.__module__, Helper.__qualname__ = "adaface.not_mirrored", "Helper"
+    mod.SubjBasisGenerator, other.Helper = SubjBasisGenerator, Helper
+    saved_modules = {k: sys.modules.get(k) for k in ("adaface", "adaface.subj_basis_generator", "adaface.not_mirrored")}
+    sys.modules.update({"adaface": pkg, "adaface.subj_basis_generator": mod, "adaface.not_mirrored": other})
+    try:
+        ref_path = str(tmp_path / "ref_style.pt")
+        torch.save({"string_to_subj_basis_generator_dict": nn.ModuleDict({"z": SubjBasisGenerator()}), "placeholder_strings": ["z"]}, ref_path)
+    finally:
+        for k, v in saved_modules.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    ck = load_adaface_ckpt_file(ref_path)
+    g = ck["string_to_subj_basis_generator_dict"]["z"]
+    from adaface_dev_amd.adaface.subj_basis_generator import SubjBasisGenerator as Mirror
+    assert isinstance(g, Mirror) and isinstance(g.helper, ShellModule)
+    assert g.N_ID == 16 and g.prompt2token_proj_attention_multipliers == [1, 2]
+    sd = module_state_dict(g)
+    assert set(sd) == {"hidden_state_layer_weights", "helper.w"} and torch.equal(sd["helper.w"], torch.arange(3.0))

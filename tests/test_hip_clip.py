@@ -53,7 +53,7 @@ def _small_model(dev, seed=21, multipliers=None):
     if multipliers:
         for li, mult in enumerate(multipliers):
             if mult > 1:
-                m.extend_clip_attention_MKV_multiplier(li, li, mult, perturb_std=0.0)
+                m.extend_clip_attention_MKV_multiplier(begin_layer_idx=li, end_layer_idx=li, multiplier=mult, perturb_std=0.0)
     rng.load_synth_weights(m, seed=seed)
     sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
     return m.to(dev).eval(), sd

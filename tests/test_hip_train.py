@@ -88,7 +88,7 @@ def test_unet_distill_loss_and_context_grad_vs_oracle(dev, steps):
     assert el < 5e-3 and eg < 1e-2
 
 
-def _oracle_distill(sds, ucfg, ids512, x0, noise, t, fg, steps, pres, sbg_sd=None, ffn_lora=None):
+def _oracle_distill(sds, ucfg, ids512, x0, noise, t, fg, steps, pres, sbg_sd=None, ffn_lora=None, skip_weights=None):
     from adaface_dev_amd.adaface.subj_basis_generator import template_ids
     from oracle import clip_oracle as CO
     from oracle import diffusion_oracle as D
@@ -106,7 +106,7 @@ def _oracle_distill(sds, ucfg, ids512, x0, noise, t, fg, steps, pres, sbg_sd=Non
     pid = template_ids(["a", "photo", "of"] + [","] * 16, 77).repeat(B, 1)
     tok = sds["text"]["text_model.embeddings.token_embedding.weight"][pid].clone()
     tok = torch.cat([tok[:, :4], ada, tok[:, 20:]], dim=1)
-    ctx = CO.clip_text_forward(sds["text"], cc, pid, tok)[0]
+    ctx = CO.clip_text_forward(sds["text"], cc, pid, tok, skip_weights)[0]      # FrozenCLIPEmbedder: LN(sum_k w_k h_k), modules.py:330-339
     tctx = torch.cat([prefix.repeat(B, 1, 1), id2img], dim=1)
     tabs = D.register_schedule(D.make_beta_schedule_linear())
     loss = 8 * T.unet_distill_loss(lambda x, tt, c: O.unet_forward(sds["student"], ucfg, x, tt, c, {"res_hidden_states_gradscale": 0.5, "ffn_lora": ffn_lora}),
@@ -152,6 +152,41 @@ def test_distill_trainer_micro_batch_loss_and_weight_gradients_vs_oracle(dev):
     e_w = rel_l2((sb.hidden_state_layer_weights.grad / S).cpu().numpy(), 5.0 * lw.grad.numpy())      # x5 grad scaler (:716)
     print(f"trainer micro-batch: loss rel err {el:.2e}; worst weight-gradient rel-L2 over {n_checked} tensors {worst:.2e}; layer-mix {e_w:.2e}")
     assert e_w < 3e-2
+
+
+def test_distill_trainer_through_embedding_manager_vs_oracle(dev):
+    """The same micro-batch through the reference's conditioning path: prompts -> FrozenCLIPEmbedder (skip weights 0.5 / 0.5 over the
+    last two layers) with the EmbeddingManager generating and patching the ada embeddings inside the embedding step."""
+    from adaface_dev_amd import rng
+    tr, sds, ucfg = trainer_setup(dev, embedding_manager=True)
+    BS, steps = 4, 2
+    ids512 = rng.synth_input("tr.ids", (BS, 512), seed=46)
+    x0 = rng.synth_input("tr.x0", (BS, 4, 32, 32), seed=46)
+    noise = rng.synth_input("tr.noise", (BS, 4, 32, 32), seed=46)
+    fg = (rng.synth_input("tr.fg", (BS, 1, 32, 32), seed=46) > -0.3).float()
+    t = torch.tensor([760, 850])
+    pres = [(torch.rand(2, generator=torch.Generator().manual_seed(3)), rng.synth_input("tr.n1", (2, 4, 32, 32), seed=46))]
+    batch = dict(x_start=x0.to(dev), face_id_embs=ids512.to(dev), fg_mask=fg.to(dev), noise=noise.to(dev))
+    tr.optimizer.zero_grad()
+    loss = tr.shared_step(batch, num_unet_denoising_steps=steps, t=t.to(dev), presampled=[(r.to(dev), n.to(dev)) for r, n in pres])
+    S = tr.scaler.scale
+    (loss * S).backward()
+    em = tr.ldm.embedding_manager
+    b, n = em.placeholder2indices["z"]
+    assert b.tolist() == [0] * 16 + [1] * 16 and n.tolist() == list(range(4, 20)) * 2
+    ref, sbg, lw = _oracle_distill(sds, ucfg, ids512[:2], x0[:2], noise[:2], t, fg[:2], steps, pres, skip_weights=torch.tensor([[0.5], [0.5]]))
+    plain = _oracle_distill(sds, ucfg, ids512[:2], x0[:2], noise[:2], t, fg[:2], steps, pres)[0]
+    ref.backward()
+    el = abs(float(loss) - float(ref)) / abs(float(ref))
+    assert el < 5e-3 and abs(float(plain) - float(ref)) / abs(float(ref)) > 2 * el, (float(loss), float(ref), float(plain))
+    sb = tr.id2ada.subj_basis_generator
+    worst = 0.0
+    for name, p in sb.prompt2token_proj.named_parameters():
+        if not p.requires_grad or name.endswith("k_proj.bias"):
+            continue
+        worst = max(worst, rel_l2((p.grad / S).cpu().numpy(), sbg[name].grad.numpy()))
+    print(f"trainer through the embedding manager: loss rel err {el:.2e}; worst weight-gradient rel-L2 {worst:.2e}")
+    assert worst < 3e-2
 
 
 def test_distill_trainer_accumulate_and_step(dev):

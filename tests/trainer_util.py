@@ -5,7 +5,7 @@ CFG = dict(in_channels=4, model_channels=64, out_channels=4, num_res_blocks=2, a
            channel_mult=[1, 2, 4, 4], num_heads=8, use_spatial_transformer=True, transformer_depth=1, context_dim=64, legacy=False)
 
 
-def trainer_setup(dev, accum=1, process_group=None, ffn_lora=False):
+def trainer_setup(dev, accum=1, process_group=None, ffn_lora=False, embedding_manager=False):
     """Reduced-width replica of the whole Stage-1 stack: CLIP encoders hidden 128 / 3 layers, U-Nets model_channels 64."""
     from adaface_dev_amd import rng
     from adaface_dev_amd.adaface.arc2face_models import CLIPTextModelWrapper, clip_text_config
@@ -29,6 +29,10 @@ def trainer_setup(dev, accum=1, process_group=None, ffn_lora=False):
                arc2face=id2ada.text_to_image_prompt_encoder.state_dict(),
                sbg=id2ada.subj_basis_generator.prompt2token_proj.state_dict(), text=text_enc.state_dict())
     sds = {k: {n: v.detach().clone() for n, v in sd.items()} for k, sd in sds.items()}
+    if embedding_manager:           # the reference's conditioning path: hooked text encoder + EmbeddingManager around the same modules
+        from adaface_dev_amd.ldm.modules.encoders.modules import FrozenCLIPEmbedder
+        ld.instantiate_cond_stage(FrozenCLIPEmbedder(transformer=text_enc, clip_config=ccfg, last_layers_skip_weights=[1, 1]))
+        ld.instantiate_embedding_manager({"id2ada_prompt_encoder": id2ada})
     ld = ld.to(dev)
     ld.unet_teacher = Arc2FaceTeacher(teacher_unet.to(dev))
     if ffn_lora:
