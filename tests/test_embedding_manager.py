@@ -164,3 +164,41 @@ def test_checkpoint_roundtrip_and_reference_class_paths(tmp_path):
     assert g.N_ID == 16 and g.prompt2token_proj_attention_multipliers == [1, 2]
     sd = module_state_dict(g)
     assert set(sd) == {"hidden_state_layer_weights", "helper.w"} and torch.equal(sd["helper.w"], torch.arange(3.0))
+
+
+def test_load_adaface_ckpt_reproduces_kv_widths_and_weights(tmp_path):
+    """Arc2Face_ID2AdaPrompt.load_adaface_ckpt (face_id_to_ada_prompt.py:109-162): the checkpointed generator has widened K/V
+    projections in some layers; the fresh one is widened to match before the weights are copied, then optionally widened again."""
+    from adaface_dev_amd import rng
+    from adaface_dev_amd.adaface.adaface_wrapper import WordTokenizer
+    from adaface_dev_amd.adaface.arc2face_models import clip_text_config
+    from adaface_dev_amd.adaface.face_id_to_ada_prompt import Arc2Face_ID2AdaPrompt
+    from adaface_dev_amd.ldm.modules.embedding_manager import EmbeddingManager
+    cfg = clip_text_config(hidden_size=64, num_attention_heads=2, num_hidden_layers=3, intermediate_size=128, vocab_size=512)
+    table = U.token_table()
+    src = Arc2Face_ID2AdaPrompt(clip_config=cfg, num_static_img_suffix_embs=2)
+    src.subj_basis_generator.extend_prompt2token_proj_attention([1, 2, 1], -1, -1, 1, perturb_std=0)
+    rng.load_synth_weights(src.subj_basis_generator.prompt2token_proj, seed=7)
+    with torch.no_grad():
+        src.subj_basis_generator.hidden_state_layer_weights.copy_(torch.tensor([[0.5], [1.5], [3.0]]))
+    assert src.subj_basis_generator.prompt2token_proj_attention_multipliers == [1, 2, 1]
+    em = EmbeddingManager(U.text_embedder(WordTokenizer(), table), ["z"], out_emb_dim=64, id2ada_prompt_encoder=src, num_static_img_suffix_embs=2)
+    assert em.token2num_vectors["z"] == 18
+    path = str(tmp_path / "embeddings_gs-20.pt")
+    em.save(path)
+    dst = Arc2Face_ID2AdaPrompt(clip_config=cfg, num_static_img_suffix_embs=2, extend_prompt2token_proj_attention_multiplier=2,
+                                prompt2token_proj_ext_attention_perturb_ratio=0)
+    em2 = EmbeddingManager(U.text_embedder(WordTokenizer(), table), ["z"], out_emb_dim=64, id2ada_prompt_encoder=dst,
+                           num_static_img_suffix_embs=2, adaface_ckpt_paths=[path])
+    g1, g2 = src.subj_basis_generator, dst.subj_basis_generator
+    assert g2.prompt2token_proj_attention_multipliers == [2, 4, 2]                # checkpoint widths x the configured extra factor
+    assert torch.equal(g1.hidden_state_layer_weights, g2.hidden_state_layer_weights)
+    assert torch.equal(g1.static_img_suffix_embs, g2.static_img_suffix_embs)
+    sd1, sd2 = g1.prompt2token_proj.state_dict(), g2.prompt2token_proj.state_dict()
+    for k, v in sd1.items():
+        if "k_proj" in k or "v_proj" in k:                                        # repeated copies (perturb ratio 0)
+            assert torch.equal(sd2[k], torch.cat([v, v], dim=0)), k
+        else:
+            assert torch.equal(sd2[k], v), k
+    assert not any(p.requires_grad for p in g2.prompt2token_proj.text_model.embeddings.parameters())
+    assert em2.subject_strings == ["z"]
