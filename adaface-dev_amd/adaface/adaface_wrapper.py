@@ -119,20 +119,42 @@ class AdaFaceWrapper(nn.Module):
         self.ldm = None if pipeline_name is None else (ldm or LatentDiffusion(unet_config or SD15_UNET_CONFIG))
         self.vae = vae
         self.img_prompt_embs = None
+        if base_model_path is not None:
+            self.load_base_model(base_model_path)
         self.extend_tokenizer_and_text_encoder()
         if adaface_ckpt_paths:
             self.load_subj_basis_generator(adaface_ckpt_paths)
 
     # ------------------------------------------------------------------ checkpoints
+    def load_base_model(self, base_model_path):
+        """An LDM-format SD-1.5 checkpoint (.safetensors / .ckpt): U-Net, VAE and CLIP text encoder by their key prefixes
+        (the reference hands the same file to diffusers' ``from_single_file``, adaface_wrapper.py:236-246, 301-308)."""
+        from ..ldm.modules.encoders.modules import FrozenCLIPEmbedder
+        if self.ldm is None:
+            raise RuntimeError("pipeline_name=None builds the face encoder only: there is no U-Net to load a base model into")
+        if self.ldm.first_stage_model is None:
+            self.ldm.instantiate_first_stage()
+        if self.ldm.cond_stage_model is None:       # share the wrapper's text encoder so that the checkpoint's CLIP weights reach it
+            self.ldm.instantiate_cond_stage(FrozenCLIPEmbedder(tokenizer=self.tokenizer, transformer=self.text_encoder,
+                                                               last_layers_skip_weights=None))
+        missing, unexpected = self.ldm.init_from_ckpt(base_model_path)
+        if self.vae is None:
+            self.vae = self.ldm.first_stage_model
+        return missing, unexpected
+
     def load_subj_basis_generator(self, adaface_ckpt_paths):
-        """Reference checkpoints (`embeddings_gs-N.pt`) pickle whole reference modules; a plain state dict of
-        `subj_basis_generator` (as written by `torch.save(sbg.state_dict())`) is what loads here."""
+        """``embeddings_gs-N.pt`` as written by ``EmbeddingManager.save`` (pickled generator modules; the reference's class paths
+        are mapped to the mirrors by adaface/ckpt.py), or a plain state dict of ``subj_basis_generator``."""
+        from .ckpt import load_adaface_ckpt_file
         path = adaface_ckpt_paths[0] if isinstance(adaface_ckpt_paths, (list, tuple)) else adaface_ckpt_paths
-        sd = torch.load(path, map_location="cpu")
-        sd = sd.get("subj_basis_generator", sd)
+        ck = load_adaface_ckpt_file(path.split(":")[0])
+        if isinstance(ck, dict) and "string_to_subj_basis_generator_dict" in ck:
+            self.id2ada_prompt_encoder.subject_string = self.subject_string
+            return self.id2ada_prompt_encoder.load_adaface_ckpt(path)
+        sd = ck.get("subj_basis_generator", ck)
         if not isinstance(sd, dict):
             sd = sd.state_dict()
-        self.id2ada_prompt_encoder.subj_basis_generator.load_state_dict(sd, strict=False)
+        return self.id2ada_prompt_encoder.subj_basis_generator.load_state_dict(sd, strict=False)
 
     # ------------------------------------------------------------------ tokens (reference :414-489)
     def extend_tokenizer_and_text_encoder(self):

@@ -168,6 +168,42 @@ class LatentDiffusion(nn.Module):
         reg("posterior_mean_coef1", betas * np.sqrt(alphas_cumprod_prev) / (1.0 - alphas_cumprod))
         reg("posterior_mean_coef2", (1.0 - alphas_cumprod_prev) * np.sqrt(alphas) / (1.0 - alphas_cumprod))
 
+    # ------------------------------------------------------------------ Stable Diffusion checkpoints
+    def init_from_ckpt(self, path, ignore_keys=(), only_model=False):
+        """Load an LDM-format Stable Diffusion checkpoint (``v1-5-pruned-emaonly.safetensors`` / ``.ckpt``; reference
+        ``DDPM.init_from_ckpt`` ddpm.py:347-387).  The key prefixes of such a file are this class's own module paths --
+        ``model.diffusion_model.*`` (U-Net), ``first_stage_model.*`` (VAE, if ``instantiate_first_stage`` was called),
+        ``cond_stage_model.transformer.text_model.*`` (CLIP text encoder, if ``instantiate_cond_stage`` was called) and the schedule
+        buffers -- so it is one non-strict ``load_state_dict``.  Keys starting with an entry of ``ignore_keys`` are dropped first.  When
+        the text encoder's position table was extended beyond 77 rows (``max_length`` 97), the checkpoint's 77 rows are loaded and the
+        extension is re-applied, as the reference's constructor order achieves (:373-382, :555).  Returns (missing, unexpected)."""
+        if path.endswith(".safetensors"):
+            from safetensors.torch import load_file
+            sd = load_file(path, device="cpu")
+        elif path.endswith(".ckpt") or path.endswith(".pt"):
+            sd = torch.load(path, map_location="cpu", weights_only=False)
+            sd = sd.get("state_dict", sd)
+        else:
+            raise ValueError(f"Unknown checkpoint format: {path}")
+        sd = {k: v for k, v in sd.items() if not any(k.startswith(ik) for ik in ignore_keys)}
+        self.model._set_loras((None, False))                  # never load into merged weights
+        pos_key = "cond_stage_model.transformer.text_model.embeddings.position_embedding.weight"
+        extended = None
+        if self.cond_stage_model is not None and pos_key in sd and not only_model:
+            emb = self.cond_stage_model.transformer.text_model.embeddings.position_embedding
+            if emb.num_embeddings > sd[pos_key].shape[0]:
+                extended = emb.num_embeddings
+                pos = sd.pop(pos_key)
+                el = extended - pos.shape[0]
+                with torch.no_grad():
+                    emb.weight.copy_(torch.cat([pos, pos[-el:]], dim=0).to(emb.weight))
+        if only_model:
+            res = self.model.load_state_dict({k[len("model."):]: v for k, v in sd.items() if k.startswith("model.")}, strict=False)
+        else:
+            res = self.load_state_dict(sd, strict=False)
+        missing = [k for k in res.missing_keys if not (extended and k == pos_key)]
+        return missing, list(res.unexpected_keys)
+
     # ------------------------------------------------------------------ text conditioning (SURVEY.md 8f rank 2)
     def instantiate_cond_stage(self, config=None):
         """The hooked, frozen CLIP text encoder (reference ddpm.py:705-710, 612-617).  ``config``: a ``FrozenCLIPEmbedder`` or its
