@@ -498,7 +498,7 @@ extern "C" int af_gemm(const af_gemm_desc* d, void* stream) {
     const long t128 = (long)((d->M + 127) / 128) * ((d->N + 127) / 128);
     tile = (t128 >= 192 && d->N >= 96) ? 1 : 2;
   }
-  AF_REQUIRE(tile >= 1 && tile <= 4, "af_gemm: tile must be 0 .. 4");
+  AF_REQUIRE(tile >= 1 && tile <= 6, "af_gemm: tile must be 0 .. 6");
 
   AfLaunchScope scope(AF_FAM_GEMM, stream);
   hipStream_t s = (hipStream_t)stream;
@@ -506,7 +506,7 @@ extern "C" int af_gemm(const af_gemm_desc* d, void* stream) {
   if (tile >= 3 && d->tap_shift) tile = 1;          // the ring kernel keeps the symmetric-padding loader only
   if (tile >= 3) {
     const int eff = af_gemm3_effective_splits(d, p.splits);
-    const int rc3 = af_gemm3_try_launch(d, p.splits, tile == 4, s);
+    const int rc3 = af_gemm3_try_launch(d, p.splits, tile - 3, s);
     if (rc3 == 0) return af_check_launch("af_gemm(tile 3)");
     if (rc3 == 2) {
       p.splits = eff;

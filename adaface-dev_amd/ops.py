@@ -94,7 +94,7 @@ def interleave_geglu(w: torch.Tensor, b: torch.Tensor):
 import json as _json
 import os as _os
 
-_TUNE_PATH = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "tuning", "gfx950_gemm.json")
+_TUNE_PATH = _os.environ.get("AF_TUNE_TABLE") or _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "tuning", "gfx950_gemm.json")
 _tune_table = None
 _tune_recorder = None      # set by tools/autotune_gemm.py: callable(key, desc, device) -> (tile, splits)
 _splitk_ws = {}

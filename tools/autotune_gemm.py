@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--train", action="store_true")
     ap.add_argument("--vae", action="store_true", help="also tune the VAE decoder's shapes (batch 4 and 1, 64x64 latent)")
     ap.add_argument("--fresh", action="store_true", help="ignore the existing table instead of extending it")
+    ap.add_argument("--retune", action="store_true", help="re-time every shape this run meets; entries of shapes it does not meet are kept")
     args = ap.parse_args()
     from adaface_dev_amd import SD15_UNET_CONFIG, _lib, ops, rng
     from adaface_dev_amd.ldm.modules.diffusionmodules.openaimodel import UNetModel
@@ -63,13 +64,20 @@ def main():
         e1.synchronize()
         return e0.elapsed_time(e1) / args.reps
 
+    retuned = set()
+
     def recorder(key, d, device):
-        if key in table:
+        if key in table and (not args.retune or key in retuned):
             return table[key]
+        retuned.add(key)
         nk = d.kpad // 64
         best, best_t, res = (0, 1), None, {}
-        for tile in (1, 2, 3, 4):
+        for tile in (1, 2, 3, 4, 5, 6):
+            if tile >= 5 and (d.taps != 1 or d.out_mode != 0 or d.M * d.N < 256 * 256 * 128):
+                continue                        # 256-row tiles: plain / GEGLU 1x1 GEMMs with at least ~128 tiles
             for splits in (1, 2, 3, 4, 6, 8, 12, 16):
+                if tile >= 5 and splits > 1:
+                    continue
                 if splits > 1 and (d.act == _lib.AF_ACT_GEGLU or d.out_mode != 0 or nk < 4 * splits):
                     continue
                 t = timed(d, device, tile, splits)

@@ -4,6 +4,7 @@
     python tools/bench_kernel.py gemm  M N K [tile] [splits] [reps] [act]      (act 2 = GEGLU, 3 = quick-GELU, 1 = SiLU)
     python tools/bench_kernel.py conv  B H W Cin Cout [tile] [splits] [reps]
     python tools/bench_kernel.py gn    B HW C [reps]
+    python tools/bench_kernel.py blas  M N K [reps]      (hipBLASLt via torch.matmul: reference point only)
 """
 import os
 import sys
@@ -68,6 +69,13 @@ def main():
         pw = ops.pack_matrix(w, torch.zeros(N), dev)
         ms = timeit(lambda: ops.gemm(x, pw, tile=tile, splits=splits, act=act), reps)
         print(f"gemm M{M} N{N} K{K} tile{tile} splits{splits} act{act}: {ms * 1e3:.1f} us  {2.0 * M * N * K / ms / 1e9:.1f} TFLOP/s")
+    elif kind == "blas":          # the vendor library (hipBLASLt through torch.matmul) on the same shape: a reference point, not a product path
+        M, N, K = a[:3]
+        reps = a[3] if len(a) > 3 else 20
+        x, w = rnd(M, K), rnd(N, K)
+        out = torch.empty(M, N, dtype=torch.float16, device=dev)
+        ms = timeit(lambda: torch.matmul(x, w.t(), out=out), reps)
+        print(f"blas M{M} N{N} K{K}: {ms * 1e3:.1f} us  {2.0 * M * N * K / ms / 1e9:.1f} TFLOP/s")
     elif kind == "conv":
         B, H, W, ci, co = a[:5]
         tile, splits = (a[5] if len(a) > 5 else 0), (a[6] if len(a) > 6 else 0)
