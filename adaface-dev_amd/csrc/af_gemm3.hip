@@ -46,7 +46,7 @@ struct Gemm3Dev {
 };
 
 constexpr int BK3 = 32;
-constexpr int NST = 4;                 // ring slots
+constexpr int NST_DEFAULT = 4;         // ring slots (template parameter NST of the kernel; 5 where 160 KB of LDS allow it)
 
 
 // PI = {0, 2, 3, 1} packed two bits per entry: 0b01'11'10'00 = 0x78, PI[g] = (0x78 >> 2g) & 3
@@ -66,7 +66,7 @@ __device__ __forceinline__ void glds16(const half_t* src, char* lds_dst) {
 // padded from 20 to 24; padding pieces fetch the zero page), so the counted waits are the same constants.
 enum { E3_STD = 0, E3_GEGLU = 1, E3_SPLIT_T = 2 };
 
-template <int TAPS, int NWM, int NWN, int TN, int EPI>
+template <int TAPS, int NWM, int NWN, int TN, int EPI, int NST>
 __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void af_gemm3_kernel(Gemm3Dev p) {
   constexpr int TM = 4;
   constexpr int NW = NWM * NWN;
@@ -153,6 +153,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void af_gem
       for (int j = 0; j < APW; ++j) {
         const bool ok = (a_mask[j] >> tp) & 1u;     // tp >= 9 (K padding): no bit set
         const half_t* g = ok ? src + (size_t)(a_base[j] + dpix) * cs + coff : p.zeros;
+        if (p.ablate & 64) g = p.zeros + (((size_t)g >> 4) & 7) * 8;       // timing experiments: every DMA reads the hot 128-byte zero page
         glds16(g, As + (wave * APW + j) * 1024);
       }
     } else {
@@ -169,7 +170,11 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void af_gem
       }
     }
 #pragma unroll
-    for (int j = 0; j < WPW; ++j) glds16(wok[j] ? wptr[j] + k0 : p.zeros, Ws + (wave + NW * j) * 1024);
+    for (int j = 0; j < WPW; ++j) {
+      const half_t* g = wok[j] ? wptr[j] + k0 : p.zeros;
+      if (p.ablate & 64) g = p.zeros + (((size_t)g >> 4) & 7) * 8;
+      glds16(g, Ws + (wave + NW * j) * 1024);
+    }
   };
 
   floatx4 acc[TN][TM];
@@ -194,17 +199,24 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void af_gem
 
   half8_t wf[TN], xf[TM];
   for (int i = 0; i < nk; ++i) {
-    // my own pieces of stage i have landed when at most the (up to two) younger stages' 8 DMAs are still in flight
-    if (i + 2 < nk) {
-      if (DPS == 5) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-      else if (DPS == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    } else if (i + 1 < nk) {
-      if (DPS == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-      else if (DPS == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // my own pieces of stage i have landed when at most the (up to NST - 2) younger stages' DMAs are still in flight
+    {
+      const int younger = min(nk - 1 - i, NST - 2);
+      if (younger >= 3) {
+        if (DPS == 5) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+        else if (DPS == 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+      } else if (younger == 2) {
+        if (DPS == 5) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else if (DPS == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      } else if (younger == 1) {
+        if (DPS == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else if (DPS == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
     }
     if (!(p.ablate & 4)) __builtin_amdgcn_s_barrier();   // every wave's pieces of stage i are in LDS; everyone is done reading slot (i-1)%4
     if (i + NST - 1 < nk && !(p.ablate & 1)) issue_stage(kt_begin + i + NST - 1, (i + NST - 1) % NST);
@@ -406,7 +418,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void af_gem
   }
 }
 
-template <int TAPS, int NWM, int NWN, int TN, int EPI = E3_STD>
+template <int TAPS, int NWM, int NWN, int TN, int EPI = E3_STD, int NST = NST_DEFAULT>
 void launch3(const Gemm3Dev& p0, hipStream_t stream) {
   Gemm3Dev p = p0;
   constexpr int NW = NWM * NWN, BM = NWM * 64, BN = NWN * TN * 16;
@@ -418,12 +430,12 @@ void launch3(const Gemm3Dev& p0, hipStream_t stream) {
   p.n_major = af_gemm_n_major(p.M, p.N, p.K, TAPS == 9 ? p.c1 + p.c2 : p.K);
   static bool attr_set = false;
   if (lds > 65536 && !attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&af_gemm3_kernel<TAPS, NWM, NWN, TN, EPI>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&af_gemm3_kernel<TAPS, NWM, NWN, TN, EPI, NST>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   dim3 grid(tiles_m * p.tiles_n, p.splits), block(64 * NW);
-  hipLaunchKernelGGL((af_gemm3_kernel<TAPS, NWM, NWN, TN, EPI>), grid, block, lds, stream, p);
+  hipLaunchKernelGGL((af_gemm3_kernel<TAPS, NWM, NWN, TN, EPI, NST>), grid, block, lds, stream, p);
 }
 
 }  // namespace
