@@ -192,48 +192,54 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void af_gem
   int nk = kt_end - kt_begin;
   if (p.ablate & 8) nk = 0;                       // timing experiments: launch + setup + epilogue only
 
-  // prologue: three stages in flight
-#pragma unroll
-  for (int s = 0; s < NST - 1; ++s)
-    if (s < nk) issue_stage(kt_begin + s, s);
-
   half8_t wf[TN], xf[TM];
-  for (int i = 0; i < nk; ++i) {
-    // my own pieces of stage i have landed when at most the (up to NST - 2) younger stages' DMAs are still in flight
-    {
-      const int younger = min(nk - 1 - i, NST - 2);
-      if (younger >= 3) {
-        if (DPS == 5) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
-        else if (DPS == 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-      } else if (younger == 2) {
-        if (DPS == 5) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-        else if (DPS == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-      } else if (younger == 1) {
-        if (DPS == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-        else if (DPS == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
+  // own pieces of a stage have landed when at most `younger` later stages' DMAs (DPS each, issued in order) are outstanding
+  auto wait_own = [&](int younger) {
+    if (younger >= 3) {
+      if (DPS == 5) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+      else if (DPS == 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    } else if (younger == 2) {
+      if (DPS == 5) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+      else if (DPS == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else if (younger == 1) {
+      if (DPS == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      else if (DPS == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    if (!(p.ablate & 4)) __builtin_amdgcn_s_barrier();   // every wave's pieces of stage i are in LDS; everyone is done reading slot (i-1)%4
-    if (i + NST - 1 < nk && !(p.ablate & 1)) issue_stage(kt_begin + i + NST - 1, (i + NST - 1) % NST);
-
-    const char* As = af_smem + (i % NST) * STAGE;
+  };
+  auto read_frags = [&](int slot) {
+    const char* As = af_smem + slot * STAGE;
     const char* Ws = As + BM * 64;
-    if (!(p.ablate & 2) || i == 0) {
 #pragma unroll
-      for (int tn = 0; tn < TN; ++tn) wf[tn] = *reinterpret_cast<const half8_t*>(Ws + (wn * TN * 16 + tn * 16) * 64 + rd_off);
+    for (int tn = 0; tn < TN; ++tn) wf[tn] = *reinterpret_cast<const half8_t*>(Ws + (wn * TN * 16 + tn * 16) * 64 + rd_off);
 #pragma unroll
-      for (int tm = 0; tm < TM; ++tm) xf[tm] = *reinterpret_cast<const half8_t*>(As + (wm * 64 + tm * 16) * 64 + rd_off);
-    }
+    for (int tm = 0; tm < TM; ++tm) xf[tm] = *reinterpret_cast<const half8_t*>(As + (wm * 64 + tm * 16) * 64 + rd_off);
+  };
+  auto mfma_step = [&]() {
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm)
         acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[tn], xf[tm], acc[tn][tm], 0, 0, 0);
+  };
+
+  {
+    // ---- lock-step schedule: wait -> barrier -> DMA issue -> fragment reads -> MFMAs per 32-wide K step (a ping-pong schedule of
+    // the two waves per SIMD was measured slower, profiles/r01r_gemm_diagnosis.txt)
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s)
+      if (s < nk) issue_stage(kt_begin + s, s);
+    for (int i = 0; i < nk; ++i) {
+      wait_own(min(nk - 1 - i, NST - 2));
+      if (!(p.ablate & 4)) __builtin_amdgcn_s_barrier();   // every wave's pieces of stage i are in LDS; everyone is done reading slot (i-1)%NST
+      if (i + NST - 1 < nk && !(p.ablate & 1)) issue_stage(kt_begin + i + NST - 1, (i + NST - 1) % NST);
+      if (!(p.ablate & 2) || i == 0) read_frags(i % NST);
+      mfma_step();
+    }
   }
 
   if (p.ablate & 16) {                            // timing experiments: no epilogue (one store keeps the accumulators alive)
