@@ -67,7 +67,8 @@ class DistillTrainer:
     def __init__(self, ldm, id2ada, text_encoder, base_lr=2e-6, batch_size=4, accumulate_grad_batches=2,
                  betas=(0.9, 0.995), eps=1e-6, weight_decay=0.0, lora_weight_decay=0.02, warm_up_steps=500, max_decay_steps=60000,
                  bucket_bytes=32 << 20, loss_scaler=None, prompt_len=77, subj_slot=4, process_group=None,
-                 gradient_clip_val=0.01, gradient_clip_algorithm="value"):
+                 gradient_clip_val=0.01, gradient_clip_algorithm="value", p_gen_rand_id_for_id2img=0.0, p_perturb_face_id_embs=0.0,
+                 perturb_face_id_embs_std_range=(0.3, 0.6)):
         self.ldm, self.id2ada, self.text_encoder = ldm, id2ada, text_encoder
         for p in text_encoder.parameters():
             p.requires_grad_(False)
@@ -101,6 +102,12 @@ class DistillTrainer:
         if gradient_clip_algorithm != "value":
             raise NotImplementedError("only gradient_clip_algorithm='value' (the reference's setting) is built")
         self.gradient_clip_val = gradient_clip_val
+        # per-iteration input variants of a U-Net distillation iteration (ddpm.py:1131-1137, 1152-1169, 1222-1261); the reference's yaml
+        # uses 0 / 0.2 / [0.3, 0.6] (v1-distill-arc2face-ada.yaml:36-42).  Off (0, 0) by default here so that a batch is used as given.
+        self.p_gen_rand_id_for_id2img = p_gen_rand_id_for_id2img
+        self.p_perturb_face_id_embs = p_perturb_face_id_embs
+        self.perturb_face_id_embs_std_range = tuple(perturb_face_id_embs_std_range)
+        self.iter_flags = {}
         self._bad = None                                                        # device flag: a non-finite gradient was seen
 
     # ------------------------------------------------------------------ conditioning
@@ -138,10 +145,48 @@ class DistillTrainer:
                 self._prefix = enc(input_ids=ids)[0][:, :4].to(id2img_prompt_embs.dtype)
         return torch.cat([self._prefix.repeat(bs, 1, 1), id2img_prompt_embs], dim=1)
 
+    # ------------------------------------------------------------------ per-iteration input variants
+    def select_iteration_inputs(self, batch):
+        """The data-dependent head of a U-Net distillation iteration (reference ddpm.py:1131-1169, 1222-1245), consuming the global
+        torch RNG in the reference's order.  With probability ``p_gen_rand_id_for_id2img`` the iteration distils on RANDOM face IDs
+        (``randn(BS, 512)``), a random ``x_start`` and no masks; with probability ``p_perturb_face_id_embs`` the batch becomes BS copies
+        of its first instance whose image-prompt embeddings [1:] are perturbed later (``perturb_img_prompt_embs``).  Returns a new
+        batch dict; ``self.iter_flags`` records the draws."""
+        from .util import select_and_repeat_instances
+        out = dict(batch)
+        BS = batch["x_start"].shape[0]
+        flags = {"gen_rand_id_for_id2img": False, "same_subject_in_batch": False, "perturb_face_id_embs": False}
+        if self.p_gen_rand_id_for_id2img > 0 and bool(torch.rand(1) < self.p_gen_rand_id_for_id2img):
+            flags["gen_rand_id_for_id2img"] = True
+            x = batch["x_start"]
+            out["face_id_embs"] = torch.randn(BS, batch["face_id_embs"].shape[-1], device=x.device)
+            out["fg_mask"], out["img_mask"] = None, None
+            out["x_start"] = torch.randn_like(x)
+        flags["perturb_face_id_embs"] = bool(torch.rand(1) < self.p_perturb_face_id_embs)
+        if flags["perturb_face_id_embs"]:
+            flags["same_subject_in_batch"] = True
+            keys = [k for k in ("x_start", "fg_mask", "img_mask", "face_id_embs") if out.get(k) is not None]
+            reps = select_and_repeat_instances(slice(0, 1), BS, *[out[k] for k in keys])
+            out.update(dict(zip(keys, reps)))
+        self.iter_flags = flags
+        return out
+
+    def perturb_img_prompt_embs(self, id2img_prompt_embs):
+        """Keep the first instance's image-prompt embeddings, add norm-preserving Gaussian noise of relative std ~ U(range) to the
+        others (reference ddpm.py:1247-1261): neighbours of the subject in embedding space as extra distillation targets."""
+        from .util import anneal_perturb_embedding
+        if not self.iter_flags.get("perturb_face_id_embs") or id2img_prompt_embs.shape[0] < 2:
+            return id2img_prompt_embs
+        rest = anneal_perturb_embedding(id2img_prompt_embs[1:], 0, self.perturb_face_id_embs_std_range, None, perturb_prob=1,
+                                        perturb_std_is_relative=True, keep_norm=True)
+        return torch.cat([id2img_prompt_embs[:1], rest], dim=0)
+
     # ------------------------------------------------------------------ one micro-batch
     def shared_step(self, batch, num_unet_denoising_steps=None, t=None, presampled=None):
         """batch: dict with 'x_start' [B,4,h,w] latents, 'face_id_embs' [B,512], optional 'fg_mask'/'img_mask' [B,1,h,w]
         and 'noise'.  Returns the (unscaled) loss tensor."""
+        if self.p_gen_rand_id_for_id2img > 0 or self.p_perturb_face_id_embs > 0:
+            batch = self.select_iteration_inputs(batch)
         x_start = batch["x_start"]
         BS = x_start.shape[0]
         steps = num_unet_denoising_steps or (self.unet_distill_iters_count % 3 + 2)      # ddpm.py:1270
@@ -155,7 +200,7 @@ class DistillTrainer:
         noise = batch["noise"][sel] if "noise" in batch else torch.randn_like(x_start)
         with torch.no_grad():
             _, _, id2img = self.id2ada.get_img_prompt_embs(batch["face_id_embs"][sel], id_batch_size=half)[:3]
-        id2img = id2img.float()
+        id2img = self.perturb_img_prompt_embs(id2img.float())
         em = getattr(self.ldm, "embedding_manager", None)
         if em is not None:
             # the reference's conditioning path (ddpm.py:739-853): prompts -> hooked text encoder, the embedding manager generates

@@ -122,6 +122,22 @@ def merge_cls_token_embeddings(prompt_embedding, cls_delta_string_indices):
     return out
 
 
+def select_and_repeat_instances(sel_indices, REPEAT, *args):
+    """args[sel_indices] repeated REPEAT times along dim 0 (tensors / arrays) or as a list (reference ldm/util.py:1366-1380)."""
+    out = []
+    for a in args:
+        if a is None:
+            out.append(None)
+        elif isinstance(a, (torch.Tensor, np.ndarray)):
+            sel = a[sel_indices]
+            out.append(sel.repeat([REPEAT] + [1] * (a.ndim - 1)) if isinstance(a, torch.Tensor) else np.tile(sel, [REPEAT] + [1] * (a.ndim - 1)))
+        elif isinstance(a, (list, tuple)):
+            out.append(a[sel_indices] * REPEAT)
+        else:
+            raise TypeError(f"select_and_repeat_instances: unsupported argument type {type(a)}")
+    return out
+
+
 def get_clip_tokens_for_string(clip_tokenizer, string, force_single_token=False):
     """Token ids of `string` without BOS / EOS padding (reference ldm/util.py:867-887)."""
     enc = clip_tokenizer(string, truncation=True, max_length=77, padding="max_length", return_tensors="pt")

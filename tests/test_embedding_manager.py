@@ -202,3 +202,41 @@ def test_load_adaface_ckpt_reproduces_kv_widths_and_weights(tmp_path):
             assert torch.equal(sd2[k], v), k
     assert not any(p.requires_grad for p in g2.prompt2token_proj.text_model.embeddings.parameters())
     assert em2.subject_strings == ["z"]
+
+
+def test_trainer_iteration_input_variants_follow_the_reference_rng_order():
+    """DistillTrainer.select_iteration_inputs / perturb_img_prompt_embs (ddpm.py:1131-1169, 1222-1261): random-ID iterations and
+    first-subject-repeated + perturbed image-prompt embeddings, drawing from the global RNG in the reference's order."""
+    from adaface_dev_amd.adaface.util import perturb_tensor
+    from adaface_dev_amd.ldm.trainer import DistillTrainer
+    tr = DistillTrainer.__new__(DistillTrainer)
+    tr.p_gen_rand_id_for_id2img, tr.p_perturb_face_id_embs, tr.perturb_face_id_embs_std_range = 1.0, 1.0, (0.3, 0.6)
+    tr.iter_flags = {}
+    g = torch.Generator().manual_seed(1)
+    batch = dict(x_start=torch.randn(3, 4, 8, 8, generator=g), face_id_embs=torch.randn(3, 512, generator=g),
+                 fg_mask=torch.ones(3, 1, 8, 8), noise=torch.randn(3, 4, 8, 8, generator=g))
+    torch.manual_seed(77)
+    out = tr.select_iteration_inputs(batch)
+    torch.manual_seed(77)
+    torch.rand(1)                                                   # the random-ID coin
+    ids = torch.randn(3, 512)
+    x = torch.randn(3, 4, 8, 8)
+    torch.rand(1)                                                   # the perturbation coin
+    assert tr.iter_flags == {"gen_rand_id_for_id2img": True, "same_subject_in_batch": True, "perturb_face_id_embs": True}
+    assert torch.equal(out["face_id_embs"], ids[:1].repeat(3, 1)) and torch.equal(out["x_start"], x[:1].repeat(3, 1, 1, 1))
+    assert out["fg_mask"] is None and out["img_mask"] is None and torch.equal(out["noise"], batch["noise"])
+    assert torch.equal(batch["x_start"][1], batch["x_start"][1]) and out is not batch
+    id2img = torch.randn(3, 16, 32, generator=g)
+    torch.manual_seed(5)
+    got = tr.perturb_img_prompt_embs(id2img)
+    torch.manual_seed(5)
+    torch.rand(1)
+    std = torch.rand(1).item() * 0.3 + 0.3
+    want = perturb_tensor(id2img[1:], std, True, True)
+    assert torch.equal(got[:1], id2img[:1]) and torch.equal(got[1:], want)
+    assert torch.allclose(got.norm(dim=-1), id2img.norm(dim=-1), rtol=1e-5)          # keep_norm
+    # probabilities 0: the batch passes through and no RNG is consumed by the coins' branches
+    tr.p_gen_rand_id_for_id2img, tr.p_perturb_face_id_embs = 0.0, 0.0
+    out = tr.select_iteration_inputs(batch)
+    assert torch.equal(out["x_start"], batch["x_start"]) and tr.iter_flags["perturb_face_id_embs"] is False
+    assert tr.perturb_img_prompt_embs(id2img) is id2img
