@@ -107,6 +107,8 @@ typedef struct af_gemm_desc {
   int32_t tile;         /* 0 = auto, 1 = 128x128, 2 = 64x64 (register-staged), 3 = 128x128 and 4 = 128x320 LDS-DMA
                            pipelined ring (standard epilogue, channel counts % 32 == 0, no upsample, tile 4: N % 320
                            == 0; otherwise falls back to 1) */
+                        /* 5 = 256x256 and 6 = 256x320 ring tiles (8 waves as 4 x 2): plain or GEGLU 1x1 GEMMs only, N % 256 / N % 320 == 0,
+                           no split-K; anything outside a ring tile's scope falls back to tile 1 */
   int32_t splits;       /* split-K factor (<=1: none).  >1 needs the standard epilogue and a workspace:
                            each split writes an fp32 partial [M][N], a second launch reduces + applies the epilogue */
   void* workspace;      /* fp32, >= splits*M*N*4 bytes when splits > 1 */
