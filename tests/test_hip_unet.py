@@ -154,6 +154,26 @@ def test_unet_reduced_width_vs_oracle(dev):
     assert not m.output_blocks[-1][1].transformer_blocks[0].attn2.save_cross_attn_vars
 
 
+@pytest.mark.parametrize("B,H,W,T", [(1, 24, 40, 20), (3, 16, 16, 97), (2, 40, 24, 1), (1, 8, 8, 77)])
+def test_unet_ragged_shapes_vs_oracle(dev, B, H, W, T):
+    """Non-square latents (down to 3 x 5 = 15 tokens on the lowest level), odd batch sizes and context lengths other than 77
+    (1, the teacher's 20, the training length 97), with an image mask: token counts that are no multiple of any tile."""
+    from adaface_dev_amd import rng
+    from oracle import unet_oracle as O
+    m, sd = _build(GPU_TINY_CONFIG, 11, dev)
+    x = rng.synth_input("rag.x", (B, 4, H, W), seed=12)
+    ctx = rng.synth_input("rag.ctx", (B, T, 64), seed=12)
+    t = torch.randint(0, 1000, (B,), generator=torch.Generator().manual_seed(H * W + T))
+    mask = torch.ones(B, 1, H, W)
+    mask[0, :, : H // 3, :] = 0
+    for ei, ei_ref in (({}, {}), ({"img_mask": mask.to(dev)}, {"img_mask": mask})):
+        with torch.no_grad():
+            eps = m(x.to(dev), t.to(dev), ctx.to(dev), extra_info=ei)
+        ref = O.unet_forward(sd, GPU_TINY_CONFIG, x, t, ctx, ei_ref)
+        assert eps.shape == ref.shape == (B, 4, H, W)
+        assert rel_l2(eps.cpu().numpy(), ref.numpy()) < NET_TOL, (B, H, W, T, bool(ei))
+
+
 def test_unet_reduced_width_backward_vs_oracle_autograd(dev):
     """d(eps . cot)/dx and /dcontext through the manual HIP backward (one autograd node for the whole U-Net)
     against torch autograd through the CPU oracle.  fp16 activation gradients across ~25 blocks: 2e-2 rel-L2."""
@@ -183,6 +203,28 @@ def test_unet_reduced_width_backward_vs_oracle_autograd(dev):
     eps = m(x.to(dev), t.to(dev), cg, extra_info={})
     (eps * cot.to(dev)).sum().backward()
     assert rel_l2(cg.grad.cpu().numpy(), cr.grad.numpy()) < 2e-2 or img_mask is not None
+
+
+@pytest.mark.parametrize("B,H,W,T", [(1, 24, 40, 20), (3, 16, 16, 97)])
+def test_unet_backward_ragged_shapes_vs_oracle_autograd(dev, B, H, W, T):
+    """The manual backward on token counts that are no multiple of any tile (15 tokens on the lowest level; 97 / 20 context tokens)."""
+    from adaface_dev_amd import rng
+    from oracle import unet_oracle as O
+    m, sd = _build(GPU_TINY_CONFIG, 11, dev)
+    x = rng.synth_input("ragb.x", (B, 4, H, W), seed=13)
+    ctx = rng.synth_input("ragb.ctx", (B, T, 64), seed=13)
+    cot = rng.synth_input("ragb.cot", (B, 4, H, W), seed=13)
+    t = torch.randint(0, 1000, (B,), generator=torch.Generator().manual_seed(T))
+    mask = torch.ones(B, 1, H, W)
+    mask[0, :, :, : W // 4] = 0
+    xg, cg = x.clone().to(dev).requires_grad_(True), ctx.clone().to(dev).requires_grad_(True)
+    eps = m(xg, t.to(dev), cg, extra_info={"img_mask": mask.to(dev), "res_hidden_states_gradscale": 0.5})
+    (eps * cot.to(dev)).sum().backward()
+    xr, cr = x.clone().requires_grad_(True), ctx.clone().requires_grad_(True)
+    ref = O.unet_forward(sd, GPU_TINY_CONFIG, xr, t, cr, {"img_mask": mask, "res_hidden_states_gradscale": 0.5})
+    (ref * cot).sum().backward()
+    ex, ec = rel_l2(xg.grad.cpu().numpy(), xr.grad.numpy()), rel_l2(cg.grad.cpu().numpy(), cr.grad.numpy())
+    assert rel_l2(eps.detach().cpu().numpy(), ref.detach().numpy()) < NET_TOL and ex < 2e-2 and ec < 2e-2, (ex, ec)
 
 
 def test_unet_backward_skip_gradient_scale_vs_oracle(dev):
