@@ -275,6 +275,24 @@ def test_unet_full_size_vs_reference_golden(dev, full_model):
     assert err < NET_TOL
 
 
+def test_unet_full_size_nonsquare_768x512_vs_oracle(dev, full_model):
+    """SD-1.5-size U-Net on a 96 x 64 latent (768 x 512 image: 6144 / 1536 / 384 / 96 tokens per level) with 97 context tokens,
+    against the fp32 CPU oracle run on the same weights (a few seconds on the GPU box's host cores)."""
+    from adaface_dev_amd import SD15_UNET_CONFIG, rng
+    from oracle import unet_oracle as O
+    sd = {k: v.detach().float().cpu() for k, v in full_model.state_dict().items()}
+    x = rng.synth_input("ns.x", (1, 4, 96, 64), seed=3)
+    ctx = rng.synth_input("ns.ctx", (1, 97, 768), seed=3)
+    t = torch.tensor([321])
+    with torch.no_grad():
+        eps = full_model(x.to(dev), t.to(dev), ctx.to(dev), extra_info={})
+        torch.set_num_threads(min(32, os.cpu_count() or 8))
+        ref = O.unet_forward(sd, SD15_UNET_CONFIG, x, t, ctx, {})
+    err = rel_l2(eps.cpu().numpy(), ref.numpy())
+    print(f"full-size 96x64 latent, 97 tokens: eps rel-L2 vs oracle {err:.3e}")
+    assert eps.shape == (1, 4, 96, 64) and err < NET_TOL
+
+
 def test_unet_full_size_batch_properties(dev, full_model):
     """At the benchmark shape (U-Net batch 8 = 4 cond + 4 uncond): every sample equals its own bs-1 run
     (no cross-sample leakage through tiles / GroupNorm / attention), and two runs are bit-identical."""
