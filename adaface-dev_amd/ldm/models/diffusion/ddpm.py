@@ -324,6 +324,9 @@ class LatentDiffusion(nn.Module):
         """q_sample -> U-Net (with or without gradient) -> optional no-grad unconditional pass and CFG combine
         eps = eps_c * s - eps_u * (s - 1) -> optional x0 (reference ddpm.py:1597-1750; the 'subject-compos'
         batch partition belongs to Stage-2)."""
+        if normalize_cross_attn or mix_sc_mc_attn:
+            raise NotImplementedError("normalize_cross_attn / mix_sc_mc_attn rewrite the cross-attention scores of Stage-2 batches "
+                                      "(diffusers_attn_lora_capture.py:108-133; SURVEY.md 8f rank 4): not built")
         x_noisy = self.q_sample(x_start, t, noise)
         extra_info = cond_context[2]
         extra_info["capture_ca_activations"] = capture_ca_activations

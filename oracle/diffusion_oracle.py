@@ -97,3 +97,16 @@ def guide_scale_sequence(total_steps, guidance_scale):
         out.append(g)
         g = g - delta if i <= total_steps - 1 else 1
     return out
+
+
+def guided_denoise(eps_fn, tables, x_start, noise, t, cond_ctx, uncond_ctx=None, cfg_scale=-1, do_pixel_recon=False, uncond_eps_fn=None):
+    """LatentDiffusion.guided_denoise, ddpm.py:1597-1750 (batch_part_has_grad 'all' / 'none' are the same arithmetic): q_sample ->
+    eps_c = U-Net(x_t, t, cond) -> if cfg_scale > 1: eps = eps_c * s - eps_u * (s - 1) (:1741) with eps_u from the unconditional
+    context, whose extra_info is a copy of ``uncond_context[2]`` -- i.e. WITHOUT the conditional pass's img_mask / flags (:1728-1735),
+    hence the separate ``uncond_eps_fn`` -> optional x0 = predict_start_from_noise (:1747).  eps_fn(x, t, ctx) is the U-Net."""
+    x_noisy = q_sample(tables, x_start, t, noise)
+    eps = eps_fn(x_noisy, t, cond_ctx)
+    if cfg_scale > 1:
+        eps = eps * cfg_scale - (uncond_eps_fn or eps_fn)(x_noisy, t, uncond_ctx).detach() * (cfg_scale - 1)
+    x_recon = predict_start_from_noise(tables, x_noisy, t, eps) if do_pixel_recon else None
+    return eps, x_recon

@@ -360,6 +360,57 @@ def test_latent_diffusion_apply_model_contract(dev):
     assert rel_l2(xt[0].cpu().numpy(), (x[0] * ld.sqrt_alphas_cumprod[0]).cpu().numpy()) < 1e-6
 
 
+def test_guided_denoise_cfg_x0_grad_modes_vs_oracle(dev):
+    """LatentDiffusion.guided_denoise (ddpm.py:1597-1750): q_sample -> U-Net -> CFG with a no-grad unconditional pass ->
+    eps_c * s - eps_u * (s - 1) -> x0; gradient w.r.t. the prompt embedding flows through the conditional pass only; captures."""
+    from adaface_dev_amd import rng
+    from adaface_dev_amd.ldm.models.diffusion.ddpm import LatentDiffusion
+    from oracle import diffusion_oracle as D
+    from oracle import unet_oracle as O
+    ld = LatentDiffusion(GPU_TINY_CONFIG)
+    rng.load_synth_weights(ld.model.diffusion_model, seed=11)
+    sd = {k: v.detach().clone() for k, v in ld.model.diffusion_model.state_dict().items()}
+    ld = ld.to(dev)
+    x0 = rng.synth_input("gd.x0", (2, 4, 32, 32), seed=14)
+    noise = rng.synth_input("gd.noise", (2, 4, 32, 32), seed=14)
+    ctx = rng.synth_input("gd.ctx", (2, 77, 64), seed=14)
+    unc = rng.synth_input("gd.unc", (1, 77, 64), seed=14)
+    cot = rng.synth_input("gd.cot", (2, 4, 32, 32), seed=14)
+    t = torch.tensor([310, 870])
+    mask = torch.ones(2, 1, 32, 32)
+    mask[1, :, 24:, :] = 0
+    ld.uncond_context = (unc.to(dev), [""], {})
+    tabs = D.register_schedule(D.make_beta_schedule_linear())
+    eps_fn = lambda x, tt, c: O.unet_forward(sd, GPU_TINY_CONFIG, x, tt, c, {"img_mask": mask, "res_hidden_states_gradscale": 0.5})
+    unc_fn = lambda x, tt, c: O.unet_forward(sd, GPU_TINY_CONFIG, x, tt, c, {})      # the unconditional pass carries no image mask
+    for cfg in (-1, 2.5):
+        cg = ctx.clone().to(dev).requires_grad_(True)
+        ei = {}
+        eps, x_rec, acts = ld.guided_denoise(x0.to(dev), noise.to(dev), t.to(dev), (cg, ["a", "b"], ei), img_mask=mask.to(dev),
+                                             batch_part_has_grad="all", do_pixel_recon=True, cfg_scale=cfg,
+                                             capture_ca_activations=False, res_hidden_states_gradscale=0.5)
+        (eps * cot.to(dev)).sum().backward()
+        cr = ctx.clone().requires_grad_(True)
+        ref, ref_rec = D.guided_denoise(eps_fn, tabs, x0, noise, t, cr, unc.repeat(2, 1, 1), cfg, True, unc_fn)
+        (ref * cot).sum().backward()
+        assert rel_l2(eps.detach().cpu().numpy(), ref.detach().numpy()) < NET_TOL, cfg
+        assert rel_l2(x_rec.detach().cpu().numpy(), ref_rec.detach().numpy()) < NET_TOL, cfg
+        assert rel_l2(cg.grad.cpu().numpy(), cr.grad.numpy()) < 2e-2, cfg
+        assert acts is None and ei["res_hidden_states_gradscale"] == 0.5
+    e_none, rec_none, acts_none = ld.guided_denoise(x0.to(dev), noise.to(dev), t.to(dev), (ctx.to(dev).requires_grad_(True), ["a", "b"], {}),
+                                                    img_mask=mask.to(dev), batch_part_has_grad="none", cfg_scale=2.5,
+                                                    capture_ca_activations=True)
+    assert rec_none is None and not e_none.requires_grad and rel_l2(e_none.cpu().numpy(), ref.detach().numpy()) < NET_TOL
+    assert sorted(acts_none["attn"].keys()) == [22, 23, 24]                       # captures are available on the no-grad path
+    with pytest.raises(NotImplementedError):                                      # ... and refused loudly together with gradients
+        ld.guided_denoise(x0.to(dev), noise.to(dev), t.to(dev), (ctx.to(dev).requires_grad_(True), ["a", "b"], {}),
+                          capture_ca_activations=True)
+    with pytest.raises(NotImplementedError):
+        ld.guided_denoise(x0.to(dev), noise.to(dev), t.to(dev), (ctx.to(dev), ["a", "b"], {}), normalize_cross_attn=True)
+    with pytest.raises(NotImplementedError):
+        ld.guided_denoise(x0.to(dev), noise.to(dev), t.to(dev), (ctx.to(dev), ["a", "b"], {}), batch_part_has_grad="subject-compos")
+
+
 def test_unet_wrapper_ffn_lora_flags_merge_and_restore(dev):
     """apply_model(use_ffn_lora=True, ffn_lora_adapter_name=...) runs the U-Net with the DoRA adapters of the six
     up_blocks.3 conv layers merged in (adaface/lora.py; merged weight == peft's branch form is pinned on CPU in
