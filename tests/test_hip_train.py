@@ -115,6 +115,53 @@ def _oracle_distill(sds, ucfg, ids512, x0, noise, t, fg, steps, pres, sbg_sd=Non
     return loss, sbg, lw
 
 
+def test_unet_teacher_cfg_and_shared_noise_vs_oracle(dev):
+    """UNetTeacher.forward (unet_teachers.py:64-187) with classifier-free guidance: doubled [positive; negative] context, a separate
+    negative context, and same_t_noise_across_instances -- 3 denoising steps, every eps / x0 / t against the oracle."""
+    from adaface_dev_amd import rng
+    from adaface_dev_amd.adaface.unet_teachers import UNetTeacher
+    from adaface_dev_amd.ldm.models.diffusion.ddpm import LatentDiffusion
+    from adaface_dev_amd.ldm.modules.diffusionmodules.openaimodel import UNetModel
+    from oracle import diffusion_oracle as D
+    from oracle import train_oracle as T
+    from oracle import unet_oracle as O
+    ucfg = dict(CFG, context_dim=128)
+    unet = UNetModel(**ucfg)
+    rng.load_synth_weights(unet, seed=42)
+    sd = {k: v.detach().clone() for k, v in unet.state_dict().items()}
+    ld = LatentDiffusion(ucfg).to(dev)
+    teacher = UNetTeacher(unet.to(dev), cfg_scale_range=(1.7, 1.7), p_uses_cfg=0.0)
+    x0 = rng.synth_input("tc.x0", (2, 4, 32, 32), seed=47)
+    noise = rng.synth_input("tc.noise", (2, 4, 32, 32), seed=47)
+    pos = rng.synth_input("tc.pos", (2, 20, 128), seed=47)
+    neg = rng.synth_input("tc.neg", (2, 20, 128), seed=47)
+    t = torch.tensor([800, 720])
+    g = torch.Generator().manual_seed(9)
+    pres = [(torch.rand(2, generator=g), rng.synth_input(f"tc.n{i}", (2, 4, 32, 32), seed=47)) for i in range(2)]
+    tabs = D.register_schedule(D.make_beta_schedule_linear())
+    eps_fn = lambda x, tt, c: O.unet_forward(sd, ucfg, x, tt, c, {})
+    to = lambda v: v.to(dev)
+    cases = [dict(ctx=torch.cat([pos, neg]), negative=None, same=False), dict(ctx=pos, negative=neg, same=False),
+             dict(ctx=torch.cat([pos, neg]), negative=None, same=True)]
+    for c in cases:
+        preds, xs, ns, ts = teacher(ld, to(x0), to(noise), to(t), to(c["ctx"]), negative_context=None if c["negative"] is None else to(c["negative"]),
+                                    num_denoising_steps=3, force_uses_cfg=True, same_t_noise_across_instances=c["same"],
+                                    presampled=[(to(r), to(n)) for r, n in pres])
+        assert teacher.uses_cfg and abs(teacher.cfg_scale - 1.7) < 1e-9
+        rp, rx, rn, rt = T.teacher_multistep(eps_fn, tabs, x0, noise, t, c["ctx"], 3, pres, cfg_scale=1.7, negative_ctx=c["negative"],
+                                             same_t_noise_across_instances=c["same"])
+        for i in range(3):
+            assert torch.equal(ts[i].cpu(), rt[i]), (c["same"], i)
+            assert rel_l2(preds[i].cpu().numpy(), rp[i].numpy()) < 1e-2, (c["same"], i)
+            assert rel_l2(xs[i + 1].cpu().numpy(), rx[i + 1].numpy()) < 1e-2, (c["same"], i)
+        if c["same"]:
+            assert torch.equal(ts[1][0], ts[1][1]) and torch.equal(ns[1][0], ns[1][1])
+    # without CFG a doubled context is reduced to its positive half (extract_pos_context)
+    preds, *_ = teacher(ld, to(x0), to(noise), to(t), to(torch.cat([pos, neg])), num_denoising_steps=1)
+    assert not teacher.uses_cfg and teacher.cfg_scale == 1
+    assert rel_l2(preds[0].cpu().numpy(), T.teacher_multistep(eps_fn, tabs, x0, noise, t, pos, 1, [])[0][0].numpy()) < 1e-2
+
+
 def test_distill_trainer_micro_batch_loss_and_weight_gradients_vs_oracle(dev):
     """face IDs -> Arc2Face encoder -> trainable SubjBasisGenerator -> frozen text encoder -> student/teacher U-Nets ->
     loss; the gradients of every SubjBasisGenerator weight (flat arena) against autograd through the fp32 CPU oracles."""
