@@ -143,6 +143,17 @@ def gen_unet_full(out):
     dt = time.time() - t0
     res["eps"] = eps.numpy()
     res["ref_cpu_seconds"] = np.float64(dt)
+    # gradients of <eps, cot> w.r.t. x and context through the REFERENCE module's autograd at full size (base weights frozen)
+    for h in hooks:
+        h.remove()
+    for p in m.parameters():
+        p.requires_grad_(False)
+    cot = rng.synth_input("full.cot", (1, 4, 64, 64), seed=0)
+    xg, cg = x.clone().requires_grad_(True), ctx.clone().requires_grad_(True)
+    t0 = time.time()
+    (m(xg, t, cg, extra_info={}) * cot).sum().backward()
+    res["grad_x"], res["grad_ctx"] = xg.grad.numpy(), cg.grad.numpy()
+    print(f"unet_full backward {time.time() - t0:.1f}s, |grad_ctx| {float(cg.grad.abs().mean()):.3e}")
     np.savez_compressed(os.path.join(out, "unet_full.npz"), **res)
     print(f"unet_full: {nparams} params, {ntens} tensors, fwd {dt:.1f}s, eps absmean {float(eps.abs().mean()):.4f}")
 

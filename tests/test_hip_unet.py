@@ -275,6 +275,21 @@ def test_unet_full_size_vs_reference_golden(dev, full_model):
     assert err < NET_TOL
 
 
+def test_unet_full_size_backward_vs_reference_autograd(dev, full_model):
+    """SD-1.5-size manual backward (one autograd node, hand-written backward kernels): d<eps, cot>/dx and /dcontext against the
+    gradients torch autograd produced through the REFERENCE UNetModel in fp32 (tests/golden/unet_full.npz)."""
+    from adaface_dev_amd import rng
+    g = np.load(os.path.join(GOLDEN, "unet_full.npz"))
+    x = rng.synth_input("full.x", (1, 4, 64, 64), seed=0).to(dev).requires_grad_(True)
+    ctx = rng.synth_input("full.ctx", (1, 77, 768), seed=0).to(dev).requires_grad_(True)
+    cot = rng.synth_input("full.cot", (1, 4, 64, 64), seed=0).to(dev)
+    eps = full_model(x, torch.tensor([500], device=dev), ctx, extra_info={})
+    (eps * cot).sum().backward()
+    ex, ec = rel_l2(x.grad.cpu().numpy(), g["grad_x"]), rel_l2(ctx.grad.cpu().numpy(), g["grad_ctx"])
+    print(f"full-size backward vs reference autograd: dx {ex:.3e}  dcontext {ec:.3e}")
+    assert rel_l2(eps.detach().cpu().numpy(), g["eps"]) < NET_TOL and ex < 2e-2 and ec < 2e-2
+
+
 def test_unet_full_size_nonsquare_768x512_vs_oracle(dev, full_model):
     """SD-1.5-size U-Net on a 96 x 64 latent (768 x 512 image: 6144 / 1536 / 384 / 96 tokens per level) with 97 context tokens,
     against the fp32 CPU oracle run on the same weights (a few seconds on the GPU box's host cores)."""

@@ -76,8 +76,13 @@ def test_full_unet_eps():
     sd = rng.synth_state_dict(shapes, seed=0)
     x = rng.synth_input("full.x", (1, 4, 64, 64), seed=0)
     ctx = rng.synth_input("full.ctx", (1, 77, 768), seed=0)
+    x.requires_grad_(True)
+    ctx.requires_grad_(True)
     eps = O.unet_forward(sd, SD15_UNET_CONFIG, x, torch.tensor([500]), ctx, {})
-    assert rel_l2(eps.numpy(), g["eps"]) < 1e-4
+    assert rel_l2(eps.detach().numpy(), g["eps"]) < 1e-4
+    # the oracle's autograd against the reference module's at full size (what the full-size GPU backward test is held to)
+    (eps * rng.synth_input("full.cot", (1, 4, 64, 64), seed=0)).sum().backward()
+    assert rel_l2(x.grad.numpy(), g["grad_x"]) < 1e-4 and rel_l2(ctx.grad.numpy(), g["grad_ctx"]) < 1e-4
 
 
 def test_schedule_tables():
