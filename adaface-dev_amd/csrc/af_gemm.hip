@@ -407,7 +407,7 @@ int launch_tile(const GemmDev& p, int tile, hipStream_t stream) {
 
 // af_gemm3.hip
 int af_gemm3_try_launch(const af_gemm_desc* d, int splits, int wide, hipStream_t stream);
-int af_gemm3_effective_splits(const af_gemm_desc* d, int splits);
+int af_gemm3_effective_splits(const af_gemm_desc* d, int splits, int wide);
 
 extern "C" int af_gemm(const af_gemm_desc* d, void* stream) {
   AF_REQUIRE(d != nullptr, "af_gemm: null descriptor");
@@ -498,14 +498,14 @@ extern "C" int af_gemm(const af_gemm_desc* d, void* stream) {
     const long t128 = (long)((d->M + 127) / 128) * ((d->N + 127) / 128);
     tile = (t128 >= 192 && d->N >= 96) ? 1 : 2;
   }
-  AF_REQUIRE(tile >= 1 && tile <= 6, "af_gemm: tile must be 0 .. 6");
+  AF_REQUIRE(tile >= 1 && tile <= 7, "af_gemm: tile must be 0 .. 7");
 
   AfLaunchScope scope(AF_FAM_GEMM, stream);
   hipStream_t s = (hipStream_t)stream;
   AF_REQUIRE(d->tap_shift == 0 || (d->tap_shift == 1 && d->taps == 9 && !p.upsample), "af_gemm: tap_shift is 0 or 1 (3x3, no upsample)");
   if (tile >= 3 && d->tap_shift) tile = 1;          // the ring kernel keeps the symmetric-padding loader only
   if (tile >= 3) {
-    const int eff = af_gemm3_effective_splits(d, p.splits);
+    const int eff = af_gemm3_effective_splits(d, p.splits, tile - 3);
     const int rc3 = af_gemm3_try_launch(d, p.splits, tile - 3, s);
     if (rc3 == 0) return af_check_launch("af_gemm(tile 3)");
     if (rc3 == 2) {

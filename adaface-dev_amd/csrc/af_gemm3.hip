@@ -444,17 +444,251 @@ void launch3(const Gemm3Dev& p0, hipStream_t stream) {
   hipLaunchKernelGGL((af_gemm3_kernel<TAPS, NWM, NWN, TN, EPI, NST>), grid, block, lds, stream, p);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Whole-line variant (tile 7): 128 x 320 tile, 8 waves, 64-wide K stages whose rows are 128 bytes, so that every LDS-DMA wave
+// instruction fetches 8 rows x one full 128-byte cache line (the 32-wide ring fetches 16 rows x half a line: twice the L2 requests,
+// profiles/r01r_gemm_diagnosis.txt) and the wait -> barrier -> issue chain runs once per 64 K instead of once per 32.  Two 56 KB
+// slots: stage i+1 streams in while stage i is computed.  56 pieces per stage = exactly 7 per wave (2 A + 5 W).  Fragment rows are
+// 128 bytes apart, so 16 consecutive lanes alias two rows per 256 bytes of banks: the 16-byte chunk index is XOR-ed with
+// (row >> 1) & 7 on the DMA source side.  Standard epilogue only (staged); channel counts and K padding multiples of 64.
+template <int TAPS>
+__global__ __launch_bounds__(512, 1) void af_gemm3w_kernel(Gemm3Dev p) {
+  constexpr int TM = 4, TN = 5, NWM = 2, NW = 8;
+  constexpr int BM = 128, BN = 320, BKW = 64;
+  constexpr int APW = (BM / 8) / NW;                  // 2 A pieces (8 rows x 128 B) per wave per stage
+  constexpr int WPW = (BN / 8) / NW;                  // 5 W pieces
+  constexpr int STAGE = (BM + BN) * 128;              // 57344 bytes
+  extern __shared__ __attribute__((aligned(16))) char af_smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave % NWM, wn = wave / NWM;
+
+  int tile_m, tile_n;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    if (p.n_major) {
+      tile_n = lid / p.tiles_m;
+      tile_m = lid - tile_n * p.tiles_m;
+    } else {
+      tile_m = lid / p.tiles_n;
+      tile_n = lid - tile_m * p.tiles_n;
+    }
+  }
+
+  // ---- loader state: wave w fills A pieces {w*APW + j} and W pieces {w*WPW + j}; lane = (row in piece, chunk slot)
+  const int prow = lane >> 3, slot = lane & 7;
+  const int Cin = p.c1 + p.c2;
+  int a_base[APW], a_lc[APW];
+  unsigned a_mask[APW];
+  const half_t* wptr[WPW];
+  bool wok[WPW];
+#pragma unroll
+  for (int j = 0; j < APW; ++j) {
+    const int row = (wave * APW + j) * 8 + prow;              // row inside the tile
+    a_lc[j] = slot ^ ((row >> 1) & 7);                       // logical chunk this lane fetches
+    const int m = tile_m * BM + row;
+    if (TAPS == 9) {
+      unsigned mk = 0;
+      int base = 0;
+      if (m < p.M) {
+        const int b = m / p.HoWo;
+        const int rem = m - b * p.HoWo;
+        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        const int cy = oy * p.stride, cx = ox * p.stride;
+#pragma unroll
+        for (int t9 = 0; t9 < 9; ++t9) {
+          const int iy = cy + t9 / 3 - 1, ix = cx + t9 % 3 - 1;
+          if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) mk |= 1u << t9;
+        }
+        base = (b * p.H + cy) * p.W + cx;
+      }
+      a_mask[j] = mk;
+      a_base[j] = base;
+    } else {
+      a_mask[j] = m < p.M ? 1u : 0u;
+      a_base[j] = m;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < WPW; ++j) {
+    const int row = (wave * WPW + j) * 8 + prow;
+    const int n = tile_n * BN + row;
+    wok[j] = n < p.npad;
+    wptr[j] = p.wt + (size_t)(wok[j] ? n : 0) * p.kpad + (slot ^ ((row >> 1) & 7)) * 8;
+  }
+
+  auto issue_stage = [&](int kt, int sl) {
+    char* As = af_smem + sl * STAGE;
+    char* Ws = As + BM * 128;
+    const int k0 = kt * BKW;
+    if (TAPS == 9) {
+      const int tp = k0 / Cin;                      // workgroup-uniform (64 | c1, c2)
+      const int c0 = k0 - tp * Cin;
+      const bool first = c0 < p.c1;
+      const half_t* src = first ? p.a1 : p.a2;
+      const int cs = first ? p.c1 : p.c2;
+      const int coff = first ? c0 : c0 - p.c1;
+      const int dpix = (tp / 3 - 1) * p.W + (tp % 3 - 1);
+#pragma unroll
+      for (int j = 0; j < APW; ++j) {
+        const bool ok = (a_mask[j] >> tp) & 1u;     // tp >= 9 (K padding): no bit set
+        const half_t* g = ok ? src + (size_t)(a_base[j] + dpix) * cs + coff + a_lc[j] * 8 : p.zeros;
+        glds16(g, As + (wave * APW + j) * 1024);
+      }
+    } else {
+      const bool first = k0 < p.c1;                 // uniform: 64 | c1
+      const half_t* src = first ? p.a1 : p.a2;
+      const int ld = first ? p.lda1 : p.lda2;
+      const int koff = first ? k0 : k0 - p.c1;
+#pragma unroll
+      for (int j = 0; j < APW; ++j) {
+        const bool ok = a_mask[j] && (k0 + a_lc[j] * 8 < p.K);
+        const half_t* g = ok ? src + (size_t)a_base[j] * ld + koff + a_lc[j] * 8 : p.zeros;
+        glds16(g, As + (wave * APW + j) * 1024);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < WPW; ++j) glds16(wok[j] ? wptr[j] + k0 : p.zeros, Ws + (wave * WPW + j) * 1024);
+  };
+
+  floatx4 acc[TN][TM];
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) acc[tn][tm] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+  const int fr = lane & 15, fq = lane >> 4;
+  // fragment offsets inside a 16-row group (rows are group-aligned, so (row >> 1) & 7 == fr >> 1): K half kk, chunk kk*4 + fq
+  const int rd0 = fr * 128 + (((0 * 4 + fq) ^ (fr >> 1)) * 16);
+  const int rd1 = fr * 128 + (((1 * 4 + fq) ^ (fr >> 1)) * 16);
+
+  const int nk_total = p.kpad / BKW;
+  const int kt_begin = blockIdx.y * p.kt_per_split;
+  const int kt_end = min(nk_total, kt_begin + p.kt_per_split);
+  const int nk = kt_end - kt_begin;
+
+  if (nk > 0) issue_stage(kt_begin, 0);
+  half8_t wf[TN], xf[TM];
+  for (int i = 0; i < nk; ++i) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // stage i (the only one in flight) has landed
+    __builtin_amdgcn_s_barrier();                           // ... for every wave; everyone is done reading the other slot
+    if (i + 1 < nk) issue_stage(kt_begin + i + 1, (i + 1) & 1);
+    const char* As = af_smem + (i & 1) * STAGE;
+    const char* Ws = As + BM * 128;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int rd = kk ? rd1 : rd0;
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) wf[tn] = *reinterpret_cast<const half8_t*>(Ws + (wn * TN * 16 + tn * 16) * 128 + rd);
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) xf[tm] = *reinterpret_cast<const half8_t*>(As + (wm * 64 + tm * 16) * 128 + rd);
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+          acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[tn], xf[tm], acc[tn][tm], 0, 0, 0);
+    }
+  }
+
+  if (p.splits > 1) {
+    float* wsp = p.ws + (size_t)blockIdx.y * p.M * p.N;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      const int m = tile_m * BM + wm * 64 + tm * 16 + fr;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        const int n0 = tile_n * BN + wn * TN * 16 + tn * 16 + 4 * fq;
+        if (n0 < p.N) *reinterpret_cast<floatx4*>(wsp + (size_t)m * p.N + n0) = acc[tn][tm];
+      }
+    }
+    return;
+  }
+  // ---- staged standard epilogue (same arithmetic as af_gemm3_kernel's)
+  constexpr int TS = BN + 8;
+  __syncthreads();
+  half_t* T = reinterpret_cast<half_t*>(af_smem);
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    const int row = wm * 64 + tm * 16 + fr;
+    const int m = tile_m * BM + row;
+    const bool mok = m < p.M;
+    const int bidx = (p.rowbias && mok) ? m / p.rows_per_batch : 0;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const int col = wn * TN * 16 + tn * 16 + 4 * fq;
+      const int n0 = tile_n * BN + col;
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      if (mok && n0 < p.N) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[tn][tm][e];
+        if (p.bias) {
+          const floatx4 bv = *reinterpret_cast<const floatx4*>(p.bias + n0);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += bv[e];
+        }
+        if (p.rowbias) {
+          const half4_t rv = *reinterpret_cast<const half4_t*>(p.rowbias + (size_t)bidx * p.ld_rowbias + n0);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
+        }
+        if (p.act == 1) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = af_silu(v[e]);
+        } else if (p.act == 3) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = v[e] / (1.0f + __expf(-1.702f * v[e]));
+        }
+        if (p.residual) {
+          const half4_t rv = *reinterpret_cast<const half4_t*>(p.residual + (size_t)m * p.N + n0);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
+        }
+      }
+      const half4_t h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+      *reinterpret_cast<half4_t*>(T + row * TS + col) = h;
+    }
+  }
+  __syncthreads();
+  constexpr int CPR = BN / 8;
+  for (int c = tid; c < BM * CPR; c += 64 * NW) {
+    const int row = c / CPR, cc = c - row * CPR;
+    const int m = tile_m * BM + row, n = tile_n * BN + cc * 8;
+    if (m < p.M && n < p.N)
+      *reinterpret_cast<half8_t*>(p.out + (size_t)m * p.ld_out + n) = *reinterpret_cast<const half8_t*>(T + row * TS + cc * 8);
+  }
+}
+
+template <int TAPS>
+void launch3w(const Gemm3Dev& p0, hipStream_t stream) {
+  Gemm3Dev p = p0;
+  constexpr size_t lds = 2 * (128 + 320) * 128;
+  p.tiles_n = (p.N + 319) / 320;
+  p.tiles_m = (p.M + 127) / 128;
+  p.n_major = af_gemm_n_major(p.M, p.N, p.K, TAPS == 9 ? p.c1 + p.c2 : p.K);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&af_gemm3w_kernel<TAPS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  dim3 grid(p.tiles_m * p.tiles_n, p.splits), block(512);
+  hipLaunchKernelGGL((af_gemm3w_kernel<TAPS>), grid, block, lds, stream, p);
+}
+
 }  // namespace
 
 // Called by af_gemm (af_gemm.hip) for tile == 3 after the common argument validation.  Returns 1 if the shape is
 // outside this kernel's scope (caller falls back), 0 after a launch.
 int af_gemm3_try_launch(const af_gemm_desc* d, int splits, int wide, hipStream_t stream) {
-  // wide: 0 = 128 x 128, 1 = 128 x 320 (GEGLU 128 x 256), 2 = 256 x 256, 3 = 256 x 320 (8 waves as 4 x 2)
+  // wide: 0 = 128 x 128, 1 = 128 x 320 (GEGLU 128 x 256), 2 = 256 x 256, 3 = 256 x 320 (8 waves as 4 x 2), 4 = 128 x 320 whole-line
   const bool geglu = d->act == AF_ACT_GEGLU, split_t = d->out_mode == AF_OUT_SPLIT_T;
   if (d->upsample || d->c1 % BK3 != 0 || d->c2 % BK3 != 0 || d->zeros == nullptr) return 1;
   if ((geglu || split_t) && (d->taps != 1 || splits > 1)) return 1;
   if (geglu && (!wide || d->N % 256 != 0)) return 1;          // GEGLU: 128 x 256 tile (or the 256-row tiles)
   if (!geglu && wide == 1 && d->N % 320 != 0) return 1;
+  if (wide == 4 && (geglu || split_t || d->N % 320 != 0 || d->c1 % 64 != 0 || d->c2 % 64 != 0 || d->kpad % 64 != 0)) return 1;
   if (wide == 2 && (d->N % 256 != 0 || d->taps != 1 || split_t || splits > 1)) return 1;
   if (wide == 3 && (d->N % 320 != 0 || d->taps != 1 || split_t || splits > 1)) return 1;
   Gemm3Dev p;
@@ -501,6 +735,16 @@ int af_gemm3_try_launch(const af_gemm_desc* d, int splits, int wide, hipStream_t
     const int ncols = geglu ? d->N / 2 : d->N;
     p.stage_ok = ncols % 8 == 0 && p.ld_out % 8 == 0 && (reinterpret_cast<uintptr_t>(p.out) & 15) == 0;
   }
+  if (wide == 4) {
+    if (!p.stage_ok) return 1;
+    const int nk64 = p.kpad / 64;                               // this variant counts 64-wide K steps
+    p.splits = splits > 1 ? splits : 1;
+    if (p.splits > nk64) p.splits = nk64;
+    p.kt_per_split = (nk64 + p.splits - 1) / p.splits;
+    p.splits = (nk64 + p.kt_per_split - 1) / p.kt_per_split;
+    if (d->taps == 9) launch3w<9>(p, stream); else launch3w<1>(p, stream);
+    return p.splits > 1 ? 2 : 0;
+  }
   if (wide == 2) {
     if (geglu) launch3<1, 4, 2, 8, E3_GEGLU>(p, stream); else launch3<1, 4, 2, 8>(p, stream);
   } else if (wide == 3) {
@@ -517,8 +761,8 @@ int af_gemm3_try_launch(const af_gemm_desc* d, int splits, int wide, hipStream_t
   return p.splits > 1 ? 2 : 0;   // 2: caller must run the split-K reduce pass with p.splits
 }
 
-int af_gemm3_effective_splits(const af_gemm_desc* d, int splits) {
-  const int nk = d->kpad / BK3;
+int af_gemm3_effective_splits(const af_gemm_desc* d, int splits, int wide) {
+  const int nk = d->kpad / (wide == 4 ? 64 : BK3);
   int s = splits > 1 ? splits : 1;
   if (s > nk) s = nk;
   const int per = (nk + s - 1) / s;

@@ -125,6 +125,54 @@ def test_conv3x3_tile4_wide(dev, B, H, W, c1, c2, cout, stride, splits):
     assert rel_l2(out.float().cpu().permute(0, 3, 1, 2).numpy(), ref.numpy()) < TOL
 
 
+@pytest.mark.parametrize("M,N,K,tile,act", [(700, 1280, 320, 5, 0), (700, 1280, 320, 6, 0), (300, 2560, 192, 5, 2), (520, 2560, 320, 6, 2),
+                                             (256, 640, 64, 6, 0)])
+def test_gemm_256_row_tiles(dev, M, N, K, tile, act):
+    """256 x 256 (tile 5) / 256 x 320 (tile 6) ring tiles: plain GEMM with bias + residual (staged epilogue) and GEGLU, ragged M."""
+    from adaface_dev_amd import ops
+    a, w = rnd((M, K), 1), rnd((N, K), 2, K ** -0.5)
+    b = torch.randn(N, generator=torch.Generator().manual_seed(3)) * 0.1
+    if act == 2:
+        wi, bi = ops.interleave_geglu(w.float(), b)
+        out = ops.gemm(a.to(dev), ops.pack_matrix(wi, bi, dev), act=ops.AF_ACT_GEGLU, tile=tile)
+        x, g = (a.float() @ w.float().t() + b).chunk(2, dim=-1)
+        ref = x * F.gelu(g)
+    else:
+        r = rnd((M, N), 4)
+        out = ops.gemm(a.to(dev), ops.pack_matrix(w, b, dev), residual=r.to(dev), tile=tile)
+        ref = a.float() @ w.float().t() + b + r.float()
+    assert out.shape == ref.shape and rel_l2(out.float().cpu().numpy(), ref.numpy()) < TOL
+
+
+@pytest.mark.parametrize("M,N,K,splits", [(300, 320, 320, 1), (4096, 640, 1280, 2), (130, 960, 64, 1), (1000, 320, 2880, 3)])
+def test_gemm_tile7_whole_line(dev, M, N, K, splits):
+    """128 x 320 tile with 64-wide K stages (whole-cache-line LDS-DMA pieces, two slots): ragged M, one-stage K, split-K."""
+    from adaface_dev_amd import ops
+    a, w = rnd((M, K), 1), rnd((N, K), 2, K ** -0.5)
+    b, r = torch.randn(N, generator=torch.Generator().manual_seed(3)), rnd((M, N), 4)
+    out = ops.gemm(a.to(dev), ops.pack_matrix(w, b, dev), residual=r.to(dev), tile=7, splits=splits)
+    ref = a.float() @ w.float().t() + b + r.float()
+    assert rel_l2(out.float().cpu().numpy(), ref.numpy()) < TOL
+
+
+@pytest.mark.parametrize("B,H,W,c1,c2,cout,stride,splits", [(1, 32, 32, 320, 0, 320, 1, 1), (2, 16, 16, 640, 320, 640, 1, 2), (2, 16, 16, 320, 0, 320, 2, 1),
+                                                           (3, 8, 8, 1280, 1280, 1280, 1, 4)])
+def test_conv3x3_tile7_whole_line(dev, B, H, W, c1, c2, cout, stride, splits):
+    from adaface_dev_amd import ops
+    cin = c1 + c2
+    x1 = rnd((B, H, W, c1), 1)
+    x2 = rnd((B, H, W, c2), 2) if c2 else None
+    w = rnd((cout, cin, 3, 3), 3, (9 * cin) ** -0.5)
+    bias, rowb = torch.randn(cout, generator=torch.Generator().manual_seed(4)), rnd((B, cout), 5)
+    xin = (x1 if x2 is None else torch.cat([x1, x2], -1)).float().permute(0, 3, 1, 2)
+    ref = F.conv2d(xin, w.float(), bias, stride=stride, padding=1) + rowb.float()[:, :, None, None]
+    res = rnd(tuple(ref.permute(0, 2, 3, 1).shape), 6)
+    ref = ref + res.float().permute(0, 3, 1, 2)
+    out = ops.conv3x3(x1.to(dev), ops.pack_conv3x3(w, bias, dev), x2=None if x2 is None else x2.to(dev), stride=stride,
+                      rowbias=rowb.to(dev), residual=res.to(dev), tile=7, splits=splits)
+    assert rel_l2(out.float().cpu().permute(0, 3, 1, 2).numpy(), ref.numpy()) < TOL
+
+
 def test_gemm_concat_k_and_silu(dev):
     from adaface_dev_amd import ops
     M, K1, K2, N = 300, 128, 64, 192

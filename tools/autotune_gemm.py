@@ -72,11 +72,13 @@ def main():
         retuned.add(key)
         nk = d.kpad // 64
         best, best_t, res = (0, 1), None, {}
-        for tile in (1, 2, 3, 4, 5, 6):
-            if tile >= 5 and (d.taps != 1 or d.out_mode != 0 or d.M * d.N < 256 * 256 * 128):
+        for tile in (1, 2, 3, 4, 5, 6, 7):
+            if tile == 7 and (d.N % 320 != 0 or d.act == _lib.AF_ACT_GEGLU or d.out_mode != 0 or d.upsample or d.c1 % 64 or d.c2 % 64):
+                continue                        # whole-line 128 x 320 variant: standard epilogue, 64-multiples of channels
+            if tile in (5, 6) and (d.taps != 1 or d.out_mode != 0 or d.M * d.N < 256 * 256 * 128):
                 continue                        # 256-row tiles: plain / GEGLU 1x1 GEMMs with at least ~128 tiles
             for splits in (1, 2, 3, 4, 6, 8, 12, 16):
-                if tile >= 5 and splits > 1:
+                if tile in (5, 6) and splits > 1:
                     continue
                 if splits > 1 and (d.act == _lib.AF_ACT_GEGLU or d.out_mode != 0 or nk < 4 * splits):
                     continue
