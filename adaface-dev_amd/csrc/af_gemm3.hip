@@ -66,6 +66,185 @@ __device__ __forceinline__ void glds16(const half_t* src, char* lds_dst) {
 // padded from 20 to 24; padding pieces fetch the zero page), so the counted waits are the same constants.
 enum { E3_STD = 0, E3_GEGLU = 1, E3_SPLIT_T = 2 };
 
+// Epilogue shared by the ring kernel and the whole-line kernel: split-K partial tiles, or bias / row bias / activation / residual
+// (identical arithmetic to af_gemm.hip's standard epilogue), GEGLU, transposed-V split.  LDSB = bytes of LDS the main loop owned.
+template <int EPI, int NWM, int NWN, int TN, int LDSB>
+__device__ __forceinline__ void gemm3_epilogue(const Gemm3Dev& p, floatx4 (&acc)[TN][4], char* af_smem, int tile_m, int tile_n, int wm, int wn,
+                                               int fr, int fq, int tid) {
+  constexpr int TM = 4, NW = NWM * NWN, BM = NWM * 64, BN = NWN * TN * 16;
+  // ---- epilogue (identical arithmetic to af_gemm.hip's standard epilogue)
+  if (p.splits > 1) {
+    float* wsp = p.ws + (size_t)blockIdx.y * p.M * p.N;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      const int m = tile_m * BM + wm * 64 + tm * 16 + fr;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        const int n0 = tile_n * BN + wn * TN * 16 + tn * 16 + 4 * fq;
+        if (n0 < p.N) *reinterpret_cast<floatx4*>(wsp + (size_t)m * p.N + n0) = acc[tn][tm];
+      }
+    }
+    return;
+  }
+  // Staged epilogue: the tile is assembled in LDS (the ring is idle now) and written out as whole rows, 16 bytes per lane, instead
+  // of 8-byte stores that touch 16 rows x 32 bytes per wave instruction.  Measured on M32768 N2560 K320 the direct form spends
+  // 66 of 141 us in the epilogue (profiles/r01r_gemm_epilogue.txt).
+  constexpr int BNO = EPI == E3_GEGLU ? BN / 2 : BN;          // output columns of the tile
+  constexpr int TS = BNO + 8;                                  // staging row stride (halves): 16 bytes of padding
+  constexpr bool kCanStage = (EPI == E3_STD || EPI == E3_GEGLU) && (size_t)BM * TS * 2 <= (size_t)LDSB;
+  if (kCanStage && p.stage_ok && !(p.ablate & 32)) {
+    __syncthreads();                                           // every wave is done reading the last ring slot
+    half_t* T = reinterpret_cast<half_t*>(af_smem);
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      const int row = wm * 64 + tm * 16 + fr;
+      const int m = tile_m * BM + row;
+      const bool mok = m < p.M;
+      const int bidx = (p.rowbias && mok) ? m / p.rows_per_batch : 0;
+      if (EPI == E3_GEGLU) {
+#pragma unroll
+        for (int tn = 0; tn + 1 < TN; tn += 2) {
+          const int nt = tile_n * BN + wn * TN * 16 + tn * 16;
+          const int n0 = nt + 4 * fq;
+          const int col = ((wn * TN * 16 + tn * 16) >> 1) + 4 * fq;
+          float v[4] = {0.f, 0.f, 0.f, 0.f};
+          if (mok && (nt >> 1) + 4 * fq < (p.N >> 1)) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float xv = acc[tn][tm][e], gv = acc[tn + 1][tm][e];
+              if (p.bias) {
+                xv += p.bias[n0 + e];
+                gv += p.bias[n0 + 16 + e];
+              }
+              v[e] = xv * af_gelu_erf(gv);
+            }
+          }
+          const half4_t h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+          *reinterpret_cast<half4_t*>(T + row * TS + col) = h;
+        }
+      } else {
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+          const int col = wn * TN * 16 + tn * 16 + 4 * fq;
+          const int n0 = tile_n * BN + col;
+          float v[4] = {0.f, 0.f, 0.f, 0.f};
+          if (mok && n0 < p.N) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[tn][tm][e];
+            if (p.bias) {
+              const floatx4 bv = *reinterpret_cast<const floatx4*>(p.bias + n0);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] += bv[e];
+            }
+            if (p.rowbias) {
+              const half4_t rv = *reinterpret_cast<const half4_t*>(p.rowbias + (size_t)bidx * p.ld_rowbias + n0);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
+            }
+            if (p.act == 1) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = af_silu(v[e]);
+            } else if (p.act == 3) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = v[e] / (1.0f + __expf(-1.702f * v[e]));
+            }
+            if (p.residual) {
+              const half4_t rv = *reinterpret_cast<const half4_t*>(p.residual + (size_t)m * p.N + n0);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
+            }
+          }
+          const half4_t h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+          *reinterpret_cast<half4_t*>(T + row * TS + col) = h;
+        }
+      }
+    }
+    __syncthreads();
+    constexpr int CPR = BNO / 8;                                // 16-byte chunks per output row
+    const int ncols = EPI == E3_GEGLU ? (p.N >> 1) : p.N;
+    for (int c = tid; c < BM * CPR; c += 64 * NW) {
+      const int row = c / CPR, cc = c - row * CPR;
+      const int m = tile_m * BM + row, n = tile_n * BNO + cc * 8;
+      if (m < p.M && n < ncols)
+        *reinterpret_cast<half8_t*>(p.out + (size_t)m * p.ld_out + n) = *reinterpret_cast<const half8_t*>(T + row * TS + cc * 8);
+    }
+    return;
+  }
+  if (EPI == E3_GEGLU) {
+    // W rows interleaved [16 value | 16 gate]: adjacent MFMA n-tiles pair up in the same lane / register
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      const int m = tile_m * BM + wm * 64 + tm * 16 + fr;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int tn = 0; tn + 1 < TN; tn += 2) {
+        const int nt = tile_n * BN + wn * TN * 16 + tn * 16;
+        const int n0 = nt + 4 * fq, no = (nt >> 1) + 4 * fq;
+        if (no >= (p.N >> 1)) continue;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float xv = acc[tn][tm][e], gv = acc[tn + 1][tm][e];
+          if (p.bias) {
+            xv += p.bias[n0 + e];
+            gv += p.bias[n0 + 16 + e];
+          }
+          v[e] = xv * af_gelu_erf(gv);
+        }
+        const half4_t h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+        *reinterpret_cast<half4_t*>(p.out + (size_t)m * p.ld_out + no) = h;
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    const int m = tile_m * BM + wm * 64 + tm * 16 + fr;
+    if (m >= p.M) continue;
+    const int bidx = (p.rowbias || EPI == E3_SPLIT_T) ? m / p.rows_per_batch : 0;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const int n0 = tile_n * BN + wn * TN * 16 + tn * 16 + 4 * fq;
+      if (n0 >= p.N) continue;
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = acc[tn][tm][e];
+      if (p.bias) {
+        const floatx4 bv = *reinterpret_cast<const floatx4*>(p.bias + n0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += bv[e];
+      }
+      if (p.rowbias) {
+        const half4_t rv = *reinterpret_cast<const half4_t*>(p.rowbias + (size_t)bidx * p.ld_rowbias + n0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
+      }
+      if (p.act == 1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = af_silu(v[e]);
+      } else if (p.act == 3) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] / (1.0f + __expf(-1.702f * v[e]));
+      }
+      if (EPI == E3_SPLIT_T && n0 >= p.split_col) {   // V columns: written transposed [B][N - split_col][ld_out2]
+        const int tok = m - bidx * p.rows_per_batch;
+        half_t* o2 = p.out2 + ((size_t)bidx * (p.N - p.split_col) + (n0 - p.split_col)) * p.ld_out2 + tok;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o2[(size_t)e * p.ld_out2] = (half_t)v[e];
+        continue;
+      }
+      if (p.residual) {
+        const half4_t rv = *reinterpret_cast<const half4_t*>(p.residual + (size_t)m * p.N + n0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
+      }
+      const half4_t h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+      *reinterpret_cast<half4_t*>(p.out + (size_t)m * p.ld_out + n0) = h;
+    }
+  }
+}
+
 template <int TAPS, int NWM, int NWN, int TN, int EPI, int NST>
 __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void af_gemm3_kernel(Gemm3Dev p) {
   constexpr int TM = 4;
@@ -251,177 +430,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void af_gem
     if (sacc == 12345.678f) p.out[0] = (half_t)sacc;
     return;
   }
-  // ---- epilogue (identical arithmetic to af_gemm.hip's standard epilogue)
-  if (p.splits > 1) {
-    float* wsp = p.ws + (size_t)blockIdx.y * p.M * p.N;
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm) {
-      const int m = tile_m * BM + wm * 64 + tm * 16 + fr;
-      if (m >= p.M) continue;
-#pragma unroll
-      for (int tn = 0; tn < TN; ++tn) {
-        const int n0 = tile_n * BN + wn * TN * 16 + tn * 16 + 4 * fq;
-        if (n0 < p.N) *reinterpret_cast<floatx4*>(wsp + (size_t)m * p.N + n0) = acc[tn][tm];
-      }
-    }
-    return;
-  }
-  // Staged epilogue: the tile is assembled in LDS (the ring is idle now) and written out as whole rows, 16 bytes per lane, instead
-  // of 8-byte stores that touch 16 rows x 32 bytes per wave instruction.  Measured on M32768 N2560 K320 the direct form spends
-  // 66 of 141 us in the epilogue (profiles/r01r_gemm_epilogue.txt).
-  constexpr int BNO = EPI == E3_GEGLU ? BN / 2 : BN;          // output columns of the tile
-  constexpr int TS = BNO + 8;                                  // staging row stride (halves): 16 bytes of padding
-  constexpr bool kCanStage = (EPI == E3_STD || EPI == E3_GEGLU) && (size_t)BM * TS * 2 <= (size_t)NST * STAGE;
-  if (kCanStage && p.stage_ok && !(p.ablate & 32)) {
-    __syncthreads();                                           // every wave is done reading the last ring slot
-    half_t* T = reinterpret_cast<half_t*>(af_smem);
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm) {
-      const int row = wm * 64 + tm * 16 + fr;
-      const int m = tile_m * BM + row;
-      const bool mok = m < p.M;
-      const int bidx = (p.rowbias && mok) ? m / p.rows_per_batch : 0;
-      if (EPI == E3_GEGLU) {
-#pragma unroll
-        for (int tn = 0; tn + 1 < TN; tn += 2) {
-          const int nt = tile_n * BN + wn * TN * 16 + tn * 16;
-          const int n0 = nt + 4 * fq;
-          const int col = ((wn * TN * 16 + tn * 16) >> 1) + 4 * fq;
-          float v[4] = {0.f, 0.f, 0.f, 0.f};
-          if (mok && (nt >> 1) + 4 * fq < (p.N >> 1)) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              float xv = acc[tn][tm][e], gv = acc[tn + 1][tm][e];
-              if (p.bias) {
-                xv += p.bias[n0 + e];
-                gv += p.bias[n0 + 16 + e];
-              }
-              v[e] = xv * af_gelu_erf(gv);
-            }
-          }
-          const half4_t h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-          *reinterpret_cast<half4_t*>(T + row * TS + col) = h;
-        }
-      } else {
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-          const int col = wn * TN * 16 + tn * 16 + 4 * fq;
-          const int n0 = tile_n * BN + col;
-          float v[4] = {0.f, 0.f, 0.f, 0.f};
-          if (mok && n0 < p.N) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = acc[tn][tm][e];
-            if (p.bias) {
-              const floatx4 bv = *reinterpret_cast<const floatx4*>(p.bias + n0);
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] += bv[e];
-            }
-            if (p.rowbias) {
-              const half4_t rv = *reinterpret_cast<const half4_t*>(p.rowbias + (size_t)bidx * p.ld_rowbias + n0);
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
-            }
-            if (p.act == 1) {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = af_silu(v[e]);
-            } else if (p.act == 3) {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = v[e] / (1.0f + __expf(-1.702f * v[e]));
-            }
-            if (p.residual) {
-              const half4_t rv = *reinterpret_cast<const half4_t*>(p.residual + (size_t)m * p.N + n0);
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
-            }
-          }
-          const half4_t h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-          *reinterpret_cast<half4_t*>(T + row * TS + col) = h;
-        }
-      }
-    }
-    __syncthreads();
-    constexpr int CPR = BNO / 8;                                // 16-byte chunks per output row
-    const int ncols = EPI == E3_GEGLU ? (p.N >> 1) : p.N;
-    for (int c = tid; c < BM * CPR; c += 64 * NW) {
-      const int row = c / CPR, cc = c - row * CPR;
-      const int m = tile_m * BM + row, n = tile_n * BNO + cc * 8;
-      if (m < p.M && n < ncols)
-        *reinterpret_cast<half8_t*>(p.out + (size_t)m * p.ld_out + n) = *reinterpret_cast<const half8_t*>(T + row * TS + cc * 8);
-    }
-    return;
-  }
-  if (EPI == E3_GEGLU) {
-    // W rows interleaved [16 value | 16 gate]: adjacent MFMA n-tiles pair up in the same lane / register
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm) {
-      const int m = tile_m * BM + wm * 64 + tm * 16 + fr;
-      if (m >= p.M) continue;
-#pragma unroll
-      for (int tn = 0; tn + 1 < TN; tn += 2) {
-        const int nt = tile_n * BN + wn * TN * 16 + tn * 16;
-        const int n0 = nt + 4 * fq, no = (nt >> 1) + 4 * fq;
-        if (no >= (p.N >> 1)) continue;
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float xv = acc[tn][tm][e], gv = acc[tn + 1][tm][e];
-          if (p.bias) {
-            xv += p.bias[n0 + e];
-            gv += p.bias[n0 + 16 + e];
-          }
-          v[e] = xv * af_gelu_erf(gv);
-        }
-        const half4_t h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-        *reinterpret_cast<half4_t*>(p.out + (size_t)m * p.ld_out + no) = h;
-      }
-    }
-    return;
-  }
-#pragma unroll
-  for (int tm = 0; tm < TM; ++tm) {
-    const int m = tile_m * BM + wm * 64 + tm * 16 + fr;
-    if (m >= p.M) continue;
-    const int bidx = (p.rowbias || EPI == E3_SPLIT_T) ? m / p.rows_per_batch : 0;
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-      const int n0 = tile_n * BN + wn * TN * 16 + tn * 16 + 4 * fq;
-      if (n0 >= p.N) continue;
-      float v[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = acc[tn][tm][e];
-      if (p.bias) {
-        const floatx4 bv = *reinterpret_cast<const floatx4*>(p.bias + n0);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] += bv[e];
-      }
-      if (p.rowbias) {
-        const half4_t rv = *reinterpret_cast<const half4_t*>(p.rowbias + (size_t)bidx * p.ld_rowbias + n0);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
-      }
-      if (p.act == 1) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = af_silu(v[e]);
-      } else if (p.act == 3) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = v[e] / (1.0f + __expf(-1.702f * v[e]));
-      }
-      if (EPI == E3_SPLIT_T && n0 >= p.split_col) {   // V columns: written transposed [B][N - split_col][ld_out2]
-        const int tok = m - bidx * p.rows_per_batch;
-        half_t* o2 = p.out2 + ((size_t)bidx * (p.N - p.split_col) + (n0 - p.split_col)) * p.ld_out2 + tok;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o2[(size_t)e * p.ld_out2] = (half_t)v[e];
-        continue;
-      }
-      if (p.residual) {
-        const half4_t rv = *reinterpret_cast<const half4_t*>(p.residual + (size_t)m * p.N + n0);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
-      }
-      const half4_t h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-      *reinterpret_cast<half4_t*>(p.out + (size_t)m * p.ld_out + n0) = h;
-    }
-  }
+  gemm3_epilogue<EPI, NWM, NWN, TN, NST * STAGE>(p, acc, af_smem, tile_m, tile_n, wm, wn, fr, fq, tid);
 }
 
 template <int TAPS, int NWM, int NWN, int TN, int EPI = E3_STD, int NST = NST_DEFAULT>
@@ -451,13 +460,14 @@ void launch3(const Gemm3Dev& p0, hipStream_t stream) {
 // slots: stage i+1 streams in while stage i is computed.  56 pieces per stage = exactly 7 per wave (2 A + 5 W).  Fragment rows are
 // 128 bytes apart, so 16 consecutive lanes alias two rows per 256 bytes of banks: the 16-byte chunk index is XOR-ed with
 // (row >> 1) & 7 on the DMA source side.  Standard epilogue only (staged); channel counts and K padding multiples of 64.
-template <int TAPS>
-__global__ __launch_bounds__(512, 1) void af_gemm3w_kernel(Gemm3Dev p) {
-  constexpr int TM = 4, TN = 5, NWM = 2, NW = 8;
-  constexpr int BM = 128, BN = 320, BKW = 64;
-  constexpr int APW = (BM / 8) / NW;                  // 2 A pieces (8 rows x 128 B) per wave per stage
-  constexpr int WPW = (BN / 8) / NW;                  // 5 W pieces
-  constexpr int STAGE = (BM + BN) * 128;              // 57344 bytes
+template <int TAPS, int NWM, int NWN, int TN, int EPI>
+__global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void af_gemm3w_kernel(Gemm3Dev p) {
+  constexpr int TM = 4, NW = NWM * NWN;
+  constexpr int BM = NWM * 64, BN = NWN * TN * 16, BKW = 64;
+  constexpr int APW = (BM / 8) / NW;                  // A pieces (8 rows x 128 B) per wave per stage
+  constexpr int WPW = (BN / 8) / NW;                  // W pieces
+  static_assert(APW * NW * 8 == BM && WPW * NW * 8 == BN, "pieces must divide evenly among the waves");
+  constexpr int STAGE = (BM + BN) * 128;              // bytes (57344 for 128 x 320)
   extern __shared__ __attribute__((aligned(16))) char af_smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -592,89 +602,25 @@ __global__ __launch_bounds__(512, 1) void af_gemm3w_kernel(Gemm3Dev p) {
     }
   }
 
-  if (p.splits > 1) {
-    float* wsp = p.ws + (size_t)blockIdx.y * p.M * p.N;
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm) {
-      const int m = tile_m * BM + wm * 64 + tm * 16 + fr;
-      if (m >= p.M) continue;
-#pragma unroll
-      for (int tn = 0; tn < TN; ++tn) {
-        const int n0 = tile_n * BN + wn * TN * 16 + tn * 16 + 4 * fq;
-        if (n0 < p.N) *reinterpret_cast<floatx4*>(wsp + (size_t)m * p.N + n0) = acc[tn][tm];
-      }
-    }
-    return;
-  }
-  // ---- staged standard epilogue (same arithmetic as af_gemm3_kernel's)
-  constexpr int TS = BN + 8;
-  __syncthreads();
-  half_t* T = reinterpret_cast<half_t*>(af_smem);
-#pragma unroll
-  for (int tm = 0; tm < TM; ++tm) {
-    const int row = wm * 64 + tm * 16 + fr;
-    const int m = tile_m * BM + row;
-    const bool mok = m < p.M;
-    const int bidx = (p.rowbias && mok) ? m / p.rows_per_batch : 0;
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-      const int col = wn * TN * 16 + tn * 16 + 4 * fq;
-      const int n0 = tile_n * BN + col;
-      float v[4] = {0.f, 0.f, 0.f, 0.f};
-      if (mok && n0 < p.N) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[tn][tm][e];
-        if (p.bias) {
-          const floatx4 bv = *reinterpret_cast<const floatx4*>(p.bias + n0);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += bv[e];
-        }
-        if (p.rowbias) {
-          const half4_t rv = *reinterpret_cast<const half4_t*>(p.rowbias + (size_t)bidx * p.ld_rowbias + n0);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
-        }
-        if (p.act == 1) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = af_silu(v[e]);
-        } else if (p.act == 3) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = v[e] / (1.0f + __expf(-1.702f * v[e]));
-        }
-        if (p.residual) {
-          const half4_t rv = *reinterpret_cast<const half4_t*>(p.residual + (size_t)m * p.N + n0);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
-        }
-      }
-      const half4_t h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-      *reinterpret_cast<half4_t*>(T + row * TS + col) = h;
-    }
-  }
-  __syncthreads();
-  constexpr int CPR = BN / 8;
-  for (int c = tid; c < BM * CPR; c += 64 * NW) {
-    const int row = c / CPR, cc = c - row * CPR;
-    const int m = tile_m * BM + row, n = tile_n * BN + cc * 8;
-    if (m < p.M && n < p.N)
-      *reinterpret_cast<half8_t*>(p.out + (size_t)m * p.ld_out + n) = *reinterpret_cast<const half8_t*>(T + row * TS + cc * 8);
-  }
+  gemm3_epilogue<EPI, NWM, NWN, TN, 2 * STAGE>(p, acc, af_smem, tile_m, tile_n, wm, wn, fr, fq, tid);
 }
 
-template <int TAPS>
+template <int TAPS, int NWM, int NWN, int TN, int EPI = E3_STD>
 void launch3w(const Gemm3Dev& p0, hipStream_t stream) {
   Gemm3Dev p = p0;
-  constexpr size_t lds = 2 * (128 + 320) * 128;
-  p.tiles_n = (p.N + 319) / 320;
-  p.tiles_m = (p.M + 127) / 128;
+  constexpr int NW = NWM * NWN, BM = NWM * 64, BN = NWN * TN * 16;
+  constexpr size_t lds = 2 * (size_t)(BM + BN) * 128;
+  p.tiles_n = (p.N + BN - 1) / BN;
+  p.tiles_m = (p.M + BM - 1) / BM;
   p.n_major = af_gemm_n_major(p.M, p.N, p.K, TAPS == 9 ? p.c1 + p.c2 : p.K);
   static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&af_gemm3w_kernel<TAPS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (lds > 65536 && !attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&af_gemm3w_kernel<TAPS, NWM, NWN, TN, EPI>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  dim3 grid(p.tiles_m * p.tiles_n, p.splits), block(512);
-  hipLaunchKernelGGL((af_gemm3w_kernel<TAPS>), grid, block, lds, stream, p);
+  dim3 grid(p.tiles_m * p.tiles_n, p.splits), block(64 * NW);
+  hipLaunchKernelGGL((af_gemm3w_kernel<TAPS, NWM, NWN, TN, EPI>), grid, block, lds, stream, p);
 }
 
 }  // namespace
@@ -682,13 +628,21 @@ void launch3w(const Gemm3Dev& p0, hipStream_t stream) {
 // Called by af_gemm (af_gemm.hip) for tile == 3 after the common argument validation.  Returns 1 if the shape is
 // outside this kernel's scope (caller falls back), 0 after a launch.
 int af_gemm3_try_launch(const af_gemm_desc* d, int splits, int wide, hipStream_t stream) {
-  // wide: 0 = 128 x 128, 1 = 128 x 320 (GEGLU 128 x 256), 2 = 256 x 256, 3 = 256 x 320 (8 waves as 4 x 2), 4 = 128 x 320 whole-line
+  // wide: 0 = 128 x 128, 1 = 128 x 320 (GEGLU 128 x 256), 2 = 256 x 256, 3 = 256 x 320 (8 waves as 4 x 2); whole-line kernel:
+  // 4 = 128 x 320 (GEGLU 128 x 256), 5 = 128 x 128, 6 = GEGLU 256 x 320, 7 = GEGLU 256 x 256
   const bool geglu = d->act == AF_ACT_GEGLU, split_t = d->out_mode == AF_OUT_SPLIT_T;
   if (d->upsample || d->c1 % BK3 != 0 || d->c2 % BK3 != 0 || d->zeros == nullptr) return 1;
   if ((geglu || split_t) && (d->taps != 1 || splits > 1)) return 1;
   if (geglu && (!wide || d->N % 256 != 0)) return 1;          // GEGLU: 128 x 256 tile (or the 256-row tiles)
   if (!geglu && wide == 1 && d->N % 320 != 0) return 1;
-  if (wide == 4 && (geglu || split_t || d->N % 320 != 0 || d->c1 % 64 != 0 || d->c2 % 64 != 0 || d->kpad % 64 != 0)) return 1;
+  if (wide >= 4) {                                            // whole-line variants: 64-multiples of channels and K padding
+    if (d->c1 % 64 != 0 || d->c2 % 64 != 0 || d->kpad % 64 != 0) return 1;
+    if (wide == 4 && (geglu ? d->N % 256 != 0 : d->N % 320 != 0)) return 1;
+    if (wide == 5 && geglu) return 1;
+    if (wide == 6 && (!geglu || d->N % 320 != 0)) return 1;
+    if (wide == 7 && (!geglu || d->N % 256 != 0)) return 1;
+    if (wide > 7) return 1;
+  }
   if (wide == 2 && (d->N % 256 != 0 || d->taps != 1 || split_t || splits > 1)) return 1;
   if (wide == 3 && (d->N % 320 != 0 || d->taps != 1 || split_t || splits > 1)) return 1;
   Gemm3Dev p;
@@ -735,14 +689,25 @@ int af_gemm3_try_launch(const af_gemm_desc* d, int splits, int wide, hipStream_t
     const int ncols = geglu ? d->N / 2 : d->N;
     p.stage_ok = ncols % 8 == 0 && p.ld_out % 8 == 0 && (reinterpret_cast<uintptr_t>(p.out) & 15) == 0;
   }
-  if (wide == 4) {
-    if (!p.stage_ok) return 1;
-    const int nk64 = p.kpad / 64;                               // this variant counts 64-wide K steps
+  if (wide >= 4) {
+    // whole-line variants (64-wide K stages): 4 = 128 x 320 (GEGLU: 128 x 256), 5 = 128 x 128 (4 waves), 6 / 7 = GEGLU 256 x 320 / 256 x 256
+    const int nk64 = p.kpad / 64;
     p.splits = splits > 1 ? splits : 1;
     if (p.splits > nk64) p.splits = nk64;
     p.kt_per_split = (nk64 + p.splits - 1) / p.splits;
     p.splits = (nk64 + p.kt_per_split - 1) / p.kt_per_split;
-    if (d->taps == 9) launch3w<9>(p, stream); else launch3w<1>(p, stream);
+    if (wide == 4) {
+      if (geglu) launch3w<1, 2, 4, 4, E3_GEGLU>(p, stream);
+      else if (split_t) launch3w<1, 2, 4, 5, E3_SPLIT_T>(p, stream);
+      else if (d->taps == 9) launch3w<9, 2, 4, 5>(p, stream);
+      else launch3w<1, 2, 4, 5>(p, stream);
+    } else if (wide == 5) {
+      if (split_t) launch3w<1, 2, 2, 4, E3_SPLIT_T>(p, stream);
+      else if (d->taps == 9) launch3w<9, 2, 2, 4>(p, stream);
+      else launch3w<1, 2, 2, 4>(p, stream);
+    } else {
+      if (wide == 6) launch3w<1, 4, 2, 10, E3_GEGLU>(p, stream); else launch3w<1, 4, 2, 8, E3_GEGLU>(p, stream);
+    }
     return p.splits > 1 ? 2 : 0;
   }
   if (wide == 2) {
@@ -762,7 +727,7 @@ int af_gemm3_try_launch(const af_gemm_desc* d, int splits, int wide, hipStream_t
 }
 
 int af_gemm3_effective_splits(const af_gemm_desc* d, int splits, int wide) {
-  const int nk = d->kpad / (wide == 4 ? 64 : BK3);
+  const int nk = d->kpad / (wide >= 4 ? 64 : BK3);
   int s = splits > 1 ? splits : 1;
   if (s > nk) s = nk;
   const int per = (nk + s - 1) / s;

@@ -144,20 +144,23 @@ def test_gemm_256_row_tiles(dev, M, N, K, tile, act):
     assert out.shape == ref.shape and rel_l2(out.float().cpu().numpy(), ref.numpy()) < TOL
 
 
-@pytest.mark.parametrize("M,N,K,splits", [(300, 320, 320, 1), (4096, 640, 1280, 2), (130, 960, 64, 1), (1000, 320, 2880, 3)])
-def test_gemm_tile7_whole_line(dev, M, N, K, splits):
-    """128 x 320 tile with 64-wide K stages (whole-cache-line LDS-DMA pieces, two slots): ragged M, one-stage K, split-K."""
+@pytest.mark.parametrize("M,N,K,splits,tile", [(300, 320, 320, 1, 7), (4096, 640, 1280, 2, 7), (130, 960, 64, 1, 7), (1000, 320, 2880, 3, 7),
+                                                (300, 200, 320, 1, 8), (1000, 384, 1280, 2, 8), (77, 768, 64, 1, 8)])
+def test_gemm_whole_line_tiles(dev, M, N, K, splits, tile):
+    """Whole-line kernel (64-wide K stages, whole-cache-line LDS-DMA pieces, two slots): 128 x 320 (tile 7) and 128 x 128 (tile 8);
+    ragged M and N, one-stage K, split-K."""
     from adaface_dev_amd import ops
     a, w = rnd((M, K), 1), rnd((N, K), 2, K ** -0.5)
     b, r = torch.randn(N, generator=torch.Generator().manual_seed(3)), rnd((M, N), 4)
-    out = ops.gemm(a.to(dev), ops.pack_matrix(w, b, dev), residual=r.to(dev), tile=7, splits=splits)
+    out = ops.gemm(a.to(dev), ops.pack_matrix(w, b, dev), residual=r.to(dev), tile=tile, splits=splits)
     ref = a.float() @ w.float().t() + b + r.float()
     assert rel_l2(out.float().cpu().numpy(), ref.numpy()) < TOL
 
 
-@pytest.mark.parametrize("B,H,W,c1,c2,cout,stride,splits", [(1, 32, 32, 320, 0, 320, 1, 1), (2, 16, 16, 640, 320, 640, 1, 2), (2, 16, 16, 320, 0, 320, 2, 1),
-                                                           (3, 8, 8, 1280, 1280, 1280, 1, 4)])
-def test_conv3x3_tile7_whole_line(dev, B, H, W, c1, c2, cout, stride, splits):
+@pytest.mark.parametrize("B,H,W,c1,c2,cout,stride,splits,tile", [(1, 32, 32, 320, 0, 320, 1, 1, 7), (2, 16, 16, 640, 320, 640, 1, 2, 7),
+                                                                (2, 16, 16, 320, 0, 320, 2, 1, 7), (3, 8, 8, 1280, 1280, 1280, 1, 4, 7),
+                                                                (2, 16, 16, 128, 64, 192, 1, 1, 8), (1, 12, 20, 64, 0, 72, 2, 2, 8)])
+def test_conv3x3_whole_line_tiles(dev, B, H, W, c1, c2, cout, stride, splits, tile):
     from adaface_dev_amd import ops
     cin = c1 + c2
     x1 = rnd((B, H, W, c1), 1)
@@ -169,7 +172,7 @@ def test_conv3x3_tile7_whole_line(dev, B, H, W, c1, c2, cout, stride, splits):
     res = rnd(tuple(ref.permute(0, 2, 3, 1).shape), 6)
     ref = ref + res.float().permute(0, 3, 1, 2)
     out = ops.conv3x3(x1.to(dev), ops.pack_conv3x3(w, bias, dev), x2=None if x2 is None else x2.to(dev), stride=stride,
-                      rowbias=rowb.to(dev), residual=res.to(dev), tile=7, splits=splits)
+                      rowbias=rowb.to(dev), residual=res.to(dev), tile=tile, splits=splits)
     assert rel_l2(out.float().cpu().permute(0, 3, 1, 2).numpy(), ref.numpy()) < TOL
 
 
@@ -184,21 +187,22 @@ def test_gemm_concat_k_and_silu(dev):
     assert rel_l2(out.float().cpu().numpy(), ref.numpy()) < TOL
 
 
-def test_gemm_split_transposed_wide_tile4(dev):
+@pytest.mark.parametrize("tile", [4, 7])
+def test_gemm_split_transposed_wide_tile4(dev, tile):
     from adaface_dev_amd import ops
     B, C, K, tokens = 2, 320, 320, 100
     a, w = rnd((B * tokens, K), 1), rnd((3 * C, K), 2, K ** -0.5)
-    out, out2 = ops.gemm(a.to(dev), ops.pack_matrix(w, None, dev), rows_per_batch=tokens, split_col=2 * C, tile=4)
+    out, out2 = ops.gemm(a.to(dev), ops.pack_matrix(w, None, dev), rows_per_batch=tokens, split_col=2 * C, tile=tile)
     ref = a.float() @ w.float().t()
     assert rel_l2(out.float().cpu().numpy(), ref[:, :2 * C].numpy()) < TOL
     vt = ref[:, 2 * C:].reshape(B, tokens, C).permute(0, 2, 1)
     assert rel_l2(out2[:, :, :tokens].float().cpu().numpy(), vt.numpy()) < TOL
 
 
-@pytest.mark.parametrize("tile", [1, 2, 4])
-def test_gemm_geglu(dev, tile):
+@pytest.mark.parametrize("tile,C", [(1, 64), (2, 64), (4, 64), (7, 64), (10, 64), (9, 320), (10, 320)])
+def test_gemm_geglu(dev, tile, C):
     from adaface_dev_amd import ops
-    M, C = 520, 64
+    M = 520
     a, w = rnd((M, C), 1), rnd((8 * C, C), 2, C ** -0.5)
     b = torch.randn(8 * C, generator=torch.Generator().manual_seed(3)) * 0.1
     wi, bi = ops.interleave_geglu(w.float(), b)
@@ -210,7 +214,7 @@ def test_gemm_geglu(dev, tile):
     assert rel_l2(out.float().cpu().numpy(), ref.numpy()) < TOL
 
 
-@pytest.mark.parametrize("tokens,tile", [(77, 2), (64, 1), (256, 0), (77, 3), (256, 3)])
+@pytest.mark.parametrize("tokens,tile", [(77, 2), (64, 1), (256, 0), (77, 3), (256, 3), (77, 8), (256, 8)])
 def test_gemm_split_transposed(dev, tokens, tile):
     from adaface_dev_amd import ops
     B, C, K = 3, 64, 96

@@ -72,11 +72,18 @@ def main():
         retuned.add(key)
         nk = d.kpad // 64
         best, best_t, res = (0, 1), None, {}
-        for tile in (1, 2, 3, 4, 5, 6, 7):
-            if tile == 7 and (d.N % 320 != 0 or d.act == _lib.AF_ACT_GEGLU or d.out_mode != 0 or d.upsample or d.c1 % 64 or d.c2 % 64):
-                continue                        # whole-line 128 x 320 variant: standard epilogue, 64-multiples of channels
+        for tile in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10):
+            geglu = d.act == _lib.AF_ACT_GEGLU
+            if tile >= 7 and (d.upsample or d.c1 % 64 or d.c2 % 64):
+                continue                        # whole-line kernel: 64-multiples of channels, no upsample
+            if tile == 7 and (d.N % (256 if geglu else 320) != 0):
+                continue
+            if tile == 8 and geglu:
+                continue
+            if tile in (9, 10) and (not geglu or d.N % (320 if tile == 9 else 256) != 0):
+                continue
             if tile in (5, 6) and (d.taps != 1 or d.out_mode != 0 or d.M * d.N < 256 * 256 * 128):
-                continue                        # 256-row tiles: plain / GEGLU 1x1 GEMMs with at least ~128 tiles
+                continue                        # 256-row ring tiles: plain / GEGLU 1x1 GEMMs with at least ~128 tiles
             for splits in (1, 2, 3, 4, 6, 8, 12, 16):
                 if tile in (5, 6) and splits > 1:
                     continue
