@@ -37,6 +37,7 @@ struct Gemm3Dev {
   int M, N, K, kpad, npad;
   int c1, c2, lda1, lda2;
   int H, W, Ho, Wo, HoWo, stride;
+  int upsample;   // 1: nearest x2 folded into the 3x3 gather (whole-line kernel only): Ho = 2H, Wo = 2W
   int rows_per_batch, ld_rowbias, act, ld_out;
   int tiles_n, tiles_m, n_major, splits, kt_per_split;
   float* ws;
@@ -490,7 +491,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void af_gem
   // ---- loader state: wave w fills A pieces {w*APW + j} and W pieces {w*WPW + j}; lane = (row in piece, chunk slot)
   const int prow = lane >> 3, slot = lane & 7;
   const int Cin = p.c1 + p.c2;
-  int a_base[APW], a_lc[APW];
+  int a_base[APW], a_lc[APW], a_par[APW];
   unsigned a_mask[APW];
   const half_t* wptr[WPW];
   bool wok[WPW];
@@ -502,23 +503,32 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void af_gem
     if (TAPS == 9) {
       unsigned mk = 0;
       int base = 0;
+      int par = 0;
       if (m < p.M) {
         const int b = m / p.HoWo;
         const int rem = m - b * p.HoWo;
         const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
         const int cy = oy * p.stride, cx = ox * p.stride;
+        const int He = p.upsample ? 2 * p.H : p.H, We = p.upsample ? 2 * p.W : p.W;     // the grid the taps walk on
 #pragma unroll
         for (int t9 = 0; t9 < 9; ++t9) {
           const int iy = cy + t9 / 3 - 1, ix = cx + t9 % 3 - 1;
-          if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) mk |= 1u << t9;
+          if ((unsigned)iy < (unsigned)He && (unsigned)ix < (unsigned)We) mk |= 1u << t9;
         }
-        base = (b * p.H + cy) * p.W + cx;
+        if (p.upsample) {               // source pixel of tap (ty, tx): ((oy + ty - 1) >> 1, (ox + tx - 1) >> 1)
+          base = (b * p.H + (oy >> 1)) * p.W + (ox >> 1);
+          par = (oy & 1) | ((ox & 1) << 1);
+        } else {
+          base = (b * p.H + cy) * p.W + cx;
+        }
       }
       a_mask[j] = mk;
       a_base[j] = base;
+      a_par[j] = par;
     } else {
       a_mask[j] = m < p.M ? 1u : 0u;
       a_base[j] = m;
+      a_par[j] = 0;
     }
   }
 #pragma unroll
@@ -540,10 +550,12 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void af_gem
       const half_t* src = first ? p.a1 : p.a2;
       const int cs = first ? p.c1 : p.c2;
       const int coff = first ? c0 : c0 - p.c1;
-      const int dpix = (tp / 3 - 1) * p.W + (tp % 3 - 1);
+      const int ty = tp / 3, tx = tp - ty * 3;
 #pragma unroll
       for (int j = 0; j < APW; ++j) {
         const bool ok = (a_mask[j] >> tp) & 1u;     // tp >= 9 (K padding): no bit set
+        const int dpix = p.upsample ? (((a_par[j] & 1) + ty - 1) >> 1) * p.W + (((a_par[j] >> 1) + tx - 1) >> 1)
+                                    : (ty - 1) * p.W + (tx - 1);
         const half_t* g = ok ? src + (size_t)(a_base[j] + dpix) * cs + coff + a_lc[j] * 8 : p.zeros;
         glds16(g, As + (wave * APW + j) * 1024);
       }
@@ -631,7 +643,8 @@ int af_gemm3_try_launch(const af_gemm_desc* d, int splits, int wide, hipStream_t
   // wide: 0 = 128 x 128, 1 = 128 x 320 (GEGLU 128 x 256), 2 = 256 x 256, 3 = 256 x 320 (8 waves as 4 x 2); whole-line kernel:
   // 4 = 128 x 320 (GEGLU 128 x 256), 5 = 128 x 128, 6 = GEGLU 256 x 320, 7 = GEGLU 256 x 256
   const bool geglu = d->act == AF_ACT_GEGLU, split_t = d->out_mode == AF_OUT_SPLIT_T;
-  if (d->upsample || d->c1 % BK3 != 0 || d->c2 % BK3 != 0 || d->zeros == nullptr) return 1;
+  if (d->upsample && !((wide == 4 || wide == 5) && d->upsample == 1 && d->taps == 9)) return 1;   // nearest x2: whole-line kernel only
+  if (d->c1 % BK3 != 0 || d->c2 % BK3 != 0 || d->zeros == nullptr) return 1;
   if ((geglu || split_t) && (d->taps != 1 || splits > 1)) return 1;
   if (geglu && (!wide || d->N % 256 != 0)) return 1;          // GEGLU: 128 x 256 tile (or the 256-row tiles)
   if (!geglu && wide == 1 && d->N % 320 != 0) return 1;
@@ -672,6 +685,7 @@ int af_gemm3_try_launch(const af_gemm_desc* d, int splits, int wide, hipStream_t
   p.Wo = d->Wo;
   p.HoWo = d->Ho * d->Wo;
   p.stride = d->stride ? d->stride : 1;
+  p.upsample = d->upsample;
   p.rows_per_batch = d->rows_per_batch > 0 ? d->rows_per_batch : d->M;
   p.ld_rowbias = d->ld_rowbias;
   p.act = d->act == AF_ACT_SILU ? 1 : (d->act == AF_ACT_QUICKGELU ? 3 : 0);

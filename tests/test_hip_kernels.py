@@ -232,6 +232,7 @@ def test_gemm_split_transposed(dev, tokens, tile):
     (2, 16, 16, 64, 0, 64, 1, False, 2), (2, 16, 16, 64, 0, 128, 1, False, 1), (1, 64, 64, 8, 0, 320, 1, False, 0),
     (2, 16, 16, 64, 0, 64, 2, False, 2), (2, 15, 17, 32, 0, 64, 2, False, 2), (2, 8, 8, 64, 0, 64, 1, True, 2),
     (2, 8, 8, 128, 64, 64, 1, False, 2), (1, 32, 32, 320, 0, 4, 1, False, 0), (2, 8, 8, 96, 32, 128, 1, False, 1),
+    (2, 8, 8, 64, 0, 64, 1, True, 8), (2, 9, 7, 320, 0, 320, 1, True, 7), (1, 16, 16, 640, 0, 640, 1, True, 7), (3, 5, 6, 128, 0, 192, 1, True, 8),
 ])
 def test_conv3x3(dev, B, H, W, c1, c2, cout, stride, ups, tile):
     from adaface_dev_amd import ops

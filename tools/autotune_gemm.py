@@ -74,8 +74,8 @@ def main():
         best, best_t, res = (0, 1), None, {}
         for tile in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10):
             geglu = d.act == _lib.AF_ACT_GEGLU
-            if tile >= 7 and (d.upsample or d.c1 % 64 or d.c2 % 64):
-                continue                        # whole-line kernel: 64-multiples of channels, no upsample
+            if tile >= 7 and (d.upsample not in (0, 1) or (d.upsample and tile not in (7, 8)) or d.c1 % 64 or d.c2 % 64):
+                continue                        # whole-line kernel: 64-multiples of channels; nearest-x2 upsample in tiles 7 / 8
             if tile == 7 and (d.N % (256 if geglu else 320) != 0):
                 continue
             if tile == 8 and geglu:

@@ -2,7 +2,7 @@
 """Micro-benchmark of one kernel shape on the GPU box (also the target of rocprofv3 --pmc runs).
     python tools/bench_kernel.py attn  B N L heads d [reps]
     python tools/bench_kernel.py gemm  M N K [tile] [splits] [reps] [act]      (act 2 = GEGLU, 3 = quick-GELU, 1 = SiLU)
-    python tools/bench_kernel.py conv  B H W Cin Cout [tile] [splits] [reps]
+    python tools/bench_kernel.py conv  B H W Cin Cout [tile] [splits] [reps] [upsample]
     python tools/bench_kernel.py gn    B HW C [reps]
     python tools/bench_kernel.py blas  M N K [reps]      (hipBLASLt via torch.matmul: reference point only)
 """
@@ -80,10 +80,12 @@ def main():
         B, H, W, ci, co = a[:5]
         tile, splits = (a[5] if len(a) > 5 else 0), (a[6] if len(a) > 6 else 0)
         reps = a[7] if len(a) > 7 else 20
+        ups = bool(a[8]) if len(a) > 8 else False          # nearest x2 folded into the gather (H, W are the INPUT size)
         x, w = rnd(B, H, W, ci), rnd(co, ci, 3, 3)
         pw = ops.pack_conv3x3(w, None, dev)
-        ms = timeit(lambda: ops.conv3x3(x, pw, tile=tile, splits=splits), reps)
-        print(f"conv B{B} {H}x{W} {ci}->{co} tile{tile} splits{splits}: {ms * 1e3:.1f} us  {2.0 * B * H * W * co * 9 * ci / ms / 1e9:.1f} TFLOP/s")
+        ms = timeit(lambda: ops.conv3x3(x, pw, tile=tile, splits=splits, upsample=ups), reps)
+        f = 4 if ups else 1
+        print(f"conv B{B} {H}x{W} {ci}->{co} tile{tile} splits{splits} ups{int(ups)}: {ms * 1e3:.1f} us  {2.0 * f * B * H * W * co * 9 * ci / ms / 1e9:.1f} TFLOP/s")
     elif kind == "gn":
         B, HW, C = a[:3]
         reps = a[3] if len(a) > 3 else 20
