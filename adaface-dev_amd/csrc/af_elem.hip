@@ -197,6 +197,26 @@ extern "C" int af_softmax_rows(const void* x, void* y, int64_t rows, int L, void
   return af_check_launch("af_softmax_rows");
 }
 
+// Pull a byte range (the next layers' packed weights) toward the GPU's caches: every 128-byte line is read once, nothing is written.
+// Launched on a side stream ahead of the GEMM that will stream the range (memory-side Infinity Cache hits instead of HBM misses).
+__global__ __launch_bounds__(256) void prefetch_kernel(const unsigned* __restrict__ p, long nlines, unsigned* __restrict__ sink) {
+  unsigned acc = 0;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nlines; i += (long)gridDim.x * 256) {
+    acc ^= p[i * 32];                                                  // one dword per 128-byte line fetches the line
+  }
+  if (acc == 0x9e3779b9u && sink) *sink = acc;                       // keeps the loads alive; practically never taken
+}
+
+extern "C" int af_prefetch(const void* ptr, int64_t bytes, void* stream) {
+  AF_REQUIRE(ptr && bytes >= 0 && (reinterpret_cast<uintptr_t>(ptr) & 15) == 0, "af_prefetch: 16-byte aligned range");
+  const long nlines = bytes / 128;
+  if (nlines == 0) return 0;
+  AfLaunchScope scope(AF_FAM_ELEM, stream);
+  const unsigned grid = (unsigned)((nlines + 255) / 256 < 2048 ? (nlines + 255) / 256 : 2048);
+  hipLaunchKernelGGL(prefetch_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const unsigned*)ptr, nlines, (unsigned*)nullptr);
+  return af_check_launch("af_prefetch");
+}
+
 extern "C" int af_mask_pairs(void* p, const void* cls, int N, void* stream) {
   AF_REQUIRE(p && cls && N > 0 && N % 8 == 0, "af_mask_pairs: N must be a positive multiple of 8");
   AfLaunchScope scope(AF_FAM_ELEM, stream);

@@ -253,6 +253,9 @@ int af_clamp_f32(void* a, float lo, float hi, int64_t n, void* stream);
 int af_softmax_rows(const void* x, void* y, int64_t rows, int L, void* stream);
 /* masked VAE-encoder attention (model.py:191-209): p fp16 [N, N] (post-softmax) *= ((cls[i] & cls[j]) != 0); cls uint8 [N]: bit 0 fg*aug != 0, bit 1 (1-fg)*aug != 0 */
 int af_mask_pairs(void* p, const void* cls, int N, void* stream);
+/* read every 128-byte line of [ptr, ptr + bytes) once (no writes): cache warm-up of packed weights ahead of the GEMM that streams them,
+   meant for a side stream */
+int af_prefetch(const void* ptr, int64_t bytes, void* stream);
 
 /* ---- ArcFace ResNetFace-18 IR-SE face encoder (reference evaluation/arcface_resnet.py:62-97, 139-154, 157-217) ----
  * NHWC fp16 activations, C % 8 == 0.  Convolutions / FCs are af_gemm calls with eval-mode BatchNorm folded on the host.

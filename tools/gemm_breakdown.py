@@ -15,6 +15,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--warm-weights", action="store_true", help="with --cold: af_prefetch the packed weights after the flush (what a side-stream prefetcher would achieve)")
+    ap.add_argument("--cold", action="store_true", help="evict L2 / Infinity Cache (a 1 GB fill) before every timed launch: cold operands, as in the real step where 1.7 GB of weights stream from HBM")
     args = ap.parse_args()
     from adaface_dev_amd import SD15_UNET_CONFIG, _lib, ops, rng
     from adaface_dev_amd.ldm.modules.diffusionmodules.openaimodel import UNetModel
@@ -49,6 +51,7 @@ def main():
     torch.cuda.synchronize()
     big = torch.empty(1 << 28, dtype=torch.float16, device=dev)               # 512 MB scratch: any operand pointer we re-aim lands here
     st = torch.cuda.current_stream().cuda_stream
+    flush = torch.empty(1 << 28, dtype=torch.float32, device=dev) if args.cold else None
     rows = []
     for key, (cnt, d, ts) in seen.items():
         # re-aim activation operands / outputs at the scratch (timing only; weights stay real)
@@ -65,13 +68,26 @@ def main():
         if rc < 0:
             print("skip", key, L.af_last_error())
             continue
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(args.reps):
-            L.af_gemm(C.byref(d), st)
-        e1.record()
-        e1.synchronize()
-        us = e0.elapsed_time(e1) / args.reps * 1e3
+        if args.cold:
+            us = 0.0
+            for _ in range(5):
+                flush.fill_(1.0)                                      # 1 GB of writes: nothing of the operands stays in L2 / MALL
+                if args.warm_weights:
+                    L.af_prefetch(d.wt, int(d.kpad) * ((int(d.N) + 127) // 128 * 128) * 2, st)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                L.af_gemm(C.byref(d), st)
+                e1.record()
+                e1.synchronize()
+                us += e0.elapsed_time(e1) / 5 * 1e3
+        else:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(args.reps):
+                L.af_gemm(C.byref(d), st)
+            e1.record()
+            e1.synchronize()
+            us = e0.elapsed_time(e1) / args.reps * 1e3
         fl = 2.0 * d.M * d.N * d.K
         rows.append((cnt * us, key, cnt, us, fl / us / 1e6, ts))
     rows.sort(reverse=True)
