@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--train", action="store_true")
     ap.add_argument("--vae", action="store_true", help="also tune the VAE decoder's shapes (batch 4 and 1, 64x64 latent)")
     ap.add_argument("--fresh", action="store_true", help="ignore the existing table instead of extending it")
+    ap.add_argument("--cold-weights", action="store_true", help="time single launches after evicting the caches (weights cold, 1x1 activations re-read): what a GEMM meets inside the real step")
     ap.add_argument("--retune", action="store_true", help="re-time every shape this run meets; entries of shapes it does not meet are kept")
     args = ap.parse_args()
     from adaface_dev_amd import SD15_UNET_CONFIG, _lib, ops, rng
@@ -44,6 +45,8 @@ def main():
             table = {k: tuple(v) for k, v in json.load(f).items()}
         print(f"extending {len(table)} existing entries")
 
+    flush = torch.empty(1 << 28, dtype=torch.float32, device=dev) if args.cold_weights else None
+
     def timed(d, device, tile, splits):
         d.tile, d.splits = tile, splits
         d.zeros = ops._zero_page(device).data_ptr()
@@ -56,6 +59,22 @@ def main():
         for _ in range(2):
             if L.af_gemm(C.byref(d), st) < 0:
                 return None
+        if args.cold_weights:
+            # the real step meets every weight cold in HBM (1.7 GB read once per step) while activations were just produced: evict
+            # everything, re-read the activation operands, then time ONE launch; median of 5
+            ts = []
+            for _ in range(5):
+                flush.fill_(1.0)
+                for ptr, nb in ((d.a1, d.M * max(d.lda1, d.c1) * 2), (d.a2, d.M * max(d.lda2, d.c2) * 2 if d.a2 else 0)):
+                    if ptr and nb and d.taps == 1:
+                        L.af_prefetch(ptr, int(nb), st)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                L.af_gemm(C.byref(d), st)
+                e1.record()
+                e1.synchronize()
+                ts.append(e0.elapsed_time(e1))
+            return sorted(ts)[2]
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(args.reps):
