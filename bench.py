@@ -290,7 +290,7 @@ def main():
         # (separate passes, gfx950 x2 fetch correction; tools/pmc_traffic.py), committed under profiles/ -- counters cannot be
         # read from inside the process, so the latest committed measurement is reported (null if absent)
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01m_hbm_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r01x_hbm_traffic.json")
         if os.path.exists(tpath) and B == 4:
             with open(tpath) as f:
                 traffic = round(json.load(f)["gemm"]["bytes_per_step"] / g_n, 1) if g_n else None   # per af_gemm call, like `achieved`
