@@ -295,7 +295,7 @@ def main():
             with open(tpath) as f:
                 traffic = round(json.load(f)["gemm"]["bytes_per_step"] / g_n, 1) if g_n else None   # per af_gemm call, like `achieved`
         roofline = {
-            "kernel": "af_gemm_kernel (conv3x3 implicit GEMM + linear + conv1x1)",
+            "kernel": "af_gemm family: af_gemm3w_kernel / af_gemm3_kernel / af_gemm_kernel (conv3x3 implicit GEMM + linear + conv1x1)",
             "bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
             "flops_per_launch": flops_step / g_n if g_n else None,
