@@ -426,3 +426,17 @@ def test_error_reporting(dev):
         ops.gemm(a, pw)
     with pytest.raises(RuntimeError, match="head dim"):
         ops.attention(a, a, a.reshape(1, 24, 16), B=1, Nq=16, L=16, heads=2, d=12, ldq=24, ldk=24)
+
+
+def test_prefetch_reads_without_side_effects(dev):
+    """af_prefetch only reads: the range is unchanged, odd sizes / empty ranges / misaligned pointers are handled."""
+    from adaface_dev_amd import _lib
+    L = _lib.lib()
+    x = torch.arange(1 << 20, dtype=torch.float16, device=dev)
+    ref = x.clone()
+    st = torch.cuda.current_stream().cuda_stream
+    assert L.af_prefetch(x.data_ptr(), x.numel() * 2, st) == 0
+    assert L.af_prefetch(x.data_ptr(), 100, st) == 0 and L.af_prefetch(x.data_ptr(), 0, st) == 0
+    assert L.af_prefetch(x.data_ptr() + 2, 1024, st) < 0 and b"aligned" in L.af_last_error()
+    torch.cuda.synchronize()
+    assert torch.equal(x, ref)
