@@ -646,12 +646,12 @@ int af_gemm3_try_launch(const af_gemm_desc* d, int splits, int wide, hipStream_t
   if (d->upsample && !((wide == 4 || wide == 5) && d->upsample == 1 && d->taps == 9)) return 1;   // nearest x2: whole-line kernel only
   if (d->c1 % BK3 != 0 || d->c2 % BK3 != 0 || d->zeros == nullptr) return 1;
   if ((geglu || split_t) && (d->taps != 1 || splits > 1)) return 1;
-  if (geglu && (!wide || d->N % 256 != 0)) return 1;          // GEGLU: 128 x 256 tile (or the 256-row tiles)
+  if (geglu && (!wide || d->N % (wide == 5 ? 128 : 256) != 0)) return 1;   // GEGLU: 128 x 256 tile, the 256-row tiles, or 128 x 128 whole-line
   if (!geglu && wide == 1 && d->N % 320 != 0) return 1;
   if (wide >= 4) {                                            // whole-line variants: 64-multiples of channels and K padding
     if (d->c1 % 64 != 0 || d->c2 % 64 != 0 || d->kpad % 64 != 0) return 1;
     if (wide == 4 && (geglu ? d->N % 256 != 0 : d->N % 320 != 0)) return 1;
-    if (wide == 5 && geglu) return 1;
+    if (wide == 5 && geglu && d->N % 128 != 0) return 1;
     if (wide == 6 && (!geglu || d->N % 320 != 0)) return 1;
     if (wide == 7 && (!geglu || d->N % 256 != 0)) return 1;
     if (wide > 7) return 1;
@@ -716,7 +716,8 @@ int af_gemm3_try_launch(const af_gemm_desc* d, int splits, int wide, hipStream_t
       else if (d->taps == 9) launch3w<9, 2, 4, 5>(p, stream);
       else launch3w<1, 2, 4, 5>(p, stream);
     } else if (wide == 5) {
-      if (split_t) launch3w<1, 2, 2, 4, E3_SPLIT_T>(p, stream);
+      if (geglu) launch3w<1, 2, 2, 4, E3_GEGLU>(p, stream);
+      else if (split_t) launch3w<1, 2, 2, 4, E3_SPLIT_T>(p, stream);
       else if (d->taps == 9) launch3w<9, 2, 2, 4>(p, stream);
       else launch3w<1, 2, 2, 4>(p, stream);
     } else {

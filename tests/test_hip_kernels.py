@@ -199,7 +199,7 @@ def test_gemm_split_transposed_wide_tile4(dev, tile):
     assert rel_l2(out2[:, :, :tokens].float().cpu().numpy(), vt.numpy()) < TOL
 
 
-@pytest.mark.parametrize("tile,C", [(1, 64), (2, 64), (4, 64), (7, 64), (10, 64), (9, 320), (10, 320)])
+@pytest.mark.parametrize("tile,C", [(1, 64), (2, 64), (4, 64), (7, 64), (8, 64), (10, 64), (9, 320), (10, 320), (8, 320)])
 def test_gemm_geglu(dev, tile, C):
     from adaface_dev_amd import ops
     M = 520
