@@ -177,3 +177,86 @@ def anneal_perturb_embedding(embeddings, training_percent, begin_noise_std_range
         lb, ub = begin_noise_std_range
     std = torch.rand(1).item() * (ub - lb) + lb
     return perturb_tensor(embeddings, std, perturb_std_is_relative, keep_norm, std_dim=std_dim, norm_dim=norm_dim)
+
+
+# ----------------------------------------------------------------------------- prompt-delta regularisation (host glue on [4, 77, 768])
+def ortho_subtract(a, b, b_discount=1, on_last_n_dims=1, return_align_coeffs=False):
+    """a minus its projection onto b over the last ``on_last_n_dims`` dims: a - b <a,b> / (<b,b> + 1e-6) (reference ldm/util.py:296-332)."""
+    if a.ndim != b.ndim:
+        raise ValueError("ortho_subtract: a and b must have the same number of dimensions")
+    shape = None
+    if on_last_n_dims > 1:
+        if a.numel() < b.numel():
+            a = a.expand(b.shape)
+        elif b.numel() < a.numel():
+            b = b.expand(a.shape)
+        shape = a.shape
+        a = a.reshape(*shape[:-on_last_n_dims], -1)
+        b = b.reshape(*shape[:-on_last_n_dims], -1)
+    w = (a * b).sum(dim=-1) / ((b * b).sum(dim=-1) + 1e-6)
+    out = a - b * w.unsqueeze(-1) * b_discount
+    if shape is not None:
+        out = out.reshape(shape)
+        w = w.reshape(list(shape[:-on_last_n_dims]) + [1] * on_last_n_dims)
+    return (out, w) if return_align_coeffs else out
+
+
+def demean(x, demean_dims=(-1,)):
+    """Reference ldm/util.py:334-340."""
+    return x if demean_dims is None else x - x.mean(dim=list(demean_dims), keepdim=True)
+
+
+def calc_ref_cosine_loss(delta, ref_delta, emb_mask=None, exponent=2, do_demeans=(False, False), first_n_dims_into_instances=2,
+                         ref_grad_scale=0, aim_to_align=True, reduction="mean"):
+    """Mean (1 - cos) between every embedding of ``delta`` and the sign-preserving power of the matching embedding of ``ref_delta``,
+    per batch item over the tokens whose mask is > 0, weighted by the mask; the reference side gets ``ref_grad_scale`` of the gradient
+    (reference ldm/util.py:365-470)."""
+    import torch.nn.functional as F
+    from ..adaface.subj_basis_generator import ScaleGrad
+    per_item = []
+    for i in range(delta.shape[0]):
+        d, r = delta[i:i + 1], ref_delta[i:i + 1]
+        m = None if emb_mask is None else emb_mask[i:i + 1]
+        if m is not None:
+            lead = d.shape[:first_n_dims_into_instances]
+            keep = (m > 0).squeeze(-1).expand(lead)
+            d, r = d[keep], r[keep]
+            m = m.squeeze(-1).expand(lead)[keep]
+        else:
+            d = d.reshape(d.shape[:first_n_dims_into_instances].numel(), -1)
+            r = r.reshape(d.shape)
+        if do_demeans[0]:
+            d = demean(d)
+        if do_demeans[1]:
+            r = demean(r)
+        r = ScaleGrad.apply(r, ref_grad_scale)
+        r_pow = r * r.abs().pow(exponent - 1)
+        label = torch.full_like(d[:, 0], 1.0 if aim_to_align else -1.0)
+        li = F.cosine_embedding_loss(d, r_pow, label, reduction="none")
+        if m is not None:
+            li = li * m
+        if reduction == "mean":
+            per_item.append(li.sum() / (m.sum() + 1e-8) if m is not None else li.mean())
+        elif reduction == "none":
+            per_item.append(li)
+        else:
+            raise ValueError(f"reduction {reduction!r}")
+    return sum(per_item) / delta.shape[0] if reduction == "mean" else torch.stack(per_item, dim=0)
+
+
+def calc_prompt_emb_delta_loss(prompt_embeddings, prompt_emb_mask, cls_delta_grad_scale=0.05):
+    """Prompt-delta regularisation (reference ldm/util.py:1426-1480; weight 1e-4 in p_losses, ddpm.py:2285-2293): the batch holds the
+    prompt embeddings of (subject-single, subject-comp, class-single, class-comp); the change a composition makes to the SUBJECT
+    prompt (orthogonal to the single prompt) should align with the change it makes to the CLASS prompt.  Tokens present in both
+    prompts weigh 1, composition-only tokens 0.25, the BOS token 0."""
+    ss, sc, cs, cc = prompt_embeddings.chunk(4)
+    w = None
+    if prompt_emb_mask is not None:
+        m = prompt_emb_mask.float().clone()           # (the reference zeroes the BOS row of the caller's float mask in place)
+        m[:, 0] = 0
+        ms, mc, _, _ = m.chunk(4)
+        w = (ms + mc).pow(2) / 4
+    subj_delta = ortho_subtract(sc, ss)
+    cls_delta = ortho_subtract(cc, cs)
+    return calc_ref_cosine_loss(subj_delta, cls_delta, emb_mask=w, do_demeans=(False, True), first_n_dims_into_instances=2,
+                                ref_grad_scale=cls_delta_grad_scale, aim_to_align=True)

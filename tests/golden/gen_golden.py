@@ -402,6 +402,9 @@ def gen_arcface(out):
 VAE_SMALL = dict(ch=32, out_ch=3, ch_mult=(1, 2, 4, 4), num_res_blocks=2, attn_resolutions=[], dropout=0.0, in_channels=3, resolution=128, z_channels=4)
 
 
+E_PD = 32
+
+
 def gen_embedding_manager(out):
     """The REFERENCE EmbeddingManager (ldm/modules/embedding_manager.py) and its ldm.util helpers on the prompt cases of
     tests/em_fixture_util.py.  The manager imports ``adaface.face_id_to_ada_prompt`` (diffusers / insightface: absent), of which it
@@ -464,6 +467,23 @@ def gen_embedding_manager(out):
     multi = [(1, 9, 3, "x"), (1, 3, 2, "y"), (2, 5, 1, "x"), (0, 2, 4, "y")]
     d["merge.in"], d["merge.out"] = emb.numpy(), RU.merge_cls_token_embeddings(emb, multi).numpy()
     d["merge.idx"] = np.array([m[:3] for m in multi], dtype=np.int64)
+    # prompt-delta regularisation (ldm/util.py:296-470, 1426-1480): values and gradients through the reference functions
+    pe = torch.randn(4, 77, E_PD, generator=g).requires_grad_(True)
+    ids4 = torch.full((4, 77), 49407)
+    ids4[:, 0] = 49406
+    for bi, nreal in enumerate((9, 14, 9, 14)):
+        ids4[bi, 1:1 + nreal] = 1000 + torch.arange(nreal)
+    mask4 = ((ids4 != 49406) & (ids4 != 49407)).unsqueeze(2)
+    loss = RU.calc_prompt_emb_delta_loss(pe, mask4.clone())
+    loss.backward()
+    d["pd.emb"], d["pd.mask"], d["pd.loss"], d["pd.grad"] = pe.detach().numpy(), mask4.numpy(), loss.detach().numpy(), pe.grad.numpy()
+    a3, b3 = torch.randn(2, 5, 6, 8, generator=g), torch.randn(2, 1, 6, 8, generator=g)
+    o2, w2 = RU.ortho_subtract(a3, b3, b_discount=0.7, on_last_n_dims=2, return_align_coeffs=True)
+    d["os.a"], d["os.b"], d["os.out"], d["os.w"] = a3.numpy(), b3.numpy(), o2.numpy(), w2.numpy()
+    dl, rf = torch.randn(3, 4, 10, 16, generator=g), torch.randn(3, 4, 10, 16, generator=g)
+    d["rc.delta"], d["rc.ref"] = dl.numpy(), rf.numpy()
+    d["rc.none"] = RU.calc_ref_cosine_loss(dl, rf, None, exponent=3, do_demeans=[True, False], first_n_dims_into_instances=3,
+                                           ref_grad_scale=0, aim_to_align=False, reduction="none").numpy()
     np.savez_compressed(os.path.join(out, "embedding_manager.npz"), **d)
 
 

@@ -240,3 +240,28 @@ def test_trainer_iteration_input_variants_follow_the_reference_rng_order():
     out = tr.select_iteration_inputs(batch)
     assert torch.equal(out["x_start"], batch["x_start"]) and tr.iter_flags["perturb_face_id_embs"] is False
     assert tr.perturb_img_prompt_embs(id2img) is id2img
+
+
+def test_prompt_delta_loss_matches_reference(golden):
+    """ortho_subtract / calc_ref_cosine_loss / calc_prompt_emb_delta_loss (ldm/util.py:296-470, 1426-1480) against values AND gradients
+    produced by the reference functions (the class-side gradient is scaled by 0.05 inside)."""
+    from adaface_dev_amd.ldm.util import calc_prompt_emb_delta_loss, calc_ref_cosine_loss, ortho_subtract
+    pe = torch.from_numpy(golden["pd.emb"]).requires_grad_(True)
+    mask = torch.from_numpy(golden["pd.mask"])
+    before = mask.clone()
+    loss = calc_prompt_emb_delta_loss(pe, mask)
+    loss.backward()
+    assert torch.equal(mask, before)                                            # the caller's mask is not modified
+    assert abs(float(loss.detach()) - float(golden["pd.loss"])) < 1e-6
+    assert np.allclose(pe.grad.numpy(), golden["pd.grad"], rtol=1e-4, atol=1e-8)
+    out, w = ortho_subtract(torch.from_numpy(golden["os.a"]), torch.from_numpy(golden["os.b"]), b_discount=0.7, on_last_n_dims=2,
+                            return_align_coeffs=True)
+    assert np.allclose(out.numpy(), golden["os.out"], atol=1e-6) and np.allclose(w.numpy(), golden["os.w"], atol=1e-6)
+    none = calc_ref_cosine_loss(torch.from_numpy(golden["rc.delta"]), torch.from_numpy(golden["rc.ref"]), None, exponent=3,
+                                do_demeans=(True, False), first_n_dims_into_instances=3, ref_grad_scale=0, aim_to_align=False,
+                                reduction="none")
+    assert np.allclose(none.numpy(), golden["rc.none"], atol=1e-6)
+    # float masks (as ddpm passes them after .float()) are not modified either, unlike in the reference
+    fm = mask.float()
+    calc_prompt_emb_delta_loss(pe.detach(), fm)
+    assert fm[:, 0].sum() == 0 or torch.equal(fm, mask.float())
