@@ -110,8 +110,8 @@ typedef struct af_gemm_desc {
                         /* 5 = 256x256 and 6 = 256x320 ring tiles (8 waves as 4 x 2): plain or GEGLU 1x1 GEMMs only, N % 256 / N % 320 == 0,
                            no split-K */
                         /* 7 .. 10 = whole-line kernel (64-wide K stages, LDS-DMA pieces of 8 rows x one 128-byte line, two slots; channel
-                           counts and K padding multiples of 64): 7 = 128x320 (GEGLU 128x256, transposed-V split), 8 = 128x128 (4 waves),
-                           9 / 10 = GEGLU 256x320 / 256x256.  Anything outside a tile's scope falls back to tile 1 */
+                           counts and K padding multiples of 64): 7 = 128x320 (GEGLU 128x256, transposed-V split), 8 = 128x128 (4 waves; also GEGLU,
+                           transposed-V split), 9 / 10 = GEGLU 256x320 / 256x256; tiles 7 and 8 also take upsample = 1 (nearest x2).  Anything outside a tile's scope falls back to tile 1 */
   int32_t splits;       /* split-K factor (<=1: none).  >1 needs the standard epilogue and a workspace:
                            each split writes an fp32 partial [M][N], a second launch reduces + applies the epilogue */
   void* workspace;      /* fp32, >= splits*M*N*4 bytes when splits > 1 */
