@@ -27,6 +27,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batches", default="8,2")
     ap.add_argument("--reps", type=int, default=12)
+    ap.add_argument("--latents", default="64x64", help="comma-separated latent sizes HxW to run the U-Net at (64x64 = 512^2 images; 96x64 = 768x512)")
     ap.add_argument("--out", default=None)
     ap.add_argument("--train", action="store_true")
     ap.add_argument("--vae", action="store_true", help="also tune the VAE decoder's shapes (batch 4 and 1, 64x64 latent)")
@@ -124,8 +125,8 @@ def main():
     unet = unet.to(dev).eval()
     ops._tune_recorder = recorder
     with torch.no_grad():
-        for b in [int(v) for v in args.batches.split(",")]:
-            x = rng.synth_input("bench.x", (b, 4, 64, 64), seed=1).to(dev)
+        for b, (lh, lw) in [(int(v), tuple(int(q) for q in hw.split("x"))) for hw in args.latents.split(",") for v in args.batches.split(",")]:
+            x = rng.synth_input("bench.x", (b, 4, lh, lw), seed=1).to(dev)
             ctx = rng.synth_input("bench.ctx", (b, 77, 768), seed=1).to(dev)
             unet(x, torch.full((b,), 500, device=dev), ctx, extra_info=None)
             torch.cuda.synchronize()
