@@ -265,3 +265,42 @@ def test_prompt_delta_loss_matches_reference(golden):
     fm = mask.float()
     calc_prompt_emb_delta_loss(pe.detach(), fm)
     assert fm[:, 0].sum() == 0 or torch.equal(fm, mask.float())
+
+
+def test_token_helpers_against_brute_force_random_cases():
+    """extract_first_index_in_each_instance / merge_cls_token_embeddings on random inputs against straightforward loops."""
+    from adaface_dev_amd.ldm.util import extract_first_index_in_each_instance, merge_cls_token_embeddings
+    g = torch.Generator().manual_seed(17)
+    for _ in range(50):
+        n = int(torch.randint(1, 30, (1,), generator=g))
+        b = torch.randint(0, 5, (n,), generator=g)
+        t = torch.randint(0, 77, (n,), generator=g)
+        fb, ft = extract_first_index_in_each_instance((b, t))
+        want = {}
+        for bi, ti in zip(b.tolist(), t.tolist()):
+            want.setdefault(bi, ti)                                            # first occurrence in the given order
+        assert fb.tolist() == sorted(want) and ft.tolist() == [want[k] for k in sorted(want)]
+    for _ in range(30):
+        B, N, E = 3, 24, 4
+        emb = torch.randn(B, N, E, generator=g)
+        idx, used = [], {}
+        for bi in range(B):
+            pos = 1
+            for _k in range(int(torch.randint(0, 3, (1,), generator=g))):
+                M = int(torch.randint(1, 4, (1,), generator=g))
+                start = pos + int(torch.randint(0, 3, (1,), generator=g))
+                if start + M >= N - 6:
+                    break
+                idx.append((bi, start, M, "s"))
+                pos = start + M
+        out = merge_cls_token_embeddings(emb, idx)
+        for bi in range(B):
+            row, off = emb[bi].clone(), 0
+            cur = emb[bi].clone()
+            for (_, start, M, _n) in sorted([x for x in idx if x[0] == bi], key=lambda x: x[1]):
+                cur[start - off] = emb[bi, start:start + M].sum(0)
+                red = off + M - 1
+                if red > 0:
+                    cur[start - off + 1: N - red] = emb[bi, start + M:]
+                off = red
+            assert torch.equal(out[bi], cur)
