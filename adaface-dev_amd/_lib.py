@@ -53,6 +53,17 @@ def build(verbose: bool = False) -> str:
     return LIB_PATH
 
 
+def sources_sha() -> str:
+    """Hash of everything that decides what the GEMM family executes (kernel sources + the tuned tile table).  Measurements
+    that cannot be taken in-process (PMC traffic) record it, and bench.py reports them only while it still matches."""
+    import hashlib
+    h = hashlib.sha256()
+    for rel in ("csrc/af_common.h", "csrc/af_gemm.hip", "csrc/af_gemm3.hip", "csrc/af_runtime.hip", "tuning/gfx950_gemm.json"):
+        with open(os.path.join(_HERE, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 _lib = None
 
 

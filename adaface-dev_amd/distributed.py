@@ -11,6 +11,9 @@ Replaces what Lightning's ``strategy="ddp"`` (reference main.py:618) does implic
   bandwidth- rather than latency-bound, small enough that the first one starts early in the backward;
 * a bucket's all-reduce is launched (async, on RCCL's own stream) from the post-accumulate-grad hook of the LAST
   of its parameters to become ready, i.e. while the U-Net's activation-gradient backward is still running;
+* collectives are ISSUED IN BUCKET-INDEX ORDER on every rank (bucket b only after buckets 0..b-1; buckets are numbered
+  from the end of the arena, the order gradients become ready in): ranks whose graphs differ for one iteration
+  (per-rank RNG flags, unused parameters) still pair the same buffers, the rest is flushed in order by ``finish()``;
 * ``no_sync()`` skips the exchange on the non-final micro-batches of gradient accumulation
   (``accumulate_grad_batches: 2`` in the reference yaml) -- the arena keeps accumulating.
 
@@ -23,18 +26,25 @@ import torch.distributed as dist
 
 
 class GradReducer:
-    def __init__(self, arenas: List, bucket_bytes: int = 32 << 20, process_group=None, broadcast_params: bool = True):
+    def __init__(self, arenas: List, bucket_bytes: int = 32 << 20, process_group=None, broadcast_params: bool = True,
+                 reduce_single_rank: bool = False):
+        """reduce_single_rank: run the collectives even when the group has ONE rank (they are identities there) -- lets a
+        single-GPU box exercise the RCCL path end to end."""
         self.arenas = list(arenas)
         self.pg = process_group
         self.world = dist.get_world_size(self.pg) if dist.is_initialized() else 1
+        self.active = self.world > 1 or (reduce_single_rank and dist.is_initialized())
         self.sync = True
         self.handles = []
         self.buckets = []          # (arena, lo, hi, n_params)
         self._pending = {}
         self._hooks = []
-        if self.world > 1 and broadcast_params:
+        self.launch_log = []       # bucket indices in the order their collectives were issued (last backward)
+        if self.active and broadcast_params:
             for a in self.arenas:                      # same start point on every rank (DDP's initial broadcast)
                 dist.broadcast(a.flat_p, src=0, group=self.pg)
+                if hasattr(a, "bump_generation"):
+                    a.bump_generation()                # the arena was written outside autograd: cached weight packs are stale
         for ai, a in enumerate(self.arenas):
             per = max(1, bucket_bytes // 4)
             # gradients become ready roughly in reverse parameter order: build buckets from the end of the arena
@@ -54,15 +64,25 @@ class GradReducer:
 
     def _reset(self):
         self._pending = {b: n for b, (_, _, _, n) in enumerate(self.buckets)}
+        self._next = 0             # next bucket index to issue
+
+    def _launch_ready(self, flush: bool = False):
+        """Issue, in index order, every bucket whose parameters all have their gradient (all remaining ones when flushing)."""
+        while self._next < len(self.buckets) and (flush or self._pending[self._next] == 0):
+            a, lo, hi, _ = self.buckets[self._next]
+            self.handles.append(dist.all_reduce(a.flat_g[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+            self.launch_log.append(self._next)
+            self._next += 1
 
     def _make_hook(self, b):
         def hook(param):
-            if not self.sync or self.world == 1:
+            if not self.sync or not self.active:
                 return
+            if self._next == 0 and not self.handles:
+                self.launch_log = []
             self._pending[b] -= 1
             if self._pending[b] == 0:
-                a, lo, hi, _ = self.buckets[b]
-                self.handles.append(dist.all_reduce(a.flat_g[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+                self._launch_ready()
         return hook
 
     @contextlib.contextmanager
@@ -78,18 +98,16 @@ class GradReducer:
         """Wait for the in-flight bucket reductions of this backward and turn sums into means.  Buckets whose
         parameters received no gradient in this backward (unused parameters) are reduced here, so every rank
         issues the same collectives in the same order."""
-        if self.world == 1:
+        if not self.active:
             self._reset()
             return
-        for b, left in self._pending.items():
-            if left > 0:
-                a, lo, hi, _ = self.buckets[b]
-                self.handles.append(dist.all_reduce(a.flat_g[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+        self._launch_ready(flush=True)
         for h in self.handles:
             h.wait()
         self.handles.clear()
-        for a in self.arenas:
-            a.flat_g.div_(self.world)
+        if self.world > 1:
+            for a in self.arenas:
+                a.flat_g.div_(self.world)
         self._reset()
 
     def remove(self):

@@ -31,12 +31,19 @@ class FlatArena:
         self.flat_p = torch.zeros(self.numel, dtype=torch.float32, device=dev)
         self.flat_g = torch.zeros(self.numel, dtype=torch.float32, device=dev)
         self.offsets = offs
+        # generation of the parameter values: bumped whenever the arena is written outside autograd (the fused optimizer
+        # kernel, the data-parallel start-up broadcast); every derived-weight cache keys on it through ops.param_key
+        self.gen = [0]
         with torch.no_grad():
             for p, o in zip(self.params, offs[:-1]):
                 n = p.numel()
                 self.flat_p[o:o + n].copy_(p.detach().reshape(-1))
                 p.data = self.flat_p[o:o + n].view(p.shape)
                 p.grad = self.flat_g[o:o + n].view(p.shape)
+                p._af_gen = self.gen
+
+    def bump_generation(self):
+        self.gen[0] += 1
 
     def zero_grad(self):
         self.flat_g.zero_()
@@ -89,6 +96,7 @@ class AdamW(Optimizer):
             ops.cadamw_step(a.flat_p, a.flat_g, a.exp_avg, a.exp_avg_sq, a.seg_offsets, a.counts, lr=group["lr"],
                             betas=group["betas"], eps=group["eps"], weight_decay=group["weight_decay"], step=a.step,
                             correct_bias=group["correct_bias"])
+            a.bump_generation()          # raw write of flat_p: p._version cannot see it, the fp16 weight packs must be rebuilt
         return loss
 
 

@@ -105,7 +105,7 @@ class UNetWrapper(nn.Module):
                 extra_info.pop("_ffn_lora_adapters", None)
             return out.to(out_dtype)
         if want != (None, False) and self.ffn_lora is not None and self.unet_lora_state_dict is None:
-            key = tuple(p._version for p in self.ffn_lora.parameters())        # inference with the module-held adapters: merge them
+            key = tuple(ops.param_key(p) for p in self.ffn_lora.parameters())        # inference with the module-held adapters: merge them
             if key != getattr(self, "_merged_from_key", None):
                 self._set_loras((None, False))
                 self._module_sd = self.ffn_lora.peft_state_dict()

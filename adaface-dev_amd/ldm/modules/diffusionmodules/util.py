@@ -46,7 +46,7 @@ class _PackCache:
         self._val = None
 
     def get(self, params, build):
-        key = tuple((p.data_ptr(), p._version, str(p.device)) for p in params if p is not None)
+        key = tuple(ops.param_key(p) for p in params if p is not None)
         if key != self._key:
             self._val = build()
             self._key = key

@@ -34,7 +34,7 @@ class DoRAConvAdapter(nn.Module):
 
     # ---- packs (rebuilt when the parameters change: once per optimizer step)
     def _packs(self):
-        key = (self.lora_A._version, self.lora_B._version, self.lora_A.data_ptr(), self.lora_B.data_ptr())
+        key = (ops.param_key(self.lora_A), ops.param_key(self.lora_B))
         if getattr(self, "_pack_key", None) != key:
             dev = self.lora_A.device
             A, Bm = self.lora_A.detach(), self.lora_B.detach().flatten(1)

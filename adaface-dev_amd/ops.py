@@ -25,6 +25,18 @@ F16 = torch.float16
 NEG_MAX = -torch.finfo(torch.float32).max
 
 
+
+def param_key(p):
+    """Identity + modification state of a parameter, the key of every derived-weight cache (fp16 packs, merged adapters).
+    `_version` only sees autograd-visible in-place writes; parameters that live in a flat optimizer arena
+    (ldm.c_adamw.FlatArena) are rewritten by a raw HIP kernel / an in-place collective, so the arena hands each of them its
+    generation counter (`p._af_gen`, a shared one-element list) and bumps it on every such write."""
+    if p is None:
+        return None
+    gen = getattr(p, "_af_gen", None)
+    return (p.data_ptr(), p._version, str(p.device), gen[0] if gen is not None else -1)
+
+
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 

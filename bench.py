@@ -10,8 +10,13 @@ of the SD-1.5 architecture (no network for checkpoints).
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
 
-N > 1: one process per GPU, independent replicas (inference has no exchange step: SURVEY 8e),
-weak scaling; `value` = N*K steps / max-over-ranks time.
+N > 1: one process per GPU.  Started WITHOUT a launcher (`python bench.py --gpus 8`), this process touches no GPU and
+starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD (never an exec), relays its rank-0
+JSON line and exits with its code.  Inference has no exchange step: independent replicas, weak scaling,
+`value` = N*K steps / max-over-ranks time.  The same JSON line carries a `train` object: the Stage-1 distillation
+micro-batch (BASELINE configs[2]/[3], reference main.py:618, 911-915) on the same ranks, data parallel with the bucketed
+RCCL gradient all-reduce overlapped with the backward -- `train.value` (images/s) at N = 1 and N = 8 is what north_star's
+">= 6x training images/s" is read from.  `--mode denoise` / `--mode train` run one leg only.
 
 The JSON line carries, besides the driver contract:
   roofline     -- dominant kernel family (the MFMA GEMM / implicit-conv template): algorithmic
@@ -45,23 +50,39 @@ HBM_PEAK_GBS = 8000.0
 XATTN_BYTES_PER_SAMPLE = 2 * sum(n_l * (2 * N * C + 2 * 77 * C) for n_l, N, C in ((5, 4096, 320), (5, 1024, 640), (5, 256, 1280), (1, 64, 1280)))
 
 
-def main_train(args):
-    """Secondary bench (not the driver's line): BASELINE configs[2] (1 GPU) / configs[3] (DDP).  One *step* = one training
+def dist_context():
+    """(world, rank, local_rank, launched): launched = under torch.distributed.run (also with one rank)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    launched = "RANK" in os.environ and "MASTER_PORT" in os.environ
+    return world, rank, local_rank, launched
+
+
+def init_device(ctx):
+    """Bind this rank to its GPU and, under a launcher, join the RCCL process group (backend "nccl" IS RCCL on ROCm)."""
+    world, rank, local_rank, launched = ctx
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1 or launched:
+        import datetime
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if not dist.is_initialized():
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=datetime.timedelta(seconds=600))
+    return dev
+
+
+def run_train(args, ctx, dev):
+    """BASELINE configs[2] (1 GPU) / configs[3] (DDP).  One *step* = one training
     micro-batch of bs images/GPU: face IDs -> Arc2Face encoder -> trainable SubjBasisGenerator -> frozen text encoder ->
     teacher multi-step targets + student eps per step (HALF_BS = ceil(bs/steps) instances, steps cycling 2,3,4 as
     ddpm.py:1270-1289) -> masked MSE -> backward to the 85 M SubjBasisGenerator weights; every 2nd micro-batch the
     bucketed gradient all-reduce (overlapped with the backward), unscale and fused CAdamW.  Full-size models: 2 x SD-1.5
-    U-Net (student, teacher) + 3 x CLIP-L text transformers, seeded random weights."""
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert torch.cuda.is_available(), "bench.py needs an MI355X"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    U-Net (student, teacher) + 3 x CLIP-L text transformers, seeded random weights.  Returns the result dict on rank 0."""
+    world, rank, local_rank, launched = ctx
     import torch.distributed as dist
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     from adaface_dev_amd import SD15_UNET_CONFIG, _lib, ops, rng
     from adaface_dev_amd.adaface.arc2face_models import CLIPTextModelWrapper
     from adaface_dev_amd.adaface.face_id_to_ada_prompt import Arc2Face_ID2AdaPrompt
@@ -97,8 +118,8 @@ def main_train(args):
                     face_id_embs=rng.synth_input(f"tb.id{i % 4}", (B, 512), seed=seed).to(dev),
                     fg_mask=torch.ones(B, 1, 64, 64, device=dev))
     batches = [batch(i) for i in range(4)]
-    steps = args.steps + (args.steps % 2)            # whole accumulation windows
-    warm = max(2, args.warmup + (args.warmup % 2))
+    steps = args.train_steps + (args.train_steps % 2)            # whole accumulation windows
+    warm = max(2, args.train_warmup + (args.train_warmup % 2))
     losses = []
     for i in range(warm):
         tr.training_step(batches[i % 4], i)
@@ -117,7 +138,8 @@ def main_train(args):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     fam = None
-    if rank == 0 and not args.no_roofline:
+    if not args.no_roofline:
+        # every rank runs the instrumented micro-batches (the gradient exchange is a collective); rank 0 reports its families
         ops.prof_reset()
         ops.prof_enable(True)
         for i in range(6):                             # one full 2,3,4-step cycle twice over (6 micro-batches)
@@ -130,8 +152,14 @@ def main_train(args):
             n, ms = ops.prof_read(f)
             fam[name] = {"launches_per_step": round(n / 6, 1), "ms_per_step": round(ms / 6, 3)}
         ops.prof_reset()
+    out = None
     if rank == 0:
         ms = elapsed / steps * 1e3
+        # algorithmic FLOPs of one micro-batch (SURVEY.md 8d, T = 97: 804.96 GFLOP per U-Net sample forward; student = fwd +
+        # activation-gradient bwd ~ 2x fwd, teacher = 1x fwd): the 2,3,4-step cycle runs HALF_BS x steps = 4, 6, 4 student and
+        # as many teacher sample-passes => 14/3 of each per micro-batch on average at bs 4
+        per_mb = sum(-(-B // s) * s for s in (2, 3, 4)) / 3.0
+        train_tflop = per_mb * 3 * 0.80496
         out = {"metric": "train-images/sec Stage-1 Arc2Face distillation bs=4/GPU", "value": round(world * B * steps / elapsed, 3),
                "unit": "images/s", "n_gpus": world, "steps": steps, "warmup": warm, "ms_per_step": round(ms, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
@@ -141,42 +169,19 @@ def main_train(args):
                           "parallelism": f"dp{world} (RCCL bucketed all-reduce overlapped with backward)" if world > 1 else "single GPU",
                           "optimizer_steps": tr.global_step, "skipped_steps": tr.skipped_steps, "loss_scale": tr.scaler.scale,
                           "last_loss": float(losses[-1]), "finite": bool(all(torch.isfinite(l) for l in losses))},
+               "roofline": {"bound": "mfma", "achieved": round(train_tflop / (ms * 1e-3), 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                            "frac": round(train_tflop / (ms * 1e-3) / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                            "what": f"whole micro-batch: {per_mb:.2f} student fwd+bwd + {per_mb:.2f} teacher fwd U-Net sample-passes "
+                                    f"= {train_tflop:.2f} TFLOP algorithmic (conv/matmul only, encoders not counted) / wall time"},
                "families_per_micro_batch": fam}
-        print(json.dumps(out))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    del tr, ldm, teacher, id2ada, text_enc
+    torch.cuda.empty_cache()
+    return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=4, help="images per GPU (U-Net batch is 2x with CFG)")
-    ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying a hipGraph")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--no-ffn-lora", action="store_true", help="train mode: without the U-Net's trainable FFN DoRA adapters")
-    ap.add_argument("--mode", choices=["denoise", "train"], default="denoise",
-                    help="denoise: BASELINE configs[1] (the headline metric, default); train: configs[2]/[3], the Stage-1 "
-                         "distillation micro-batch (fwd + bwd + overlapped RCCL gradient exchange + CAdamW every 2nd)")
-    args = ap.parse_args()
-    if args.mode == "train":
-        return main_train(args)
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert torch.cuda.is_available(), "bench.py needs an MI355X"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    launched = "RANK" in os.environ and "MASTER_PORT" in os.environ     # under torch.distributed.run (also with one rank)
-    if world > 1 or launched:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-
+def run_denoise(args, ctx, dev):
+    """BASELINE configs[1]: the headline line.  Returns the result dict on rank 0 (None elsewhere)."""
+    world, rank, local_rank, launched = ctx
     from adaface_dev_amd import SD15_UNET_CONFIG, _lib, ops, rng
     from adaface_dev_amd.ldm.models.diffusion.ddim import DDIMSampler
     from adaface_dev_amd.ldm.models.diffusion.ddpm import LatentDiffusion
@@ -290,14 +295,21 @@ def main():
         # (separate passes, gfx950 x2 fetch correction; tools/pmc_traffic.py), committed under profiles/ -- counters cannot be
         # read from inside the process, so the latest committed measurement is reported (null if absent)
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01x_hbm_traffic.json")
-        if os.path.exists(tpath) and B == 4:
+        traffic_src = None
+        import glob
+        for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")), reverse=True):
             with open(tpath) as f:
-                traffic = round(json.load(f)["gemm"]["bytes_per_step"] / g_n, 1) if g_n else None   # per af_gemm call, like `achieved`
+                tj = json.load(f)
+            # a measurement is only reported for the kernels it was taken on: the file records the hash of the GEMM sources
+            # + tuning table (tools/pmc_traffic.py writes it); anything else is stale => null
+            if tj.get("sources_sha") == _lib.sources_sha() and tj.get("batch", 4) == B and g_n:
+                traffic = round(tj["gemm"]["bytes_per_step"] / g_n, 1)   # per af_gemm call, like `achieved`
+                traffic_src = os.path.basename(tpath)
+                break
         roofline = {
             "kernel": "af_gemm family: af_gemm3w_kernel / af_gemm3_kernel / af_gemm_kernel (conv3x3 implicit GEMM + linear + conv1x1)",
             "bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+            "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
             "flops_per_launch": flops_step / g_n if g_n else None,
             "avg_launch_ms": g_ms / g_n if g_n else None,
             "families_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in fam.items()},
@@ -337,6 +349,7 @@ def main():
                       f"step), mean {dt:.2f} s each; value = 1 / ({2 * B} x that)",
         }
 
+    out = None
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = world * args.steps / elapsed
@@ -353,10 +366,94 @@ def main():
                        "finite": finite},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
-        print(json.dumps(out))
+    del unet, ldm, sampler
+    state.clear()
+    torch.cuda.empty_cache()
+    return out
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` without a launcher: start N ranks as a CHILD process (this parent never touches the GPU:
+    torch.cuda.device_count() does not initialise it), relay the rank-0 JSON line, exit with the child's code."""
+    import socket
+    import subprocess
+    n_dev = torch.cuda.device_count()
+    if n_dev < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but only {n_dev} GPU(s) visible", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in r.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if line is not None:
+        print(line)
+    return r.returncode if line is not None or r.returncode else 1
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=4, help="images per GPU (U-Net batch is 2x with CFG)")
+    ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying a hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-ffn-lora", action="store_true", help="train leg: without the U-Net's trainable FFN DoRA adapters")
+    ap.add_argument("--train-steps", type=int, default=12, help="timed micro-batches of the train leg")
+    ap.add_argument("--train-warmup", type=int, default=6)
+    ap.add_argument("--mode", choices=["all", "denoise", "train"], default="all",
+                    help="all (default): the headline denoise line (BASELINE configs[1]) carrying the Stage-1 training leg "
+                         "(configs[2]/[3]) as its `train` object; denoise / train: one leg only (train prints its own line)")
+    args = ap.parse_args()
+    ctx = dist_context()
+    world, rank, local_rank, launched = ctx
+    if args.gpus > 1 and not launched:
+        sys.exit(launch_ranks(args, sys.argv[1:]))
+    if launched and world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} under a launcher with WORLD_SIZE {world}; using {world}", file=sys.stderr)
+    dev = init_device(ctx)
+    out = None
+    if args.mode in ("all", "denoise"):
+        out = run_denoise(args, ctx, dev)
+    if args.mode in ("all", "train"):
+        # the train leg must never cost the headline line: an exception is reported inside the line, and a hang (a stuck
+        # collective) is cut by a watchdog on rank 0 that prints what it has and leaves
+        import threading
+        done = threading.Event()
+
+        def watchdog():
+            if not done.wait(900.0) and rank == 0:
+                res = dict(out or {}, train={"error": "train leg exceeded 900 s"})
+                print(json.dumps(res), flush=True)
+                os._exit(3)
+        threading.Thread(target=watchdog, daemon=True).start()
+        try:
+            tr = run_train(args, ctx, dev)
+        except Exception as e:                          # noqa: BLE001  (reported, not swallowed)
+            import traceback
+            traceback.print_exc()
+            tr = {"error": f"{type(e).__name__}: {e}"}
+        done.set()
+        if args.mode == "train":
+            out = tr
+        elif rank == 0:
+            out["train"] = tr
+    if rank == 0:
+        print(json.dumps(out), flush=True)
     if world > 1 or launched:
         import torch.distributed as dist
-        dist.barrier()                  # rank 0 may still be in its instrumented pass: leave together
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -1,5 +1,6 @@
 """Worker of tests/test_hip_train.py::test_data_parallel_step_two_ranks_equals_accumulated_single_process (launched with
-torch.distributed.run, 2 ranks on one GPU, gloo).  Rank r trains on micro-batch r with accumulate_grad_batches=1."""
+torch.distributed.run, 2 ranks on one GPU, gloo) and ::test_rccl_world1_train_step_under_launcher (AF_DDP_BACKEND=nccl, ONE
+rank: RCCL refuses two ranks on one device).  Rank r trains on micro-batch r with accumulate_grad_batches=1."""
 import os
 import sys
 
@@ -10,11 +11,27 @@ import torch.distributed as dist
 def main():
     out = sys.argv[1]
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    backend = os.environ.get("AF_DDP_BACKEND", "gloo")
     dev = torch.device("cuda:0")
+    if backend == "nccl":
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     from adaface_dev_amd import rng
+    from adaface_dev_amd.distributed import GradReducer
     from trainer_util import trainer_setup
     tr, _, _ = trainer_setup(dev, accum=1)
+    if world == 1:      # one rank: run the collectives anyway (identities) so the RCCL path is what executes
+        tr.reducer.remove()
+        tr.reducer = GradReducer(tr.arenas, bucket_bytes=256 << 10, reduce_single_rank=True)
+    n_coll = {"n": 0}
+    orig_all_reduce = dist.all_reduce
+
+    def counting_all_reduce(*a, **k):
+        n_coll["n"] += 1
+        return orig_all_reduce(*a, **k)
+    dist.all_reduce = counting_all_reduce
     # the lr rule counts accumulate * world: the single-process twin uses accum 2 x world 1
     p0 = tr.arena.flat_p.clone()
     seen = {}
@@ -36,11 +53,13 @@ def main():
     tr.reducer._reset()
     tr.optimizer.zero_grad()
     tr.unet_distill_iters_count = 0
+    n_coll["n"] = 0
     tr.training_step(b, 0, num_unet_denoising_steps=1, t=t)
+    collectives, launch_log = n_coll["n"], list(tr.reducer.launch_log)
     tot = local.clone()
     dist.all_reduce(tot)
     if rank == 0:
-        torch.save({"flat_p": tr.arena.flat_p.cpu(), "p0": p0.cpu(), "global_step": tr.global_step, "world": tr.world, "lr": tr.learning_rate,
+        torch.save({"backend": dist.get_backend(), "collectives": collectives, "launch_log": launch_log, "flat_p": tr.arena.flat_p.cpu(), "p0": p0.cpu(), "global_step": tr.global_step, "world": tr.world, "lr": tr.learning_rate,
                     "mean_grad": seen["g"].cpu(), "mean_grad_expected_from_rank_sums": (tot / world).cpu()}, out)
     dist.barrier()
     dist.destroy_process_group()

@@ -422,3 +422,72 @@ def test_distill_trainer_with_ffn_dora_param_group(dev):
     assert tr.global_step == 1 and tr.skipped_steps == 0
     assert float((tr.arenas[0].flat_p - p_sbg).abs().max()) > 0 and float((tr.arenas[1].flat_p - p_lora).abs().max()) > 0
     assert all(torch.equal(a, b.detach()) for a, b in zip(other, lora.adapters["recon_loss"].parameters()))
+
+
+def test_weight_packs_follow_the_optimizer(dev):
+    """The fused CAdamW kernel rewrites the flat fp32 arena behind autograd's back (p._version never moves): every cached
+    fp16 weight pack of a trainable layer must be rebuilt after optimizer.step().  Two optimizer steps with a large lr; after
+    each one the generator's output must equal what a FRESHLY built module holding the same fp32 masters computes, and must
+    differ from the output before the step (frozen packs would reproduce it bit for bit)."""
+    import copy
+    from adaface_dev_amd import rng
+    tr, _, _ = trainer_setup(dev, accum=1, ffn_lora=True)
+    for g in tr.optimizer.param_groups:
+        g["lr"] = 1e-2
+    tr.learning_rate = 1e-2
+    sbg = tr.id2ada.subj_basis_generator
+    x = rng.synth_input("stale.id2img", (2, 16, 128), seed=77).to(dev)
+
+    def out_of(m):
+        with torch.no_grad():
+            return m(x, out_id_embs_cfg_scale=1.0, is_face=True).float().cpu().numpy()
+
+    b = dict(x_start=rng.synth_input("stale.x", (2, 4, 32, 32), seed=77).to(dev), face_id_embs=rng.synth_input("stale.id", (2, 512), seed=77).to(dev),
+             fg_mask=torch.ones(2, 1, 32, 32, device=dev))
+    prev = out_of(sbg)
+    lora = tr.ldm.model.ffn_lora
+    ad = next(iter(next(iter(lora.active("unet_distill").values())).values()))
+    for it in range(2):
+        pk_before = ad._packs()[0].wt.clone()
+        tr.training_step(b, it, num_unet_denoising_steps=1)
+        assert tr.global_step == it + 1
+        now = out_of(sbg)
+        assert rel_l2(now, prev) > 1e-4, "the forward did not see the optimizer step (stale fp16 packs)"
+        fresh = copy.deepcopy(sbg)                     # new module objects: empty caches, same fp32 master values
+        for m in fresh.modules():
+            for name in ("_cache", "_cache_bwd"):
+                if hasattr(m, name):
+                    setattr(m, name, type(getattr(m, name))())
+        assert rel_l2(now, out_of(fresh)) < 1e-6
+        # the DoRA adapter packs are rebuilt too
+        assert not torch.equal(ad._packs()[0].wt, pk_before)
+        prev = now
+
+
+def test_rccl_world1_train_step_under_launcher(dev, tmp_path):
+    """One rank under torch.distributed.run with backend "nccl" (= RCCL): process-group init on the device, the start-up
+    parameter broadcast, every gradient bucket all-reduced from the backward hooks on RCCL's stream (reduce_single_rank),
+    the overflow-flag all-reduce and the optimizer step.  With one rank every collective is an identity, so the result must
+    equal the plain single-process step."""
+    import subprocess
+    import sys
+    from adaface_dev_amd import rng
+    out = tmp_path / "rccl1.pt"
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", PYTHONPATH=os.path.dirname(here) + os.pathsep + here, AF_DDP_BACKEND="nccl",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+                        "--master-port", "29619", os.path.join(here, "ddp_train_worker.py"), str(out)], env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    got = torch.load(out)
+    assert got["backend"] == "nccl" and got["world"] == 1 and got["global_step"] == 1
+    assert got["collectives"] >= 2 and got["launch_log"] == sorted(got["launch_log"])
+    tr, _, _ = trainer_setup(dev, accum=1)
+    t = torch.tensor([760, 850, 800, 720], device=dev)
+    b = dict(x_start=rng.synth_input("dp.x0", (4, 4, 32, 32), seed=48).to(dev), face_id_embs=rng.synth_input("dp.id0", (4, 512), seed=48).to(dev),
+             fg_mask=torch.ones(4, 1, 32, 32, device=dev), noise=rng.synth_input("dp.n0", (4, 4, 32, 32), seed=48).to(dev))
+    tr.training_step(b, 0, num_unet_denoising_steps=1, t=t)
+    assert rel_l2(got["mean_grad"].numpy(), got["mean_grad_expected_from_rank_sums"].numpy()) < 1e-6
+    same = ((got["flat_p"] - got["p0"]).sign() == (tr.arena.flat_p.cpu() - got["p0"]).sign()).float().mean()
+    assert same > 0.999, float(same)

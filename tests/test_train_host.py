@@ -120,3 +120,61 @@ def test_grad_reducer_gloo_world2_matches_single_process():
     want = (tot / 2).numpy()
     assert np.allclose(g0[: want.size], want, rtol=1e-5, atol=1e-7)
     assert np.all(g0[want.size:] == 0)                 # unused parameters: reduced, zero
+
+
+def _ddp_worker_uneven(rank, world, port, q):
+    """Ranks whose graphs differ in one iteration: rank 0's loss uses head A only, rank 1's head B only, so the sets of
+    parameters receiving a gradient (and the order buckets become ready) differ across ranks."""
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from adaface_dev_amd.distributed import GradReducer
+    from adaface_dev_amd.ldm.c_adamw import FlatArena
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(5)
+    trunk = torch.nn.Linear(16, 16)
+    heads = torch.nn.ModuleList([torch.nn.Linear(16, 8), torch.nn.Linear(16, 8)])
+    params = list(heads[0].parameters()) + list(trunk.parameters()) + list(heads[1].parameters())
+    arena = FlatArena(params)
+    red = GradReducer([arena], bucket_bytes=256)
+    torch.manual_seed(9)
+    data = torch.randn(2, 5, 16)
+    arena.zero_grad()
+    heads[rank](torch.tanh(trunk(data[rank]))).pow(2).mean().backward()
+    in_hooks = list(red.launch_log)                    # issued from the hooks, before finish() flushes the rest
+    red.finish()
+    q.put((rank, arena.flat_g.clone().numpy(), in_hooks, list(red.launch_log), len(red.buckets)))
+    dist.destroy_process_group()
+
+
+def test_grad_reducer_issues_collectives_in_bucket_order_when_rank_graphs_differ():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_ddp_worker_uneven, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, g0, hooks0, log0, nb), (_, g1, hooks1, log1, _) = res
+    assert nb >= 4
+    assert log0 == log1 == list(range(nb))             # same collectives, same order, on both ranks
+    assert hooks0 != hooks1 or len(hooks0) < nb        # the graphs really differed: not everything was ready in the hooks
+    assert np.array_equal(g0, g1)
+    # reference: mean over ranks, the other rank's head gradient is zero
+    torch.manual_seed(5)
+    trunk = torch.nn.Linear(16, 16)
+    heads = torch.nn.ModuleList([torch.nn.Linear(16, 8), torch.nn.Linear(16, 8)])
+    params = list(heads[0].parameters()) + list(trunk.parameters()) + list(heads[1].parameters())
+    torch.manual_seed(9)
+    data = torch.randn(2, 5, 16)
+    tot = torch.zeros(sum(p.numel() for p in params))
+    for r in range(2):
+        for p in params:
+            p.grad = None
+        heads[r](torch.tanh(trunk(data[r]))).pow(2).mean().backward()
+        tot += torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
+    assert np.allclose(g0, (tot / 2).numpy(), rtol=1e-5, atol=1e-7)

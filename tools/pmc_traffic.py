@@ -26,7 +26,11 @@ def per_family(db, counter):
 def main():
     fe, wr = per_family(sys.argv[1], "FETCH_SIZE"), per_family(sys.argv[2], "WRITE_SIZE")
     steps = int(sys.argv[sys.argv.index("--steps") + 1])
-    res = {"steps_traced": steps}
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from adaface_dev_amd import _lib
+    # bench.py reports this file's numbers only while the GEMM sources + tuning table still hash to this value
+    res = {"steps_traced": steps, "sources_sha": _lib.sources_sha(), "batch": 4}
     for f, _ in FAMILIES:
         n = fe[f][0]
         assert n == wr[f][0], (f, n, wr[f][0])
