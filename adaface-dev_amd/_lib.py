@@ -43,11 +43,32 @@ class GemmDesc(C.Structure):
     ]
 
 
+def _csrc_sha() -> str:
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.h")))
+    files += [os.path.join(CSRC, "Makefile"), os.path.join(os.path.dirname(_HERE), "include", "adaface_hip.h")]
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def build(verbose: bool = False) -> str:
-    """Compile every HIP source for gfx950 into csrc/libadaface_hip.so (make, in-tree)."""
-    r = subprocess.run(["make", "-C", CSRC, "-j4"], capture_output=True, text=True)
+    """Compile every HIP source for gfx950 into csrc/libadaface_hip.so (make, in-tree).  The objects are stamped with a hash
+    of ALL sources: if the stamp does not match the tree (a stale or foreign .o / .so), everything is rebuilt from scratch;
+    otherwise make's incremental rules decide."""
+    stamp = os.path.join(CSRC, ".build_sha")
+    want = _csrc_sha()
+    have = open(stamp).read().strip() if os.path.exists(stamp) else ""
+    cmd = ["make", "-C", CSRC, "-j8"] + ([] if have == want and os.path.exists(LIB_PATH) else ["-B"])
+    r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("building libadaface_hip.so failed:\n" + r.stdout + r.stderr)
+    with open(stamp, "w") as f:
+        f.write(want)
     if verbose:
         print(r.stdout)
     return LIB_PATH

@@ -24,7 +24,8 @@ int af_fail(int code, const std::string& msg);
 struct AfLaunchScope {
   int family;
   hipStream_t stream;
-  int slot;
+  hipEvent_t ev_stop;      // the scope owns its stop event handle (no index into shared state); nullptr = not recording
+  unsigned epoch;          // af_prof_reset() generation the pair belongs to
   AfLaunchScope(int family, void* stream);
   ~AfLaunchScope();
 };

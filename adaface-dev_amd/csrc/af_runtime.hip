@@ -1,4 +1,5 @@
 // af_runtime.hip -- error strings, version, device probe and the hipEvent profiling hook.
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -32,7 +33,8 @@ int af_check_launch(const char* what) {
 namespace {
 struct ProfState {
   std::mutex mu;
-  bool on = false;
+  std::atomic<bool> on{false};
+  unsigned epoch = 0;      // bumped by af_prof_reset(): scopes opened before a reset do not record their stop event
   struct Pair {
     hipEvent_t a, b;
   };
@@ -45,39 +47,48 @@ ProfState& prof() {
 }
 }  // namespace
 
-AfLaunchScope::AfLaunchScope(int family_, void* stream_) : family(family_), stream((hipStream_t)stream_), slot(-1) {
+AfLaunchScope::AfLaunchScope(int family_, void* stream_) : family(family_), stream((hipStream_t)stream_), ev_stop(nullptr), epoch(0) {
   ProfState& p = prof();
-  if (!p.on) return;
+  if (!p.on.load(std::memory_order_relaxed)) return;
+  // events cannot be recorded into a stream that is being captured into a hipGraph: skip (the graph replays carry no events)
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return;
   std::lock_guard<std::mutex> lk(p.mu);
   ProfState::Pair pr;
   if (!p.pool.empty()) {
     pr = p.pool.back();
     p.pool.pop_back();
   } else {
-    if (hipEventCreate(&pr.a) != hipSuccess || hipEventCreate(&pr.b) != hipSuccess) return;
+    if (hipEventCreate(&pr.a) != hipSuccess) return;
+    if (hipEventCreate(&pr.b) != hipSuccess) {
+      (void)hipEventDestroy(pr.a);
+      return;
+    }
   }
   (void)hipEventRecord(pr.a, stream);
   p.pairs[family].push_back(pr);
-  slot = (int)p.pairs[family].size() - 1;
+  ev_stop = pr.b;
+  epoch = p.epoch;
 }
 
 AfLaunchScope::~AfLaunchScope() {
-  if (slot < 0) return;
+  if (!ev_stop) return;
   ProfState& p = prof();
   std::lock_guard<std::mutex> lk(p.mu);
-  (void)hipEventRecord(p.pairs[family][slot].b, stream);
+  if (epoch != p.epoch) return;      // af_prof_reset() ran meanwhile: the pair went back to the pool, leave it alone
+  (void)hipEventRecord(ev_stop, stream);
 }
 
 extern "C" int af_prof_enable(int on) {
   ProfState& p = prof();
-  std::lock_guard<std::mutex> lk(p.mu);
-  p.on = on != 0;
+  p.on.store(on != 0);
   return AF_OK;
 }
 
 extern "C" int af_prof_reset(void) {
   ProfState& p = prof();
   std::lock_guard<std::mutex> lk(p.mu);
+  ++p.epoch;
   for (int f = 0; f < AF_FAM_COUNT; ++f) {
     for (auto& pr : p.pairs[f]) p.pool.push_back(pr);
     p.pairs[f].clear();

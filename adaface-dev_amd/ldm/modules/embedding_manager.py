@@ -221,12 +221,14 @@ class EmbeddingManager(nn.Module):
 
     # ------------------------------------------------------------------ embeddings_gs-N.pt
     def save(self, adaface_ckpt_path):
-        """Same dict layout as the reference (the generator modules are pickled whole)."""
+        """Same dict layout as the reference, embedding_manager.py:513-524 (the generator modules are pickled whole).  Written
+        through ``adaface.ckpt.save_adaface_ckpt_file``: reference class paths, CPU tensors, no derived fp16 weight packs."""
+        from ...adaface.ckpt import save_adaface_ckpt_file
         saved = {"string_to_subj_basis_generator_dict": self.string_to_subj_basis_generator_dict,
                  "placeholder_strings": self.placeholder_strings, "subject_strings": self.subject_strings}
         if self.unet_lora_modules is not None:
             saved["unet_lora_modules"] = self.unet_lora_modules.state_dict()
-        torch.save(saved, adaface_ckpt_path)
+        save_adaface_ckpt_file(saved, adaface_ckpt_path)
 
     def load(self, adaface_ckpt_paths, load_unet_attn_lora_from_ckpt=True, unet_ffn_adapters_to_load=("recon_loss", "unet_distill")):
         from ...adaface.ckpt import load_adaface_ckpt_file

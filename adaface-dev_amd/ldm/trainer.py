@@ -12,9 +12,10 @@ What one micro-batch does (everything below the Python control flow is a HIP ker
   teacher: "photo of a" prefix (4 tokens) ++ image-prompt embs -> multi-step Arc2Face U-Net (no grad)    (D5)
   student: per step eps-prediction of the frozen SD-1.5 U-Net under subj_context, fg-masked MSE x 8      (D4, D6)
   backward: whole-U-Net activation-gradient node -> text encoder dgrad -> SubjBasisGenerator weights
-  after every backward: gradient clipping by value (+-0.01, the yaml's Lightning setting) on the flat arena;
   every `accumulate_grad_batches`-th micro-batch: bucketed RCCL all-reduce overlapped with the backward
-  (GradReducer), unscale, cautious AdamW on the flat fp32 arena, warm-up/cosine LR.
+  (GradReducer), gradient clipping by value (+-0.01, the yaml's Lightning setting; once per optimizer step on the
+  accumulated rank-averaged gradients, as Lightning's automatic optimization does), unscale, cautious AdamW on the
+  flat fp32 arena, warm-up/cosine LR.
 
 Like the reference's do_unet_distill iterations the batch is cut to HALF_BS = ceil(BS / steps) instances when
 `num_unet_denoising_steps` > 1 (ddpm.py:1283-1311) and the step count cycles 2,3,4 deterministically so every rank runs
@@ -97,8 +98,8 @@ class DistillTrainer:
         self.unet_distill_iters_count = 0
         self.skipped_steps = 0
         self.prompt_len, self.subj_slot = prompt_len, subj_slot
-        # Lightning trainer settings of the reference yaml (v1-distill-arc2face-ada.yaml:150-152), applied after every backward as
-        # DDPM.training_step does (ddpm.py:494-497)
+        # Lightning trainer settings of the reference yaml (v1-distill-arc2face-ada.yaml:150-152), applied once per optimizer step
+        # (automatic optimization)
         if gradient_clip_algorithm != "value":
             raise NotImplementedError("only gradient_clip_algorithm='value' (the reference's setting) is built")
         self.gradient_clip_val = gradient_clip_val
@@ -235,11 +236,15 @@ class DistillTrainer:
         # overflow check BEFORE the clip (a clamp would hide an inf), accumulated on the device across the window
         bad = sum((~torch.isfinite(a.flat_g.sum())).float() for a in self.arenas)       # inf/nan anywhere poisons the sum
         self._bad = bad if self._bad is None else self._bad + bad
-        if self.gradient_clip_val:
-            lim = self.gradient_clip_val * self.scaler.scale                            # gradients are still loss-scaled
-            for a in self.arenas:
-                ops.clamp_f32_(a.flat_g, -lim, lim)
         if last:
+            # Lightning automatic optimization (the reference's default, lightning_auto_optimization=True): the loss is divided by
+            # accumulate_grad_batches, and the value clip runs ONCE per optimizer step, on the accumulated, rank-averaged,
+            # unscaled gradients, right before optimizer.step() -- clamp((g1 + g2) / 2), not clamp(clamp(g1 / 2) + g2 / 2)
+            # (the manual-optimization path ddpm.py:494-497 clips after every backward instead; it is not the mode mirrored here)
+            if self.gradient_clip_val:
+                lim = self.gradient_clip_val * self.scaler.scale                        # gradients are still loss-scaled
+                for a in self.arenas:
+                    ops.clamp_f32_(a.flat_g, -lim, lim)
             self.optimizer_step()
         return loss.detach()
 

@@ -304,3 +304,84 @@ def test_token_helpers_against_brute_force_random_cases():
                     cur[start - off + 1: N - red] = emb[bi, start + M:]
                 off = red
             assert torch.equal(out[bi], cur)
+
+
+def test_saved_checkpoint_is_loadable_with_reference_class_paths(tmp_path):
+    """EmbeddingManager.save writes what the REFERENCE's torch.load can restore: every pickled class path is one the
+    reference environment resolves (adaface.subj_basis_generator.*, adaface.arc2face_models.*, transformers' CLIP modules,
+    torch.nn layers), nothing from this package and no derived fp16 weight packs are in the file, tensors are on the CPU, and
+    the restored object's state_dict() equals the saved generator's.  The reference classes are stood in for by bare nn.Module
+    subclasses registered under the reference's module names (restoring runs no constructors)."""
+    import pickletools
+    import sys
+    import types
+    import zipfile
+    import torch.nn as nn
+    from adaface_dev_amd import rng
+    from adaface_dev_amd.adaface.adaface_wrapper import WordTokenizer
+    from adaface_dev_amd.adaface.arc2face_models import clip_text_config
+    from adaface_dev_amd.adaface.face_id_to_ada_prompt import Arc2Face_ID2AdaPrompt
+    from adaface_dev_amd.ldm.modules.embedding_manager import EmbeddingManager
+    cfg = clip_text_config(hidden_size=64, num_attention_heads=2, num_hidden_layers=2, intermediate_size=128, vocab_size=512)
+    src = Arc2Face_ID2AdaPrompt(clip_config=cfg)
+    rng.load_synth_weights(src.subj_basis_generator.prompt2token_proj, seed=9)
+    # leave cache objects behind, as a forward pass would
+    from adaface_dev_amd.ldm.modules.diffusionmodules.util import Linear
+    n_cached = 0
+    for m in src.subj_basis_generator.modules():
+        if isinstance(m, Linear):
+            m._cache._key, m._cache._val = ("stale",), torch.zeros(3)
+            n_cached += 1
+    assert n_cached > 0
+    em = EmbeddingManager(U.text_embedder(WordTokenizer(), U.token_table()), ["z"], out_emb_dim=64, id2ada_prompt_encoder=src)
+    path = str(tmp_path / "embeddings_gs-30.pt")
+    em.save(path)
+    with zipfile.ZipFile(path) as z:
+        pkl = z.read([n for n in z.namelist() if n.endswith("data.pkl")][0])
+    globs = set()
+    for op, arg, _ in pickletools.genops(pkl):
+        if op.name == "GLOBAL":
+            globs.add(arg.replace(" ", "."))
+    strs = [arg for op, arg, _ in pickletools.genops(pkl) if op.name in ("SHORT_BINUNICODE", "BINUNICODE") and isinstance(arg, str)]
+    for i, a in enumerate(strs[:-1]):                      # STACK_GLOBAL pairs (module, name) pushed as two strings
+        if a.startswith(("adaface", "torch.", "transformers", "collections", "ldm")) and "." in a or a in ("adaface", "collections"):
+            globs.add(a + "." + strs[i + 1])
+    assert not any("adaface_dev_amd" in g for g in globs), sorted(globs)
+    assert b"adaface_dev_amd" not in pkl and b"_PackCache" not in pkl
+    assert "adaface.subj_basis_generator.SubjBasisGenerator" in globs and "adaface.arc2face_models.CLIPTextModelWrapper" in globs
+    assert "adaface.arc2face_models.CLIPAttentionMKV" in globs and "transformers.models.clip.modeling_clip.CLIPEncoderLayer" in globs
+    assert "torch.nn.modules.linear.Linear" in globs and "torch.nn.modules.normalization.LayerNorm" in globs
+
+    # restore with stand-ins for the reference classes under the reference's module names
+    names = {"adaface.subj_basis_generator": ["SubjBasisGenerator"], "adaface.arc2face_models": ["CLIPTextModelWrapper", "CLIPAttentionMKV"],
+             "transformers.models.clip.modeling_clip": ["CLIPTextTransformer"]}
+    import transformers.models.clip.modeling_clip as real_clip
+    saved = {k: sys.modules.get(k) for k in ("adaface", "adaface.subj_basis_generator", "adaface.arc2face_models")}
+    added = []
+    try:
+        sys.modules["adaface"] = types.ModuleType("adaface")
+        for modname, classes in names.items():
+            mod = real_clip if modname.startswith("transformers") else types.ModuleType(modname)
+            for c in classes:
+                if not hasattr(mod, c):
+                    setattr(mod, c, type(c, (nn.Module,), {"__module__": modname}))
+                    added.append((mod, c))
+            sys.modules[modname] = mod
+        ck = torch.load(path, map_location="cpu", weights_only=False)          # the reference's own call (embedding_manager.py:531)
+    finally:
+        for mod, c in added:
+            if mod is real_clip:
+                delattr(mod, c)
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    g = ck["string_to_subj_basis_generator_dict"]["z"]
+    assert type(g).__module__ == "adaface.subj_basis_generator" and type(g.prompt2token_proj.text_model.encoder.layers[0].mlp.fc1) is nn.Linear
+    assert g.prompt2token_proj_attention_multipliers == src.subj_basis_generator.prompt2token_proj_attention_multipliers and g.N_ID == 16
+    sd, want = g.state_dict(), src.subj_basis_generator.state_dict()
+    assert set(sd) == set(want)
+    for k in want:
+        assert sd[k].device.type == "cpu" and torch.equal(sd[k], want[k].cpu()), k
+    assert not any(hasattr(m, "_cache") for m in g.modules())

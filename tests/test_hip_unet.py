@@ -22,8 +22,11 @@ from conftest import GOLDEN, rel_l2
 
 pytestmark = pytest.mark.gpu
 
-BLOCK_TOL = 3e-3
-NET_TOL = 1e-2
+# measured on MI355X: blocks <= 1e-3, full-size eps 1.55e-3, gradients 2.4 - 2.9e-3, batch property 1e-3;
+# the bounds are 2-3x that, so a 2x numerical regression fails
+BLOCK_TOL = 2e-3
+NET_TOL = 4e-3
+GRAD_TOL = 8e-3
 
 GPU_TINY_CONFIG = dict(in_channels=4, model_channels=64, out_channels=4, num_res_blocks=2, attention_resolutions=[4, 2, 1],
                        channel_mult=[1, 2, 4, 4], num_heads=8, use_spatial_transformer=True, transformer_depth=1,
@@ -197,12 +200,12 @@ def test_unet_reduced_width_backward_vs_oracle_autograd(dev):
         assert rel_l2(eps.detach().cpu().numpy(), ref.detach().numpy()) < NET_TOL
         ex, ec = rel_l2(xg.grad.cpu().numpy(), xr.grad.numpy()), rel_l2(cg.grad.cpu().numpy(), cr.grad.numpy())
         print(f"grad rel-L2: dx {ex:.3e} dcontext {ec:.3e}")
-        assert ex < 2e-2 and ec < 2e-2
+        assert ex < GRAD_TOL and ec < GRAD_TOL
     # context-only gradient (the training case: x_noisy carries no gradient)
     cg = ctx.clone().to(dev).requires_grad_(True)
     eps = m(x.to(dev), t.to(dev), cg, extra_info={})
     (eps * cot.to(dev)).sum().backward()
-    assert rel_l2(cg.grad.cpu().numpy(), cr.grad.numpy()) < 2e-2 or img_mask is not None
+    assert rel_l2(cg.grad.cpu().numpy(), cr.grad.numpy()) < GRAD_TOL or img_mask is not None
 
 
 @pytest.mark.parametrize("B,H,W,T", [(1, 24, 40, 20), (3, 16, 16, 97)])
@@ -224,7 +227,7 @@ def test_unet_backward_ragged_shapes_vs_oracle_autograd(dev, B, H, W, T):
     ref = O.unet_forward(sd, GPU_TINY_CONFIG, xr, t, cr, {"img_mask": mask, "res_hidden_states_gradscale": 0.5})
     (ref * cot).sum().backward()
     ex, ec = rel_l2(xg.grad.cpu().numpy(), xr.grad.numpy()), rel_l2(cg.grad.cpu().numpy(), cr.grad.numpy())
-    assert rel_l2(eps.detach().cpu().numpy(), ref.detach().numpy()) < NET_TOL and ex < 2e-2 and ec < 2e-2, (ex, ec)
+    assert rel_l2(eps.detach().cpu().numpy(), ref.detach().numpy()) < NET_TOL and ex < GRAD_TOL and ec < GRAD_TOL, (ex, ec)
 
 
 def test_unet_backward_skip_gradient_scale_vs_oracle(dev):
@@ -249,7 +252,7 @@ def test_unet_backward_skip_gradient_scale_vs_oracle(dev):
         assert rel_l2(eps.detach().cpu().numpy(), ref.detach().numpy()) < NET_TOL
         ex, ec = rel_l2(xg.grad.cpu().numpy(), xr.grad.numpy()), rel_l2(cg.grad.cpu().numpy(), cr.grad.numpy())
         print(f"gradscale {gs}: dx {ex:.3e} dcontext {ec:.3e}")
-        assert ex < 2e-2 and ec < 2e-2
+        assert ex < GRAD_TOL and ec < GRAD_TOL
         grads[gs] = (xr.grad.clone(), cr.grad.clone())
     assert rel_l2(grads[0.5][1].numpy(), grads[1.0][1].numpy()) > 0.05          # the scaler really changes the gradient
 
@@ -287,7 +290,7 @@ def test_unet_full_size_backward_vs_reference_autograd(dev, full_model):
     (eps * cot).sum().backward()
     ex, ec = rel_l2(x.grad.cpu().numpy(), g["grad_x"]), rel_l2(ctx.grad.cpu().numpy(), g["grad_ctx"])
     print(f"full-size backward vs reference autograd: dx {ex:.3e}  dcontext {ec:.3e}")
-    assert rel_l2(eps.detach().cpu().numpy(), g["eps"]) < NET_TOL and ex < 2e-2 and ec < 2e-2
+    assert rel_l2(eps.detach().cpu().numpy(), g["eps"]) < NET_TOL and ex < GRAD_TOL and ec < GRAD_TOL
 
 
 def test_unet_full_size_nonsquare_768x512_vs_oracle(dev, full_model):
@@ -323,7 +326,7 @@ def test_unet_full_size_batch_properties(dev, full_model):
     assert torch.isfinite(e8).all()
     # not bitwise: the tuned (tile, split-K) per GEMM shape differs between M = 8*HW and M = HW, which moves fp16
     # roundings (measured 1.6e-3 through the ~300 dependent roundings of the network); cross-sample leakage would be O(1)
-    assert rel_l2(e8[3:4].cpu().numpy(), e1.cpu().numpy()) < 4e-3
+    assert rel_l2(e8[3:4].cpu().numpy(), e1.cpu().numpy()) < 3e-3
 
 
 def test_ddim_sampler_vs_reference_trajectory(dev):
@@ -410,7 +413,7 @@ def test_guided_denoise_cfg_x0_grad_modes_vs_oracle(dev):
         (ref * cot).sum().backward()
         assert rel_l2(eps.detach().cpu().numpy(), ref.detach().numpy()) < NET_TOL, cfg
         assert rel_l2(x_rec.detach().cpu().numpy(), ref_rec.detach().numpy()) < NET_TOL, cfg
-        assert rel_l2(cg.grad.cpu().numpy(), cr.grad.numpy()) < 2e-2, cfg
+        assert rel_l2(cg.grad.cpu().numpy(), cr.grad.numpy()) < GRAD_TOL, cfg
         assert acts is None and ei["res_hidden_states_gradscale"] == 0.5
     e_none, rec_none, acts_none = ld.guided_denoise(x0.to(dev), noise.to(dev), t.to(dev), (ctx.to(dev).requires_grad_(True), ["a", "b"], {}),
                                                     img_mask=mask.to(dev), batch_part_has_grad="none", cfg_scale=2.5,
