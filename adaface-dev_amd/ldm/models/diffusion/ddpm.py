@@ -88,6 +88,9 @@ class UNetWrapper(nn.Module):
     def forward(self, x, t, cond_context, out_dtype=torch.float32):
         prompt_emb, prompt_in, extra_info = cond_context
         ei = extra_info or {}
+        if ei.get("normalize_cross_attn", False) or ei.get("mix_attn_mats_in_batch", False):
+            raise NotImplementedError("normalize_cross_attn / mix_attn_mats_in_batch rewrite the cross-attention scores of layers 22-24 "
+                                      "(diffusers_attn_lora_capture.py:108-133; SURVEY.md 8a row L3): not built in the HIP U-Net yet")
         want = (ei.get("ffn_lora_adapter_name") if ei.get("use_ffn_lora", False) else None, bool(ei.get("use_attn_lora", False)))
         training_pass = torch.is_grad_enabled() and (x.requires_grad or prompt_emb.requires_grad or
                                                      (self.ffn_lora is not None and any(p.requires_grad for p in self.ffn_lora.parameters())))
@@ -321,12 +324,14 @@ class LatentDiffusion(nn.Module):
                        normalize_cross_attn=False, mix_sc_mc_attn=False, batch_part_has_grad="all", do_pixel_recon=False,
                        cfg_scale=-1, capture_ca_activations=False, res_hidden_states_gradscale=1, use_attn_lora=False,
                        use_ffn_lora=False, ffn_lora_adapter_name=None):
-        """q_sample -> U-Net (with or without gradient) -> optional no-grad unconditional pass and CFG combine
-        eps = eps_c * s - eps_u * (s - 1) -> optional x0 (reference ddpm.py:1597-1750; the 'subject-compos'
-        batch partition belongs to Stage-2)."""
-        if normalize_cross_attn or mix_sc_mc_attn:
-            raise NotImplementedError("normalize_cross_attn / mix_sc_mc_attn rewrite the cross-attention scores of Stage-2 batches "
-                                      "(diffusers_attn_lora_capture.py:108-133; SURVEY.md 8f rank 4): not built")
+        """q_sample -> U-Net (gradient mode 'all' / 'none' / 'subject-compos') -> optional no-grad unconditional pass and CFG combine
+        eps = eps_c * s - eps_u * (s - 1) -> optional x0 (reference ddpm.py:1597-1750).
+
+        'subject-compos' (Stage 2, :1635-1707): the batch is four one-instance blocks [SS, SC, SR (= sc_comp_rep), MC].  SS and SR run
+        without gradient (SR keeps the caller's ``normalize_cross_attn``); then either SC and MC TOGETHER as one batch of two with
+        ``mix_attn_mats_in_batch`` (their cross-attention scores are averaged; no attention LoRA; MC's eps and activations detached)
+        or SC alone with gradient and MC alone without gradient and without any LoRA.  The FFN LoRA stays on with probability 0.5."""
+        from ...util import collate_dicts, recursive_detach, split_dict
         x_noisy = self.q_sample(x_start, t, noise)
         extra_info = cond_context[2]
         extra_info["capture_ca_activations"] = capture_ca_activations
@@ -334,16 +339,50 @@ class LatentDiffusion(nn.Module):
         extra_info["img_mask"] = img_mask
         extra_info["normalize_cross_attn"] = normalize_cross_attn
         extra_info["subj_indices"] = subj_indices
+        ca_layers_activations = None
+        lora = dict(use_attn_lora=use_attn_lora, use_ffn_lora=use_ffn_lora, ffn_lora_adapter_name=ffn_lora_adapter_name)
         if batch_part_has_grad == "none":
             with torch.no_grad():
-                noise_pred = self.apply_model(x_noisy, t, cond_context, use_attn_lora=use_attn_lora, use_ffn_lora=use_ffn_lora,
-                                              ffn_lora_adapter_name=ffn_lora_adapter_name)
+                noise_pred = self.apply_model(x_noisy, t, cond_context, **lora)
+            if capture_ca_activations:
+                ca_layers_activations = extra_info["ca_layers_activations"]
         elif batch_part_has_grad == "all":
-            noise_pred = self.apply_model(x_noisy, t, cond_context, use_attn_lora=use_attn_lora, use_ffn_lora=use_ffn_lora,
-                                          ffn_lora_adapter_name=ffn_lora_adapter_name)
+            noise_pred = self.apply_model(x_noisy, t, cond_context, **lora)
+            if capture_ca_activations:
+                ca_layers_activations = extra_info["ca_layers_activations"]
+        elif batch_part_has_grad == "subject-compos":
+            use_ffn_lora = use_ffn_lora and bool(torch.rand(1) < 0.5)
+            lora["use_ffn_lora"] = use_ffn_lora
+
+            def context_with(**flags):
+                ei = copy.copy(extra_info)
+                ei.update(flags)
+                return (cond_context[0], cond_context[1], ei)
+            ctx_ss = context_with(normalize_cross_attn=False, mix_attn_mats_in_batch=False)
+            noise_pred_ss = self.sliced_apply_model(x_noisy, t, ctx_ss, slice_indices=[0], enable_grad=False, **lora)
+            ctx_sr = context_with(normalize_cross_attn=normalize_cross_attn, mix_attn_mats_in_batch=False)
+            noise_pred_sr = self.sliced_apply_model(x_noisy, t, ctx_sr, slice_indices=[2], enable_grad=False, **lora)
+            if mix_sc_mc_attn:
+                ctx_sm = context_with(normalize_cross_attn=False, mix_attn_mats_in_batch=True)
+                noise_pred_sm = self.sliced_apply_model(x_noisy, t, ctx_sm, slice_indices=[1, 3], enable_grad=True, use_attn_lora=False,
+                                                        use_ffn_lora=use_ffn_lora, ffn_lora_adapter_name=ffn_lora_adapter_name)
+                noise_pred_sc, noise_pred_mc = noise_pred_sm.chunk(2, dim=0)
+                noise_pred_mc = noise_pred_mc.detach()
+                sc_acts, mc_acts = split_dict(ctx_sm[2]["ca_layers_activations"], 2)
+                mc_acts = recursive_detach(mc_acts)
+            else:
+                ctx_sc = context_with(normalize_cross_attn=normalize_cross_attn, mix_attn_mats_in_batch=False)
+                noise_pred_sc = self.sliced_apply_model(x_noisy, t, ctx_sc, slice_indices=[1], enable_grad=True, **lora)
+                sc_acts = ctx_sc[2]["ca_layers_activations"]
+                ctx_mc = context_with(normalize_cross_attn=False)
+                noise_pred_mc = self.sliced_apply_model(x_noisy, t, ctx_mc, slice_indices=[3], enable_grad=False, use_attn_lora=False,
+                                                        use_ffn_lora=False, ffn_lora_adapter_name=ffn_lora_adapter_name)
+                mc_acts = ctx_mc[2]["ca_layers_activations"]
+            noise_pred = torch.cat([noise_pred_ss, noise_pred_sc, noise_pred_sr, noise_pred_mc], dim=0)
+            if capture_ca_activations:
+                ca_layers_activations = collate_dicts([ctx_ss[2]["ca_layers_activations"], sc_acts, ctx_sr[2]["ca_layers_activations"], mc_acts])
         else:
-            raise NotImplementedError("batch_part_has_grad='subject-compos' is the Stage-2 partition (SURVEY.md 8f rank 4)")
-        ca_layers_activations = extra_info.get("ca_layers_activations") if capture_ca_activations else None
+            raise ValueError(f"batch_part_has_grad={batch_part_has_grad!r}: 'all', 'none' or 'subject-compos'")
         if cfg_scale > 1:
             if uncond_emb is None:
                 uncond_emb = self.uncond_context[0].repeat(x_noisy.shape[0], 1, 1)
@@ -354,6 +393,30 @@ class LatentDiffusion(nn.Module):
             noise_pred = noise_pred * cfg_scale - noise_pred_uncond * (cfg_scale - 1)
         x_recon = self.predict_start_from_noise(x_noisy, t=t, noise=noise_pred) if do_pixel_recon else None
         return noise_pred, x_recon, ca_layers_activations
+
+    def sliced_apply_model(self, x_noisy, t, cond_context, slice_indices, enable_grad, use_attn_lora=False, use_ffn_lora=False,
+                           ffn_lora_adapter_name=None):
+        """apply_model on the instances ``slice_indices`` of the batch, with or without gradient (reference ddpm.py:1572-1587)."""
+        prompt_emb, prompt_in, extra_info = cond_context
+        ctx = (prompt_emb[slice_indices], [prompt_in[i] for i in slice_indices], extra_info)
+        with torch.set_grad_enabled(enable_grad):
+            return self.apply_model(x_noisy[slice_indices], t[slice_indices], ctx, use_attn_lora=use_attn_lora, use_ffn_lora=use_ffn_lora,
+                                    ffn_lora_adapter_name=ffn_lora_adapter_name)
+
+    def prepare_unet_teacher_context(self, subj_context, uncond_context, BLOCK_SIZE, id2img_prompt_embs, id2img_neg_prompt_embs,
+                                     img_prompt_prefix_embs, unet_teacher_types, encoders_num_id_vecs, p_unet_teacher_uses_cfg,
+                                     unet_distill_uses_comp_prompt):
+        """The teacher's prompt embeddings (reference ddpm.py:2885-2980) for the Arc2Face teacher, the only teacher of the Stage-1
+        yaml: ["photo of a" prefix ++ ID image-prompt embeddings] per instance, [BS, 4 + 16, 768]; when the teacher may use
+        classifier-free guidance the unconditional embedding cut to the same length is stacked below it on dim 0."""
+        if list(unet_teacher_types) != ["arc2face"] or encoders_num_id_vecs is not None:
+            raise NotImplementedError(f"unet_teacher_types={unet_teacher_types}: only the single Arc2Face teacher is built "
+                                      "(consistentID / unet_ensemble need the external ConsistentID package)")
+        teacher_context = torch.cat([img_prompt_prefix_embs.repeat(BLOCK_SIZE, 1, 1), id2img_prompt_embs], dim=1)
+        if p_unet_teacher_uses_cfg > 0:
+            neg = uncond_context[0][:, :teacher_context.shape[1]].repeat(BLOCK_SIZE, 1, 1)
+            teacher_context = torch.cat([teacher_context, neg.to(teacher_context.dtype)], dim=0)
+        return teacher_context
 
     def calc_unet_distill_loss(self, x_start, noise, subj_context, teacher_context, img_mask, fg_mask,
                                num_unet_denoising_steps, t=None, recon_bg_pixel_weight=0, presampled=None):

@@ -260,3 +260,48 @@ def calc_prompt_emb_delta_loss(prompt_embeddings, prompt_emb_mask, cls_delta_gra
     cls_delta = ortho_subtract(cc, cs)
     return calc_ref_cosine_loss(subj_delta, cls_delta, emb_mask=w, do_demeans=(False, True), first_n_dims_into_instances=2,
                                 ref_grad_scale=cls_delta_grad_scale, aim_to_align=True)
+
+
+def collate_dicts(dicts):
+    """Concatenate a list of equally structured (nested) dicts of tensors / lists along the batch (reference ldm/util.py:1112-1126)."""
+    out = {}
+    for k, v in dicts[0].items():
+        col = [d[k] for d in dicts]
+        if isinstance(v, list):
+            out[k] = sum(col, [])
+        elif torch.is_tensor(v):
+            out[k] = torch.cat(col, dim=0)
+        elif isinstance(v, dict):
+            out[k] = collate_dicts(col)
+        else:
+            raise TypeError(f"collate_dicts: {k!r} holds {type(v).__name__}")
+    return out
+
+
+def split_dict(d_all, num_splits):
+    """Reverse of collate_dicts (reference ldm/util.py:1129-1165)."""
+    result = [{} for _ in range(num_splits)]
+    for k, v in d_all.items():
+        if isinstance(v, list):
+            per = len(v) // num_splits
+            parts = [v[i * per:(i + 1) * per] for i in range(num_splits)]
+        elif torch.is_tensor(v):
+            parts = torch.split(v, v.size(0) // num_splits, dim=0)
+        elif isinstance(v, dict):
+            parts = split_dict(v, num_splits)
+        else:
+            raise TypeError(f"split_dict: {k!r} holds {type(v).__name__}")
+        for i in range(num_splits):
+            result[i][k] = parts[i]
+    return result
+
+
+def recursive_detach(obj):
+    """detach every tensor of a nested dict / list / tuple structure."""
+    if torch.is_tensor(obj):
+        return obj.detach()
+    if isinstance(obj, dict):
+        return {k: recursive_detach(v) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(recursive_detach(v) for v in obj)
+    return obj

@@ -110,3 +110,114 @@ def guided_denoise(eps_fn, tables, x_start, noise, t, cond_ctx, uncond_ctx=None,
         eps = eps * cfg_scale - (uncond_eps_fn or eps_fn)(x_noisy, t, uncond_ctx).detach() * (cfg_scale - 1)
     x_recon = predict_start_from_noise(tables, x_noisy, t, eps) if do_pixel_recon else None
     return eps, x_recon
+
+
+def _collate(dicts):
+    """ldm/util.py:1112-1126."""
+    out = {}
+    for k, v in dicts[0].items():
+        col = [d[k] for d in dicts]
+        out[k] = sum(col, []) if isinstance(v, list) else torch.cat(col, dim=0) if torch.is_tensor(v) else _collate(col)
+    return out
+
+
+def _split(d, n):
+    """ldm/util.py:1129-1165 (reverse of _collate)."""
+    res = [{} for _ in range(n)]
+    for k, v in d.items():
+        if isinstance(v, list):
+            per = len(v) // n
+            parts = [v[i * per:(i + 1) * per] for i in range(n)]
+        elif torch.is_tensor(v):
+            parts = list(torch.split(v, v.size(0) // n, dim=0))
+        else:
+            parts = _split(v, n)
+        for i in range(n):
+            res[i][k] = parts[i]
+    return res
+
+
+def _detach(o):
+    if torch.is_tensor(o):
+        return o.detach()
+    if isinstance(o, dict):
+        return {k: _detach(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return type(o)(_detach(v) for v in o)
+    return o
+
+
+def guided_denoise_full(model, tables, x_start, noise, t, cond_context, default_uncond_context, uncond_emb=None, img_mask=None,
+                        subj_indices=None, normalize_cross_attn=False, mix_sc_mc_attn=False, batch_part_has_grad="all",
+                        do_pixel_recon=False, cfg_scale=-1, capture_ca_activations=False, res_hidden_states_gradscale=1,
+                        use_attn_lora=False, use_ffn_lora=False, ffn_lora_adapter_name=None, ffn_coin=None):
+    """LatentDiffusion.guided_denoise with every gradient mode, ddpm.py:1597-1750, over the wrapper protocol
+    ``model(x, t, (prompt_emb, prompts, extra_info)) -> eps`` (which leaves ``extra_info['ca_layers_activations']``).
+    PINNED by tests/golden/guided_denoise.npz (the reference method itself, driven around a stand-in wrapper).
+
+    'subject-compos' (:1635-1707): the batch is [SS, SC, SR(=sc_comp_rep), MC] blocks of one instance each.  SS and SR run without
+    gradient (SR with the caller's normalize_cross_attn), then either SC and MC jointly as one batch with
+    ``mix_attn_mats_in_batch`` (no attention LoRA; MC's eps and activations detached) or SC alone with gradient and MC alone
+    without gradient and without any LoRA.  The FFN LoRA is kept on only when a coin ``torch.rand(1) < 0.5`` says so (:1638;
+    ``ffn_coin`` overrides the draw)."""
+    import copy
+
+    def apply(x, tt, ctx, attn_lora, ffn_lora, name):
+        ctx[2]["use_attn_lora"], ctx[2]["use_ffn_lora"], ctx[2]["ffn_lora_adapter_name"] = attn_lora, ffn_lora, name
+        return model(x, tt, ctx)
+
+    def sliced(x, tt, ctx, idx, grad, attn_lora, ffn_lora, name):
+        emb, prompts, extra = ctx
+        with torch.set_grad_enabled(grad):
+            return apply(x[idx], tt[idx], (emb[idx], [prompts[i] for i in idx], extra), attn_lora, ffn_lora, name)
+
+    x_noisy = q_sample(tables, x_start, t, noise)
+    extra = cond_context[2]
+    extra.update(capture_ca_activations=capture_ca_activations, res_hidden_states_gradscale=res_hidden_states_gradscale,
+                 img_mask=img_mask, normalize_cross_attn=normalize_cross_attn, subj_indices=subj_indices)
+    acts = None
+    if batch_part_has_grad in ("none", "all"):
+        with torch.set_grad_enabled(batch_part_has_grad == "all" and torch.is_grad_enabled()):
+            eps = apply(x_noisy, t, cond_context, use_attn_lora, use_ffn_lora, ffn_lora_adapter_name)
+        if capture_ca_activations:
+            acts = extra["ca_layers_activations"]
+    elif batch_part_has_grad == "subject-compos":
+        coin = bool(torch.rand(1) < 0.5) if ffn_coin is None else ffn_coin
+        use_ffn_lora = use_ffn_lora and coin
+
+        def ctx_with(**kw):
+            e = copy.copy(extra)
+            e.update(kw)
+            return (cond_context[0], cond_context[1], e)
+        c_ss = ctx_with(normalize_cross_attn=False, mix_attn_mats_in_batch=False)
+        e_ss = sliced(x_noisy, t, c_ss, [0], False, use_attn_lora, use_ffn_lora, ffn_lora_adapter_name)
+        c_sr = ctx_with(normalize_cross_attn=normalize_cross_attn, mix_attn_mats_in_batch=False)
+        e_sr = sliced(x_noisy, t, c_sr, [2], False, use_attn_lora, use_ffn_lora, ffn_lora_adapter_name)
+        if mix_sc_mc_attn:
+            c_sm = ctx_with(normalize_cross_attn=False, mix_attn_mats_in_batch=True)
+            e_sm = sliced(x_noisy, t, c_sm, [1, 3], True, False, use_ffn_lora, ffn_lora_adapter_name)
+            e_sc, e_mc = e_sm.chunk(2, dim=0)
+            e_mc = e_mc.detach()
+            a_sc, a_mc = _split(c_sm[2]["ca_layers_activations"], 2)
+            a_mc = _detach(a_mc)
+        else:
+            c_sc = ctx_with(normalize_cross_attn=normalize_cross_attn, mix_attn_mats_in_batch=False)
+            e_sc = sliced(x_noisy, t, c_sc, [1], True, use_attn_lora, use_ffn_lora, ffn_lora_adapter_name)
+            a_sc = c_sc[2]["ca_layers_activations"]
+            c_mc = ctx_with(normalize_cross_attn=False)
+            e_mc = sliced(x_noisy, t, c_mc, [3], False, False, False, ffn_lora_adapter_name)
+            a_mc = c_mc[2]["ca_layers_activations"]
+        eps = torch.cat([e_ss, e_sc, e_sr, e_mc], dim=0)
+        if capture_ca_activations:
+            acts = _collate([c_ss[2]["ca_layers_activations"], a_sc, c_sr[2]["ca_layers_activations"], a_mc])
+    else:
+        raise ValueError(batch_part_has_grad)
+    if cfg_scale > 1:
+        if uncond_emb is None:
+            uncond_emb = default_uncond_context[0].repeat(x_noisy.shape[0], 1, 1)
+        un = (uncond_emb, default_uncond_context[1] * x_noisy.shape[0], copy.copy(default_uncond_context[2]))
+        with torch.no_grad():
+            e_un = apply(x_noisy, t, un, False, use_ffn_lora, ffn_lora_adapter_name)
+        eps = eps * cfg_scale - e_un * (cfg_scale - 1)
+    x_recon = predict_start_from_noise(tables, x_noisy, t, eps) if do_pixel_recon else None
+    return eps, x_recon, acts

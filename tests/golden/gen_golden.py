@@ -543,6 +543,246 @@ def gen_vae(out):
     np.savez_compressed(os.path.join(out, "vae.npz"), **d)
 
 
+
+# ----------------------------------------------------------------------------- host orchestration, driven through the REAL reference
+def _ref_ddpm_shell(**attrs):
+    """A reference ``LatentDiffusion`` object WITHOUT running its constructor (which needs Lightning, diffusers pipelines and model
+    files): nn.Module state + the real ``register_schedule`` tables (SD-1.5 linear schedule, v1-finetune yaml) + whatever attributes
+    the driven method reads.  Every method executed on it is the reference's own code."""
+    import ldm.models.diffusion.ddpm as ref_ddpm
+    obj = ref_ddpm.LatentDiffusion.__new__(ref_ddpm.LatentDiffusion)
+    torch.nn.Module.__init__(obj)
+    obj.parameterization, obj.v_posterior = "eps", 0.0
+    obj.register_schedule(beta_schedule="linear", timesteps=1000, linear_start=0.00085, linear_end=0.012)
+    for k, v in attrs.items():
+        setattr(obj, k, v)
+    return obj
+
+
+class _AsDiffusersUNet(torch.nn.Module):
+    """Call protocol of the teacher's U-Net (unet_teachers.py:137-138): unet(sample=, timestep=, encoder_hidden_states=, return_dict=False)[0]."""
+
+    def __init__(self, eps_model):
+        super().__init__()
+        self.eps_model = eps_model
+
+    def forward(self, sample, timestep, encoder_hidden_states, return_dict=False):
+        return (self.eps_model(sample, timestep, encoder_hidden_states),)
+
+
+TEACHER_CASES = (
+    dict(name="nocfg_1step_doubled_ctx", steps=1, force=False, p=0.0, ctx="doubled", neg=False, same=False),
+    dict(name="nocfg_4step", steps=4, force=False, p=0.0, ctx="pos", neg=False, same=False),
+    dict(name="cfg_3step_doubled_ctx", steps=3, force=True, p=0.0, ctx="doubled", neg=False, same=False),
+    dict(name="cfg_3step_separate_neg", steps=3, force=True, p=0.0, ctx="pos", neg=True, same=False),
+    dict(name="cfg_4step_same_t_noise", steps=4, force=True, p=0.0, ctx="doubled", neg=False, same=True),
+    dict(name="pcfg_2step_coin", steps=2, force=False, p=0.6, ctx="doubled", neg=False, same=False),
+)
+
+
+def gen_teacher(out):
+    """REFERENCE ``UNetTeacher.forward`` (adaface/unet_teachers.py:64-187) around the stand-in eps-model (tests/standin.py), with the
+    reference's own ``q_sample`` / ``predict_start_from_noise``: with and without classifier-free guidance (doubled context, separate
+    negative context, the p_uses_cfg coin), same_t_noise_across_instances, 1 - 4 denoising steps, seeded torch / numpy RNG.  Stored:
+    every eps, x0, noise and timestep, the drawn cfg scale, and the RNG draws (relative_ts) recovered by replaying the seed."""
+    import contextlib
+    import io
+    import adaface.unet_teachers as ref_teachers
+    from adaface_dev_amd import rng
+    from standin import StandInEps
+    B, h, T, D = 3, 8, 6, 16
+    eps_model = StandInEps(D, seed=61)
+    ddpm = _ref_ddpm_shell()
+    res = {}
+    for c in TEACHER_CASES:
+        x0 = rng.synth_input("teacher.x0", (B, 4, h, h), seed=62)
+        noise = rng.synth_input("teacher.noise", (B, 4, h, h), seed=62)
+        pos = rng.synth_input("teacher.pos", (B, T, D), seed=62)
+        neg = rng.synth_input("teacher.neg", (B, T, D), seed=62)
+        t = torch.tensor([880, 745, 801])
+        with contextlib.redirect_stdout(io.StringIO()):
+            teacher = ref_teachers.UNetTeacher(p_uses_cfg=c["p"], cfg_scale_range=[1.3, 2])
+        teacher.name, teacher.unet = "standin", _AsDiffusersUNet(eps_model)
+        ctx = torch.cat([pos, neg]) if c["ctx"] == "doubled" else pos
+        torch.manual_seed(1234)
+        np.random.seed(77)
+        with contextlib.redirect_stdout(io.StringIO()):
+            preds, xs, ns, ts = teacher(ddpm, x0, noise, t, ctx, negative_context=neg if c["neg"] else None, num_denoising_steps=c["steps"],
+                                        force_uses_cfg=c["force"], same_t_noise_across_instances=c["same"])
+        k = c["name"]
+        res[f"{k}.uses_cfg"] = np.asarray(bool(teacher.uses_cfg))
+        res[f"{k}.cfg_scale"] = np.asarray(float(teacher.cfg_scale))
+        for i in range(c["steps"]):
+            res[f"{k}.eps{i}"] = preds[i].numpy()
+            res[f"{k}.x{i + 1}"] = xs[i + 1].numpy()
+            res[f"{k}.t{i}"] = ts[i].numpy()
+            res[f"{k}.noise{i}"] = ns[i].numpy()
+        # the draws the reference made from the global torch RNG, in its order: rand_like(t.float()) then randn_like(pred_x0) per extra step
+        torch.manual_seed(1234)
+        for i in range(c["steps"] - 1):
+            res[f"{k}.rel{i}"] = torch.rand(B).numpy()
+            res[f"{k}.drawn_noise{i}"] = torch.randn(B, 4, h, h).numpy()
+    np.savez_compressed(os.path.join(out, "teacher.npz"), **res)
+    print("teacher:", {c["name"]: (bool(res[c["name"] + ".uses_cfg"]), round(float(res[c["name"] + ".cfg_scale"]), 4)) for c in TEACHER_CASES})
+
+
+def gen_sdpa(out):
+    """REFERENCE ``scaled_dot_product_attention`` and ``ScaleGrad`` (adaface/diffusers_attn_lora_capture.py:23-42, 79-139): plain,
+    boolean / additive mask, ``mix_attn_mats_in_batch`` (SC scores averaged with detached MC scores), ``normalize_cross_attn``
+    (subject-token scores centred over the pixels and scaled by the learnable factor through the x10 gradient scaler); outputs, scores,
+    probabilities and the gradients of sum(out * g) w.r.t. q, k, v and the scale factor."""
+    import adaface.diffusers_attn_lora_capture as ref_cap
+    from adaface_dev_amd import rng
+    B, H, L, S, d = 4, 2, 12, 7, 8
+    res = {}
+
+    def run(tag, **kw):
+        q = rng.synth_input("sdpa.q", (B, H, L, d), seed=63).requires_grad_(True)
+        k = rng.synth_input("sdpa.k", (B, H, S, d), seed=63).requires_grad_(True)
+        v = rng.synth_input("sdpa.v", (B, H, S, d), seed=63).requires_grad_(True)
+        sf = torch.tensor(0.8, requires_grad=True)
+        g = rng.synth_input("sdpa.g", (B, H, L, d), seed=63)
+        o, score, w = ref_cap.scaled_dot_product_attention(q, k, v, sf, **kw)
+        (o * g).sum().backward()
+        res[f"{tag}.out"], res[f"{tag}.score"], res[f"{tag}.prob"] = o.detach().numpy(), score.detach().numpy(), w.detach().numpy()
+        res[f"{tag}.dq"], res[f"{tag}.dk"], res[f"{tag}.dv"] = q.grad.numpy(), k.grad.numpy(), v.grad.numpy()
+        res[f"{tag}.dscale"] = np.asarray(0.0 if sf.grad is None else float(sf.grad))
+
+    run("plain")
+    keep = rng.synth_input("sdpa.mask", (B, 1, L, S), seed=63) > -0.6
+    keep[..., 0] = True
+    run("boolmask", attn_mask=keep)
+    run("addmask", attn_mask=rng.synth_input("sdpa.bias", (B, 1, L, S), seed=63))
+    run("mix", mix_attn_mats_in_batch=True)
+    subj_b = torch.tensor([0, 0, 0, 1, 1, 1, 3, 3, 3])
+    subj_n = torch.tensor([2, 3, 4, 2, 3, 4, 1, 2, 3])
+    run("normalize", subj_indices=(subj_b, subj_n), normalize_cross_attn=True)
+    run("scale", scale=0.2)
+    res["normalize.subj_b"], res["normalize.subj_n"] = subj_b.numpy(), subj_n.numpy()
+
+    # ScaleGrad / gen_gradient_scaler: identity forward, gradient x alpha (alpha 0 -> detach, alpha 1 -> Identity)
+    x = rng.synth_input("sg.x", (5, 3), seed=63).requires_grad_(True)
+    y = ref_cap.ScaleGrad.apply(x, torch.tensor(0.5), torch.tensor(False))
+    (y * y).sum().backward()
+    res["scalegrad.y"], res["scalegrad.dx"] = y.detach().numpy(), x.grad.numpy()
+    for alpha in (10, 1, 0):
+        x = rng.synth_input("sg.x", (5, 3), seed=63).requires_grad_(True)
+        y = ref_cap.gen_gradient_scaler(alpha)(x)
+        z = (y * y).sum() + x.sum()
+        z.backward()
+        res[f"gradscaler{alpha}.dx"] = x.grad.numpy()
+    np.savez_compressed(os.path.join(out, "sdpa.npz"), **res)
+    print("sdpa:", sorted(k for k in res if k.endswith(".dscale")), float(res["normalize.dscale"]))
+
+
+GUIDED_CASES = (
+    dict(name="all_cfg3_recon", mode="all", cfg=3.0, recon=True, capture=False, uncond="given"),
+    dict(name="none_cfg1", mode="none", cfg=-1, recon=False, capture=True, uncond=None),
+    dict(name="all_cfg2_default_uncond_mask", mode="all", cfg=2.0, recon=True, capture=True, uncond=None, mask=True, gradscale=0.5),
+    dict(name="compos_mix", mode="subject-compos", cfg=-1, recon=True, capture=True, uncond=None, mix=True, norm=True, attn_lora=True, ffn=True),
+    dict(name="compos_nomix", mode="subject-compos", cfg=-1, recon=False, capture=True, uncond=None, mix=False, norm=True, attn_lora=True, ffn=True),
+)
+
+
+def gen_guided_denoise(out):
+    """REFERENCE ``LatentDiffusion.guided_denoise`` / ``apply_model`` / ``sliced_apply_model`` (ddpm.py:1560-1750) on a constructor-free
+    shell, with the stand-in wrapper as ``self.model``: gradient modes all / none / subject-compos (the four single-instance passes or
+    the joint SC+MC pass with mixed attention), classifier-free guidance with a given or the default unconditional context, x0
+    reconstruction, activation capture and collation; eps, x_recon, captured activations, d(sum eps)/d(prompt_emb), and the per-call
+    (batch size, flags) log of the wrapper."""
+    import json
+    from adaface_dev_amd import rng
+    from standin import StandInEps, StandInWrapper
+    B, h, T, D = 4, 8, 6, 16
+    res = {}
+    for c in GUIDED_CASES:
+        wrapper = StandInWrapper(StandInEps(D, seed=61))
+        un = rng.synth_input("gd.uncond_default", (1, T, D), seed=64)
+        ld = _ref_ddpm_shell(model=wrapper, uncond_context=(un, [""], {}))
+        x0 = rng.synth_input("gd.x0", (B, 4, h, h), seed=64)
+        noise = rng.synth_input("gd.noise", (B, 4, h, h), seed=64)
+        emb = rng.synth_input("gd.emb", (B, T, D), seed=64).requires_grad_(True)
+        t = torch.tensor([500, 20, 981, 333])
+        mask = (rng.synth_input("gd.mask", (B, 1, h, h), seed=64) > 0).float() if c.get("mask") else None
+        uncond = rng.synth_input("gd.uncond", (B, T, D), seed=64) if c["uncond"] == "given" else None
+        cond = (emb, [f"p{i}" for i in range(B)], {})
+        torch.manual_seed(4321)            # subject-compos draws torch.rand(1) < 0.5 for the FFN LoRA
+        eps, recon, acts = ld.guided_denoise(x0, noise, t, cond, uncond_emb=uncond, img_mask=mask, subj_indices=None,
+                                             normalize_cross_attn=c.get("norm", False), mix_sc_mc_attn=c.get("mix", False),
+                                             batch_part_has_grad=c["mode"], do_pixel_recon=c["recon"], cfg_scale=c["cfg"],
+                                             capture_ca_activations=c["capture"], res_hidden_states_gradscale=c.get("gradscale", 1),
+                                             use_attn_lora=c.get("attn_lora", False), use_ffn_lora=c.get("ffn", False),
+                                             ffn_lora_adapter_name="comp_distill" if c.get("ffn") else None)
+        k = c["name"]
+        res[f"{k}.eps"] = eps.detach().numpy()
+        res[f"{k}.requires_grad"] = np.asarray(bool(eps.requires_grad))
+        if eps.requires_grad:
+            eps.sum().backward()
+            res[f"{k}.demb"] = emb.grad.numpy()
+        if recon is not None:
+            res[f"{k}.recon"] = recon.detach().numpy()
+        if acts is not None:
+            res[f"{k}.act_attn"] = acts["attn"].detach().numpy()
+            res[f"{k}.act_attn_requires_grad"] = np.asarray(bool(acts["attn"].requires_grad))
+            for li, v in acts["outfeat"].items():
+                res[f"{k}.act_outfeat{li}"] = v.detach().numpy()
+            res[f"{k}.act_names"] = np.asarray(json.dumps(acts["names"]))
+        res[f"{k}.calls"] = np.asarray(json.dumps([[n, fl, ad, npr, ge] for n, fl, ad, npr, ge in wrapper.calls]))
+    np.savez_compressed(os.path.join(out, "guided_denoise.npz"), **res)
+    print("guided_denoise:", {c["name"]: res[c["name"] + ".eps"].shape for c in GUIDED_CASES})
+
+
+def gen_distill_loss(out):
+    """REFERENCE ``LatentDiffusion.calc_unet_distill_loss`` (ddpm.py:2984-3184; the on-image branch Stage 1 runs) with the REFERENCE
+    ``prepare_unet_teacher_context`` (:2885-2980), ``UNetTeacher.forward``, ``guided_denoise`` and ``calc_recon_loss``, stand-in eps-models
+    for teacher and student, logging / VAE decode no-ops: the loss, d loss / d prompt_emb, the timesteps drawn inside, for 1 and 3
+    denoising steps, without and with teacher CFG (p_unet_teacher_uses_cfg 1: doubled [positive; negative] teacher context and the
+    student's guided_denoise at the teacher's cfg scale)."""
+    import contextlib
+    import io
+    import adaface.unet_teachers as ref_teachers
+    from adaface_dev_amd import rng
+    from standin import StandInEps, StandInWrapper
+    B, h, T, D = 2, 8, 24, 16
+    res = {}
+    for steps, pcfg in ((1, 0.0), (3, 0.0), (2, 1.0)):
+        student = StandInWrapper(StandInEps(D, seed=61))
+        with contextlib.redirect_stdout(io.StringIO()):
+            teacher = ref_teachers.UNetTeacher(p_uses_cfg=pcfg, cfg_scale_range=[1.3, 2])
+        teacher.name, teacher.unet = "arc2face", _AsDiffusersUNet(StandInEps(D, seed=65))
+        un = rng.synth_input("dl.uncond", (1, T, D), seed=66)
+        id2img = rng.synth_input("dl.id2img", (B, 16, D), seed=66)
+        flags = {"id2img_prompt_embs": id2img, "id2img_neg_prompt_embs": None, "encoders_num_id_vecs": None, "unet_distill_uses_comp_prompt": False}
+        ld = _ref_ddpm_shell(model=student, uncond_context=(un, [""], {}), unet_teacher=teacher, iter_flags=flags,
+                             img_prompt_prefix_embs=rng.synth_input("dl.prefix", (1, 4, D), seed=66), unet_teacher_types=["arc2face"],
+                             p_unet_teacher_uses_cfg=pcfg, res_hidden_states_gradscale=0.5, unet_distill_on_noise_iters_count=0,
+                             trainer=types.SimpleNamespace(global_rank=0))
+        ld.decode_first_stage = lambda z: torch.zeros(z.shape[0], 3, 8, 8)
+        ld.cache_and_log_generations = lambda *a, **k: None
+        x0 = rng.synth_input("dl.x0", (B, 4, h, h), seed=66)
+        noise = rng.synth_input("dl.noise", (B, 4, h, h), seed=66)
+        emb = rng.synth_input("dl.emb", (B, T, D), seed=66).requires_grad_(True)
+        fg = (rng.synth_input("dl.fg", (B, 1, h, h), seed=66) > -0.3).float()
+        mon = {}
+        torch.manual_seed(2468)
+        np.random.seed(99)
+        with contextlib.redirect_stdout(io.StringIO()):
+            loss = ld.calc_unet_distill_loss(mon, "train", x0, noise, (emb, ["p"] * B, {}), None, fg, steps, False)
+        loss.backward()
+        k = f"steps{steps}_pcfg{int(pcfg)}"
+        res[f"{k}.loss"], res[f"{k}.demb"] = loss.detach().numpy(), emb.grad.numpy()
+        res[f"{k}.cfg_scale"] = np.asarray(float(teacher.cfg_scale))
+        res[f"{k}.mon"] = np.asarray(float(mon["train/unet_distill_on_image"]))
+        # replay of the global torch RNG in the reference's order: t ~ randint(700, 900), then per extra teacher step rand(B), randn
+        torch.manual_seed(2468)
+        res[f"{k}.t"] = torch.randint(700, 900, (B,)).numpy()
+        for i in range(steps - 1):
+            res[f"{k}.rel{i}"] = torch.rand(B).numpy()
+            res[f"{k}.drawn_noise{i}"] = torch.randn(B, 4, h, h).numpy()
+    np.savez_compressed(os.path.join(out, "distill_loss.npz"), **res)
+    print("distill_loss:", {k: float(v) for k, v in res.items() if k.endswith(".loss")})
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-full", action="store_true")
@@ -551,6 +791,19 @@ def main():
     install_reference_stubs()
     torch.set_num_threads(8)
     out = HERE
+    # host-orchestration fixtures: the reference's ddpm.py / unet_teachers.py / diffusers_attn_lora_capture.py are imported with
+    # EMPTY stand-ins for their absent third-party packages (tests/golden/ref_import.py)
+    host_jobs = {"teacher": gen_teacher, "sdpa": gen_sdpa, "guided_denoise": gen_guided_denoise, "distill_loss": gen_distill_loss}
+    if args.only in host_jobs or args.only is None:
+        sys.path.insert(0, HERE)
+        sys.path.insert(0, os.path.dirname(HERE))
+        import ref_import
+        ref_import.install(REF)
+        for name, fn in host_jobs.items():
+            if args.only in (None, name):
+                fn(out)
+        if args.only is not None:
+            return
     jobs = {"embedding_manager": gen_embedding_manager, "blocks": gen_blocks, "schedule": gen_schedule, "train": gen_train, "clip": gen_clip, "arcface": gen_arcface, "vae": gen_vae, "unet_tiny": gen_unet_tiny, "unet_full": gen_unet_full}
     for name, fn in jobs.items():
         if args.only and name != args.only:

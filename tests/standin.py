@@ -1,0 +1,62 @@
+"""Stand-in eps-model shared by tests/golden/gen_golden.py (where it drives the REFERENCE's host code: ``UNetTeacher.forward``,
+``LatentDiffusion.guided_denoise``, ``calc_unet_distill_loss``) and by the tests (where the same function drives the oracle and
+the mirrors).  It is a fixed cheap nonlinear map of (x, t, context) whose output also encodes the per-call flags the reference
+routes through ``extra_info``, so a fixture generated through it pins the ORCHESTRATION (which instances / contexts / flags /
+timesteps each U-Net call gets, how results are combined), not U-Net arithmetic.  Weights come from adaface_dev_amd.rng, so both
+sides rebuild it from the seed."""
+import torch
+import torch.nn.functional as F
+
+
+class StandInEps(torch.nn.Module):
+    def __init__(self, ctx_dim=16, seed=61):
+        super().__init__()
+        from adaface_dev_amd import rng
+        self.register_buffer("w", rng.synth_input("standin.w", (4, 4, 3, 3), seed=seed) * 0.3)
+        self.register_buffer("p", rng.synth_input("standin.p", (ctx_dim, 4), seed=seed) * 0.5)
+
+    def forward(self, x, t, ctx):
+        """x [B,4,h,w], t [B] int, ctx [B,T,D] -> eps [B,4,h,w] (differentiable in x and ctx)."""
+        w, p = self.w.to(x.dtype), self.p.to(x.dtype)
+        h = F.conv2d(x, w, padding=1) + (ctx.to(x.dtype).mean(dim=1) @ p)[:, :, None, None]
+        h = h + torch.sin(t.to(x.dtype) * 0.01)[:, None, None, None]
+        return torch.tanh(h) * 0.8 + 0.1 * x
+
+
+FLAG_WEIGHTS = (("normalize_cross_attn", 0.05), ("mix_attn_mats_in_batch", 0.1), ("use_attn_lora", 0.2), ("use_ffn_lora", 0.4))
+
+
+class StandInWrapper(torch.nn.Module):
+    """Plays ``LatentDiffusion.model`` (the U-Net wrapper, reference ddpm.py:4187-4252): ``model(x, t, cond_context)``.
+    The flags found in ``extra_info`` shift eps by fixed amounts, ``img_mask`` scales it, and with ``capture_ca_activations`` a small
+    activation dict (one tensor, one nested dict, one list entry per instance) is left in ``extra_info['ca_layers_activations']`` like
+    the reference wrapper does (:4233-4239).  ``calls`` records (batch size, flags) per call."""
+
+    def __init__(self, eps_model):
+        super().__init__()
+        self.eps_model = eps_model
+        self.calls = []
+
+    def forward(self, x, t, cond_context, out_dtype=torch.float32):
+        ctx, prompts, extra = cond_context
+        eps = self.eps_model(x, t, ctx)
+        code = 0.0
+        for name, wgt in FLAG_WEIGHTS:
+            if bool(extra.get(name, False)):
+                code += wgt
+        if extra.get("ffn_lora_adapter_name") == "unet_distill":
+            code += 0.8
+        eps = eps + code
+        if extra.get("img_mask") is not None:
+            eps = eps * (0.5 + 0.5 * extra["img_mask"].to(eps.dtype))
+        gs = extra.get("res_hidden_states_gradscale", 1)
+        if gs != 1:
+            eps = eps * 1.0 + 0.001 * gs
+        self.calls.append((x.shape[0], {k: (bool(extra.get(k, False))) for k, _ in FLAG_WEIGHTS}, extra.get("ffn_lora_adapter_name"),
+                           len(prompts), torch.is_grad_enabled()))
+        if extra.get("capture_ca_activations", False):
+            extra["ca_layers_activations"] = {"outfeat": {23: eps * 2.0, 24: eps[:, :2] + 1.0}, "attn": eps.mean(dim=(2, 3)),
+                                              "names": [f"inst{i}" for i in range(x.shape[0])]}
+        else:
+            extra["ca_layers_activations"] = {"outfeat": {}, "attn": eps.new_zeros(x.shape[0], 0), "names": []}
+        return eps.to(out_dtype)

@@ -1,0 +1,121 @@
+"""The HOST-side mirrors of the reference's orchestration (``adaface/unet_teachers.py::UNetTeacher.forward``,
+``LatentDiffusion.guided_denoise`` / ``sliced_apply_model`` / ``prepare_unet_teacher_context`` / ``calc_unet_distill_loss``) against
+fixtures written by the REFERENCE methods themselves (tests/golden/gen_golden.py imports them from /root/reference), around the same
+stand-in eps-model (tests/standin.py) placed where the reference puts its U-Net.  ``-m gpu``: the mirrors run q_sample through the HIP
+extension and have no CPU path; the stand-in is plain torch on the GPU.  fp32 throughout => tight bounds."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, rel_l2
+from standin import StandInEps, StandInWrapper
+from test_host_orchestration import GUIDED_CASES, TEACHER_CASES, check_guided, distill_inputs, guided_inputs, teacher_inputs
+
+pytestmark = pytest.mark.gpu
+TOL = 5e-6
+CFG = dict(in_channels=4, model_channels=32, out_channels=4, num_res_blocks=2, attention_resolutions=[4, 2, 1], channel_mult=[1, 2, 4, 4],
+           num_heads=8, use_spatial_transformer=True, transformer_depth=1, context_dim=16, legacy=False)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from adaface_dev_amd import _lib
+    _lib.lib()
+    return torch.device("cuda:0")
+
+
+class _AsUNet(torch.nn.Module):
+    """The teacher mirror calls its U-Net as unet(x, t, context, extra_info=None)."""
+
+    def __init__(self, eps_model):
+        super().__init__()
+        self.eps_model = eps_model
+
+    def forward(self, x, t, ctx, extra_info=None):
+        return self.eps_model(x, t, ctx)
+
+
+def _ld(dev, wrapper=None):
+    from adaface_dev_amd.ldm.models.diffusion.ddpm import LatentDiffusion
+    ld = LatentDiffusion(CFG).to(dev)
+    if wrapper is not None:
+        ld.model = wrapper.to(dev)
+    return ld
+
+
+@pytest.mark.parametrize("case", TEACHER_CASES, ids=[c["name"] for c in TEACHER_CASES])
+def test_unet_teacher_mirror_vs_reference(dev, case):
+    from adaface_dev_amd.adaface.unet_teachers import UNetTeacher
+    g, k = np.load(os.path.join(GOLDEN, "teacher.npz")), case["name"]
+    inp = {n: v.to(dev) for n, v in teacher_inputs().items()}
+    teacher = UNetTeacher(_AsUNet(StandInEps(16, seed=61)).to(dev), cfg_scale_range=[1.3, 2], p_uses_cfg=case["p"])
+    ctx = torch.cat([inp["pos"], inp["neg"]]) if case["ctx"] == "doubled" else inp["pos"]
+    pres = [(torch.from_numpy(g[f"{k}.rel{i}"]).to(dev), torch.from_numpy(g[f"{k}.drawn_noise{i}"]).to(dev)) for i in range(case["steps"] - 1)]
+    np.random.seed(77)                                       # the reference's numpy draws: the p_uses_cfg coin, then the cfg scale
+    preds, xs, ns, ts = teacher(_ld(dev), inp["x0"], inp["noise"], inp["t"], ctx, negative_context=inp["neg"] if case["neg"] else None,
+                                num_denoising_steps=case["steps"], force_uses_cfg=case["force"],
+                                same_t_noise_across_instances=case["same"], presampled=pres)
+    assert bool(teacher.uses_cfg) == bool(g[f"{k}.uses_cfg"]) and abs(float(teacher.cfg_scale) - float(g[f"{k}.cfg_scale"])) < 1e-12
+    for i in range(case["steps"]):
+        assert np.array_equal(ts[i].cpu().numpy(), g[f"{k}.t{i}"]), (k, i)
+        assert rel_l2(ns[i].cpu().numpy(), g[f"{k}.noise{i}"]) < 1e-7
+        assert rel_l2(preds[i].cpu().numpy(), g[f"{k}.eps{i}"]) < TOL, (k, i)
+        assert rel_l2(xs[i + 1].cpu().numpy(), g[f"{k}.x{i + 1}"]) < 2e-5, (k, i)
+
+
+def test_unet_teacher_mirror_draws_like_the_reference(dev):
+    """Without presampled draws the mirror consumes the global torch RNG in the reference's order (rand_like(t) then randn_like(x0) per
+    extra step): on the CPU generator the fixture's timesteps are reproduced exactly when the tensors live on the CPU side of the draw."""
+    from adaface_dev_amd.adaface.unet_teachers import UNetTeacher
+    g, k = np.load(os.path.join(GOLDEN, "teacher.npz")), "nocfg_4step"
+    torch.manual_seed(1234)
+    draws = [(torch.rand(3), torch.randn(3, 4, 8, 8)) for _ in range(3)]
+    for i, (r, n) in enumerate(draws):
+        assert np.array_equal(r.numpy(), g[f"{k}.rel{i}"]) and np.array_equal(n.numpy(), g[f"{k}.drawn_noise{i}"])
+
+
+@pytest.mark.parametrize("case", GUIDED_CASES, ids=[c["name"] for c in GUIDED_CASES])
+def test_guided_denoise_mirror_vs_reference(dev, case):
+    g, c = np.load(os.path.join(GOLDEN, "guided_denoise.npz")), case
+    i = guided_inputs(c, dev)
+    wrapper = StandInWrapper(StandInEps(16, seed=61))
+    ld = _ld(dev, wrapper)
+    ld.uncond_context = (i["un"], [""], {})
+    cond = (i["emb"], [f"p{j}" for j in range(i["B"])], {})
+    torch.manual_seed(4321)                                  # the FFN-LoRA coin of subject-compos: torch.rand(1) on the CPU generator
+    eps, recon, acts = ld.guided_denoise(i["x0"], i["noise"], i["t"], cond, uncond_emb=i["uncond"], img_mask=i["mask"],
+                                         normalize_cross_attn=c.get("norm", False), mix_sc_mc_attn=c.get("mix", False),
+                                         batch_part_has_grad=c["mode"], do_pixel_recon=c["recon"], cfg_scale=c["cfg"],
+                                         capture_ca_activations=c["capture"], res_hidden_states_gradscale=c.get("gradscale", 1),
+                                         use_attn_lora=c.get("attn_lora", False), use_ffn_lora=c.get("ffn", False),
+                                         ffn_lora_adapter_name="comp_distill" if c.get("ffn") else None)
+    check_guided(c, g, eps, recon, acts, i["emb"], wrapper.calls, tol=TOL)
+
+
+@pytest.mark.parametrize("steps,pcfg", [(1, 0), (3, 0), (2, 1)])
+def test_calc_unet_distill_loss_mirror_vs_reference(dev, steps, pcfg):
+    """prepare_unet_teacher_context + UNetTeacher + guided_denoise per step + fg-masked MSE / sqrt(steps), exactly the reference's
+    on-image branch (ddpm.py:2984-3184): loss and d loss / d prompt_emb, per-step (the reference's loop) and batched student passes."""
+    from adaface_dev_amd.adaface.unet_teachers import UNetTeacher
+    g, k = np.load(os.path.join(GOLDEN, "distill_loss.npz")), f"steps{steps}_pcfg{pcfg}"
+    for batched in (False, True):
+        i = distill_inputs(dev)
+        student = StandInWrapper(StandInEps(16, seed=61))
+        student.ffn_lora = object()                          # "adapters exist": the mirror turns use_ffn_lora on like the reference always does
+        ld = _ld(dev, student)
+        ld.batch_student_steps = batched
+        ld.uncond_context = (i["un"], [""], {})
+        ld.unet_teacher = UNetTeacher(_AsUNet(StandInEps(16, seed=65)).to(dev), cfg_scale_range=[1.3, 2], p_uses_cfg=float(pcfg), name="arc2face")
+        tctx = ld.prepare_unet_teacher_context(None, ld.uncond_context, i["B"], i["id2img"], None, i["prefix"], ["arc2face"], None, float(pcfg), False)
+        pres = [(torch.from_numpy(g[f"{k}.rel{j}"]).to(dev), torch.from_numpy(g[f"{k}.drawn_noise{j}"]).to(dev)) for j in range(steps - 1)]
+        np.random.seed(99)
+        loss = ld.calc_unet_distill_loss(i["x0"], i["noise"], (i["emb"], ["p"] * i["B"], {}), tctx, None, i["fg"], steps,
+                                         t=torch.from_numpy(g[f"{k}.t"]).to(dev), presampled=pres)
+        loss.backward()
+        assert abs(float(ld.unet_teacher.cfg_scale) - float(g[f"{k}.cfg_scale"])) < 1e-12
+        assert abs(float(loss.detach()) - float(g[f"{k}.loss"])) < 1e-5 * abs(float(g[f"{k}.loss"])), (batched, float(loss.detach()), float(g[f"{k}.loss"]))
+        assert rel_l2(i["emb"].grad.cpu().numpy(), g[f"{k}.demb"]) < 2e-5, batched
