@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(CSRC, "libadaface_hip.so")
 AF_OK, AF_E_BADARG, AF_E_UNSUPPORTED, AF_E_HIP = 0, -1, -2, -3
 AF_ACT_NONE, AF_ACT_SILU, AF_ACT_GEGLU, AF_ACT_QUICKGELU = 0, 1, 2, 3
 AF_OUT_NORMAL, AF_OUT_SPLIT_T = 0, 1
+AF_SPLITK_COUNTER_BYTES = 4096 * 4
 AF_FAM_GEMM, AF_FAM_ATTN, AF_FAM_GNORM, AF_FAM_LNORM, AF_FAM_ELEM, AF_FAM_XATTN = 0, 1, 2, 3, 4, 5
 
 # every symbol include/adaface_hip.h declares (tests check the .so exports exactly these)
@@ -39,7 +40,7 @@ class GemmDesc(C.Structure):
         ("act", C.c_int32), ("out_mode", C.c_int32), ("ld_out", C.c_int32), ("split_col", C.c_int32),
         ("ld_out2", C.c_int32), ("tile", C.c_int32), ("splits", C.c_int32),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64), ("zeros", C.c_void_p),
-        ("tap_shift", C.c_int32), ("reserved0", C.c_int32),
+        ("tap_shift", C.c_int32), ("splitk_fused", C.c_int32),
     ]
 
 

@@ -489,8 +489,8 @@ extern "C" int af_gemm(const af_gemm_desc* d, void* stream) {
   AF_REQUIRE(p.ld_out % 4 == 0, "af_gemm: ld_out must be a multiple of 4");
   if (p.splits > 1) {
     AF_REQUIRE(!geglu && d->out_mode == AF_OUT_NORMAL, "af_gemm: split-K only with the standard epilogue");
-    AF_REQUIRE(d->workspace != nullptr && d->workspace_bytes >= (int64_t)p.splits * d->M * d->N * 4,
-               "af_gemm: split-K needs workspace >= splits*M*N*4 bytes");
+    AF_REQUIRE(d->workspace != nullptr && d->workspace_bytes - (d->splitk_fused ? AF_SPLITK_COUNTER_BYTES : 0) >= (int64_t)p.splits * d->M * d->N * 4,
+               "af_gemm: split-K needs workspace >= splits*M*N*4 bytes (+ AF_SPLITK_COUNTER_BYTES of zeroed counters with splitk_fused)");
   }
 
   int tile = d->tile;

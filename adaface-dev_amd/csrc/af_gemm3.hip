@@ -41,6 +41,7 @@ struct Gemm3Dev {
   int rows_per_batch, ld_rowbias, act, ld_out;
   int tiles_n, tiles_m, n_major, splits, kt_per_split;
   float* ws;
+  int* counters;  // in-kernel split-K reduction: one arrival counter per output tile (zero between launches); nullptr = separate reduce pass
   int ablate;  // profiling only (AF_GEMM3_ABLATE): 1 = no DMA after the prologue, 2 = fragments read once, 4 = no barrier,
                // 8 = no main loop, 16 = no epilogue, 32 = direct (un-staged) epilogue stores
   int stage_ok;  // output rows can be written as 16-byte chunks (N, ld_out multiples of 8, 16-byte aligned base)
@@ -86,7 +87,44 @@ __device__ __forceinline__ void gemm3_epilogue(const Gemm3Dev& p, floatx4 (&acc)
         if (n0 < p.N) *reinterpret_cast<floatx4*>(wsp + (size_t)m * p.N + n0) = acc[tn][tm];
       }
     }
-    return;
+    if (p.counters == nullptr) return;               // the caller runs af_splitk_reduce_kernel
+    // ---- in-kernel reduction (no second launch): every K-slice publishes its slab, the LAST slice to arrive at the tile's counter
+    // sums all slabs in slice order (the same order as the reduce kernel: bit-identical results, independent of arrival order)
+    // and runs the epilogue.  Hand-off = the counter form of the agent-scope release / acquire protocol (cdna_hip_programming.md,
+    // Guideline 16 / "Projection GEMM" item 2): plain slab stores -> every wave drains its stores -> workgroup barrier -> one lane:
+    // agent release, drained, relaxed agent fetch_add; the last arriver: agent acquire, drained, barrier, plain loads.  Placement
+    // independent; the counter is restored to zero by the last arriver (launch boundaries order it for the next launch).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int* last_flag = reinterpret_cast<int*>(af_smem);  // the staging ring is idle; ONE LDS object in the kernel (no second __shared__)
+    if (tid == 0) {
+      int* cnt = p.counters + tile_m * p.tiles_n + tile_n;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const int ticket = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = ticket == p.splits - 1;
+      if (last) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      *last_flag = last;
+    }
+    __syncthreads();
+    if (!*last_flag) return;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      const int m = tile_m * BM + wm * 64 + tm * 16 + fr;
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        const int n0 = tile_n * BN + wn * TN * 16 + tn * 16 + 4 * fq;
+        floatx4 v = {0.f, 0.f, 0.f, 0.f};
+        if (m < p.M && n0 < p.N)
+          for (int sp = 0; sp < p.splits; ++sp) v += *reinterpret_cast<const floatx4*>(p.ws + ((size_t)sp * p.M + m) * p.N + n0);
+        acc[tn][tm] = v;
+      }
+    }
+    // fall through: acc now holds the full sums, the ordinary epilogue follows
   }
   // Staged epilogue: the tile is assembled in LDS (the ring is idle now) and written out as whole rows, 16 bytes per lane, instead
   // of 8-byte stores that touch 16 rows x 32 bytes per wave instruction.  Measured on M32768 N2560 K320 the direct form spends
@@ -435,7 +473,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void af_gem
 }
 
 template <int TAPS, int NWM, int NWN, int TN, int EPI = E3_STD, int NST = NST_DEFAULT>
-void launch3(const Gemm3Dev& p0, hipStream_t stream) {
+bool launch3(const Gemm3Dev& p0, hipStream_t stream) {
   Gemm3Dev p = p0;
   constexpr int NW = NWM * NWN, BM = NWM * 64, BN = NWN * TN * 16;
   constexpr int WROWS = ((BN / 16 + NW - 1) / NW) * NW * 16;
@@ -443,6 +481,7 @@ void launch3(const Gemm3Dev& p0, hipStream_t stream) {
   p.tiles_n = (p.N + BN - 1) / BN;
   const int tiles_m = (p.M + BM - 1) / BM;
   p.tiles_m = tiles_m;
+  if (p.counters && (p.splits <= 1 || tiles_m * p.tiles_n > AF_SPLITK_MAX_TILES)) p.counters = nullptr;
   p.n_major = af_gemm_n_major(p.M, p.N, p.K, TAPS == 9 ? p.c1 + p.c2 : p.K);
   static bool attr_set = false;
   if (lds > 65536 && !attr_set) {
@@ -452,6 +491,7 @@ void launch3(const Gemm3Dev& p0, hipStream_t stream) {
   }
   dim3 grid(tiles_m * p.tiles_n, p.splits), block(64 * NW);
   hipLaunchKernelGGL((af_gemm3_kernel<TAPS, NWM, NWN, TN, EPI, NST>), grid, block, lds, stream, p);
+  return p.counters != nullptr;      // true: the kernel reduced the K-slices itself
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -593,10 +633,15 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void af_gem
 
   if (nk > 0) issue_stage(kt_begin, 0);
   half8_t wf[TN], xf[TM];
+  // experiment switches (AF_GEMM3_ABLATE): 128 = raise the wave's priority around each MFMA cluster; 256 = the second half of the
+  // waves (the SIMD partners of the first half) issue the next stage's DMA between the two K halves instead of ahead of them, so
+  // that the partners' DMA-issue segments do not coincide
+  const bool prio = (p.ablate & 128) != 0;
+  const bool late_dma = (p.ablate & 256) != 0 && wave >= NW / 2;
   for (int i = 0; i < nk; ++i) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // stage i (the only one in flight) has landed
     __builtin_amdgcn_s_barrier();                           // ... for every wave; everyone is done reading the other slot
-    if (i + 1 < nk) issue_stage(kt_begin + i + 1, (i + 1) & 1);
+    if (!late_dma && i + 1 < nk) issue_stage(kt_begin + i + 1, (i + 1) & 1);
     const char* As = af_smem + (i & 1) * STAGE;
     const char* Ws = As + BM * 128;
 #pragma unroll
@@ -606,11 +651,14 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void af_gem
       for (int tn = 0; tn < TN; ++tn) wf[tn] = *reinterpret_cast<const half8_t*>(Ws + (wn * TN * 16 + tn * 16) * 128 + rd);
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm) xf[tm] = *reinterpret_cast<const half8_t*>(As + (wm * 64 + tm * 16) * 128 + rd);
+      if (prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
           acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[tn], xf[tm], acc[tn][tm], 0, 0, 0);
+      if (prio) __builtin_amdgcn_s_setprio(0);
+      if (kk == 0 && late_dma && i + 1 < nk) issue_stage(kt_begin + i + 1, (i + 1) & 1);
     }
   }
 
@@ -618,12 +666,13 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void af_gem
 }
 
 template <int TAPS, int NWM, int NWN, int TN, int EPI = E3_STD>
-void launch3w(const Gemm3Dev& p0, hipStream_t stream) {
+bool launch3w(const Gemm3Dev& p0, hipStream_t stream) {
   Gemm3Dev p = p0;
   constexpr int NW = NWM * NWN, BM = NWM * 64, BN = NWN * TN * 16;
   constexpr size_t lds = 2 * (size_t)(BM + BN) * 128;
   p.tiles_n = (p.N + BN - 1) / BN;
   p.tiles_m = (p.M + BM - 1) / BM;
+  if (p.counters && (p.splits <= 1 || p.tiles_m * p.tiles_n > AF_SPLITK_MAX_TILES)) p.counters = nullptr;
   p.n_major = af_gemm_n_major(p.M, p.N, p.K, TAPS == 9 ? p.c1 + p.c2 : p.K);
   static bool attr_set = false;
   if (lds > 65536 && !attr_set) {
@@ -633,6 +682,7 @@ void launch3w(const Gemm3Dev& p0, hipStream_t stream) {
   }
   dim3 grid(p.tiles_m * p.tiles_n, p.splits), block(64 * NW);
   hipLaunchKernelGGL((af_gemm3w_kernel<TAPS, NWM, NWN, TN, EPI>), grid, block, lds, stream, p);
+  return p.counters != nullptr;
 }
 
 }  // namespace
@@ -659,6 +709,7 @@ int af_gemm3_try_launch(const af_gemm_desc* d, int splits, int wide, hipStream_t
   if (wide == 2 && (d->N % 256 != 0 || d->taps != 1 || split_t || splits > 1)) return 1;
   if (wide == 3 && (d->N % 320 != 0 || d->taps != 1 || split_t || splits > 1)) return 1;
   Gemm3Dev p;
+  bool fused = false;
   p.a1 = (const half_t*)d->a1;
   p.a2 = (const half_t*)d->a2;
   p.wt = (const half_t*)d->wt;
@@ -697,8 +748,12 @@ int af_gemm3_try_launch(const af_gemm_desc* d, int splits, int wide, hipStream_t
   p.kt_per_split = (nk + p.splits - 1) / p.splits;
   p.splits = (nk + p.kt_per_split - 1) / p.kt_per_split;
   p.ws = (float*)d->workspace;
+  // in-kernel split-K reduction (af_gemm_desc.splitk_fused): the last AF_SPLITK_COUNTER_BYTES of the workspace are the tile counters
+  p.counters = (d->splitk_fused && d->workspace && d->workspace_bytes > AF_SPLITK_COUNTER_BYTES)
+                   ? reinterpret_cast<int*>(static_cast<char*>(d->workspace) + d->workspace_bytes - AF_SPLITK_COUNTER_BYTES) : nullptr;
   static const int ablate = getenv("AF_GEMM3_ABLATE") ? atoi(getenv("AF_GEMM3_ABLATE")) : 0;
-  p.ablate = ablate;
+  static const bool ablate_dynamic = getenv("AF_GEMM3_ABLATE_DYNAMIC") != nullptr;   // experiments: re-read per call (in-process A/B)
+  p.ablate = ablate_dynamic ? (getenv("AF_GEMM3_ABLATE") ? atoi(getenv("AF_GEMM3_ABLATE")) : 0) : ablate;
   {
     const int ncols = geglu ? d->N / 2 : d->N;
     p.stage_ok = ncols % 8 == 0 && p.ld_out % 8 == 0 && (reinterpret_cast<uintptr_t>(p.out) & 15) == 0;
@@ -711,34 +766,34 @@ int af_gemm3_try_launch(const af_gemm_desc* d, int splits, int wide, hipStream_t
     p.kt_per_split = (nk64 + p.splits - 1) / p.splits;
     p.splits = (nk64 + p.kt_per_split - 1) / p.kt_per_split;
     if (wide == 4) {
-      if (geglu) launch3w<1, 2, 4, 4, E3_GEGLU>(p, stream);
-      else if (split_t) launch3w<1, 2, 4, 5, E3_SPLIT_T>(p, stream);
-      else if (d->taps == 9) launch3w<9, 2, 4, 5>(p, stream);
-      else launch3w<1, 2, 4, 5>(p, stream);
+      if (geglu) fused = launch3w<1, 2, 4, 4, E3_GEGLU>(p, stream);
+      else if (split_t) fused = launch3w<1, 2, 4, 5, E3_SPLIT_T>(p, stream);
+      else if (d->taps == 9) fused = launch3w<9, 2, 4, 5>(p, stream);
+      else fused = launch3w<1, 2, 4, 5>(p, stream);
     } else if (wide == 5) {
-      if (geglu) launch3w<1, 2, 2, 4, E3_GEGLU>(p, stream);
-      else if (split_t) launch3w<1, 2, 2, 4, E3_SPLIT_T>(p, stream);
-      else if (d->taps == 9) launch3w<9, 2, 2, 4>(p, stream);
-      else launch3w<1, 2, 2, 4>(p, stream);
+      if (geglu) fused = launch3w<1, 2, 2, 4, E3_GEGLU>(p, stream);
+      else if (split_t) fused = launch3w<1, 2, 2, 4, E3_SPLIT_T>(p, stream);
+      else if (d->taps == 9) fused = launch3w<9, 2, 2, 4>(p, stream);
+      else fused = launch3w<1, 2, 2, 4>(p, stream);
     } else {
-      if (wide == 6) launch3w<1, 4, 2, 10, E3_GEGLU>(p, stream); else launch3w<1, 4, 2, 8, E3_GEGLU>(p, stream);
+      if (wide == 6) fused = launch3w<1, 4, 2, 10, E3_GEGLU>(p, stream); else fused = launch3w<1, 4, 2, 8, E3_GEGLU>(p, stream);
     }
-    return p.splits > 1 ? 2 : 0;
+    return (p.splits > 1 && !fused) ? 2 : 0;
   }
   if (wide == 2) {
-    if (geglu) launch3<1, 4, 2, 8, E3_GEGLU>(p, stream); else launch3<1, 4, 2, 8>(p, stream);
+    if (geglu) fused = launch3<1, 4, 2, 8, E3_GEGLU>(p, stream); else fused = launch3<1, 4, 2, 8>(p, stream);
   } else if (wide == 3) {
-    if (geglu) launch3<1, 4, 2, 10, E3_GEGLU>(p, stream); else launch3<1, 4, 2, 10>(p, stream);
+    if (geglu) fused = launch3<1, 4, 2, 10, E3_GEGLU>(p, stream); else fused = launch3<1, 4, 2, 10>(p, stream);
   } else if (geglu) {
-    launch3<1, 2, 4, 4, E3_GEGLU>(p, stream);
+    fused = launch3<1, 2, 4, 4, E3_GEGLU>(p, stream);
   } else if (split_t) {
-    if (wide) launch3<1, 2, 4, 5, E3_SPLIT_T>(p, stream); else launch3<1, 2, 2, 4, E3_SPLIT_T>(p, stream);
+    if (wide) fused = launch3<1, 2, 4, 5, E3_SPLIT_T>(p, stream); else fused = launch3<1, 2, 2, 4, E3_SPLIT_T>(p, stream);
   } else if (wide) {
-    if (d->taps == 9) launch3<9, 2, 4, 5>(p, stream); else launch3<1, 2, 4, 5>(p, stream);
+    if (d->taps == 9) fused = launch3<9, 2, 4, 5>(p, stream); else fused = launch3<1, 2, 4, 5>(p, stream);
   } else {
-    if (d->taps == 9) launch3<9, 2, 2, 4>(p, stream); else launch3<1, 2, 2, 4>(p, stream);
+    if (d->taps == 9) fused = launch3<9, 2, 2, 4>(p, stream); else fused = launch3<1, 2, 2, 4>(p, stream);
   }
-  return p.splits > 1 ? 2 : 0;   // 2: caller must run the split-K reduce pass with p.splits
+  return (p.splits > 1 && !fused) ? 2 : 0;   // 2: caller must run the split-K reduce pass with p.splits
 }
 
 int af_gemm3_effective_splits(const af_gemm_desc* d, int splits, int wide) {

@@ -136,11 +136,19 @@ def _zero_page(device) -> torch.Tensor:
 
 
 def _splitk_workspace(device) -> torch.Tensor:
+    """fp32 partial slabs + (last AF_SPLITK_COUNTER_BYTES) the per-tile arrival counters of the in-kernel reduction, which must be
+    zero between launches: zeroed here once, every launch restores them."""
     ws = _splitk_ws.get(device)
     if ws is None:
         ws = torch.empty((SPLITK_WS_BYTES // 4,), dtype=torch.float32, device=device)
+        ws[-(_lib.AF_SPLITK_COUNTER_BYTES // 4):].zero_()
         _splitk_ws[device] = ws
     return ws
+
+
+# split-K with at most this many slices is reduced inside the GEMM launch by the last-arriving workgroup of each tile (one launch
+# instead of two); wider splits keep the separate, chip-wide reduce pass (a single workgroup would read too many slabs)
+SPLITK_FUSED_MAX = int(_os.environ.get("AF_SPLITK_FUSED_MAX", "4"))
 
 
 def _launch_gemm(d: "GemmDesc", device, what: str, tile: int = 0, splits: int = 0):
@@ -159,8 +167,9 @@ def _launch_gemm(d: "GemmDesc", device, what: str, tile: int = 0, splits: int = 
             d.splits = 1
         else:
             ws = _splitk_workspace(device)
-            d.splits = max(1, min(d.splits, (ws.numel() * 4) // (d.M * d.N * 4)))
+            d.splits = max(1, min(d.splits, (ws.numel() * 4 - _lib.AF_SPLITK_COUNTER_BYTES) // (d.M * d.N * 4)))
             d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+            d.splitk_fused = int(d.splits <= SPLITK_FUSED_MAX)
     _lib.check(_lib.lib().af_gemm(C.byref(d), _stream()), what)
 
 

@@ -119,8 +119,14 @@ typedef struct af_gemm_desc {
   const void* zeros;    /* >= 16 bytes of zeros, 16-byte aligned: source of halo / out-of-range lanes (tile 3) */
   int32_t tap_shift;    /* 3x3 only: 0 = padding 1 on every side; 1 = taps shifted by +1 pixel, i.e. padding (0, 1, 0, 1) as the VAE
                            encoder's Downsample pads before its stride-2 conv (ldm/modules/diffusionmodules/model.py:73-77) */
-  int32_t reserved0;
+  int32_t splitk_fused; /* split-K only: 1 = reduce inside the GEMM launch (tiles 3 .. 10, at most AF_SPLITK_MAX_TILES output tiles; otherwise the
+                           two-launch form is used).  The LAST AF_SPLITK_COUNTER_BYTES of the workspace are then per-tile arrival counters:
+                           the caller zeroes them once when it allocates the workspace, every launch leaves them zero.  The partial slabs
+                           must fit in the first workspace_bytes - AF_SPLITK_COUNTER_BYTES bytes.  Results are bit-identical to the
+                           two-launch form (slices are summed in slice order by the last-arriving workgroup of each tile) */
 } af_gemm_desc;
+#define AF_SPLITK_MAX_TILES 4096
+#define AF_SPLITK_COUNTER_BYTES (AF_SPLITK_MAX_TILES * 4)
 
 int af_gemm(const af_gemm_desc* d, void* stream);
 

@@ -440,3 +440,44 @@ def test_prefetch_reads_without_side_effects(dev):
     assert L.af_prefetch(x.data_ptr() + 2, 1024, st) < 0 and b"aligned" in L.af_last_error()
     torch.cuda.synchronize()
     assert torch.equal(x, ref)
+
+
+@pytest.mark.parametrize("tile", [3, 4, 7, 8])
+def test_split_k_in_kernel_reduction_is_bit_identical_and_repeatable(dev, tile, monkeypatch):
+    """Split-K with the reduction inside the GEMM launch (af_gemm_desc.splitk_fused: the last-arriving K-slice of every output tile sums the
+    slabs in slice order and runs the epilogue) against the two-launch form: bit-identical outputs (same summation order), for
+    every epilogue input (bias, per-batch row bias, SiLU, residual), ragged M, 2 - 4 slices -- and again over many back-to-back
+    launches of different shapes sharing the workspace (the arrival counters must come back to zero every time; a stale or lost
+    hand-off would show as a wrong tile)."""
+    from adaface_dev_amd import ops, rng
+    shapes = [(1000, 320, 1280, 2), (4096, 640, 1280, 3), (616, 640, 2560, 4), (2048, 1280, 1280, 2), (130, 320, 640, 2)]
+    if tile in (4, 7):
+        shapes = [sh for sh in shapes if sh[1] % 320 == 0]
+    cases = []
+    for M, N, K, sp in shapes:
+        a = rng.synth_input(f"skf.a{M}", (M, K), seed=5).half().to(dev)
+        pw = ops.pack_matrix(rng.synth_input(f"skf.w{N}x{K}", (N, K), seed=5) * K ** -0.5, rng.synth_input(f"skf.b{N}", (N,), seed=5), dev)
+        res = rng.synth_input(f"skf.r{M}x{N}", (M, N), seed=5).half().to(dev)
+        rowb = rng.synth_input(f"skf.rb{N}", (4, N), seed=5).half().to(dev)
+        cases.append((a, pw, res, rowb, sp, -(-M // 4)))
+
+    def run_all(fused_max):
+        monkeypatch.setattr(ops, "SPLITK_FUSED_MAX", fused_max)
+        return [ops.gemm(a, pw, residual=res, rowbias=rowb, rows_per_batch=rpb, act=ops.AF_ACT_SILU, tile=tile, splits=sp)
+                for a, pw, res, rowb, sp, rpb in cases]
+    want = run_all(0)                                   # two launches: GEMM slabs + af_splitk_reduce_kernel
+    for rep in range(25):
+        got = run_all(4)
+        for g, w, c in zip(got, want, cases):
+            assert torch.equal(g, w), (tile, rep, tuple(c[0].shape), c[4])
+    ws = ops._splitk_workspace(dev)
+    assert int(ws[-(ops._lib.AF_SPLITK_COUNTER_BYTES // 4):].view(torch.int32).abs().sum()) == 0      # counters restored
+    # 3x3 convolution with two sources and split-K through the same path
+    x = rng.synth_input("skf.x", (2, 16, 16, 640), seed=5).half().to(dev)
+    x2 = rng.synth_input("skf.x2", (2, 16, 16, 320), seed=5).half().to(dev)
+    pc = ops.pack_conv3x3(rng.synth_input("skf.wc", (640, 960, 3, 3), seed=5) * (960 * 9) ** -0.5, rng.synth_input("skf.bc", (640,), seed=5), dev)
+    monkeypatch.setattr(ops, "SPLITK_FUSED_MAX", 0)
+    wc = ops.conv3x3(x, pc, x2=x2, tile=tile, splits=3)
+    monkeypatch.setattr(ops, "SPLITK_FUSED_MAX", 4)
+    for rep in range(5):
+        assert torch.equal(ops.conv3x3(x, pc, x2=x2, tile=tile, splits=3), wc), rep

@@ -421,7 +421,7 @@ def test_guided_denoise_cfg_x0_grad_modes_vs_oracle(dev):
     e_none, rec_none, acts_none = ld.guided_denoise(x0.to(dev), noise.to(dev), t.to(dev), (ctx.to(dev).requires_grad_(True), ["a", "b"], {}),
                                                     img_mask=mask.to(dev), batch_part_has_grad="none", cfg_scale=2.5,
                                                     capture_ca_activations=True)
-    assert rec_none is None and not e_none.requires_grad and rel_l2(e_none.cpu().numpy(), ref.detach().numpy()) < NET_TOL
+    assert rec_none is None and not e_none.requires_grad and rel_l2(e_none.cpu().numpy(), ref.detach().numpy()) < 2 * NET_TOL      # guided at s = 2.5, as above
     assert sorted(acts_none["attn"].keys()) == [22, 23, 24]                       # captures are available on the no-grad path
     with pytest.raises(NotImplementedError):                                      # ... and refused loudly together with gradients
         ld.guided_denoise(x0.to(dev), noise.to(dev), t.to(dev), (ctx.to(dev).requires_grad_(True), ["a", "b"], {}),

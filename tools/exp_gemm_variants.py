@@ -1,0 +1,54 @@
+#!/usr/bin/env python
+"""In-process A/B of main-loop variants of the whole-line GEMM kernel (AF_GEMM3_ABLATE switches) on the shapes that carry the
+denoise step: interleaved rounds, graph-replayed timing, median and min per (shape, variant).
+    AF_GEMM3_ABLATE_DYNAMIC=1 python tools/exp_gemm_variants.py [rounds]"""
+import os
+import sys
+
+os.environ["AF_GEMM3_ABLATE_DYNAMIC"] = "1"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import torch  # noqa: E402
+
+from bench_kernel import timeit  # noqa: E402
+
+
+def main():
+    from adaface_dev_amd import ops
+    rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+    variants = [int(v) for v in os.environ.get("AF_EXP_VARIANTS", "0,128,256,384").split(",")]
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(0)
+    rnd = lambda *s: torch.randn(*s, generator=g).half().to(dev)
+    cases = []
+    # (name, callable factory): convs B H W Cin Cout tile splits ; gemms M N K tile splits act
+    for B, H, W, ci, co, tile, sp in ((8, 64, 64, 320, 320, 7, 1), (8, 32, 32, 640, 640, 7, 2), (8, 16, 16, 1280, 1280, 7, 4), (8, 64, 64, 640, 320, 7, 1)):
+        x = rnd(B, H, W, ci)
+        pw = ops.pack_conv3x3(torch.randn(co, ci, 3, 3, generator=g) * (ci * 9) ** -0.5, torch.randn(co, generator=g), dev)
+        cases.append((f"conv {B}x{H}x{W} {ci}->{co} t{tile} s{sp}", 2.0 * B * H * W * co * ci * 9,
+                      lambda x=x, pw=pw, tile=tile, sp=sp: ops.conv3x3(x, pw, tile=tile, splits=sp)))
+    for M, N, K, tile, sp, act in ((32768, 320, 320, 7, 1, 0), (8192, 640, 640, 8, 1, 0), (2048, 1280, 1280, 8, 1, 0), (2048, 1280, 1280, 8, 2, 0),
+                                   (32768, 2560, 320, 10, 1, 2), (8192, 5120, 640, 7, 1, 2), (32768, 320, 1280, 7, 1, 0), (8192, 640, 2560, 8, 1, 0)):
+        a = rnd(M, K)
+        pw = ops.pack_matrix(torch.randn(N, K, generator=g) * K ** -0.5, torch.randn(N, generator=g), dev)
+        cases.append((f"gemm {M} {N} {K} t{tile} s{sp} act{act}", 2.0 * M * N * K,
+                      lambda a=a, pw=pw, tile=tile, sp=sp, act=act: ops.gemm(a, pw, tile=tile, splits=sp, act=act)))
+    res = {(n, v): [] for n, _, _ in cases for v in variants}
+    for r in range(rounds):
+        for name, fl, fn in cases:
+            for v in variants:
+                os.environ["AF_GEMM3_ABLATE"] = str(v)
+                res[(name, v)].append(timeit(fn, 20) * 1e3)
+    print(f"{'shape':44s} " + " ".join(f"{'v' + str(v):>16s}" for v in variants) + "   (us median/min, TFLOP/s at median)")
+    for name, fl, _ in cases:
+        cells = []
+        for v in variants:
+            t = sorted(res[(name, v)])
+            med = t[len(t) // 2]
+            cells.append(f"{med:6.1f}/{t[0]:6.1f} {fl / med / 1e6:4.0f}")
+        print(f"{name:44s} " + " ".join(f"{c:>16s}" for c in cells))
+
+
+if __name__ == "__main__":
+    main()
