@@ -48,6 +48,7 @@ struct GemmDev {
   int tap_shift;   // 0: padding 1 all round; 1: taps shifted by +1 (padding (0,1,0,1))
   int splits, kt_per_split;  // split-K: blockIdx.y owns K steps [y*kt_per_split, ...)
   float* ws;                 // fp32 partials [splits][M][N] when splits > 1
+  int* counters;             // in-kernel split-K reduction: per-tile arrival counters (zero between launches); nullptr = reduce pass
 };
 
 constexpr int BK = 64;
@@ -261,17 +262,63 @@ __global__ __launch_bounds__(256, 2) void af_gemm_kernel(GemmDev p) {
   // ---- split-K: raw fp32 partial tile to the workspace; af_splitk_reduce applies the epilogue
   if (EPI == EPI_STD && p.splits > 1) {
     float* wsp = p.ws + (size_t)blockIdx.y * p.M * p.N;
+    if (p.counters != nullptr) {
+      // slabs handed to another workgroup inside this launch: WRITE-THROUGH (sc1) 16-byte stores, so that no release fence (an L2
+      // write-back of every dirty line, ~20 us with every workgroup's slab dirty) is needed before the arrival counter
+      const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(wsp, 0, p.M * p.N * 4, 0x00020000);
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        const int m = tile_m * BM + wm * WM + tm * 16 + fr;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+          const int n0 = tile_n * BN + wn * WN + tn * 16 + 4 * fq;
+          if (n0 < p.N) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4_t, acc[tn][tm]), rsrc, (m * p.N + n0) * 4, 0, 16);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        const int m = tile_m * BM + wm * WM + tm * 16 + fr;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+          const int n0 = tile_n * BN + wn * WN + tn * 16 + 4 * fq;
+          if (n0 < p.N) *reinterpret_cast<floatx4*>(wsp + (size_t)m * p.N + n0) = acc[tn][tm];
+        }
+      }
+    }
+    if (p.counters == nullptr) return;               // af_splitk_reduce_kernel follows
+    // in-kernel reduction by the last-arriving K-slice of this tile: same protocol and same summation order as af_gemm3.hip's
+    // gemm3_epilogue (agent-scope release / acquire around a relaxed arrival counter; slabs summed in slice order)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int* last_flag = reinterpret_cast<int*>(af_smem);
+    if (threadIdx.x == 0) {
+      int* cnt = p.counters + tile_m * p.tiles_n + tile_n;
+      const int ticket = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = ticket == p.splits - 1;
+      if (last) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      *last_flag = last;
+    }
+    __syncthreads();
+    if (!*last_flag) return;
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
       const int m = tile_m * BM + wm * WM + tm * 16 + fr;
-      if (m >= p.M) continue;
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn) {
         const int n0 = tile_n * BN + wn * WN + tn * 16 + 4 * fq;
-        if (n0 < p.N) *reinterpret_cast<floatx4*>(wsp + (size_t)m * p.N + n0) = acc[tn][tm];
+        floatx4 v = {0.f, 0.f, 0.f, 0.f};
+        if (m < p.M && n0 < p.N)
+          for (int sp = 0; sp < p.splits; ++sp) v += *reinterpret_cast<const floatx4*>(p.ws + ((size_t)sp * p.M + m) * p.N + n0);
+        acc[tn][tm] = v;
       }
     }
-    return;
   }
 
   // ---- epilogue: lane holds rows n0..n0+3 (consecutive output channels) of column m
@@ -383,9 +430,10 @@ int launch(const GemmDev& p0, hipStream_t stream) {
   p.kt_per_split = (nk + p.splits - 1) / p.splits;
   p.splits = (nk + p.kt_per_split - 1) / p.kt_per_split;  // no empty split
   const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(half_t);
+  if (p.counters && (EPI != EPI_STD || p.splits <= 1 || tiles_m * p.tiles_n > AF_SPLITK_MAX_TILES)) p.counters = nullptr;
   dim3 grid(tiles_m * p.tiles_n, p.splits), block(256);
   hipLaunchKernelGGL((af_gemm_kernel<BM, BN, TAPS, EPI, FAST>), grid, block, lds, stream, p);
-  if (EPI == EPI_STD && p.splits > 1) {
+  if (EPI == EPI_STD && p.splits > 1 && p.counters == nullptr) {
     const long n = (long)p.M * (p.N >> 2);
     hipLaunchKernelGGL(af_splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, p);
   }
@@ -459,6 +507,8 @@ extern "C" int af_gemm(const af_gemm_desc* d, void* stream) {
   p.splits = d->splits > 1 ? d->splits : 1;
   p.kt_per_split = 0;
   p.ws = (float*)d->workspace;
+  p.counters = (d->splitk_fused && d->workspace && d->workspace_bytes > AF_SPLITK_COUNTER_BYTES)
+                   ? reinterpret_cast<int*>(static_cast<char*>(d->workspace) + d->workspace_bytes - AF_SPLITK_COUNTER_BYTES) : nullptr;
   if (d->taps == 9) {
     AF_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Ho > 0 && d->Wo > 0, "af_gemm: conv geometry missing");
     AF_REQUIRE(p.stride == 1 || p.stride == 2, "af_gemm: stride must be 1 or 2");

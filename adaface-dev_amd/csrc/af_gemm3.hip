@@ -77,30 +77,44 @@ __device__ __forceinline__ void gemm3_epilogue(const Gemm3Dev& p, floatx4 (&acc)
   // ---- epilogue (identical arithmetic to af_gemm.hip's standard epilogue)
   if (p.splits > 1) {
     float* wsp = p.ws + (size_t)blockIdx.y * p.M * p.N;
+    if (p.counters != nullptr) {
+      // slabs handed to another workgroup inside this launch: WRITE-THROUGH (sc1) 16-byte stores, so that no release fence (an L2
+      // write-back of every dirty line, ~20 us with every workgroup's slab dirty) is needed before the arrival counter
+      const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(wsp, 0, p.M * p.N * 4, 0x00020000);
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm) {
-      const int m = tile_m * BM + wm * 64 + tm * 16 + fr;
-      if (m >= p.M) continue;
+      for (int tm = 0; tm < TM; ++tm) {
+        const int m = tile_m * BM + wm * 64 + tm * 16 + fr;
+        if (m >= p.M) continue;
 #pragma unroll
-      for (int tn = 0; tn < TN; ++tn) {
-        const int n0 = tile_n * BN + wn * TN * 16 + tn * 16 + 4 * fq;
-        if (n0 < p.N) *reinterpret_cast<floatx4*>(wsp + (size_t)m * p.N + n0) = acc[tn][tm];
+        for (int tn = 0; tn < TN; ++tn) {
+          const int n0 = tile_n * BN + wn * TN * 16 + tn * 16 + 4 * fq;
+          if (n0 < p.N) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4_t, acc[tn][tm]), rsrc, (m * p.N + n0) * 4, 0, 16);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        const int m = tile_m * BM + wm * 64 + tm * 16 + fr;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+          const int n0 = tile_n * BN + wn * TN * 16 + tn * 16 + 4 * fq;
+          if (n0 < p.N) *reinterpret_cast<floatx4*>(wsp + (size_t)m * p.N + n0) = acc[tn][tm];
+        }
       }
     }
     if (p.counters == nullptr) return;               // the caller runs af_splitk_reduce_kernel
     // ---- in-kernel reduction (no second launch): every K-slice publishes its slab, the LAST slice to arrive at the tile's counter
     // sums all slabs in slice order (the same order as the reduce kernel: bit-identical results, independent of arrival order)
     // and runs the epilogue.  Hand-off = the counter form of the agent-scope release / acquire protocol (cdna_hip_programming.md,
-    // Guideline 16 / "Projection GEMM" item 2): plain slab stores -> every wave drains its stores -> workgroup barrier -> one lane:
-    // agent release, drained, relaxed agent fetch_add; the last arriver: agent acquire, drained, barrier, plain loads.  Placement
-    // independent; the counter is restored to zero by the last arriver (launch boundaries order it for the next launch).
+    // Guideline 16 recipe R1 / "Projection GEMM" item 2): write-through (sc1) slab stores -> every storing wave drains its stores ->
+    // workgroup barrier -> one lane: relaxed agent fetch_add; the last arriver: agent acquire, drained, barrier, plain loads.
+    // Placement independent; the counter is restored to zero by the last arriver (launch boundaries order it for the next launch).
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int* last_flag = reinterpret_cast<int*>(af_smem);  // the staging ring is idle; ONE LDS object in the kernel (no second __shared__)
     if (tid == 0) {
       int* cnt = p.counters + tile_m * p.tiles_n + tile_n;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       const int ticket = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const int last = ticket == p.splits - 1;
       if (last) {
@@ -633,11 +647,16 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void af_gem
 
   if (nk > 0) issue_stage(kt_begin, 0);
   half8_t wf[TN], xf[TM];
-  // experiment switches (AF_GEMM3_ABLATE): 128 = raise the wave's priority around each MFMA cluster; 256 = the second half of the
-  // waves (the SIMD partners of the first half) issue the next stage's DMA between the two K halves instead of ahead of them, so
-  // that the partners' DMA-issue segments do not coincide
-  const bool prio = (p.ablate & 128) != 0;
-  const bool late_dma = (p.ablate & 256) != 0 && wave >= NW / 2;
+  // 8-wave tiles put two waves on every SIMD, and with one barrier per K step the partners walk the step in lock step: both issue
+  // their DMA pieces (~60 - 100 cycles each, 7 per wave) at the same time while the MFMA pipe idles.  The second half of the waves
+  // (the SIMD partners of the first half) therefore issues the next stage's DMA BETWEEN the two K halves, under the partner's
+  // MFMAs, and each MFMA cluster runs at raised priority (the pair keeps the compiler from moving MFMAs across the barrier).
+  // Measured in one process (profiles/r02c_gemm_variants.txt): conv 8x64x64 320->320 69.1 -> 64.1 us, 640->320 146.1 -> 125.1,
+  // GEGLU M32768 N2560 K320 112.0 -> 101.2, M32768 N320 K1280 34.5 -> 32.4; the 4-wave tile (partners belong to different
+  // workgroups, not in lock step) gets 1 - 3 % slower with it, so it keeps the plain order.
+  // AF_GEMM3_ABLATE bits 128 / 256 switch the priority pair / the late DMA OFF (A/B runs).
+  const bool prio = NW == 8 && (p.ablate & 128) == 0;
+  const bool late_dma = NW == 8 && (p.ablate & 256) == 0 && wave >= NW / 2;
   for (int i = 0; i < nk; ++i) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // stage i (the only one in flight) has landed
     __builtin_amdgcn_s_barrier();                           // ... for every wave; everyone is done reading the other slot

@@ -442,7 +442,7 @@ def test_prefetch_reads_without_side_effects(dev):
     assert torch.equal(x, ref)
 
 
-@pytest.mark.parametrize("tile", [3, 4, 7, 8])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 7, 8])
 def test_split_k_in_kernel_reduction_is_bit_identical_and_repeatable(dev, tile, monkeypatch):
     """Split-K with the reduction inside the GEMM launch (af_gemm_desc.splitk_fused: the last-arriving K-slice of every output tile sums the
     slabs in slice order and runs the epilogue) against the two-launch form: bit-identical outputs (same summation order), for

@@ -53,9 +53,12 @@ def main():
         d.zeros = ops._zero_page(device).data_ptr()
         if splits > 1:
             ws = ops._splitk_workspace(device)
-            if splits * d.M * d.N * 4 > ws.numel() * 4:
+            if splits * d.M * d.N * 4 > ws.numel() * 4 - _lib.AF_SPLITK_COUNTER_BYTES:
                 return None
             d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+            d.splitk_fused = int(splits <= ops.SPLITK_FUSED_MAX)      # the rule ops._launch_gemm applies: narrow splits reduce in-kernel
+        else:
+            d.splitk_fused = 0
         st = torch.cuda.current_stream().cuda_stream
         for _ in range(2):
             if L.af_gemm(C.byref(d), st) < 0:
