@@ -307,16 +307,37 @@ __global__ __launch_bounds__(256, 2) void af_gemm_kernel(GemmDev p) {
     }
     __syncthreads();
     if (!*last_flag) return;
+    // The slabs were written through to memory, so every load is a full round trip: issue them in big batches.  Slice 0 lands
+    // directly in the (now dead) accumulators, all TN x TM fragments in flight at once; every further slice is added from a
+    // half-tile of temporaries.  Summation order = slice order, as in af_splitk_reduce_kernel (0 + s0 == s0 exactly).
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
       const int m = tile_m * BM + wm * WM + tm * 16 + fr;
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn) {
         const int n0 = tile_n * BN + wn * WN + tn * 16 + 4 * fq;
-        floatx4 v = {0.f, 0.f, 0.f, 0.f};
-        if (m < p.M && n0 < p.N)
-          for (int sp = 0; sp < p.splits; ++sp) v += *reinterpret_cast<const floatx4*>(p.ws + ((size_t)sp * p.M + m) * p.N + n0);
-        acc[tn][tm] = v;
+        acc[tn][tm] = (m < p.M && n0 < p.N) ? *reinterpret_cast<const floatx4*>(p.ws + (size_t)m * p.N + n0) : floatx4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    for (int sp = 1; sp < p.splits; ++sp) {
+      const float* slab = p.ws + (size_t)sp * p.M * p.N;
+#pragma unroll
+      for (int th = 0; th < TM; th += 2) {
+        floatx4 part[TN][2];
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) {
+          const int tm = th + t2;
+          const int m = tile_m * BM + wm * WM + tm * 16 + fr;
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn) {
+            const int n0 = tile_n * BN + wn * WN + tn * 16 + 4 * fq;
+            part[tn][t2] = (m < p.M && n0 < p.N) ? *reinterpret_cast<const floatx4*>(slab + (size_t)m * p.N + n0) : floatx4{0.f, 0.f, 0.f, 0.f};
+          }
+        }
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn) acc[tn][th + t2] += part[tn][t2];
       }
     }
   }
@@ -430,7 +451,7 @@ int launch(const GemmDev& p0, hipStream_t stream) {
   p.kt_per_split = (nk + p.splits - 1) / p.splits;
   p.splits = (nk + p.kt_per_split - 1) / p.kt_per_split;  // no empty split
   const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(half_t);
-  if (p.counters && (EPI != EPI_STD || p.splits <= 1 || tiles_m * p.tiles_n > AF_SPLITK_MAX_TILES)) p.counters = nullptr;
+  if (p.counters && (EPI != EPI_STD || p.splits <= 1 || p.splits > 4 || tiles_m * p.tiles_n > AF_SPLITK_MAX_TILES)) p.counters = nullptr;
   dim3 grid(tiles_m * p.tiles_n, p.splits), block(256);
   hipLaunchKernelGGL((af_gemm_kernel<BM, BN, TAPS, EPI, FAST>), grid, block, lds, stream, p);
   if (EPI == EPI_STD && p.splits > 1 && p.counters == nullptr) {

@@ -103,7 +103,7 @@ __device__ __forceinline__ void gemm3_epilogue(const Gemm3Dev& p, floatx4 (&acc)
         }
       }
     }
-    if (p.counters == nullptr) return;               // the caller runs af_splitk_reduce_kernel
+    if (TN > 5 || p.counters == nullptr) return;      // the caller runs af_splitk_reduce_kernel (TN > 5: tiles that never split)
     // ---- in-kernel reduction (no second launch): every K-slice publishes its slab, the LAST slice to arrive at the tile's counter
     // sums all slabs in slice order (the same order as the reduce kernel: bit-identical results, independent of arrival order)
     // and runs the epilogue.  Hand-off = the counter form of the agent-scope release / acquire protocol (cdna_hip_programming.md,
@@ -126,16 +126,37 @@ __device__ __forceinline__ void gemm3_epilogue(const Gemm3Dev& p, floatx4 (&acc)
     }
     __syncthreads();
     if (!*last_flag) return;
+    // The slabs were written through to memory, so every load is a full round trip: issue them in big batches.  Slice 0 lands
+    // directly in the (now dead) accumulators, all TN x TM fragments in flight at once; every further slice is added from a
+    // half-tile of temporaries.  Summation order = slice order, as in af_splitk_reduce_kernel (0 + s0 == s0 exactly).
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
       const int m = tile_m * BM + wm * 64 + tm * 16 + fr;
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn) {
         const int n0 = tile_n * BN + wn * TN * 16 + tn * 16 + 4 * fq;
-        floatx4 v = {0.f, 0.f, 0.f, 0.f};
-        if (m < p.M && n0 < p.N)
-          for (int sp = 0; sp < p.splits; ++sp) v += *reinterpret_cast<const floatx4*>(p.ws + ((size_t)sp * p.M + m) * p.N + n0);
-        acc[tn][tm] = v;
+        acc[tn][tm] = (m < p.M && n0 < p.N) ? *reinterpret_cast<const floatx4*>(p.ws + (size_t)m * p.N + n0) : floatx4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    for (int sp = 1; sp < p.splits; ++sp) {
+      const float* slab = p.ws + (size_t)sp * p.M * p.N;
+#pragma unroll
+      for (int th = 0; th < TM; th += 2) {
+        floatx4 part[TN][2];
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) {
+          const int tm = th + t2;
+          const int m = tile_m * BM + wm * 64 + tm * 16 + fr;
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn) {
+            const int n0 = tile_n * BN + wn * TN * 16 + tn * 16 + 4 * fq;
+            part[tn][t2] = (m < p.M && n0 < p.N) ? *reinterpret_cast<const floatx4*>(slab + (size_t)m * p.N + n0) : floatx4{0.f, 0.f, 0.f, 0.f};
+          }
+        }
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn) acc[tn][th + t2] += part[tn][t2];
       }
     }
     // fall through: acc now holds the full sums, the ordinary epilogue follows
@@ -495,7 +516,7 @@ bool launch3(const Gemm3Dev& p0, hipStream_t stream) {
   p.tiles_n = (p.N + BN - 1) / BN;
   const int tiles_m = (p.M + BM - 1) / BM;
   p.tiles_m = tiles_m;
-  if (p.counters && (p.splits <= 1 || tiles_m * p.tiles_n > AF_SPLITK_MAX_TILES)) p.counters = nullptr;
+  if (p.counters && (TN > 5 || p.splits <= 1 || p.splits > 4 || tiles_m * p.tiles_n > AF_SPLITK_MAX_TILES)) p.counters = nullptr;
   p.n_major = af_gemm_n_major(p.M, p.N, p.K, TAPS == 9 ? p.c1 + p.c2 : p.K);
   static bool attr_set = false;
   if (lds > 65536 && !attr_set) {
@@ -657,9 +678,26 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void af_gem
   // AF_GEMM3_ABLATE bits 128 / 256 switch the priority pair / the late DMA OFF (A/B runs).
   const bool prio = NW == 8 && (p.ablate & 128) == 0;
   const bool late_dma = NW == 8 && (p.ablate & 256) == 0 && wave >= NW / 2;
+  // experiment (AF_GEMM3_ABLATE bit 512): skew the second half of the waves by one K half -- they READ the second K half's
+  // fragments before the barrier as everyone must (the slot is overwritten after it), but run its MFMAs after the barrier, under
+  // the first half's DMA issue and fragment reads
+  // (compiled in only with -DAF_GEMM3_SKEW=1: the deferred MFMAs keep both fragment sets live over the loop edge, +86 VGPRs)
+#ifndef AF_GEMM3_SKEW
+#define AF_GEMM3_SKEW 0
+#endif
+  const bool skew = AF_GEMM3_SKEW && NW == 8 && TN <= 5 && (p.ablate & 512) != 0 && wave >= NW / 2;
   for (int i = 0; i < nk; ++i) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // stage i (the only one in flight) has landed
     __builtin_amdgcn_s_barrier();                           // ... for every wave; everyone is done reading the other slot
+    if (skew && i > 0) {                                    // deferred MFMAs of stage i - 1, second K half (fragments are in registers)
+      if (prio) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+          acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[tn], xf[tm], acc[tn][tm], 0, 0, 0);
+      if (prio) __builtin_amdgcn_s_setprio(0);
+    }
     if (!late_dma && i + 1 < nk) issue_stage(kt_begin + i + 1, (i + 1) & 1);
     const char* As = af_smem + (i & 1) * STAGE;
     const char* Ws = As + BM * 128;
@@ -670,6 +708,10 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void af_gem
       for (int tn = 0; tn < TN; ++tn) wf[tn] = *reinterpret_cast<const half8_t*>(Ws + (wn * TN * 16 + tn * 16) * 128 + rd);
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm) xf[tm] = *reinterpret_cast<const half8_t*>(As + (wm * 64 + tm * 16) * 128 + rd);
+      if (kk == 1 && skew) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the fragments must be out of the slot before the next barrier
+        break;
+      }
       if (prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn)
@@ -679,6 +721,13 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void af_gem
       if (prio) __builtin_amdgcn_s_setprio(0);
       if (kk == 0 && late_dma && i + 1 < nk) issue_stage(kt_begin + i + 1, (i + 1) & 1);
     }
+  }
+  if (skew && nk > 0) {
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+        acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[tn], xf[tm], acc[tn][tm], 0, 0, 0);
   }
 
   gemm3_epilogue<EPI, NWM, NWN, TN, 2 * STAGE>(p, acc, af_smem, tile_m, tile_n, wm, wn, fr, fq, tid);
@@ -691,7 +740,7 @@ bool launch3w(const Gemm3Dev& p0, hipStream_t stream) {
   constexpr size_t lds = 2 * (size_t)(BM + BN) * 128;
   p.tiles_n = (p.N + BN - 1) / BN;
   p.tiles_m = (p.M + BM - 1) / BM;
-  if (p.counters && (p.splits <= 1 || p.tiles_m * p.tiles_n > AF_SPLITK_MAX_TILES)) p.counters = nullptr;
+  if (p.counters && (TN > 5 || p.splits <= 1 || p.splits > 4 || p.tiles_m * p.tiles_n > AF_SPLITK_MAX_TILES)) p.counters = nullptr;
   p.n_major = af_gemm_n_major(p.M, p.N, p.K, TAPS == 9 ? p.c1 + p.c2 : p.K);
   static bool attr_set = false;
   if (lds > 65536 && !attr_set) {

@@ -34,11 +34,26 @@ def main():
         pw = ops.pack_matrix(torch.randn(N, K, generator=g) * K ** -0.5, torch.randn(N, generator=g), dev)
         cases.append((f"gemm {M} {N} {K} t{tile} s{sp} act{act}", 2.0 * M * N * K,
                       lambda a=a, pw=pw, tile=tile, sp=sp, act=act: ops.gemm(a, pw, tile=tile, splits=sp, act=act)))
+    if os.environ.get("AF_EXP_SPLITK"):
+        # fused (in-kernel) vs two-launch split-K on the small / mid shapes where a split can pay: variant = SPLITK_FUSED_MAX (0 = never fuse)
+        cases, variants = [], [0, 4]
+        for M, N, K, tile, sp in ((2048, 1280, 1280, 8, 1), (2048, 1280, 1280, 8, 2), (2048, 1280, 1280, 2, 2), (8192, 640, 640, 8, 2), (512, 1280, 1280, 2, 1), (512, 1280, 1280, 2, 2),
+                                  (512, 1280, 1280, 2, 4), (388, 768, 768, 2, 1), (388, 768, 768, 2, 2), (388, 768, 768, 2, 4), (388, 3072, 768, 2, 2), (388, 768, 3072, 2, 4), (2048, 1280, 5120, 8, 3)):
+            a = rnd(M, K)
+            pw = ops.pack_matrix(torch.randn(N, K, generator=g) * K ** -0.5, torch.randn(N, generator=g), dev)
+            cases.append((f"gemm {M} {N} {K} t{tile} s{sp}", 2.0 * M * N * K, lambda a=a, pw=pw, tile=tile, sp=sp: ops.gemm(a, pw, tile=tile, splits=sp)))
+        for B, H, W, ci, co, tile, sp in ((8, 16, 16, 1280, 1280, 7, 4), (8, 32, 32, 640, 640, 7, 2), (8, 8, 8, 1280, 1280, 7, 4)):
+            x = rnd(B, H, W, ci)
+            pw = ops.pack_conv3x3(torch.randn(co, ci, 3, 3, generator=g) * (ci * 9) ** -0.5, torch.randn(co, generator=g), dev)
+            cases.append((f"conv {B}x{H}x{W} {ci}->{co} t{tile} s{sp}", 2.0 * B * H * W * co * ci * 9, lambda x=x, pw=pw, tile=tile, sp=sp: ops.conv3x3(x, pw, tile=tile, splits=sp)))
     res = {(n, v): [] for n, _, _ in cases for v in variants}
     for r in range(rounds):
         for name, fl, fn in cases:
             for v in variants:
-                os.environ["AF_GEMM3_ABLATE"] = str(v)
+                if os.environ.get("AF_EXP_SPLITK"):
+                    ops.SPLITK_FUSED_MAX = v
+                else:
+                    os.environ["AF_GEMM3_ABLATE"] = str(v)
                 res[(name, v)].append(timeit(fn, 20) * 1e3)
     print(f"{'shape':44s} " + " ".join(f"{'v' + str(v):>16s}" for v in variants) + "   (us median/min, TFLOP/s at median)")
     for name, fl, _ in cases:
