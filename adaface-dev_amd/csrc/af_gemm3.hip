@@ -675,29 +675,14 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void af_gem
   // Measured in one process (profiles/r02c_gemm_variants.txt): conv 8x64x64 320->320 69.1 -> 64.1 us, 640->320 146.1 -> 125.1,
   // GEGLU M32768 N2560 K320 112.0 -> 101.2, M32768 N320 K1280 34.5 -> 32.4; the 4-wave tile (partners belong to different
   // workgroups, not in lock step) gets 1 - 3 % slower with it, so it keeps the plain order.
-  // AF_GEMM3_ABLATE bits 128 / 256 switch the priority pair / the late DMA OFF (A/B runs).
+  // AF_GEMM3_ABLATE bits 128 / 256 switch the priority pair / the late DMA OFF (A/B runs).  Tried on top and dropped
+  // (profiles/r02e_gemm_skew.txt): skewing the partner waves by one K half (their second-half MFMAs run after the barrier, under
+  // the first half's DMA issue and reads) -- +86 VGPRs, faster on one shape, 5 - 17 % slower on four.
   const bool prio = NW == 8 && (p.ablate & 128) == 0;
   const bool late_dma = NW == 8 && (p.ablate & 256) == 0 && wave >= NW / 2;
-  // experiment (AF_GEMM3_ABLATE bit 512): skew the second half of the waves by one K half -- they READ the second K half's
-  // fragments before the barrier as everyone must (the slot is overwritten after it), but run its MFMAs after the barrier, under
-  // the first half's DMA issue and fragment reads
-  // (compiled in only with -DAF_GEMM3_SKEW=1: the deferred MFMAs keep both fragment sets live over the loop edge, +86 VGPRs)
-#ifndef AF_GEMM3_SKEW
-#define AF_GEMM3_SKEW 0
-#endif
-  const bool skew = AF_GEMM3_SKEW && NW == 8 && TN <= 5 && (p.ablate & 512) != 0 && wave >= NW / 2;
   for (int i = 0; i < nk; ++i) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // stage i (the only one in flight) has landed
     __builtin_amdgcn_s_barrier();                           // ... for every wave; everyone is done reading the other slot
-    if (skew && i > 0) {                                    // deferred MFMAs of stage i - 1, second K half (fragments are in registers)
-      if (prio) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
-          acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[tn], xf[tm], acc[tn][tm], 0, 0, 0);
-      if (prio) __builtin_amdgcn_s_setprio(0);
-    }
     if (!late_dma && i + 1 < nk) issue_stage(kt_begin + i + 1, (i + 1) & 1);
     const char* As = af_smem + (i & 1) * STAGE;
     const char* Ws = As + BM * 128;
@@ -708,10 +693,6 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void af_gem
       for (int tn = 0; tn < TN; ++tn) wf[tn] = *reinterpret_cast<const half8_t*>(Ws + (wn * TN * 16 + tn * 16) * 128 + rd);
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm) xf[tm] = *reinterpret_cast<const half8_t*>(As + (wm * 64 + tm * 16) * 128 + rd);
-      if (kk == 1 && skew) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the fragments must be out of the slot before the next barrier
-        break;
-      }
       if (prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn)
@@ -722,14 +703,6 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void af_gem
       if (kk == 0 && late_dma && i + 1 < nk) issue_stage(kt_begin + i + 1, (i + 1) & 1);
     }
   }
-  if (skew && nk > 0) {
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-      for (int tm = 0; tm < TM; ++tm)
-        acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[tn], xf[tm], acc[tn][tm], 0, 0, 0);
-  }
-
   gemm3_epilogue<EPI, NWM, NWN, TN, 2 * STAGE>(p, acc, af_smem, tile_m, tile_n, wm, wn, fr, fq, tid);
 }
 

@@ -147,8 +147,12 @@ def _splitk_workspace(device) -> torch.Tensor:
 
 
 # split-K with at most this many slices is reduced inside the GEMM launch by the last-arriving workgroup of each tile (one launch
-# instead of two); wider splits keep the separate, chip-wide reduce pass (a single workgroup would read too many slabs)
-SPLITK_FUSED_MAX = int(_os.environ.get("AF_SPLITK_FUSED_MAX", "4"))
+# instead of two: af_gemm_desc.splitk_fused).  MEASURED SLOWER than the chip-wide reduce pass on every shape of this path but two
+# tiny ones (profiles/r02e_splitk_fused.txt: e.g. M2048 N1280 K1280 x2: 29.1 vs 24.5 us, conv 8x16x16 1280->1280 x4: 89.3 vs
+# 78.3 us -- the one reducer workgroup per tile reads its slabs at a dependent-latency rate while the separate pass spreads them
+# over all CUs and the launch boundary costs only ~1.5 us under graph replay), so the default is 0 = never; the path stays
+# available (bit-identical results, tests/test_hip_kernels.py) for callers whose launch boundaries are expensive.
+SPLITK_FUSED_MAX = int(_os.environ.get("AF_SPLITK_FUSED_MAX", "0"))
 
 
 def _launch_gemm(d: "GemmDesc", device, what: str, tile: int = 0, splits: int = 0):
