@@ -26,6 +26,7 @@ EXPORTS = (
     "af_groupnorm_bwd", "af_layernorm_bwd", "af_geglu_fwd", "af_geglu_bwd", "af_sumpool2x2", "af_add_f16",
     "af_transpose_tokens", "af_cadamw_step", "af_attention_ex", "af_colsum", "af_quickgelu_fwd", "af_quickgelu_bwd",
     "af_scale_f32", "af_affine_prelu", "af_maxpool2x2", "af_global_avgpool", "af_se_residual_prelu", "af_axpy_f16", "af_dora_combine", "af_mul_f16", "af_im2col3x3", "af_colsum_tall", "af_softmax_rows", "af_attention_strided", "af_clamp_f32", "af_mask_pairs", "af_prefetch",
+    "af_xattn_scores", "af_xattn_softmax_pv", "af_xattn_softmax_pv_bwd", "af_xattn_rowmix", "af_xattn_colmix_ws_bytes", "af_xattn_colmix",
 )
 
 
@@ -136,6 +137,12 @@ def lib() -> C.CDLL:
     L.af_softmax_rows.argtypes = [vp, vp, i64, i32, vp]
     L.af_mask_pairs.argtypes = [vp, vp, i32, vp]
     L.af_prefetch.argtypes = [vp, i64, vp]
+    L.af_xattn_scores.argtypes = [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, f32, vp]
+    L.af_xattn_softmax_pv.argtypes = [vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, vp]
+    L.af_xattn_softmax_pv_bwd.argtypes = [vp, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp]
+    L.af_xattn_rowmix.argtypes = [vp, vp, i32, vp, i32, f32, i32, i32, i32, i32, i32, vp]
+    L.af_xattn_colmix_ws_bytes.argtypes = [i32, i32, i32, i32]
+    L.af_xattn_colmix.argtypes = [vp, vp, i32, vp, i32, f32, vp, i64, i32, i32, i32, i32, i32, vp]
     L.af_colsum.argtypes = [vp, vp, vp, i32, i32, i32, vp]
     L.af_colsum_tall.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp]
     L.af_quickgelu_fwd.argtypes = [vp, vp, i64, vp]
@@ -158,6 +165,7 @@ def lib() -> C.CDLL:
         if name != "af_last_error":
             getattr(L, name).restype = C.c_int
     L.af_attention_bwd_scratch_bytes.restype = C.c_int64
+    L.af_xattn_colmix_ws_bytes.restype = C.c_int64
     _lib = L
     return L
 

@@ -347,6 +347,59 @@ def attention_scores(q: torch.Tensor, k: torch.Tensor, *, B: int, Nq: int, L: in
     return score, prob
 
 
+# ---- explicit cross-attention (capture / score-rewrite path; csrc/af_xattn_explicit.hip) -- q [B*Nq, >=C], k / v [B*L, >=C] fp16 rows
+def _ld(t: torch.Tensor) -> int:
+    assert t.dim() == 2 and t.stride(1) == 1, "row-major 2-D operand expected"
+    return t.stride(0)
+
+
+def xattn_scores(q, k, *, B, Nq, L, heads, d, scale):
+    """score fp32 [B, heads, Nq, L] = scale * q k^T."""
+    _chk_f16(q, "xattn_scores.q")
+    _chk_f16(k, "xattn_scores.k")
+    score = torch.empty((B, heads, Nq, L), dtype=torch.float32, device=q.device)
+    _lib.check(_lib.lib().af_xattn_scores(_p(q), _ld(q), _p(k), _ld(k), _p(score), B, Nq, L, heads, d, float(scale), _stream()), "af_xattn_scores")
+    return score
+
+
+def xattn_softmax_pv(score, v, *, B, Nq, L, heads, d):
+    """(prob fp32 [B, heads, Nq, L], o fp16 [B*Nq, heads*d]) from (rewritten) scores."""
+    _chk_f16(v, "xattn_softmax_pv.v")
+    assert score.dtype == torch.float32 and score.is_contiguous() and tuple(score.shape) == (B, heads, Nq, L)
+    prob = torch.empty_like(score)
+    o = torch.empty((B * Nq, heads * d), dtype=F16, device=v.device)
+    _lib.check(_lib.lib().af_xattn_softmax_pv(_p(score), _p(v), _ld(v), _p(prob), _p(o), heads * d, B, Nq, L, heads, d, _stream()), "af_xattn_softmax_pv")
+    return prob, o
+
+
+def xattn_softmax_pv_bwd(prob, v, dout, dprob_ext, *, B, Nq, L, heads, d):
+    """dscore fp32 [B, heads, Nq, L]; dprob_ext: gradient arriving on the captured probabilities (fp32, same shape) or None."""
+    _chk_f16(dout, "xattn_softmax_pv_bwd.dout")
+    dscore = torch.empty_like(prob)
+    if dprob_ext is not None:
+        dprob_ext = dprob_ext.to(torch.float32).contiguous()
+    _lib.check(_lib.lib().af_xattn_softmax_pv_bwd(_p(prob), _p(v), _ld(v), _p(dout), _ld(dout), _p(dprob_ext), _p(dscore), B, Nq, L, heads, d,
+                                                  _stream()), "af_xattn_softmax_pv_bwd")
+    return dscore
+
+
+def xattn_rowmix(w, x, alpha, *, B, Nq, L, heads, d):
+    """out fp16 [B*Nq, heads*d] = alpha * w x  (w fp32 [B, heads, Nq, L], x fp16 [B*L, >=C])."""
+    out = torch.empty((B * Nq, heads * d), dtype=F16, device=x.device)
+    _lib.check(_lib.lib().af_xattn_rowmix(_p(w), _p(x), _ld(x), _p(out), heads * d, float(alpha), B, Nq, L, heads, d, _stream()), "af_xattn_rowmix")
+    return out
+
+
+def xattn_colmix(w, x, alpha, *, B, Nq, L, heads, d):
+    """out fp16 [B*L, heads*d] = alpha * w^T x  (x fp16 [B*Nq, >=C]): the reductions over the queries (dk, dv)."""
+    out = torch.empty((B * L, heads * d), dtype=F16, device=x.device)
+    nb = int(_lib.lib().af_xattn_colmix_ws_bytes(B, L, heads, d))
+    ws = torch.empty((nb // 4,), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().af_xattn_colmix(_p(w), _p(x), _ld(x), _p(out), heads * d, float(alpha), _p(ws), nb, B, Nq, L, heads, d, _stream()),
+               "af_xattn_colmix")
+    return out
+
+
 def make_keybias(mask: torch.Tensor, L: int) -> torch.Tensor:
     """mask [B, L] (nonzero = keep) -> fp32 [B, roundup(L, 64)] additive bias: 0 / -FLT_MAX
     (== masked_fill_(~mask, -finfo.max), attention.py:188-194)."""

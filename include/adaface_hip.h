@@ -194,6 +194,26 @@ int af_attention_bwd(const void* q, const void* k, const void* v, const void* o,
 int af_attention_scores(const void* q, const void* k, void* score, void* prob, int B, int Nq, int L, int heads,
                         int d, float scale, void* stream);
 
+/* ---- explicit cross-attention of the capture / score-rewrite path (adaface/diffusers_attn_lora_capture.py:79-139, 309-315) ----
+ * The captured cross-attention layers (22-24) materialise their scores so that they can be rewritten between the product and the
+ * softmax (SC/MC mixing, subject-token normalisation) and captured WITH gradients.  q [B*Nq, ldq], k / v [B*L, ldk / ldv] fp16
+ * row-major (head h = columns h*d ..), score / prob / dscore fp32 [B, heads, Nq, L] contiguous, L <= 128, d % 8 == 0.
+ *   af_xattn_scores          score = scale * q k^T
+ *   af_xattn_softmax_pv      prob = softmax_L(score);  o[B*Nq, ldo] = prob v                        (fp16)
+ *   af_xattn_softmax_pv_bwd  dscore = prob * (dP - sum_L prob dP),  dP = dout v^T (+ dprob_ext, the gradient arriving on a captured prob; may be NULL)
+ *   af_xattn_rowmix          out[B*Nq, ldout] = alpha * w x      (w fp32 [B,heads,Nq,L], x fp16 [B*L, ldx]):   dq = scale * dscore k
+ *   af_xattn_colmix          out[B*L, ldout]  = alpha * w^T x    (x fp16 [B*Nq, ldx]):   dv = prob^T dout,  dk = scale * dscore^T q;
+ *                            deterministic two-pass reduction over the queries through a caller-owned fp32 workspace             */
+#define AF_XATTN_COLMIX_CHUNKS 8
+int af_xattn_scores(const void* q, int ldq, const void* k, int ldk, void* score, int B, int Nq, int L, int heads, int d, float scale, void* stream);
+int af_xattn_softmax_pv(const void* score, const void* v, int ldv, void* prob, void* o, int ldo, int B, int Nq, int L, int heads, int d, void* stream);
+int af_xattn_softmax_pv_bwd(const void* prob, const void* v, int ldv, const void* dout, int lddo, const void* dprob_ext, void* dscore, int B, int Nq,
+                            int L, int heads, int d, void* stream);
+int af_xattn_rowmix(const void* w, const void* x, int ldx, void* out, int ldout, float alpha, int B, int Nq, int L, int heads, int d, void* stream);
+int64_t af_xattn_colmix_ws_bytes(int B, int L, int heads, int d);
+int af_xattn_colmix(const void* w, const void* x, int ldx, void* out, int ldout, float alpha, void* workspace, int64_t workspace_bytes, int B, int Nq,
+                    int L, int heads, int d, void* stream);
+
 /* ---- small element-wise kernels --------------------------------------------------------
  * timestep embedding [cos | sin] (util.py:154-174) -> fp16 [B, dim]                        */
 int af_timestep_embedding(const void* timesteps_i64, void* out, int B, int dim, float max_period, void* stream);
