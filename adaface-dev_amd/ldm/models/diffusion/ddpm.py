@@ -42,6 +42,11 @@ class UNetWrapper(nn.Module):
         self.ffn_lora = None                  # modules/dora.py::UNetLoRA (trainable adapters), see set_up_ffn_loras
         self._merged = (None, False)          # (ffn adapter name | None, attention LoRA on)
         self._merge_saved = {}
+        # learnable scale of the normalised subject-token scores, one per captured cross-attention layer (init 0.8,
+        # diffusers_attn_lora_capture.py:166-168), under the reference's unet_lora_modules key names (:512-514)
+        self.cross_attn_scale_factors = nn.ParameterDict({
+            f"up_blocks_3_attentions_{i}_transformer_blocks_0_attn2_processor_cross_attn_scale_factor": nn.Parameter(torch.tensor(0.8))
+            for i in range(3)})
 
     @property
     def dtype(self):
@@ -88,9 +93,18 @@ class UNetWrapper(nn.Module):
     def forward(self, x, t, cond_context, out_dtype=torch.float32):
         prompt_emb, prompt_in, extra_info = cond_context
         ei = extra_info or {}
-        if ei.get("normalize_cross_attn", False) or ei.get("mix_attn_mats_in_batch", False):
-            raise NotImplementedError("normalize_cross_attn / mix_attn_mats_in_batch rewrite the cross-attention scores of layers 22-24 "
-                                      "(diffusers_attn_lora_capture.py:108-133; SURVEY.md 8a row L3): not built in the HIP U-Net yet")
+        if extra_info is not None:
+            # read by the capture / score-rewrite pass (modules/diffusionmodules/capture_graph.py), ignored by the plain passes
+            extra_info["_cross_attn_scale_factors"] = list(self.cross_attn_scale_factors.values())
+        try:
+            return self._forward(x, t, cond_context, out_dtype)
+        finally:
+            if extra_info is not None:
+                extra_info.pop("_cross_attn_scale_factors", None)
+
+    def _forward(self, x, t, cond_context, out_dtype):
+        prompt_emb, prompt_in, extra_info = cond_context
+        ei = extra_info or {}
         want = (ei.get("ffn_lora_adapter_name") if ei.get("use_ffn_lora", False) else None, bool(ei.get("use_attn_lora", False)))
         training_pass = torch.is_grad_enabled() and (x.requires_grad or prompt_emb.requires_grad or
                                                      (self.ffn_lora is not None and any(p.requires_grad for p in self.ffn_lora.parameters())))

@@ -29,7 +29,7 @@ import math
 import torch
 import torch.nn.functional as F
 
-from .... import autograd_ops, ops
+from .... import ops
 from ....ops import F16
 from .util import from_nhwc_f16, to_nhwc_f16
 
@@ -270,13 +270,26 @@ class _NHWCToNCHW(torch.autograd.Function):
         return out, None, None
 
 
+class _FrozenLinearFn(torch.autograd.Function):
+    """y = x W^T + b of a FROZEN layer (the U-Net's base weights, ddpm.py:4131-4132): gradient to the input only."""
+
+    @staticmethod
+    def forward(ctx, x, mod):
+        ctx.mod = mod
+        return mod.hip(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ctx.mod.hip_dgrad(dy.to(F16).contiguous()), None
+
+
 # ----------------------------------------------------------------------------- the pass
 def _linear(mod, x, lora=None, generator=None):
     """frozen Linear with gradient to its input; `lora`: a DoRA linear adapter (modules/dora.py) trained through this call."""
     if lora is not None:
         from ..dora import dora_linear
         return dora_linear(mod, lora, x, generator=generator)
-    return autograd_ops.linear(mod, x)
+    return _FrozenLinearFn.apply(x, mod)
 
 
 def captured_cross_attention(attn2, qin, context2d, B, N, flags, loras=None):
@@ -287,7 +300,7 @@ def captured_cross_attention(attn2, qin, context2d, B, N, flags, loras=None):
     C, heads, d = attn2.inner_dim, attn2.heads, attn2.dim_head
     L = context2d.shape[0] // B
     scale = attn2.scale
-    q = autograd_ops.linear(attn2.to_q, qin)
+    q = _linear(attn2.to_q, qin)
     q2 = q
     if "q" in loras:                               # the q LoRA feeds query2 only, unless q_lora_updates_query (:239-249)
         q2 = _linear(attn2.to_q, qin, loras["q"])
@@ -339,8 +352,10 @@ def unet_forward_captured(unet, x, timesteps, context, extra_info, n_tail=3):
             kb = ops.make_keybias(F.interpolate(img_mask.float(), size=(H, W), mode="nearest").reshape(B, N), N)
         x1, qin = _STPreFn.apply(st, h, kb)
         attn2 = st.transformer_blocks[0].attn2
+        factors = ei.get("_cross_attn_scale_factors")            # the wrapper's learnable factors (init 0.8, :168); plain 0.8 without a wrapper
+        factor = factors[ti] if factors is not None else torch.tensor(0.8, device=x.device)
         flags = dict(normalize_cross_attn=ei.get("normalize_cross_attn", False), mix_attn_mats_in_batch=ei.get("mix_attn_mats_in_batch", False),
-                     subj_indices=ei.get("subj_indices"), cross_attn_scale_factor=unet.cross_attn_scale_factors[ti],
+                     subj_indices=ei.get("subj_indices"), cross_attn_scale_factor=factor,
                      q_lora_updates_query=ei.get("q_lora_updates_query", False))
         ao, caps = captured_cross_attention(attn2, qin, ctx2d, B, N, flags, attn_loras.get(bi))
         x2 = ao + x1

@@ -540,6 +540,46 @@ class UNetModel(nn.Module):
         g, st = self.out[0].hip_train(h, silu=True)
         return self.out[2].hip(g), (saved_in, saved_mid, saved_out, h, st, context.shape)
 
+    def hip_train_trunk(self, x_nhwc, emb, context, img_mask, n_tail):
+        """hip_train without the last ``n_tail`` decoder blocks and the output head (modules/diffusionmodules/capture_graph.py):
+        -> (h, [the skips those blocks will pop, in pop order], saved)."""
+        saved_in, saved_out, hs = [], [], []
+        h = x_nhwc
+        for module in self.input_blocks:
+            h, s = module.hip_train(h, emb, context, img_mask)
+            saved_in.append(s)
+            hs.append(h)
+        h, saved_mid = self.middle_block.hip_train(h, emb, context, img_mask)
+        for module in list(self.output_blocks)[:len(self.output_blocks) - n_tail]:
+            h, s = module.hip_train(SkipCat((h, hs.pop())), emb, context, img_mask)
+            saved_out.append(s)
+        skips = [hs.pop() for _ in range(n_tail)]
+        assert not hs
+        return h, skips, (saved_in, saved_mid, saved_out, context.shape)
+
+    def hip_bwd_trunk(self, saved, dh, dskips_tail, need_dx=True, res_gradscale=1.0):
+        """Backward of hip_train_trunk: dh = gradient of h, dskips_tail[i] = gradient of the i-th popped skip (already scaled by the
+        tail where the live path scales it) or None.  Same walk as hip_bwd."""
+        saved_in, saved_mid, saved_out, ctx_shape = saved
+        n_in, n_out, n_tail = len(self.input_blocks), len(self.output_blocks), len(dskips_tail)
+        d, dctx = dh, None
+        dskips = {}
+        for k, g in enumerate(dskips_tail):                      # the k-th tail block popped hs[n_tail - 1 - k]
+            dskips[n_tail - 1 - k] = (g, False)
+        blocks = list(self.output_blocks)[:n_out - n_tail]
+        for oi in range(len(blocks) - 1, -1, -1):
+            (d, dskip), dctx = blocks[oi].hip_bwd(saved_out[oi], d, dctx)
+            dskips[n_in - 1 - oi] = (dskip, res_gradscale != 1.0 and oi >= self.num_res_blocks + 1)
+        d, dctx = self.middle_block.hip_bwd(saved_mid, d, dctx)
+        for i in range(n_in - 1, -1, -1):
+            g, scaled = dskips[i]
+            if g is not None:
+                d = ops.axpy(d, g, res_gradscale) if scaled else ops.add(d, g)
+            if i == 0 and not need_dx:
+                return None, dctx.reshape(ctx_shape)
+            d, dctx = self.input_blocks[i].hip_bwd(saved_in[i], d, dctx)
+        return d, dctx.reshape(ctx_shape)
+
     def hip_bwd(self, saved, deps_nhwc, need_dx=True, res_gradscale=1.0):
         """Activation-gradient backward: deps [B,H,W,roundup(out_channels,8)] fp16 (zero padded) ->
         (dx [B,H,W,in_channels] or None, dcontext [B,L,ctx] fp16).  Skip-connection gradients from the
@@ -575,9 +615,23 @@ class UNetModel(nn.Module):
         old_flags = None
         if capture:
             old_flags, _ = self.set_cross_attn_flags(ca_flag_dict={"save_cross_attn_vars": True}, ca_layer_indices=captured)
-        if torch.is_grad_enabled() and (x.requires_grad or context.requires_grad or (extra_info or {}).get("_ffn_lora_adapters")):
+        ei = extra_info or {}
+        rewrites = bool(ei.get("normalize_cross_attn", False) or ei.get("mix_attn_mats_in_batch", False))
+        trainable = torch.is_grad_enabled() and (x.requires_grad or context.requires_grad or ei.get("_ffn_lora_adapters")
+                                                 or ei.get("_attn_lora_adapters"))
+        if rewrites or ei.get("_attn_lora_adapters") or (capture and trainable):
+            # Stage-2 pass: explicit attention in the last three cross-attention layers (score rewrites, captures with gradients,
+            # attention LoRAs) as a chain of autograd nodes -- modules/diffusionmodules/capture_graph.py
+            from .capture_graph import unet_forward_captured
+            if extra_info is None:
+                raise ValueError("extra_info must be a dict on the capture / score-rewrite path")
             if capture:
-                raise NotImplementedError("capture_ca_activations together with gradients (Stage-2 losses) is SURVEY.md 8f rank 4")
+                self.set_cross_attn_flags(ca_flag_dict=old_flags, ca_layer_indices=captured)     # this path does its own capturing
+            eps = unet_forward_captured(self, x, timesteps, context, extra_info)
+            if not capture:
+                extra_info.pop("ca_layers_activations", None)
+            return eps
+        if trainable:
             gs = float((extra_info or {}).get("res_hidden_states_gradscale", 1) or 1)
             lora = (extra_info or {}).get("_ffn_lora_adapters")           # set by UNetWrapper when use_ffn_lora is on
             return _UNetFunction.apply(self, x, timesteps, context, img_mask, gs, lora, *[t[3] for t in lora_param_order(lora)])

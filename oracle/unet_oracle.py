@@ -65,19 +65,35 @@ def attention_core(q, k, v, heads, mask=None, want_probs=False):
     return out
 
 
-def cross_attention(sd, p, x, context=None, mask=None, heads=8, capture=None):
-    """CrossAttention.forward, attention.py:168-222.  `capture`: dict to fill or None."""
+def cross_attention(sd, p, x, context=None, mask=None, heads=8, capture=None, rewrite=None):
+    """CrossAttention.forward, attention.py:168-222.  `capture`: dict to fill or None.  `rewrite`: the live path's explicit attention
+    of the captured layers (adaface/diffusers_attn_lora_capture.py:79-139, 309-315, 344-362; pinned through oracle/capture_oracle.py):
+    dict with normalize_cross_attn / mix_attn_mats_in_batch / subj_indices / cross_attn_scale_factor -- the scores are rewritten
+    between the product and the softmax, and q2 / k / v are captured as well."""
     q = F.linear(x, sd[p + "to_q.weight"])
     ctx = x if context is None else context
     k = F.linear(ctx, sd[p + "to_k.weight"])
     v = F.linear(ctx, sd[p + "to_v.weight"])
     m = None if mask is None else mask.reshape(mask.shape[0], -1)
-    core, attn, score = attention_core(q, k, v, heads, m, want_probs=True)
+    d = q.shape[-1] // heads
+    if rewrite is not None and capture is not None:
+        from . import capture_oracle as C
+        b, n, Cq = q.shape
+        split = lambda t: t.reshape(b, t.shape[1], heads, d).permute(0, 2, 1, 3)
+        o, score, attn = C.scaled_dot_product_attention(split(q), split(k), split(v), rewrite.get("cross_attn_scale_factor", torch.tensor(0.8)),
+                                                        subj_indices=rewrite.get("subj_indices"),
+                                                        normalize_cross_attn=bool(rewrite.get("normalize_cross_attn", False)),
+                                                        mix_attn_mats_in_batch=bool(rewrite.get("mix_attn_mats_in_batch", False)))
+        core = o.permute(0, 2, 1, 3).reshape(b, n, Cq)
+    else:
+        core, attn, score = attention_core(q, k, v, heads, m, want_probs=True)
     out = F.linear(core, sd[p + "to_out.0.weight"], sd[p + "to_out.0.bias"])
     if capture is not None:
-        d = q.shape[-1] // heads
         s = math.sqrt(d ** -0.5)
         capture["q"] = q.permute(0, 2, 1).contiguous() * s          # attention.py:212
+        capture["q2"] = capture["q"]                                 # no q LoRA: query2 = query (diffusers_attn_lora_capture.py:250)
+        capture["k"] = k.permute(0, 2, 1).contiguous() * s
+        capture["v"] = v.permute(0, 2, 1).contiguous() * s
         capture["attn"] = attn.contiguous()                          # :217
         capture["attnscore"] = score.contiguous()                    # :218
         capture["attn_out"] = out.permute(0, 2, 1).contiguous()      # :220
@@ -92,16 +108,16 @@ def geglu_ff(sd, p, x):
     return F.linear(h, sd[p + "net.2.weight"], sd[p + "net.2.bias"])
 
 
-def basic_transformer_block(sd, p, x, context, mask, heads, capture=None):
+def basic_transformer_block(sd, p, x, context, mask, heads, capture=None, rewrite=None):
     """BasicTransformerBlock._forward, attention.py:242-252 (LayerNorm eps 1e-5)."""
     C = x.shape[-1]
     ln = lambda t, n: F.layer_norm(t, (C,), sd[p + n + ".weight"], sd[p + n + ".bias"], 1e-5)
     x1 = cross_attention(sd, p + "attn1.", ln(x, "norm1"), None, mask, heads) + x
-    x2 = x1 + cross_attention(sd, p + "attn2.", ln(x1, "norm2"), context, None, heads, capture)
+    x2 = x1 + cross_attention(sd, p + "attn2.", ln(x1, "norm2"), context, None, heads, capture, rewrite)
     return geglu_ff(sd, p + "ff.", ln(x2, "norm3")) + x2
 
 
-def spatial_transformer(sd, p, x, context, mask, heads, capture=None):
+def spatial_transformer(sd, p, x, context, mask, heads, capture=None, rewrite=None):
     """SpatialTransformer.forward, attention.py:287-304."""
     b, c, h, w = x.shape
     x_in = x
@@ -111,7 +127,7 @@ def spatial_transformer(sd, p, x, context, mask, heads, capture=None):
     mask2 = None
     if mask is not None:
         mask2 = F.interpolate(mask, size=(h, w), mode="nearest")         # attention.py:298
-    y = basic_transformer_block(sd, p + "transformer_blocks.0.", y, context, mask2, heads, capture)
+    y = basic_transformer_block(sd, p + "transformer_blocks.0.", y, context, mask2, heads, capture, rewrite)
     y = y.reshape(b, h, w, c).permute(0, 3, 1, 2)
     y = conv2d(y, sd[p + "proj_out.weight"], sd[p + "proj_out.bias"], padding=0)
     return y + x_in
@@ -209,7 +225,14 @@ def unet_forward(sd, cfg, x, timesteps, context, extra_info=None):
                 h = res_block(sd, p, h, emb, (extra_info.get("ffn_lora") or {}).get(p))
             elif kind == "attn":
                 cap = {} if (capture_on and layer_idx in CAPTURED_LAYERS) else None
-                h = spatial_transformer(sd, p, h, context, img_mask, heads, cap)
+                rw = None
+                if layer_idx in CAPTURED_LAYERS and (extra_info.get("normalize_cross_attn") or extra_info.get("mix_attn_mats_in_batch")):
+                    cap = {} if cap is None else cap
+                    factors = extra_info.get("cross_attn_scale_factors")
+                    rw = dict(normalize_cross_attn=extra_info.get("normalize_cross_attn", False), subj_indices=extra_info.get("subj_indices"),
+                              mix_attn_mats_in_batch=extra_info.get("mix_attn_mats_in_batch", False),
+                              cross_attn_scale_factor=factors[CAPTURED_LAYERS.index(layer_idx)] if factors is not None else torch.tensor(0.8))
+                h = spatial_transformer(sd, p, h, context, img_mask, heads, cap, rw)
             elif kind == "down":
                 h = conv2d(h, sd[p + "op.weight"], sd[p + "op.bias"], stride=2)     # :135-161
             elif kind == "up":
@@ -242,7 +265,7 @@ def unet_forward(sd, cfg, x, timesteps, context, extra_info=None):
 
     extra_info["ca_layers_activations"] = {                                        # :931-935
         key: {li: acts[li][key] for li in acts}
-        for key in ("outfeat", "attn", "attnscore", "q", "attn_out")
+        for key in ("outfeat", "attn", "attnscore", "q", "q2", "k", "v", "attn_out")
     }
     h = group_norm(h, sd["out.0.weight"], sd["out.0.bias"], 1e-5, silu=True)
     return conv2d(h, sd["out.2.weight"], sd["out.2.bias"])
