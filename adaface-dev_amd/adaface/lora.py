@@ -66,11 +66,12 @@ def extract_adapter(state_dict, target, adapter_name):
 
 @torch.no_grad()
 def merge_unet_loras(unet, lora_state_dict, adapter_name="unet_distill", use_ffn_lora=True, use_attn_lora=False, lora_rank=None,
-                     ffn_lora_alpha=16, attn_lora_scale_down=8):
+                     ffn_lora_alpha=16, attn_lora_scale_down=8, q_lora_updates_query=False):
     """Merge the named adapter into `unet` (this package's UNetModel) in place.  Returns {ldm_path: original weight} for
     `unmerge_unet_loras`.  Layers without an entry in the state dict are left untouched.  scaling = lora_alpha / rank with the
     reference's alphas (FFN: 16; attention: rank // 8, diffusers_attn_lora_capture.py:497-502, 541); the rank is read from
-    lora_A unless given."""
+    lora_A unless given.  The q adapter of the attention layers is merged only with ``q_lora_updates_query``: by default
+    (ddpm.py:134) it feeds the captured ``query2`` alone and leaves the attention output untouched (:239-249)."""
     saved = {}
     groups = []
     if use_ffn_lora:
@@ -79,6 +80,8 @@ def merge_unet_loras(unet, lora_state_dict, adapter_name="unet_distill", use_ffn
         groups.append((ATTN_LORA_TARGETS, lambda r: (r // attn_lora_scale_down) / r))
     for targets, scale_of in groups:
         for dname, lpath in targets.items():
+            if targets is ATTN_LORA_TARGETS and dname.endswith(".to_q") and not q_lora_updates_query:
+                continue
             ad = extract_adapter(lora_state_dict, dname, adapter_name)
             if ad is None:
                 continue

@@ -102,17 +102,46 @@ class UNetWrapper(nn.Module):
             if extra_info is not None:
                 extra_info.pop("_cross_attn_scale_factors", None)
 
+    def set_up_attn_loras(self, layer_names=("q", "k", "v", "out"), lora_rank=192, lora_scale_down=8, lora_dropout=0.1,
+                          q_lora_updates_query=False):
+        """Reference ``set_up_attn_processors`` with ``use_attn_lora`` (diffusers_attn_lora_capture.py:451-537): trainable DoRA adapters
+        on to_q / to_k / to_v / to_out.0 of the three captured cross-attention layers.  Call after the U-Net is on its device."""
+        from ...modules.dora import UNetAttnLoRA
+        self.attn_lora = UNetAttnLoRA(self.diffusion_model, layer_names, lora_rank, lora_scale_down, lora_dropout)
+        self.attn_lora.to(next(self.diffusion_model.parameters()).device)
+        self.q_lora_updates_query = q_lora_updates_query
+        return self.attn_lora
+
+    attn_lora = None
+    q_lora_updates_query = False
+
     def _forward(self, x, t, cond_context, out_dtype):
         prompt_emb, prompt_in, extra_info = cond_context
         ei = extra_info or {}
         want = (ei.get("ffn_lora_adapter_name") if ei.get("use_ffn_lora", False) else None, bool(ei.get("use_attn_lora", False)))
+        if want[1] and self.attn_lora is not None:
+            # module-held attention adapters: applied UN-merged by the explicit attention of the capture pass, with or without
+            # gradients (the q adapter feeds query2 only, the others key / value / output: diffusers_attn_lora_capture.py:239-288, 328-331)
+            extra_info["_attn_lora_adapters"] = self.attn_lora.active()
+            extra_info["q_lora_updates_query"] = self.q_lora_updates_query
+            want = (want[0], False)
+            try:
+                return self._forward_ffn(x, t, cond_context, out_dtype, want)
+            finally:
+                extra_info.pop("_attn_lora_adapters", None)
+        return self._forward_ffn(x, t, cond_context, out_dtype, want)
+
+    def _forward_ffn(self, x, t, cond_context, out_dtype, want):
+        prompt_emb, prompt_in, extra_info = cond_context
+        ei = extra_info or {}
         training_pass = torch.is_grad_enabled() and (x.requires_grad or prompt_emb.requires_grad or
                                                      (self.ffn_lora is not None and any(p.requires_grad for p in self.ffn_lora.parameters())))
         if want != (None, False) and training_pass:
             # TRAINING through the adapters: un-merged base weights + the DoRA branch with gradients (modules/dora.py)
             if want[1]:
-                raise NotImplementedError("training the attention LoRAs is not built (Stage 1 never enables them, ddpm.py:3130-3132)")
-            if self.ffn_lora is None:
+                raise RuntimeError("use_attn_lora in a training pass needs module-held adapters (UNetWrapper.set_up_attn_loras); "
+                                   "adapters loaded from a state dict are inference-only (merged)")
+            if want[0] is not None and self.ffn_lora is None:
                 raise RuntimeError("use_ffn_lora requested in a training pass but no trainable adapters exist (UNetWrapper.set_up_ffn_loras)")
             self._set_loras((None, False))
             extra_info["_ffn_lora_adapters"] = self.ffn_lora.active(want[0])

@@ -180,3 +180,125 @@ class UNetLoRA(nn.Module):
                         key = f"{target}.{pname}.{name}"
                     if key in sd:
                         getattr(ad, pname).copy_(sd[key].reshape(getattr(ad, pname).shape))
+
+
+# ----------------------------------------------------------------------------- attention LoRAs (Linear layers)
+class DoRALinearAdapter(nn.Module):
+    """peft DoRA adapter of one ``nn.Linear`` (the to_q / to_k / to_v / to_out.0 projections of the captured cross-attention layers;
+    reference ``AttnProcessor_LoRA_Capture.__init__`` diffusers_attn_lora_capture.py:171-181: rank 192, alpha rank // 8, dropout 0.1).
+    Parameters are stored like peft's Linear adapter: lora_A [r, Cin], lora_B [Cout, r], lora_magnitude_vector [Cout]."""
+
+    def __init__(self, linear, rank=192, lora_alpha=24, lora_dropout=0.1, generator=None):
+        super().__init__()
+        from ...adaface.lora import init_dora_adapter
+        a, b, m = init_dora_adapter(linear.weight, rank, generator)
+        self.lora_A, self.lora_B, self.lora_magnitude_vector = nn.Parameter(a), nn.Parameter(b), nn.Parameter(m)
+        self.rank, self.scaling, self.p = rank, lora_alpha / rank, lora_dropout
+
+    def _packs(self):
+        key = (ops.param_key(self.lora_A), ops.param_key(self.lora_B))
+        if getattr(self, "_pack_key", None) != key:
+            dev = self.lora_A.device
+            A, Bm = self.lora_A.detach(), self.lora_B.detach()
+            self._pk = (ops.pack_matrix(A, None, dev), ops.pack_matrix(A.t().contiguous(), None, dev), ops.pack_matrix(Bm, None, dev),
+                        ops.pack_matrix(Bm.t().contiguous(), None, dev))
+            self._pack_key = key
+        return self._pk
+
+    def scales(self, linear):
+        w = linear.weight.detach().float()
+        norm = (w + self.scaling * (self.lora_B.detach().float() @ self.lora_A.detach().float())).norm(dim=1)
+        s = self.lora_magnitude_vector.detach().float() / norm
+        return (s - 1).contiguous(), (s * self.scaling).contiguous(), norm
+
+    def draw_mask(self, shape, device, generator=None):
+        if not self.training or self.p == 0:
+            return None
+        keep = torch.rand(shape, device=device, generator=generator) >= self.p
+        return (keep.to(torch.float32) / (1 - self.p)).to(F16)
+
+
+class _DoRALinearFn(torch.autograd.Function):
+    """y = base(x) + (s - 1) * (xd W^T) + s * scaling * (xd A^T) B^T with xd = dropout(x) -- peft's DoraLinearLayer in training form,
+    the 1x1 case of dora_conv_fwd / dora_conv_bwd: three af_gemm launches + af_dora_combine forward, the transposed GEMMs, weight
+    gradients as GEMMs over tokens and column sums backward.  Gradients: x, lora_A, lora_B, lora_magnitude_vector."""
+
+    @staticmethod
+    def forward(ctx, x, lora_A, lora_B, lora_m, linear, ad, mask):
+        y0 = linear.hip(x)
+        xd = x if mask is None else ops.mul(x, mask)
+        pa, _, pb, _ = ad._packs()
+        pw = linear.packed()
+        c2 = ops.gemm(xd, ops.PackedWeight(pw.wt, None, pw.N, pw.K, pw.kpad, pw.taps, pw.cin))
+        t = ops.gemm(xd, pa)
+        lb = ops.gemm(t, pb)
+        u, v, norm = ad.scales(linear)
+        M, cout = c2.shape
+        y = ops.dora_combine(y0.reshape(1, 1, M, cout), c2.reshape(1, 1, M, cout), lb.reshape(1, 1, M, cout), u, v).reshape(M, cout)
+        ctx.linear, ctx.ad, ctx.saved = linear, ad, (xd, c2, lb, t, mask, u, v, norm)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        linear, ad = ctx.linear, ctx.ad
+        xd, c2, lb, t, mask, u, v, norm = ctx.saved
+        dy = dy.to(F16).contiguous()
+        M, cout = dy.shape
+        zeros = torch.zeros_like(u)
+        _, pa_t, _, pb_t = ad._packs()
+        dy4 = dy.reshape(1, 1, M, cout)
+        dc2 = ops.affine_prelu(dy4, u, zeros).reshape(M, cout)
+        dlb = ops.affine_prelu(dy4, v, zeros).reshape(M, cout)
+        dt = ops.gemm(dlb, pb_t)
+        dxd = ops.add(linear.hip_dgrad(dc2), ops.gemm(dt, pa_t))
+        if mask is not None:
+            dxd = ops.mul(dxd, mask)
+        dx = ops.add(linear.hip_dgrad(dy), dxd)
+        dB = wgrad(dlb, t).float().reshape(ad.lora_B.shape)
+        dA = wgrad(dt, xd).float().reshape(ad.lora_A.shape)
+        dm = (ops.colsum(dy, c2) + ad.scaling * ops.colsum(dy, lb)) / norm
+        ctx.saved = None
+        return dx, dA.to(ad.lora_A.dtype), dB.to(ad.lora_B.dtype), dm.to(ad.lora_magnitude_vector.dtype), None, None, None
+
+
+def dora_linear(linear, ad, x, generator=None):
+    """x [M, Cin] fp16 -> [M, Cout] through ``linear`` with the trainable DoRA adapter ``ad`` (dropout mask drawn here)."""
+    return _DoRALinearFn.apply(x, ad.lora_A, ad.lora_B, ad.lora_magnitude_vector, linear, ad, ad.draw_mask(x.shape, x.device, generator))
+
+
+class UNetAttnLoRA(nn.Module):
+    """The attention DoRA adapters of one U-Net: q / k / v / out of the cross-attention of the last three output blocks (diffusers
+    ``up_blocks.3.attentions.{0,1,2}``; reference ``set_up_attn_processors`` diffusers_attn_lora_capture.py:451-537), keys as in the
+    reference's ``unet_lora_modules``: ``up_blocks_3_attentions_<i>_transformer_blocks_0_attn2_processor_to_<q|k|v|out>_lora``."""
+
+    LAYERS = (("q", lambda a: a.to_q), ("k", lambda a: a.to_k), ("v", lambda a: a.to_v), ("out", lambda a: a.to_out[0]))
+
+    def __init__(self, unet, layer_names=("q", "k", "v", "out"), rank=192, lora_scale_down=8, lora_dropout=0.1):
+        super().__init__()
+        n_out = len(unet.output_blocks)
+        self.blocks = (n_out - 3, n_out - 2, n_out - 1)
+        self.adapters = nn.ModuleDict()
+        for i, bi in enumerate(self.blocks):
+            attn2 = unet.output_blocks[bi][1].transformer_blocks[0].attn2
+            for name, get in self.LAYERS:
+                if name in layer_names:
+                    self.adapters[f"up_blocks_3_attentions_{i}_transformer_blocks_0_attn2_processor_to_{name}_lora"] = DoRALinearAdapter(
+                        get(attn2), rank, rank // lora_scale_down, lora_dropout)
+
+    def active(self):
+        """{output-block index: {'q' | 'k' | 'v' | 'out': adapter}} (what the capture graph consumes)."""
+        out = {}
+        for k, ad in self.adapters.items():
+            i, name = int(k.split("_")[4]), k.split("_to_")[1].split("_")[0]
+            out.setdefault(self.blocks[i], {})[name] = ad
+        return out
+
+    def peft_state_dict(self, adapter_name="default"):
+        sd = {}
+        for k, ad in self.adapters.items():
+            i, name = int(k.split("_")[4]), k.split("_to_")[1].split("_")[0]
+            target = f"up_blocks.3.attentions.{i}.transformer_blocks.0.attn2." + ("to_out.0" if name == "out" else f"to_{name}")
+            sd[f"{target}.lora_A.{adapter_name}.weight"] = ad.lora_A.detach()
+            sd[f"{target}.lora_B.{adapter_name}.weight"] = ad.lora_B.detach()
+            sd[f"{target}.lora_magnitude_vector.{adapter_name}.weight"] = ad.lora_magnitude_vector.detach()
+        return sd

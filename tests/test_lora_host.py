@@ -63,5 +63,9 @@ def test_merge_and_unmerge_on_unet_module_tree():
     assert L.merge_unet_loras(unet, sd, "recon_loss") == {}                                  # adapter not in the state dict: no-op
     L.unmerge_unet_loras(unet, saved)
     assert all(torch.equal(v, before[k]) for k, v in unet.state_dict().items())
+    # the attention q adapter only feeds the captured query2 by default (q_lora_updates_query=False, ddpm.py:134): not merged
     saved2 = L.merge_unet_loras(unet, sd, "unet_distill", use_ffn_lora=False, use_attn_lora=True)
+    assert set(saved2) == {v for k, v in L.ATTN_LORA_TARGETS.items() if not k.endswith(".to_q")}
+    L.unmerge_unet_loras(unet, saved2)
+    saved2 = L.merge_unet_loras(unet, sd, "unet_distill", use_ffn_lora=False, use_attn_lora=True, q_lora_updates_query=True)
     assert set(saved2) == set(L.ATTN_LORA_TARGETS.values())
