@@ -353,10 +353,16 @@ def _ld(t: torch.Tensor) -> int:
     return t.stride(0)
 
 
+def _chk_f16_rows(t: torch.Tensor, name: str):
+    """fp16 device matrix whose rows are contiguous (a column slice of a wider buffer is fine: the kernels take leading dimensions)."""
+    if t.dtype != F16 or not t.is_cuda or t.dim() != 2 or t.stride(1) != 1 or t.stride(0) % 8 != 0 or t.data_ptr() % 16 != 0:
+        raise RuntimeError(f"{name}: expected an fp16 device matrix with contiguous, 16-byte aligned rows, got {t.dtype} {t.device} strides {t.stride()}")
+
+
 def xattn_scores(q, k, *, B, Nq, L, heads, d, scale):
     """score fp32 [B, heads, Nq, L] = scale * q k^T."""
-    _chk_f16(q, "xattn_scores.q")
-    _chk_f16(k, "xattn_scores.k")
+    _chk_f16_rows(q, "xattn_scores.q")
+    _chk_f16_rows(k, "xattn_scores.k")
     score = torch.empty((B, heads, Nq, L), dtype=torch.float32, device=q.device)
     _lib.check(_lib.lib().af_xattn_scores(_p(q), _ld(q), _p(k), _ld(k), _p(score), B, Nq, L, heads, d, float(scale), _stream()), "af_xattn_scores")
     return score
@@ -364,7 +370,7 @@ def xattn_scores(q, k, *, B, Nq, L, heads, d, scale):
 
 def xattn_softmax_pv(score, v, *, B, Nq, L, heads, d):
     """(prob fp32 [B, heads, Nq, L], o fp16 [B*Nq, heads*d]) from (rewritten) scores."""
-    _chk_f16(v, "xattn_softmax_pv.v")
+    _chk_f16_rows(v, "xattn_softmax_pv.v")
     assert score.dtype == torch.float32 and score.is_contiguous() and tuple(score.shape) == (B, heads, Nq, L)
     prob = torch.empty_like(score)
     o = torch.empty((B * Nq, heads * d), dtype=F16, device=v.device)
@@ -374,7 +380,7 @@ def xattn_softmax_pv(score, v, *, B, Nq, L, heads, d):
 
 def xattn_softmax_pv_bwd(prob, v, dout, dprob_ext, *, B, Nq, L, heads, d):
     """dscore fp32 [B, heads, Nq, L]; dprob_ext: gradient arriving on the captured probabilities (fp32, same shape) or None."""
-    _chk_f16(dout, "xattn_softmax_pv_bwd.dout")
+    _chk_f16_rows(dout, "xattn_softmax_pv_bwd.dout")
     dscore = torch.empty_like(prob)
     if dprob_ext is not None:
         dprob_ext = dprob_ext.to(torch.float32).contiguous()
