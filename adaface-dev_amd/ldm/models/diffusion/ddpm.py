@@ -40,6 +40,8 @@ class UNetWrapper(nn.Module):
         self.unet_lora_modules = nn.ModuleDict()
         self.unet_lora_state_dict = None
         self.ffn_lora = None                  # modules/dora.py::UNetLoRA (trainable adapters), see set_up_ffn_loras
+        self.attn_lora = None                 # modules/dora.py::UNetAttnLoRA (trainable attention adapters), see set_up_attn_loras
+        self.q_lora_updates_query = False
         self._merged = (None, False)          # (ffn adapter name | None, attention LoRA on)
         self._merge_saved = {}
         # learnable scale of the normalised subject-token scores, one per captured cross-attention layer (init 0.8,
@@ -111,9 +113,6 @@ class UNetWrapper(nn.Module):
         self.attn_lora.to(next(self.diffusion_model.parameters()).device)
         self.q_lora_updates_query = q_lora_updates_query
         return self.attn_lora
-
-    attn_lora = None
-    q_lora_updates_query = False
 
     def _forward(self, x, t, cond_context, out_dtype):
         prompt_emb, prompt_in, extra_info = cond_context

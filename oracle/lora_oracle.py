@@ -32,3 +32,12 @@ def dora_conv2d_train(x, weight, bias, lora_A, lora_B, magnitude, scaling, mask=
     xd = x if mask is None else x * mask
     base = F.conv2d(x, weight, bias, stride, padding)
     return base + (s - 1) * F.conv2d(xd, weight, None, stride, padding) + s * F.conv2d(F.conv2d(xd, lora_A, None, stride, padding), lora_B) * scaling
+
+
+def dora_linear_train(x, weight, bias, lora_A, lora_B, magnitude, scaling, mask=None):
+    """Training-mode DoRA Linear (peft ``lora.Linear.forward`` with ``use_dora``: ``result = base(x); x = dropout(x);
+    result += dora(x)``), explicit dropout mask; the weight norm is detached."""
+    weight_norm = torch.linalg.norm(weight + scaling * (lora_B @ lora_A).detach(), dim=1).detach()
+    s = (magnitude / weight_norm).view(1, -1)
+    xd = x if mask is None else x * mask
+    return F.linear(x, weight, bias) + (s - 1) * F.linear(xd, weight) + s * F.linear(F.linear(xd, lora_A), lora_B) * scaling

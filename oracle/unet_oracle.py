@@ -72,8 +72,20 @@ def cross_attention(sd, p, x, context=None, mask=None, heads=8, capture=None, re
     between the product and the softmax, and q2 / k / v are captured as well."""
     q = F.linear(x, sd[p + "to_q.weight"])
     ctx = x if context is None else context
-    k = F.linear(ctx, sd[p + "to_k.weight"])
-    v = F.linear(ctx, sd[p + "to_v.weight"])
+    loras = (rewrite or {}).get("attn_lora") or {}                # {'q' | 'k' | 'v' | 'out': (A, B, magnitude, scaling)}, no dropout
+
+    def proj(name, inp, wkey, bkey=None):
+        from . import lora_oracle as LO
+        bias = None if bkey is None else sd[p + bkey]
+        if name in loras:
+            A, Bm, mag, scaling = loras[name]
+            return LO.dora_linear_train(inp, sd[p + wkey], bias, A, Bm, mag, scaling)
+        return F.linear(inp, sd[p + wkey], bias)
+    q2 = proj("q", x, "to_q.weight") if "q" in loras else q      # the q adapter feeds query2 only (:239-249)
+    if (rewrite or {}).get("q_lora_updates_query"):
+        q = q2
+    k = proj("k", ctx, "to_k.weight")
+    v = proj("v", ctx, "to_v.weight")
     m = None if mask is None else mask.reshape(mask.shape[0], -1)
     d = q.shape[-1] // heads
     if rewrite is not None and capture is not None:
@@ -87,11 +99,11 @@ def cross_attention(sd, p, x, context=None, mask=None, heads=8, capture=None, re
         core = o.permute(0, 2, 1, 3).reshape(b, n, Cq)
     else:
         core, attn, score = attention_core(q, k, v, heads, m, want_probs=True)
-    out = F.linear(core, sd[p + "to_out.0.weight"], sd[p + "to_out.0.bias"])
+    out = proj("out", core, "to_out.0.weight", "to_out.0.bias")
     if capture is not None:
         s = math.sqrt(d ** -0.5)
         capture["q"] = q.permute(0, 2, 1).contiguous() * s          # attention.py:212
-        capture["q2"] = capture["q"]                                 # no q LoRA: query2 = query (diffusers_attn_lora_capture.py:250)
+        capture["q2"] = q2.permute(0, 2, 1).contiguous() * s         # query2 = query without a q LoRA (diffusers_attn_lora_capture.py:250)
         capture["k"] = k.permute(0, 2, 1).contiguous() * s
         capture["v"] = v.permute(0, 2, 1).contiguous() * s
         capture["attn"] = attn.contiguous()                          # :217
@@ -226,12 +238,14 @@ def unet_forward(sd, cfg, x, timesteps, context, extra_info=None):
             elif kind == "attn":
                 cap = {} if (capture_on and layer_idx in CAPTURED_LAYERS) else None
                 rw = None
-                if layer_idx in CAPTURED_LAYERS and (extra_info.get("normalize_cross_attn") or extra_info.get("mix_attn_mats_in_batch")):
+                al = (extra_info.get("attn_lora") or {}).get(layer_idx)
+                if layer_idx in CAPTURED_LAYERS and (extra_info.get("normalize_cross_attn") or extra_info.get("mix_attn_mats_in_batch") or al):
                     cap = {} if cap is None else cap
                     factors = extra_info.get("cross_attn_scale_factors")
                     rw = dict(normalize_cross_attn=extra_info.get("normalize_cross_attn", False), subj_indices=extra_info.get("subj_indices"),
                               mix_attn_mats_in_batch=extra_info.get("mix_attn_mats_in_batch", False),
-                              cross_attn_scale_factor=factors[CAPTURED_LAYERS.index(layer_idx)] if factors is not None else torch.tensor(0.8))
+                              cross_attn_scale_factor=factors[CAPTURED_LAYERS.index(layer_idx)] if factors is not None else torch.tensor(0.8),
+                              attn_lora=al, q_lora_updates_query=extra_info.get("q_lora_updates_query", False))
                 h = spatial_transformer(sd, p, h, context, img_mask, heads, cap, rw)
             elif kind == "down":
                 h = conv2d(h, sd[p + "op.weight"], sd[p + "op.bias"], stride=2)     # :135-161

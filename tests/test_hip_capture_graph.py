@@ -147,3 +147,71 @@ def test_unet_score_rewrite_without_capture_and_without_grad(dev):
     assert rel_l2(eps.cpu().numpy(), ref.numpy()) < NET_TOL
     plain = O.unet_forward(sd, GPU_TINY_CONFIG, x, t, ctx, {})
     assert rel_l2(ref.numpy(), plain.numpy()) > 1e-3                       # the rewrite really changes the result
+
+
+@pytest.mark.parametrize("q_updates", [False, True])
+def test_unet_attention_dora_training_gradients_vs_oracle(dev, q_updates):
+    """Trainable attention DoRA adapters on to_q / to_k / to_v / to_out.0 of the three captured cross-attention layers
+    (diffusers_attn_lora_capture.py:171-181, 239-249, 280-288, 328-331): the q adapter feeds the captured query2 only (unless
+    q_lora_updates_query), the others key / value / output.  eps, q / q2 captures, d/dcontext and the gradients of all 36 adapter
+    tensors against autograd through the oracle with the same adapters (dropout 0)."""
+    from adaface_dev_amd import rng
+    from adaface_dev_amd.ldm.models.diffusion.ddpm import LatentDiffusion
+    from oracle import unet_oracle as O
+    ld = LatentDiffusion(GPU_TINY_CONFIG)
+    rng.load_synth_weights(ld.model.diffusion_model, seed=11)
+    sd = {k: v.detach().clone() for k, v in ld.model.diffusion_model.state_dict().items()}
+    ld = ld.to(dev)
+    for p in ld.model.diffusion_model.parameters():
+        p.requires_grad_(False)
+    lora = ld.model.set_up_attn_loras(lora_rank=16, lora_scale_down=8, lora_dropout=0.0, q_lora_updates_query=q_updates)
+    with torch.no_grad():
+        for n, p in lora.named_parameters():
+            if "lora_B" in n:
+                p.copy_(rng.synth_input(n, p.shape, seed=83, scale=0.3))
+            if "magnitude" in n:
+                p.mul_(1.0 + 0.1 * rng.synth_input(n, p.shape, seed=83).to(dev).abs())
+    B, Hh, T = 2, 16, 20
+    x = rng.synth_input("cg.x", (B, 4, Hh, Hh), seed=12)
+    ctx = rng.synth_input("cg.ctx", (B, T, 64), seed=12)
+    t = torch.tensor([30, 620])
+    # oracle side: the same adapters as fp32 leaf tensors
+    ref_lora, leaves = {}, {}
+    for bi, d in lora.active().items():
+        li = 22 + (bi - 9)
+        ref_lora[li] = {}
+        for name, ad in d.items():
+            ts = [getattr(ad, pn).detach().cpu().float().clone().requires_grad_(True) for pn in ("lora_A", "lora_B", "lora_magnitude_vector")]
+            ref_lora[li][name] = (ts[0], ts[1], ts[2], ad.scaling)
+            leaves[(bi, name)] = ts
+    cr = ctx.clone().requires_grad_(True)
+    ei_ref = dict(capture_ca_activations=True, attn_lora=ref_lora, q_lora_updates_query=q_updates)
+    ref = O.unet_forward(sd, GPU_TINY_CONFIG, x, t, cr, ei_ref)
+    racts = ei_ref["ca_layers_activations"]
+    w_eps = rng.synth_input("al.w.eps", tuple(ref.shape), seed=12)
+    w_q2 = {li: rng.synth_input(f"al.w.q2{li}", tuple(racts["q2"][li].shape), seed=12) for li in (22, 23, 24)}
+    loss_of = lambda e, a, we, wq: (e * we).sum() + sum((a["q2"][li].float() * wq[li]).sum() * 0.05 for li in (22, 23, 24))
+    loss_of(ref, racts, w_eps, w_q2).backward()
+
+    cg = ctx.clone().to(dev).requires_grad_(True)
+    ei = dict(capture_ca_activations=True)
+    eps = ld.apply_model(x.to(dev), t.to(dev), (cg, ["a", "b"], ei), use_attn_lora=True)
+    acts = ei["ca_layers_activations"]
+    assert rel_l2(eps.detach().cpu().numpy(), ref.detach().numpy()) < NET_TOL
+    for li in (22, 23, 24):
+        assert rel_l2(acts["q2"][li].detach().cpu().numpy(), racts["q2"][li].detach().numpy()) < 2 * NET_TOL
+        same = torch.equal(acts["q"][li], acts["q2"][li])
+        assert same == q_updates                                   # query2 differs from query unless the adapter updates the query
+    S = 256.0
+    (loss_of(eps, acts, w_eps.to(dev), {k: v.to(dev) for k, v in w_q2.items()}) * S).backward()
+    assert rel_l2((cg.grad / S).cpu().numpy(), cr.grad.numpy()) < GRAD_TOL
+    worst = 0.0
+    for bi, d in lora.active().items():
+        for name, ad in d.items():
+            for pn, leaf in zip(("lora_A", "lora_B", "lora_magnitude_vector"), leaves[(bi, name)]):
+                g = getattr(ad, pn).grad
+                assert g is not None, (bi, name, pn)
+                err = rel_l2((g / S).cpu().numpy(), leaf.grad.numpy())
+                worst = max(worst, err)
+                assert err < 2 * GRAD_TOL, (bi, name, pn, err)
+    print(f"attention DoRA: worst adapter-gradient rel-L2 {worst:.2e}")
