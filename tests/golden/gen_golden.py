@@ -783,6 +783,74 @@ def gen_distill_loss(out):
     print("distill_loss:", {k: float(v) for k, v in res.items() if k.endswith(".loss")})
 
 
+
+def comp_loss_inputs(device="cpu"):
+    """Seeded stand-ins for captured activations of a four-block Stage-2 batch (BLOCK_SIZE 1: [SS, SC, SC-rep, MC]), layers 22-24:
+    attention probabilities [4, 8, 64, 20] (rows softmaxed), k / v [4, 32, 20], out features [4, 32, 8, 8]; 4 subject tokens."""
+    from adaface_dev_amd import rng
+    B4, H, N, L, C = 4, 8, 64, 20, 32
+    acts = {"attn": {}, "k": {}, "v": {}, "outfeat": {}}
+    for li in (22, 23, 24):
+        acts["attn"][li] = torch.softmax(rng.synth_input(f"cl.attn{li}", (B4, H, N, L), seed=71) * 1.5, dim=-1).to(device).requires_grad_(True)
+        acts["k"][li] = rng.synth_input(f"cl.k{li}", (B4, C, L), seed=71).to(device).requires_grad_(True)
+        acts["v"][li] = rng.synth_input(f"cl.v{li}", (B4, C, L), seed=71).to(device).requires_grad_(True)
+        acts["outfeat"][li] = rng.synth_input(f"cl.of{li}", (B4, C, 8, 8), seed=71).to(device)
+    future = {"attn": {li: torch.softmax(rng.synth_input(f"cl.fattn{li}", (B4, H, N, L), seed=71), dim=-1).to(device) for li in (22, 23, 24)}}
+    subj_1b = (torch.zeros(4, dtype=torch.long, device=device), torch.tensor([4, 5, 6, 7], device=device))
+    subj_2b = (torch.tensor([0, 0, 0, 0, 1, 1, 1, 1], device=device), torch.tensor([4, 5, 6, 7, 4, 5, 6, 7], device=device))
+    emb_mask = torch.zeros(B4, L, 1, device=device)
+    emb_mask[:, 1:12] = 1
+    emb_mask[1, 12:15] = 1
+    pad_mask = torch.zeros(B4, L, 1, device=device)
+    pad_mask[:, 16:] = 1
+    fg_mask = torch.zeros(B4, 1, 16, 16, device=device)
+    fg_mask[:, :, 3:11, 4:13] = 1
+    return acts, future, subj_1b, subj_2b, emb_mask, pad_mask, fg_mask
+
+
+def gen_comp_losses(out):
+    """REFERENCE ldm/util.py loss functions on the captured-activation stand-ins: values and gradients w.r.t. attn / k / v."""
+    import ldm.util as RU
+    res = {}
+
+    def grads(acts, tag):
+        for key in ("attn", "k", "v"):
+            for li in (23, 24):
+                g = acts[key][li].grad
+                res[f"{tag}.d{key}{li}"] = np.zeros(1, np.float32) if g is None else g.numpy()
+
+    for pct in (0.05, 0.15, 0.22, 0.3):
+        acts, future, s1, s2, em, pm, fg = comp_loss_inputs()
+        ls = RU.calc_sc_rep_attn_distill_loss(acts, s1, em, pm, pct, FG_THRES=0.1)
+        res[f"rep{pct}.values"] = np.asarray([float(v) for v in ls], dtype=np.float64)
+        if pct >= 0.1:
+            sum(ls).backward()
+            grads(acts, f"rep{pct}")
+    acts, future, s1, s2, em, pm, fg = comp_loss_inputs()
+    l = RU.calc_subj_attn_cross_t_diff_loss(acts, future, s1)
+    l.backward()
+    res["crosst.value"] = np.asarray(float(l))
+    grads(acts, "crosst")
+    acts, future, s1, s2, em, pm, fg = comp_loss_inputs()
+    l = RU.calc_attn_norm_loss(acts["outfeat"], acts["attn"], s2, 1)
+    l.backward()
+    res["attnnorm.value"] = np.asarray(float(l))
+    grads(acts, "attnnorm")
+    acts, future, s1, s2, em, pm, fg = comp_loss_inputs()
+    # as called by calc_comp_face_align_and_mb_suppress_losses (ddpm.py:3701-3707): the SC block's attention, the SC face mask
+    sc_attn = {li: a.chunk(4)[1] for li, a in acts["attn"].items()}
+    l = RU.calc_subj_masked_bg_suppress_loss(sc_attn, s1, 1, fg[:1])
+    l.backward()
+    res["mbsuppress.value"] = np.asarray(float(l))
+    grads(acts, "mbsuppress")
+    res["mbsuppress.allfg"] = np.asarray(float(RU.calc_subj_masked_bg_suppress_loss(sc_attn, s1, 1, torch.ones_like(fg[:1]))))
+    xs = np.asarray([0.0, 0.1, 0.2, 0.22, 0.25, 0.5])
+    res["dyn.x"] = xs
+    res["dyn.scale"] = np.asarray([RU.calc_dyn_loss_scale(x, (0.20, 0.5), (0.25, 2), valid_scale_range=(0.05, 2)) for x in xs])
+    np.savez_compressed(os.path.join(out, "comp_losses.npz"), **res)
+    print("comp_losses:", {k: v.tolist() for k, v in res.items() if k.endswith("values") or k.endswith(".value")})
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-full", action="store_true")
@@ -793,7 +861,8 @@ def main():
     out = HERE
     # host-orchestration fixtures: the reference's ddpm.py / unet_teachers.py / diffusers_attn_lora_capture.py are imported with
     # EMPTY stand-ins for their absent third-party packages (tests/golden/ref_import.py)
-    host_jobs = {"teacher": gen_teacher, "sdpa": gen_sdpa, "guided_denoise": gen_guided_denoise, "distill_loss": gen_distill_loss}
+    host_jobs = {"teacher": gen_teacher, "sdpa": gen_sdpa, "guided_denoise": gen_guided_denoise, "distill_loss": gen_distill_loss,
+                 "comp_losses": gen_comp_losses}
     if args.only in host_jobs or args.only is None:
         sys.path.insert(0, HERE)
         sys.path.insert(0, os.path.dirname(HERE))
