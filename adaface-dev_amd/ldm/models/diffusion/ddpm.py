@@ -436,6 +436,46 @@ class LatentDiffusion(nn.Module):
         x_recon = self.predict_start_from_noise(x_noisy, t=t, noise=noise_pred) if do_pixel_recon else None
         return noise_pred, x_recon, ca_layers_activations
 
+    def comp_distill_multistep_denoise(self, x_starts, noises, ts, subj_context, uncond_emb, all_subj_indices_1b=None,
+                                       normalize_cross_attn=False, mix_sc_mc_attn=False, cfg_scale=2.5, num_denoising_steps=4,
+                                       old_x_starts_mix_ratio=0.3, use_attn_lora=False, use_ffn_lora=False, ffn_lora_adapter_name=None,
+                                       BLKS=4, batch_part_has_grad="subject-compos"):
+        """The denoising chain of a compositional-distillation iteration (reference ddpm.py:1997-2086): ``num_denoising_steps``
+        guided_denoise passes over the four-block batch with activation capture; each step's x0 prediction (detached) seeds the next
+        step -- mixed with the caller's earlier x_start when one is given -- at an earlier timestep drawn in
+        [t * 0.5^p, t * 0.7^p], p = (steps - 1)^-0.3, with ONE noise / timestep shared by the four blocks.  ``x_starts``, ``noises``,
+        ``ts`` are lists that are extended in place, as in the reference.  LoRAs are off on every instance while SC / MC attention
+        is mixed."""
+        assert num_denoising_steps <= 10
+        use_attn_lora = use_attn_lora and (not mix_sc_mc_attn)
+        use_ffn_lora = use_ffn_lora and (not mix_sc_mc_attn)
+        noise_preds, x_recons, acts_list = [], [], []
+        for i in range(num_denoising_steps):
+            x_start, t, noise = x_starts[i], ts[i], noises[i]
+            noise_pred, x_recon, acts = self.guided_denoise(
+                x_start, noise, t, subj_context, uncond_emb, img_mask=None, subj_indices=all_subj_indices_1b,
+                normalize_cross_attn=normalize_cross_attn, mix_sc_mc_attn=mix_sc_mc_attn, batch_part_has_grad=batch_part_has_grad,
+                do_pixel_recon=True, cfg_scale=cfg_scale, capture_ca_activations=True,
+                res_hidden_states_gradscale=self.res_hidden_states_gradscale, use_attn_lora=use_attn_lora, use_ffn_lora=use_ffn_lora,
+                ffn_lora_adapter_name=ffn_lora_adapter_name)
+            noise_preds.append(noise_pred)
+            x_recons.append(x_recon)
+            acts_list.append(acts)
+            if i < num_denoising_steps - 1:
+                if len(noises) <= i + 1:
+                    noise = torch.randn_like(x_start.chunk(BLKS)[0]).repeat(BLKS, 1, 1, 1)
+                    t0 = t.chunk(BLKS)[0]
+                    rand_ts = torch.rand_like(t0.float())
+                    p = np.power(num_denoising_steps - 1, -0.3)
+                    t_lb, t_ub = t0 * np.power(0.5, p), t0 * np.power(0.7, p)
+                    ts.append(((t_ub - t_lb) * rand_ts + t_lb).long().repeat(BLKS))
+                    noises.append(noise)
+                if len(x_starts) <= i + 1:
+                    x_starts.append(x_recon.detach())
+                else:
+                    x_starts[i + 1] = x_starts[i + 1] * old_x_starts_mix_ratio + x_recon.detach() * (1 - old_x_starts_mix_ratio)
+        return noise_preds, x_starts, x_recons, noises, ts, acts_list
+
     def sliced_apply_model(self, x_noisy, t, cond_context, slice_indices, enable_grad, use_attn_lora=False, use_ffn_lora=False,
                            ffn_lora_adapter_name=None):
         """apply_model on the instances ``slice_indices`` of the batch, with or without gradient (reference ddpm.py:1572-1587)."""

@@ -851,6 +851,49 @@ def gen_comp_losses(out):
     print("comp_losses:", {k: v.tolist() for k, v in res.items() if k.endswith("values") or k.endswith(".value")})
 
 
+
+def gen_comp_multistep(out):
+    """REFERENCE ``LatentDiffusion.comp_distill_multistep_denoise`` (ddpm.py:1997-2086) around the stand-in wrapper: 3 steps on a
+    four-block batch, subject-compos gradient mode; (a) timesteps / noises drawn inside (seeded), (b) a second pass re-using the first
+    pass's x_starts (the 'old x_start' mixing), with SC / MC attention mixing (LoRAs forced off)."""
+    import json
+    from adaface_dev_amd import rng
+    from standin import StandInEps, StandInWrapper
+    B, h, T, D = 4, 8, 6, 16
+    res = {}
+    wrapper = StandInWrapper(StandInEps(D, seed=61))
+    un = rng.synth_input("cm.uncond", (B, T, D), seed=67)
+    ld = _ref_ddpm_shell(model=wrapper, uncond_context=(un[:1], [""], {}), res_hidden_states_gradscale=0.5)
+    x0 = rng.synth_input("cm.x0", (1, 4, h, h), seed=67).repeat(B, 1, 1, 1)
+    noise = rng.synth_input("cm.noise", (1, 4, h, h), seed=67).repeat(B, 1, 1, 1)
+    emb = rng.synth_input("cm.emb", (B, T, D), seed=67).requires_grad_(True)
+    t = torch.tensor([900]).repeat(B)
+    subj = (torch.tensor([0, 0]), torch.tensor([2, 3]))
+    for tag, kw, reuse in (("draw", dict(normalize_cross_attn=True, mix_sc_mc_attn=False, use_attn_lora=True, use_ffn_lora=True), False),
+                           ("mix_reuse", dict(normalize_cross_attn=False, mix_sc_mc_attn=True, use_attn_lora=True, use_ffn_lora=True), True)):
+        wrapper.calls.clear()
+        if not reuse:
+            x_starts, noises, ts = [x0], [noise], [t]
+        else:
+            x_starts, noises, ts = [x.clone() for x in keep[0]], list(keep[1]), list(keep[2])
+        torch.manual_seed(97)
+        preds, xs, recons, ns, tss, acts = ld.comp_distill_multistep_denoise(x_starts, noises, ts, (emb, [f"p{i}" for i in range(B)], {}), un,
+                                                                            all_subj_indices_1b=subj, cfg_scale=2.5, num_denoising_steps=3,
+                                                                            ffn_lora_adapter_name="comp_distill", **kw)
+        keep = ([x.clone() for x in xs], list(ns), list(tss))
+        for i in range(3):
+            res[f"{tag}.eps{i}"], res[f"{tag}.recon{i}"] = preds[i].detach().numpy(), recons[i].detach().numpy()
+            res[f"{tag}.x{i}"], res[f"{tag}.t{i}"], res[f"{tag}.noise{i}"] = xs[i].numpy(), tss[i].numpy(), ns[i].numpy()
+            res[f"{tag}.attn{i}"] = acts[i]["attn"].detach().numpy()
+        if emb.grad is not None:
+            emb.grad = None
+        sum(p.sum() for p in preds).backward()
+        res[f"{tag}.demb"] = emb.grad.numpy().copy()
+        res[f"{tag}.calls"] = np.asarray(json.dumps([[n, fl, ad, npr, ge] for n, fl, ad, npr, ge in wrapper.calls]))
+    np.savez_compressed(os.path.join(out, "comp_multistep.npz"), **res)
+    print("comp_multistep:", [res[f"draw.t{i}"].tolist() for i in range(3)], len(json.loads(str(res["draw.calls"]))))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-full", action="store_true")
@@ -862,7 +905,7 @@ def main():
     # host-orchestration fixtures: the reference's ddpm.py / unet_teachers.py / diffusers_attn_lora_capture.py are imported with
     # EMPTY stand-ins for their absent third-party packages (tests/golden/ref_import.py)
     host_jobs = {"teacher": gen_teacher, "sdpa": gen_sdpa, "guided_denoise": gen_guided_denoise, "distill_loss": gen_distill_loss,
-                 "comp_losses": gen_comp_losses}
+                 "comp_losses": gen_comp_losses, "comp_multistep": gen_comp_multistep}
     if args.only in host_jobs or args.only is None:
         sys.path.insert(0, HERE)
         sys.path.insert(0, os.path.dirname(HERE))

@@ -119,3 +119,66 @@ def test_calc_unet_distill_loss_mirror_vs_reference(dev, steps, pcfg):
         assert abs(float(ld.unet_teacher.cfg_scale) - float(g[f"{k}.cfg_scale"])) < 1e-12
         assert abs(float(loss.detach()) - float(g[f"{k}.loss"])) < 1e-5 * abs(float(g[f"{k}.loss"])), (batched, float(loss.detach()), float(g[f"{k}.loss"]))
         assert rel_l2(i["emb"].grad.cpu().numpy(), g[f"{k}.demb"]) < 2e-5, batched
+
+
+def test_comp_distill_multistep_denoise_mirror_vs_reference(dev):
+    """``LatentDiffusion.comp_distill_multistep_denoise`` (ddpm.py:1997-2086): three subject-compos denoising steps with capture on the
+    four-block batch -- per-step eps / x0 / next x_start / timestep / noise / captured attention, d/d(prompt_emb) and the per-call flag
+    log; first with the timesteps and noises drawn inside (the reference's draws are replayed from its seed on the CPU generator and
+    handed over), then re-using the first pass's trajectory (old-x_start mixing) with SC / MC attention mixing (all LoRAs off)."""
+    import json
+    from adaface_dev_amd import rng
+    g = np.load(os.path.join(GOLDEN, "comp_multistep.npz"))
+    B, h, T, D = 4, 8, 6, 16
+    wrapper = StandInWrapper(StandInEps(D, seed=61))
+    ld = _ld(dev, wrapper)
+    un = rng.synth_input("cm.uncond", (B, T, D), seed=67).to(dev)
+    ld.uncond_context = (un[:1], [""], {})
+    ld.res_hidden_states_gradscale = 0.5
+    x0 = rng.synth_input("cm.x0", (1, 4, h, h), seed=67).repeat(B, 1, 1, 1).to(dev)
+    noise = rng.synth_input("cm.noise", (1, 4, h, h), seed=67).repeat(B, 1, 1, 1).to(dev)
+    emb = rng.synth_input("cm.emb", (B, T, D), seed=67).to(dev).requires_grad_(True)
+    t = torch.tensor([900]).repeat(B).to(dev)
+    subj = (torch.tensor([0, 0], device=dev), torch.tensor([2, 3], device=dev))
+    keep = None
+    for tag, kw, reuse in (("draw", dict(normalize_cross_attn=True, mix_sc_mc_attn=False, use_attn_lora=True, use_ffn_lora=True), False),
+                           ("mix_reuse", dict(normalize_cross_attn=False, mix_sc_mc_attn=True, use_attn_lora=True, use_ffn_lora=True), True)):
+        wrapper.calls.clear()
+        if not reuse:
+            # the draws happen on the GPU generator here; feed the reference's (recorded) noises / timesteps instead, which the method accepts
+            x_starts = [x0]
+            noises = [torch.from_numpy(g[f"{tag}.noise{i}"]).to(dev) for i in range(3)]
+            ts = [torch.from_numpy(g[f"{tag}.t{i}"]).to(dev) for i in range(3)]
+        else:
+            x_starts, noises, ts = [x.clone() for x in keep[0]], list(keep[1]), list(keep[2])
+        torch.manual_seed(97)                              # the FFN-LoRA coin of every subject-compos pass: CPU generator, as in the reference
+        if not reuse:
+            # the reference consumed extra CPU draws (randn / rand for the next step) between the coins; replay them to stay aligned
+            real_gd = ld.guided_denoise
+            step = {"i": 0}
+
+            def gd(*a, **k):
+                out = real_gd(*a, **k)
+                if step["i"] < 2:
+                    torch.randn(1, 4, h, h)
+                    torch.rand(1)
+                step["i"] += 1
+                return out
+            ld.guided_denoise = gd
+        preds, xs, recons, ns, tss, acts = ld.comp_distill_multistep_denoise(x_starts, noises, ts, (emb, [f"p{i}" for i in range(B)], {}), un,
+                                                                            all_subj_indices_1b=subj, cfg_scale=2.5, num_denoising_steps=3,
+                                                                            ffn_lora_adapter_name="comp_distill", **kw)
+        if not reuse:
+            ld.guided_denoise = real_gd
+        keep = ([x.clone() for x in xs], list(ns), list(tss))
+        for i in range(3):
+            assert np.array_equal(tss[i].cpu().numpy(), g[f"{tag}.t{i}"]), (tag, i)
+            assert rel_l2(preds[i].detach().cpu().numpy(), g[f"{tag}.eps{i}"]) < 2e-5, (tag, i)
+            assert rel_l2(recons[i].detach().cpu().numpy(), g[f"{tag}.recon{i}"]) < 1e-4, (tag, i)
+            assert rel_l2(xs[i].cpu().numpy(), g[f"{tag}.x{i}"]) < 1e-4, (tag, i)
+            assert rel_l2(acts[i]["attn"].detach().cpu().numpy(), g[f"{tag}.attn{i}"]) < 2e-5, (tag, i)
+        emb.grad = None
+        sum(p.sum() for p in preds).backward()
+        assert rel_l2(emb.grad.cpu().numpy(), g[f"{tag}.demb"]) < 5e-5, tag
+        want_calls = json.loads(str(g[f"{tag}.calls"]))
+        assert [[n, fl, ad, npr, ge] for n, fl, ad, npr, ge in wrapper.calls] == want_calls, tag
