@@ -177,6 +177,7 @@ class LatentDiffusion(nn.Module):
         self.first_stage_model = None   # AutoencoderKLDecoder (instantiate_first_stage); VAE scale factor of SD-1.5:
         self.scale_factor = 0.18215
         self.unet_teacher = None     # adaface.unet_teachers.UNetTeacher (frozen)
+        self.comp_distill_priming_unet = None   # UNetTeacher with CFG on: primes the Stage-2 latents (ddpm.py:582-610)
         self.cond_stage_model = None    # FrozenCLIPEmbedder (instantiate_cond_stage)
         self.embedding_manager = None   # EmbeddingManager (instantiate_embedding_manager)
         self.iter_flags = {"do_comp_feat_distill": False, "do_unet_distill": False}
@@ -436,6 +437,25 @@ class LatentDiffusion(nn.Module):
         x_recon = self.predict_start_from_noise(x_noisy, t=t, noise=noise_pred) if do_pixel_recon else None
         return noise_pred, x_recon, ca_layers_activations
 
+    def prime_x_start_for_comp_prompts(self, subj_context, x_start, noise, num_comp_priming_denoising_steps, cls_subj_mix_ratio, BLOCK_SIZE=1):
+        """Compositional priming (reference ddpm.py:1923-1985): pure noise is denoised for a few steps by the PRIMING U-Net
+        (``self.comp_distill_priming_unet``, a second frozen U-Net teacher -- the "dual U-Net" of a Stage-2 iteration) with
+        classifier-free guidance, one trajectory under the subject-single prompt and one under a mix of the subject-comp and class-comp
+        prompt embeddings, sharing timesteps and noise.  Returns the two primed latents [2 * BLOCK_SIZE, 4, h, w]."""
+        prompt_emb = subj_context[0]
+        x_start_2 = torch.randn_like(x_start)[:BLOCK_SIZE].repeat(2, 1, 1, 1)
+        noise_2 = noise[:BLOCK_SIZE].repeat(2, 1, 1, 1)
+        t_rear = torch.randint(int(self.num_timesteps * 0.7), int(self.num_timesteps * 0.9), (BLOCK_SIZE,), device=x_start.device)
+        t_2 = t_rear.repeat(2)
+        subj_single_emb, subj_comp_emb, _, cls_comp_emb = prompt_emb.chunk(4)
+        cls_comp_emb_mix = subj_comp_emb * (1 - cls_subj_mix_ratio) + cls_comp_emb * cls_subj_mix_ratio
+        with torch.no_grad():
+            _, primed_x_starts, _, _ = self.comp_distill_priming_unet(
+                self, x_start_2, noise_2, t_2, teacher_context=torch.cat([subj_single_emb, cls_comp_emb_mix], dim=0).detach(),
+                negative_context=self.uncond_context[0], num_denoising_steps=num_comp_priming_denoising_steps,
+                same_t_noise_across_instances=True)
+        return primed_x_starts[-1].to(dtype=x_start.dtype)
+
     def comp_distill_multistep_denoise(self, x_starts, noises, ts, subj_context, uncond_emb, all_subj_indices_1b=None,
                                        normalize_cross_attn=False, mix_sc_mc_attn=False, cfg_scale=2.5, num_denoising_steps=4,
                                        old_x_starts_mix_ratio=0.3, use_attn_lora=False, use_ffn_lora=False, ffn_lora_adapter_name=None,
@@ -475,6 +495,60 @@ class LatentDiffusion(nn.Module):
                 else:
                     x_starts[i + 1] = x_starts[i + 1] * old_x_starts_mix_ratio + x_recon.detach() * (1 - old_x_starts_mix_ratio)
         return noise_preds, x_starts, x_recons, noises, ts, acts_list
+
+    comp_sc_subj_mb_suppress_loss_weight = 0.2          # reference ctor default (ddpm.py:87)
+
+    def calc_comp_feat_distill_loss(self, mon_loss_dict, session_prefix, noise_preds, ca_layers_activations_list, all_subj_indices_1b,
+                                    prompt_emb_mask_4b, prompt_pad_mask_4b, BLOCK_SIZE, sc_fg_mask=None, face_terms=None):
+        """The part of the reference's ``calc_comp_feat_distill_loss`` (ddpm.py:3190-3602) that is taken on the captured activations:
+
+        * per denoising step the five subject-comp rep distillation terms (``calc_sc_rep_attn_distill_loss``), averaged over the steps
+          and weighted as :3557-3589 (subject terms x2, non-subject k x5, v x2, all scaled by the detected face's share);
+        * the subject-attention background suppression of the SC instance (``calc_subj_masked_bg_suppress_loss`` as called at
+          :3701-3709, averaged over the steps, x ``comp_sc_subj_mb_suppress_loss_weight``);
+        * monitors: cross-step subject attention difference (:3482-3486, weight 0 in the reference), ``pred_l2``.
+
+        ``sc_fg_mask`` [BLOCK_SIZE, 1, h, w]: the face area of the subject-comp instance -- the reference gets it from RetinaFace on the
+        decoded x0 (:3238-3268; external package, absent from the reference tree), here the caller supplies it (None = no face found =
+        every face-gated term is zero, as in the reference).  ``face_terms``: already weighted scalar losses the caller computed from
+        face crops (ArcFace alignment, face suppression) to be added.  NOT built: the elastic-matching background preservation
+        (``calc_comp_subj_bg_preserve_loss``, optical-flow model) and the subject-single re-denoising."""
+        from ... import comp_losses as CL
+        device = noise_preds[0].device
+        loss = torch.zeros((), device=device, dtype=noise_preds[0].dtype)
+        sc_fg_mask_percent = float(sc_fg_mask.float().mean().item()) if sc_fg_mask is not None else 0.0
+        if sc_fg_mask is not None:
+            mon_loss_dict[f"{session_prefix}/sc_fg_mask_percent"] = sc_fg_mask_percent
+        reps, mbs, crosst, pred_l2s = [], [], [], []
+        for step, acts in enumerate(ca_layers_activations_list):
+            pred_l2s.append((noise_preds[step] ** 2).mean())
+            ls = CL.calc_sc_rep_attn_distill_loss(acts, all_subj_indices_1b, prompt_emb_mask_4b, prompt_pad_mask_4b, sc_fg_mask_percent,
+                                                  FG_THRES=0.1)
+            reps.append([v if torch.is_tensor(v) else torch.zeros((), device=device) for v in ls])
+            if sc_fg_mask is not None:
+                sc_attn = {li: a.chunk(4)[1] for li, a in acts["attn"].items()}
+                mbs.append(CL.calc_subj_masked_bg_suppress_loss(sc_attn, all_subj_indices_1b, BLOCK_SIZE, sc_fg_mask))
+                if step + 1 < len(ca_layers_activations_list):
+                    crosst.append(CL.calc_subj_attn_cross_t_diff_loss(acts, ca_layers_activations_list[step + 1], all_subj_indices_1b))
+        rep_means = tuple(torch.stack([r[i] for r in reps]).mean() for i in range(5))
+        if mbs:
+            mb = torch.stack(mbs).mean()
+            mon_loss_dict[f"{session_prefix}/comp_sc_subj_mb_suppress"] = float(mb.detach())
+            loss = loss + mb * self.comp_sc_subj_mb_suppress_loss_weight
+        if crosst:
+            mon_loss_dict[f"{session_prefix}/subj_attn_cross_t_diff"] = float(torch.stack(crosst).mean().detach())
+        if float(rep_means[0].detach()) > 0:
+            for name, v in zip(("subj_attn", "subj_k", "nonsubj_k", "subj_v", "nonsubj_v"), rep_means):
+                mon_loss_dict[f"{session_prefix}/comp_rep_distill_{name}"] = float(v.detach())
+            rep_total = CL.comp_rep_distill_total(rep_means, sc_fg_mask_percent)
+            mon_loss_dict[f"{session_prefix}/comp_rep_distill_total"] = float(rep_total.detach())
+            loss = loss + rep_total
+        for v in (face_terms or ()):
+            loss = loss + v
+        mon_loss_dict[f"{session_prefix}/pred_l2"] = float(torch.stack(pred_l2s).mean().detach())
+        if float(loss.detach()) > 0:
+            mon_loss_dict[f"{session_prefix}/comp_feat_distill_total"] = float(loss.detach())
+        return loss
 
     def sliced_apply_model(self, x_noisy, t, cond_context, slice_indices, enable_grad, use_attn_lora=False, use_ffn_lora=False,
                            ffn_lora_adapter_name=None):

@@ -69,8 +69,9 @@ class DistillTrainer:
                  betas=(0.9, 0.995), eps=1e-6, weight_decay=0.0, lora_weight_decay=0.02, warm_up_steps=500, max_decay_steps=60000,
                  bucket_bytes=32 << 20, loss_scaler=None, prompt_len=77, subj_slot=4, process_group=None,
                  gradient_clip_val=0.01, gradient_clip_algorithm="value", p_gen_rand_id_for_id2img=0.0, p_perturb_face_id_embs=0.0,
-                 perturb_face_id_embs_std_range=(0.3, 0.6)):
+                 perturb_face_id_embs_std_range=(0.3, 0.6), stage=1):
         self.ldm, self.id2ada, self.text_encoder = ldm, id2ada, text_encoder
+        self.iter_type = "comp_distill" if stage == 2 else "unet_distill"
         for p in text_encoder.parameters():
             p.requires_grad_(False)
         self.accum = accumulate_grad_batches
@@ -84,10 +85,23 @@ class DistillTrainer:
         # second group: the U-Net's `unet_distill` FFN DoRA adapters when they exist (embedding_manager.optimized_parameters gives
         # them their own weight decay, ddpm.py:143 lora_weight_decay = 0.02); the other adapter names are not touched in Stage 1
         self.ffn_lora = getattr(ldm.model, "ffn_lora", None)
+        lora_params = []
         if self.ffn_lora is not None:
+            adapter = "comp_distill" if stage == 2 else "unet_distill"      # the adapter each stage trains (ddpm.py:3130-3134, 2167-2173)
             for n, p in self.ffn_lora.named_parameters():
-                p.requires_grad_(n.startswith("adapters.unet_distill."))
-            groups.append({"params": [p for p in self.ffn_lora.parameters() if p.requires_grad], "weight_decay": lora_weight_decay})
+                p.requires_grad_(n.startswith(f"adapters.{adapter}."))
+            lora_params += [p for p in self.ffn_lora.parameters() if p.requires_grad]
+        if stage == 2:
+            # Stage 2 also trains the attention DoRA adapters of the three captured layers and their score scale factors
+            # (diffusers_attn_lora_capture.py:511-524 puts both into the optimised unet_lora_modules)
+            if getattr(ldm.model, "attn_lora", None) is not None:
+                lora_params += list(ldm.model.attn_lora.parameters())
+            lora_params += list(ldm.model.cross_attn_scale_factors.values())
+        else:
+            for p in ldm.model.cross_attn_scale_factors.values():
+                p.requires_grad_(False)
+        if lora_params:
+            groups.append({"params": lora_params, "weight_decay": lora_weight_decay})
         self.optimizer = CAdamW(groups, lr=self.learning_rate, betas=betas, eps=eps, weight_decay=weight_decay)
         self.arenas = [self.optimizer.arena(i) for i in range(len(groups))]
         self.arena = self.arenas[0]
@@ -221,6 +235,71 @@ class DistillTrainer:
                                                t=t, presampled=presampled)
         return loss * self.unet_distill_weight
 
+    # ------------------------------------------------------------------ Stage 2: one compositional-distillation micro-batch
+    num_comp_distill_denoising_steps = 4          # reference ctor defaults (ddpm.py:105-107, 84)
+    max_num_comp_priming_denoising_steps = 4
+    cls_subj_mix_ratio = 0.6
+    comp_iters_count = 0
+
+    def comp_prompt_context(self, ada_embs, comp_words=("of", "a", "person")):
+        """The four prompts of a compositional iteration for ONE subject -- subject-single "a photo of z", subject-comp
+        "a photo of z <comp>", subject-comp-rep (the compositional part repeated) and class-comp "a photo of person <comp>" -- as
+        [4, T, 768] prompt embeddings with the AdaFace embeddings patched into the subject slots of the first three, plus the
+        subject-token indices of block 0 and the [4, T, 1] embedding / padding masks the Stage-2 losses consume (the reference
+        builds these through its dataset's prompt lists and the EmbeddingManager, ddpm.py:1392-1558)."""
+        dev = ada_embs.device
+        n_id, T = self.id2ada.subj_basis_generator.N_ID, self.prompt_len
+        subj = ["a", "photo", "of"] + [","] * n_id
+        word_lists = [subj, subj + list(comp_words), subj + list(comp_words) * 2, ["a", "photo", "of", "person"] + [","] * (n_id - 1) + list(comp_words)]
+        ids = torch.cat([template_ids(w, T, dev) for w in word_lists])
+        s = self.subj_slot
+        with torch.no_grad():
+            tok = self.text_encoder(input_ids=ids, return_token_embs=True).float()
+        ada = ada_embs.float()
+        tok = torch.cat([torch.cat([tok[:3, :s], ada.expand(3, -1, -1), tok[:3, s + n_id:]], dim=1), tok[3:]], dim=0)
+        ctx = self.text_encoder(input_ids=ids, input_token_embs=tok)[0]
+        lens = torch.tensor([len(w) + 2 for w in word_lists], device=dev)
+        pos = torch.arange(T, device=dev)[None, :]
+        emb_mask = ((pos >= 1) & (pos < (lens - 1)[:, None])).float().unsqueeze(2)          # real tokens (no BOS / EOS / padding)
+        pad_mask = (pos >= lens[:, None]).float().unsqueeze(2)
+        subj_indices_1b = (torch.zeros(n_id, dtype=torch.long, device=dev), torch.arange(s, s + n_id, device=dev))
+        return ctx, ["ss", "sc", "sc-rep", "mc"], subj_indices_1b, emb_mask, pad_mask
+
+    def comp_distill_step(self, batch, face_mask_fn=None, attn_aug=None):
+        """do_comp_feat_distill iteration (reference ddpm.py:2371-2480): BLOCK_SIZE 1; four prompts; latents primed from pure noise by
+        the priming U-Net; ``num_comp_distill_denoising_steps`` subject-compos passes of the student with activation capture (only
+        the subject-comp instance carries gradients; SC / MC scores mixed or subject scores normalised, p = 0.5 each, :940-952);
+        losses on the captured activations.  ``face_mask_fn(x_recons) -> [1,1,h,w] mask | None`` stands where the reference runs
+        RetinaFace on the decoded x0 predictions.  Returns the loss."""
+        ldm = self.ldm
+        x_start = batch["x_start"][:1]
+        with torch.no_grad():
+            _, _, id2img = self.id2ada.get_img_prompt_embs(batch["face_id_embs"][:1], id_batch_size=1)[:3]
+        ada = self.id2ada.subj_basis_generator(id2img.float(), out_id_embs_cfg_scale=self.id2ada.out_id_embs_cfg_scale, is_face=True)
+        ctx, prompts, subj_1b, emb_mask, pad_mask = self.comp_prompt_context(ada)
+        if attn_aug is None:
+            attn_aug = ("normalize_cross_attn", "mix_sc_mc_attn")[int(torch.multinomial(torch.tensor([0.5, 0.5]), 1))]
+        steps_prime = self.comp_iters_count % 2 - 1 + self.max_num_comp_priming_denoising_steps
+        self.comp_iters_count += 1
+        noise = torch.randn_like(x_start)
+        primed = ldm.prime_x_start_for_comp_prompts((ctx, prompts, {}), x_start, noise, steps_prime, 0.5 + self.cls_subj_mix_ratio / 2)
+        noise = torch.randn_like(x_start).repeat(4, 1, 1, 1)
+        xs, xc = primed.chunk(2)
+        x_start_primed = torch.cat([xs, xc, xc, xc], dim=0)
+        uncond_emb = ldm.uncond_context[0].repeat(4, 1, 1)
+        t = torch.randint(int(ldm.num_timesteps * 0.45), int(ldm.num_timesteps * 0.65), (1,), device=x_start.device).repeat(4)
+        has_attn_lora = ldm.model.attn_lora is not None
+        noise_preds, x_starts, x_recons, noises, ts, acts = ldm.comp_distill_multistep_denoise(
+            [x_start_primed], [noise], [t], (ctx, prompts, {}), uncond_emb=uncond_emb, all_subj_indices_1b=subj_1b,
+            normalize_cross_attn=attn_aug == "normalize_cross_attn", mix_sc_mc_attn=attn_aug == "mix_sc_mc_attn", cfg_scale=2.5,
+            num_denoising_steps=self.num_comp_distill_denoising_steps, old_x_starts_mix_ratio=0, use_attn_lora=has_attn_lora,
+            use_ffn_lora=ldm.model.ffn_lora is not None, ffn_lora_adapter_name="comp_distill", batch_part_has_grad="subject-compos")
+        sc_fg_mask = face_mask_fn(x_recons) if face_mask_fn is not None else None
+        self.mon_loss_dict = {}
+        return ldm.calc_comp_feat_distill_loss(self.mon_loss_dict, "train", noise_preds, acts, subj_1b, emb_mask, pad_mask, 1, sc_fg_mask=sc_fg_mask)
+
+    iter_type = "unet_distill"        # or "comp_distill" (Stage 2)
+
     def training_step(self, batch, batch_idx, epoch=0, **kw):
         """One micro-batch: forward, scaled backward (with the gradient exchange overlapped on the last micro-batch of an
         accumulation window), and on window end: unscale, optimizer step, LR schedule.  Returns the loss (detached)."""
@@ -228,7 +307,7 @@ class DistillTrainer:
         self.unet_distill_iters_count += 1
         last = (batch_idx + 1) % self.accum == 0
         sync = contextlib.nullcontext() if last else self.reducer.no_sync()
-        loss = self.shared_step(batch, **kw)
+        loss = self.comp_distill_step(batch, **kw) if self.iter_type == "comp_distill" else self.shared_step(batch, **kw)
         with sync:
             (loss * (self.scaler.scale / self.accum)).backward()
         if last:

@@ -499,3 +499,46 @@ def test_rccl_world1_train_step_under_launcher(dev, tmp_path):
     assert rel_l2(got["mean_grad"].numpy(), got["mean_grad_expected_from_rank_sums"].numpy()) < 1e-6
     same = ((got["flat_p"] - got["p0"]).sign() == (tr.arena.flat_p.cpu() - got["p0"]).sign()).float().mean()
     assert same > 0.999, float(same)
+
+
+@pytest.mark.parametrize("attn_aug", ["normalize_cross_attn", "mix_sc_mc_attn"])
+def test_comp_distill_iteration_reduced_width(dev, attn_aug):
+    """One Stage-2 compositional-distillation micro-batch end to end on the HIP path (reference ddpm.py:2371-2480): priming by the
+    second U-Net with classifier-free guidance, four subject-compos denoising steps with capture (no-grad SS / SR / MC passes, the SC
+    pass -- or the joint SC+MC pass with mixed scores -- with gradients, attention + FFN adapters), the captured-activation losses
+    with a supplied face box, backward.  Checks: finite positive loss with every expected term, gradients reach the
+    SubjBasisGenerator, the attention adapters (not while scores are mixed: LoRAs are off then, :2004-2006) and, with normalisation,
+    the score scale factors; then a full optimizer step through training_step."""
+    from adaface_dev_amd import rng
+    tr, sds, ucfg = trainer_setup(dev, accum=1, ffn_lora=True, stage2=True)
+    assert tr.iter_type == "comp_distill" and len(tr.arenas) == 2
+    b = dict(x_start=rng.synth_input("s2.x", (2, 4, 32, 32), seed=49).to(dev), face_id_embs=rng.synth_input("s2.id", (2, 512), seed=49).to(dev))
+
+    def face_box(x_recons):                       # stands in for RetinaFace on the decoded x0 (ddpm.py:3238-3268): a 40 % box
+        m = torch.zeros(1, 1, 32, 32, device=dev)
+        m[:, :, 6:26, 8:28] = 1
+        return m
+    tr.optimizer.zero_grad()
+    torch.manual_seed(5)
+    loss = tr.comp_distill_step(b, face_mask_fn=face_box, attn_aug=attn_aug)
+    mon = tr.mon_loss_dict
+    assert torch.isfinite(loss) and float(loss) > 0
+    for k in ("comp_rep_distill_subj_attn", "comp_rep_distill_nonsubj_k", "comp_sc_subj_mb_suppress", "pred_l2", "sc_fg_mask_percent", "comp_rep_distill_total"):
+        assert f"train/{k}" in mon, (k, sorted(mon))
+    assert abs(mon["train/sc_fg_mask_percent"] - 400 / 1024) < 1e-6
+    (loss * tr.scaler.scale).backward()
+    g_sbg = tr.arenas[0].flat_g
+    assert torch.isfinite(g_sbg).all() and float(g_sbg.abs().sum()) > 0
+    alora = tr.ldm.model.attn_lora
+    g_attn = sum(float(p.grad.abs().sum()) for p in alora.parameters() if p.grad is not None)
+    g_fac = sum(float(p.grad.abs().sum()) for p in tr.ldm.model.cross_attn_scale_factors.values() if p.grad is not None)
+    if attn_aug == "mix_sc_mc_attn":
+        assert g_attn == 0 and g_fac == 0
+    else:
+        assert g_attn > 0 and g_fac > 0
+    # the whole training step (loss scaling, clip, fused CAdamW on both arenas)
+    p0 = [a.flat_p.clone() for a in tr.arenas]
+    tr.optimizer.zero_grad()
+    l = tr.training_step(b, 0, face_mask_fn=face_box, attn_aug=attn_aug)
+    assert torch.isfinite(l) and tr.global_step == 1 and tr.skipped_steps == 0
+    assert float((tr.arenas[0].flat_p - p0[0]).abs().sum()) > 0

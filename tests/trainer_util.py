@@ -5,7 +5,7 @@ CFG = dict(in_channels=4, model_channels=64, out_channels=4, num_res_blocks=2, a
            channel_mult=[1, 2, 4, 4], num_heads=8, use_spatial_transformer=True, transformer_depth=1, context_dim=64, legacy=False)
 
 
-def trainer_setup(dev, accum=1, process_group=None, ffn_lora=False, embedding_manager=False):
+def trainer_setup(dev, accum=1, process_group=None, ffn_lora=False, embedding_manager=False, stage2=False):
     """Reduced-width replica of the whole Stage-1 stack: CLIP encoders hidden 128 / 3 layers, U-Nets model_channels 64."""
     from adaface_dev_amd import rng
     from adaface_dev_amd.adaface.arc2face_models import CLIPTextModelWrapper, clip_text_config
@@ -41,6 +41,21 @@ def trainer_setup(dev, accum=1, process_group=None, ffn_lora=False, embedding_ma
             for n, p in lora.named_parameters():
                 if "lora_B" in n:
                     p.copy_(rng.synth_input(n, p.shape, seed=82, scale=0.3))
+    if stage2:
+        # Stage 2 (compositional distillation): a priming U-Net with classifier-free guidance, the unconditional prompt embedding,
+        # trainable attention DoRA adapters on the captured layers, and the comp_distill FFN adapters
+        from adaface_dev_amd.adaface.unet_teachers import UNetTeacher
+        priming_unet = UNetModel(**ucfg)
+        rng.load_synth_weights(priming_unet, seed=46)
+        ld.comp_distill_priming_unet = UNetTeacher(priming_unet.to(dev), cfg_scale_range=(2, 4), p_uses_cfg=1.0, name="comp_priming")
+        ld.uncond_context = (rng.synth_input("s2.uncond", (1, 77, 128), seed=46).to(dev), [""], {})
+        for p in ld.model.diffusion_model.parameters():
+            p.requires_grad_(False)
+        alora = ld.model.set_up_attn_loras(lora_rank=16, lora_dropout=0.0)
+        with torch.no_grad():
+            for n, p in alora.named_parameters():
+                if "lora_B" in n:
+                    p.copy_(rng.synth_input(n, p.shape, seed=84, scale=0.2))
     tr = DistillTrainer(ld, id2ada.to(dev), text_enc.to(dev), accumulate_grad_batches=accum, warm_up_steps=0,
-                        loss_scaler=LossScaler(init_scale=2.0 ** 10), process_group=process_group)
+                        loss_scaler=LossScaler(init_scale=2.0 ** 10), process_group=process_group, stage=2 if stage2 else 1)
     return tr, sds, ucfg
