@@ -167,8 +167,14 @@ class CrossAttention(nn.Module):
             qc = q if context is not None else qk[:, :Ci].contiguous()
             kc = k.contiguous() if context is not None else qk[:, Ci:].contiguous()
             score, prob = ops.attention_scores(qc, kc, B=B, Nq=N, L=L, heads=h, d=d, scale=self.scale)
+            rs = math.sqrt(self.scale)
+            qcap = (qc.reshape(B, N, Ci).permute(0, 2, 1).float() * rs).contiguous()
+            # v^T comes out of the projection already as [B, C, ld] (ld = L rounded up): the captured layout 'b (h d) n'
             self.cached_activations = {
-                "q": (qc.reshape(B, N, Ci).permute(0, 2, 1).float() * math.sqrt(self.scale)).contiguous(),
+                "q": qcap,
+                "q2": qcap,                                   # query2 = query without a q LoRA (diffusers_attn_lora_capture.py:250, 347-354)
+                "k": (kc.reshape(B, L, Ci).permute(0, 2, 1).float() * rs).contiguous(),
+                "v": (vt[:, :Ci, :L].float() * rs).contiguous(),
                 "attn": prob,
                 "attnscore": score,
                 "attn_out": out_plain.reshape(B, N, -1).permute(0, 2, 1).float().contiguous(),

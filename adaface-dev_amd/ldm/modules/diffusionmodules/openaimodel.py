@@ -644,7 +644,7 @@ class UNetModel(nn.Module):
                 self.set_cross_attn_flags(ca_flag_dict=old_flags, ca_layer_indices=captured)
         if extra_info is not None:
             extra_info["ca_layers_activations"] = {
-                key: {li: acts[li][key] for li in acts} for key in ("outfeat", "attn", "attnscore", "q", "attn_out")
+                key: {li: acts[li][key] for li in acts} for key in ("outfeat", "attn", "attnscore", "q", "q2", "k", "v", "attn_out")
             }
         return from_nhwc_f16(eps, x.dtype, self.out_channels)
 
