@@ -74,13 +74,19 @@ def init_device(ctx):
     return dev
 
 
-def run_train(args, ctx, dev):
-    """BASELINE configs[2] (1 GPU) / configs[3] (DDP).  One *step* = one training
+def run_train(args, ctx, dev, stage=1):
+    """stage 1: BASELINE configs[2] (1 GPU) / configs[3] (DDP); stage 2: configs[4] (see the end of this docstring).  One *step* = one training
     micro-batch of bs images/GPU: face IDs -> Arc2Face encoder -> trainable SubjBasisGenerator -> frozen text encoder ->
     teacher multi-step targets + student eps per step (HALF_BS = ceil(bs/steps) instances, steps cycling 2,3,4 as
     ddpm.py:1270-1289) -> masked MSE -> backward to the 85 M SubjBasisGenerator weights; every 2nd micro-batch the
     bucketed gradient all-reduce (overlapped with the backward), unscale and fused CAdamW.  Full-size models: 2 x SD-1.5
-    U-Net (student, teacher) + 3 x CLIP-L text transformers, seeded random weights.  Returns the result dict on rank 0."""
+    U-Net (student, teacher) + 3 x CLIP-L text transformers, seeded random weights.  Returns the result dict on rank 0.
+
+    stage 2 (BASELINE configs[4], reference ddpm.py:2371-2480): one *step* = one compositional-distillation micro-batch: BLOCK_SIZE 1 of
+    the bs-3 batch (the reference fixes it, :2372-2374), latents primed from pure noise by the second (teacher) U-Net with
+    classifier-free guidance over 3-4 steps, then 4 subject-compos denoising steps of the student on the four-prompt batch with
+    activation capture (explicit attention in layers 22-24, score mixing / normalisation, trainable attention + FFN DoRA adapters),
+    guidance passes, captured-activation losses (a fixed face box stands in for the absent RetinaFace detector), backward, CAdamW."""
     world, rank, local_rank, launched = ctx
     import torch.distributed as dist
     from adaface_dev_amd import SD15_UNET_CONFIG, _lib, ops, rng
@@ -109,7 +115,17 @@ def run_train(args, ctx, dev):
     ldm.unet_teacher = Arc2FaceTeacher(teacher.to(dev))
     if not args.no_ffn_lora:
         ldm.model.set_up_ffn_loras()         # rank-192 DoRA on up_blocks.3 convs; 'unet_distill' is always on in Stage 1 (ddpm.py:3130-3134)
-    tr = DistillTrainer(ldm, id2ada.to(dev), text_enc.to(dev), batch_size=B, accumulate_grad_batches=2, prompt_len=97)
+    step_kw = {}
+    if stage == 2:
+        from adaface_dev_amd.adaface.unet_teachers import UNetTeacher
+        B = 3                                                              # configs[4]: bs 3 / GPU
+        ldm.comp_distill_priming_unet = UNetTeacher(ldm.unet_teacher.unet, cfg_scale_range=(2, 4), p_uses_cfg=1.0, name="comp_priming")
+        ldm.uncond_context = (rng.synth_input("bench.uncond", (1, 97, 768), seed=5).to(dev), [""], {})
+        ldm.model.set_up_attn_loras()                                      # rank-192 DoRA on q / k / v / out of layers 22-24
+        box = torch.zeros(1, 1, 64, 64, device=dev)
+        box[:, :, 16:44, 18:46] = 1                                        # 19 % of the image: inside the reference's 'good' face range
+        step_kw = dict(face_mask_fn=lambda x_recons: box)
+    tr = DistillTrainer(ldm, id2ada.to(dev), text_enc.to(dev), batch_size=B, accumulate_grad_batches=2, prompt_len=97, stage=stage)
     n_train = sum(a.numel for a in tr.arenas)
 
     def batch(i):
@@ -122,13 +138,13 @@ def run_train(args, ctx, dev):
     warm = max(2, args.train_warmup + (args.train_warmup % 2))
     losses = []
     for i in range(warm):
-        tr.training_step(batches[i % 4], i)
+        tr.training_step(batches[i % 4], i, **step_kw)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(steps):
-        losses.append(tr.training_step(batches[i % 4], warm + i))
+        losses.append(tr.training_step(batches[i % 4], warm + i, **step_kw))
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -143,7 +159,7 @@ def run_train(args, ctx, dev):
         ops.prof_reset()
         ops.prof_enable(True)
         for i in range(6):                             # one full 2,3,4-step cycle twice over (6 micro-batches)
-            tr.training_step(batches[i % 4], warm + steps + i)
+            tr.training_step(batches[i % 4], warm + steps + i, **step_kw)
         torch.cuda.synchronize()
         ops.prof_enable(False)
         fam = {}
@@ -160,19 +176,33 @@ def run_train(args, ctx, dev):
         # as many teacher sample-passes => 14/3 of each per micro-batch on average at bs 4
         per_mb = sum(-(-B // s) * s for s in (2, 3, 4)) / 3.0
         train_tflop = per_mb * 3 * 0.80496
-        out = {"metric": "train-images/sec Stage-1 Arc2Face distillation bs=4/GPU", "value": round(world * B * steps / elapsed, 3),
+        what = (f"whole micro-batch: {per_mb:.2f} student fwd+bwd + {per_mb:.2f} teacher fwd U-Net sample-passes "
+                f"= {train_tflop:.2f} TFLOP algorithmic (conv/matmul only, encoders not counted) / wall time")
+        metric = "train-images/sec Stage-1 Arc2Face distillation bs=4/GPU"
+        workload = (f"stage1_unet_distill micro-batch: bs={B}/GPU, 512x512 (latent 64x64), 97 context tokens, denoising steps cycle 2,3,4 "
+                    "with HALF_BS=ceil(bs/steps), teacher+student SD-1.5 U-Nets, 3 CLIP-L encoders, "
+                    f"{n_train} trainable fp32 params, accumulate_grad_batches=2, CAdamW")
+        if stage == 2:
+            # priming: 3.5 steps x (positive + negative pass at batch 2) = 14 sample forwards; student: 4 steps x (SS + SR + SC + MC
+            # + 4 unconditional = 8 sample forwards, the SC pass -- SC and MC when the scores are mixed -- also backward: ~1.5)
+            fwd_equiv = 3.5 * 4 + 4 * (8 + 1.5)
+            train_tflop = fwd_equiv * 0.80496
+            what = (f"whole micro-batch: ~{fwd_equiv:.0f} U-Net sample-forward equivalents (14 priming, 32 student forward incl. guidance, "
+                    f"~6 backward) = {train_tflop:.1f} TFLOP algorithmic / wall time")
+            metric = "train-images/sec Stage-2 compositional distillation bs=3/GPU"
+            workload = ("stage2_comp_distill micro-batch: bs=3/GPU of which BLOCK_SIZE=1 is denoised (reference ddpm.py:2372-2374), 512x512, 97 tokens, "
+                        "priming U-Net 3-4 CFG steps + student 4 subject-compos steps x 4 prompts with capture of layers 22-24 + guidance passes, "
+                        f"attention + FFN DoRA adapters, {n_train} trainable fp32 params, accumulate_grad_batches=2, CAdamW")
+        out = {"metric": metric, "value": round(world * B * steps / elapsed, 3),
                "unit": "images/s", "n_gpus": world, "steps": steps, "warmup": warm, "ms_per_step": round(ms, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-               "config": {"workload": f"stage1_unet_distill micro-batch: bs={B}/GPU, 512x512 (latent 64x64), 97 context tokens, denoising steps cycle 2,3,4 "
-                                      "with HALF_BS=ceil(bs/steps), teacher+student SD-1.5 U-Nets, 3 CLIP-L encoders, "
-                                      f"{n_train} trainable fp32 params, accumulate_grad_batches=2, CAdamW",
+               "config": {"workload": workload,
                           "parallelism": f"dp{world} (RCCL bucketed all-reduce overlapped with backward)" if world > 1 else "single GPU",
                           "optimizer_steps": tr.global_step, "skipped_steps": tr.skipped_steps, "loss_scale": tr.scaler.scale,
                           "last_loss": float(losses[-1]), "finite": bool(all(torch.isfinite(l) for l in losses))},
                "roofline": {"bound": "mfma", "achieved": round(train_tflop / (ms * 1e-3), 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                             "frac": round(train_tflop / (ms * 1e-3) / MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                            "what": f"whole micro-batch: {per_mb:.2f} student fwd+bwd + {per_mb:.2f} teacher fwd U-Net sample-passes "
-                                    f"= {train_tflop:.2f} TFLOP algorithmic (conv/matmul only, encoders not counted) / wall time"},
+                            "what": what},
                "families_per_micro_batch": fam}
     del tr, ldm, teacher, id2ada, text_enc
     torch.cuda.empty_cache()
@@ -412,7 +442,7 @@ def main():
     ap.add_argument("--no-ffn-lora", action="store_true", help="train leg: without the U-Net's trainable FFN DoRA adapters")
     ap.add_argument("--train-steps", type=int, default=12, help="timed micro-batches of the train leg")
     ap.add_argument("--train-warmup", type=int, default=6)
-    ap.add_argument("--mode", choices=["all", "denoise", "train"], default="all",
+    ap.add_argument("--mode", choices=["all", "denoise", "train", "train2"], default="all",
                     help="all (default): the headline denoise line (BASELINE configs[1]) carrying the Stage-1 training leg "
                          "(configs[2]/[3]) as its `train` object; denoise / train: one leg only (train prints its own line)")
     args = ap.parse_args()
@@ -426,7 +456,7 @@ def main():
     out = None
     if args.mode in ("all", "denoise"):
         out = run_denoise(args, ctx, dev)
-    if args.mode in ("all", "train"):
+    if args.mode in ("all", "train", "train2"):
         # the train leg must never cost the headline line: an exception is reported inside the line, and a hang (a stuck
         # collective) is cut by a watchdog on rank 0 that prints what it has and leaves
         import threading
@@ -438,17 +468,22 @@ def main():
                 print(json.dumps(res), flush=True)
                 os._exit(3)
         threading.Thread(target=watchdog, daemon=True).start()
-        try:
-            tr = run_train(args, ctx, dev)
-        except Exception as e:                          # noqa: BLE001  (reported, not swallowed)
-            import traceback
-            traceback.print_exc()
-            tr = {"error": f"{type(e).__name__}: {e}"}
+        def leg(stage):
+            try:
+                return run_train(args, ctx, dev, stage=stage)
+            except Exception as e:                      # noqa: BLE001  (reported, not swallowed)
+                import traceback
+                traceback.print_exc()
+                return {"error": f"{type(e).__name__}: {e}"}
+        tr = leg(1) if args.mode in ("all", "train") else None
+        tr2 = leg(2) if args.mode in ("all", "train2") else None
         done.set()
         if args.mode == "train":
             out = tr
+        elif args.mode == "train2":
+            out = tr2
         elif rank == 0:
-            out["train"] = tr
+            out["train"], out["train_stage2"] = tr, tr2
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1 or launched:
