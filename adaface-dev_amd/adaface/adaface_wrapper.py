@@ -225,6 +225,10 @@ class AdaFaceWrapper(nn.Module):
     # ------------------------------------------------------------------ embeddings (reference :541-569, 671-727)
     def prepare_adaface_embeddings(self, image_paths, face_id_embs=None, avg_at_stage="id_emb", perturb_at_stage=None, perturb_std=0,
                                    update_text_encoder=True):
+        if face_id_embs is not None and face_id_embs.shape[0] > 1 and avg_at_stage == "id_emb":
+            # pre-extracted IDs of several images of the subject: the 'id_emb' averaging of the reference lives in its image -> ID
+            # extraction (insightface, absent here), so it is applied to the IDs brought in instead
+            face_id_embs = self.id2ada_prompt_encoder.average_id_embs(face_id_embs)
         embs, img_prompt_embs, lens = self.id2ada_prompt_encoder.generate_adaface_embeddings(
             image_paths, face_id_embs=face_id_embs, img_prompt_embs=None, avg_at_stage=avg_at_stage, perturb_at_stage=perturb_at_stage,
             perturb_std=perturb_std, enable_static_img_suffix_embs=self.enable_static_img_suffix_embs)

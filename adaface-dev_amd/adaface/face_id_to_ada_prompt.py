@@ -101,7 +101,7 @@ class Arc2Face_ID2AdaPrompt(nn.Module):
                             skip_non_faces=True, avg_at_stage=None, perturb_at_stage=None, perturb_std=0.0, verbose=False):
         if image_paths is not None or image_objs is not None:
             raise NotImplementedError("face detection / ID extraction from images uses insightface ONNX (third-party, absent)")
-        dev = self.text_to_image_prompt_encoder.text_model.final_layer_norm.weight.device
+        dev = next(self.text_to_image_prompt_encoder.parameters()).device
         if init_id_embs is None:
             faceid_embeds = torch.randn(id_batch_size, 512).to(device=dev, dtype=torch.float16)        # reference :384
         else:
@@ -119,6 +119,12 @@ class Arc2Face_ID2AdaPrompt(nn.Module):
             pos_prompt_embs = perturb_tensor(pos_prompt_embs, perturb_std, perturb_std_is_relative=True, keep_norm=True)
         return 0, faceid_embeds, pos_prompt_embs, None
 
+    @staticmethod
+    def average_id_embs(face_id_embs):
+        """[N, 512] IDs of N images of one subject -> [1, 512]: mean, then L2 normalisation -- what the reference's
+        ``extract_init_id_embeds_from_images(calc_avg=True)`` does with the IDs it extracts (face_id_to_ada_prompt.py:347-350)."""
+        return F.normalize(face_id_embs.mean(dim=0, keepdim=True), p=2, dim=-1)
+
     def generate_adaface_embeddings(self, image_paths=None, face_id_embs=None, img_prompt_embs=None, p_dropout=0,
                                     return_zero_embs_for_dropped_encoders=True, avg_at_stage="id_emb", perturb_at_stage=None,
                                     perturb_std=0, enable_static_img_suffix_embs=None):
@@ -127,9 +133,10 @@ class Arc2Face_ID2AdaPrompt(nn.Module):
         lens = [self.num_id_vecs + enable_static_img_suffix_embs * self.num_static_img_suffix_embs]
         avg = None if (avg_at_stage is None or str(avg_at_stage).lower() == "none") else avg_at_stage
         if img_prompt_embs is None:
+            # as the reference (:529-538): with an averaging stage the ID batch size is 1.  IDs handed in directly are NOT averaged at
+            # the 'id_emb' stage -- the reference averages there only while it extracts IDs from images (calc_avg, :325-350;
+            # ``average_id_embs`` below is that step for callers that bring pre-extracted IDs of several images)
             bs = 1 if avg is not None else (face_id_embs.shape[0] if face_id_embs is not None else 1)
-            if avg == "id_emb" and face_id_embs is not None and face_id_embs.shape[0] > 1:
-                face_id_embs = face_id_embs.mean(dim=0, keepdim=True)        # calc_avg at the id_emb stage (:400-405)
             _, _, img_prompt_embs, _ = self.get_img_prompt_embs(face_id_embs, None, None, None, bs, perturb_at_stage=perturb_at_stage,
                                                                 perturb_std=perturb_std, avg_at_stage=avg)
         elif avg is not None:

@@ -894,6 +894,98 @@ def gen_comp_multistep(out):
     print("comp_multistep:", [res[f"draw.t{i}"].tolist() for i in range(3)], len(json.loads(str(res["draw.calls"]))))
 
 
+
+def _ref_shell(cls, **attrs):
+    obj = cls.__new__(cls)
+    torch.nn.Module.__init__(obj)
+    for k, v in attrs.items():
+        setattr(obj, k, v)
+    return obj
+
+
+ID2ADA_CASES = (
+    dict(name="given3", init="3", bs=3),
+    dict(name="given1_rep3", init="1", bs=3),
+    dict(name="avg_img_prompt", init="3", bs=3, avg="img_prompt_emb"),
+    dict(name="perturb_id", init="3", bs=3, pstage="id_emb", pstd=0.2),
+    dict(name="perturb_prompt", init="3", bs=3, pstage="img_prompt_emb", pstd=0.3),
+    dict(name="random_ids", init=None, bs=2),
+)
+
+
+def gen_id2ada_glue(out):
+    """The GLUE of the face -> prompt stack executed by the REFERENCE classes themselves, with the CLIP text transformers (whose
+    forward does not run under the installed transformers 5) replaced by a stand-in of the same call protocol
+    (tests/standin.py::StandInCLIP) and the tokenizer by a six-word stand-in: ``SubjBasisGenerator.forward`` /
+    ``inverse_img_prompt_embs`` (subj_basis_generator.py:443-562, 692-770: template, slot replacement, x5 gradient-scaled layer
+    weights, static suffix embeddings, core slicing, mixing with the pad embeddings), ``Arc2Face_ID2AdaPrompt
+    .map_init_id_to_img_prompt_embs`` (face_id_to_ada_prompt.py:680-724), ``FaceID2AdaPrompt.get_img_prompt_embs`` (:368-470: given /
+    repeated / random IDs, the two perturbation stages, L2 normalisation, the averaging stage) and ``generate_adaface_embeddings``
+    (:503-578).  Objects are built without their constructors (those download pretrained CLIP files)."""
+    import contextlib
+    import io
+    import adaface.face_id_to_ada_prompt as ref_f2a
+    import adaface.subj_basis_generator as ref_sbg
+    from adaface_dev_amd import rng
+    from standin import StandInCLIP, WordTokenizer
+    D, N_ID, N_SFX = 768, 16, 2
+    res = {}
+
+    def make_sbg():
+        g = _ref_shell(ref_sbg.SubjBasisGenerator, N_ID=N_ID, N_SFX=N_SFX, max_prompt_length=77, dtype=torch.float32, placeholder_is_bg=False,
+                       tokenizer=WordTokenizer(), prompt2token_proj=StandInCLIP(D, seed=73), layerwise_proj=torch.nn.Identity(), output_dim=D)
+        g.static_img_suffix_embs = torch.nn.Parameter(rng.synth_input("glue.sfx", (1, N_SFX, D), seed=74))
+        g.register_buffer("pad_embeddings", rng.synth_input("glue.pad", (77, D), seed=74))
+        with contextlib.redirect_stdout(io.StringIO()):
+            g.initialize_hidden_state_layer_weights("per-layer", "cpu")
+        return g
+
+    for tag, cfg_scale, sfx in (("plain", 1.0, False), ("cfg07_sfx", 0.7, True), ("cfg13", 1.3, False)):
+        g = make_sbg()
+        x = rng.synth_input("glue.id2img", (2, N_ID, D), seed=74).requires_grad_(True)
+        y = g(x, out_id_embs_cfg_scale=cfg_scale, is_face=True, enable_static_img_suffix_embs=sfx)
+        (y * rng.synth_input(f"glue.w.{tag}", tuple(y.shape), seed=74)).sum().backward()
+        res[f"sbg.{tag}.out"], res[f"sbg.{tag}.dx"] = y.detach().numpy(), x.grad.numpy()
+        res[f"sbg.{tag}.dlayer_w"] = g.hidden_state_layer_weights.grad.numpy()
+        res[f"sbg.{tag}.dsfx"] = np.zeros(1, np.float32) if g.static_img_suffix_embs.grad is None else g.static_img_suffix_embs.grad.numpy()
+
+    def make_id2ada():
+        enc = StandInCLIP(D, seed=75)
+        a = _ref_shell(ref_f2a.Arc2Face_ID2AdaPrompt, name="arc2face", tokenizer=WordTokenizer(), id_img_prompt_max_length=22, dtype=torch.float32,
+                       text_to_image_prompt_encoder=enc, clip_image_encoder=types.SimpleNamespace(device="cpu"), use_clip_embs=False,
+                       gen_neg_img_prompt=False, num_id_vecs=N_ID, num_id_vecs0=N_ID, num_static_img_suffix_embs=N_SFX,
+                       default_enable_static_img_suffix_embs=False, out_id_embs_cfg_scale=0.8, subj_basis_generator=make_sbg())
+        a.get_clip_neg_features = lambda BS: None
+        return a
+
+    ids3 = rng.synth_input("glue.ids", (3, 512), seed=76)
+    a = make_id2ada()
+    res["map.out"] = a.map_init_id_to_img_prompt_embs(torch.nn.functional.normalize(ids3, dim=-1)).detach().numpy()
+    for c in ID2ADA_CASES:
+        a = make_id2ada()
+        init = None if c["init"] is None else (ids3 if c["init"] == "3" else ids3[:1])
+        torch.manual_seed(808)
+        with contextlib.redirect_stdout(io.StringIO()):
+            cnt, fid, pos, neg = a.get_img_prompt_embs(init, None, None, None, id_batch_size=c["bs"], avg_at_stage=c.get("avg"),
+                                                       perturb_at_stage=c.get("pstage"), perturb_std=c.get("pstd", 0.0))
+        assert neg is None
+        res[f"get.{c['name']}.faceid"], res[f"get.{c['name']}.pos"] = fid.float().numpy(), pos.float().detach().numpy()
+    for tag, kw in (("ids_avg_id", dict(face_id_embs=ids3, avg_at_stage="id_emb")), ("ids_noavg", dict(face_id_embs=ids3, avg_at_stage=None)),
+                    ("ids_avg_prompt_sfx", dict(face_id_embs=ids3, avg_at_stage="img_prompt_emb", enable_static_img_suffix_embs=True)),
+                    ("prompts_avg", dict(img_prompt_embs=rng.synth_input("glue.ip", (3, N_ID, D), seed=76), avg_at_stage="img_prompt_emb"))):
+        a = make_id2ada()
+        # the reference counts detected face IMAGES and returns (None, None, lens) when that count is 0 (:549-550), which is also what it
+        # does for IDs handed in directly (the count is only raised while reading images); report one image so that the rest of the
+        # function -- what the fixture is about -- runs
+        orig = a.get_img_prompt_embs
+        a.get_img_prompt_embs = lambda *args, _o=orig, **kws: (1,) + tuple(_o(*args, **kws))[1:]
+        with contextlib.redirect_stdout(io.StringIO()):
+            embs, ip, lens = a.generate_adaface_embeddings(None, **kw)
+        res[f"gen.{tag}.embs"], res[f"gen.{tag}.img_prompt"], res[f"gen.{tag}.lens"] = embs.detach().numpy(), ip.detach().numpy(), np.asarray(lens)
+    np.savez_compressed(os.path.join(out, "id2ada_glue.npz"), **res)
+    print("id2ada_glue:", {k: v.shape for k, v in res.items() if k.startswith("gen.") and k.endswith("embs")})
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-full", action="store_true")
@@ -905,7 +997,7 @@ def main():
     # host-orchestration fixtures: the reference's ddpm.py / unet_teachers.py / diffusers_attn_lora_capture.py are imported with
     # EMPTY stand-ins for their absent third-party packages (tests/golden/ref_import.py)
     host_jobs = {"teacher": gen_teacher, "sdpa": gen_sdpa, "guided_denoise": gen_guided_denoise, "distill_loss": gen_distill_loss,
-                 "comp_losses": gen_comp_losses, "comp_multistep": gen_comp_multistep}
+                 "comp_losses": gen_comp_losses, "comp_multistep": gen_comp_multistep, "id2ada_glue": gen_id2ada_glue}
     if args.only in host_jobs or args.only is None:
         sys.path.insert(0, HERE)
         sys.path.insert(0, os.path.dirname(HERE))

@@ -60,3 +60,54 @@ class StandInWrapper(torch.nn.Module):
         else:
             extra["ca_layers_activations"] = {"outfeat": {}, "attn": eps.new_zeros(x.shape[0], 0), "names": []}
         return eps.to(out_dtype)
+
+
+# ----------------------------------------------------------------------------- stand-ins for the CLIP text encoders of the ID -> prompt stack
+CLIP_WORD_IDS = {"photo": 1125, "of": 539, "a": 320, ",": 267, "id": 1014, "person": 2533}
+CLIP_BOS, CLIP_EOS = 49406, 49407
+
+
+class WordTokenizer:
+    """Call protocol of the CLIP tokenizer for the few template prompts of the ID -> prompt stack (whitespace split, the six words
+    above; the vocabulary files of the real tokenizer are not available offline).  ',' glued to a word ("a ,") is split off."""
+
+    def encode(self, text, add_special_tokens=False):
+        return [CLIP_WORD_IDS[w] for w in text.replace(",", " , ").split()]
+
+    def __call__(self, prompts, truncation=True, padding="max_length", max_length=77, return_tensors="pt"):
+        prompts = [prompts] if isinstance(prompts, str) else list(prompts)
+        rows = []
+        for p in prompts:
+            ids = [CLIP_BOS] + self.encode(p) + [CLIP_EOS]
+            ids = ids[:max_length] + [CLIP_EOS] * (max_length - len(ids))
+            rows.append(ids)
+        import types
+        return types.SimpleNamespace(input_ids=torch.tensor(rows, dtype=torch.long))
+
+
+class StandInCLIP(torch.nn.Module):
+    """Plays ``CLIPTextModelWrapper`` (adaface/arc2face_models.py:236-338) in the fixtures that pin the GLUE around it
+    (slot replacement, layer weights, static suffix, slicing, averaging / perturbation stages): same call protocol --
+    ``(input_ids=, return_token_embs=True)`` -> token embeddings, ``(input_ids=, input_token_embs=, hidden_state_layer_weights=)`` ->
+    ``(hidden [B, T, D],)`` -- computed by a fixed cheap nonlinear map that depends on every argument (differentiable in the token
+    embeddings and the layer weights)."""
+
+    def __init__(self, hidden_size=768, seed=73):
+        super().__init__()
+        import types
+        from adaface_dev_amd import rng
+        self.config = types.SimpleNamespace(hidden_size=hidden_size)
+        self.table = torch.nn.Parameter(rng.synth_input("standin.clip.table", (1024, hidden_size), seed=seed), requires_grad=False)
+        self.pos = torch.nn.Parameter(rng.synth_input("standin.clip.pos", (128, hidden_size), seed=seed) * 0.1, requires_grad=False)
+        self.w = torch.nn.Parameter(rng.synth_input("standin.clip.w", (hidden_size, hidden_size), seed=seed) * hidden_size ** -0.5, requires_grad=False)
+
+    def forward(self, input_ids=None, input_token_embs=None, hidden_state_layer_weights=None, return_token_embs=False, **kw):
+        if return_token_embs:
+            return self.table[input_ids % 1024].clone()
+        x = self.table[input_ids % 1024] if input_token_embs is None else input_token_embs
+        x = x.to(self.w.dtype)
+        h = torch.tanh((x + self.pos[: x.shape[1]]) @ self.w)
+        if hidden_state_layer_weights is not None:
+            wl = hidden_state_layer_weights.to(h.dtype).reshape(-1)
+            h = sum(wl[k] / wl.sum() * (h * (0.5 + 0.25 * k) + 0.05 * k) for k in range(wl.numel()))
+        return (h,)

@@ -110,9 +110,9 @@ def test_arc2face_id_to_adaface_embeddings_full_size_vs_oracle(dev):
     err = rel_l2(ada.float().cpu().numpy(), ref_ada.numpy())
     print(f"AdaFace embeddings rel-L2 vs oracle: {err:.3e}")
     assert err < 1e-2
-    # averaging at the id_emb stage returns one subject's [16, 768]
+    # one subject's averaged ID (the reference averages while extracting IDs from images: average_id_embs) -> [16, 768]
     with torch.no_grad():
-        ada1, _, _ = enc.generate_adaface_embeddings(face_id_embs=ids512.to(dev), avg_at_stage="id_emb")
+        ada1, _, _ = enc.generate_adaface_embeddings(face_id_embs=enc.average_id_embs(ids512.to(dev)), avg_at_stage="id_emb")
     assert ada1.shape == (16, 768)
 
 
