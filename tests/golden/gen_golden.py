@@ -986,6 +986,46 @@ def gen_id2ada_glue(out):
     print("id2ada_glue:", {k: v.shape for k, v in res.items() if k.startswith("gen.") and k.endswith("embs")})
 
 
+
+WRAPPER_PROMPTS = ("a z walking a dog", "portrait of the z, oil painting", "z", "an z and a cat, z smiling", None, "photo of a woman",
+                   "a zebra next to z")
+
+
+def gen_wrapper_glue(out):
+    """REFERENCE ``AdaFaceWrapper.update_text_encoder_subj_embeddings`` and ``update_prompt`` (adaface/adaface_wrapper.py:461-532) on a
+    constructor-free wrapper with a fake pipeline (token table + name -> id map): which rows of the token table receive the subject
+    embeddings, the updated-token strings, and the rewritten prompts (append / prepend, per-encoder repetition, null placeholders)."""
+    import json
+    import adaface.adaface_wrapper as ref_w
+    from adaface_dev_amd import rng
+    res = {}
+    for tag, enc_types, enabled, lens in (("arc2face", ["arc2face"], None, [16]), ("joint_one_disabled", ["consistentID", "arc2face"], ["arc2face"], [4, 16])):
+        vocab = {f"z_{i}_{j}": 1000 + 100 * i + j for i in range(len(enc_types)) for j in range(20)}
+        table = torch.zeros(1300, 8)
+        tok = types.SimpleNamespace(convert_tokens_to_ids=lambda t, v=vocab: v[t])
+        te = types.SimpleNamespace(get_input_embeddings=lambda t=table: types.SimpleNamespace(weight=types.SimpleNamespace(data=t)))
+        w = ref_w.AdaFaceWrapper.__new__(ref_w.AdaFaceWrapper)
+        torch.nn.Module.__init__(w)
+        w.subject_string, w.adaface_encoder_types, w.enabled_encoders = "z", enc_types, enabled
+        w.pipeline = types.SimpleNamespace(text_encoder=te, tokenizer=tok)
+        w.all_null_placeholder_tokens_str = " ".join([","] * sum(lens))
+        embs = rng.synth_input(f"wrap.embs.{tag}", (sum(lens), 8), seed=77)
+        import contextlib, io
+        with contextlib.redirect_stdout(io.StringIO()):
+            w.update_text_encoder_subj_embeddings(embs, lens)
+        res[f"{tag}.table_rows"] = np.asarray(sorted(int(i) for i in torch.nonzero(table.abs().sum(1)).flatten()))
+        res[f"{tag}.table"] = table.numpy()
+        info = {"updated_tokens_str": w.updated_tokens_str, "all_encoders_updated_token_strs": w.all_encoders_updated_token_strs, "prompts": {}}
+        for pi, prompt in enumerate(WRAPPER_PROMPTS):
+            for pos in ("append", "prepend"):
+                for rep in (True, False):
+                    for null in (False, True):
+                        info["prompts"][f"{pi}|{pos}|{int(rep)}|{int(null)}"] = w.update_prompt(prompt, pos, rep, null)
+        res[f"{tag}.info"] = np.asarray(json.dumps(info))
+    np.savez_compressed(os.path.join(out, "wrapper_glue.npz"), **res)
+    print("wrapper_glue:", json.loads(str(res["arc2face.info"]))["prompts"]["0|append|1|0"][:60])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-full", action="store_true")
@@ -997,7 +1037,7 @@ def main():
     # host-orchestration fixtures: the reference's ddpm.py / unet_teachers.py / diffusers_attn_lora_capture.py are imported with
     # EMPTY stand-ins for their absent third-party packages (tests/golden/ref_import.py)
     host_jobs = {"teacher": gen_teacher, "sdpa": gen_sdpa, "guided_denoise": gen_guided_denoise, "distill_loss": gen_distill_loss,
-                 "comp_losses": gen_comp_losses, "comp_multistep": gen_comp_multistep, "id2ada_glue": gen_id2ada_glue}
+                 "comp_losses": gen_comp_losses, "comp_multistep": gen_comp_multistep, "id2ada_glue": gen_id2ada_glue, "wrapper_glue": gen_wrapper_glue}
     if args.only in host_jobs or args.only is None:
         sys.path.insert(0, HERE)
         sys.path.insert(0, os.path.dirname(HERE))

@@ -61,3 +61,34 @@ def test_word_tokenizer_protocol():
     assert t.convert_tokens_to_ids("z_0_1") == 49409 and t.convert_tokens_to_ids(["photo", ","]) == [1125, 267]
     ids = t(["A photo, z_0_0"], max_length=8).input_ids[0].tolist()
     assert ids == [49406, 320, 1125, 267, 49408, 49407, 49407, 49407]
+
+
+def test_prompt_rewrite_and_token_patching_vs_reference_fixture():
+    """The same two functions against what the REFERENCE's own ``AdaFaceWrapper.update_text_encoder_subj_embeddings`` / ``update_prompt``
+    produced (tests/golden/wrapper_glue.npz, written by gen_golden.py::gen_wrapper_glue on a constructor-free reference wrapper): 7 prompts
+    x append / prepend x per-encoder repetition x null placeholders, for the single Arc2Face encoder and for a two-encoder setup with one
+    encoder disabled."""
+    import json
+    import os
+    import numpy as np
+    from conftest import GOLDEN
+    from adaface_dev_amd import rng
+    g = np.load(os.path.join(GOLDEN, "wrapper_glue.npz"))
+    prompts = ("a z walking a dog", "portrait of the z, oil painting", "z", "an z and a cat, z smiling", None, "photo of a woman", "a zebra next to z")
+    for tag, enc_types, enabled, lens in (("arc2face", ["arc2face"], None, [16]), ("joint_one_disabled", ["consistentID", "arc2face"], ["arc2face"], [4, 16])):
+        w = _wrapper()
+        w.adaface_encoder_types, w.enabled_encoders = enc_types, enabled
+        vocab = {f"z_{i}_{j}": 1000 + 100 * i + j for i in range(len(enc_types)) for j in range(20)}
+        w.tokenizer = type("T", (), {"convert_tokens_to_ids": staticmethod(lambda t, v=vocab: v[t])})()
+        w.text_encoder.text_model.embeddings.token_embedding.weight.data = torch.zeros(1300, 8)
+        w.all_null_placeholder_tokens_str = " ".join([","] * sum(lens))
+        w.update_text_encoder_subj_embeddings(rng.synth_input(f"wrap.embs.{tag}", (sum(lens), 8), seed=77), lens)
+        table = w.text_encoder.text_model.embeddings.token_embedding.weight.data
+        assert np.array_equal(table.numpy(), g[f"{tag}.table"])
+        info = json.loads(str(g[f"{tag}.info"]))
+        assert w.updated_tokens_str == info["updated_tokens_str"] and w.all_encoders_updated_token_strs == info["all_encoders_updated_token_strs"]
+        for pi, prompt in enumerate(prompts):
+            for pos in ("append", "prepend"):
+                for rep in (True, False):
+                    for null in (False, True):
+                        assert w.update_prompt(prompt, pos, rep, null) == info["prompts"][f"{pi}|{pos}|{int(rep)}|{int(null)}"], (tag, prompt, pos, rep, null)
