@@ -423,10 +423,13 @@ def test_guided_denoise_cfg_x0_grad_modes_vs_oracle(dev):
                                                     capture_ca_activations=True)
     assert rec_none is None and not e_none.requires_grad and rel_l2(e_none.cpu().numpy(), ref.detach().numpy()) < 2 * NET_TOL      # guided at s = 2.5, as above
     assert sorted(acts_none["attn"].keys()) == [22, 23, 24]                       # captures are available on the no-grad path
-    with pytest.raises(NotImplementedError):                                      # ... and refused loudly together with gradients
-        ld.guided_denoise(x0.to(dev), noise.to(dev), t.to(dev), (ctx.to(dev).requires_grad_(True), ["a", "b"], {}),
-                          capture_ca_activations=True)
-    with pytest.raises(NotImplementedError):                                      # the score rewrites are refused by the U-Net wrapper
+    # ... and together with gradients (the Stage-2 capture pass, tests/test_hip_capture_graph.py): same eps, captures carry autograd
+    cgc = ctx.clone().to(dev).requires_grad_(True)
+    e_cap, _, acts_cap = ld.guided_denoise(x0.to(dev), noise.to(dev), t.to(dev), (cgc, ["a", "b"], {}), img_mask=mask.to(dev),
+                                           batch_part_has_grad="all", cfg_scale=2.5, capture_ca_activations=True)
+    assert e_cap.requires_grad and acts_cap["attn"][24].requires_grad
+    assert rel_l2(e_cap.detach().cpu().numpy(), ref.detach().numpy()) < 2 * NET_TOL
+    with pytest.raises(ValueError, match="subj_indices"):                         # the normalisation needs the subject-token indices
         ld.guided_denoise(x0.to(dev), noise.to(dev), t.to(dev), (ctx.to(dev), ["a", "b"], {}), normalize_cross_attn=True)
 
 
@@ -475,5 +478,5 @@ def test_unet_wrapper_ffn_lora_flags_merge_and_restore(dev):
     cg = ctx.clone().requires_grad_(True)
     with pytest.raises(RuntimeError, match="no trainable adapters"):
         ld.apply_model(x, t, (cg, ["a"] * 2, {}), use_ffn_lora=True, ffn_lora_adapter_name="unet_distill")
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(RuntimeError, match="set_up_attn_loras"):                  # training through state-dict (merged) attention adapters
         ld.apply_model(x, t, (cg, ["a"] * 2, {}), use_attn_lora=True)
