@@ -209,6 +209,64 @@ def run_train(args, ctx, dev, stage=1):
     return out
 
 
+XATTN_BLOCK_GFLOP_PER_SAMPLE = 32.1        # to_q + to_k + to_v + core + to_out of the 16 attn2 blocks
+
+
+def cross_attn_block_time(unet, ctx2, B, dev):
+    """north_star's "MFMA utilisation on U-Net cross-attention", on the WHOLE attn2 block as SURVEY.md 8d defines it: for each of the
+    16 cross-attention layers the q projection, the 77-key attention core and the output projection with its residual (what
+    ``CrossAttention.hip`` launches per layer) are timed in isolation -- 10 calls captured in a hipGraph, inputs resident -- plus ONE
+    launch of the batched k / v projection of all layers.  The algorithmic work (32.1 GFLOP per U-Net sample) over the summed time
+    is priced against the dense fp16 MFMA peak; the core alone is the HBM-bound ``cross_attn_core`` entry above."""
+    from adaface_dev_amd.ldm.modules.attention import SpatialTransformer
+
+    def timed(fn, reps=10):
+        fn()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            fn()
+        torch.cuda.current_stream().wait_stream(s)
+        with torch.cuda.graph(g):
+            for _ in range(reps):
+                fn()
+        g.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        g.replay()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / reps
+    with torch.no_grad():
+        t_kv = timed(lambda: [setattr(m, "_kv_pre", None) for m in unet._project_context_all(ctx2)])
+        layers = unet._project_context_all(ctx2)          # leave the projections in place for the per-layer calls
+        per_layer, tot = [], t_kv
+        n = 2 * B
+        for blocks in (unet.input_blocks, [unet.middle_block], unet.output_blocks):
+            for module in blocks:
+                for layer in module:
+                    if isinstance(layer, SpatialTransformer):
+                        a2 = layer.transformer_blocks[0].attn2
+                        C = a2.inner_dim
+                        N = {320: 4096, 640: 1024}.get(C, 256)
+                        if C == 1280 and module is unet.middle_block:
+                            N = 64
+                        x = torch.randn(n * N, C, device=dev).half()
+                        ms = timed(lambda a2=a2, x=x, N=N: a2.hip(x, n, N, ctx2, None, residual=x))
+                        per_layer.append((C, N, round(ms * 1e3, 1)))
+                        tot += ms
+        for m in layers:
+            m._kv_pre = None
+    tf = XATTN_BLOCK_GFLOP_PER_SAMPLE * 1e9 * n / (tot * 1e-3) / 1e12
+    return {"ms_per_step": round(tot, 4), "kv_projection_ms": round(t_kv, 4), "tflops": round(tf, 1), "mfma_frac": round(tf / MFMA_PEAK_TFLOPS, 4),
+            "definition": "sum over the 16 attn2 blocks of [to_q GEMM + 77-key attention core + to_out GEMM with residual] + one batched "
+                          "k/v projection, each timed in isolation (hipGraph of 10 calls); 32.1 GFLOP per U-Net sample (SURVEY.md 8d)",
+            "layers_C_N_us": per_layer}
+
+
 def run_denoise(args, ctx, dev):
     """BASELINE configs[1]: the headline line.  Returns the result dict on rank 0 (None elsewhere)."""
     world, rank, local_rank, launched = ctx
@@ -355,6 +413,7 @@ def run_denoise(args, ctx, dev):
                 "algorithmic_GBps": round(XATTN_BYTES_PER_SAMPLE * 2 * B / (x_ms * 1e-3) / 1e9, 1),
                 "hbm_frac": round(XATTN_BYTES_PER_SAMPLE * 2 * B / (x_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
         }
+        roofline["cross_attn_block"] = cross_attn_block_time(unet, ctx2, B, dev)
 
     cpu_baseline = None
     if not args.no_cpu_baseline and rank == 0 and world == 1:

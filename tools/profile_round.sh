@@ -1,0 +1,28 @@
+#!/bin/bash
+# Profiles of the default bench (run on the GPU box from the repo root):   bash tools/profile_round.sh r02j
+#   <tag>_bench_line.json        python bench.py (all legs)
+#   <tag>_bench_kernel_stats.txt rocprofv3 --kernel-trace --stats of the denoise leg, last 10 steps
+#   <tag>_hbm_traffic.json       two separate --pmc passes (FETCH_SIZE, WRITE_SIZE) of 6 eager denoise steps, per kernel family
+set -u
+TAG=${1:-r02}
+OUT=$PWD/gpurun_out
+export TMPDIR=/tmp
+python3 bench.py > $OUT/${TAG}_bench_line.json 2> $OUT/${TAG}_bench.err
+rm -rf $OUT/${TAG}_trace $OUT/${TAG}_pmc_f $OUT/${TAG}_pmc_w
+rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_trace -- python3 bench.py --mode denoise --steps 20 --warmup 3 --no-cpu-baseline --no-roofline > $OUT/${TAG}_trace.log 2>&1
+DB=$(find $OUT/${TAG}_trace -name "*_results.db" | head -1)
+N=$(python3 - <<PY
+import sqlite3
+c = sqlite3.connect("$DB")
+names = [r[0] for r in c.execute("select name from kernels order by start")]
+# dispatches per denoise step = distance between the last two cfg_ddim kernels
+idx = [i for i, n in enumerate(names) if "cfg_ddim" in n]
+print((idx[-1] - idx[-2]) * 10)
+PY
+)
+{ echo "# rocprofv3 --kernel-trace --stats -- python3 bench.py --mode denoise --steps 20 --warmup 3 --no-cpu-baseline --no-roofline   (last 10 steps = $N dispatches)"; python3 tools/rocpd_summary.py $DB --last $N; } > $OUT/${TAG}_bench_kernel_stats.txt
+rocprofv3 --pmc FETCH_SIZE -d $OUT/${TAG}_pmc_f -- python3 bench.py --mode denoise --steps 5 --warmup 0 --no-graph --no-cpu-baseline --no-roofline > $OUT/${TAG}_pmc_f.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $OUT/${TAG}_pmc_w -- python3 bench.py --mode denoise --steps 5 --warmup 0 --no-graph --no-cpu-baseline --no-roofline > $OUT/${TAG}_pmc_w.log 2>&1
+python3 tools/pmc_traffic.py $(find $OUT/${TAG}_pmc_f -name "*_results.db" | head -1) $(find $OUT/${TAG}_pmc_w -name "*_results.db" | head -1) --steps 6 --json $OUT/${TAG}_hbm_traffic.json > $OUT/${TAG}_hbm_traffic.txt 2>&1
+rm -rf $OUT/${TAG}_trace $OUT/${TAG}_pmc_f $OUT/${TAG}_pmc_w
+tail -3 $OUT/${TAG}_hbm_traffic.txt; head -12 $OUT/${TAG}_bench_kernel_stats.txt
