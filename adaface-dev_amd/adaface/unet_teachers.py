@@ -19,6 +19,7 @@ class UNetTeacher(nn.Module):
         self.cfg_scale_range = cfg_scale_range
         self.cfg_scale = 1
         self.uses_cfg = False
+        self.graphs = None            # graphs.GraphedSegment: set by the trainer (use_graphs) to replay the multi-step forward as one hipGraph
         if self.unet is not None:
             for p in self.unet.parameters():
                 p.requires_grad_(False)
@@ -54,7 +55,22 @@ class UNetTeacher(nn.Module):
         if same_t_noise_across_instances:
             t = t[0].repeat(x_start.shape[0])
             noise = noise[:1].repeat(x_start.shape[0], 1, 1, 1)
+        same = bool(same_t_noise_across_instances)
+        if self.graphs is not None and presampled is None and x_start.is_cuda and not self.uses_cfg:
+            # fixed shapes, no host decision inside: one hipGraph per signature (graphs.py).  The random draws of the extra steps are
+            # captured as graph-safe generator increments, so every replay draws fresh numbers.  (With CFG the scale is a fresh host
+            # draw per call and would be frozen into the capture: that path stays eager.)
+            key = (tuple(x_start.shape), tuple(teacher_context.shape), int(num_denoising_steps), same, global_t_lb, global_t_ub)
+            return self.graphs.run(key, lambda xs, nz, tt, tc: self._multistep(ddpm_model, xs, nz, tt, tc, None, num_denoising_steps, same,
+                                                                               global_t_lb, global_t_ub, None),
+                                   [x_start, noise, t, teacher_context])
+        return self._multistep(ddpm_model, x_start, noise, t, teacher_context, negative_context, num_denoising_steps, same, global_t_lb,
+                               global_t_ub, presampled)
 
+    def _multistep(self, ddpm_model, x_start, noise, t, teacher_context, negative_context, num_denoising_steps, same_t_noise_across_instances,
+                   global_t_lb, global_t_ub, presampled):
+        """The denoising loop of forward() (unet_teachers.py:115-185); same_t_noise was already applied to t / noise by the caller, the
+        flag re-applies it to the draws of the extra steps."""
         x_starts, noises, ts, noise_preds = [x_start], [noise], [t], []
         for i in range(num_denoising_steps):
             x_start, t, noise = x_starts[i], ts[i], noises[i]

@@ -1,0 +1,54 @@
+"""hipGraph capture of the fixed-shape segments of the training micro-batch.
+
+A Stage-1 micro-batch issues ~4,100 kernel launches from Python (ctypes), ~10 us of host time each: the host, not the GPU, bounds the
+step (rocprofv3: 55 ms of kernels in a 78 ms micro-batch, profiles/r02k_train_kernel_stats.txt).  The teacher's multi-step forward and
+the student U-Net's forward and backward walks have fixed shapes per (batch, step count) and contain no host decision, so each is
+captured ONCE per signature into a hipGraph (``torch.cuda.CUDAGraph``: capture on torch's stream, allocations from the graph's
+private pool) and replayed afterwards: one host call instead of 400-1,300.
+
+Protocol of a ``GraphedSegment``: call 1 with a new key runs eagerly (weights get packed, workspaces allocated); call 2 captures (the
+inputs are copied into static buffers first, outputs and every tensor the segment saved live in the graph's pool); later calls copy
+the inputs, replay, and return the SAME output tensors -- consumers must be done with them before the next replay of that key, which
+holds here because a micro-batch finishes before the next begins.  Anything that changes between replays must be visible through
+fixed device addresses: parameters live in their (flat-arena) storage; derived weight packs are refreshed IN PLACE by the caller
+before a replay (``refresh`` hook)."""
+import torch
+
+
+class GraphedSegment:
+    def __init__(self, name):
+        self.name = name
+        self.entries = {}          # key -> dict(state, graph, static_inputs, outputs, extra)
+        self.enabled = True
+
+    def run(self, key, fn, inputs, refresh=None):
+        """fn(*inputs) -> (outputs: tensor | tuple/list of tensors | nested, extra: any python object kept with the capture)."""
+        if not self.enabled:
+            return fn(*inputs)
+        e = self.entries.get(key)
+        if e is None:
+            self.entries[key] = {"state": "warm"}
+            return fn(*inputs)                                   # eager: lazy initialisation happens here
+        if e["state"] == "warm":
+            static = [None if t is None else t.detach().clone() for t in inputs]
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):                           # side-stream warm-up with the static buffers (torch's capture rule)
+                fn(*static)
+            torch.cuda.current_stream().wait_stream(s)
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                out = fn(*static)
+            e.update(state="graph", graph=g, static=static, out=out)
+            return out
+        for dst, src in zip(e["static"], inputs):
+            if dst is not None:
+                dst.copy_(src)
+        if refresh is not None:
+            refresh()
+        e["graph"].replay()
+        return e["out"]
+
+    def reset(self):
+        self.entries.clear()

@@ -657,39 +657,73 @@ class _UNetFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, unet, x, timesteps, context, img_mask, res_gradscale=1.0, lora=None, *lora_params):
         """lora: {output-block index: {"conv1" | "conv2" | "conv_shortcut": DoRAConvAdapter}} or None; lora_params: the adapters'
-        parameters in `lora_param_order(lora)` order (passed so that autograd routes their gradients)."""
+        parameters in `lora_param_order(lora)` order (passed so that autograd routes their gradients).
+        With ``unet.train_graphs`` (graphs.GraphedSegment pair, set by the trainer) the forward and the backward walk are each replayed
+        as ONE hipGraph per input signature instead of ~450 / ~700 launches from Python."""
         ctx.res_gradscale = res_gradscale
         ctx.lora = lora
-        xh = to_nhwc_f16(x.detach(), ops.round_up(unet.in_channels, 8))
-        try:
-            for bi, ads in (lora or {}).items():
-                unet.output_blocks[bi][0]._lora = ads
-            eps, saved = unet.hip_train(xh, timesteps, context.detach().to(F16).contiguous(), img_mask)
-        finally:
-            for bi in (lora or {}):
-                unet.output_blocks[bi][0]._lora = None
-        ctx.unet, ctx.saved = unet, saved
         ctx.need_dx, ctx.x_dtype, ctx.c_dtype = x.requires_grad, x.dtype, context.dtype
-        return from_nhwc_f16(eps, x.dtype, unet.out_channels)
+
+        def body(xs, ts, cs, ms):
+            xh = to_nhwc_f16(xs, ops.round_up(unet.in_channels, 8))
+            try:
+                for bi, ads in (lora or {}).items():
+                    unet.output_blocks[bi][0]._lora = ads
+                eps, saved = unet.hip_train(xh, ts, cs.to(F16).contiguous(), ms)
+            finally:
+                for bi in (lora or {}):
+                    unet.output_blocks[bi][0]._lora = None
+            return from_nhwc_f16(eps, xs.dtype, unet.out_channels), saved
+
+        graphs = getattr(unet, "train_graphs", None)
+        if graphs is not None and x.is_cuda:
+            ctx.key = (tuple(x.shape), tuple(context.shape), str(x.dtype), str(context.dtype), img_mask is not None, float(res_gradscale),
+                       tuple(id(a) for _, _, _, a in lora_param_order(lora)), ctx.need_dx)
+            out, ctx.saved = graphs[0].run(ctx.key, body, [x.detach(), timesteps, context.detach(), img_mask],
+                                           refresh=lambda: _refresh_adapter_packs(lora))
+        else:
+            ctx.key = None
+            out, ctx.saved = body(x.detach(), timesteps, context.detach(), img_mask)
+        ctx.unet = unet
+        return out
 
     @staticmethod
     def backward(ctx, deps):
         unet = ctx.unet
-        # The backward is linear in d(eps), and loss gradients are tiny (MSE over ~16k pixels): scale d(eps) by a
-        # power of two so that its largest entry is ~256 before the fp16 cast, unscale the results in fp32.  The
-        # scale is computed and applied on the device (no host sync); a power of two makes it exact.
-        amax = deps.detach().abs().amax().float().clamp_min(1e-30)
-        scale = torch.exp2(torch.floor(torch.log2(256.0 / amax)))
-        dh = to_nhwc_f16((deps * scale).contiguous(), ops.round_up(unet.out_channels, 8))
-        saved_out = ctx.saved[2]
-        dx, dctx = unet.hip_bwd(ctx.saved, dh, need_dx=ctx.need_dx, res_gradscale=ctx.res_gradscale)
-        lora_grads = []
-        for bi, key, pname, p in lora_param_order(ctx.lora):
-            g = saved_out[bi][0][5][4][key][pname]             # ResBlock saved -> (lora, s1, s2, ssc, grads)
-            lora_grads.append((g / scale).to(p.dtype))
+        lora = ctx.lora
+        saved = ctx.saved
+
+        def body(de):
+            # The backward is linear in d(eps), and loss gradients are tiny (MSE over ~16k pixels): scale d(eps) by a
+            # power of two so that its largest entry is ~256 before the fp16 cast, unscale the results in fp32.  The
+            # scale is computed and applied on the device (no host sync); a power of two makes it exact.
+            amax = de.abs().amax().float().clamp_min(1e-30)
+            scale = torch.exp2(torch.floor(torch.log2(256.0 / amax)))
+            dh = to_nhwc_f16((de * scale).contiguous(), ops.round_up(unet.out_channels, 8))
+            dx, dctx = unet.hip_bwd(saved, dh, need_dx=ctx.need_dx, res_gradscale=ctx.res_gradscale)
+            lora_grads = []
+            for bi, key, pname, p in lora_param_order(lora):
+                g = saved[2][bi][0][5][4][key][pname]             # ResBlock saved -> (lora, s1, s2, ssc, grads)
+                lora_grads.append((g / scale).to(p.dtype))
+            gx = (from_nhwc_f16(dx, torch.float32, unet.in_channels) / scale).to(ctx.x_dtype) if dx is not None else None
+            return (gx, (dctx.float() / scale).to(ctx.c_dtype)) + tuple(lora_grads)
+
+        graphs = getattr(unet, "train_graphs", None)
+        if graphs is not None and ctx.key is not None and graphs[0].entries.get(ctx.key, {}).get("state") == "graph":
+            # only once the forward of this signature is itself a graph: its saved activations then sit at fixed addresses
+            res = graphs[1].run(ctx.key, body, [deps.detach()])
+        else:
+            res = body(deps.detach())
         ctx.saved = None
-        gx = (from_nhwc_f16(dx, torch.float32, unet.in_channels) / scale).to(ctx.x_dtype) if dx is not None else None
-        return (None, gx, None, (dctx.float() / scale).to(ctx.c_dtype), None, None, None) + tuple(lora_grads)
+        return (None, res[0], None, res[1], None, None, None) + tuple(res[2:])
+
+
+def _refresh_adapter_packs(lora):
+    """Before a graph replay: re-derive the adapters' fp16 weight packs IN PLACE if the optimizer moved their parameters (the captured
+    kernels read the packs at fixed addresses; modules/dora.py::DoRAConvAdapter._packs copies into the existing buffers)."""
+    for bi in (lora or {}):
+        for ad in lora[bi].values():
+            ad._packs()
 
 
 def lora_param_order(lora):

@@ -44,7 +44,13 @@ class DoRAConvAdapter(nn.Module):
             else:
                 pa = ops.pack_matrix(A.flatten(1), None, dev)
                 pa_t = ops.pack_matrix(A.flatten(1).t().contiguous(), None, dev)
-            self._pk = (pa, pa_t, ops.pack_matrix(Bm, None, dev), ops.pack_matrix(Bm.t().contiguous(), None, dev))
+            new = (pa, pa_t, ops.pack_matrix(Bm, None, dev), ops.pack_matrix(Bm.t().contiguous(), None, dev))
+            old = getattr(self, "_pk", None)
+            if old is not None and all(o.wt.shape == n.wt.shape and o.wt.device == n.wt.device for o, n in zip(old, new)):
+                for o, n in zip(old, new):          # same buffers, new values: captured hipGraphs keep reading these addresses
+                    o.wt.copy_(n.wt)
+            else:
+                self._pk = new
             self._pack_key = key
         return self._pk
 

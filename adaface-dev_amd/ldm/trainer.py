@@ -69,9 +69,20 @@ class DistillTrainer:
                  betas=(0.9, 0.995), eps=1e-6, weight_decay=0.0, lora_weight_decay=0.02, warm_up_steps=500, max_decay_steps=60000,
                  bucket_bytes=32 << 20, loss_scaler=None, prompt_len=77, subj_slot=4, process_group=None,
                  gradient_clip_val=0.01, gradient_clip_algorithm="value", p_gen_rand_id_for_id2img=0.0, p_perturb_face_id_embs=0.0,
-                 perturb_face_id_embs_std_range=(0.3, 0.6), stage=1):
+                 perturb_face_id_embs_std_range=(0.3, 0.6), stage=1, use_graphs=False):
         self.ldm, self.id2ada, self.text_encoder = ldm, id2ada, text_encoder
         self.iter_type = "comp_distill" if stage == 2 else "unet_distill"
+        self.graph_segments = []
+        if use_graphs:
+            # hipGraph replay of the fixed-shape segments of the micro-batch (graphs.py): the teacher's multi-step forward and the
+            # student U-Net's forward / backward walks -- ~2,400 of the ~4,100 Python-issued launches of a Stage-1 micro-batch
+            from ..graphs import GraphedSegment
+            unet = ldm.model.diffusion_model
+            unet.train_graphs = (GraphedSegment("student.forward"), GraphedSegment("student.backward"))
+            self.graph_segments += list(unet.train_graphs)
+            if getattr(ldm, "unet_teacher", None) is not None:
+                ldm.unet_teacher.graphs = GraphedSegment("teacher.multistep")
+                self.graph_segments.append(ldm.unet_teacher.graphs)
         for p in text_encoder.parameters():
             p.requires_grad_(False)
         self.accum = accumulate_grad_batches
@@ -299,6 +310,11 @@ class DistillTrainer:
         return ldm.calc_comp_feat_distill_loss(self.mon_loss_dict, "train", noise_preds, acts, subj_1b, emb_mask, pad_mask, 1, sc_fg_mask=sc_fg_mask)
 
     iter_type = "unet_distill"        # or "comp_distill" (Stage 2)
+
+    def set_graphs_enabled(self, on: bool):
+        """Switch the captured segments between replay and eager launches (eager is needed when launches are to be timed one by one)."""
+        for g in self.graph_segments:
+            g.enabled = bool(on)
 
     def training_step(self, batch, batch_idx, epoch=0, **kw):
         """One micro-batch: forward, scaled backward (with the gradient exchange overlapped on the last micro-batch of an

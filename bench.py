@@ -125,7 +125,8 @@ def run_train(args, ctx, dev, stage=1):
         box = torch.zeros(1, 1, 64, 64, device=dev)
         box[:, :, 16:44, 18:46] = 1                                        # 19 % of the image: inside the reference's 'good' face range
         step_kw = dict(face_mask_fn=lambda x_recons: box)
-    tr = DistillTrainer(ldm, id2ada.to(dev), text_enc.to(dev), batch_size=B, accumulate_grad_batches=2, prompt_len=97, stage=stage)
+    tr = DistillTrainer(ldm, id2ada.to(dev), text_enc.to(dev), batch_size=B, accumulate_grad_batches=2, prompt_len=97, stage=stage,
+                        use_graphs=(stage == 1 and not args.no_train_graphs))
     n_train = sum(a.numel for a in tr.arenas)
 
     def batch(i):
@@ -156,6 +157,7 @@ def run_train(args, ctx, dev, stage=1):
     fam = None
     if not args.no_roofline:
         # every rank runs the instrumented micro-batches (the gradient exchange is a collective); rank 0 reports its families
+        tr.set_graphs_enabled(False)                   # per-launch events need eager launches
         ops.prof_reset()
         ops.prof_enable(True)
         for i in range(6):                             # one full 2,3,4-step cycle twice over (6 micro-batches)
@@ -198,6 +200,7 @@ def run_train(args, ctx, dev, stage=1):
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
                "config": {"workload": workload,
                           "parallelism": f"dp{world} (RCCL bucketed all-reduce overlapped with backward)" if world > 1 else "single GPU",
+                          "hipgraph_segments": [f"{g.name}: {sum(1 for e in g.entries.values() if e.get('state') == 'graph')} captured" for g in tr.graph_segments],
                           "optimizer_steps": tr.global_step, "skipped_steps": tr.skipped_steps, "loss_scale": tr.scaler.scale,
                           "last_loss": float(losses[-1]), "finite": bool(all(torch.isfinite(l) for l in losses))},
                "roofline": {"bound": "mfma", "achieved": round(train_tflop / (ms * 1e-3), 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -500,7 +503,8 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-ffn-lora", action="store_true", help="train leg: without the U-Net's trainable FFN DoRA adapters")
     ap.add_argument("--train-steps", type=int, default=12, help="timed micro-batches of the train leg")
-    ap.add_argument("--train-warmup", type=int, default=6)
+    ap.add_argument("--train-warmup", type=int, default=12, help="untimed micro-batches (the hipGraph segments of every signature are captured in here)")
+    ap.add_argument("--no-train-graphs", action="store_true", help="train leg: launch every kernel from Python instead of replaying captured segments")
     ap.add_argument("--mode", choices=["all", "denoise", "train", "train2"], default="all",
                     help="all (default): the headline denoise line (BASELINE configs[1]) carrying the Stage-1 training leg "
                          "(configs[2]/[3]) as its `train` object; denoise / train: one leg only (train prints its own line)")

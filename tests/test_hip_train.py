@@ -542,3 +542,41 @@ def test_comp_distill_iteration_reduced_width(dev, attn_aug):
     l = tr.training_step(b, 0, face_mask_fn=face_box, attn_aug=attn_aug)
     assert torch.isfinite(l) and tr.global_step == 1 and tr.skipped_steps == 0
     assert float((tr.arenas[0].flat_p - p0[0]).abs().sum()) > 0
+
+
+def test_graph_replayed_segments_reproduce_the_eager_micro_batch(dev):
+    """use_graphs: the teacher's forward and the student U-Net's forward / backward walks are captured into hipGraphs on their second
+    call per signature and replayed afterwards.  Six micro-batches of one signature (explicit timesteps / noise, one denoising step, no
+    dropout: nothing random inside the segments) -- eager, captured and replayed ones -- must give bit-identical losses and
+    parameter trajectories to a trainer without graphs, across optimizer steps that move the FFN adapters (their packs are
+    refreshed in place for the replays)."""
+    from adaface_dev_amd import rng
+    from adaface_dev_amd.ldm.trainer import DistillTrainer, LossScaler
+
+    def run(use_graphs):
+        tr, _, _ = trainer_setup(dev, accum=1, ffn_lora=True)
+        for ad in (a for d in tr.ldm.model.ffn_lora.active("unet_distill").values() for a in d.values()):
+            ad.p = 0.0
+        if use_graphs:
+            tr2 = DistillTrainer(tr.ldm, tr.id2ada, tr.text_encoder, accumulate_grad_batches=1, warm_up_steps=0,
+                                 loss_scaler=LossScaler(init_scale=2.0 ** 10), use_graphs=True)
+            tr.reducer.remove()
+            tr = tr2
+        for g in tr.optimizer.param_groups:
+            g["lr"] = 1e-3
+        tr.learning_rate = 1e-3
+        t = torch.tensor([760, 850, 800, 720], device=dev)
+        losses = []
+        for i in range(6):
+            b = dict(x_start=rng.synth_input(f"gr.x{i % 2}", (4, 4, 32, 32), seed=50).to(dev), face_id_embs=rng.synth_input(f"gr.id{i % 2}", (4, 512), seed=50).to(dev),
+                     fg_mask=torch.ones(4, 1, 32, 32, device=dev), noise=rng.synth_input(f"gr.n{i % 2}", (4, 4, 32, 32), seed=50).to(dev))
+            losses.append(float(tr.training_step(b, i, num_unet_denoising_steps=1, t=t)))
+        return losses, [a.flat_p.clone() for a in tr.arenas], tr
+    l0, p0, _ = run(False)
+    l1, p1, tr = run(True)
+    states = [[e.get("state") for e in g.entries.values()] for g in tr.graph_segments]
+    assert all(st == ["graph"] for st in states), states                    # every segment was captured (and then replayed)
+    assert l0 == l1, (l0, l1)
+    for a, b in zip(p0, p1):
+        assert torch.equal(a, b)
+    assert len(set(l0)) > 2                                                  # the optimizer really moved things between micro-batches
