@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(CSRC, "libadaface_hip.so")
 
 AF_OK, AF_E_BADARG, AF_E_UNSUPPORTED, AF_E_HIP = 0, -1, -2, -3
 AF_ACT_NONE, AF_ACT_SILU, AF_ACT_GEGLU, AF_ACT_QUICKGELU = 0, 1, 2, 3
-AF_OUT_NORMAL, AF_OUT_SPLIT_T = 0, 1
+AF_OUT_NORMAL, AF_OUT_SPLIT_T, AF_OUT_F32 = 0, 1, 2
 AF_SPLITK_COUNTER_BYTES = 4096 * 4
 AF_FAM_GEMM, AF_FAM_ATTN, AF_FAM_GNORM, AF_FAM_LNORM, AF_FAM_ELEM, AF_FAM_XATTN = 0, 1, 2, 3, 4, 5
 

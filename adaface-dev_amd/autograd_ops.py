@@ -20,11 +20,14 @@ from .ops import F16, round_up
 
 
 def wgrad(dy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
-    """dW [N, K] = dy^T [N, M] @ x [M, K] through af_gemm: both operands are token-transposed so the reduction (M) is the
-    K-contiguous axis the GEMM kernels want; pads are zero-filled."""
+    """dW [N, K] (fp32) = dy^T [N, M] @ x [M, K] through af_gemm: both operands are token-transposed so the reduction (M) is the
+    K-contiguous axis the GEMM kernels want; pads are zero-filled.  The result is the fp32 accumulator (AF_OUT_F32): a sum over
+    thousands of tokens of |dy| ~ 40, |x| ~ 20 passes 65504 -- seen on the 1x1 shortcut adapters -- and an fp16 cast there would
+    make every optimizer step of the run an overflow-skip, because the U-Net backward normalises d(eps) itself (openaimodel.py)
+    and the loss scaler cannot shrink it."""
     M, N = dy.shape
     K = x.shape[1]
-    m64 = round_up(M, 64)
+    m64 = max(128, round_up(M, 64))
     dev = dy.device
     dyt = torch.empty((N, m64), dtype=F16, device=dev)                         # the transpose zero-fills columns M..m64
     k128 = round_up(K, 128)
@@ -33,7 +36,7 @@ def wgrad(dy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     _lib.check(L.af_transpose_tokens(ops._p(dy), ops._p(dyt), 1, M, N, N, m64, ops._stream()), "af_transpose_tokens")
     _lib.check(L.af_transpose_tokens(ops._p(x), ops._p(xt), 1, M, K, K, m64, ops._stream()), "af_transpose_tokens")
     pw = ops.PackedWeight(xt, None, K, m64, m64, 1, m64)
-    return ops.gemm(dyt, pw)
+    return ops.gemm(dyt, pw, out_f32=True)
 
 
 class LinearFn(torch.autograd.Function):

@@ -40,6 +40,7 @@ class GraphedSegment:
             torch.cuda.current_stream().wait_stream(s)
             with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 out = fn(*static)
+            g.replay()                                           # capture only records: this is the launch that computes `out`
             e.update(state="graph", graph=g, static=static, out=out)
             return out
         for dst, src in zip(e["static"], inputs):

@@ -19,7 +19,7 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import AF_ACT_GEGLU, AF_ACT_NONE, AF_ACT_QUICKGELU, AF_ACT_SILU, AF_OUT_NORMAL, AF_OUT_SPLIT_T, GemmDesc
+from ._lib import AF_ACT_GEGLU, AF_ACT_NONE, AF_ACT_QUICKGELU, AF_ACT_SILU, AF_OUT_F32, AF_OUT_NORMAL, AF_OUT_SPLIT_T, GemmDesc
 
 F16 = torch.float16
 NEG_MAX = -torch.finfo(torch.float32).max
@@ -158,31 +158,34 @@ SPLITK_FUSED_MAX = int(_os.environ.get("AF_SPLITK_FUSED_MAX", "0"))
 def _launch_gemm(d: "GemmDesc", device, what: str, tile: int = 0, splits: int = 0):
     """Pick (tile, splits) -- explicit args > recorder (autotune) > table > heuristic -- and launch."""
     if tile == 0 and splits == 0:
-        key = f"{d.taps},{d.M},{d.N},{d.K},{d.act},{d.out_mode},{d.stride},{d.upsample}"
+        key = f"{d.taps},{d.M},{d.N},{d.K},{d.act},{0 if d.out_mode == AF_OUT_F32 else d.out_mode},{d.stride},{d.upsample}"
         if _tune_recorder is not None:
             tile, splits = _tune_recorder(key, d, device)
         else:
             tile, splits = tune_table().get(key, (0, 1))
     d.tile = tile
     d.zeros = _zero_page(device).data_ptr()
-    d.splits = max(1, splits)
+    f32 = d.out_mode == AF_OUT_F32
+    d.splits = max(2 if f32 else 1, splits)                    # fp32 results are written by the split-K reduce pass
     if d.splits > 1:
-        if d.act == AF_ACT_GEGLU or d.out_mode != AF_OUT_NORMAL:
+        if d.act == AF_ACT_GEGLU or d.out_mode == AF_OUT_SPLIT_T:
             d.splits = 1
         else:
             ws = _splitk_workspace(device)
             d.splits = max(1, min(d.splits, (ws.numel() * 4 - _lib.AF_SPLITK_COUNTER_BYTES) // (d.M * d.N * 4)))
+            assert not f32 or d.splits >= 2, f"{what}: fp32 output [{d.M}, {d.N}] does not fit the split-K workspace twice"
             d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
-            d.splitk_fused = int(d.splits <= SPLITK_FUSED_MAX)
+            d.splitk_fused = int(d.splits <= SPLITK_FUSED_MAX and not f32)
     _lib.check(_lib.lib().af_gemm(C.byref(d), _stream()), what)
 
 
 # ----------------------------------------------------------------------------- gemm / conv
 def gemm(a1: torch.Tensor, pw: PackedWeight, *, a2: Optional[torch.Tensor] = None, rowbias: Optional[torch.Tensor] = None,
          rows_per_batch: int = 0, residual: Optional[torch.Tensor] = None, act: int = AF_ACT_NONE,
-         split_col: int = 0, ld_out2: int = 0, tile: int = 0, splits: int = 0):
+         split_col: int = 0, ld_out2: int = 0, tile: int = 0, splits: int = 0, out_f32: bool = False):
     """Plain-rows GEMM: a1 [M, K1] (+ a2 [M, K2], concatenated along K) x pw.  Returns out
-    ([M, N], or [M, N/2] for GEGLU), or (out [M, split_col], out2 [B, N-split_col, ld_out2])."""
+    ([M, N], or [M, N/2] for GEGLU), or (out [M, split_col], out2 [B, N-split_col, ld_out2]).  out_f32: the fp32 accumulator is
+    returned (AF_OUT_F32; weight gradients)."""
     _chk_f16(a1, "gemm.a1")
     M, k1 = a1.shape
     k2 = 0
@@ -207,6 +210,10 @@ def gemm(a1: torch.Tensor, pw: PackedWeight, *, a2: Optional[torch.Tensor] = Non
         out = torch.empty((M, split_col), dtype=F16, device=a1.device)
         out2 = torch.empty((nb, pw.N - split_col, ld_out2), dtype=F16, device=a1.device)
         d.out_mode, d.split_col, d.ld_out2, d.out2 = AF_OUT_SPLIT_T, split_col, ld_out2, _p(out2)
+    elif out_f32:
+        assert act == AF_ACT_NONE and pw.kpad >= 128 and pw.N % 4 == 0
+        out = torch.empty((M, pw.N), dtype=torch.float32, device=a1.device)
+        d.out_mode = AF_OUT_F32
     else:
         n_out = pw.N // 2 if act == AF_ACT_GEGLU else pw.N
         out = torch.empty((M, n_out), dtype=F16, device=a1.device)

@@ -71,6 +71,9 @@ int af_prof_read(int family, int* launches, double* total_ms);
  *   out has N/2 columns: a * gelu_erf(g), attention.py:36-38).
  *   out_mode AF_OUT_SPLIT_T: columns n >= split_col are written TRANSPOSED to out2
  *   ([B, N - split_col, ld_out2] with token index contiguous): V^T for the attention kernel.
+ *   out_mode AF_OUT_F32: out is fp32 [M][ld_out] -- the accumulator is stored without the fp16 cast (weight gradients: sums over
+ *   thousands of tokens overflow fp16 long before they lose precision).  Needs splits >= 2, kpad >= 128, the standard
+ *   epilogue and the two-launch split-K form: the reduce pass is what writes fp32.
  */
 #define AF_ACT_NONE 0
 #define AF_ACT_SILU 1
@@ -78,6 +81,7 @@ int af_prof_read(int family, int* launches, double* total_ms);
 #define AF_ACT_QUICKGELU 3 /* x * sigmoid(1.702 x): CLIP text MLP (transformers QuickGELUActivation) */
 #define AF_OUT_NORMAL 0
 #define AF_OUT_SPLIT_T 1
+#define AF_OUT_F32 2
 
 typedef struct af_gemm_desc {
   const void* a1;       /* fp16 */
@@ -86,7 +90,7 @@ typedef struct af_gemm_desc {
   const void* bias;     /* fp32 [N] or NULL */
   const void* rowbias;  /* fp16 [B][ld_rowbias] or NULL */
   const void* residual; /* fp16 [M][N] or NULL */
-  void* out;            /* fp16 [M][ld_out] */
+  void* out;            /* fp16 [M][ld_out] (fp32 with AF_OUT_F32) */
   void* out2;           /* fp16, AF_OUT_SPLIT_T only */
   int32_t M, N, K;      /* logical sizes (K = taps*(c1+c2) for taps == 9) */
   int32_t kpad;         /* row stride of wt in elements */

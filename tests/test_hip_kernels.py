@@ -66,6 +66,32 @@ def test_gemm_and_conv_split_k(dev, tile, splits):
     assert rel_l2(oc.float().cpu().permute(0, 3, 1, 2).numpy(), refc.numpy()) < TOL
 
 
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 7, 8])
+def test_gemm_fp32_output_and_wgrad_past_the_fp16_range(dev, tile):
+    """AF_OUT_F32: the split-K reduce pass stores the fp32 accumulator.  Entries far beyond 65504 (a weight gradient summed over
+    thousands of tokens) come back finite and exact to fp32 summation error; autograd_ops.wgrad uses this mode."""
+    from adaface_dev_amd import ops
+    from adaface_dev_amd.autograd_ops import wgrad
+    M, N, K = 48, 320, 4096
+    a, w = rnd((M, K), 1, 30.0), rnd((N, K), 2, 20.0)
+    a[:, :64] = a[:, :64].abs()
+    w[:, :64] = w[:, :64].abs()                                       # a coherent block: sums of ~64 * 600 on top of the random walk
+    b = torch.randn(N, generator=torch.Generator().manual_seed(3))
+    out = ops.gemm(a.to(dev), ops.pack_matrix(w, b, dev), tile=tile, out_f32=True)
+    ref = a.double() @ w.double().t() + b.double()
+    assert out.dtype == torch.float32 and ref.abs().max() > 70000
+    assert torch.isfinite(out).all()
+    assert rel_l2(out.cpu().numpy(), ref.numpy()) < 1e-5
+    if tile == 0:
+        for (T, n, k) in [(4096, 16, 128), (77, 64, 96), (300, 8, 320)]:     # tokens, dy columns, x columns (ragged, < 128 tokens too)
+            dy, x = rnd((T, n), 5, 8.0), rnd((T, k), 6, 8.0)
+            dy[:, 0], x[:, 0] = 40.0, 45.0                                    # dW[0, 0] = T * 1800: 7.4e6 at T = 4096
+            dw = wgrad(dy.to(dev), x.to(dev))
+            refw = dy.double().t() @ x.double()
+            assert dw.dtype == torch.float32 and tuple(dw.shape) == (n, k) and torch.isfinite(dw).all()
+            assert rel_l2(dw.cpu().numpy(), refw.numpy()) < 1e-5
+
+
 @pytest.mark.parametrize("M,N,K,splits", [(256, 128, 64, 1), (1000, 320, 320, 1), (616, 640, 768, 2), (4096, 320, 1280, 1), (130, 4, 320, 1),
                                             (512, 1280, 2560, 4), (77, 64, 32, 1)])
 def test_gemm_tile3_pipelined(dev, M, N, K, splits):

@@ -555,11 +555,12 @@ def test_graph_replayed_segments_reproduce_the_eager_micro_batch(dev):
 
     def run(use_graphs):
         tr, _, _ = trainer_setup(dev, accum=1, ffn_lora=True)
+        tr.scaler = LossScaler(init_scale=2.0 ** 8)     # headroom for the fp16 weight-gradient GEMMs of the adapters at lr 1e-3
         for ad in (a for d in tr.ldm.model.ffn_lora.active("unet_distill").values() for a in d.values()):
             ad.p = 0.0
         if use_graphs:
             tr2 = DistillTrainer(tr.ldm, tr.id2ada, tr.text_encoder, accumulate_grad_batches=1, warm_up_steps=0,
-                                 loss_scaler=LossScaler(init_scale=2.0 ** 10), use_graphs=True)
+                                 loss_scaler=LossScaler(init_scale=2.0 ** 8), use_graphs=True)
             tr.reducer.remove()
             tr = tr2
         for g in tr.optimizer.param_groups:
@@ -568,9 +569,10 @@ def test_graph_replayed_segments_reproduce_the_eager_micro_batch(dev):
         t = torch.tensor([760, 850, 800, 720], device=dev)
         losses = []
         for i in range(6):
-            b = dict(x_start=rng.synth_input(f"gr.x{i % 2}", (4, 4, 32, 32), seed=50).to(dev), face_id_embs=rng.synth_input(f"gr.id{i % 2}", (4, 512), seed=50).to(dev),
-                     fg_mask=torch.ones(4, 1, 32, 32, device=dev), noise=rng.synth_input(f"gr.n{i % 2}", (4, 4, 32, 32), seed=50).to(dev))
+            b = dict(x_start=rng.synth_input(f"dp.x{i % 2}", (4, 4, 32, 32), seed=48).to(dev), face_id_embs=rng.synth_input(f"dp.id{i % 2}", (4, 512), seed=48).to(dev),
+                     fg_mask=torch.ones(4, 1, 32, 32, device=dev), noise=rng.synth_input(f"dp.n{i % 2}", (4, 4, 32, 32), seed=48).to(dev))
             losses.append(float(tr.training_step(b, i, num_unet_denoising_steps=1, t=t)))
+        assert tr.global_step == 6 and tr.skipped_steps == 0, (tr.global_step, tr.skipped_steps)
         return losses, [a.flat_p.clone() for a in tr.arenas], tr
     l0, p0, _ = run(False)
     l1, p1, tr = run(True)

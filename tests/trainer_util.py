@@ -41,6 +41,8 @@ def trainer_setup(dev, accum=1, process_group=None, ffn_lora=False, embedding_ma
             for n, p in lora.named_parameters():
                 if "lora_B" in n:
                     p.copy_(rng.synth_input(n, p.shape, seed=82, scale=0.3))
+                elif "lora_A" in n:       # (the module's own init draws from the global generator: two setups would differ)
+                    p.copy_(rng.synth_input(n, p.shape, seed=82, scale=p[0].numel() ** -0.5))
     if stage2:
         # Stage 2 (compositional distillation): a priming U-Net with classifier-free guidance, the unconditional prompt embedding,
         # trainable attention DoRA adapters on the captured layers, and the comp_distill FFN adapters
@@ -56,6 +58,8 @@ def trainer_setup(dev, accum=1, process_group=None, ffn_lora=False, embedding_ma
             for n, p in alora.named_parameters():
                 if "lora_B" in n:
                     p.copy_(rng.synth_input(n, p.shape, seed=84, scale=0.2))
+                elif "lora_A" in n:
+                    p.copy_(rng.synth_input(n, p.shape, seed=84, scale=p[0].numel() ** -0.5))
     tr = DistillTrainer(ld, id2ada.to(dev), text_enc.to(dev), accumulate_grad_batches=accum, warm_up_steps=0,
                         loss_scaler=LossScaler(init_scale=2.0 ** 10), process_group=process_group, stage=2 if stage2 else 1)
     return tr, sds, ucfg
