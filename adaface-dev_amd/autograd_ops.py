@@ -27,7 +27,7 @@ def wgrad(dy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     and the loss scaler cannot shrink it."""
     M, N = dy.shape
     K = x.shape[1]
-    m64 = max(128, round_up(M, 64))
+    m64 = round_up(M, 64)
     dev = dy.device
     dyt = torch.empty((N, m64), dtype=F16, device=dev)                         # the transpose zero-fills columns M..m64
     k128 = round_up(K, 128)

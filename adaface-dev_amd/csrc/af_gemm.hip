@@ -401,8 +401,12 @@ __global__ __launch_bounds__(256, 2) void af_gemm_kernel(GemmDev p) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] += (float)rv[i];
           }
-          half4_t h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-          *reinterpret_cast<half4_t*>(p.out + (size_t)m * p.ld_out + n0) = h;
+          if (EPI == EPI_STD && p.out_f32) {           // AF_OUT_F32: the accumulator itself (weight gradients)
+            *reinterpret_cast<floatx4*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ld_out + n0) = floatx4{v[0], v[1], v[2], v[3]};
+          } else {
+            half4_t h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+            *reinterpret_cast<half4_t*>(p.out + (size_t)m * p.ld_out + n0) = h;
+          }
         }
       }
     }
@@ -565,8 +569,8 @@ extern "C" int af_gemm(const af_gemm_desc* d, void* stream) {
   AF_REQUIRE(p.ld_out % 4 == 0, "af_gemm: ld_out must be a multiple of 4");
   p.out_f32 = d->out_mode == AF_OUT_F32;
   if (p.out_f32)
-    AF_REQUIRE(!geglu && p.splits >= 2 && d->kpad >= 128 && !d->splitk_fused && d->N % 4 == 0,
-               "af_gemm: AF_OUT_F32 needs the standard epilogue, splits >= 2, kpad >= 128, N % 4 == 0 and the two-launch split-K form");
+    AF_REQUIRE(!geglu && !d->splitk_fused && d->N % 4 == 0,
+               "af_gemm: AF_OUT_F32 needs the standard epilogue, N % 4 == 0 and (with split-K) the two-launch form");
   if (p.splits > 1) {
     AF_REQUIRE(!geglu && d->out_mode != AF_OUT_SPLIT_T, "af_gemm: split-K only with the standard epilogue");
     AF_REQUIRE(d->workspace != nullptr && d->workspace_bytes - (d->splitk_fused ? AF_SPLITK_COUNTER_BYTES : 0) >= (int64_t)p.splits * d->M * d->N * 4,
@@ -586,6 +590,7 @@ extern "C" int af_gemm(const af_gemm_desc* d, void* stream) {
   if (tile >= 3 && d->tap_shift) tile = 1;          // the ring kernel keeps the symmetric-padding loader only
   if (tile >= 3) {
     const int eff = af_gemm3_effective_splits(d, p.splits, tile - 3);
+    // AF_OUT_F32: the LDS-DMA kernels only reach fp32 through the split-K reduce pass; unsplit, the register-staged kernel stores it
     const int rc3 = (p.out_f32 && eff < 2) ? 1 : af_gemm3_try_launch(d, p.splits, tile - 3, s);
     if (rc3 == 0) return af_check_launch("af_gemm(tile 3)");
     if (rc3 == 2) {

@@ -158,7 +158,7 @@ SPLITK_FUSED_MAX = int(_os.environ.get("AF_SPLITK_FUSED_MAX", "0"))
 def _launch_gemm(d: "GemmDesc", device, what: str, tile: int = 0, splits: int = 0):
     """Pick (tile, splits) -- explicit args > recorder (autotune) > table > heuristic -- and launch."""
     if tile == 0 and splits == 0:
-        key = f"{d.taps},{d.M},{d.N},{d.K},{d.act},{0 if d.out_mode == AF_OUT_F32 else d.out_mode},{d.stride},{d.upsample}"
+        key = f"{d.taps},{d.M},{d.N},{d.K},{d.act},{d.out_mode},{d.stride},{d.upsample}"
         if _tune_recorder is not None:
             tile, splits = _tune_recorder(key, d, device)
         else:
@@ -166,14 +166,13 @@ def _launch_gemm(d: "GemmDesc", device, what: str, tile: int = 0, splits: int = 
     d.tile = tile
     d.zeros = _zero_page(device).data_ptr()
     f32 = d.out_mode == AF_OUT_F32
-    d.splits = max(2 if f32 else 1, splits)                    # fp32 results are written by the split-K reduce pass
+    d.splits = max(1, splits)
     if d.splits > 1:
         if d.act == AF_ACT_GEGLU or d.out_mode == AF_OUT_SPLIT_T:
             d.splits = 1
         else:
             ws = _splitk_workspace(device)
             d.splits = max(1, min(d.splits, (ws.numel() * 4 - _lib.AF_SPLITK_COUNTER_BYTES) // (d.M * d.N * 4)))
-            assert not f32 or d.splits >= 2, f"{what}: fp32 output [{d.M}, {d.N}] does not fit the split-K workspace twice"
             d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
             d.splitk_fused = int(d.splits <= SPLITK_FUSED_MAX and not f32)
     _lib.check(_lib.lib().af_gemm(C.byref(d), _stream()), what)
@@ -211,7 +210,7 @@ def gemm(a1: torch.Tensor, pw: PackedWeight, *, a2: Optional[torch.Tensor] = Non
         out2 = torch.empty((nb, pw.N - split_col, ld_out2), dtype=F16, device=a1.device)
         d.out_mode, d.split_col, d.ld_out2, d.out2 = AF_OUT_SPLIT_T, split_col, ld_out2, _p(out2)
     elif out_f32:
-        assert act == AF_ACT_NONE and pw.kpad >= 128 and pw.N % 4 == 0
+        assert act == AF_ACT_NONE and pw.N % 4 == 0
         out = torch.empty((M, pw.N), dtype=torch.float32, device=a1.device)
         d.out_mode = AF_OUT_F32
     else:

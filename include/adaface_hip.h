@@ -72,8 +72,8 @@ int af_prof_read(int family, int* launches, double* total_ms);
  *   out_mode AF_OUT_SPLIT_T: columns n >= split_col are written TRANSPOSED to out2
  *   ([B, N - split_col, ld_out2] with token index contiguous): V^T for the attention kernel.
  *   out_mode AF_OUT_F32: out is fp32 [M][ld_out] -- the accumulator is stored without the fp16 cast (weight gradients: sums over
- *   thousands of tokens overflow fp16 long before they lose precision).  Needs splits >= 2, kpad >= 128, the standard
- *   epilogue and the two-launch split-K form: the reduce pass is what writes fp32.
+ *   thousands of tokens overflow fp16 long before they lose precision).  Standard epilogue only, N % 4 == 0, no splitk_fused.
+ *   With split-K the reduce pass writes fp32; unsplit, tiles 1 / 2 do (tiles 3 .. 10 fall back to tile 1).
  */
 #define AF_ACT_NONE 0
 #define AF_ACT_SILU 1

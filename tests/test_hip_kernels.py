@@ -68,7 +68,7 @@ def test_gemm_and_conv_split_k(dev, tile, splits):
 
 @pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 7, 8])
 def test_gemm_fp32_output_and_wgrad_past_the_fp16_range(dev, tile):
-    """AF_OUT_F32: the split-K reduce pass stores the fp32 accumulator.  Entries far beyond 65504 (a weight gradient summed over
+    """AF_OUT_F32: the epilogue (or the split-K reduce pass) stores the fp32 accumulator.  Entries far beyond 65504 (a weight gradient summed over
     thousands of tokens) come back finite and exact to fp32 summation error; autograd_ops.wgrad uses this mode."""
     from adaface_dev_amd import ops
     from adaface_dev_amd.autograd_ops import wgrad
@@ -77,11 +77,12 @@ def test_gemm_fp32_output_and_wgrad_past_the_fp16_range(dev, tile):
     a[:, :64] = a[:, :64].abs()
     w[:, :64] = w[:, :64].abs()                                       # a coherent block: sums of ~64 * 600 on top of the random walk
     b = torch.randn(N, generator=torch.Generator().manual_seed(3))
-    out = ops.gemm(a.to(dev), ops.pack_matrix(w, b, dev), tile=tile, out_f32=True)
     ref = a.double() @ w.double().t() + b.double()
-    assert out.dtype == torch.float32 and ref.abs().max() > 70000
-    assert torch.isfinite(out).all()
-    assert rel_l2(out.cpu().numpy(), ref.numpy()) < 1e-5
+    assert ref.abs().max() > 70000
+    for splits in (1, 3):                              # unsplit: tiles 1 / 2 store fp32 themselves (3 .. 10 fall back to 1); split: the reduce pass does
+        out = ops.gemm(a.to(dev), ops.pack_matrix(w, b, dev), tile=tile, splits=splits, out_f32=True)
+        assert out.dtype == torch.float32 and torch.isfinite(out).all()
+        assert rel_l2(out.cpu().numpy(), ref.numpy()) < 1e-5
     if tile == 0:
         for (T, n, k) in [(4096, 16, 128), (77, 64, 96), (300, 8, 320)]:     # tokens, dy columns, x columns (ragged, < 128 tokens too)
             dy, x = rnd((T, n), 5, 8.0), rnd((T, k), 6, 8.0)

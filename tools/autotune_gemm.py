@@ -30,6 +30,8 @@ def main():
     ap.add_argument("--latents", default="64x64", help="comma-separated latent sizes HxW to run the U-Net at (64x64 = 512^2 images; 96x64 = 768x512)")
     ap.add_argument("--out", default=None)
     ap.add_argument("--train", action="store_true")
+    ap.add_argument("--bench-train", action="store_true", help="tune the shapes of bench.py's Stage-1 training leg (97 context tokens, FFN adapters)")
+    ap.add_argument("--bench-train2", action="store_true", help="tune the shapes of bench.py's Stage-2 (compositional distillation) leg")
     ap.add_argument("--vae", action="store_true", help="also tune the VAE decoder's shapes (batch 4 and 1, 64x64 latent)")
     ap.add_argument("--fresh", action="store_true", help="ignore the existing table instead of extending it")
     ap.add_argument("--cold-weights", action="store_true", help="time single launches after evicting the caches (weights cold, 1x1 activations re-read): what a GEMM meets inside the real step")
@@ -110,7 +112,10 @@ def main():
             for splits in (1, 2, 3, 4, 6, 8, 12, 16):
                 if tile in (5, 6) and splits > 1:
                     continue
-                if splits > 1 and (d.act == _lib.AF_ACT_GEGLU or d.out_mode != 0 or nk < 4 * splits):
+                f32 = d.out_mode == _lib.AF_OUT_F32                      # weight gradients: fp32 from the reduce pass, or unsplit from tiles 1 / 2
+                if f32 and splits == 1 and tile > 2:
+                    continue
+                if splits > 1 and (d.act == _lib.AF_ACT_GEGLU or d.out_mode == _lib.AF_OUT_SPLIT_T or nk < 4 * splits):
                     continue
                 t = timed(d, device, tile, splits)
                 if t is None:
@@ -157,6 +162,12 @@ def main():
                      face_id_embs=rng.synth_input("tb.id", (4, 512), seed=5).to(dev), fg_mask=torch.ones(4, 1, 64, 64, device=dev))
             tr.training_step(b, i)
             torch.cuda.synchronize()
+    for stage in [s for s, on in ((1, args.bench_train), (2, args.bench_train2)) if on]:
+        # exactly the micro-batches bench.py times (its own model construction), eager, six of them = two 2,3,4-step cycles
+        import bench
+        ns = argparse.Namespace(batch=4, no_ffn_lora=False, no_train_graphs=True, train_steps=6, train_warmup=2, no_roofline=True)
+        bench.run_train(ns, (1, 0, 0, False), dev, stage=stage)
+        torch.cuda.synchronize()
     if args.vae:
         from adaface_dev_amd.ldm.modules.diffusionmodules.model import AutoencoderKLDecoder
         ae = AutoencoderKLDecoder()
