@@ -582,3 +582,74 @@ def test_graph_replayed_segments_reproduce_the_eager_micro_batch(dev):
     for a, b in zip(p0, p1):
         assert torch.equal(a, b)
     assert len(set(l0)) > 2                                                  # the optimizer really moved things between micro-batches
+
+
+def test_full_size_distill_loss_gradient_of_bs4_equals_its_bs1_slices(dev):
+    """BASELINE configs[2] at FULL size (SD-1.5 student + teacher, 64x64 latents, 97 context tokens, bs 4, FFN adapters on): the
+    distillation loss is finite, and -- a size-independent property, the oracle being far too slow here -- the context gradient
+    of every sample of the bs-4 micro-batch equals the gradient of that sample run alone (x 1/4: the loss is a batch mean;
+    GroupNorm, attention and the masked MSE are per sample).  Different GEMM tiles / split-K serve M = 4 x 4096 and 1 x 4096."""
+    from adaface_dev_amd import SD15_UNET_CONFIG, rng
+    from adaface_dev_amd.adaface.unet_teachers import Arc2FaceTeacher
+    from adaface_dev_amd.ldm.models.diffusion.ddpm import LatentDiffusion
+    from adaface_dev_amd.ldm.modules.diffusionmodules.openaimodel import UNetModel
+    ld = LatentDiffusion(SD15_UNET_CONFIG)
+    rng.load_synth_weights(ld.model.diffusion_model, seed=0)
+    teacher = UNetModel(**SD15_UNET_CONFIG)
+    rng.load_synth_weights(teacher, seed=1)
+    ld = ld.to(dev)
+    for p in ld.model.diffusion_model.parameters():
+        p.requires_grad_(False)
+    ld.unet_teacher = Arc2FaceTeacher(teacher.to(dev))
+    lora = ld.model.set_up_ffn_loras(lora_dropout=0.0)
+    with torch.no_grad():
+        for n, p in lora.named_parameters():
+            if "lora_B" in n:
+                p.copy_(rng.synth_input(n, p.shape, seed=7, scale=0.02))
+            elif "lora_A" in n:
+                p.copy_(rng.synth_input(n, p.shape, seed=7, scale=p[0].numel() ** -0.5))
+    B = 4
+    x0 = rng.synth_input("fs.x0", (B, 4, 64, 64), seed=21).to(dev)
+    noise = rng.synth_input("fs.noise", (B, 4, 64, 64), seed=21).to(dev)
+    t = torch.tensor([760, 850, 800, 720], device=dev)
+    sctx = rng.synth_input("fs.sctx", (B, 97, 768), seed=21).to(dev)
+    tctx = rng.synth_input("fs.tctx", (B, 21, 768), seed=21).to(dev)
+    fg = (rng.synth_input("fs.fg", (B, 1, 64, 64), seed=21) > -0.3).float().to(dev)
+
+    def run(sl):
+        sg = sctx[sl].clone().requires_grad_(True)
+        n = sg.shape[0]
+        loss = ld.calc_unet_distill_loss(x0[sl], noise[sl], (sg, ["a"] * n, {}), tctx[sl], None, fg[sl], 1, t=t[sl])
+        loss.backward()
+        grads = {k: p.grad.detach().clone() for k, p in lora.named_parameters() if "unet_distill" in k and p.grad is not None}
+        for p in lora.parameters():
+            p.grad = None
+        return float(loss), sg.grad.detach().float(), grads
+    l4, g4, w4 = run(slice(0, 4))
+    assert np.isfinite(l4) and torch.isfinite(g4).all() and len(w4) == 18 and all(torch.isfinite(g).all() for g in w4.values())
+    l1s, wsum = [], None
+    for i in range(B):
+        l1, g1, w1 = run(slice(i, i + 1))
+        l1s.append(l1)
+        e = rel_l2((4 * g4[i]).cpu().numpy(), g1[0].cpu().numpy())
+        print(f"sample {i}: loss {l1:.5f}, dcontext bs4-slice vs bs1 rel-L2 {e:.2e}")
+        assert e < 8e-3                                               # GRAD_TOL of tests/test_hip_unet.py
+        wsum = w1 if wsum is None else {k: wsum[k] + w1[k] for k in w1}
+    assert abs(l4 - float(np.mean(l1s))) < 2e-3 * abs(l4)
+    for k in w4:                                                      # adapter weight gradients add over the samples
+        e = rel_l2(w4[k].float().cpu().numpy(), (wsum[k] / 4).float().cpu().numpy())
+        assert e < 1.5e-2, (k, e)
+
+
+def test_full_size_bs4_train_step_of_the_bench_leg(dev):
+    """The micro-batch bench.py times (BASELINE configs[2]: full-size student + teacher + 3 CLIP-L encoders, bs 4, 97 tokens, FFN
+    adapters, accumulate 2, CAdamW) through its own construction code: two accumulation windows, finite losses, optimizer steps
+    taken, none skipped, graphs captured."""
+    import argparse
+    import bench
+    ns = argparse.Namespace(batch=4, no_ffn_lora=False, no_train_graphs=False, train_steps=4, train_warmup=2, no_roofline=True)
+    out = bench.run_train(ns, (1, 0, 0, False), dev, stage=1)
+    cfg = out["config"]
+    assert cfg["finite"] and cfg["skipped_steps"] == 0 and cfg["optimizer_steps"] == 3, cfg
+    assert out["n_gpus"] == 1 and out["steps"] == 4 and out["value"] > 0
+    assert any("captured" in s and not s.endswith(" 0 captured") for s in cfg["hipgraph_segments"]), cfg["hipgraph_segments"]
