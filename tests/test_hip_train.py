@@ -633,7 +633,7 @@ def test_full_size_distill_loss_gradient_of_bs4_equals_its_bs1_slices(dev):
         l1s.append(l1)
         e = rel_l2((4 * g4[i]).cpu().numpy(), g1[0].cpu().numpy())
         print(f"sample {i}: loss {l1:.5f}, dcontext bs4-slice vs bs1 rel-L2 {e:.2e}")
-        assert e < 8e-3                                               # GRAD_TOL of tests/test_hip_unet.py
+        assert e < 1.6e-2          # two fp16 passes against each other: each is within GRAD_TOL = 8e-3 of exact (tests/test_hip_unet.py)
         wsum = w1 if wsum is None else {k: wsum[k] + w1[k] for k in w1}
     assert abs(l4 - float(np.mean(l1s))) < 2e-3 * abs(l4)
     for k in w4:                                                      # adapter weight gradients add over the samples
