@@ -485,9 +485,7 @@ int launch_tile(const GemmDev& p, int tile, hipStream_t stream) {
 
 // af_gemm3.hip
 int af_gemm3_try_launch(const af_gemm_desc* d, int splits, int wide, hipStream_t stream);
-int af_gemm_skinny_try_launch(const af_gemm_desc* d, hipStream_t stream);
 int af_gemm3_effective_splits(const af_gemm_desc* d, int splits, int wide);
-int af_gemm_skinny_try_launch(const af_gemm_desc* d, hipStream_t stream);   // af_gemm_skinny.hip (tile 11)
 
 extern "C" int af_gemm(const af_gemm_desc* d, void* stream) {
   AF_REQUIRE(d != nullptr, "af_gemm: null descriptor");
@@ -580,20 +578,16 @@ extern "C" int af_gemm(const af_gemm_desc* d, void* stream) {
   }
 
   int tile = d->tile;
-  const long t128 = (long)((d->M + 127) / 128) * ((d->N + 127) / 128);
-  const int auto_tile = (t128 >= 192 && d->N >= 96) ? 1 : 2;
-  if (tile == 0) tile = auto_tile;
-  AF_REQUIRE(tile >= 1 && tile <= 11, "af_gemm: tile must be 0 .. 11");
+  if (tile == 0) {
+    const long t128 = (long)((d->M + 127) / 128) * ((d->N + 127) / 128);
+    tile = (t128 >= 192 && d->N >= 96) ? 1 : 2;
+  }
+  AF_REQUIRE(tile >= 1 && tile <= 10, "af_gemm: tile must be 0 .. 10");
 
   AfLaunchScope scope(AF_FAM_GEMM, stream);
   hipStream_t s = (hipStream_t)stream;
   AF_REQUIRE(d->tap_shift == 0 || (d->tap_shift == 1 && d->taps == 9 && !p.upsample), "af_gemm: tap_shift is 0 or 1 (3x3, no upsample)");
   if (tile >= 3 && d->tap_shift) tile = 1;          // the ring kernel keeps the symmetric-padding loader only
-  if (tile == 11) {                                 // small 1x1 GEMMs: the four waves of a tile split K, no barrier in the K loop
-    if (af_gemm_skinny_try_launch(d, s) == 0) return af_check_launch("af_gemm(tile 11)");
-    tile = auto_tile;
-    if (p.out_f32 && p.splits < 2 && tile > 2) tile = 1;
-  }
   if (tile >= 3) {
     const int eff = af_gemm3_effective_splits(d, p.splits, tile - 3);
     // AF_OUT_F32: the LDS-DMA kernels only reach fp32 through the split-K reduce pass; unsplit, the register-staged kernel stores it

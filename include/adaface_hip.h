@@ -116,9 +116,6 @@ typedef struct af_gemm_desc {
                         /* 7 .. 10 = whole-line kernel (64-wide K stages, LDS-DMA pieces of 8 rows x one 128-byte line, two slots; channel
                            counts and K padding multiples of 64): 7 = 128x320 (GEGLU 128x256, transposed-V split), 8 = 128x128 (4 waves; also GEGLU,
                            transposed-V split), 9 / 10 = GEGLU 256x320 / 256x256; tiles 7 and 8 also take upsample = 1 (nearest x2).  Anything outside a tile's scope falls back to tile 1 */
-                        /* 11 = small 1x1 GEMMs (af_gemm_skinny.hip): one 64x64 tile per workgroup whose four waves split K and load their MFMA
-                           fragments straight from global memory (no LDS staging, no barrier in the K loop); standard epilogue incl.
-                           AF_OUT_F32, single source (a2 == NULL), c1 % 8 == 0; splits is ignored; otherwise falls back to tile 1 / 2 */
   int32_t splits;       /* split-K factor (<=1: none).  >1 needs the standard epilogue and a workspace:
                            each split writes an fp32 partial [M][N], a second launch reduces + applies the epilogue */
   void* workspace;      /* fp32, >= splits*M*N*4 bytes when splits > 1 */

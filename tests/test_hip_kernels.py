@@ -66,36 +66,6 @@ def test_gemm_and_conv_split_k(dev, tile, splits):
     assert rel_l2(oc.float().cpu().permute(0, 3, 1, 2).numpy(), refc.numpy()) < TOL
 
 
-@pytest.mark.parametrize("M,N,K,act,extras", [(22, 768, 768, 0, ""), (97, 3072, 768, 3, ""), (388, 768, 3072, 0, "r"), (2048, 1280, 1280, 0, "r"),
-                                               (512, 320, 1280, 1, "b"), (8192, 320, 320, 0, "br"), (130, 4, 320, 0, ""), (77, 100, 16, 0, "r"),
-                                               (300, 192, 320, 0, "f"), (64, 64, 64, 0, ""), (1, 1280, 320, 1, "")])
-def test_gemm_tile11_small_gemms_with_k_split_over_the_waves(dev, M, N, K, act, extras):
-    """af_gemm_skinny.hip: ragged M, N tails (incl. N < 64), K tails (K = 16 in a 64-wide pack, K = 320 = 10 k-steps over 4 waves),
-    bias, row bias (b), residual (r), SiLU / quick-GELU, fp32 output (f) -- against fp32 matmul; bit-identical run to run."""
-    from adaface_dev_amd import ops
-    a, w = rnd((M, K), 1), rnd((N, K), 2, K ** -0.5)
-    b = torch.randn(N, generator=torch.Generator().manual_seed(3))
-    res = rnd((M, N), 4) if "r" in extras else None
-    rows = 64 if M % 64 == 0 else M
-    rowb = rnd((M // rows, N), 5) if "b" in extras else None
-    kw = dict(residual=None if res is None else res.to(dev), rowbias=None if rowb is None else rowb.to(dev),
-              rows_per_batch=rows if rowb is not None else 0, act=act, tile=11, out_f32="f" in extras)
-    pw = ops.pack_matrix(w, b, dev)
-    out = ops.gemm(a.to(dev), pw, **kw)
-    ref = a.double() @ w.double().t() + b.double()
-    if rowb is not None:
-        ref = ref + rowb.double().repeat_interleave(rows, dim=0)
-    if act == 1:
-        ref = ref * torch.sigmoid(ref)
-    elif act == 3:
-        ref = ref * torch.sigmoid(1.702 * ref)
-    if res is not None:
-        ref = ref + res.double()
-    assert out.dtype == (torch.float32 if "f" in extras else torch.float16)
-    assert rel_l2(out.float().cpu().numpy(), ref.float().numpy()) < (1e-5 if "f" in extras else TOL)
-    assert torch.equal(out, ops.gemm(a.to(dev), pw, **kw))
-
-
 @pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 7, 8])
 def test_gemm_fp32_output_and_wgrad_past_the_fp16_range(dev, tile):
     """AF_OUT_F32: the epilogue (or the split-K reduce pass) stores the fp32 accumulator.  Entries far beyond 65504 (a weight gradient summed over

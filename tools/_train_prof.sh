@@ -1,20 +1,18 @@
 set -u
-TAG=r02n
+TAG=r02m
 OUT=$PWD/gpurun_out
 export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_t2trace -- python3 bench.py --mode train2 --train-steps 4 --train-warmup 2 --no-cpu-baseline --no-roofline > $OUT/${TAG}_t2trace.log 2>&1
-DBT=$(find $OUT/${TAG}_t2trace -name "*_results.db" | head -1)
+rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_ttrace -- python3 bench.py --mode train --train-steps 12 --train-warmup 12 --no-cpu-baseline --no-roofline > $OUT/${TAG}_ttrace.log 2>&1
+DBT=$(find $OUT/${TAG}_ttrace -name "*_results.db" | head -1)
 NT=$(python3 - <<PY
 import sqlite3
 c = sqlite3.connect("$DBT")
 names = [r[0] for r in c.execute("select name from kernels order by start")]
 idx = [i for i, n in enumerate(names) if "cadamw_update" in n]
-per = sum(1 for i in idx if i > idx[-1] - 10)   # launches of the last optimizer step (one per arena)
-print(idx[-1] - idx[-1 - 2 * per], per)
+print(idx[-1] - idx[-7])
 PY
 )
-set -- $NT
-{ echo "# rocprofv3 --kernel-trace --stats -- python3 bench.py --mode train2 --train-steps 4 --train-warmup 2 ... (last 2 optimizer steps = 4 micro-batches = $1 dispatches; $2 arenas)"; python3 tools/rocpd_summary.py $DBT --last $1; } > $OUT/${TAG}_train2_kernel_stats.txt
-rm -rf $OUT/${TAG}_t2trace
-head -70 $OUT/${TAG}_train2_kernel_stats.txt | cut -c1-200
-tail -2 $OUT/${TAG}_t2trace.log | cut -c1-300
+{ echo "# last 12 micro-batches = $NT dispatches"; python3 tools/rocpd_summary.py $DBT --last $NT; } > $OUT/${TAG}_train_kernel_stats.txt
+rm -rf $OUT/${TAG}_ttrace
+head -60 $OUT/${TAG}_train_kernel_stats.txt | cut -c1-200
+tail -3 $OUT/${TAG}_ttrace.log

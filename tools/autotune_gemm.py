@@ -35,7 +35,6 @@ def main():
     ap.add_argument("--vae", action="store_true", help="also tune the VAE decoder's shapes (batch 4 and 1, 64x64 latent)")
     ap.add_argument("--fresh", action="store_true", help="ignore the existing table instead of extending it")
     ap.add_argument("--cold-weights", action="store_true", help="time single launches after evicting the caches (weights cold, 1x1 activations re-read): what a GEMM meets inside the real step")
-    ap.add_argument("--retune-small", action="store_true", help="re-time the 1x1 shapes this run meets whose entry is a register-staged tile (1 / 2): candidates for tile 11")
     ap.add_argument("--retune", action="store_true", help="re-time every shape this run meets; entries of shapes it does not meet are kept")
     args = ap.parse_args()
     from adaface_dev_amd import SD15_UNET_CONFIG, _lib, ops, rng
@@ -93,16 +92,13 @@ def main():
     retuned = set()
 
     def recorder(key, d, device):
-        stale = args.retune or (args.retune_small and table.get(key, (0, 1))[0] <= 2 and d.taps == 1)
-        if key in table and (not stale or key in retuned):
+        if key in table and (not args.retune or key in retuned):
             return table[key]
         retuned.add(key)
         nk = d.kpad // 64
         best, best_t, res = (0, 1), None, {}
-        for tile in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11):
+        for tile in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10):
             geglu = d.act == _lib.AF_ACT_GEGLU
-            if tile == 11 and (d.taps != 1 or d.a2 or geglu or d.out_mode == _lib.AF_OUT_SPLIT_T or d.c1 % 8 or 2.0 * d.M * d.N * d.K > 2.5e10):
-                continue                        # small 1x1 GEMMs only (the four waves of a tile split K)
             if tile >= 7 and (d.upsample not in (0, 1) or (d.upsample and tile not in (7, 8)) or d.c1 % 64 or d.c2 % 64):
                 continue                        # whole-line kernel: 64-multiples of channels; nearest-x2 upsample in tiles 7 / 8
             if tile == 7 and (d.N % (256 if geglu else 320) != 0):
@@ -114,10 +110,10 @@ def main():
             if tile in (5, 6) and (d.taps != 1 or d.out_mode != 0 or d.M * d.N < 256 * 256 * 128):
                 continue                        # 256-row ring tiles: plain / GEGLU 1x1 GEMMs with at least ~128 tiles
             for splits in (1, 2, 3, 4, 6, 8, 12, 16):
-                if tile in (5, 6, 11) and splits > 1:
+                if tile in (5, 6) and splits > 1:
                     continue
                 f32 = d.out_mode == _lib.AF_OUT_F32                      # weight gradients: fp32 from the reduce pass, or unsplit from tiles 1 / 2
-                if f32 and splits == 1 and tile > 2 and tile != 11:
+                if f32 and splits == 1 and tile > 2:
                     continue
                 if splits > 1 and (d.act == _lib.AF_ACT_GEGLU or d.out_mode == _lib.AF_OUT_SPLIT_T or nk < 4 * splits):
                     continue
