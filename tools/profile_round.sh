@@ -2,7 +2,7 @@
 # Profiles of the default bench (run on the GPU box from the repo root):   bash tools/profile_round.sh r02j
 #   <tag>_bench_line.json        python bench.py (all legs)
 #   <tag>_bench_kernel_stats.txt rocprofv3 --kernel-trace --stats of the denoise leg, last 10 steps
-#   <tag>_train_kernel_stats.txt rocprofv3 --kernel-trace --stats of the Stage-1 training leg, last 12 micro-batches
+#   <tag>_train_kernel_stats.txt, <tag>_train2_kernel_stats.txt   rocprofv3 --kernel-trace --stats of the Stage-1 / Stage-2 training legs, last 6 micro-batches
 #   <tag>_hbm_traffic.json       two separate --pmc passes (FETCH_SIZE, WRITE_SIZE) of 6 eager denoise steps, per kernel family
 set -u
 TAG=${1:-r02}
@@ -22,19 +22,22 @@ print((idx[-1] - idx[-2]) * 10)
 PY
 )
 { echo "# rocprofv3 --kernel-trace --stats -- python3 bench.py --mode denoise --steps 20 --warmup 3 --no-cpu-baseline --no-roofline   (last 10 steps = $N dispatches)"; python3 tools/rocpd_summary.py $DB --last $N; } > $OUT/${TAG}_bench_kernel_stats.txt
-# train leg: the last 6 optimizer steps (= 12 micro-batches, four 2,3,4-step cycles), delimited by the CAdamW kernel
-rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_ttrace -- python3 bench.py --mode train --train-steps 12 --train-warmup 12 --no-cpu-baseline --no-roofline > $OUT/${TAG}_ttrace.log 2>&1
-DBT=$(find $OUT/${TAG}_ttrace -name "*_results.db" | head -1)
-NT=$(python3 - <<PY
+# train legs: the last 3 optimizer steps (= 6 micro-batches, two 2,3,4-step cycles), delimited by the CAdamW kernels (one launch per arena)
+for LEG in train train2; do
+  rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_ttrace -- python3 bench.py --mode $LEG --train-steps 12 --train-warmup 12 --no-cpu-baseline --no-roofline > $OUT/${TAG}_${LEG}_trace.log 2>&1
+  DBT=$(find $OUT/${TAG}_ttrace -name "*_results.db" | head -1)
+  NT=$(python3 - <<PY
 import sqlite3
 c = sqlite3.connect("$DBT")
 names = [r[0] for r in c.execute("select name from kernels order by start")]
 idx = [i for i, n in enumerate(names) if "cadamw_update" in n]
-print(idx[-1] - idx[-7])
+per = sum(1 for i in idx if i > idx[-1] - 10)          # arenas = CAdamW launches of one optimizer step
+print(idx[-1] - idx[-1 - 3 * per])
 PY
 )
-{ echo "# rocprofv3 --kernel-trace --stats -- python3 bench.py --mode train --train-steps 12 --train-warmup 12 --no-cpu-baseline --no-roofline   (last 12 micro-batches = $NT dispatches; divide by 12 for one micro-batch)"; python3 tools/rocpd_summary.py $DBT --last $NT; } > $OUT/${TAG}_train_kernel_stats.txt
-rm -rf $OUT/${TAG}_ttrace
+  { echo "# rocprofv3 --kernel-trace --stats -- python3 bench.py --mode $LEG --train-steps 12 --train-warmup 12 --no-cpu-baseline --no-roofline   (last 3 optimizer steps = 6 micro-batches = $NT dispatches; divide by 6 for one micro-batch)"; python3 tools/rocpd_summary.py $DBT --last $NT; } > $OUT/${TAG}_${LEG}_kernel_stats.txt
+  rm -rf $OUT/${TAG}_ttrace
+done
 rocprofv3 --pmc FETCH_SIZE -d $OUT/${TAG}_pmc_f -- python3 bench.py --mode denoise --steps 5 --warmup 0 --no-graph --no-cpu-baseline --no-roofline > $OUT/${TAG}_pmc_f.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $OUT/${TAG}_pmc_w -- python3 bench.py --mode denoise --steps 5 --warmup 0 --no-graph --no-cpu-baseline --no-roofline > $OUT/${TAG}_pmc_w.log 2>&1
 python3 tools/pmc_traffic.py $(find $OUT/${TAG}_pmc_f -name "*_results.db" | head -1) $(find $OUT/${TAG}_pmc_w -name "*_results.db" | head -1) --steps 6 --json $OUT/${TAG}_hbm_traffic.json > $OUT/${TAG}_hbm_traffic.txt 2>&1
