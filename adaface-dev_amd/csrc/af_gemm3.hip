@@ -732,9 +732,9 @@ bool launch3w(const Gemm3Dev& p0, hipStream_t stream) {
 // outside this kernel's scope (caller falls back), 0 after a launch.
 int af_gemm3_try_launch(const af_gemm_desc* d, int splits, int wide, hipStream_t stream) {
   // wide: 0 = 128 x 128, 1 = 128 x 320 (GEGLU 128 x 256), 2 = 256 x 256, 3 = 256 x 320 (8 waves as 4 x 2); whole-line kernel:
-  // 4 = 128 x 320 (GEGLU 128 x 256), 5 = 128 x 128, 6 = GEGLU 256 x 320, 7 = GEGLU 256 x 256
+  // 4 = 128 x 320 (GEGLU 128 x 256), 5 = 128 x 128, 6 = GEGLU 256 x 320, 7 = GEGLU 256 x 256, 8 = 128 x 160 (4 waves, 2 workgroups per CU)
   const bool geglu = d->act == AF_ACT_GEGLU, split_t = d->out_mode == AF_OUT_SPLIT_T;
-  if (d->upsample && !((wide == 4 || wide == 5) && d->upsample == 1 && d->taps == 9)) return 1;   // nearest x2: whole-line kernel only
+  if (d->upsample && !((wide == 4 || wide == 5 || wide == 8) && d->upsample == 1 && d->taps == 9)) return 1;   // nearest x2: whole-line kernel only
   if (d->c1 % BK3 != 0 || d->c2 % BK3 != 0 || d->zeros == nullptr) return 1;
   if ((geglu || split_t) && (d->taps != 1 || splits > 1)) return 1;
   if (geglu && (!wide || d->N % (wide == 5 ? 128 : 256) != 0)) return 1;   // GEGLU: 128 x 256 tile, the 256-row tiles, or 128 x 128 whole-line
@@ -745,7 +745,8 @@ int af_gemm3_try_launch(const af_gemm_desc* d, int splits, int wide, hipStream_t
     if (wide == 5 && geglu && d->N % 128 != 0) return 1;
     if (wide == 6 && (!geglu || d->N % 320 != 0)) return 1;
     if (wide == 7 && (!geglu || d->N % 256 != 0)) return 1;
-    if (wide > 7) return 1;
+    if (wide == 8 && (geglu || split_t || d->N % 160 != 0)) return 1;
+    if (wide > 8) return 1;
   }
   if (wide == 2 && (d->N % 256 != 0 || d->taps != 1 || split_t || splits > 1)) return 1;
   if (wide == 3 && (d->N % 320 != 0 || d->taps != 1 || split_t || splits > 1)) return 1;
@@ -816,6 +817,8 @@ int af_gemm3_try_launch(const af_gemm_desc* d, int splits, int wide, hipStream_t
       else if (split_t) fused = launch3w<1, 2, 2, 4, E3_SPLIT_T>(p, stream);
       else if (d->taps == 9) fused = launch3w<9, 2, 2, 4>(p, stream);
       else fused = launch3w<1, 2, 2, 4>(p, stream);
+    } else if (wide == 8) {                                  // 128 x 160, 4 waves, two workgroups per CU
+      if (d->taps == 9) fused = launch3w<9, 2, 2, 5>(p, stream); else fused = launch3w<1, 2, 2, 5>(p, stream);
     } else {
       if (wide == 6) fused = launch3w<1, 4, 2, 10, E3_GEGLU>(p, stream); else fused = launch3w<1, 4, 2, 8, E3_GEGLU>(p, stream);
     }

@@ -46,11 +46,35 @@ def main():
             x = rnd(B, H, W, ci)
             pw = ops.pack_conv3x3(torch.randn(co, ci, 3, 3, generator=g) * (ci * 9) ** -0.5, torch.randn(co, generator=g), dev)
             cases.append((f"conv {B}x{H}x{W} {ci}->{co} t{tile} s{sp}", 2.0 * B * H * W * co * ci * 9, lambda x=x, pw=pw, tile=tile, sp=sp: ops.conv3x3(x, pw, tile=tile, splits=sp)))
+    if os.environ.get("AF_EXP_TILES"):
+        # tile shapes against each other on the same operands: variant = tile id (7 = 128x320 / 8 waves, 8 = 128x128, 11 = 128x160 two workgroups per CU)
+        cases, variants = [], [int(v) for v in os.environ["AF_EXP_TILES"].split(",")]
+        tile_of = [7]
+        for B, H, W, ci, co, sp in ((8, 64, 64, 320, 320, 1), (8, 32, 32, 640, 640, 2), (8, 16, 16, 1280, 1280, 4), (8, 64, 64, 640, 320, 1), (8, 32, 32, 1280, 640, 2),
+                                    (8, 64, 64, 960, 320, 1), (8, 32, 32, 640, 640, 1), (2, 64, 64, 320, 320, 2), (4, 64, 64, 320, 320, 1)):
+            x = rnd(B, H, W, ci)
+            pw = ops.pack_conv3x3(torch.randn(co, ci, 3, 3, generator=g) * (ci * 9) ** -0.5, torch.randn(co, generator=g), dev)
+            cases.append((f"conv {B}x{H}x{W} {ci}->{co} s{sp}", 2.0 * B * H * W * co * ci * 9, lambda x=x, pw=pw, sp=sp: ops.conv3x3(x, pw, tile=tile_of[0], splits=sp)))
+        for M, N, K, sp in ((32768, 320, 320, 1), (32768, 320, 1280, 1), (8192, 640, 640, 1), (8192, 640, 2560, 1), (2048, 1280, 1280, 1), (2048, 1280, 5120, 3), (32768, 960, 320, 1)):
+            a = rnd(M, K)
+            pw = ops.pack_matrix(torch.randn(N, K, generator=g) * K ** -0.5, torch.randn(N, generator=g), dev)
+            r = rnd(M, N)
+            cases.append((f"gemm {M} {N} {K} s{sp}", 2.0 * M * N * K, lambda a=a, pw=pw, sp=sp, r=r: ops.gemm(a, pw, tile=tile_of[0], splits=sp, residual=r)))
+        for name, fl, fn in cases:                      # same results from every tile
+            outs = []
+            for v in variants:
+                tile_of[0] = v
+                outs.append(fn().float())
+            for o in outs[1:]:
+                err = float((o - outs[0]).norm() / outs[0].norm())
+                assert err < 2e-3, (name, err)
     res = {(n, v): [] for n, _, _ in cases for v in variants}
     for r in range(rounds):
         for name, fl, fn in cases:
             for v in variants:
-                if os.environ.get("AF_EXP_SPLITK"):
+                if os.environ.get("AF_EXP_TILES"):
+                    tile_of[0] = v
+                elif os.environ.get("AF_EXP_SPLITK"):
                     ops.SPLITK_FUSED_MAX = v
                 else:
                     os.environ["AF_GEMM3_ABLATE"] = str(v)
