@@ -108,7 +108,7 @@ typedef struct af_gemm_desc {
   int32_t ld_out;       /* elements; 0 -> N (or N/2 for GEGLU) */
   int32_t split_col;    /* AF_OUT_SPLIT_T */
   int32_t ld_out2;      /* AF_OUT_SPLIT_T: tokens per batch item rounded up to 8 */
-  int32_t tile;         /* 0 = auto, 1 = 128x128, 2 = 64x64 (register-staged), 3 = 128x128 and 4 = 128x320 LDS-DMA
+  int32_t tile;         /* 0 = auto (1 or 2), 1 = 128x128, 2 = 64x64 (register-staged), 3 = 128x128 and 4 = 128x320 LDS-DMA
                            pipelined ring (standard epilogue, channel counts % 32 == 0, no upsample, tile 4: N % 320
                            == 0; otherwise falls back to 1) */
                         /* 5 = 256x256 and 6 = 256x320 ring tiles (8 waves as 4 x 2): plain or GEGLU 1x1 GEMMs only, N % 256 / N % 320 == 0,
@@ -116,6 +116,9 @@ typedef struct af_gemm_desc {
                         /* 7 .. 10 = whole-line kernel (64-wide K stages, LDS-DMA pieces of 8 rows x one 128-byte line, two slots; channel
                            counts and K padding multiples of 64): 7 = 128x320 (GEGLU 128x256, transposed-V split), 8 = 128x128 (4 waves; also GEGLU,
                            transposed-V split), 9 / 10 = GEGLU 256x320 / 256x256; tiles 7 and 8 also take upsample = 1 (nearest x2).  Anything outside a tile's scope falls back to tile 1 */
+                        /* 11 = whole-line kernel, 128x160 tile of four waves (N % 160 == 0; standard epilogue, taps 1 / 9, nearest x2): 74 KB of
+                           LDS, so TWO workgroups share a CU and one's epilogue / barrier waits run under the other's MFMAs: the faster
+                           form when the 128x320 grid has under ~1.5 workgroups per CU (batch 1 - 4 passes, the 32x32 level) */
   int32_t splits;       /* split-K factor (<=1: none).  >1 needs the standard epilogue and a workspace:
                            each split writes an fp32 partial [M][N], a second launch reduces + applies the epilogue */
   void* workspace;      /* fp32, >= splits*M*N*4 bytes when splits > 1 */
