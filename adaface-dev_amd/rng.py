@@ -12,6 +12,7 @@ SpatialTransformer ``proj_out``, final ``out.2`` -- openaimodel.py:230-232,689,
 attention.py:280); a random-weight network with those left at zero outputs exactly 0,
 so they are drawn like every other tensor here (SURVEY.md 8c caveat 1).
 """
+import contextlib
 import zlib
 
 import numpy as np
@@ -42,11 +43,40 @@ def synth_state_dict(named_shapes, seed: int = 0):
     return {name: synth_tensor(name, shape, seed) for name, shape in named_shapes}
 
 
-def load_synth_weights(module: torch.nn.Module, seed: int = 0) -> None:
-    """Overwrite every parameter of `module` in place with its synthetic value."""
+def load_synth_weights(module: torch.nn.Module, seed: int = 0, on_device: bool = False) -> None:
+    """Overwrite every parameter of `module` in place with its synthetic value.  on_device: draw the values with torch's generator
+    on the parameter's own (GPU) device instead -- the same rules and scales, NOT the Philox values the fixtures are made from:
+    for benchmarks only, where 2.6 G numbers per process from a single-threaded host generator would be most of the run time."""
     with torch.no_grad():
         for name, p in module.named_parameters():
-            p.copy_(synth_tensor(name, p.shape, seed).to(p.dtype))
+            if not on_device:
+                p.copy_(synth_tensor(name, p.shape, seed).to(p.dtype))
+                continue
+            g = torch.Generator(device=p.device)
+            g.manual_seed(((int(seed) + 1) * 0x9E3779B1 + zlib.crc32(name.encode())) & 0x7FFFFFFFFFFFFFFF)
+            z = torch.randn(p.shape, device=p.device, dtype=torch.float32, generator=g)
+            if name.endswith(".bias"):
+                z *= 0.05
+            elif p.dim() == 1:
+                z = 1.0 + 0.1 * z
+            else:
+                z *= float(np.prod(p.shape[1:])) ** -0.5
+            p.copy_(z.to(p.dtype))
+
+
+@contextlib.contextmanager
+def skip_default_init():
+    """Construct modules without torch's default random initialisation (for callers that overwrite EVERY parameter right after:
+    the default init of an 860 M-parameter U-Net is ~15 s of host time per process)."""
+    names = ("kaiming_uniform_", "kaiming_normal_", "uniform_", "normal_", "trunc_normal_", "xavier_uniform_", "xavier_normal_")
+    saved = {n: getattr(torch.nn.init, n) for n in names}
+    try:
+        for n in names:
+            setattr(torch.nn.init, n, lambda t, *a, **k: t)
+        yield
+    finally:
+        for n, f in saved.items():
+            setattr(torch.nn.init, n, f)
 
 
 def synth_input(name: str, shape, seed: int = 0, scale: float = 1.0) -> torch.Tensor:

@@ -99,15 +99,19 @@ def run_train(args, ctx, dev, stage=1):
 
     _lib.lib()
     B = args.batch
-    ldm = LatentDiffusion(SD15_UNET_CONFIG)
-    rng.load_synth_weights(ldm.model.diffusion_model, seed=0)
-    teacher = UNetModel(**SD15_UNET_CONFIG)
-    rng.load_synth_weights(teacher, seed=1)
-    id2ada = Arc2Face_ID2AdaPrompt()
-    rng.load_synth_weights(id2ada.text_to_image_prompt_encoder, seed=2)
-    rng.load_synth_weights(id2ada.subj_basis_generator.prompt2token_proj, seed=3)
-    text_enc = CLIPTextModelWrapper()
-    rng.load_synth_weights(text_enc, seed=4)
+    # random-init weights of the architecture (no checkpoints offline): the two U-Nets skip torch's default init and draw their
+    # synthetic values on the GPU (rng.load_synth_weights(on_device=True): same rules, generated where they live)
+    with rng.skip_default_init():
+        ldm = LatentDiffusion(SD15_UNET_CONFIG)
+        teacher = UNetModel(**SD15_UNET_CONFIG)
+    ldm, teacher = ldm.to(dev), teacher.to(dev)
+    rng.load_synth_weights(ldm.model.diffusion_model, seed=0, on_device=True)
+    rng.load_synth_weights(teacher, seed=1, on_device=True)
+    id2ada = Arc2Face_ID2AdaPrompt().to(dev)
+    rng.load_synth_weights(id2ada.text_to_image_prompt_encoder, seed=2, on_device=True)
+    rng.load_synth_weights(id2ada.subj_basis_generator.prompt2token_proj, seed=3, on_device=True)
+    text_enc = CLIPTextModelWrapper().to(dev)
+    rng.load_synth_weights(text_enc, seed=4, on_device=True)
     text_enc.extend_position_embeddings(97)          # --clip_prompt_max_length 97: the training context length (main.py:272)
     ldm = ldm.to(dev)
     for p in ldm.model.diffusion_model.parameters():
@@ -279,10 +283,11 @@ def run_denoise(args, ctx, dev):
 
     _lib.lib()  # no fallback: fail here if the HIP extension is absent
     B = args.batch
-    ldm = LatentDiffusion(SD15_UNET_CONFIG)
-    unet = ldm.model.diffusion_model
-    rng.load_synth_weights(unet, seed=0)
+    with rng.skip_default_init():
+        ldm = LatentDiffusion(SD15_UNET_CONFIG)
     ldm = ldm.to(dev).eval()
+    unet = ldm.model.diffusion_model
+    rng.load_synth_weights(unet, seed=0, on_device=True)     # random-init weights, drawn on the GPU (same rules as the fixtures' Philox values)
     unet.prepare()
     for p in unet.parameters():
         p.requires_grad_(False)
@@ -517,8 +522,17 @@ def main():
         print(f"bench.py: --gpus {args.gpus} under a launcher with WORLD_SIZE {world}; using {world}", file=sys.stderr)
     dev = init_device(ctx)
     out = None
+    t_leg = time.perf_counter()
+
+    def lap(what):                                   # wall time per leg on stderr (model construction + warm-up + timed region)
+        nonlocal t_leg
+        now = time.perf_counter()
+        if rank == 0:
+            print(f"[bench] {what}: {now - t_leg:.1f} s", file=sys.stderr, flush=True)
+        t_leg = now
     if args.mode in ("all", "denoise"):
         out = run_denoise(args, ctx, dev)
+        lap("denoise leg")
     if args.mode in ("all", "train", "train2"):
         # the train leg must never cost the headline line: an exception is reported inside the line, and a hang (a stuck
         # collective) is cut by a watchdog on rank 0 that prints what it has and leaves
@@ -539,7 +553,9 @@ def main():
                 traceback.print_exc()
                 return {"error": f"{type(e).__name__}: {e}"}
         tr = leg(1) if args.mode in ("all", "train") else None
+        lap("train leg")
         tr2 = leg(2) if args.mode in ("all", "train2") else None
+        lap("train_stage2 leg")
         done.set()
         if args.mode == "train":
             out = tr
