@@ -653,3 +653,25 @@ def test_full_size_bs4_train_step_of_the_bench_leg(dev):
     assert cfg["finite"] and cfg["skipped_steps"] == 0 and cfg["optimizer_steps"] == 3, cfg
     assert out["n_gpus"] == 1 and out["steps"] == 4 and out["value"] > 0
     assert any("captured" in s and not s.endswith(" 0 captured") for s in cfg["hipgraph_segments"]), cfg["hipgraph_segments"]
+
+
+def test_bench_train_leg_under_the_launcher_with_rccl_and_graph_replay(dev):
+    """`bench.py --mode train` as the driver starts it for N > 1 -- under torch.distributed.run, backend nccl (= RCCL), here with one
+    rank: process-group init, start-up broadcast, the gradient buckets' all-reduces issued from the backward hooks WHILE the student /
+    teacher segments are captured into hipGraphs and then replayed, overflow all-reduce, optimizer steps; one JSON line from rank 0."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+                        "--master-port", "29623", os.path.join(root, "bench.py"), "--gpus", "1", "--mode", "train", "--train-steps", "6",
+                        "--train-warmup", "6", "--no-roofline"], env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    cfg = out["config"]
+    assert out["n_gpus"] == 1 and out["steps"] == 6 and out["unit"] == "images/s" and out["value"] > 0
+    assert cfg["finite"] and cfg["skipped_steps"] == 0 and cfg["optimizer_steps"] == 6
+    assert sorted(cfg["hipgraph_segments"]) == ["student.backward: 2 captured", "student.forward: 2 captured", "teacher.multistep: 3 captured"]
