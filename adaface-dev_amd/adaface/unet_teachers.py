@@ -56,22 +56,26 @@ class UNetTeacher(nn.Module):
             t = t[0].repeat(x_start.shape[0])
             noise = noise[:1].repeat(x_start.shape[0], 1, 1, 1)
         same = bool(same_t_noise_across_instances)
-        if self.graphs is not None and presampled is None and x_start.is_cuda and not self.uses_cfg:
+        if self.graphs is not None and presampled is None and x_start.is_cuda:
             # fixed shapes, no host decision inside: one hipGraph per signature (graphs.py).  The random draws of the extra steps are
-            # captured as graph-safe generator increments, so every replay draws fresh numbers.  (With CFG the scale is a fresh host
-            # draw per call and would be frozen into the capture: that path stays eager.)
-            key = (tuple(x_start.shape), tuple(teacher_context.shape), int(num_denoising_steps), same, global_t_lb, global_t_ub)
-            return self.graphs.run(key, lambda xs, nz, tt, tc: self._multistep(ddpm_model, xs, nz, tt, tc, None, num_denoising_steps, same,
-                                                                               global_t_lb, global_t_ub, None),
-                                   [x_start, noise, t, teacher_context])
+            # captured as graph-safe generator increments, so every replay draws fresh numbers; the guidance scale (a fresh host draw
+            # per call) enters as a 0-dim device tensor, so a replay combines with THIS call's scale.
+            guided = bool(self.uses_cfg and self.cfg_scale > 1)
+            cfg_t = torch.full((), float(self.cfg_scale), device=x_start.device, dtype=torch.float32) if guided else None
+            key = (tuple(x_start.shape), tuple(teacher_context.shape), None if negative_context is None else tuple(negative_context.shape),
+                   int(num_denoising_steps), same, global_t_lb, global_t_ub, guided)
+            return self.graphs.run(key, lambda xs, nz, tt, tc, nc, cf: self._multistep(ddpm_model, xs, nz, tt, tc, nc, num_denoising_steps, same,
+                                                                                       global_t_lb, global_t_ub, None, cfg=cf),
+                                   [x_start, noise, t, teacher_context, negative_context, cfg_t])
         return self._multistep(ddpm_model, x_start, noise, t, teacher_context, negative_context, num_denoising_steps, same, global_t_lb,
                                global_t_ub, presampled)
 
     def _multistep(self, ddpm_model, x_start, noise, t, teacher_context, negative_context, num_denoising_steps, same_t_noise_across_instances,
-                   global_t_lb, global_t_ub, presampled):
+                   global_t_lb, global_t_ub, presampled, cfg=None):
         """The denoising loop of forward() (unet_teachers.py:115-185); same_t_noise was already applied to t / noise by the caller, the
         flag re-applies it to the draws of the extra steps."""
         x_starts, noises, ts, noise_preds = [x_start], [noise], [t], []
+        cfg = self.cfg_scale if cfg is None else cfg                  # float, or a 0-dim device tensor under graph capture
         for i in range(num_denoising_steps):
             x_start, t, noise = x_starts[i], ts[i], noises[i]
             x_noisy = ddpm_model.q_sample(x_start, t, noise)
@@ -83,7 +87,7 @@ class UNetTeacher(nn.Module):
                     pos, neg = torch.chunk(noise_pred, 2, dim=0)
                 else:
                     pos, neg = noise_pred, self._eps(x_noisy, t, negative_context)
-                noise_pred = pos * self.cfg_scale - neg * (self.cfg_scale - 1)
+                noise_pred = pos * cfg - neg * (cfg - 1)
             noise_preds.append(noise_pred)
             pred_x0 = ddpm_model.predict_start_from_noise(x_noisy, t, noise_pred)
             x_starts.append(pred_x0)

@@ -83,6 +83,9 @@ class DistillTrainer:
             if getattr(ldm, "unet_teacher", None) is not None:
                 ldm.unet_teacher.graphs = GraphedSegment("teacher.multistep")
                 self.graph_segments.append(ldm.unet_teacher.graphs)
+            if getattr(ldm, "comp_distill_priming_unet", None) is not None:      # Stage 2: the priming U-Net's guided multi-step forward
+                ldm.comp_distill_priming_unet.graphs = GraphedSegment("priming.multistep")
+                self.graph_segments.append(ldm.comp_distill_priming_unet.graphs)
         for p in text_encoder.parameters():
             p.requires_grad_(False)
         self.accum = accumulate_grad_batches

@@ -130,7 +130,7 @@ def run_train(args, ctx, dev, stage=1):
         box[:, :, 16:44, 18:46] = 1                                        # 19 % of the image: inside the reference's 'good' face range
         step_kw = dict(face_mask_fn=lambda x_recons: box)
     tr = DistillTrainer(ldm, id2ada.to(dev), text_enc.to(dev), batch_size=B, accumulate_grad_batches=2, prompt_len=97, stage=stage,
-                        use_graphs=(stage == 1 and not args.no_train_graphs))
+                        use_graphs=not args.no_train_graphs)
     n_train = sum(a.numel for a in tr.arenas)
 
     def batch(i):

@@ -675,3 +675,45 @@ def test_bench_train_leg_under_the_launcher_with_rccl_and_graph_replay(dev):
     assert out["n_gpus"] == 1 and out["steps"] == 6 and out["unit"] == "images/s" and out["value"] > 0
     assert cfg["finite"] and cfg["skipped_steps"] == 0 and cfg["optimizer_steps"] == 6
     assert sorted(cfg["hipgraph_segments"]) == ["student.backward: 2 captured", "student.forward: 2 captured", "teacher.multistep: 3 captured"]
+
+
+def test_guided_teacher_graph_replay_follows_the_per_call_guidance_scale(dev):
+    """UNetTeacher with classifier-free guidance under graph replay (the Stage-2 priming U-Net): the guidance scale is drawn on the
+    host per call and enters the captured segment as a 0-dim device tensor, so replays must follow it.  One denoising step (nothing
+    random inside): eager, captured and replayed calls equal a teacher without graphs that is fed the same draws; with 2 steps the
+    replays draw fresh timesteps / noise every time."""
+    from adaface_dev_amd import rng
+    from adaface_dev_amd.adaface.unet_teachers import UNetTeacher
+    from adaface_dev_amd.graphs import GraphedSegment
+    from adaface_dev_amd.ldm.models.diffusion.ddpm import LatentDiffusion
+    from adaface_dev_amd.ldm.modules.diffusionmodules.openaimodel import UNetModel
+    ucfg = dict(CFG, context_dim=128)
+    unet = UNetModel(**ucfg)
+    rng.load_synth_weights(unet, seed=42)
+    ld = LatentDiffusion(ucfg).to(dev)
+    unet = unet.to(dev)
+    plain = UNetTeacher(unet, cfg_scale_range=(2, 4), p_uses_cfg=1.0)
+    graphed = UNetTeacher(unet, cfg_scale_range=(2, 4), p_uses_cfg=1.0)
+    graphed.graphs = GraphedSegment("priming.multistep")
+    to = lambda name, shape: rng.synth_input(name, shape, seed=47).to(dev)
+    pos, neg = to("tg.pos", (2, 20, 128)), to("tg.neg", (1, 20, 128))
+    t = torch.tensor([800, 720], device=dev)
+    scales = []
+    for call in range(5):
+        x0, noise = to(f"tg.x{call}", (2, 4, 32, 32)), to(f"tg.n{call}", (2, 4, 32, 32))
+        outs = []
+        for teacher in (plain, graphed):
+            np.random.seed(100 + call)                                   # the same two host draws (uses_cfg, cfg_scale) for both
+            preds, xs, _, _ = teacher(ld, x0, noise, t, pos, negative_context=neg, num_denoising_steps=1)
+            outs.append((preds[0].clone(), xs[1].clone(), teacher.cfg_scale))
+        scales.append(outs[0][2])
+        assert outs[0][2] == outs[1][2] and torch.isfinite(outs[1][0]).all()
+        assert rel_l2(outs[1][0].cpu().numpy(), outs[0][0].cpu().numpy()) < 1e-5, call       # (cfg - 1) in fp32 vs double: last-bit differences
+        assert rel_l2(outs[1][1].cpu().numpy(), outs[0][1].cpu().numpy()) < 1e-5, call
+    assert len(set(scales)) == 5 and [e["state"] for e in graphed.graphs.entries.values()] == ["graph"]
+    seen = []
+    for call in range(4):                                                # 2 steps: the second step's timestep / noise are drawn inside the graph
+        _, xs, ns, ts = graphed(ld, to("tg.x0", (2, 4, 32, 32)), to("tg.n0", (2, 4, 32, 32)), t, pos, negative_context=neg, num_denoising_steps=2)
+        assert torch.isfinite(xs[2]).all() and (ts[1] < t).all()
+        seen.append(ns[1].clone())
+    assert not torch.equal(seen[2], seen[3]) and not torch.equal(seen[1], seen[2])
