@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Census of the GEMM launches of bench.py's training legs: how many times each (shape, epilogue) key is launched per micro-batch,
 which (tile, split-K) the table gives it, and the time the autotune log measured for that choice.
-    python tools/gemm_census.py [--stage 1|2] [--log profiles/r02m_autotune_train.log]"""
+    python tools/gemm_census.py [--stage 0|1|2] [--log profiles/r02p_autotune_all.log]        (stage 0 = one denoise step at U-Net batch 8)"""
 import argparse
 import ast
 import collections
@@ -16,7 +16,7 @@ import torch  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--stage", type=int, default=1)
-    ap.add_argument("--log", default=os.path.join(ROOT, "profiles", "r02m_autotune_train.log"))
+    ap.add_argument("--log", default=os.path.join(ROOT, "profiles", "r02p_autotune_all.log"))
     args = ap.parse_args()
     from adaface_dev_amd import ops
     import bench
@@ -47,8 +47,23 @@ def main():
         return orig()
     bench.time.perf_counter = pc
     n_mb = 6
-    ns = argparse.Namespace(batch=4, no_ffn_lora=False, no_train_graphs=True, train_steps=n_mb, train_warmup=2, no_roofline=True)
-    bench.run_train(ns, (1, 0, 0, False), torch.device("cuda:0"), stage=args.stage)
+    if args.stage == 0:                                  # the denoise leg: one U-Net forward at batch 8 = one step
+        from adaface_dev_amd import SD15_UNET_CONFIG, rng
+        from adaface_dev_amd.ldm.modules.diffusionmodules.openaimodel import UNetModel
+        dev = torch.device("cuda:0")
+        with rng.skip_default_init():
+            unet = UNetModel(**SD15_UNET_CONFIG)
+        unet = unet.to(dev).eval()
+        rng.load_synth_weights(unet, seed=0, on_device=True)
+        x, ctx = rng.synth_input("bench.x", (8, 4, 64, 64), seed=1).to(dev), rng.synth_input("bench.ctx", (8, 77, 768), seed=1).to(dev)
+        with torch.no_grad():
+            unet(x, torch.full((8,), 500, device=dev), ctx, extra_info=None)
+            on[0], n_mb = True, 1
+            unet(x, torch.full((8,), 500, device=dev), ctx, extra_info=None)
+            on[0] = False
+    else:
+        ns = argparse.Namespace(batch=4, no_ffn_lora=False, no_train_graphs=True, train_steps=n_mb, train_warmup=2, no_roofline=True)
+        bench.run_train(ns, (1, 0, 0, False), torch.device("cuda:0"), stage=args.stage)
     tot_us = 0.0
     rows = []
     for key, n in counts.items():
