@@ -536,8 +536,8 @@ bool launch3(const Gemm3Dev& p0, hipStream_t stream) {
 // slots: stage i+1 streams in while stage i is computed.  56 pieces per stage = exactly 7 per wave (2 A + 5 W).  Fragment rows are
 // 128 bytes apart, so 16 consecutive lanes alias two rows per 256 bytes of banks: the 16-byte chunk index is XOR-ed with
 // (row >> 1) & 7 on the DMA source side.  Standard epilogue only (staged); channel counts and K padding multiples of 64.
-template <int TAPS, int NWM, int NWN, int TN, int EPI>
-__global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void af_gemm3w_kernel(Gemm3Dev p) {
+template <int TAPS, int NWM, int NWN, int TN, int EPI, int NSLOT = 2>
+__global__ __launch_bounds__(64 * NWM * NWN, (NWM * NWN == 4 && NSLOT == 2) ? 2 : 1) void af_gemm3w_kernel(Gemm3Dev p) {
   constexpr int TM = 4, NW = NWM * NWN;
   constexpr int BM = NWM * 64, BN = NWN * TN * 16, BKW = 64;
   constexpr int APW = (BM / 8) / NW;                  // A pieces (8 rows x 128 B) per wave per stage
@@ -666,7 +666,12 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void af_gem
   const int kt_end = min(nk_total, kt_begin + p.kt_per_split);
   const int nk = kt_end - kt_begin;
 
-  if (nk > 0) issue_stage(kt_begin, 0);
+  // NSLOT - 1 stages are in flight ahead of the one being computed (NSLOT = 2: the shipped tiles; NSLOT = 4: the deep-ring variants for
+  // grids of at most one workgroup per CU, where nothing else hides the L2 / HBM latency of a stage -- the 16x16 level's GEMMs)
+#pragma unroll
+  for (int s0 = 0; s0 < NSLOT - 1; ++s0)
+    if (s0 < nk) issue_stage(kt_begin + s0, s0);
+  constexpr int DPS = APW + WPW;                          // LDS-DMA pieces per wave per stage
   half8_t wf[TN], xf[TM];
   // 8-wave tiles put two waves on every SIMD, and with one barrier per K step the partners walk the step in lock step: both issue
   // their DMA pieces (~60 - 100 cycles each, 7 per wave) at the same time while the MFMA pipe idles.  The second half of the waves
@@ -681,10 +686,17 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void af_gem
   const bool prio = NW == 8 && (p.ablate & 128) == 0;
   const bool late_dma = NW == 8 && (p.ablate & 256) == 0 && wave >= NW / 2;
   for (int i = 0; i < nk; ++i) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // stage i (the only one in flight) has landed
-    __builtin_amdgcn_s_barrier();                           // ... for every wave; everyone is done reading the other slot
-    if (!late_dma && i + 1 < nk) issue_stage(kt_begin + i + 1, (i + 1) & 1);
-    const char* As = af_smem + (i & 1) * STAGE;
+    if (NSLOT == 2) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // stage i (the only one in flight) has landed
+    } else {                                                // stage i has landed when at most the younger stages' pieces are outstanding
+      const int younger = min(NSLOT - 2, nk - 1 - i);
+      if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DPS) : "memory");
+      else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPS) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();                           // ... for every wave; everyone is done reading the slot refilled next
+    if (!late_dma && i + NSLOT - 1 < nk) issue_stage(kt_begin + i + NSLOT - 1, (i + NSLOT - 1) % NSLOT);
+    const char* As = af_smem + (i % NSLOT) * STAGE;
     const char* Ws = As + BM * 128;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
@@ -700,29 +712,30 @@ __global__ __launch_bounds__(64 * NWM * NWN, NWM * NWN == 4 ? 2 : 1) void af_gem
         for (int tm = 0; tm < TM; ++tm)
           acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[tn], xf[tm], acc[tn][tm], 0, 0, 0);
       if (prio) __builtin_amdgcn_s_setprio(0);
-      if (kk == 0 && late_dma && i + 1 < nk) issue_stage(kt_begin + i + 1, (i + 1) & 1);
+      if (kk == 0 && late_dma && i + NSLOT - 1 < nk) issue_stage(kt_begin + i + NSLOT - 1, (i + NSLOT - 1) % NSLOT);
     }
   }
-  gemm3_epilogue<EPI, NWM, NWN, TN, 2 * STAGE>(p, acc, af_smem, tile_m, tile_n, wm, wn, fr, fq, tid);
+  gemm3_epilogue<EPI, NWM, NWN, TN, NSLOT * STAGE>(p, acc, af_smem, tile_m, tile_n, wm, wn, fr, fq, tid);
 }
 
-template <int TAPS, int NWM, int NWN, int TN, int EPI = E3_STD>
+template <int TAPS, int NWM, int NWN, int TN, int EPI = E3_STD, int NSLOT = 2>
 bool launch3w(const Gemm3Dev& p0, hipStream_t stream) {
   Gemm3Dev p = p0;
   constexpr int NW = NWM * NWN, BM = NWM * 64, BN = NWN * TN * 16;
-  constexpr size_t lds = 2 * (size_t)(BM + BN) * 128;
+  constexpr size_t lds = NSLOT * (size_t)(BM + BN) * 128;
+  static_assert(NSLOT == 2 || NSLOT == 4, "ring depths built: 2 and 4 (the counted waits cover at most two younger stages)");
   p.tiles_n = (p.N + BN - 1) / BN;
   p.tiles_m = (p.M + BM - 1) / BM;
   if (p.counters && (TN > 5 || p.splits <= 1 || p.splits > 4 || p.tiles_m * p.tiles_n > AF_SPLITK_MAX_TILES)) p.counters = nullptr;
   p.n_major = af_gemm_n_major(p.M, p.N, p.K, TAPS == 9 ? p.c1 + p.c2 : p.K);
   static bool attr_set = false;
   if (lds > 65536 && !attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&af_gemm3w_kernel<TAPS, NWM, NWN, TN, EPI>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&af_gemm3w_kernel<TAPS, NWM, NWN, TN, EPI, NSLOT>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   dim3 grid(p.tiles_m * p.tiles_n, p.splits), block(64 * NW);
-  hipLaunchKernelGGL((af_gemm3w_kernel<TAPS, NWM, NWN, TN, EPI>), grid, block, lds, stream, p);
+  hipLaunchKernelGGL((af_gemm3w_kernel<TAPS, NWM, NWN, TN, EPI, NSLOT>), grid, block, lds, stream, p);
   return p.counters != nullptr;
 }
 
@@ -732,9 +745,10 @@ bool launch3w(const Gemm3Dev& p0, hipStream_t stream) {
 // outside this kernel's scope (caller falls back), 0 after a launch.
 int af_gemm3_try_launch(const af_gemm_desc* d, int splits, int wide, hipStream_t stream) {
   // wide: 0 = 128 x 128, 1 = 128 x 320 (GEGLU 128 x 256), 2 = 256 x 256, 3 = 256 x 320 (8 waves as 4 x 2); whole-line kernel:
-  // 4 = 128 x 320 (GEGLU 128 x 256), 5 = 128 x 128, 6 = GEGLU 256 x 320, 7 = GEGLU 256 x 256, 8 = 128 x 160 (4 waves, 2 workgroups per CU)
+  // 4 = 128 x 320 (GEGLU 128 x 256), 5 = 128 x 128, 6 = GEGLU 256 x 320, 7 = GEGLU 256 x 256, 8 = 128 x 160 (4 waves, 2 workgroups per CU),
+  // 9 / 10 = 128 x 128 / 128 x 160 with a four-slot ring (three stages in flight, one workgroup per CU)
   const bool geglu = d->act == AF_ACT_GEGLU, split_t = d->out_mode == AF_OUT_SPLIT_T;
-  if (d->upsample && !((wide == 4 || wide == 5 || wide == 8) && d->upsample == 1 && d->taps == 9)) return 1;   // nearest x2: whole-line kernel only
+  if (d->upsample && !((wide == 4 || wide == 5 || wide >= 8) && d->upsample == 1 && d->taps == 9)) return 1;   // nearest x2: whole-line kernel only
   if (d->c1 % BK3 != 0 || d->c2 % BK3 != 0 || d->zeros == nullptr) return 1;
   if ((geglu || split_t) && (d->taps != 1 || splits > 1)) return 1;
   if (geglu && (!wide || d->N % (wide == 5 ? 128 : 256) != 0)) return 1;   // GEGLU: 128 x 256 tile, the 256-row tiles, or 128 x 128 whole-line
@@ -745,8 +759,9 @@ int af_gemm3_try_launch(const af_gemm_desc* d, int splits, int wide, hipStream_t
     if (wide == 5 && geglu && d->N % 128 != 0) return 1;
     if (wide == 6 && (!geglu || d->N % 320 != 0)) return 1;
     if (wide == 7 && (!geglu || d->N % 256 != 0)) return 1;
-    if (wide == 8 && (geglu || split_t || d->N % 160 != 0)) return 1;
-    if (wide > 8) return 1;
+    if ((wide == 8 || wide == 10) && (geglu || split_t || d->N % 160 != 0)) return 1;
+    if (wide == 9 && (geglu || split_t)) return 1;
+    if (wide > 10) return 1;
   }
   if (wide == 2 && (d->N % 256 != 0 || d->taps != 1 || split_t || splits > 1)) return 1;
   if (wide == 3 && (d->N % 320 != 0 || d->taps != 1 || split_t || splits > 1)) return 1;
@@ -819,6 +834,10 @@ int af_gemm3_try_launch(const af_gemm_desc* d, int splits, int wide, hipStream_t
       else fused = launch3w<1, 2, 2, 4>(p, stream);
     } else if (wide == 8) {                                  // 128 x 160, 4 waves, two workgroups per CU
       if (d->taps == 9) fused = launch3w<9, 2, 2, 5>(p, stream); else fused = launch3w<1, 2, 2, 5>(p, stream);
+    } else if (wide == 9) {                                  // 128 x 128, 4 waves, FOUR slots (three stages in flight), one workgroup per CU
+      if (d->taps == 9) fused = launch3w<9, 2, 2, 4, E3_STD, 4>(p, stream); else fused = launch3w<1, 2, 2, 4, E3_STD, 4>(p, stream);
+    } else if (wide == 10) {                                 // 128 x 160, 4 waves, four slots
+      if (d->taps == 9) fused = launch3w<9, 2, 2, 5, E3_STD, 4>(p, stream); else fused = launch3w<1, 2, 2, 5, E3_STD, 4>(p, stream);
     } else {
       if (wide == 6) fused = launch3w<1, 4, 2, 10, E3_GEGLU>(p, stream); else fused = launch3w<1, 4, 2, 8, E3_GEGLU>(p, stream);
     }

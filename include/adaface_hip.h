@@ -119,6 +119,9 @@ typedef struct af_gemm_desc {
                         /* 11 = whole-line kernel, 128x160 tile of four waves (N % 160 == 0; standard epilogue, taps 1 / 9, nearest x2): 74 KB of
                            LDS, so TWO workgroups share a CU and one's epilogue / barrier waits run under the other's MFMAs: the faster
                            form when the 128x320 grid has under ~1.5 workgroups per CU (batch 1 - 4 passes, the 32x32 level) */
+                        /* 12 / 13 = the 128x128 / 128x160 whole-line tiles with a FOUR-slot ring: three K stages in flight ahead of the MFMAs
+                           instead of one (128 / 147 KB of LDS, one workgroup per CU): for grids of at most ~one workgroup per CU, where
+                           nothing else covers a stage's L2 / HBM latency (the 16x16 level: weights read once, 160 tiles) */
   int32_t splits;       /* split-K factor (<=1: none).  >1 needs the standard epilogue and a workspace:
                            each split writes an fp32 partial [M][N], a second launch reduces + applies the epilogue */
   void* workspace;      /* fp32, >= splits*M*N*4 bytes when splits > 1 */

@@ -66,7 +66,7 @@ def test_gemm_and_conv_split_k(dev, tile, splits):
     assert rel_l2(oc.float().cpu().permute(0, 3, 1, 2).numpy(), refc.numpy()) < TOL
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 7, 8, 11])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 7, 8, 11, 12, 13])
 def test_gemm_fp32_output_and_wgrad_past_the_fp16_range(dev, tile):
     """AF_OUT_F32: the epilogue (or the split-K reduce pass) stores the fp32 accumulator.  Entries far beyond 65504 (a weight gradient summed over
     thousands of tokens) come back finite and exact to fp32 summation error; autograd_ops.wgrad uses this mode."""
@@ -173,10 +173,13 @@ def test_gemm_256_row_tiles(dev, M, N, K, tile, act):
 
 @pytest.mark.parametrize("M,N,K,splits,tile", [(300, 320, 320, 1, 7), (4096, 640, 1280, 2, 7), (130, 960, 64, 1, 7), (1000, 320, 2880, 3, 7),
                                                 (300, 200, 320, 1, 8), (1000, 384, 1280, 2, 8), (77, 768, 64, 1, 8),
-                                                (300, 320, 320, 1, 11), (4096, 640, 1280, 2, 11), (130, 960, 64, 1, 11), (1000, 160, 2880, 3, 11), (77, 1280, 64, 1, 11)])
+                                                (300, 320, 320, 1, 11), (4096, 640, 1280, 2, 11), (130, 960, 64, 1, 11), (1000, 160, 2880, 3, 11), (77, 1280, 64, 1, 11),
+                                                (300, 200, 320, 1, 12), (1000, 384, 1280, 2, 12), (77, 768, 64, 1, 12), (2048, 1280, 128, 1, 12), (130, 256, 192, 1, 12),
+                                                (300, 320, 320, 1, 13), (4096, 640, 1280, 2, 13), (130, 960, 64, 1, 13), (1000, 160, 2880, 3, 13), (77, 1280, 128, 1, 13)])
 def test_gemm_whole_line_tiles(dev, M, N, K, splits, tile):
     """Whole-line kernel (64-wide K stages, whole-cache-line LDS-DMA pieces, two slots): 128 x 320 (tile 7), 128 x 128 (tile 8) and
-    128 x 160 (tile 11: four waves, two workgroups per CU; N % 160 == 0); ragged M and N, one-stage K, split-K."""
+    128 x 160 (tile 11: four waves, two workgroups per CU; N % 160 == 0); tiles 12 / 13 = the 128 x 128 / 128 x 160 tiles with a FOUR-slot
+    ring (three stages in flight; K of one, two and three stages exercise the short-ring waits); ragged M and N, split-K."""
     from adaface_dev_amd import ops
     a, w = rnd((M, K), 1), rnd((N, K), 2, K ** -0.5)
     b, r = torch.randn(N, generator=torch.Generator().manual_seed(3)), rnd((M, N), 4)
@@ -189,7 +192,9 @@ def test_gemm_whole_line_tiles(dev, M, N, K, splits, tile):
                                                                 (2, 16, 16, 320, 0, 320, 2, 1, 7), (3, 8, 8, 1280, 1280, 1280, 1, 4, 7),
                                                                 (2, 16, 16, 128, 64, 192, 1, 1, 8), (1, 12, 20, 64, 0, 72, 2, 2, 8),
                                                                 (1, 32, 32, 320, 0, 320, 1, 1, 11), (2, 16, 16, 640, 320, 640, 1, 2, 11),
-                                                                (2, 16, 16, 320, 0, 320, 2, 1, 11), (3, 8, 8, 1280, 1280, 1280, 1, 4, 11), (1, 12, 20, 64, 0, 160, 2, 2, 11)])
+                                                                (2, 16, 16, 320, 0, 320, 2, 1, 11), (3, 8, 8, 1280, 1280, 1280, 1, 4, 11), (1, 12, 20, 64, 0, 160, 2, 2, 11),
+                                                                (2, 16, 16, 128, 64, 192, 1, 1, 12), (1, 12, 20, 64, 0, 72, 2, 2, 12), (3, 8, 8, 1280, 1280, 1280, 1, 4, 12),
+                                                                (1, 32, 32, 320, 0, 320, 1, 1, 13), (2, 16, 16, 640, 320, 640, 1, 2, 13), (3, 8, 8, 1280, 1280, 1280, 1, 4, 13)])
 def test_conv3x3_whole_line_tiles(dev, B, H, W, c1, c2, cout, stride, splits, tile):
     from adaface_dev_amd import ops
     cin = c1 + c2
@@ -263,7 +268,7 @@ def test_gemm_split_transposed(dev, tokens, tile):
     (2, 16, 16, 64, 0, 64, 2, False, 2), (2, 15, 17, 32, 0, 64, 2, False, 2), (2, 8, 8, 64, 0, 64, 1, True, 2),
     (2, 8, 8, 128, 64, 64, 1, False, 2), (1, 32, 32, 320, 0, 4, 1, False, 0), (2, 8, 8, 96, 32, 128, 1, False, 1),
     (2, 8, 8, 64, 0, 64, 1, True, 8), (2, 9, 7, 320, 0, 320, 1, True, 7), (1, 16, 16, 640, 0, 640, 1, True, 7), (3, 5, 6, 128, 0, 192, 1, True, 8),
-    (2, 9, 7, 320, 0, 320, 1, True, 11), (1, 16, 16, 640, 0, 640, 1, True, 11),
+    (2, 9, 7, 320, 0, 320, 1, True, 11), (1, 16, 16, 640, 0, 640, 1, True, 11), (3, 5, 6, 128, 0, 192, 1, True, 12), (2, 9, 7, 320, 0, 320, 1, True, 13),
 ])
 def test_conv3x3(dev, B, H, W, c1, c2, cout, stride, ups, tile):
     from adaface_dev_amd import ops
@@ -473,7 +478,7 @@ def test_prefetch_reads_without_side_effects(dev):
     assert torch.equal(x, ref)
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 7, 8, 11])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 7, 8, 11, 12, 13])
 def test_split_k_in_kernel_reduction_is_bit_identical_and_repeatable(dev, tile, monkeypatch):
     """Split-K with the reduction inside the GEMM launch (af_gemm_desc.splitk_fused: the last-arriving K-slice of every output tile sums the
     slabs in slice order and runs the epilogue) against the two-launch form: bit-identical outputs (same summation order), for
@@ -482,7 +487,7 @@ def test_split_k_in_kernel_reduction_is_bit_identical_and_repeatable(dev, tile, 
     hand-off would show as a wrong tile)."""
     from adaface_dev_amd import ops, rng
     shapes = [(1000, 320, 1280, 2), (4096, 640, 1280, 3), (616, 640, 2560, 4), (2048, 1280, 1280, 2), (130, 320, 640, 2)]
-    if tile in (4, 7, 11):
+    if tile in (4, 7, 11, 13):
         shapes = [sh for sh in shapes if sh[1] % 320 == 0]
     cases = []
     for M, N, K, sp in shapes:

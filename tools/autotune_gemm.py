@@ -97,12 +97,14 @@ def main():
         retuned.add(key)
         nk = d.kpad // 64
         best, best_t, res = (0, 1), None, {}
-        for tile in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11):
+        for tile in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13):
             geglu = d.act == _lib.AF_ACT_GEGLU
-            if tile >= 7 and (d.upsample not in (0, 1) or (d.upsample and tile not in (7, 8, 11)) or d.c1 % 64 or d.c2 % 64):
-                continue                        # whole-line kernel: 64-multiples of channels; nearest-x2 upsample in tiles 7 / 8 / 11
-            if tile == 11 and (geglu or d.out_mode == _lib.AF_OUT_SPLIT_T or d.N % 160 != 0):
-                continue                        # 128 x 160, four waves, two workgroups per CU
+            if tile >= 7 and (d.upsample not in (0, 1) or (d.upsample and tile not in (7, 8, 11, 12, 13)) or d.c1 % 64 or d.c2 % 64):
+                continue                        # whole-line kernel: 64-multiples of channels; nearest-x2 upsample in the non-GEGLU tiles
+            if tile in (11, 13) and (geglu or d.out_mode == _lib.AF_OUT_SPLIT_T or d.N % 160 != 0):
+                continue                        # 128 x 160, four waves (11: two workgroups per CU; 13: four-slot ring)
+            if tile == 12 and (geglu or d.out_mode == _lib.AF_OUT_SPLIT_T):
+                continue                        # 128 x 128 with a four-slot ring
             if tile == 7 and (d.N % (256 if geglu else 320) != 0):
                 continue
             if tile == 8 and geglu:
