@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Census of the GEMM launches of bench.py's training legs: how many times each (shape, epilogue) key is launched per micro-batch,
 which (tile, split-K) the table gives it, and the time the autotune log measured for that choice.
-    python tools/gemm_census.py [--stage 0|1|2] [--log profiles/r02p_autotune_all.log]        (stage 0 = one denoise step at U-Net batch 8)"""
+    python tools/gemm_census.py [--stage 0|1|2] [--log profiles/r02s_autotune_all.log]        (stage 0 = one denoise step at U-Net batch 8)"""
 import argparse
 import ast
 import collections
@@ -16,7 +16,7 @@ import torch  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--stage", type=int, default=1)
-    ap.add_argument("--log", default=os.path.join(ROOT, "profiles", "r02p_autotune_all.log"))
+    ap.add_argument("--log", default=os.path.join(ROOT, "profiles", "r02s_autotune_all.log"))
     args = ap.parse_args()
     from adaface_dev_amd import ops
     import bench
