@@ -79,11 +79,18 @@ class UNetTeacher(nn.Module):
         for i in range(num_denoising_steps):
             x_start, t, noise = x_starts[i], ts[i], noises[i]
             x_noisy = ddpm_model.q_sample(x_start, t, noise)
-            doubled = self.uses_cfg and self.cfg_scale > 1 and negative_context is None
-            x2, t2 = (x_noisy.repeat(2, 1, 1, 1), t.repeat(2)) if doubled else (x_noisy, t)
-            noise_pred = self._eps(x2, t2, teacher_context)
-            if self.uses_cfg and self.cfg_scale > 1:
-                if negative_context is None:
+            guided = self.uses_cfg and self.cfg_scale > 1
+            doubled = guided and negative_context is None
+            # a separate negative context of the positive one's shape rides in the SAME U-Net call as a doubled batch (the reference makes
+            # two calls, unet_teachers.py:150-158; per sample the arithmetic is identical, the launches are half as many and twice as wide)
+            stacked = guided and negative_context is not None and negative_context.shape == teacher_context.shape
+            if stacked:
+                noise_pred = self._eps(x_noisy.repeat(2, 1, 1, 1), t.repeat(2), torch.cat([teacher_context, negative_context], dim=0))
+            else:
+                x2, t2 = (x_noisy.repeat(2, 1, 1, 1), t.repeat(2)) if doubled else (x_noisy, t)
+                noise_pred = self._eps(x2, t2, teacher_context)
+            if guided:
+                if doubled or stacked:
                     pos, neg = torch.chunk(noise_pred, 2, dim=0)
                 else:
                     pos, neg = noise_pred, self._eps(x_noisy, t, negative_context)
