@@ -12,8 +12,9 @@
 //   * dK/dV kernel: KEY on the lane.  S = Q K^T, dP = dO V^T (A = Q / dO rows from LDS, B = K / V
 //     fragments in registers) -> dV^T += dO^T P, dK^T += Q^T dz (A = dO^T / Q^T rows).
 // The transposed operands (Q^T, K^T, dO^T: [B, C, tokens], token index contiguous) are produced
-// once per call by a tiled transpose into the caller's scratch buffer.  Stages are 32 tokens,
-// single LDS buffer, next stage's global loads issued before the current stage's MFMAs.
+// once per call by a tiled transpose into the caller's scratch buffer.  Stages are 32 tokens; the stage tiles exist twice in LDS:
+// stage st + 1 is stored into the other copy (from registers loaded one stage earlier) under stage st's MFMAs, stage st + 2's
+// global loads are issued right after, and ONE workgroup barrier separates stages.
 #include <float.h>
 
 #include "af_common.h"
@@ -135,9 +136,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(BwdArgs a) {
   constexpr int DP = 16 * DS, DT = (DS + 1) / 2, DV = 32 * DT, RST = DP + 8;
   constexpr int NRC = (32 * (DP / 8) + 255) / 256, NTC = (DV * 4 + 255) / 256;
   extern __shared__ __attribute__((aligned(16))) char af_smem[];
-  half_t* Ks = reinterpret_cast<half_t*>(af_smem);  // [32][RST]
-  half_t* Vs = Ks + 32 * RST;                       // [32][RST]
-  half_t* KTs = Vs + 32 * RST;                      // [DV][TST]
+  // two copies of the stage tiles: stage st + 1 is written into the other copy under stage st's MFMAs, ONE barrier per stage
+  constexpr int BUF = 2 * 32 * RST + DV * TST;      // halves per copy: K rows [32][RST], V rows [32][RST], K^T [DV][TST]
+  half_t* const smem = reinterpret_cast<half_t*>(af_smem);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, hh = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y;
@@ -174,17 +175,30 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(BwdArgs a) {
   load_rows<DP, NRC>(rk, kb, a.ldk, 0, a.L, hd, a.d, tid);
   load_rows<DP, NRC>(rv, vb, a.ldv, 0, a.L, hd, a.d, tid);
   load_tr<DV, NTC>(rt, ktb, a.ldkt, 0, a.L, a.d, tid);
+  store_rows<DP, NRC>(rk, smem, tid);
+  store_rows<DP, NRC>(rv, smem + 32 * RST, tid);
+  store_tr<DV, NTC>(rt, smem + 2 * 32 * RST, tid);
+  if (nstage > 1) {
+    load_rows<DP, NRC>(rk, kb, a.ldk, 32, a.L, hd, a.d, tid);
+    load_rows<DP, NRC>(rv, vb, a.ldv, 32, a.L, hd, a.d, tid);
+    load_tr<DV, NTC>(rt, ktb, a.ldkt, 32, a.L, a.d, tid);
+  }
   for (int st = 0; st < nstage; ++st) {
     const int key0 = st * 32;
-    __syncthreads();  // previous stage's LDS reads are done
-    store_rows<DP, NRC>(rk, Ks, tid);
-    store_rows<DP, NRC>(rv, Vs, tid);
-    store_tr<DV, NTC>(rt, KTs, tid);
-    __syncthreads();
+    __syncthreads();  // copy st & 1 is complete; everyone is done reading the other copy (stage st - 1)
+    const half_t* Ks = smem + (st & 1) * BUF;
+    const half_t* Vs = Ks + 32 * RST;
+    const half_t* KTs = Vs + 32 * RST;
     if (st + 1 < nstage) {
-      load_rows<DP, NRC>(rk, kb, a.ldk, key0 + 32, a.L, hd, a.d, tid);
-      load_rows<DP, NRC>(rv, vb, a.ldv, key0 + 32, a.L, hd, a.d, tid);
-      load_tr<DV, NTC>(rt, ktb, a.ldkt, key0 + 32, a.L, a.d, tid);
+      half_t* nx = smem + ((st + 1) & 1) * BUF;
+      store_rows<DP, NRC>(rk, nx, tid);
+      store_rows<DP, NRC>(rv, nx + 32 * RST, tid);
+      store_tr<DV, NTC>(rt, nx + 2 * 32 * RST, tid);
+      if (st + 2 < nstage) {
+        load_rows<DP, NRC>(rk, kb, a.ldk, key0 + 64, a.L, hd, a.d, tid);
+        load_rows<DP, NRC>(rv, vb, a.ldv, key0 + 64, a.L, hd, a.d, tid);
+        load_tr<DV, NTC>(rt, ktb, a.ldkt, key0 + 64, a.L, a.d, tid);
+      }
     }
     floatx16 sT, pT;
 #pragma unroll
@@ -239,10 +253,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(BwdArgs a) {
   constexpr int DP = 16 * DS, DT = (DS + 1) / 2, DV = 32 * DT, RST = DP + 8;
   constexpr int NRC = (32 * (DP / 8) + 255) / 256, NTC = (DV * 4 + 255) / 256;
   extern __shared__ __attribute__((aligned(16))) char af_smem[];
-  half_t* Qs = reinterpret_cast<half_t*>(af_smem);  // [32][RST]
-  half_t* Gs = Qs + 32 * RST;                       // dO rows [32][RST]
-  half_t* QTs = Gs + 32 * RST;                      // [DV][TST]
-  half_t* GTs = QTs + DV * TST;                     // [DV][TST]
+  constexpr int BUF = 2 * 32 * RST + 2 * DV * TST;  // halves per copy: Q rows [32][RST], dO rows [32][RST], Q^T [DV][TST], dO^T [DV][TST]
+  half_t* const smem = reinterpret_cast<half_t*>(af_smem);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, hh = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y;
@@ -283,19 +295,35 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(BwdArgs a) {
   load_rows<DP, NRC>(rg, gb, a.ldo, 0, a.Nq, hd, a.d, tid);
   load_tr<DV, NTC>(rqt, qtb, a.ldqt, 0, a.Nq, a.d, tid);
   load_tr<DV, NTC>(rgt, gtb, a.ldqt, 0, a.Nq, a.d, tid);
+  store_rows<DP, NRC>(rq, smem, tid);
+  store_rows<DP, NRC>(rg, smem + 32 * RST, tid);
+  store_tr<DV, NTC>(rqt, smem + 2 * 32 * RST, tid);
+  store_tr<DV, NTC>(rgt, smem + 2 * 32 * RST + DV * TST, tid);
+  if (nstage > 1) {
+    load_rows<DP, NRC>(rq, qb, a.ldq, 32, a.Nq, hd, a.d, tid);
+    load_rows<DP, NRC>(rg, gb, a.ldo, 32, a.Nq, hd, a.d, tid);
+    load_tr<DV, NTC>(rqt, qtb, a.ldqt, 32, a.Nq, a.d, tid);
+    load_tr<DV, NTC>(rgt, gtb, a.ldqt, 32, a.Nq, a.d, tid);
+  }
   for (int st = 0; st < nstage; ++st) {
     const int q0 = st * 32;
-    __syncthreads();
-    store_rows<DP, NRC>(rq, Qs, tid);
-    store_rows<DP, NRC>(rg, Gs, tid);
-    store_tr<DV, NTC>(rqt, QTs, tid);
-    store_tr<DV, NTC>(rgt, GTs, tid);
-    __syncthreads();
+    __syncthreads();  // copy st & 1 is complete; everyone is done reading the other copy (stage st - 1)
+    const half_t* Qs = smem + (st & 1) * BUF;
+    const half_t* Gs = Qs + 32 * RST;
+    const half_t* QTs = Gs + 32 * RST;
+    const half_t* GTs = QTs + DV * TST;
     if (st + 1 < nstage) {
-      load_rows<DP, NRC>(rq, qb, a.ldq, q0 + 32, a.Nq, hd, a.d, tid);
-      load_rows<DP, NRC>(rg, gb, a.ldo, q0 + 32, a.Nq, hd, a.d, tid);
-      load_tr<DV, NTC>(rqt, qtb, a.ldqt, q0 + 32, a.Nq, a.d, tid);
-      load_tr<DV, NTC>(rgt, gtb, a.ldqt, q0 + 32, a.Nq, a.d, tid);
+      half_t* nx = smem + ((st + 1) & 1) * BUF;
+      store_rows<DP, NRC>(rq, nx, tid);
+      store_rows<DP, NRC>(rg, nx + 32 * RST, tid);
+      store_tr<DV, NTC>(rqt, nx + 2 * 32 * RST, tid);
+      store_tr<DV, NTC>(rgt, nx + 2 * 32 * RST + DV * TST, tid);
+      if (st + 2 < nstage) {
+        load_rows<DP, NRC>(rq, qb, a.ldq, q0 + 64, a.Nq, hd, a.d, tid);
+        load_rows<DP, NRC>(rg, gb, a.ldo, q0 + 64, a.Nq, hd, a.d, tid);
+        load_tr<DV, NTC>(rqt, qtb, a.ldqt, q0 + 64, a.Nq, a.d, tid);
+        load_tr<DV, NTC>(rgt, gtb, a.ldqt, q0 + 64, a.Nq, a.d, tid);
+      }
     }
     floatx16 s, dp;
 #pragma unroll
@@ -354,9 +382,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(BwdArgs a) {
 template <int DS>
 int launch_bwd(const BwdArgs& a, hipStream_t s) {
   constexpr int DP = 16 * DS, DT = (DS + 1) / 2, DV = 32 * DT, RST = DP + 8;
-  constexpr size_t lds_dq = (size_t)(2 * 32 * RST + DV * TST) * sizeof(half_t);
-  constexpr size_t lds_dkv = (size_t)(2 * 32 * RST + 2 * DV * TST) * sizeof(half_t);
-  static_assert(lds_dkv <= 65536, "LDS budget");
+  constexpr size_t lds_dq = 2 * (size_t)(2 * 32 * RST + DV * TST) * sizeof(half_t);          // two copies of the stage tiles
+  constexpr size_t lds_dkv = 2 * (size_t)(2 * 32 * RST + 2 * DV * TST) * sizeof(half_t);
+  static_assert(lds_dkv <= 160 * 1024, "LDS budget");
+  static bool attr_set = false;
+  if (lds_dkv > 65536 && !attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<DS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dkv);
+    attr_set = true;
+  }
   hipLaunchKernelGGL(attn_bwd_dq_kernel<DS>, dim3((a.Nq + 127) / 128, a.heads, a.B), dim3(256), lds_dq, s, a);
   hipLaunchKernelGGL(attn_bwd_dkv_kernel<DS>, dim3((a.L + 127) / 128, a.heads, a.B), dim3(256), lds_dkv, s, a);
   return af_check_launch("af_attention_bwd");
