@@ -101,7 +101,7 @@ __device__ __forceinline__ void load_tr(half8_t (&r)[NC], const half_t* base, in
     const int tk = tok0 + ch * 8;
     const bool ok = i < CH && row < d && tk < ntok;
     // no VALU touch of the loaded chunk here (it would force a vmcnt(0) wait at the load); the transposed sources are
-    // produced by transpose_heads_kernel, which zero-fills tokens >= ntok up to the row stride, so no tail mask is needed
+    // produced by af_launch_transpose_tokens, which zero-fills tokens >= ntok up to the row stride, so no tail mask is needed
     r[j] = ok ? *reinterpret_cast<const half8_t*>(base + (size_t)row * ld + tk) : zero8;
   }
 }
@@ -395,22 +395,6 @@ int launch_bwd(const BwdArgs& a, hipStream_t s) {
   return af_check_launch("af_attention_bwd");
 }
 
-__global__ __launch_bounds__(256) void transpose_heads_kernel(const half_t* __restrict__ x, half_t* __restrict__ y, int N, int C,
-                                                              int ldx, int ldy) {
-  __shared__ half_t tile[64][66];
-  const int b = blockIdx.z, n0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  for (int rr = ty; rr < 64; rr += 4) {
-    const int n = n0 + rr, c = c0 + tx;
-    tile[rr][tx] = (n < N && c < C) ? x[((size_t)b * N + n) * ldx + c] : (half_t)0;
-  }
-  __syncthreads();
-  for (int rr = ty; rr < 64; rr += 4) {
-    const int c = c0 + rr, n = n0 + tx;
-    if (c < C && n < ldy) y[((size_t)b * C + c) * ldy + n] = n < N ? tile[tx][rr] : (half_t)0;
-  }
-}
-
 }  // namespace
 
 extern "C" int64_t af_attention_bwd_scratch_bytes(int B, int Nq, int L, int heads, int d) {
@@ -440,9 +424,9 @@ extern "C" int af_attention_bwd(const void* q, const void* k, const void* v, con
   float* delta = (float*)(((uintptr_t)(kt + (size_t)B * C * l8) + 255) & ~(uintptr_t)255);
   hipStream_t s = (hipStream_t)stream;
   AfLaunchScope scope(AF_FAM_ATTN, stream);
-  hipLaunchKernelGGL(transpose_heads_kernel, dim3((nq8 + 63) / 64, (C + 63) / 64, B), dim3(256), 0, s, (const half_t*)q, qt, Nq, C, ldq, nq8);
-  hipLaunchKernelGGL(transpose_heads_kernel, dim3((nq8 + 63) / 64, (C + 63) / 64, B), dim3(256), 0, s, (const half_t*)dout, dot, Nq, C, lddo, nq8);
-  hipLaunchKernelGGL(transpose_heads_kernel, dim3((l8 + 63) / 64, (C + 63) / 64, B), dim3(256), 0, s, (const half_t*)k, kt, L, C, ldk, l8);
+  af_launch_transpose_tokens((const half_t*)q, qt, B, Nq, C, ldq, nq8, s);          // Q^T, dO^T, K^T: [B, C, tokens] (af_bwd.hip)
+  af_launch_transpose_tokens((const half_t*)dout, dot, B, Nq, C, lddo, nq8, s);
+  af_launch_transpose_tokens((const half_t*)k, kt, B, L, C, ldk, l8, s);
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)(((long)B * heads * Nq + 255) / 256)), dim3(256), 0, s, (const half_t*)o,
                      (const half_t*)dout, delta, B, Nq, heads, d, ldo, lddo, nq64);
   BwdArgs a;

@@ -370,6 +370,43 @@ __global__ __launch_bounds__(256) void transpose_tokens_kernel(const half_t* __r
   }
 }
 
+// The same transpose with 16-byte global accesses on both sides (the scalar form above moves 2 bytes per lane: ~0.3 TB/s; the
+// weight-gradient operands and the attention backward's Q^T / K^T / dO^T make ~400 such launches per training micro-batch).
+// A 64-token x 64-channel tile: a lane loads 8 channels of one token (16 B), scatters them into the TRANSPOSED LDS tile
+// [channel][token] (row stride 68 halves: 8-byte aligned rows, the 8 chunks of a wave land on 4 bank groups -> 2-way at worst),
+// then reads 8 tokens of one channel (2 x ds_read_b64) and stores them as 16 B.  Needs C % 8 == 0, ldx % 8 == 0, ldy % 8 == 0 and
+// 16-byte aligned bases; tokens >= N are zero-filled up to ldy like the scalar form.
+constexpr int TT_ROW = 68;
+__global__ __launch_bounds__(256) void transpose_tokens_vec_kernel(const half_t* __restrict__ x, half_t* __restrict__ y, int N, int C,
+                                                                   int ldx, int ldy) {
+  __shared__ __attribute__((aligned(16))) half_t tile[64 * TT_ROW];
+  const int b = blockIdx.z, n0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int tid = threadIdx.x, ch = tid & 7, row = tid >> 3;           // load: token row (+32), channel chunk ch
+  const half8_t zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  half8_t v[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = n0 + row + 32 * j, c = c0 + ch * 8;
+    v[j] = (n < N && c < C) ? *reinterpret_cast<const half8_t*>(x + ((size_t)b * N + n) * ldx + c) : zero8;
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) tile[(ch * 8 + e) * TT_ROW + row + 32 * j] = v[j][e];
+  __syncthreads();
+  // store: channel row (+32), token chunk ch
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int c = c0 + row + 32 * j, n = n0 + ch * 8;
+    if (c < C && n < ldy) {
+      const half4_t lo = *reinterpret_cast<const half4_t*>(tile + (row + 32 * j) * TT_ROW + ch * 8);
+      const half4_t hi = *reinterpret_cast<const half4_t*>(tile + (row + 32 * j) * TT_ROW + ch * 8 + 4);
+      const half8_t o = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      *reinterpret_cast<half8_t*>(y + ((size_t)b * C + c) * ldy + n) = o;       // tokens >= N were loaded as zeros
+    }
+  }
+}
+
 // ---- cautious AdamW (ldm/c_adamw.py:65-123) over a flat fp32 parameter buffer with per-tensor segments
 struct AdamArgs {
   float* p;
@@ -505,6 +542,15 @@ inline dim3 g1(long n) { return dim3((unsigned)((n + 255) / 256)); }
 
 }  // namespace
 
+
+// [B, N, C (ldx)] -> [B, C, ldy] with the token index contiguous (tokens N .. ldy zero-filled); also used by af_attn_bwd.hip
+void af_launch_transpose_tokens(const half_t* x, half_t* y, int B, int N, int C, int ldx, int ldy, hipStream_t stream) {
+  dim3 grid((ldy + 63) / 64, (C + 63) / 64, B);
+  const bool vec = C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
+  if (vec) hipLaunchKernelGGL(transpose_tokens_vec_kernel, grid, dim3(256), 0, stream, x, y, N, C, ldx, ldy);
+  else hipLaunchKernelGGL(transpose_tokens_kernel, grid, dim3(256), 0, stream, x, y, N, C, ldx, ldy);
+}
+
 extern "C" int af_groupnorm_bwd(const void* x1, const void* x2, int c1, int c2, const void* gamma, const void* beta,
                                 const void* stats, const void* dy, const void* add, void* dx1, void* dx2, int B, int HW,
                                 int groups, int silu, void* workspace, void* stream) {
@@ -619,9 +665,7 @@ extern "C" int af_axpy_f16(const void* a, const void* b, float alpha, void* out,
 extern "C" int af_transpose_tokens(const void* x, void* y, int B, int N, int C, int ldx, int ldy, void* stream) {
   AF_REQUIRE(x && y && B > 0 && N > 0 && C > 0 && ldx >= C && ldy >= N, "af_transpose_tokens: bad argument");
   AfLaunchScope scope(AF_FAM_ELEM, stream);
-  dim3 grid((ldy + 63) / 64, (C + 63) / 64, B);
-  hipLaunchKernelGGL(transpose_tokens_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const half_t*)x, (half_t*)y, N, C,
-                     ldx, ldy);
+  af_launch_transpose_tokens((const half_t*)x, (half_t*)y, B, N, C, ldx, ldy, (hipStream_t)stream);
   return af_check_launch("af_transpose_tokens");
 }
 

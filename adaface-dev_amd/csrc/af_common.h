@@ -31,6 +31,8 @@ struct AfLaunchScope {
   ~AfLaunchScope();
 };
 int af_check_launch(const char* what);
+// af_bwd.hip: [B, N, C (row stride ldx)] -> [B, C, ldy], token index contiguous, tokens N .. ldy zero-filled (16-byte accesses when aligned)
+void af_launch_transpose_tokens(const _Float16* x, _Float16* y, int B, int N, int C, int ldx, int ldy, hipStream_t stream);
 
 #define AF_REQUIRE(cond, msg)                                      \
   do {                                                             \

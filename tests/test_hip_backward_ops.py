@@ -95,6 +95,13 @@ def test_sumpool_add_transpose(dev):
     assert tt.shape == (2, 64, 80)
     assert torch.equal(tt[:, :, :77].cpu(), t[:, 32:].reshape(2, 77, 64).permute(0, 2, 1))
     assert float(tt[:, :, 77:].abs().max()) == 0
+    # the 16-byte form (aligned views) and the scalar fallback (a view that starts 4 channels in; 12 channels) give the same bits
+    for (Bn, N, C, ld, off) in [(2, 77, 64, 96, 32), (3, 4096, 320, 960, 320), (1, 130, 40, 40, 0), (2, 200, 96, 100, 4), (2, 64, 12, 16, 0), (4, 1, 8, 8, 0)]:
+        src = rnd((Bn * N, ld), 5)
+        out = ops.transpose_tokens(src.to(dev)[:, off:], Bn, N, C, ld)
+        assert out.shape == (Bn, C, (N + 7) // 8 * 8)
+        assert torch.equal(out[:, :, :N].cpu(), src[:, off:off + C].reshape(Bn, N, C).permute(0, 2, 1)), (Bn, N, C, ld, off)
+        assert float(out[:, :, N:].abs().max()) == 0 if out.shape[2] > N else True
 
 
 def test_conv_dgrad_via_transposed_weights(dev):
