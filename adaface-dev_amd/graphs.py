@@ -12,7 +12,29 @@ the inputs, replay, and return the SAME output tensors -- consumers must be done
 holds here because a micro-batch finishes before the next begins.  Anything that changes between replays must be visible through
 fixed device addresses: parameters live in their (flat-arena) storage; derived weight packs are refreshed IN PLACE by the caller
 before a replay (``refresh`` hook)."""
+import atexit
+import weakref
+
 import torch
+
+_LIVE = weakref.WeakSet()
+
+
+def _release_all():
+    """Drop every captured graph (and the tensors of its private pool) while the HIP runtime is still up: graph objects that survive
+    until interpreter teardown are destroyed after it, which can fault."""
+    segs = list(_LIVE)
+    if not segs:
+        return
+    try:
+        torch.cuda.synchronize()
+    except Exception:                    # noqa: BLE001  (nothing to wait for if the runtime never came up)
+        pass
+    for s in segs:
+        s.entries.clear()
+
+
+atexit.register(_release_all)
 
 
 class GraphedSegment:
@@ -20,6 +42,7 @@ class GraphedSegment:
         self.name = name
         self.entries = {}          # key -> dict(state, graph, static_inputs, outputs, extra)
         self.enabled = True
+        _LIVE.add(self)
 
     def run(self, key, fn, inputs, refresh=None):
         """fn(*inputs) -> (outputs: tensor | tuple/list of tensors | nested, extra: any python object kept with the capture)."""

@@ -26,3 +26,20 @@ def rel_l2(a, b):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     return float(np.linalg.norm((a - b).ravel()) / max(np.linalg.norm(b.ravel()), 1e-30))
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """Free device objects while the HIP runtime is still up (captured graphs, cached workspaces): objects that live until
+    interpreter teardown are destroyed after the runtime."""
+    import gc
+    gc.collect()
+    try:
+        import torch
+        if torch.cuda.is_available() and torch.cuda.is_initialized():
+            from adaface_dev_amd import graphs
+            graphs._release_all()
+            gc.collect()
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+    except Exception:                    # noqa: BLE001  (teardown must never turn a green run red)
+        pass
