@@ -31,7 +31,9 @@ def wgrad(dy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     dev = dy.device
     dyt = torch.empty((N, m64), dtype=F16, device=dev)                         # the transpose zero-fills columns M..m64
     k128 = round_up(K, 128)
-    xt = (torch.empty if k128 == K else torch.zeros)((k128, m64), dtype=F16, device=dev)
+    xt = torch.empty((k128, m64), dtype=F16, device=dev)
+    if k128 != K:
+        xt[K:].zero_()                                                         # only the pad rows (the packed-weight layout wants 128-row multiples)
     L = _lib.lib()
     _lib.check(L.af_transpose_tokens(ops._p(dy), ops._p(dyt), 1, M, N, N, m64, ops._stream()), "af_transpose_tokens")
     _lib.check(L.af_transpose_tokens(ops._p(x), ops._p(xt), 1, M, K, K, m64, ops._stream()), "af_transpose_tokens")
