@@ -75,9 +75,34 @@ class CLIPAttentionMKV(nn.Module):
                 dst.weight.data = src.weight.data.reshape(divisor, -1, src.weight.shape[1]).mean(dim=0)
                 dst.out_features = dst.weight.shape[0]
 
+    # ---- multiplier-1 layers run q | k | v as ONE GEMM on the concatenated weights (packs rebuilt when a parameter changes)
+    def _qkv_params(self):
+        return (self.q_proj.weight, self.k_proj.weight, self.v_proj.weight, self.q_proj.bias, self.k_proj.bias, self.v_proj.bias)
+
+    def qkv_packed(self):
+        from ..ldm.modules.diffusionmodules.util import _PackCache
+        if not hasattr(self, "_cache"):
+            self._cache = _PackCache()
+        ps = self._qkv_params()
+        return self._cache.get(ps, lambda: ops.pack_matrix(torch.cat([p.detach() for p in ps[:3]], 0), torch.cat([p.detach() for p in ps[3:]], 0),
+                                                           ps[0].device))
+
+    def qkv_packed_bwd(self):
+        from ..ldm.modules.diffusionmodules.util import _PackCache
+        if not hasattr(self, "_cache_bwd"):
+            self._cache_bwd = _PackCache()
+        ps = self._qkv_params()[:3]
+        return self._cache_bwd.get(ps, lambda: ops.pack_matrix(torch.cat([p.detach() for p in ps], 0).t().contiguous(), None, ps[0].device))
+
     def hip(self, x2d, B, T, residual=None, causal=True):
         """x2d [B*T, E] fp16 -> [B*T, E] (+ residual)."""
         E, m = self.embed_dim, self.multiplier
+        if m == 1:
+            qkv = ops.gemm(x2d, self.qkv_packed())
+            vt = ops.transpose_tokens(qkv[:, 2 * E:], B, T, E, 3 * E)
+            o = ops.attention(qkv[:, :E], qkv[:, E:2 * E], vt, B=B, Nq=T, L=T, heads=self.num_heads, d=self.head_dim, ldq=3 * E, ldk=3 * E,
+                              scale=self.scale, causal_m=1 if causal else 0)
+            return self.out_proj.hip(o, residual=residual)
         q = self.q_proj.hip(x2d)
         k = self.k_proj.hip(x2d).reshape(B * T * m, E)          # [B, T, m*E] rows ARE [B, T*m, E] key rows
         v = self.v_proj.hip(x2d).reshape(B * T * m, E)
@@ -89,6 +114,10 @@ class CLIPAttentionMKV(nn.Module):
     def hip_autograd(self, x2d, B, T, residual=None, causal=True):
         """Same as `hip`, built from autograd nodes so the projection weights receive gradients."""
         E, m = self.embed_dim, self.multiplier
+        if m == 1:
+            qkv = ag.QKVLinearFn.apply(x2d, *self._qkv_params(), self)
+            o = ag.AttentionQKVFn.apply(qkv, B, T, self.num_heads, self.scale, causal)
+            return ag.linear(self.out_proj, o, residual=residual)
         q = ag.linear(self.q_proj, x2d)
         k = ag.linear(self.k_proj, x2d).reshape(B * T * m, E)
         v = ag.linear(self.v_proj, x2d).reshape(B * T * m, E)

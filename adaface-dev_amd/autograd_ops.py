@@ -122,6 +122,64 @@ class AttentionFn(torch.autograd.Function):
         return dq, dk, dv, None, None, None, None, None, None
 
 
+class QKVLinearFn(torch.autograd.Function):
+    """q | k | v projections of one attention layer as ONE GEMM on the concatenated weights ([3E, E]; multiplier-1 layers): forward one
+    launch instead of three; backward one input-gradient GEMM (instead of three and two adds), one weight-gradient GEMM over ONE pair
+    of transposed operands, one column sum.  Returns qkv [M, 3E]; the gradients are handed back per projection as views."""
+
+    @staticmethod
+    def forward(ctx, x, wq, wk, wv, bq, bk, bv, attn):
+        ctx.save_for_backward(x)
+        ctx.attn = attn
+        return ops.gemm(x, attn.qkv_packed())
+
+    @staticmethod
+    def backward(ctx, dqkv):
+        x, = ctx.saved_tensors
+        attn = ctx.attn
+        dqkv = dqkv.contiguous()
+        need = ctx.needs_input_grad
+        E = attn.embed_dim
+        dx = ops.gemm(dqkv, attn.qkv_packed_bwd()) if need[0] else None
+        dws = [None, None, None]
+        if any(need[1:4]):
+            dw = wgrad(dqkv, x)                                   # [3E, E] fp32
+            dws = [dw[i * E:(i + 1) * E] if need[1 + i] else None for i in range(3)]
+        dbs = [None, None, None]
+        if any(need[4:7]):
+            db = ops.colsum(dqkv)
+            dbs = [db[i * E:(i + 1) * E] if need[4 + i] else None for i in range(3)]
+        return (dx, *dws, *dbs, None)
+
+
+class AttentionQKVFn(torch.autograd.Function):
+    """Causal flash attention on a packed qkv [B*T, 3E] (q | k | v column blocks, row stride 3E) -> [B*T, E]; the backward writes
+    dq | dk | dv straight into the column blocks of one [B*T, 3E] gradient."""
+
+    @staticmethod
+    def forward(ctx, qkv, B, T, heads, scale, causal):
+        E = qkv.shape[1] // 3
+        d = E // heads
+        q, k, v = qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:]
+        vt = ops.transpose_tokens(v, B, T, E, 3 * E)
+        o, lse = ops.attention(q, k, vt, B=B, Nq=T, L=T, heads=heads, d=d, ldq=3 * E, ldk=3 * E, scale=scale, want_lse=True,
+                               causal_m=1 if causal else 0)
+        ctx.save_for_backward(qkv, o, lse)
+        ctx.cfg = (B, T, heads, d, scale, causal)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        qkv, o, lse = ctx.saved_tensors
+        B, T, heads, d, scale, causal = ctx.cfg
+        E = heads * d
+        dqkv = torch.empty_like(qkv)
+        ops.attention_bwd(qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], o, do.contiguous(), lse, B=B, Nq=T, L=T, heads=heads, d=d,
+                          ldq=3 * E, ldk=3 * E, ldv=3 * E, dq=dqkv[:, :E], dk=dqkv[:, E:2 * E], dv=dqkv[:, 2 * E:], lddq=3 * E, lddk=3 * E,
+                          lddv=3 * E, scale=scale, causal_m=1 if causal else 0)
+        return dqkv, None, None, None, None, None
+
+
 def linear(mod, x, residual=None):
     return LinearFn.apply(x, mod.weight, mod.bias, residual, mod)
 
