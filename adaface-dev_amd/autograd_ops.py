@@ -77,11 +77,16 @@ class LayerNormFn(torch.autograd.Function):
         need = ctx.needs_input_grad
         dx = ops.layernorm_bwd(x, g32, dy, ctx.eps) if need[0] else None
         dg = db = None
-        if need[1]:
-            xhat = ops.layernorm(x, torch.ones_like(g32), torch.zeros_like(g32), ctx.eps)
-            dg = ops.colsum(dy, xhat).to(ctx.pdtype)
-        if need[2]:
-            db = ops.colsum(dy).to(ctx.pdtype)
+        if (need[1] or need[2]) and x.numel() // x.shape[-1] <= 2048:
+            dg, db = ops.layernorm_param_grads(x, dy, ctx.eps)               # one launch (af_layernorm_param_grads)
+            dg = dg.to(ctx.pdtype) if need[1] else None
+            db = db.to(ctx.pdtype) if need[2] else None
+        else:
+            if need[1]:
+                xhat = ops.layernorm(x, torch.ones_like(g32), torch.zeros_like(g32), ctx.eps)
+                dg = ops.colsum(dy, xhat).to(ctx.pdtype)
+            if need[2]:
+                db = ops.colsum(dy).to(ctx.pdtype)
         return dx, dg, db, None
 
 

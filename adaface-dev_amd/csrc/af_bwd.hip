@@ -588,6 +588,92 @@ __global__ __launch_bounds__(256) void scale_f32_kernel(float* __restrict__ a, f
 
 inline dim3 g1(long n) { return dim3((unsigned)((n + 255) / 256)); }
 
+
+// LayerNorm parameter gradients in ONE launch: dgamma[c] = sum_r dy[r,c] * xhat[r,c], dbeta[c] = sum_r dy[r,c], xhat = (x - mean_r) * rstd_r.
+// A workgroup owns 64 columns; it first recomputes every row's (mean, rstd) into LDS (a wave per row, exact two-pass variance as in
+// layernorm_kernel: for the few hundred token rows of the CLIP encoders re-reading x once per column block costs nothing), then its
+// 8 chunk lanes x 32 row lanes fold the rows with 16-byte loads, four rows in flight.  Replaces: two fills, a LayerNorm pass for
+// xhat and two column-sum launches per trainable LayerNorm.
+constexpr int LNPG_MAX_ROWS = 2048;
+__global__ __launch_bounds__(256) void ln_param_grads_kernel(const half_t* __restrict__ x, const half_t* __restrict__ dy,
+                                                             float* __restrict__ dgamma, float* __restrict__ dbeta, int rows, int C, float eps) {
+  extern __shared__ __attribute__((aligned(16))) char af_smem[];
+  float* st = reinterpret_cast<float*>(af_smem);            // [rows][2]
+  float* red = st + 2 * rows;                               // [2][32][65]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nch = C >> 3;
+  for (int r = wave; r < rows; r += 4) {
+    const half_t* xr = x + (size_t)r * C;
+    float s = 0.f;
+    for (int ch = lane; ch < nch; ch += 64) {
+      const half8_t v = *reinterpret_cast<const half8_t*>(xr + ch * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += (float)v[e];
+    }
+    const float mean = af_wave_sum(s) / (float)C;
+    float q = 0.f;
+    for (int ch = lane; ch < nch; ch += 64) {
+      const half8_t v = *reinterpret_cast<const half8_t*>(xr + ch * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float dlt = (float)v[e] - mean;
+        q += dlt * dlt;
+      }
+    }
+    const float var = af_wave_sum(q) / (float)C;
+    if (lane == 0) {
+      st[2 * r] = mean;
+      st[2 * r + 1] = rsqrtf(var + eps);
+    }
+  }
+  __syncthreads();
+  const int ch = tid & 7, rl = tid >> 3;
+  const int c = blockIdx.x * 64 + ch * 8;
+  float sg[8], sb[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) sg[e] = sb[e] = 0.f;
+  if (c < C) {
+    for (int r = rl; r < rows; r += 128) {
+      half8_t xv[4], dv[4];
+      float mu[4], rs[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int rr = r + 32 * u;
+        const bool ok = rr < rows;
+        const int rc = ok ? rr : 0;
+        xv[u] = *reinterpret_cast<const half8_t*>(x + (size_t)rc * C + c);
+        dv[u] = ok ? *reinterpret_cast<const half8_t*>(dy + (size_t)rc * C + c) : half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+        mu[u] = st[2 * rc];
+        rs[u] = st[2 * rc + 1];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float d = (float)dv[u][e];
+          sg[e] += d * ((float)xv[u][e] - mu[u]) * rs[u];
+          sb[e] += d;
+        }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    red[rl * 65 + ch * 8 + e] = sg[e];
+    red[32 * 65 + rl * 65 + ch * 8 + e] = sb[e];
+  }
+  __syncthreads();
+  if (tid < 128) {
+    const int which = tid >> 6, col = tid & 63;
+    const int cc = blockIdx.x * 64 + col;
+    if (cc < C) {
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < 32; ++k) t += red[which * 32 * 65 + k * 65 + col];
+      (which ? dbeta : dgamma)[cc] = t;
+    }
+  }
+}
+
 }  // namespace
 
 
@@ -804,4 +890,15 @@ extern "C" int af_scale_f32(void* a, float s, int64_t n, void* stream) {
   AfLaunchScope scope(AF_FAM_ELEM, stream);
   hipLaunchKernelGGL(scale_f32_kernel, g1(n), dim3(256), 0, (hipStream_t)stream, (float*)a, s, (long)n);
   return af_check_launch("af_scale_f32");
+}
+
+extern "C" int af_layernorm_param_grads(const void* x, const void* dy, void* dgamma, void* dbeta, int rows, int C, float eps, void* stream) {
+  AF_REQUIRE(x && dy && dgamma && dbeta, "af_layernorm_param_grads: null pointer");
+  AF_REQUIRE(rows > 0 && C > 0 && C % 8 == 0, "af_layernorm_param_grads: C must be a positive multiple of 8");
+  AF_SUPPORTED(rows <= LNPG_MAX_ROWS, "af_layernorm_param_grads: more than 2048 rows (use the column-sum path)");
+  AfLaunchScope scope(AF_FAM_LNORM, stream);
+  const size_t lds = ((size_t)2 * rows + 2 * 32 * 65) * sizeof(float);
+  hipLaunchKernelGGL(ln_param_grads_kernel, dim3((C + 63) / 64), dim3(256), lds, (hipStream_t)stream, (const half_t*)x, (const half_t*)dy,
+                     (float*)dgamma, (float*)dbeta, rows, C, eps);
+  return af_check_launch("af_layernorm_param_grads");
 }

@@ -513,6 +513,16 @@ def layernorm_bwd(x, gamma, dy, eps=1e-5, add=None):
     return dx
 
 
+def layernorm_param_grads(x, dy, eps=1e-5):
+    """(dgamma, dbeta) fp32 [C] of a LayerNorm over the last dim from its input and output gradient, one launch (rows <= 2048)."""
+    Cn = x.shape[-1]
+    dg = torch.empty((Cn,), dtype=torch.float32, device=x.device)
+    db = torch.empty_like(dg)
+    _lib.check(_lib.lib().af_layernorm_param_grads(_p(x), _p(dy), _p(dg), _p(db), x.numel() // Cn, Cn, float(eps), _stream()),
+               "af_layernorm_param_grads")
+    return dg, db
+
+
 def geglu_fwd(hp):
     M, two_i = hp.shape
     out = torch.empty((M, two_i // 2), dtype=F16, device=hp.device)

@@ -63,6 +63,18 @@ def test_layernorm_bwd(dev, rows, C):
     assert rel_l2(dx.float().cpu().numpy(), (xr.grad + add.float()).numpy()) < TOL
 
 
+@pytest.mark.parametrize("rows,C", [(77, 320), (300, 640), (388, 768), (2048, 1280), (5, 8), (1, 64)])
+def test_layernorm_param_grads_one_launch(dev, rows, C):
+    """af_layernorm_param_grads: dgamma / dbeta of a LayerNorm from (x, dy) against torch autograd in fp32."""
+    from adaface_dev_amd import ops
+    x, dy = rnd((rows, C), 1, 2.0) + 0.5, rnd((rows, C), 2)
+    dg, db = ops.layernorm_param_grads(x.to(dev), dy.to(dev), 1e-5)
+    g = torch.ones(C, requires_grad=True)
+    b = torch.zeros(C, requires_grad=True)
+    F.layer_norm(x.float(), (C,), g, b, 1e-5).backward(dy.float())
+    assert rel_l2(dg.cpu().numpy(), g.grad.numpy()) < 1e-4 and rel_l2(db.cpu().numpy(), b.grad.numpy()) < 1e-5
+
+
 def test_geglu_fwd_bwd(dev):
     from adaface_dev_amd import ops
     M, I = 200, 128
