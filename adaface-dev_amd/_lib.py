@@ -156,7 +156,7 @@ def lib() -> C.CDLL:
     L.af_se_residual_prelu.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp]
     L.af_groupnorm_bwd.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]
     L.af_layernorm_bwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, f32, vp]
-    L.af_layernorm_param_grads.argtypes = [vp, vp, vp, vp, i32, i32, f32, vp]
+    L.af_layernorm_param_grads.argtypes = [vp, vp, vp, vp, vp, i32, i32, f32, vp]
     L.af_geglu_fwd.argtypes = [vp, vp, i64, i32, vp]
     L.af_geglu_bwd.argtypes = [vp, vp, vp, i64, i32, vp]
     L.af_sumpool2x2.argtypes = [vp, vp, i32, i32, i32, i32, vp]

@@ -77,8 +77,8 @@ class LayerNormFn(torch.autograd.Function):
         need = ctx.needs_input_grad
         dx = ops.layernorm_bwd(x, g32, dy, ctx.eps) if need[0] else None
         dg = db = None
-        if (need[1] or need[2]) and x.numel() // x.shape[-1] <= 2048:
-            dg, db = ops.layernorm_param_grads(x, dy, ctx.eps)               # one launch (af_layernorm_param_grads)
+        if (need[1] or need[2]) and x.numel() // x.shape[-1] <= 2048 and x.shape[-1] <= 1536:
+            dg, db = ops.layernorm_param_grads(x, dy, ctx.eps)               # row statistics + one column pass (af_layernorm_param_grads)
             dg = dg.to(ctx.pdtype) if need[1] else None
             db = db.to(ctx.pdtype) if need[2] else None
         else:

@@ -514,11 +514,12 @@ def layernorm_bwd(x, gamma, dy, eps=1e-5, add=None):
 
 
 def layernorm_param_grads(x, dy, eps=1e-5):
-    """(dgamma, dbeta) fp32 [C] of a LayerNorm over the last dim from its input and output gradient, one launch (rows <= 2048)."""
+    """(dgamma, dbeta) fp32 [C] of a LayerNorm over the last dim from its input and output gradient (rows <= 2048, C <= 1536)."""
     Cn = x.shape[-1]
-    dg = torch.empty((Cn,), dtype=torch.float32, device=x.device)
-    db = torch.empty_like(dg)
-    _lib.check(_lib.lib().af_layernorm_param_grads(_p(x), _p(dy), _p(dg), _p(db), x.numel() // Cn, Cn, float(eps), _stream()),
+    rows = x.numel() // Cn
+    out = torch.empty((2 * Cn + 2 * rows,), dtype=torch.float32, device=x.device)        # dgamma | dbeta | row statistics scratch
+    dg, db, st = out[:Cn], out[Cn:2 * Cn], out[2 * Cn:]
+    _lib.check(_lib.lib().af_layernorm_param_grads(_p(x), _p(dy), _p(dg), _p(db), _p(st), rows, Cn, float(eps), _stream()),
                "af_layernorm_param_grads")
     return dg, db
 

@@ -249,9 +249,11 @@ int af_silu_f16(const void* x, void* y, int64_t n, void* stream);
 int af_groupnorm_bwd(const void* x1, const void* x2, int c1, int c2, const void* gamma, const void* beta,
                      const void* stats, const void* dy, const void* add, void* dx1, void* dx2, int B, int HW,
                      int groups, int silu, void* workspace, void* stream);
-/* LayerNorm parameter gradients in one launch (the trainable LayerNorms of the CLIP encoders, subj_basis_generator.py:841-853):
- * dgamma[c] = sum_r dy[r,c] * (x[r,c] - mean_r) * rstd_r, dbeta[c] = sum_r dy[r,c]; x, dy fp16 [rows, C], outputs fp32 [C]; rows <= 2048 */
-int af_layernorm_param_grads(const void* x, const void* dy, void* dgamma, void* dbeta, int rows, int C, float eps, void* stream);
+/* LayerNorm parameter gradients (the trainable LayerNorms of the CLIP encoders, subj_basis_generator.py:841-853): dgamma[c] =
+ * sum_r dy[r,c] * (x[r,c] - mean_r) * rstd_r, dbeta[c] = sum_r dy[r,c]; x, dy fp16 [rows, C], outputs fp32 [C]; row_stats: caller-owned
+ * fp32 scratch [rows][2] (mean, rstd: written by the first of the two launches); rows <= 2048, C <= 1536 */
+int af_layernorm_param_grads(const void* x, const void* dy, void* dgamma, void* dbeta, void* row_stats, int rows, int C, float eps,
+                             void* stream);
 /* LayerNorm input gradient (+ optional `add`) */
 int af_layernorm_bwd(const void* x, const void* gamma, const void* dy, const void* add, void* dx, int rows, int C,
                      float eps, void* stream);

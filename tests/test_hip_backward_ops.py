@@ -64,7 +64,7 @@ def test_layernorm_bwd(dev, rows, C):
 
 
 @pytest.mark.parametrize("rows,C", [(77, 320), (300, 640), (388, 768), (2048, 1280), (5, 8), (1, 64)])
-def test_layernorm_param_grads_one_launch(dev, rows, C):
+def test_layernorm_param_grads(dev, rows, C):
     """af_layernorm_param_grads: dgamma / dbeta of a LayerNorm from (x, dy) against torch autograd in fp32."""
     from adaface_dev_amd import ops
     x, dy = rnd((rows, C), 1, 2.0) + 0.5, rnd((rows, C), 2)
