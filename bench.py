@@ -16,7 +16,9 @@ JSON line and exits with its code.  Inference has no exchange step: 
 `value` = N*K steps / max-over-ranks time.  The same JSON line carries a `train` object: the Stage-1 distillation
 micro-batch (BASELINE configs[2]/[3], reference main.py:618, 911-915) on the same ranks, data parallel with the bucketed
 RCCL gradient all-reduce overlapped with the backward -- `train.value` (images/s) at N = 1 and N = 8 is what north_star's
-">= 6x training images/s" is read from.  `--mode denoise` / `--mode train` run one leg only.
+">= 6x training images/s" is read from -- and a `train_stage2` object: the compositional-distillation micro-batch (configs[4]).
+`--mode denoise` / `--mode train` / `--mode train2` run one leg only.  Defaults: 10 warm-up + 100 timed denoise steps (two whole
+50-step samplings), 12 + 12 micro-batches per training leg; ~45 s in all on one MI355X (wall time per leg is printed on stderr).
 
 The JSON line carries, besides the driver contract:
   roofline     -- dominant kernel family (the MFMA GEMM / implicit-conv template): algorithmic
