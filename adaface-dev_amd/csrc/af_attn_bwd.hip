@@ -17,6 +17,8 @@
 // global loads are issued right after, and ONE workgroup barrier separates stages.
 #include <float.h>
 
+#include <type_traits>
+
 #include "af_common.h"
 
 namespace {
@@ -211,21 +213,31 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(BwdArgs a) {
       pT = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, gf[s], pT, 0, 0, 0);
     }
     half8_t zf[2];
+    // a stage whose 32 keys all exist and are all visible needs no per-element test (32 v_cndmask + compares per stage: the loop is
+    // VALU-bound); keys past L only occur in the last stage, the causal test only in the CLIP encoders
+    auto softmax_block = [&](auto masked_c) {
+      constexpr bool MASKED = decltype(masked_c)::value;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int kk = key0 + 8 * g + 4 * hh;
-      floatx4 bias = {0.f, 0.f, 0.f, 0.f};
-      if (a.kbias) bias = *reinterpret_cast<const floatx4*>(a.kbias + (size_t)b * a.ldb + kk);
+      for (int g = 0; g < 4; ++g) {
+        const int kk = key0 + 8 * g + 4 * hh;
+        floatx4 bias = {0.f, 0.f, 0.f, 0.f};
+        if (a.kbias) bias = *reinterpret_cast<const floatx4*>(a.kbias + (size_t)b * a.ldb + kk);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int i = 4 * g + e;
-        const float t = sT[i] * a.c + bias[e];
-        bool vis = kk + e < a.L;
-        if (a.causal_m > 0) vis = vis && ((kk + e) / a.causal_m <= query);
-        const float p = vis ? __builtin_amdgcn_exp2f(t - lse) : 0.f;
-        zf[i >> 3][i & 7] = (half_t)(p * (pT[i] - delta));
+        for (int e = 0; e < 4; ++e) {
+          const int i = 4 * g + e;
+          const float t = sT[i] * a.c + bias[e];
+          float p = __builtin_amdgcn_exp2f(t - lse);
+          if (MASKED) {
+            bool vis = kk + e < a.L;
+            if (a.causal_m > 0) vis = vis && ((kk + e) / a.causal_m <= query);
+            p = vis ? p : 0.f;
+          }
+          zf[i >> 3][i & 7] = (half_t)(p * (pT[i] - delta));
+        }
       }
-    }
+    };
+    if (a.causal_m > 0 || key0 + 32 > a.L) softmax_block(std::true_type{});
+    else softmax_block(std::false_type{});
 #pragma unroll
     for (int t = 0; t < DT; ++t)
 #pragma unroll
@@ -336,22 +348,35 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(BwdArgs a) {
       dp = __builtin_amdgcn_mfma_f32_32x32x16_f16(ga, vf[ks], dp, 0, 0, 0);
     }
     half8_t pf[2], zf[2];
+    // a stage whose 32 queries all exist needs no per-element test when nothing is causal (the loop is VALU-bound: 32 v_cndmask +
+    // compares per stage): lanes of keys past L then carry finite junk in accumulators that are never stored
+    auto softmax_block = [&](auto masked_c) {
+      constexpr bool MASKED = decltype(masked_c)::value;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int qq = q0 + 8 * g + 4 * hh;  // queries qq .. qq+3 live in regs 4g .. 4g+3 (nqpad covers the overrun)
-      const floatx4 lse = *reinterpret_cast<const floatx4*>(lseb + qq);
-      const floatx4 del = *reinterpret_cast<const floatx4*>(delb + qq);
+      for (int g = 0; g < 4; ++g) {
+        const int qq = q0 + 8 * g + 4 * hh;  // queries qq .. qq+3 live in regs 4g .. 4g+3 (nqpad covers the overrun)
+        const floatx4 lse = *reinterpret_cast<const floatx4*>(lseb + qq);
+        const floatx4 del = *reinterpret_cast<const floatx4*>(delb + qq);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int i = 4 * g + e;
-        const float t = s[i] * a.c + kbias;
-        bool ok = key_ok && qq + e < a.Nq;   // padding rows of lse/delta may hold anything: select, never multiply
-        if (a.causal_m > 0) ok = ok && (key / a.causal_m <= qq + e);
-        const float p = ok ? __builtin_amdgcn_exp2f(t - lse[e]) : 0.f;
-        pf[i >> 3][i & 7] = (half_t)p;
-        zf[i >> 3][i & 7] = (half_t)(ok ? p * (dp[i] - del[e]) : 0.f);
+        for (int e = 0; e < 4; ++e) {
+          const int i = 4 * g + e;
+          const float t = s[i] * a.c + kbias;
+          if (MASKED) {
+            bool ok = key_ok && qq + e < a.Nq;   // padding rows of lse/delta may hold anything: select, never multiply
+            if (a.causal_m > 0) ok = ok && (key / a.causal_m <= qq + e);
+            const float p = ok ? __builtin_amdgcn_exp2f(t - lse[e]) : 0.f;
+            pf[i >> 3][i & 7] = (half_t)p;
+            zf[i >> 3][i & 7] = (half_t)(ok ? p * (dp[i] - del[e]) : 0.f);
+          } else {
+            const float p = __builtin_amdgcn_exp2f(t - lse[e]);
+            pf[i >> 3][i & 7] = (half_t)p;
+            zf[i >> 3][i & 7] = (half_t)(p * (dp[i] - del[e]));
+          }
+        }
       }
-    }
+    };
+    if (a.causal_m > 0 || q0 + 32 > a.Nq) softmax_block(std::true_type{});
+    else softmax_block(std::false_type{});
 #pragma unroll
     for (int t = 0; t < DT; ++t)
 #pragma unroll
