@@ -35,8 +35,8 @@ def wgrad(dy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     if k128 != K:
         xt[K:].zero_()                                                         # only the pad rows (the packed-weight layout wants 128-row multiples)
     L = _lib.lib()
-    _lib.check(L.af_transpose_tokens(ops._p(dy), ops._p(dyt), 1, M, N, N, m64, ops._stream()), "af_transpose_tokens")
-    _lib.check(L.af_transpose_tokens(ops._p(x), ops._p(xt), 1, M, K, K, m64, ops._stream()), "af_transpose_tokens")
+    _lib.check(L.af_transpose_tokens_pair(ops._p(dy), ops._p(dyt), N, N, ops._p(x), ops._p(xt), K, K, 1, M, m64, ops._stream()),
+               "af_transpose_tokens_pair")                                     # both operands in one launch
     pw = ops.PackedWeight(xt, None, K, m64, m64, 1, m64)
     return ops.gemm(dyt, pw, out_f32=True)
 

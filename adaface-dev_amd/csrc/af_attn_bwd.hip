@@ -449,9 +449,9 @@ extern "C" int af_attention_bwd(const void* q, const void* k, const void* v, con
   float* delta = (float*)(((uintptr_t)(kt + (size_t)B * C * l8) + 255) & ~(uintptr_t)255);
   hipStream_t s = (hipStream_t)stream;
   AfLaunchScope scope(AF_FAM_ATTN, stream);
-  af_launch_transpose_tokens((const half_t*)q, qt, B, Nq, C, ldq, nq8, s);          // Q^T, dO^T, K^T: [B, C, tokens] (af_bwd.hip)
-  af_launch_transpose_tokens((const half_t*)dout, dot, B, Nq, C, lddo, nq8, s);
-  af_launch_transpose_tokens((const half_t*)k, kt, B, L, C, ldk, l8, s);
+  const AfTransposeJob jobs[3] = {{(const half_t*)q, qt, Nq, C, ldq, nq8}, {(const half_t*)dout, dot, Nq, C, lddo, nq8},
+                                  {(const half_t*)k, kt, L, C, ldk, l8}};
+  af_launch_transpose_tokens_multi(jobs, 3, B, s);                                   // Q^T, dO^T, K^T: [B, C, tokens], one launch (af_bwd.hip)
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)(((long)B * heads * Nq + 255) / 256)), dim3(256), 0, s, (const half_t*)o,
                      (const half_t*)dout, delta, B, Nq, heads, d, ldo, lddo, nq64);
   BwdArgs a;

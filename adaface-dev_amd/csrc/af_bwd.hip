@@ -377,10 +377,8 @@ __global__ __launch_bounds__(256) void transpose_tokens_kernel(const half_t* __r
 // then reads 8 tokens of one channel (2 x ds_read_b64) and stores them as 16 B.  Needs C % 8 == 0, ldx % 8 == 0, ldy % 8 == 0 and
 // 16-byte aligned bases; tokens >= N are zero-filled up to ldy like the scalar form.
 constexpr int TT_ROW = 68;
-__global__ __launch_bounds__(256) void transpose_tokens_vec_kernel(const half_t* __restrict__ x, half_t* __restrict__ y, int N, int C,
-                                                                   int ldx, int ldy) {
-  __shared__ __attribute__((aligned(16))) half_t tile[64 * TT_ROW];
-  const int b = blockIdx.z, n0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+__device__ __forceinline__ void transpose_tile_vec(const half_t* __restrict__ x, half_t* __restrict__ y, int N, int C, int ldx, int ldy,
+                                                   int b, int n0, int c0, half_t* tile) {
   const int tid = threadIdx.x, ch = tid & 7, row = tid >> 3;           // load: token row (+32), channel chunk ch
   const half8_t zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
   half8_t v[2];
@@ -405,6 +403,41 @@ __global__ __launch_bounds__(256) void transpose_tokens_vec_kernel(const half_t*
       *reinterpret_cast<half8_t*>(y + ((size_t)b * C + c) * ldy + n) = o;       // tokens >= N were loaded as zeros
     }
   }
+}
+
+__global__ __launch_bounds__(256) void transpose_tokens_vec_kernel(const half_t* __restrict__ x, half_t* __restrict__ y, int N, int C,
+                                                                   int ldx, int ldy) {
+  __shared__ __attribute__((aligned(16))) half_t tile[64 * TT_ROW];
+  transpose_tile_vec(x, y, N, C, ldx, ldy, blockIdx.z, blockIdx.x * 64, blockIdx.y * 64, tile);
+}
+
+// up to three transposes of one batch in ONE launch (the attention backward's Q^T / dO^T / K^T, a weight gradient's two operands):
+// blockIdx.x walks the tiles of the descriptors one after the other
+struct TrDesc {
+  const half_t* x;
+  half_t* y;
+  int N, C, ldx, ldy, tiles_n, tile_end;      // tile_end: first linear tile index past this descriptor
+};
+struct TrDescs {
+  TrDesc d[3];
+  int n;
+};
+__global__ __launch_bounds__(256) void transpose_tokens_multi_kernel(TrDescs ds) {
+  __shared__ __attribute__((aligned(16))) half_t tile[64 * TT_ROW];
+  int k = 0, first = 0;
+  const int bid = blockIdx.x;
+  if (ds.n > 1 && bid >= ds.d[0].tile_end) {
+    k = 1;
+    first = ds.d[0].tile_end;
+    if (ds.n > 2 && bid >= ds.d[1].tile_end) {
+      k = 2;
+      first = ds.d[1].tile_end;
+    }
+  }
+  const TrDesc d = ds.d[k];
+  const int t = bid - first;
+  const int tc = t / d.tiles_n, tn = t - tc * d.tiles_n;
+  transpose_tile_vec(d.x, d.y, d.N, d.C, d.ldx, d.ldy, blockIdx.y, tn * 64, tc * 64, tile);
 }
 
 // ---- cautious AdamW (ldm/c_adamw.py:65-123) over a flat fp32 parameter buffer with per-tensor segments
@@ -686,11 +719,38 @@ __global__ __launch_bounds__(256) void ln_param_grads_kernel(const half_t* __res
 
 
 // [B, N, C (ldx)] -> [B, C, ldy] with the token index contiguous (tokens N .. ldy zero-filled); also used by af_attn_bwd.hip
+static bool transpose_vec_ok(const half_t* x, const half_t* y, int C, int ldx, int ldy) {
+  return C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
+}
 void af_launch_transpose_tokens(const half_t* x, half_t* y, int B, int N, int C, int ldx, int ldy, hipStream_t stream) {
   dim3 grid((ldy + 63) / 64, (C + 63) / 64, B);
-  const bool vec = C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
-  if (vec) hipLaunchKernelGGL(transpose_tokens_vec_kernel, grid, dim3(256), 0, stream, x, y, N, C, ldx, ldy);
+  if (transpose_vec_ok(x, y, C, ldx, ldy)) hipLaunchKernelGGL(transpose_tokens_vec_kernel, grid, dim3(256), 0, stream, x, y, N, C, ldx, ldy);
   else hipLaunchKernelGGL(transpose_tokens_kernel, grid, dim3(256), 0, stream, x, y, N, C, ldx, ldy);
+}
+// n <= 3 transposes of the same batch count: one launch when every one qualifies for the 16-byte form, separate launches otherwise
+void af_launch_transpose_tokens_multi(const AfTransposeJob* jobs, int n, int B, hipStream_t stream) {
+  bool vec = n >= 1 && n <= 3;
+  for (int i = 0; vec && i < n; ++i) vec = transpose_vec_ok(jobs[i].x, jobs[i].y, jobs[i].C, jobs[i].ldx, jobs[i].ldy);
+  if (!vec || n == 1) {
+    for (int i = 0; i < n; ++i) af_launch_transpose_tokens(jobs[i].x, jobs[i].y, B, jobs[i].N, jobs[i].C, jobs[i].ldx, jobs[i].ldy, stream);
+    return;
+  }
+  TrDescs ds;
+  ds.n = n;
+  int total = 0;
+  for (int i = 0; i < n; ++i) {
+    TrDesc& d = ds.d[i];
+    d.x = jobs[i].x;
+    d.y = jobs[i].y;
+    d.N = jobs[i].N;
+    d.C = jobs[i].C;
+    d.ldx = jobs[i].ldx;
+    d.ldy = jobs[i].ldy;
+    d.tiles_n = (jobs[i].ldy + 63) / 64;
+    total += d.tiles_n * ((jobs[i].C + 63) / 64);
+    d.tile_end = total;
+  }
+  hipLaunchKernelGGL(transpose_tokens_multi_kernel, dim3(total, B), dim3(256), 0, stream, ds);
 }
 
 extern "C" int af_groupnorm_bwd(const void* x1, const void* x2, int c1, int c2, const void* gamma, const void* beta,
@@ -917,4 +977,14 @@ extern "C" int af_layernorm_param_grads(const void* x, const void* dy, void* dga
   hipLaunchKernelGGL(ln_param_grads_kernel, dim3((C + 63) / 64), blk, 0, s, xx, (const half_t*)dy, (const float*)st, (float*)dgamma,
                      (float*)dbeta, rows, C);
   return af_check_launch("af_layernorm_param_grads");
+}
+
+extern "C" int af_transpose_tokens_pair(const void* x1, void* y1, int C1, int ldx1, const void* x2, void* y2, int C2, int ldx2, int B, int N,
+                                        int ldy, void* stream) {
+  AF_REQUIRE(x1 && y1 && x2 && y2 && B > 0 && N > 0 && C1 > 0 && C2 > 0 && ldx1 >= C1 && ldx2 >= C2 && ldy >= N,
+             "af_transpose_tokens_pair: bad argument");
+  AfLaunchScope scope(AF_FAM_ELEM, stream);
+  const AfTransposeJob jobs[2] = {{(const half_t*)x1, (half_t*)y1, N, C1, ldx1, ldy}, {(const half_t*)x2, (half_t*)y2, N, C2, ldx2, ldy}};
+  af_launch_transpose_tokens_multi(jobs, 2, B, (hipStream_t)stream);
+  return af_check_launch("af_transpose_tokens_pair");
 }

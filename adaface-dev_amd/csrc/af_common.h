@@ -33,6 +33,13 @@ struct AfLaunchScope {
 int af_check_launch(const char* what);
 // af_bwd.hip: [B, N, C (row stride ldx)] -> [B, C, ldy], token index contiguous, tokens N .. ldy zero-filled (16-byte accesses when aligned)
 void af_launch_transpose_tokens(const _Float16* x, _Float16* y, int B, int N, int C, int ldx, int ldy, hipStream_t stream);
+struct AfTransposeJob {
+  const _Float16* x;
+  _Float16* y;
+  int N, C, ldx, ldy;
+};
+// up to three such transposes (same batch count) in one launch when all qualify for the 16-byte form
+void af_launch_transpose_tokens_multi(const AfTransposeJob* jobs, int n, int B, hipStream_t stream);
 
 #define AF_REQUIRE(cond, msg)                                      \
   do {                                                             \

@@ -268,6 +268,10 @@ int af_add_f16(const void* a, const void* b, void* out, int64_t n, void* stream)
 int af_axpy_f16(const void* a, const void* b, float alpha, void* out, int64_t n, void* stream);
 /* x [B,N,ldx] (C columns) -> y [B,C,ldy] with the token index contiguous (zero padded to ldy) */
 int af_transpose_tokens(const void* x, void* y, int B, int N, int C, int ldx, int ldy, void* stream);
+/* two such transposes of the same [B, N] token grid in one launch (a weight gradient's operands dy^T and x^T): x1 [B*N, ldx1] -> y1 [B, C1, ldy],
+ * x2 [B*N, ldx2] -> y2 [B, C2, ldy] */
+int af_transpose_tokens_pair(const void* x1, void* y1, int C1, int ldx1, const void* x2, void* y2, int C2, int ldx2, int B, int N, int ldy,
+                             void* stream);
 /* cautious AdamW (ldm/c_adamw.py:65-123) over a flat fp32 buffer; seg_offsets int64 [nseg+1] delimit the
  * parameter tensors (the caution mask is renormalised per tensor); counts: uint32 [nseg] scratch.          */
 int af_cadamw_step(void* p, const void* g, void* m, void* v, const void* seg_offsets, int nseg, void* counts, float lr,

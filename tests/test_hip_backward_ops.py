@@ -114,6 +114,15 @@ def test_sumpool_add_transpose(dev):
         assert out.shape == (Bn, C, (N + 7) // 8 * 8)
         assert torch.equal(out[:, :, :N].cpu(), src[:, off:off + C].reshape(Bn, N, C).permute(0, 2, 1)), (Bn, N, C, ld, off)
         assert float(out[:, :, N:].abs().max()) == 0 if out.shape[2] > N else True
+    # two operands of a weight gradient in one launch (af_transpose_tokens_pair), incl. a pair that must fall back to the scalar form
+    from adaface_dev_amd import _lib
+    for (M, n1, n2) in [(300, 16, 320), (4096, 192, 2880), (77, 12, 64)]:
+        a, b = rnd((M, n1), 6).to(dev), rnd((M, n2), 7).to(dev)
+        m64 = (M + 63) // 64 * 64
+        at, bt = torch.empty((n1, m64), dtype=torch.float16, device=dev), torch.empty((n2, m64), dtype=torch.float16, device=dev)
+        _lib.check(_lib.lib().af_transpose_tokens_pair(ops._p(a), ops._p(at), n1, n1, ops._p(b), ops._p(bt), n2, n2, 1, M, m64, ops._stream()), "pair")
+        assert torch.equal(at[:, :M], a.t()) and torch.equal(bt[:, :M], b.t())
+        assert float(at[:, M:].abs().max()) == 0 and float(bt[:, M:].abs().max()) == 0
 
 
 def test_conv_dgrad_via_transposed_weights(dev):
