@@ -122,7 +122,7 @@ def test_sumpool_add_transpose(dev):
         at, bt = torch.empty((n1, m64), dtype=torch.float16, device=dev), torch.empty((n2, m64), dtype=torch.float16, device=dev)
         _lib.check(_lib.lib().af_transpose_tokens_pair(ops._p(a), ops._p(at), n1, n1, ops._p(b), ops._p(bt), n2, n2, 1, M, m64, ops._stream()), "pair")
         assert torch.equal(at[:, :M], a.t()) and torch.equal(bt[:, :M], b.t())
-        assert float(at[:, M:].abs().max()) == 0 and float(bt[:, M:].abs().max()) == 0
+        assert m64 == M or (float(at[:, M:].abs().max()) == 0 and float(bt[:, M:].abs().max()) == 0)
 
 
 def test_conv_dgrad_via_transposed_weights(dev):
