@@ -43,6 +43,7 @@ class GemmDesc(C.Structure):
         ("ld_out2", C.c_int32), ("tile", C.c_int32), ("splits", C.c_int32),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64), ("zeros", C.c_void_p),
         ("tap_shift", C.c_int32), ("splitk_fused", C.c_int32),
+        ("ln_colsum", C.c_void_p), ("ln_eps", C.c_float),
     ]
 
 

@@ -602,6 +602,8 @@ extern "C" int af_gemm(const af_gemm_desc* d, void* stream) {
     }
     tile = 1;  // outside the pipelined kernel's scope
   }
+  AF_SUPPORTED(d->ln_colsum == nullptr, "af_gemm: a folded LayerNorm (ln_colsum) needs a whole-line tile (7 .. 13) whose scope covers the shape, "
+                                        "taps == 1, c2 == 0 and no split-K");
   if (geglu) return d->taps == 9 ? af_fail(AF_E_UNSUPPORTED, "af_gemm: GEGLU on a 3x3 conv")
                                  : launch_tile<1, EPI_GEGLU>(p, tile, s);
   if (d->out_mode == AF_OUT_SPLIT_T)

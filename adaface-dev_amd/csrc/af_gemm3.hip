@@ -45,6 +45,8 @@ struct Gemm3Dev {
   int ablate;  // profiling only (AF_GEMM3_ABLATE): 1 = no DMA after the prologue, 2 = fragments read once, 4 = no barrier,
                // 8 = no main loop, 16 = no epilogue, 32 = direct (un-staged) epilogue stores
   int stage_ok;  // output rows can be written as 16-byte chunks (N, ld_out multiples of 8, 16-byte aligned base)
+  const float* ln_cs;   // LayerNorm folded into the GEMM (af_gemm_desc.ln_colsum): column sums of the packed weight, or nullptr
+  float ln_eps;
 };
 
 constexpr int BK3 = 32;
@@ -72,8 +74,23 @@ enum { E3_STD = 0, E3_GEGLU = 1, E3_SPLIT_T = 2 };
 // (identical arithmetic to af_gemm.hip's standard epilogue), GEGLU, transposed-V split.  LDSB = bytes of LDS the main loop owned.
 template <int EPI, int NWM, int NWN, int TN, int LDSB>
 __device__ __forceinline__ void gemm3_epilogue(const Gemm3Dev& p, floatx4 (&acc)[TN][4], char* af_smem, int tile_m, int tile_n, int wm, int wn,
-                                               int fr, int fq, int tid) {
+                                               int fr, int fq, int tid, const float* lnst = nullptr) {
   constexpr int TM = 4, NW = NWM * NWN, BM = NWM * 64, BN = NWN * TN * 16;
+  if (lnst != nullptr) {
+    // LayerNorm folded into this GEMM: acc = x . (gamma W)^T of the UN-normalised rows; LN(x) W^T = rstd * (acc - mean * colsum) (+ b + W beta,
+    // which is the packed bias).  lnst[row] = (mean, rstd) of the tile's rows, written by the main loop's statistics waves.
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      const int row = wm * 64 + tm * 16 + fr;
+      const float mean = lnst[2 * row], rstd = lnst[2 * row + 1];
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        const floatx4 cs = *reinterpret_cast<const floatx4*>(lnst + 2 * BM + wn * TN * 16 + tn * 16 + 4 * fq);   // the tile's column sums, staged in LDS
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[tn][tm][e] = rstd * (acc[tn][tm][e] - mean * cs[e]);
+      }
+    }
+  }
   // ---- epilogue (identical arithmetic to af_gemm.hip's standard epilogue)
   if (p.splits > 1) {
     float* wsp = p.ws + (size_t)blockIdx.y * p.M * p.N;
@@ -685,6 +702,17 @@ __global__ __launch_bounds__(64 * NWM * NWN, (NWM * NWN == 4 && NSLOT == 2) ? 2 
   // the first half's DMA issue and reads) -- +86 VGPRs, faster on one shape, 5 - 17 % slower on four.
   const bool prio = NW == 8 && (p.ablate & 128) == 0;
   const bool late_dma = NW == 8 && (p.ablate & 256) == 0 && wave >= NW / 2;
+  // LayerNorm folded into the GEMM: the rows' sum / sum of squares come from the A fragments the MFMAs consume anyway (lane (fr, fq) holds
+  // row fr, K chunk fq of every 32-wide K step), two v_dot2_f32_f16 per register pair; the NWN waves that share a row group split its TM
+  // fragments among themselves (wave wn takes tm % NWN == wn), so the cost is 16 VALU per wave per 64-wide stage at NWN = 4.
+  constexpr int LNT = (TM + NWN - 1) / NWN;
+  float ln_s[LNT], ln_q[LNT];
+#pragma unroll
+  for (int j = 0; j < LNT; ++j) ln_s[j] = ln_q[j] = 0.f;
+  const bool ln_on = p.ln_cs != nullptr;
+  // the tile's column sums: fetched now (their L2 latency passes under the main loop), parked in LDS for the epilogue afterwards
+  floatx4 ln_csv = {0.f, 0.f, 0.f, 0.f};
+  if (ln_on && tid < BN / 4) ln_csv = *reinterpret_cast<const floatx4*>(p.ln_cs + tile_n * BN + tid * 4);   // packed rows are padded to 128: in range
   for (int i = 0; i < nk; ++i) {
     if (NSLOT == 2) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // stage i (the only one in flight) has landed
@@ -705,6 +733,19 @@ __global__ __launch_bounds__(64 * NWM * NWN, (NWM * NWN == 4 && NSLOT == 2) ? 2 
       for (int tn = 0; tn < TN; ++tn) wf[tn] = *reinterpret_cast<const half8_t*>(Ws + (wn * TN * 16 + tn * 16) * 128 + rd);
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm) xf[tm] = *reinterpret_cast<const half8_t*>(As + (wm * 64 + tm * 16) * 128 + rd);
+      if (ln_on) {
+        const half2_t one2 = {(half_t)1.0f, (half_t)1.0f};
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+          if (tm % NWN != wn) continue;
+#pragma unroll
+          for (int e = 0; e < 8; e += 2) {
+            const half2_t v2 = {xf[tm][e], xf[tm][e + 1]};
+            ln_s[tm / NWN] = __builtin_amdgcn_fdot2(v2, one2, ln_s[tm / NWN], false);
+            ln_q[tm / NWN] = __builtin_amdgcn_fdot2(v2, v2, ln_q[tm / NWN], false);
+          }
+        }
+      }
       if (prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn)
@@ -715,14 +756,39 @@ __global__ __launch_bounds__(64 * NWM * NWN, (NWM * NWN == 4 && NSLOT == 2) ? 2 
       if (kk == 0 && late_dma && i + NSLOT - 1 < nk) issue_stage(kt_begin + i + NSLOT - 1, (i + NSLOT - 1) % NSLOT);
     }
   }
-  gemm3_epilogue<EPI, NWM, NWN, TN, NSLOT * STAGE>(p, acc, af_smem, tile_m, tile_n, wm, wn, fr, fq, tid);
+  const float* lnst = nullptr;
+  if (ln_on) {
+    // row statistics -> LDS behind the ring (BM x (mean, rstd)); every wave of the row group reads them in the epilogue
+    float* st = reinterpret_cast<float*>(af_smem + NSLOT * STAGE);
+    const float inv_k = 1.0f / (float)p.K;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      if (tm % NWN != wn) continue;
+      float s = ln_s[tm / NWN], q = ln_q[tm / NWN];
+      s += __shfl_xor(s, 16, 64);
+      q += __shfl_xor(q, 16, 64);
+      s += __shfl_xor(s, 32, 64);
+      q += __shfl_xor(q, 32, 64);
+      if (fq == 0) {
+        const float mean = s * inv_k;
+        const float var = fmaxf(q * inv_k - mean * mean, 0.f);
+        const int row = wm * 64 + tm * 16 + fr;
+        st[2 * row] = mean;
+        st[2 * row + 1] = rsqrtf(var + p.ln_eps);
+      }
+    }
+    if (tid < BN / 4) *reinterpret_cast<floatx4*>(st + 2 * BM + tid * 4) = ln_csv;
+    __syncthreads();
+    lnst = st;
+  }
+  gemm3_epilogue<EPI, NWM, NWN, TN, NSLOT * STAGE>(p, acc, af_smem, tile_m, tile_n, wm, wn, fr, fq, tid, lnst);
 }
 
 template <int TAPS, int NWM, int NWN, int TN, int EPI = E3_STD, int NSLOT = 2>
 bool launch3w(const Gemm3Dev& p0, hipStream_t stream) {
   Gemm3Dev p = p0;
   constexpr int NW = NWM * NWN, BM = NWM * 64, BN = NWN * TN * 16;
-  constexpr size_t lds = NSLOT * (size_t)(BM + BN) * 128;
+  constexpr size_t lds = NSLOT * (size_t)(BM + BN) * 128 + (size_t)BM * 8 + (size_t)BN * 4;   // ring + the folded LayerNorm's row statistics and column sums
   static_assert(NSLOT == 2 || NSLOT == 4, "ring depths built: 2 and 4 (the counted waits cover at most two younger stages)");
   p.tiles_n = (p.N + BN - 1) / BN;
   p.tiles_m = (p.M + BM - 1) / BM;
@@ -765,8 +831,11 @@ int af_gemm3_try_launch(const af_gemm_desc* d, int splits, int wide, hipStream_t
   }
   if (wide == 2 && (d->N % 256 != 0 || d->taps != 1 || split_t || splits > 1)) return 1;
   if (wide == 3 && (d->N % 320 != 0 || d->taps != 1 || split_t || splits > 1)) return 1;
+  if (d->ln_colsum != nullptr && (wide < 4 || d->taps != 1 || d->c2 != 0 || splits > 1)) return 1;   // folded LayerNorm: whole-line tiles only
   Gemm3Dev p;
   bool fused = false;
+  p.ln_cs = (const float*)d->ln_colsum;
+  p.ln_eps = d->ln_eps;
   p.a1 = (const half_t*)d->a1;
   p.a2 = (const half_t*)d->a2;
   p.wt = (const half_t*)d->wt;

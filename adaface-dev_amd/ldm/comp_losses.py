@@ -11,8 +11,13 @@ Inputs are what the capture pass (modules/diffusionmodules/capture_graph.py) ret
 compute of a Stage-2 iteration is its U-Net passes); they are host-side tensor bookkeeping like the reference's, on device tensors.
 Pinned on fixtures written by the reference functions themselves (tests/golden/comp_losses.npz, tests/test_comp_losses.py).
 
-NOT built: the face-detection driven terms (RetinaFace crops, ArcFace alignment through the VAE decoder: external packages absent
-from the reference tree) and the optical-flow elastic matching (``calc_elastic_matching_loss`` :2549-2759 needs the GMA flow model)."""
+Round 3 added the feature-matching ("elastic matching") losses on the captured ``q2`` / ``attn_out`` / ``outfeat`` tensors --
+``calc_comp_subj_bg_preserve_loss`` :1920-2045, ``calc_elastic_matching_loss`` :2549-2759, ``calc_sc_recon_ssfg_mc_losses`` :2314-2547 --
+in the form the reference runs by default: ``flow_model is None`` (``ddpm.py:652-662``: the GMA flow network is only instantiated under
+``use_face_flow_for_sc_matching_loss``, default False), where the "flow" candidate is the same-location matching (:2382-2391); a flow
+model is refused.  Also ``calc_recon_and_suppress_losses`` :1715-1754 of the ``do_normal_recon`` iteration and small helpers
+(``add_dict_to_dict`` :1097, ``map_bboxes_coords`` :1588, ``clamp`` :81, ``torch_uniform`` :1269, ``var_of_laplacian``).
+The face boxes these functions take come from the caller's face detector (the RetinaFace network is an external package)."""
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -183,3 +188,209 @@ def comp_rep_distill_total(losses, sc_fg_mask_percent, rep_dist_fg_bounds=(0.1, 
     else:
         scale = 0
     return ((l_attn + l_sk + l_sv) * 2 + l_nk * 5 + l_nv * 2) * scale
+
+
+# ----------------------------------------------------------------------------- small helpers of the loss assembly
+def clamp(x, min_val, max_val):
+    assert min_val <= max_val, "min_val should be less than or equal to max_val"
+    return max(min_val, min(x, max_val))
+
+
+def torch_uniform(low, high, size=1, device=None):
+    return torch.rand(size, device=device) * (high - low) + low
+
+
+def add_dict_to_dict(d1, d2, weight=1, session_prefix=None):
+    """d1[k] += d2[k] * weight (missing keys start at 0); keys get ``session_prefix/`` in front when given."""
+    for k, v in d2.items():
+        k2 = k if session_prefix is None else f"{session_prefix}/{k}"
+        d1[k2] = d1.get(k2, 0) + v * weight
+    return d1
+
+
+def map_bboxes_coords(bboxes, W1, W2):
+    """Integer boxes on a W1-wide image -> the same boxes on a W2-wide one (pixel 512 -> latent 64), floor division as the reference."""
+    return None if bboxes is None else bboxes * W2 // W1
+
+
+def var_of_laplacian(images):
+    """Sharpness score per image (reference ldm/util.py ``var_of_laplacian``): variance of the 3x3 Laplacian of the grey image."""
+    grey = images.mean(dim=1, keepdim=True) if images.shape[1] > 1 else images
+    k = torch.tensor([[0.0, 1.0, 0.0], [1.0, -4.0, 1.0], [0.0, 1.0, 0.0]], device=images.device, dtype=grey.dtype).view(1, 1, 3, 3)
+    return F.conv2d(grey, k, padding=1).var(dim=(1, 2, 3))
+
+
+# ----------------------------------------------------------------------------- feature matching between the four blocks (flow_model = None)
+MATCHING_TYPES = ("attn", "flow", "sameloc")
+
+
+def reconstruct_feat_with_attn_aggregation(sc_feat, sc_to_ss_prob):
+    """[B, C, N_sc] x [B, N_sc, N_t] -> [B, N_t, C]: every target token as the probability-weighted sum of the subject-comp tokens."""
+    return torch.matmul(sc_feat, sc_to_ss_prob).permute(0, 2, 1)
+
+
+def calc_sc_recon_ssfg_mc_losses(layer_idx, flow_model, target_feats, scfg_feat, scbg_feat, ssfg_q, scfg_q, scbg_q, mc_q, ss2sc_flow, mc2sc_flow,
+                                 H, W, small_motion_ignore_thres, num_flow_est_iters, objective_name, verbose=False):
+    """How well the subject-comp (SC) features reconstruct (a) the subject-single face features (``ssfg``) and (b) the class-comp
+    features (``mc``), per target token, under three matchings: attention aggregation (softmax over the SC tokens of q_sc^T q_target),
+    "flow" and same location.  Without a flow model (the reference's default, :2382-2391) the flow candidate IS the same-location one.
+    Per token the smallest of {10 x attn, m x flow, sameloc} (m = 1.02 ssfg / 1.1 mc) is optimised (:2453-2462); the sparse
+    (identity) matching is also distilled into the attention matching with detached per-token weights (:2464-2516).
+    Returns (losses {name: [attn, flow, sameloc, min]}, sparse-distillation losses, win-rate stats, None, None)."""
+    if flow_model is not None:
+        raise NotImplementedError("calc_sc_recon_ssfg_mc_losses: the GMA optical-flow network (use_face_flow_for_sc_matching_loss) is an "
+                                  "external model; the reference's default flow_model=None path is what is built")
+    device, B, N = scbg_feat.device, scbg_feat.shape[0], H * W
+    probs = {"ssfg": F.softmax(torch.matmul(scfg_q.transpose(1, 2).contiguous(), ssfg_q), dim=1),
+             "mc": F.softmax(torch.matmul(scbg_q.transpose(1, 2).contiguous(), mc_q), dim=1)}
+    sources = {"ssfg": scfg_feat, "mc": scbg_feat}
+    eye = torch.eye(N, device=device, dtype=scbg_feat.dtype).repeat(B, 1, 1)
+    losses, sparse_distill, stats = {}, {}, {}
+    for name in ("ssfg", "mc"):
+        target = target_feats[name].permute(0, 2, 1)
+        sameloc = sources[name].permute(0, 2, 1)
+        candidates = (reconstruct_feat_with_attn_aggregation(sources[name], probs[name]), sameloc, sameloc)
+        tok = [F.mse_loss(c, target, reduction="none").mean(dim=2) for c in candidates]           # each [B, N_t]
+        losses[name] = [t.mean() for t in tok]
+        scaled = torch.stack([tok[0] * 10, tok[1] * (1.1 if name == "mc" else 1.02), tok[2]], dim=0)
+        losses[name].append(scaled.min(dim=0).values.mean())
+        # distil the sparse matching into the attention matching where it reconstructs better
+        adv = scaled[:1] - scaled[1:]                                                             # [2, B, N_t]
+        best_adv, best_type = adv.max(dim=0)
+        best_adv = best_adv.unsqueeze(1)
+        tok_w = (5 * F.layer_norm(best_adv, (best_adv.shape[2],), weight=None, bias=None, eps=1e-5)).sigmoid()
+        sparse = torch.cat([eye, eye], dim=0).gather(0, best_type.view(B, 1, -1).expand(-1, N, -1))
+        sc_w = torch.matmul(tok_w, (sparse + probs[name]).permute(0, 2, 1)).permute(0, 2, 1).detach()
+        sparse_distill[name] = ((sparse - probs[name]).abs() * sc_w).mean()
+        for i in range(adv.shape[0]):
+            stats[f"{name}_{MATCHING_TYPES[i + 1]}_win_rate"] = torch.logical_and(adv[i] > 0, best_type == i).float().mean(dim=1)
+        stats[f"{name}_avg_sparse_distill_weight"] = sc_w.mean()
+    return losses, sparse_distill, stats, None, None
+
+
+def _face_crops_resized(x4d, bboxes, H, W):
+    """Per instance the box [x1, y1, x2, y2] of the feature map, bilinearly resized back to (H, W) -- the face brought to a common frame."""
+    crops = []
+    for bi in range(len(bboxes)):
+        x1, y1, x2, y2 = bboxes[bi]
+        crops.append(F.interpolate(x4d[:, :, y1:y2, x1:x2], (H, W), mode="bilinear", align_corners=False))
+    return torch.cat(crops, dim=0)
+
+
+def calc_elastic_matching_loss(layer_idx, flow_model, ca_q, ca_attn_out, ca_outfeat, H, W, ss_face_bboxes, sc_face_bboxes,
+                               sc_face_shrink_ratio_for_bg_matching_mask=1, recon_scaled_loss_threses={"mc": 0.4, "ssfg": 0.4},
+                               recon_max_scale_of_threses=5, small_motion_ignore_thres=0.3, num_flow_est_iters=12):
+    """One captured layer: queries and features of the four blocks [SS, SC, SC-rep, MC] -> matching losses of ``outfeat`` and
+    ``attn_out`` (averaged).  Faces: the SS and SC boxes are cropped and resized to the full frame and de-meaned together; background:
+    SC with its (possibly shrunk) face box zeroed against MC, de-meaned by the average of the two means (the SC mean re-weighted by
+    its unmasked share).  A loss whose min-term reaches thres x max_scale is dropped, one above thres is scaled down to thres
+    (:2715-2731)."""
+    BLOCK_SIZE = ca_q.shape[0] // 4
+    ss_q, sc_q, _, mc_q = ca_q.chunk(4)
+    as4d = lambda t: t.reshape(*t.shape[:2], H, W)
+    sc_bg_mask = torch.ones((BLOCK_SIZE, 1, H, W), device=ca_q.device, dtype=ca_q.dtype)
+    for bi in range(len(sc_q)):
+        x1, y1, x2, y2 = [int(v * sc_face_shrink_ratio_for_bg_matching_mask) for v in sc_face_bboxes[bi]]
+        sc_bg_mask[bi, :, y1:y2, x1:x2] = 0
+    bg3d = sc_bg_mask.reshape(*sc_bg_mask.shape[:-2], -1)
+    bg_share = bg3d.numel() / (bg3d.sum() + 1e-5)
+
+    def split_fg_bg(ss, sc, mc):
+        """-> (ssfg, scfg, scbg, mc) de-meaned as described above."""
+        ssfg = _face_crops_resized(as4d(ss), ss_face_bboxes, H, W).reshape(*ss.shape)
+        scfg = _face_crops_resized(as4d(sc), sc_face_bboxes, H, W).reshape(*sc.shape)
+        fg_mean = torch.cat([ssfg, scfg], dim=0).mean(dim=(0, 2), keepdim=True).detach()
+        scbg = sc * bg3d
+        bg_mean = ((mc.mean(dim=(0, 2), keepdim=True) + scbg.mean(dim=(0, 2), keepdim=True) * bg_share) / 2).detach()
+        return ssfg - fg_mean, scfg - fg_mean, (scbg - bg_mean) * bg3d, mc - bg_mean
+
+    ssfg_q, scfg_q, scbg_q, mc_q = split_fg_bg(ss_q, sc_q, mc_q)
+    kept = {"ssfg": [], "mc": []}
+    sparse = {"ssfg": [], "mc": []}
+    all_stats = {}
+    total, discarded = 0, 0
+    ss2sc_flow = mc2sc_flow = None
+    for feat_type, feat_obj in (("outfeat", ca_outfeat), ("attn_out", ca_attn_out)):
+        ss_f, sc_f, _, mc_f = feat_obj.chunk(4)
+        ssfg_f, scfg_f, scbg_f, mc_f = split_fg_bg(ss_f, sc_f, mc_f)
+        losses, sparse_obj, stats, ss2sc_flow, mc2sc_flow = calc_sc_recon_ssfg_mc_losses(
+            layer_idx, flow_model, {"ssfg": ssfg_f, "mc": mc_f}, scfg_f, scbg_f, ssfg_q, scfg_q, scbg_q, mc_q, ss2sc_flow, mc2sc_flow,
+            H, W, small_motion_ignore_thres, num_flow_est_iters, objective_name=feat_type.ljust(8))
+        for name, ls in losses.items():
+            ls = torch.stack(ls, dim=0)
+            total += 1
+            thres = recon_scaled_loss_threses[name]
+            if ls[-1] >= thres * recon_max_scale_of_threses:
+                discarded += 1
+            else:
+                kept[name].append(ls * min(thres / (ls[-1].detach().item() + 1e-6), 1))
+            sparse[name].append(sparse_obj[name])
+        for k, v in stats.items():
+            all_stats.setdefault(k, []).append(v)
+    losses_sc_recons = {n: (torch.stack(v, dim=0).mean(dim=0) if v else torch.zeros(4, device=ca_q.device)) for n, v in kept.items()}
+    sparse_distill = {n: torch.stack(v).mean() for n, v in sparse.items()}
+    stats = {k: torch.stack(v).mean() for k, v in all_stats.items()}
+    return losses_sc_recons, sparse_distill, stats, torch.tensor(discarded / (total + 1e-6))
+
+
+PRESERVE_MONITORS = ("loss_sc_recon_ssfg_attn_agg", "loss_sc_recon_ssfg_flow", "loss_sc_recon_ssfg_sameloc", "loss_sc_recon_ssfg_min",
+                     "loss_sc_recon_mc_attn_agg", "loss_sc_recon_mc_flow", "loss_sc_recon_mc_sameloc", "loss_sc_recon_mc_min")
+
+
+def calc_comp_subj_bg_preserve_loss(mon_loss_dict, session_prefix, device, flow_model, ca_layers_activations, ss_face_bboxes, sc_face_bboxes,
+                                    sc_face_shrink_ratio_for_bg_matching_mask=1, recon_scaled_loss_threses={"mc": 0.4, "ssfg": 0.4},
+                                    recon_max_scale_of_threses=5, do_sc_fg_faces_suppress=False):
+    """Preserve the subject's face (SC vs SS) and the composition's background (SC vs MC) in the captured features of layers 22-24
+    (equal weights): 0.1 x the ssfg min-loss (0 when the SC face is being suppressed) + 0.2 x the mc min-loss; the sparse-attention
+    distillation terms are monitored at weight 0 (:2032-2043).  Adds its monitors to ``mon_loss_dict`` under ``session_prefix/``."""
+    outfeats, attn_outs, qs = ca_layers_activations["outfeat"], ca_layers_activations["attn_out"], ca_layers_activations["q2"]
+    layer_w = normalize_dict_values({22: 1, 23: 1, 24: 1})
+    opt = {k: torch.tensor(0.0, device=device) for k in ("loss_sc_recon_ssfg_min", "loss_sc_recon_mc_min",
+                                                         "loss_sc_to_ssfg_sparse_attns_distill", "loss_sc_to_mc_sparse_attns_distill")}
+    for li, outfeat in outfeats.items():
+        if li not in layer_w:
+            continue
+        q = qs[li]
+        qh = int(np.sqrt(q.shape[2] * outfeat.shape[2] // outfeat.shape[3]))
+        qw = q.shape[2] // qh
+        if outfeat.shape[2:] != (qh, qw):
+            outfeat = F.interpolate(outfeat, size=(qh, qw), mode="bilinear", align_corners=False)
+        recons, sparse, stats, discarded = calc_elastic_matching_loss(
+            li, flow_model, q, attn_outs[li], outfeat.reshape(*outfeat.shape[:2], -1), qh, qw, ss_face_bboxes, sc_face_bboxes,
+            sc_face_shrink_ratio_for_bg_matching_mask=sc_face_shrink_ratio_for_bg_matching_mask,
+            recon_scaled_loss_threses=recon_scaled_loss_threses, recon_max_scale_of_threses=recon_max_scale_of_threses,
+            small_motion_ignore_thres=0.3, num_flow_est_iters=12)
+        if recons is None:
+            continue
+        named = dict(zip(PRESERVE_MONITORS, list(recons["ssfg"]) + list(recons["mc"])))
+        named["loss_sc_to_ssfg_sparse_attns_distill"], named["loss_sc_to_mc_sparse_attns_distill"] = sparse["ssfg"], sparse["mc"]
+        add_dict_to_dict(opt, {k: named[k] for k in opt}, layer_w[li], None)
+        add_dict_to_dict(mon_loss_dict, dict(named, discarded_loss_ratio=discarded), layer_w[li], session_prefix)
+        add_dict_to_dict(mon_loss_dict, stats, layer_w[li], session_prefix)
+    return (opt["loss_sc_recon_ssfg_min"] * (0 if do_sc_fg_faces_suppress else 0.1) + opt["loss_sc_recon_mc_min"] * 0.2
+            + opt["loss_sc_to_ssfg_sparse_attns_distill"] * 0 + opt["loss_sc_to_mc_sparse_attns_distill"] * 0)
+
+
+# ----------------------------------------------------------------------------- do_normal_recon iteration (ldm/util.py:1715-1754)
+def calc_recon_and_suppress_losses(noise_gt, noise_pred, noise_pred_cls, face_detected_inst_weights, ca_layers_activations, all_subj_indices,
+                                   img_mask, fg_mask, bg_pixel_weight, BLOCK_SIZE, recon_on_pure_noise):
+    """(masked eps MSE against the true noise, masked eps MSE of the BACKGROUND against the class-prompt prediction, subject-token
+    attention landing on the background) of one recon denoising step."""
+    from .util import calc_recon_loss
+    dev = noise_pred.device
+    if not recon_on_pure_noise:
+        loss_recon, _ = calc_recon_loss(F.mse_loss, noise_pred, noise_gt, img_mask, fg_mask, face_detected_inst_weights,
+                                        fg_pixel_weight=1, bg_pixel_weight=bg_pixel_weight)
+    else:
+        loss_recon = torch.tensor(0.0, device=dev)
+    if noise_pred_cls is not None:
+        bg_mask = 1 - fg_mask
+        if bg_mask.sum() == 0:
+            bg_mask = torch.ones_like(noise_pred_cls)
+        if img_mask is not None:
+            bg_mask = bg_mask * img_mask
+        loss_recon_cls, _ = calc_recon_loss(F.mse_loss, noise_pred, noise_pred_cls, img_mask, bg_mask, face_detected_inst_weights,
+                                            fg_pixel_weight=1, bg_pixel_weight=bg_pixel_weight)
+    else:
+        loss_recon_cls = torch.tensor(0.0, device=dev)
+    return loss_recon, loss_recon_cls, calc_subj_masked_bg_suppress_loss(ca_layers_activations["attn"], all_subj_indices, BLOCK_SIZE, fg_mask)

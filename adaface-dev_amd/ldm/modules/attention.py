@@ -17,6 +17,7 @@ Constructor arguments, attribute names (``save_cross_attn_vars``, ``cached_activ
   GEGLU's ``x * gelu(gate)`` into the epilogue of its projection.
 """
 import math
+import os as _os
 
 import torch
 import torch.nn as nn
@@ -26,6 +27,10 @@ from ... import ops
 from ...ops import AF_ACT_GEGLU, F16
 from .diffusionmodules.util import (Conv2d, GroupNorm32, LayerNorm, Linear, _PackCache, checkpoint, from_nhwc_f16,
                                     to_nhwc_f16, zero_module)
+
+
+# LayerNorm -> Linear pairs of the inference pass run as ONE GEMM (ops.pack_matrix_ln); AF_FOLD_LAYERNORM=0 keeps the separate kernels (A/B runs)
+FOLD_LAYERNORM = _os.environ.get("AF_FOLD_LAYERNORM", "1") != "0"
 
 
 def exists(val):
@@ -58,8 +63,22 @@ class GEGLU(nn.Module):
 
         return self._cache.get((self.proj.weight, self.proj.bias), build)
 
-    def hip(self, x2d):
-        return ops.gemm(x2d, self.packed(), act=AF_ACT_GEGLU)
+    def packed_ln(self, ln):
+        """The projection with the LayerNorm in front of it folded in (ops.pack_matrix_ln): takes the un-normalised rows."""
+        def build():
+            w = self.proj.weight.detach().float()
+            b = self.proj.bias.detach().float() + w @ ln.bias.detach().float()
+            wi, bi = ops.interleave_geglu(w * ln.weight.detach().float()[None, :], b)
+            pw = ops.pack_matrix(wi, bi, self.proj.weight.device)
+            pw.ln_cs, pw.ln_eps = pw.wt.float().sum(dim=1).contiguous(), float(ln.eps)
+            return pw
+
+        if not hasattr(self, "_cache_ln"):
+            self._cache_ln = _PackCache()
+        return self._cache_ln.get((self.proj.weight, self.proj.bias, ln.weight, ln.bias), build)
+
+    def hip(self, x2d, ln=None):
+        return ops.gemm(x2d, self.packed() if ln is None else self.packed_ln(ln), act=AF_ACT_GEGLU)
 
     def hip_train(self, x2d):
         """Un-fused: keeps the (interleaved) pre-activation for the backward.  -> (out, hp)."""
@@ -95,8 +114,8 @@ class FeedForward(nn.Module):
             raise NotImplementedError("dropout > 0 is not supported (SD-1.5 uses 0)")
         self.net = nn.Sequential(GEGLU(dim, inner_dim), nn.Dropout(dropout), Linear(inner_dim, dim_out))
 
-    def hip(self, x2d, residual=None):
-        return self.net[2].hip(self.net[0].hip(x2d), residual=residual)
+    def hip(self, x2d, residual=None, ln=None):
+        return self.net[2].hip(self.net[0].hip(x2d, ln=ln), residual=residual)
 
     def hip_train(self, x2d, residual=None):
         g, hp = self.net[0].hip_train(x2d)
@@ -142,19 +161,34 @@ class CrossAttention(nn.Module):
         ws = (self.to_k.weight, self.to_v.weight)
         return self._kv_cache.get(ws, lambda: ops.pack_matrix(torch.cat([w.detach() for w in ws], 0), None, ws[0].device))
 
-    def hip(self, x2d, B, N, context=None, keybias=None, residual=None):
+    def _packed_qkv_ln(self, ln):
+        ws = (self.to_q.weight, self.to_k.weight, self.to_v.weight)
+        if not hasattr(self, "_qkv_cache_ln"):
+            self._qkv_cache_ln = _PackCache()
+        return self._qkv_cache_ln.get(ws + (ln.weight, ln.bias), lambda: ops.pack_matrix_ln(
+            torch.cat([w.detach() for w in ws], 0), None, ln.weight, ln.bias, ln.eps, ws[0].device))
+
+    def _packed_q_ln(self, ln):
+        if not hasattr(self, "_q_cache_ln"):
+            self._q_cache_ln = _PackCache()
+        return self._q_cache_ln.get((self.to_q.weight, ln.weight, ln.bias), lambda: ops.pack_matrix_ln(
+            self.to_q.weight, None, ln.weight, ln.bias, ln.eps, self.to_q.weight.device))
+
+    def hip(self, x2d, B, N, context=None, keybias=None, residual=None, ln=None):
         """x2d [B*N, C] fp16; context [B, L, Cc] fp16 or None (self-attention); keybias fp32
-        [B, roundup(L,64)] or None; residual [B*N, C] added after to_out.  Returns [B*N, C]."""
+        [B, roundup(L,64)] or None; residual [B*N, C] added after to_out.  ``ln``: the LayerNorm whose output this layer's query
+        (and, for self-attention, key / value) projection consumes -- x2d is then the UN-normalised input and the normalisation is
+        folded into the projection GEMM.  Returns [B*N, C]."""
         Ci, h, d = self.inner_dim, self.heads, self.dim_head
         if context is None:
             if self.to_k.in_features != self.to_q.in_features:
                 raise RuntimeError("CrossAttention: context is required (context_dim != query_dim)")
             L = N
-            qk, vt = ops.gemm(x2d, self._packed_qkv(), rows_per_batch=N, split_col=2 * Ci)
+            qk, vt = ops.gemm(x2d, self._packed_qkv() if ln is None else self._packed_qkv_ln(ln), rows_per_batch=N, split_col=2 * Ci)
             q, k, ldq, ldk = qk, qk[:, Ci:], 2 * Ci, 2 * Ci
         else:
             L = context.shape[1]
-            q = self.to_q.hip(x2d)
+            q = self.to_q.hip(x2d) if ln is None else ops.gemm(x2d, self._packed_q_ln(ln))
             ldq = ldk = Ci
             if self._kv_pre is not None:                     # projected for all layers at once by UNetModel._project_context_all
                 k, vt, ldk = self._kv_pre
@@ -256,6 +290,11 @@ class BasicTransformerBlock(nn.Module):
 
     def hip(self, x2d, B, N, context=None, keybias=None):
         """attention.py:242-252 with the three residual adds fused into GEMM epilogues."""
+        if FOLD_LAYERNORM and x2d.shape[1] % 64 == 0:
+            # the three LayerNorms never run as kernels: each is folded into the projection GEMM that consumes it
+            x1 = self.attn1.hip(x2d, B, N, None, keybias, residual=x2d, ln=self.norm1)
+            x2 = self.attn2.hip(x1, B, N, context, None, residual=x1, ln=self.norm2)
+            return self.ff.hip(x2, residual=x2, ln=self.norm3)
         x1 = self.attn1.hip(self.norm1.hip(x2d), B, N, None, keybias, residual=x2d)
         x2 = self.attn2.hip(self.norm2.hip(x1), B, N, context, None, residual=x1)
         return self.ff.hip(self.norm3.hip(x2), residual=x2)

@@ -65,6 +65,8 @@ class PackedWeight:
     kpad: int
     taps: int = 1
     cin: int = 0  # channels per tap as seen by the kernel (after any channel padding)
+    ln_cs: Optional[torch.Tensor] = None   # folded LayerNorm (pack_matrix_ln): fp32 [Npad] column sums of the fp16 rows
+    ln_eps: float = 0.0
 
 
 def pack_matrix(w2d: torch.Tensor, bias: Optional[torch.Tensor], device, taps: int = 1, cin: int = 0) -> PackedWeight:
@@ -75,6 +77,23 @@ def pack_matrix(w2d: torch.Tensor, bias: Optional[torch.Tensor], device, taps: i
     wt[:N, :K] = w2d.detach().to(device=device, dtype=F16)
     b = None if bias is None else bias.detach().to(device=device, dtype=torch.float32).contiguous()
     return PackedWeight(wt, b, N, K, kpad, taps, cin if cin else K)
+
+
+def pack_matrix_ln(w2d: torch.Tensor, bias: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor, eps: float, device) -> PackedWeight:
+    """Weight of a Linear that consumes LayerNorm(x) (BasicTransformerBlock.norm1/2/3 -> attn1 q|k|v, attn2.to_q, ff GEGLU projection;
+    reference attention.py:242-252), packed so that af_gemm can take the UN-normalised rows:
+        LN(x) W^T + b = rstd * (x (gamma * W)^T - mean * colsum(gamma * W)) + (b + W beta).
+    The kernel accumulates mean / rstd of each row from the A fragments of its own main loop (af_gemm_desc.ln_colsum).  Column sums are
+    taken over the fp16-rounded packed rows, so the rank-one correction cancels the mean term exactly as the MFMAs saw it."""
+    w = w2d.detach().to(device=device, dtype=torch.float32)
+    g, bt = gamma.detach().to(device=device, dtype=torch.float32), beta.detach().to(device=device, dtype=torch.float32)
+    b = w @ bt
+    if bias is not None:
+        b = b + bias.detach().to(device=device, dtype=torch.float32)
+    pw = pack_matrix(w * g[None, :], b, device)
+    pw.ln_cs = pw.wt.float().sum(dim=1).contiguous()
+    pw.ln_eps = float(eps)
+    return pw
 
 
 def pack_conv3x3(w: torch.Tensor, bias: Optional[torch.Tensor], device, cin_pad: int = 0) -> PackedWeight:
@@ -159,10 +178,22 @@ def _launch_gemm(d: "GemmDesc", device, what: str, tile: int = 0, splits: int = 
     """Pick (tile, splits) -- explicit args > recorder (autotune) > table > heuristic -- and launch."""
     if tile == 0 and splits == 0:
         key = f"{d.taps},{d.M},{d.N},{d.K},{d.act},{d.out_mode},{d.stride},{d.upsample}"
+        if d.ln_colsum:
+            key += ",ln"
         if _tune_recorder is not None:
             tile, splits = _tune_recorder(key, d, device)
         else:
             tile, splits = tune_table().get(key, (0, 1))
+            if d.ln_colsum and tile == 0:
+                tile, splits = tune_table().get(key[:-3], (0, 1))
+    if d.ln_colsum:
+        # the folded LayerNorm lives in the whole-line kernel only (tiles 7 .. 13), unsplit
+        splits = 1
+        if tile < 7 or (tile in (9, 10) and d.act != AF_ACT_GEGLU):
+            if d.act == AF_ACT_GEGLU:
+                tile = 7 if d.N % 256 == 0 else 8
+            else:
+                tile = 7 if (d.N % 320 == 0 and d.M >= 8192) else 8
     d.tile = tile
     d.zeros = _zero_page(device).data_ptr()
     f32 = d.out_mode == AF_OUT_F32
@@ -201,6 +232,9 @@ def gemm(a1: torch.Tensor, pw: PackedWeight, *, a2: Optional[torch.Tensor] = Non
     d.rows_per_batch = rows_per_batch
     d.ld_rowbias = 0 if rowbias is None else rowbias.stride(0)
     d.act = act
+    if pw.ln_cs is not None:
+        assert a2 is None and not out_f32, "gemm: a folded LayerNorm takes one source and the fp16 epilogues"
+        d.ln_colsum, d.ln_eps = _p(pw.ln_cs), pw.ln_eps
     out2 = None
     if split_col:
         assert rows_per_batch > 0 and M % rows_per_batch == 0

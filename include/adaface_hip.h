@@ -134,6 +134,13 @@ typedef struct af_gemm_desc {
                            the caller zeroes them once when it allocates the workspace, every launch leaves them zero.  The partial slabs
                            must fit in the first workspace_bytes - AF_SPLITK_COUNTER_BYTES bytes.  Results are bit-identical to the
                            two-launch form (slices are summed in slice order by the last-arriving workgroup of each tile) */
+  const void* ln_colsum; /* fp32 [Npad] or NULL.  Non-NULL = LayerNorm folded into this GEMM (BasicTransformerBlock.norm1/2/3 in front of
+                           attn1 q|k|v, attn2.to_q and the GEGLU projection, attention.py:242-252): a1 holds the UN-normalised rows, wt holds
+                           fp16(gamma * W), bias holds b + W beta, ln_colsum[n] = sum_k wt[n][k] (of the fp16 values), and the epilogue
+                           computes rstd_m * (acc - mean_m * ln_colsum[n]) + bias[n] with the row statistics (mean, biased variance over the
+                           K = c1 columns, eps = ln_eps) accumulated from the A fragments inside the main loop.  Whole-line tiles (7 .. 13)
+                           only, taps == 1, c2 == 0, no split-K; anything else is AF_E_UNSUPPORTED */
+  float ln_eps;
 } af_gemm_desc;
 #define AF_SPLITK_MAX_TILES 4096
 #define AF_SPLITK_COUNTER_BYTES (AF_SPLITK_MAX_TILES * 4)

@@ -852,6 +852,64 @@ def gen_comp_losses(out):
 
 
 
+def comp_preserve_inputs(device="cpu", scale=1.0):
+    """Seeded stand-ins for what the feature-matching losses read (layers 22-24 of a four-block batch, BLOCK_SIZE 1, an 8 x 8 feature
+    map): q2 / attn_out [4, 32, 64], outfeat [4, 32, 8, 8], with gradients; the SS and SC face boxes [x1, y1, x2, y2]."""
+    from adaface_dev_amd import rng
+    acts = {"q2": {}, "attn_out": {}, "outfeat": {}}
+    for li in (22, 23, 24):
+        acts["q2"][li] = (rng.synth_input(f"cp.q{li}", (4, 32, 64), seed=73) * 0.6).to(device).requires_grad_(True)
+        acts["attn_out"][li] = (rng.synth_input(f"cp.ao{li}", (4, 32, 64), seed=73) * scale).to(device).requires_grad_(True)
+        acts["outfeat"][li] = (rng.synth_input(f"cp.of{li}", (4, 32, 8, 8), seed=73) * scale).to(device).requires_grad_(True)
+    ss_boxes = torch.tensor([[1, 1, 6, 7]], device=device)
+    sc_boxes = torch.tensor([[2, 3, 7, 8]], device=device)
+    return acts, ss_boxes, sc_boxes
+
+
+PRESERVE_CASES = (("plain", dict(), 0.5), ("shrunk_suppress", dict(sc_face_shrink_ratio_for_bg_matching_mask=0.3, do_sc_fg_faces_suppress=True), 0.5),
+                  ("scaled_down", dict(), 1.0), ("discarded", dict(recon_scaled_loss_threses={"mc": 0.05, "ssfg": 2.0}, recon_max_scale_of_threses=2), 1.0))
+
+
+def gen_comp_preserve(out):
+    """REFERENCE ``calc_comp_subj_bg_preserve_loss`` (ldm/util.py:1920-2045; through ``calc_elastic_matching_loss`` :2549-2759 and
+    ``calc_sc_recon_ssfg_mc_losses`` :2314-2547) with ``flow_model=None``, the reference's default: value, every monitor entry, gradients
+    w.r.t. q2 / attn_out / outfeat; plus ``calc_recon_and_suppress_losses`` (:1715-1754) of the recon iteration."""
+    import contextlib
+    import io
+    import ldm.util as RU
+    res = {}
+    for tag, kw, scale in PRESERVE_CASES:
+        acts, ssb, scb = comp_preserve_inputs(scale=scale)
+        mon = {}
+        with contextlib.redirect_stdout(io.StringIO()):
+            loss = RU.calc_comp_subj_bg_preserve_loss(mon, "train", torch.device("cpu"), None, acts, ssb, scb, **kw)
+        loss.backward()
+        res[f"{tag}.loss"] = np.asarray(float(loss))
+        for k, v in mon.items():
+            res[f"{tag}.mon.{k.replace('/', '__')}"] = np.asarray(float(v))
+        for key in ("q2", "attn_out", "outfeat"):
+            for li in (22, 23, 24):
+                g = acts[key][li].grad
+                res[f"{tag}.d{key}{li}"] = np.zeros(1, np.float32) if g is None else g.numpy()
+    # the recon iteration's per-step losses on the comp_losses stand-ins (BLOCK_SIZE 4 there: every instance is a subject instance)
+    from adaface_dev_amd import rng
+    acts, future, s1, s2, em, pm, fg = comp_loss_inputs()
+    subj4 = (torch.arange(4).repeat_interleave(4), torch.tensor([4, 5, 6, 7]).repeat(4))
+    for tag, pure, with_cls, w in (("image", False, True, torch.tensor([1.0, 0.1, 1.0, 1.0])), ("noise", True, True, torch.ones(4)),
+                                   ("nocls", False, False, torch.ones(4))):
+        eps = rng.synth_input("cp.eps", (4, 4, 16, 16), seed=73).requires_grad_(True)
+        gt, cls = rng.synth_input("cp.gt", (4, 4, 16, 16), seed=73), rng.synth_input("cp.cls", (4, 4, 16, 16), seed=73)
+        acts, future, s1, s2, em, pm, fg = comp_loss_inputs()
+        ls = RU.calc_recon_and_suppress_losses(gt, eps, cls if with_cls else None, w, acts, subj4, None, fg, 0.025, 4, pure)
+        tot = sum(l for l in ls if torch.is_tensor(l) and l.requires_grad)
+        tot.backward()
+        res[f"recon_{tag}.values"] = np.asarray([float(l) for l in ls], dtype=np.float64)
+        res[f"recon_{tag}.deps"] = eps.grad.numpy() if eps.grad is not None else np.zeros(1, np.float32)
+        res[f"recon_{tag}.dattn23"] = acts["attn"][23].grad.numpy()
+    np.savez_compressed(os.path.join(out, "comp_preserve.npz"), **res)
+    print("comp_preserve:", {k: float(v) for k, v in res.items() if k.endswith(".loss")}, {k: v.tolist() for k, v in res.items() if k.endswith(".values")})
+
+
 def gen_comp_multistep(out):
     """REFERENCE ``LatentDiffusion.comp_distill_multistep_denoise`` (ddpm.py:1997-2086) around the stand-in wrapper: 3 steps on a
     four-block batch, subject-compos gradient mode; (a) timesteps / noises drawn inside (seeded), (b) a second pass re-using the first
@@ -1037,7 +1095,7 @@ def main():
     # host-orchestration fixtures: the reference's ddpm.py / unet_teachers.py / diffusers_attn_lora_capture.py are imported with
     # EMPTY stand-ins for their absent third-party packages (tests/golden/ref_import.py)
     host_jobs = {"teacher": gen_teacher, "sdpa": gen_sdpa, "guided_denoise": gen_guided_denoise, "distill_loss": gen_distill_loss,
-                 "comp_losses": gen_comp_losses, "comp_multistep": gen_comp_multistep, "id2ada_glue": gen_id2ada_glue, "wrapper_glue": gen_wrapper_glue}
+                 "comp_losses": gen_comp_losses, "comp_preserve": gen_comp_preserve, "comp_multistep": gen_comp_multistep, "id2ada_glue": gen_id2ada_glue, "wrapper_glue": gen_wrapper_glue}
     if args.only in host_jobs or args.only is None:
         sys.path.insert(0, HERE)
         sys.path.insert(0, os.path.dirname(HERE))

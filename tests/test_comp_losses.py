@@ -78,3 +78,74 @@ def test_dyn_loss_scale_and_rep_distill_weighting():
     want = ((v[0] + v[1] + v[3]) * 2 + v[2] * 5 + v[4] * 2) * scale
     assert abs(float(CL.comp_rep_distill_total(tuple(torch.tensor(x) for x in v), 0.22)) - want) < 1e-9
     assert float(CL.comp_rep_distill_total(tuple(torch.tensor(x) for x in v), 0.0)) == 0.0
+
+
+def _preserve_inputs(scale, device="cpu"):
+    from gen_golden import comp_preserve_inputs
+    return comp_preserve_inputs(device=device, scale=scale)
+
+
+def check_preserve_case(g, tag, kw, scale, device="cpu", tol=1e-5):
+    """One case of comp_preserve.npz (written by the reference's calc_comp_subj_bg_preserve_loss with flow_model=None): value, every
+    monitor entry the reference left in mon_loss_dict, gradients w.r.t. q2 / attn_out / outfeat of the three layers."""
+    from adaface_dev_amd.ldm import comp_losses as CL
+    acts, ssb, scb = _preserve_inputs(scale, device)
+    mon = {}
+    loss = CL.calc_comp_subj_bg_preserve_loss(mon, "train", torch.device(device), None, acts, ssb, scb, **kw)
+    want = float(g[f"{tag}.loss"])
+    assert abs(float(loss) - want) <= tol * max(abs(want), 1e-3), (tag, float(loss), want)
+    keys = [k for k in g.files if k.startswith(f"{tag}.mon.")]
+    assert len(keys) == len(mon) and len(keys) >= 17, (tag, sorted(mon), keys)
+    for k in keys:
+        name = k[len(tag) + 5:].replace("__", "/")
+        assert abs(float(mon[name]) - float(g[k])) <= 10 * tol * max(abs(float(g[k])), 1e-3), (tag, name, float(mon[name]), float(g[k]))
+    if loss.requires_grad:
+        loss.backward()
+    for key in ("q2", "attn_out", "outfeat"):
+        for li in (22, 23, 24):
+            wantg, got = g[f"{tag}.d{key}{li}"], acts[key][li].grad
+            if wantg.ndim == 1 and wantg.size == 1:
+                assert got is None or float(got.abs().sum()) == 0.0, (tag, key, li)
+            else:
+                assert got is not None and rel_l2(got.cpu().numpy(), wantg) < 10 * tol, (tag, key, li, rel_l2(got.cpu().numpy(), wantg))
+
+
+def test_comp_subj_bg_preserve_loss_vs_reference():
+    from gen_golden import PRESERVE_CASES
+    g = np.load(os.path.join(GOLDEN, "comp_preserve.npz"))
+    for tag, kw, scale in PRESERVE_CASES:
+        check_preserve_case(g, tag, kw, scale)
+    assert float(g["plain.loss"]) > 0 and float(g["discarded.loss"]) > 0
+    assert float(g["discarded.mon.train__discarded_loss_ratio"]) > 0        # a min-loss past thres x max_scale was dropped
+
+
+def test_flow_model_is_refused():
+    from adaface_dev_amd.ldm import comp_losses as CL
+    acts, ssb, scb = _preserve_inputs(0.5)
+    try:
+        CL.calc_comp_subj_bg_preserve_loss({}, "train", torch.device("cpu"), object(), acts, ssb, scb)
+    except NotImplementedError as e:
+        assert "flow" in str(e)
+    else:
+        raise AssertionError("a flow model must be refused")
+
+
+def check_recon_and_suppress(g, device="cpu", tol=1e-5):
+    from adaface_dev_amd import rng
+    from adaface_dev_amd.ldm import comp_losses as CL
+    from gen_golden import comp_loss_inputs
+    subj4 = (torch.arange(4, device=device).repeat_interleave(4), torch.tensor([4, 5, 6, 7], device=device).repeat(4))
+    for tag, pure, with_cls, w in (("image", False, True, torch.tensor([1.0, 0.1, 1.0, 1.0])), ("noise", True, True, torch.ones(4)),
+                                   ("nocls", False, False, torch.ones(4))):
+        eps = rng.synth_input("cp.eps", (4, 4, 16, 16), seed=73).to(device).requires_grad_(True)
+        gt, cls = rng.synth_input("cp.gt", (4, 4, 16, 16), seed=73).to(device), rng.synth_input("cp.cls", (4, 4, 16, 16), seed=73).to(device)
+        acts, future, s1, s2, em, pm, fg = comp_loss_inputs(device)
+        ls = CL.calc_recon_and_suppress_losses(gt, eps, cls if with_cls else None, w.to(device), acts, subj4, None, fg, 0.025, 4, pure)
+        assert np.allclose([float(l) for l in ls], g[f"recon_{tag}.values"], rtol=10 * tol, atol=1e-8), (tag, [float(l) for l in ls])
+        sum(l for l in ls if torch.is_tensor(l) and l.requires_grad).backward()
+        assert rel_l2(eps.grad.cpu().numpy(), g[f"recon_{tag}.deps"]) < 10 * tol
+        assert rel_l2(acts["attn"][23].grad.cpu().numpy(), g[f"recon_{tag}.dattn23"]) < 10 * tol
+
+
+def test_recon_and_suppress_losses_vs_reference():
+    check_recon_and_suppress(np.load(os.path.join(GOLDEN, "comp_preserve.npz")))

@@ -337,6 +337,87 @@ def test_layernorm(dev, rows, C):
     assert rel_l2(y.float().cpu().numpy(), ref.numpy()) < TOL
 
 
+def _ln_inputs(rows, C, seed=1):
+    # rows with a mean far from zero (3 sigma) and an outlier channel, as the residual stream of a transformer block has
+    x = (rnd((rows, C), seed, 2.0).float() + 3.0)
+    x[:, 5] *= 8.0
+    x = x.half()
+    g = torch.randn(C, generator=torch.Generator().manual_seed(3)) * 0.2 + 1
+    b = torch.randn(C, generator=torch.Generator().manual_seed(4)) * 0.2
+    return x, g, b
+
+
+@pytest.mark.parametrize("rows,C,N,tile", [(300, 320, 320, 7), (300, 320, 320, 8), (1000, 640, 640, 8), (513, 1280, 1280, 8), (520, 320, 640, 11),
+                                           (260, 320, 320, 12), (260, 320, 640, 13), (300, 320, 320, 0), (64, 1280, 1280, 0), (130, 64, 64, 0)])
+def test_gemm_folded_layernorm(dev, rows, C, N, tile):
+    """LayerNorm folded into the consuming GEMM (af_gemm_desc.ln_colsum, ops.pack_matrix_ln) == layer_norm then linear in fp32.
+    The un-fused pair rounds LN(x) to fp16 before the GEMM; the folded form does not, so the same one-rounding tolerance holds."""
+    from adaface_dev_amd import ops
+    x, g, b = _ln_inputs(rows, C)
+    w = rnd((N, C), 2, C ** -0.5)
+    bias = torch.randn(N, generator=torch.Generator().manual_seed(5)) * 0.3
+    r = rnd((rows, N), 6)
+    pw = ops.pack_matrix_ln(w, bias, g, b, 1e-5, dev)
+    out = ops.gemm(x.to(dev), pw, residual=r.to(dev), tile=tile)
+    ref = F.layer_norm(x.float(), (C,), g, b, 1e-5) @ w.float().t() + bias + r.float()
+    assert rel_l2(out.float().cpu().numpy(), ref.numpy()) < TOL
+
+
+@pytest.mark.parametrize("tile,C", [(7, 64), (8, 64), (9, 320), (10, 320), (8, 320), (0, 320)])
+def test_gemm_folded_layernorm_geglu(dev, tile, C):
+    from adaface_dev_amd import ops
+    from adaface_dev_amd.ldm.modules.attention import GEGLU
+    from adaface_dev_amd.ldm.modules.diffusionmodules.util import LayerNorm
+    M = 520
+    x, g, b = _ln_inputs(M, C)
+    m, ln = GEGLU(C, 4 * C).to(dev), LayerNorm(C).to(dev)
+    with torch.no_grad():
+        m.proj.weight.copy_(rnd((8 * C, C), 2, C ** -0.5).float())
+        m.proj.bias.copy_(torch.randn(8 * C, generator=torch.Generator().manual_seed(3)) * 0.1)
+        ln.weight.copy_(g)
+        ln.bias.copy_(b)
+    out = ops.gemm(x.to(dev), m.packed_ln(ln), act=ops.AF_ACT_GEGLU, tile=tile)
+    h = F.layer_norm(x.float(), (C,), g, b, 1e-5) @ m.proj.weight.detach().float().cpu().t() + m.proj.bias.detach().float().cpu()
+    xv, gv = h.chunk(2, dim=-1)
+    ref = xv * F.gelu(gv)
+    assert out.shape == (M, 4 * C)
+    assert rel_l2(out.float().cpu().numpy(), ref.numpy()) < TOL
+
+
+@pytest.mark.parametrize("tokens,tile,C", [(100, 7, 320), (77, 8, 64), (256, 8, 640), (100, 0, 320)])
+def test_gemm_folded_layernorm_split_transposed(dev, tokens, tile, C):
+    """q | k | v of a self-attention layer from the un-normalised rows: q | k row-major, v transposed."""
+    from adaface_dev_amd import ops
+    B = 2
+    x, g, b = _ln_inputs(B * tokens, C)
+    w = rnd((3 * C, C), 2, C ** -0.5)
+    out, out2 = ops.gemm(x.to(dev), ops.pack_matrix_ln(w, None, g, b, 1e-5, dev), rows_per_batch=tokens, split_col=2 * C, tile=tile)
+    ref = F.layer_norm(x.float(), (C,), g, b, 1e-5) @ w.float().t()
+    assert rel_l2(out.float().cpu().numpy(), ref[:, :2 * C].numpy()) < TOL
+    vt = ref[:, 2 * C:].reshape(B, tokens, C).permute(0, 2, 1)
+    assert rel_l2(out2[:, :, :tokens].float().cpu().numpy(), vt.numpy()) < TOL
+
+
+def test_gemm_folded_layernorm_refuses_other_kernels(dev):
+    from adaface_dev_amd import ops
+    x, g, b = _ln_inputs(64, 64)
+    pw = ops.pack_matrix_ln(rnd((64, 64), 2), None, g, b, 1e-5, dev)
+    d_ok = ops.gemm(x.to(dev), pw, tile=8)
+    assert torch.isfinite(d_ok.float()).all()
+    import adaface_dev_amd.ops as O
+    # an explicit register-staged tile cannot carry the fold: the wrapper moves it to a whole-line tile, the C ABI itself refuses
+    from adaface_dev_amd import _lib
+    import ctypes as C
+    d = _lib.GemmDesc()
+    out = torch.empty((64, 64), dtype=torch.float16, device=dev)
+    xd = x.to(dev)
+    d.a1, d.wt, d.out, d.ln_colsum, d.ln_eps = xd.data_ptr(), pw.wt.data_ptr(), out.data_ptr(), pw.ln_cs.data_ptr(), 1e-5
+    d.M, d.N, d.K, d.kpad, d.taps, d.c1, d.lda1, d.tile = 64, 64, 64, pw.kpad, 1, 64, 64, 2
+    d.zeros = O._zero_page(dev).data_ptr()
+    rc = _lib.lib().af_gemm(C.byref(d), torch.cuda.current_stream().cuda_stream)
+    assert rc != 0 and "LayerNorm" in _lib.lib().af_last_error().decode()
+
+
 # ------------------------------------------------------------------------------- attention
 def _attn_ref(q, k, v, heads, mask=None):
     from oracle.unet_oracle import attention_core

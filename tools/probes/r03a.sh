@@ -1,0 +1,8 @@
+set -u
+cd $GRAFT_REPO_ROOT
+python -m pytest tests/test_hip_kernels.py -q -x -k "folded or gemm" 2>&1 | tail -15 > gpurun_out/r03a_tests.log
+python -m pytest tests/test_hip_unet.py -q -x 2>&1 | tail -15 >> gpurun_out/r03a_tests.log
+for i in 1 2; do
+  AF_FOLD_LAYERNORM=0 python bench.py --mode denoise --no-cpu-baseline --steps 100 --warmup 10 > gpurun_out/r03a_bench_nofold_$i.json 2>gpurun_out/r03a_bench_nofold_$i.err
+  AF_FOLD_LAYERNORM=1 python bench.py --mode denoise --no-cpu-baseline --steps 100 --warmup 10 > gpurun_out/r03a_bench_fold_$i.json 2>gpurun_out/r03a_bench_fold_$i.err
+done
