@@ -705,10 +705,13 @@ __global__ __launch_bounds__(64 * NWM * NWN, (NWM * NWN == 4 && NSLOT == 2) ? 2 
   // LayerNorm folded into the GEMM: the rows' sum / sum of squares come from the A fragments the MFMAs consume anyway (lane (fr, fq) holds
   // row fr, K chunk fq of every 32-wide K step), two v_dot2_f32_f16 per register pair; the NWN waves that share a row group split its TM
   // fragments among themselves (wave wn takes tm % NWN == wn), so the cost is 16 VALU per wave per 64-wide stage at NWN = 4.
-  constexpr int LNT = (TM + NWN - 1) / NWN;
+  constexpr int LNT = TM / NWN;
+  static_assert(LNT * NWN == TM, "the row groups of a tile divide evenly among the waves that share them");
   float ln_s[LNT], ln_q[LNT];
 #pragma unroll
   for (int j = 0; j < LNT; ++j) ln_s[j] = ln_q[j] = 0.f;
+  // a RUNTIME flag on purpose: as a template parameter (straight-line statistics code the scheduler may spread through the MFMA clusters)
+  // the GEGLU tiles ran 16 - 22 us slower, profiles/r03e_lnfold.txt; the branch keeps the statistics one block per stage
   const bool ln_on = p.ln_cs != nullptr;
   // the tile's column sums: fetched now (their L2 latency passes under the main loop), parked in LDS for the epilogue afterwards
   floatx4 ln_csv = {0.f, 0.f, 0.f, 0.f};
@@ -726,6 +729,27 @@ __global__ __launch_bounds__(64 * NWM * NWN, (NWM * NWN == 4 && NSLOT == 2) ? 2 
     if (!late_dma && i + NSLOT - 1 < nk) issue_stage(kt_begin + i + NSLOT - 1, (i + NSLOT - 1) % NSLOT);
     const char* As = af_smem + (i % NSLOT) * STAGE;
     const char* Ws = As + BM * 128;
+    if (ln_on) {
+      // one block per stage, in front of the MFMA clusters (whose straight-line schedule stays as it is): this wave's share of the row groups is read from LDS once more -- a runtime-indexed register fragment would need a branch per
+      // fragment
+      const half2_t one2 = {(half_t)1.0f, (half_t)1.0f};
+#pragma unroll
+      for (int j = 0; j < LNT; ++j) {
+        const char* row = As + (wm * 64 + (j * NWN + wn) * 16) * 128;
+        const half8_t f0 = *reinterpret_cast<const half8_t*>(row + rd0), f1 = *reinterpret_cast<const half8_t*>(row + rd1);
+        float s0 = ln_s[j], q0 = ln_q[j], s1 = 0.f, q1 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+          const half2_t a = {f0[e], f0[e + 1]}, b = {f1[e], f1[e + 1]};
+          s0 = __builtin_amdgcn_fdot2(a, one2, s0, false);
+          q0 = __builtin_amdgcn_fdot2(a, a, q0, false);
+          s1 = __builtin_amdgcn_fdot2(b, one2, s1, false);
+          q1 = __builtin_amdgcn_fdot2(b, b, q1, false);
+        }
+        ln_s[j] = s0 + s1;
+        ln_q[j] = q0 + q1;
+      }
+    }
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       const int rd = kk ? rd1 : rd0;
@@ -733,19 +757,6 @@ __global__ __launch_bounds__(64 * NWM * NWN, (NWM * NWN == 4 && NSLOT == 2) ? 2 
       for (int tn = 0; tn < TN; ++tn) wf[tn] = *reinterpret_cast<const half8_t*>(Ws + (wn * TN * 16 + tn * 16) * 128 + rd);
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm) xf[tm] = *reinterpret_cast<const half8_t*>(As + (wm * 64 + tm * 16) * 128 + rd);
-      if (ln_on) {
-        const half2_t one2 = {(half_t)1.0f, (half_t)1.0f};
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
-          if (tm % NWN != wn) continue;
-#pragma unroll
-          for (int e = 0; e < 8; e += 2) {
-            const half2_t v2 = {xf[tm][e], xf[tm][e + 1]};
-            ln_s[tm / NWN] = __builtin_amdgcn_fdot2(v2, one2, ln_s[tm / NWN], false);
-            ln_q[tm / NWN] = __builtin_amdgcn_fdot2(v2, v2, ln_q[tm / NWN], false);
-          }
-        }
-      }
       if (prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn)
@@ -762,9 +773,8 @@ __global__ __launch_bounds__(64 * NWM * NWN, (NWM * NWN == 4 && NSLOT == 2) ? 2 
     float* st = reinterpret_cast<float*>(af_smem + NSLOT * STAGE);
     const float inv_k = 1.0f / (float)p.K;
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm) {
-      if (tm % NWN != wn) continue;
-      float s = ln_s[tm / NWN], q = ln_q[tm / NWN];
+    for (int j = 0; j < LNT; ++j) {
+      float s = ln_s[j], q = ln_q[j];
       s += __shfl_xor(s, 16, 64);
       q += __shfl_xor(q, 16, 64);
       s += __shfl_xor(s, 32, 64);
@@ -772,7 +782,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, (NWM * NWN == 4 && NSLOT == 2) ? 2 
       if (fq == 0) {
         const float mean = s * inv_k;
         const float var = fmaxf(q * inv_k - mean * mean, 0.f);
-        const int row = wm * 64 + tm * 16 + fr;
+        const int row = wm * 64 + (j * NWN + wn) * 16 + fr;
         st[2 * row] = mean;
         st[2 * row + 1] = rsqrtf(var + p.ln_eps);
       }

@@ -101,6 +101,8 @@ class IRBlock(nn.Module):
 
 
 class ResNetFace(nn.Module):
+    inference_only = True        # forward kernels only (ldm/modules/arcface_wrapper.py refuses a call that would need its backward)
+
     def __init__(self, block, layers, use_se=True):
         self.inplanes = 64
         self.use_se = use_se

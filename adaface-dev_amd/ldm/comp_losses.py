@@ -316,6 +316,7 @@ def calc_elastic_matching_loss(layer_idx, flow_model, ca_q, ca_attn_out, ca_outf
         losses, sparse_obj, stats, ss2sc_flow, mc2sc_flow = calc_sc_recon_ssfg_mc_losses(
             layer_idx, flow_model, {"ssfg": ssfg_f, "mc": mc_f}, scfg_f, scbg_f, ssfg_q, scfg_q, scbg_q, mc_q, ss2sc_flow, mc2sc_flow,
             H, W, small_motion_ignore_thres, num_flow_est_iters, objective_name=feat_type.ljust(8))
+        total, discarded = 0, 0              # as the reference (:2706-2707): the reported ratio is that of the LAST feature type
         for name, ls in losses.items():
             ls = torch.stack(ls, dim=0)
             total += 1

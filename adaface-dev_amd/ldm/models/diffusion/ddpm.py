@@ -4,8 +4,8 @@ the noise schedule (``DDPM.register_schedule`` 294-345), ``q_sample`` /
 U-Net wrapper contract ``self.model(x, t, cond_context, out_dtype)`` of
 ``DiffusersUNetWrapper.forward`` (4187-4252).
 
-Out of scope here: Lightning glue, the loss zoo, prompt plumbing, VAE.  The
-class is a plain ``nn.Module`` so samplers and trainers written against the reference's
+The loss assemblies of the compositional-distillation and normal-recon iterations live in ``ddpm_losses.py`` (a mixin of
+``LatentDiffusion``).  Out of scope: Lightning glue, image logging.  The class is a plain ``nn.Module`` so samplers and trainers written against the reference's
 ``LatentDiffusion`` attribute surface (``num_timesteps``, ``alphas_cumprod``, ``betas``,
 ``device``, ``q_sample``, ``apply_model``, ``model.diffusion_model``) keep working.
 """
@@ -21,6 +21,7 @@ from .... import ops
 from ...modules.diffusionmodules.openaimodel import UNetModel
 from ...modules.diffusionmodules.util import extract_into_tensor, make_beta_schedule
 from ...util import calc_recon_loss
+from .ddpm_losses import CompReconLossesMixin
 
 
 class UNetWrapper(nn.Module):
@@ -166,7 +167,7 @@ class UNetWrapper(nn.Module):
         return out.to(out_dtype)
 
 
-class LatentDiffusion(nn.Module):
+class LatentDiffusion(CompReconLossesMixin, nn.Module):
     def __init__(self, unet_config, timesteps=1000, beta_schedule="linear", linear_start=0.00085, linear_end=0.012,
                  cosine_s=8e-3, parameterization="eps"):
         super().__init__()
@@ -180,6 +181,8 @@ class LatentDiffusion(nn.Module):
         self.comp_distill_priming_unet = None   # UNetTeacher with CFG on: primes the Stage-2 latents (ddpm.py:582-610)
         self.cond_stage_model = None    # FrozenCLIPEmbedder (instantiate_cond_stage)
         self.embedding_manager = None   # EmbeddingManager (instantiate_embedding_manager)
+        self.arcface = None          # modules/arcface_wrapper.ArcFaceWrapper (face crops + ResNetFace-18) for the face-gated loss terms
+        self.flow_model = None       # ddpm.py:652-662: the GMA flow network only exists under use_face_flow_for_sc_matching_loss (default False)
         self.iter_flags = {"do_comp_feat_distill": False, "do_unet_distill": False}
         self.num_id_vecs, self.num_static_img_suffix_embs = 16, 0
         self.register_schedule(beta_schedule=beta_schedule, timesteps=timesteps, linear_start=linear_start,
@@ -495,60 +498,6 @@ class LatentDiffusion(nn.Module):
                 else:
                     x_starts[i + 1] = x_starts[i + 1] * old_x_starts_mix_ratio + x_recon.detach() * (1 - old_x_starts_mix_ratio)
         return noise_preds, x_starts, x_recons, noises, ts, acts_list
-
-    comp_sc_subj_mb_suppress_loss_weight = 0.2          # reference ctor default (ddpm.py:87)
-
-    def calc_comp_feat_distill_loss(self, mon_loss_dict, session_prefix, noise_preds, ca_layers_activations_list, all_subj_indices_1b,
-                                    prompt_emb_mask_4b, prompt_pad_mask_4b, BLOCK_SIZE, sc_fg_mask=None, face_terms=None):
-        """The part of the reference's ``calc_comp_feat_distill_loss`` (ddpm.py:3190-3602) that is taken on the captured activations:
-
-        * per denoising step the five subject-comp rep distillation terms (``calc_sc_rep_attn_distill_loss``), averaged over the steps
-          and weighted as :3557-3589 (subject terms x2, non-subject k x5, v x2, all scaled by the detected face's share);
-        * the subject-attention background suppression of the SC instance (``calc_subj_masked_bg_suppress_loss`` as called at
-          :3701-3709, averaged over the steps, x ``comp_sc_subj_mb_suppress_loss_weight``);
-        * monitors: cross-step subject attention difference (:3482-3486, weight 0 in the reference), ``pred_l2``.
-
-        ``sc_fg_mask`` [BLOCK_SIZE, 1, h, w]: the face area of the subject-comp instance -- the reference gets it from RetinaFace on the
-        decoded x0 (:3238-3268; external package, absent from the reference tree), here the caller supplies it (None = no face found =
-        every face-gated term is zero, as in the reference).  ``face_terms``: already weighted scalar losses the caller computed from
-        face crops (ArcFace alignment, face suppression) to be added.  NOT built: the elastic-matching background preservation
-        (``calc_comp_subj_bg_preserve_loss``, optical-flow model) and the subject-single re-denoising."""
-        from ... import comp_losses as CL
-        device = noise_preds[0].device
-        loss = torch.zeros((), device=device, dtype=noise_preds[0].dtype)
-        sc_fg_mask_percent = float(sc_fg_mask.float().mean().item()) if sc_fg_mask is not None else 0.0
-        if sc_fg_mask is not None:
-            mon_loss_dict[f"{session_prefix}/sc_fg_mask_percent"] = sc_fg_mask_percent
-        reps, mbs, crosst, pred_l2s = [], [], [], []
-        for step, acts in enumerate(ca_layers_activations_list):
-            pred_l2s.append((noise_preds[step] ** 2).mean())
-            ls = CL.calc_sc_rep_attn_distill_loss(acts, all_subj_indices_1b, prompt_emb_mask_4b, prompt_pad_mask_4b, sc_fg_mask_percent,
-                                                  FG_THRES=0.1)
-            reps.append([v if torch.is_tensor(v) else torch.zeros((), device=device) for v in ls])
-            if sc_fg_mask is not None:
-                sc_attn = {li: a.chunk(4)[1] for li, a in acts["attn"].items()}
-                mbs.append(CL.calc_subj_masked_bg_suppress_loss(sc_attn, all_subj_indices_1b, BLOCK_SIZE, sc_fg_mask))
-                if step + 1 < len(ca_layers_activations_list):
-                    crosst.append(CL.calc_subj_attn_cross_t_diff_loss(acts, ca_layers_activations_list[step + 1], all_subj_indices_1b))
-        rep_means = tuple(torch.stack([r[i] for r in reps]).mean() for i in range(5))
-        if mbs:
-            mb = torch.stack(mbs).mean()
-            mon_loss_dict[f"{session_prefix}/comp_sc_subj_mb_suppress"] = float(mb.detach())
-            loss = loss + mb * self.comp_sc_subj_mb_suppress_loss_weight
-        if crosst:
-            mon_loss_dict[f"{session_prefix}/subj_attn_cross_t_diff"] = float(torch.stack(crosst).mean().detach())
-        if float(rep_means[0].detach()) > 0:
-            for name, v in zip(("subj_attn", "subj_k", "nonsubj_k", "subj_v", "nonsubj_v"), rep_means):
-                mon_loss_dict[f"{session_prefix}/comp_rep_distill_{name}"] = float(v.detach())
-            rep_total = CL.comp_rep_distill_total(rep_means, sc_fg_mask_percent)
-            mon_loss_dict[f"{session_prefix}/comp_rep_distill_total"] = float(rep_total.detach())
-            loss = loss + rep_total
-        for v in (face_terms or ()):
-            loss = loss + v
-        mon_loss_dict[f"{session_prefix}/pred_l2"] = float(torch.stack(pred_l2s).mean().detach())
-        if float(loss.detach()) > 0:
-            mon_loss_dict[f"{session_prefix}/comp_feat_distill_total"] = float(loss.detach())
-        return loss
 
     def sliced_apply_model(self, x_noisy, t, cond_context, slice_indices, enable_grad, use_attn_lora=False, use_ffn_lora=False,
                            ffn_lora_adapter_name=None):

@@ -679,8 +679,15 @@ class _UNetFunction(torch.autograd.Function):
         if graphs is not None and x.is_cuda:
             ctx.key = (tuple(x.shape), tuple(context.shape), str(x.dtype), str(context.dtype), img_mask is not None, float(res_gradscale),
                        tuple(id(a) for _, _, _, a in lora_param_order(lora)), ctx.need_dx)
+            # a second forward of the same signature before this node's backward (batch_student_steps=False: one student call per
+            # denoising step) must not replay into the buffers this node still needs: GraphedSegment.busy -> that call runs eagerly
+            busy = graphs[0].busy(ctx.key)
             out, ctx.saved = graphs[0].run(ctx.key, body, [x.detach(), timesteps, context.detach(), img_mask],
                                            refresh=lambda: _refresh_adapter_packs(lora))
+            if busy:
+                ctx.key = None                                    # an eager fallback runs its backward eagerly too
+            elif any(ctx.needs_input_grad):
+                graphs[0].claim(ctx.key, ctx)                     # (no-op until the key is a captured graph)
         else:
             ctx.key = None
             out, ctx.saved = body(x.detach(), timesteps, context.detach(), img_mask)
@@ -715,6 +722,7 @@ class _UNetFunction(torch.autograd.Function):
         else:
             res = body(deps.detach())
         ctx.saved = None
+        ctx.af_holds_replay = False                               # the replayed forward's buffers are free again
         return (None, res[0], None, res[1], None, None, None) + tuple(res[2:])
 
 

@@ -298,13 +298,21 @@ def conv3x3(x: torch.Tensor, pw: PackedWeight, *, x2: Optional[torch.Tensor] = N
 _gn_ws = {}
 
 
+def _grow_scratch(cache: dict, device, need: int, dtype, floor: int = 0) -> torch.Tensor:
+    """Per-device scratch that grows on demand.  A hipGraph bakes in the address of whatever buffer a captured launch was given, and
+    growing the cached buffer frees the old one -- so while the current stream is CAPTURING the scratch comes from the capturing graph's
+    own pool instead (it lives exactly as long as that graph), and the growable buffer only ever serves eager launches."""
+    if torch.cuda.is_current_stream_capturing():
+        return torch.empty((need,), dtype=dtype, device=device)
+    sc = cache.get(device)
+    if sc is None or sc.numel() < need:
+        sc = torch.empty((max(need, floor),), dtype=dtype, device=device)
+        cache[device] = sc
+    return sc
+
+
 def _gn_workspace(device, B: int) -> torch.Tensor:
-    need = _lib.lib().af_groupnorm_ws_floats(max(B, 16))
-    ws = _gn_ws.get(device)
-    if ws is None or ws.numel() < need:
-        ws = torch.empty((need,), dtype=torch.float32, device=device)
-        _gn_ws[device] = ws
-    return ws
+    return _grow_scratch(_gn_ws, device, _lib.lib().af_groupnorm_ws_floats(max(B, 16)), torch.float32)
 
 
 def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, silu: bool, *,
@@ -363,10 +371,7 @@ def attention_bwd(q, k, v, o, dout, lse, *, B: int, Nq: int, L: int, heads: int,
     Cn = heads * d
     scale = d ** -0.5 if scale is None else scale
     need = _lib.lib().af_attention_bwd_scratch_bytes(B, Nq, L, heads, d)
-    sc = _attn_scratch.get(q.device)
-    if sc is None or sc.numel() < need:
-        sc = torch.empty((max(need, 64 << 20),), dtype=torch.uint8, device=q.device)
-        _attn_scratch[q.device] = sc
+    sc = _grow_scratch(_attn_scratch, q.device, need, torch.uint8, floor=64 << 20)
     ldb = 0 if keybias is None else keybias.stride(0)
     rc = _lib.lib().af_attention_bwd(_p(q), _p(k), _p(v), _p(o), _p(dout), _p(lse), lse.stride(1), _p(keybias), int(causal_m), _p(dq), _p(dk),
                                      _p(dv), _p(sc), sc.numel(), B, Nq, L, heads, d, ldq, ldk, ldv, Cn, Cn, lddq, lddk, lddv,

@@ -910,6 +910,59 @@ def gen_comp_preserve(out):
     print("comp_preserve:", {k: float(v) for k, v in res.items() if k.endswith(".loss")}, {k: v.tolist() for k, v in res.items() if k.endswith(".values")})
 
 
+def _ref_arcface_shell(detect):
+    """The REFERENCE ``ArcFaceWrapper`` and ``RetinaFaceClient`` without their constructors (model files / the external retinaface
+    package): the embedding network and the detector are the stand-ins, every method run is the reference's own code."""
+    import ldm.modules.arcface_wrapper as ref_aw
+    import evaluation.retinaface_pytorch as ref_rf
+    from standin import StandInFaceNet
+    rf = ref_rf.RetinaFaceClient.__new__(ref_rf.RetinaFaceClient)
+    torch.nn.Module.__init__(rf)
+    rf.detect_faces = lambda img, T=20: [ref_rf.FacialAreaRegion(x, y, w, h, confidence=c) for (x, y, w, h, c) in detect(img, T)]
+    aw = ref_aw.ArcFaceWrapper.__new__(ref_aw.ArcFaceWrapper)
+    torch.nn.Module.__init__(aw)
+    aw.arcface, aw.retinaface, aw.dtype = StandInFaceNet(), rf, torch.float32
+    return aw
+
+
+STAGE2_DETECTORS = ("standin_detect", "no_faces", "standin_detect_small_second_face")
+
+
+def gen_stage2_assembly(out):
+    """REFERENCE ``LatentDiffusion.calc_comp_feat_distill_loss`` (ddpm.py:3190-3600, with ``calc_comp_face_align_and_mb_suppress_losses``,
+    ``redenoise_subj_single``, ``calc_arcface_align_loss`` and the ldm/util.py losses it calls, flow_model None) and
+    ``calc_normal_recon_loss`` (:2593-2883, with ``recon_multistep_denoise``) on a constructor-free shell, through
+    tests/stage2_scenario.py: loss, every monitor entry, d loss / d prompt_emb."""
+    import ldm.util as RU
+    import standin
+    import stage2_scenario as SC
+    res = {}
+
+    def shell(detect):
+        ld = _ref_ddpm_shell(trainer=types.SimpleNamespace(global_rank=0), global_step=0, device=torch.device("cpu"), training=True)
+        SC.common_attrs(ld, "cpu")
+        ld.arcface = _ref_arcface_shell(detect)
+        for name in ("comp_sc_face_detected_frac", "comp_mc_face_detected_frac", "comp_sc_face_suppressed_frac", "comp_sc_face_align_loss_kept_frac",
+                     "comp_ss_redenoise_success_frac", "normal_recon_face_align_loss_kept_frac"):
+            setattr(ld, name, RU.RollingStats(num_values=1, window_size=200, stat_type="mean"))
+        ld.normal_recon_face_images_on_image_stats = RU.RollingStats(num_values=2, window_size=600, stat_type="sum")
+        ld.normal_recon_face_images_on_noise_stats = RU.RollingStats(num_values=2, window_size=200, stat_type="sum")
+        return ld
+    for dname in STAGE2_DETECTORS:
+        detect = (lambda img, T=20: []) if dname == "no_faces" else getattr(standin, dname)
+        for mix in (False, True):
+            r = SC.run_comp_feat_distill(shell(detect), "cpu", mix_sc_mc_attn=mix)
+            for k, v in r.items():
+                res[f"comp.{dname}.mix{int(mix)}.{k}"] = v
+        for pure, steps in ((False, 2), (False, 1), (True, 2)):
+            r = SC.run_normal_recon(shell(detect), "cpu", on_pure_noise=pure, steps=steps)
+            for k, v in r.items():
+                res[f"recon.{dname}.pure{int(pure)}.steps{steps}.{k}"] = v
+    np.savez_compressed(os.path.join(out, "stage2_assembly.npz"), **res)
+    print("stage2_assembly:", {k: float(v) for k, v in res.items() if k.endswith(".loss")})
+    print("  monitors of the first case:", sorted(k.split(".mon.")[1] for k in res if k.startswith("comp.standin_detect.mix0.mon.")))
+
+
 def gen_comp_multistep(out):
     """REFERENCE ``LatentDiffusion.comp_distill_multistep_denoise`` (ddpm.py:1997-2086) around the stand-in wrapper: 3 steps on a
     four-block batch, subject-compos gradient mode; (a) timesteps / noises drawn inside (seeded), (b) a second pass re-using the first
@@ -1095,7 +1148,7 @@ def main():
     # host-orchestration fixtures: the reference's ddpm.py / unet_teachers.py / diffusers_attn_lora_capture.py are imported with
     # EMPTY stand-ins for their absent third-party packages (tests/golden/ref_import.py)
     host_jobs = {"teacher": gen_teacher, "sdpa": gen_sdpa, "guided_denoise": gen_guided_denoise, "distill_loss": gen_distill_loss,
-                 "comp_losses": gen_comp_losses, "comp_preserve": gen_comp_preserve, "comp_multistep": gen_comp_multistep, "id2ada_glue": gen_id2ada_glue, "wrapper_glue": gen_wrapper_glue}
+                 "comp_losses": gen_comp_losses, "comp_preserve": gen_comp_preserve, "stage2_assembly": gen_stage2_assembly, "comp_multistep": gen_comp_multistep, "id2ada_glue": gen_id2ada_glue, "wrapper_glue": gen_wrapper_glue}
     if args.only in host_jobs or args.only is None:
         sys.path.insert(0, HERE)
         sys.path.insert(0, os.path.dirname(HERE))

@@ -111,3 +111,79 @@ class StandInCLIP(torch.nn.Module):
             wl = hidden_state_layer_weights.to(h.dtype).reshape(-1)
             h = sum(wl[k] / wl.sum() * (h * (0.5 + 0.25 * k) + 0.05 * k) for k in range(wl.numel()))
         return (h,)
+
+
+# ----------------------------------------------------------------------------- stand-ins around the Stage-2 / recon loss assemblies
+class StandInCaptureWrapper(StandInWrapper):
+    """``StandInWrapper`` whose captured-activation dict has every key the Stage-2 losses read, for layers 22-24, as fixed cheap
+    differentiable maps of (eps, context): q / q2 / attn_out [B, C, N], outfeat [B, C, h, w], k / v [B, C, L], attn / attnscore
+    [B, heads, N, L] (rows softmaxed over the L context tokens)."""
+    C, HEADS = 8, 2
+
+    def __init__(self, eps_model, ctx_dim=16, seed=63):
+        super().__init__(eps_model)
+        from adaface_dev_amd import rng
+        for li in (22, 23, 24):
+            self.register_buffer(f"pf{li}", rng.synth_input(f"standin.cap.pf{li}", (self.C, 4), seed=seed) * 0.7)
+            self.register_buffer(f"pq{li}", rng.synth_input(f"standin.cap.pq{li}", (self.C, 4), seed=seed) * 0.9)
+            self.register_buffer(f"pk{li}", rng.synth_input(f"standin.cap.pk{li}", (ctx_dim, self.C), seed=seed) * 0.5)
+            self.register_buffer(f"pv{li}", rng.synth_input(f"standin.cap.pv{li}", (ctx_dim, self.C), seed=seed) * 0.5)
+
+    def forward(self, x, t, cond_context, out_dtype=torch.float32):
+        eps = super().forward(x, t, cond_context, out_dtype)
+        ctx, _, extra = cond_context
+        if extra.get("capture_ca_activations", False):
+            B, _, h, w = eps.shape
+            acts = {k: {} for k in ("outfeat", "attn", "attnscore", "q", "q2", "k", "v", "attn_out")}
+            for li in (22, 23, 24):
+                pf, pq, pk, pv = (getattr(self, f"p{n}{li}").to(eps.dtype) for n in "fqkv")
+                feat = torch.einsum("cd,bdhw->bchw", pf, eps)
+                q = torch.einsum("cd,bdhw->bchw", pq, torch.tanh(eps + 0.1 * li - 2.3)).reshape(B, self.C, h * w)
+                k, v = (ctx.to(eps.dtype) @ pk).permute(0, 2, 1), (ctx.to(eps.dtype) @ pv).permute(0, 2, 1)
+                d = self.C // self.HEADS
+                score = torch.einsum("bhdn,bhdl->bhnl", q.reshape(B, self.HEADS, d, h * w), k.reshape(B, self.HEADS, d, -1))
+                attn = score.softmax(dim=-1)
+                ao = torch.einsum("bhnl,bhdl->bhdn", attn, v.reshape(B, self.HEADS, d, -1)).reshape(B, self.C, h * w)
+                acts["outfeat"][li], acts["attn_out"][li] = feat + 0.3 * ao.reshape(B, self.C, h, w), ao
+                acts["q"][li], acts["q2"][li], acts["k"][li], acts["v"][li] = q, q, k, v
+                acts["attn"][li], acts["attnscore"][li] = attn, score
+            extra["ca_layers_activations"] = acts
+        return eps
+
+
+FACE_PRESETS = ((40, 24, 56, 64), (16, 40, 64, 56), (56, 48, 48, 48), (24, 16, 72, 80))      # (x, y, w, h) on a 128 x 128 image
+
+
+def standin_detect(image_np, T=20):
+    """One face per image whose box is picked by coarse image content (left / right and top / bottom brightness), so that the reference
+    side and the mirror side of a fixture -- which decode the same latents with the same stand-in decoder -- see the same boxes."""
+    g = image_np.astype("float64").mean(axis=2)
+    H, W = g.shape
+    i = int(g[:, : W // 2].mean() > g[:, W // 2:].mean()) * 2 + int(g[: H // 2].mean() > g[H // 2:].mean())
+    x, y, w, h = FACE_PRESETS[i]
+    sx, sy = W / 128.0, H / 128.0
+    return [(x * sx, y * sy, w * sx, h * sy, 0.995)]
+
+
+def standin_detect_small_second_face(image_np, T=20):
+    """As standin_detect plus a smaller second (background) face."""
+    return standin_detect(image_np, T) + [(4.0, 4.0, 30.0, 28.0, 0.93)]
+
+
+def standin_decode(z):
+    """Plays the VAE decoder: latent [B, 4, h, w] -> image [B, 3, 8h, 8w] in about [-1, 1], differentiable."""
+    return F.interpolate(torch.tanh(z[:, :3] * 0.9 + 0.2 * z[:, 3:4]), scale_factor=8, mode="bilinear", align_corners=False)
+
+
+class StandInFaceNet(torch.nn.Module):
+    """Plays ResNetFace-18 behind ArcFaceWrapper: grey [N, 1, 128, 128] -> [N, 24] embeddings, differentiable, fp32."""
+
+    def __init__(self, seed=64):
+        super().__init__()
+        from adaface_dev_amd import rng
+        self.w1 = torch.nn.Parameter(rng.synth_input("standin.face.w1", (6, 1, 5, 5), seed=seed) * 0.4, requires_grad=False)
+        self.w2 = torch.nn.Parameter(rng.synth_input("standin.face.w2", (24, 6 * 16), seed=seed) * 0.3, requires_grad=False)
+
+    def forward(self, grey):
+        h = torch.tanh(F.conv2d(grey.float(), self.w1, stride=4, padding=2))
+        return F.adaptive_avg_pool2d(h, 4).flatten(1) @ self.w2.t()

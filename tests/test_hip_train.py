@@ -584,6 +584,67 @@ def test_graph_replayed_segments_reproduce_the_eager_micro_batch(dev):
     assert len(set(l0)) > 2                                                  # the optimizer really moved things between micro-batches
 
 
+def test_graph_replay_is_not_reentered_while_its_buffers_are_held(dev):
+    """batch_student_steps=False calls the student once per denoising step with ONE signature before any backward runs.  A replayed
+    hipGraph returns the same output / saved-activation buffers every time, so the second and third call must not replay while the
+    first call's autograd node still holds them (graphs.GraphedSegment.busy / claim): they run eagerly, and the losses and parameter
+    trajectories equal the graph-free trainer bit for bit.  Extra-step timesteps / noise are presampled (the teacher then runs eagerly)."""
+    from adaface_dev_amd import rng
+    from adaface_dev_amd.ldm.trainer import DistillTrainer, LossScaler
+
+    def run(use_graphs):
+        tr, _, _ = trainer_setup(dev, accum=1, ffn_lora=True)
+        tr.scaler = LossScaler(init_scale=2.0 ** 6)
+        for ad in (a for d in tr.ldm.model.ffn_lora.active("unet_distill").values() for a in d.values()):
+            ad.p = 0.0
+        if use_graphs:
+            tr2 = DistillTrainer(tr.ldm, tr.id2ada, tr.text_encoder, accumulate_grad_batches=1, warm_up_steps=0,
+                                 loss_scaler=LossScaler(init_scale=2.0 ** 6), use_graphs=True)
+            tr.reducer.remove()
+            tr = tr2
+        tr.ldm.batch_student_steps = False
+        for g in tr.optimizer.param_groups:
+            g["lr"] = 1e-4
+        tr.learning_rate = 1e-4
+        t = torch.tensor([760, 850], device=dev)                  # three denoising steps: the micro-batch keeps ceil(4 / 3) = 2 instances
+        pre = [(rng.synth_input(f"re.rel{j}", (2,), seed=49).abs().clamp(0, 1).to(dev), rng.synth_input(f"re.n{j}", (2, 4, 32, 32), seed=49).to(dev))
+               for j in range(2)]
+        losses = []
+        try:
+            for i in range(4):
+                b = dict(x_start=rng.synth_input(f"dp.x{i % 2}", (4, 4, 32, 32), seed=48).to(dev), face_id_embs=rng.synth_input(f"dp.id{i % 2}", (4, 512), seed=48).to(dev),
+                         fg_mask=torch.ones(4, 1, 32, 32, device=dev), noise=rng.synth_input(f"dp.n{i % 2}", (4, 4, 32, 32), seed=48).to(dev))
+                losses.append(float(tr.training_step(b, i, num_unet_denoising_steps=3, t=t, presampled=pre)))
+        finally:
+            tr.ldm.batch_student_steps = True
+        return losses, [a.flat_p.clone() for a in tr.arenas] + [torch.tensor([tr.global_step, tr.skipped_steps])], tr
+    l0, p0, _ = run(False)
+    l1, p1, tr = run(True)
+    assert any(e.get("state") == "graph" for g in tr.graph_segments for e in g.entries.values())     # the student segment was captured
+    assert l0 == l1, (l0, l1)
+    assert int(p0[-1][0]) >= 2, p0[-1]                                        # optimizer steps really happened (identically on both sides, below)
+    for a, b in zip(p0, p1):
+        assert torch.equal(a, b)
+
+
+def test_scratch_of_a_captured_launch_lives_in_the_graph_pool(dev):
+    """ops._grow_scratch: a launch recorded into a hipGraph must not be handed the growable per-device scratch (a later, larger eager
+    call frees it and the replay would write through a stale pointer): under capture the scratch comes from the capturing graph's pool."""
+    from adaface_dev_amd import ops
+    cache = {}
+    a = ops._grow_scratch(cache, dev, 1024, torch.uint8, floor=4096)
+    assert a.numel() == 4096 and ops._grow_scratch(cache, dev, 2048, torch.uint8, floor=4096) is a
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        inside = ops._grow_scratch(cache, dev, 1024, torch.uint8, floor=4096)
+        inside.zero_()
+    assert inside.data_ptr() != a.data_ptr() and inside.numel() == 1024
+    b = ops._grow_scratch(cache, dev, 1 << 20, torch.uint8, floor=4096)                 # growth replaces only the eager buffer
+    assert b.numel() == 1 << 20 and cache[dev] is b
+    g.replay()
+    torch.cuda.synchronize()
+
+
 def test_full_size_distill_loss_gradient_of_bs4_equals_its_bs1_slices(dev):
     """BASELINE configs[2] at FULL size (SD-1.5 student + teacher, 64x64 latents, 97 context tokens, bs 4, FFN adapters on): the
     distillation loss is finite, and -- a size-independent property, the oracle being far too slow here -- the context gradient
