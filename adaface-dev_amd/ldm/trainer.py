@@ -279,12 +279,13 @@ class DistillTrainer:
         subj_indices_1b = (torch.zeros(n_id, dtype=torch.long, device=dev), torch.arange(s, s + n_id, device=dev))
         return ctx, ["ss", "sc", "sc-rep", "mc"], subj_indices_1b, emb_mask, pad_mask
 
-    def comp_distill_step(self, batch, face_mask_fn=None, attn_aug=None):
-        """do_comp_feat_distill iteration (reference ddpm.py:2371-2480): BLOCK_SIZE 1; four prompts; latents primed from pure noise by
+    def comp_distill_step(self, batch, attn_aug=None):
+        """do_comp_feat_distill iteration (reference ddpm.py:2371-2483): BLOCK_SIZE 1; four prompts; latents primed from pure noise by
         the priming U-Net; ``num_comp_distill_denoising_steps`` subject-compos passes of the student with activation capture (only
         the subject-comp instance carries gradients; SC / MC scores mixed or subject scores normalised, p = 0.5 each, :940-952);
-        losses on the captured activations.  ``face_mask_fn(x_recons) -> [1,1,h,w] mask | None`` stands where the reference runs
-        RetinaFace on the decoded x0 predictions.  Returns the loss."""
+        the x0 predictions of every step decoded for the face detector; ``LatentDiffusion.calc_comp_feat_distill_loss`` on all of it.
+        Faces come from ``ldm.arcface`` (modules/arcface_wrapper.ArcFaceWrapper around the caller's detector); with
+        ``ldm.arcface_align_loss_weight = 0`` no face is looked for and, as in the reference, every face-gated term is zero."""
         ldm = self.ldm
         x_start = batch["x_start"][:1]
         with torch.no_grad():
@@ -295,6 +296,7 @@ class DistillTrainer:
             attn_aug = ("normalize_cross_attn", "mix_sc_mc_attn")[int(torch.multinomial(torch.tensor([0.5, 0.5]), 1))]
         steps_prime = self.comp_iters_count % 2 - 1 + self.max_num_comp_priming_denoising_steps
         self.comp_iters_count += 1
+        ldm.comp_iters_count = self.comp_iters_count
         noise = torch.randn_like(x_start)
         primed = ldm.prime_x_start_for_comp_prompts((ctx, prompts, {}), x_start, noise, steps_prime, 0.5 + self.cls_subj_mix_ratio / 2)
         noise = torch.randn_like(x_start).repeat(4, 1, 1, 1)
@@ -302,15 +304,98 @@ class DistillTrainer:
         x_start_primed = torch.cat([xs, xc, xc, xc], dim=0)
         uncond_emb = ldm.uncond_context[0].repeat(4, 1, 1)
         t = torch.randint(int(ldm.num_timesteps * 0.45), int(ldm.num_timesteps * 0.65), (1,), device=x_start.device).repeat(4)
-        has_attn_lora = ldm.model.attn_lora is not None
+        has_attn_lora, has_ffn_lora = ldm.model.attn_lora is not None, ldm.model.ffn_lora is not None
+        S = self.num_comp_distill_denoising_steps
+        ldm.num_comp_distill_denoising_steps = S
         noise_preds, x_starts, x_recons, noises, ts, acts = ldm.comp_distill_multistep_denoise(
             [x_start_primed], [noise], [t], (ctx, prompts, {}), uncond_emb=uncond_emb, all_subj_indices_1b=subj_1b,
             normalize_cross_attn=attn_aug == "normalize_cross_attn", mix_sc_mc_attn=attn_aug == "mix_sc_mc_attn", cfg_scale=2.5,
-            num_denoising_steps=self.num_comp_distill_denoising_steps, old_x_starts_mix_ratio=0, use_attn_lora=has_attn_lora,
-            use_ffn_lora=ldm.model.ffn_lora is not None, ffn_lora_adapter_name="comp_distill", batch_part_has_grad="subject-compos")
-        sc_fg_mask = face_mask_fn(x_recons) if face_mask_fn is not None else None
+            num_denoising_steps=S, old_x_starts_mix_ratio=0, use_attn_lora=has_attn_lora,
+            use_ffn_lora=has_ffn_lora, ffn_lora_adapter_name="comp_distill", batch_part_has_grad="subject-compos")
+        pixels = None
+        if ldm.arcface_align_loss_weight > 0:
+            if ldm.arcface is None or ldm.first_stage_model is None:
+                raise RuntimeError("a compositional-distillation iteration with arcface_align_loss_weight > 0 looks for faces in the decoded x0 "
+                                   "predictions: set ldm.arcface (modules/arcface_wrapper.ArcFaceWrapper around your face detector) and "
+                                   "instantiate the first-stage decoder, or set ldm.arcface_align_loss_weight = 0")
+            pixels = ldm.decode_first_stage(torch.cat(x_recons, dim=0).detach()).chunk(S)                  # ddpm.py:2454-2457
+        ss_context = (ctx.chunk(4)[0], prompts[:1], {})
         self.mon_loss_dict = {}
-        return ldm.calc_comp_feat_distill_loss(self.mon_loss_dict, "train", noise_preds, acts, subj_1b, emb_mask, pad_mask, 1, sc_fg_mask=sc_fg_mask)
+        return ldm.calc_comp_feat_distill_loss(self.mon_loss_dict, "train", x_start, x_starts, x_recons, pixels, noise_preds, noises, ts, acts, subj_1b,
+                                               ss_context, ldm.uncond_context[0], emb_mask, pad_mask, 1, ldm.sc_fg_face_suppress_mask_shrink_ratio,
+                                               use_attn_lora=has_attn_lora, use_ffn_lora=has_ffn_lora)
+
+    # ------------------------------------------------------------------ do_normal_recon iteration (ddpm.py:2296-2352, 2593-2883)
+    p_normal_recon_on_pure_noise = 0.4            # reference ctor defaults (ddpm.py:116, 126-130)
+    unet_uses_attn_lora = True
+    recon_uses_ffn_lora = False
+    comp_uses_ffn_lora = True
+
+    def recon_prompt_context(self, ada_embs, bs):
+        """(subject-single context "a photo of z", class-single context "a photo of person") for ``bs`` instances and the subject-token
+        indices of the whole batch (the reference reads them from the EmbeddingManager's placeholder2indices, ddpm.py:2302-2303)."""
+        dev = ada_embs.device
+        n_id, T, s = self.id2ada.subj_basis_generator.N_ID, self.prompt_len, self.subj_slot
+        ctx = self.get_text_conditioning(ada_embs.float())
+        cls_ids = template_ids(["a", "photo", "of", "person"] + [","] * (n_id - 1), T, dev).repeat(bs, 1)
+        with torch.no_grad():
+            cls_ctx = self.text_encoder(input_ids=cls_ids)[0]
+        subj = (torch.arange(bs, device=dev).repeat_interleave(n_id), torch.arange(s, s + n_id, device=dev).repeat(bs))
+        return ctx, cls_ctx.to(ctx.dtype), subj
+
+    def normal_recon_step(self, batch, on_pure_noise=None):
+        """do_normal_recon iteration: the subject prompt must reconstruct the input images' noise (``calc_normal_recon_loss``), on the
+        images themselves or -- with probability ``p_normal_recon_on_pure_noise`` (ddpm.py:1166-1169) -- from pure noise after four
+        priming steps; attention LoRAs on half of the time, the FFN adapter per ``recon_uses_ffn_lora`` (:2305-2326)."""
+        ldm = self.ldm
+        x_start = batch["x_start"]
+        BS = x_start.shape[0]
+        fg_mask = batch.get("fg_mask")
+        fg_mask = torch.ones(BS, 1, *x_start.shape[2:], device=x_start.device) if fg_mask is None else fg_mask
+        img_mask = batch.get("img_mask")
+        with torch.no_grad():
+            _, _, id2img = self.id2ada.get_img_prompt_embs(batch["face_id_embs"], id_batch_size=BS)[:3]
+        ada = self.id2ada.subj_basis_generator(id2img.float(), out_id_embs_cfg_scale=self.id2ada.out_id_embs_cfg_scale, is_face=True)
+        ctx, cls_ctx, subj = self.recon_prompt_context(ada, BS)
+        if on_pure_noise is None:
+            on_pure_noise = bool(torch.rand(1) < self.p_normal_recon_on_pure_noise)
+        extra = {}
+        prompts = ["a photo of z"] * BS
+        noise = batch["noise"] if "noise" in batch else torch.randn_like(x_start)
+        if on_pure_noise:
+            attn_lora, ffn_lora, adapter, priming = False, False, "recon_loss", 4
+        else:
+            attn_lora = self.unet_uses_attn_lora and ldm.model.attn_lora is not None and torch.rand(1).item() < 0.5
+            ffn_lora = self.recon_uses_ffn_lora and ldm.model.ffn_lora is not None
+            adapter = "comp_distill" if (self.comp_uses_ffn_lora and torch.randn(1).item() < 0.25) else "recon_loss"
+            priming = 0
+        do_adv = bool(torch.rand(1) < ldm.p_do_adv_attack_when_recon_on_images) and not on_pure_noise
+        self.mon_loss_dict = {}
+        return ldm.calc_normal_recon_loss(self.mon_loss_dict, "train", ldm.num_recon_denoising_steps, priming, x_start, noise, (ctx, prompts, extra),
+                                          (cls_ctx, prompts, extra), img_mask, fg_mask, subj, ldm.recon_bg_pixel_weight, on_pure_noise, attn_lora,
+                                          ffn_lora, adapter, do_adv, min(BS, 2))
+
+    # ------------------------------------------------------------------ which iteration a micro-batch is (ddpm.py:451-470)
+    comp_distill_iter_gap = 0          # reference default 5 (ddpm.py:82) when Stage 2 is on; 0 = never, as DDPM treats <= 0
+    unet_distill_iter_gap = 0          # v1-distill-arc2face-ada.yaml:28 sets 2 (every 2nd non-comp iteration distils, the others reconstruct);
+                                       # 0 here = this trainer's historical behaviour: the ``stage`` argument fixes one iteration type
+    non_comp_iters_count = 0
+    normal_recon_iters_count = 0
+
+    def schedule_iteration(self):
+        """The reference's iteration typing, keyed on the OPTIMIZER step like the reference (so the two micro-batches of an accumulation
+        window share a type): every ``comp_distill_iter_gap``-th step is compositional distillation; of the others every
+        ``unet_distill_iter_gap``-th is U-Net distillation and the rest normal recon.  With both gaps 0 the constructor's ``stage``
+        decides (iter_type)."""
+        if self.comp_distill_iter_gap <= 0 and self.unet_distill_iter_gap <= 0:
+            return self.iter_type
+        if self.comp_distill_iter_gap > 0 and self.global_step % self.comp_distill_iter_gap == 0:
+            return "comp_distill"
+        self.non_comp_iters_count += 1
+        if self.unet_distill_iter_gap > 0 and self.non_comp_iters_count % self.unet_distill_iter_gap == 0:
+            return "unet_distill"
+        self.normal_recon_iters_count += 1
+        return "normal_recon"
 
     iter_type = "unet_distill"        # or "comp_distill" (Stage 2)
 
@@ -326,7 +411,9 @@ class DistillTrainer:
         self.unet_distill_iters_count += 1
         last = (batch_idx + 1) % self.accum == 0
         sync = contextlib.nullcontext() if last else self.reducer.no_sync()
-        loss = self.comp_distill_step(batch, **kw) if self.iter_type == "comp_distill" else self.shared_step(batch, **kw)
+        kind = self.schedule_iteration()
+        self.last_iter_type = kind
+        loss = {"comp_distill": self.comp_distill_step, "normal_recon": self.normal_recon_step, "unet_distill": self.shared_step}[kind](batch, **kw)
         with sync:
             (loss * (self.scaler.scale / self.accum)).backward()
         if last:

@@ -88,7 +88,8 @@ def run_train(args, ctx, dev, stage=1):
     the bs-3 batch (the reference fixes it, :2372-2374), latents primed from pure noise by the second (teacher) U-Net with
     classifier-free guidance over 3-4 steps, then 4 subject-compos denoising steps of the student on the four-prompt batch with
     activation capture (explicit attention in layers 22-24, score mixing / normalisation, trainable attention + FFN DoRA adapters),
-    guidance passes, captured-activation losses (a fixed face box stands in for the absent RetinaFace detector), backward, CAdamW."""
+    guidance passes, the x0 predictions decoded for the face pipeline (a fixed face box stands in for the RetinaFace detector network), the
+    whole loss assembly incl. the re-denoising of the subject-single instance and the feature-matching loss, backward, CAdamW."""
     world, rank, local_rank, launched = ctx
     import torch.distributed as dist
     from adaface_dev_amd import SD15_UNET_CONFIG, _lib, ops, rng
@@ -128,9 +129,19 @@ def run_train(args, ctx, dev, stage=1):
         ldm.comp_distill_priming_unet = UNetTeacher(ldm.unet_teacher.unet, cfg_scale_range=(2, 4), p_uses_cfg=1.0, name="comp_priming")
         ldm.uncond_context = (rng.synth_input("bench.uncond", (1, 97, 768), seed=5).to(dev), [""], {})
         ldm.model.set_up_attn_loras()                                      # rank-192 DoRA on q / k / v / out of layers 22-24
-        box = torch.zeros(1, 1, 64, 64, device=dev)
-        box[:, :, 16:44, 18:46] = 1                                        # 19 % of the image: inside the reference's 'good' face range
-        step_kw = dict(face_mask_fn=lambda x_recons: box)
+        # the face-gated terms: x0 predictions are decoded by the SD-1.5 KL-f8 decoder (synthetic weights) and handed to the ArcFace
+        # wrapper; a fixed face box (28 x 28 latent pixels = 19 % of the image, inside the reference's 'good' range) stands in for the
+        # RetinaFace detector network, which is an external package -- so the whole loss assembly (face alignment values,
+        # subject-attention suppression, re-denoising of the subject-single instance, feature-matching loss) runs every micro-batch
+        from adaface_dev_amd.evaluation.arcface_resnet import resnet_face18
+        from adaface_dev_amd.ldm.modules.arcface_wrapper import ArcFaceWrapper, FaceCropper
+        with rng.skip_default_init():
+            vae = ldm.instantiate_first_stage()
+            face_net = resnet_face18()
+        vae.to(dev)
+        rng.load_synth_weights(vae, seed=6, on_device=True)
+        rng.load_synth_weights(face_net.to(dev), seed=7, on_device=True)
+        ldm.arcface = ArcFaceWrapper(face_net.eval(), FaceCropper(lambda img, T=20: [(144.0, 128.0, 224.0, 224.0, 0.995)]))
     tr = DistillTrainer(ldm, id2ada.to(dev), text_enc.to(dev), batch_size=B, accumulate_grad_batches=2, prompt_len=97, stage=stage,
                         use_graphs=not args.no_train_graphs)
     n_train = sum(a.numel for a in tr.arenas)

@@ -182,3 +182,42 @@ def test_comp_distill_multistep_denoise_mirror_vs_reference(dev):
         assert rel_l2(emb.grad.cpu().numpy(), g[f"{tag}.demb"]) < 5e-5, tag
         want_calls = json.loads(str(g[f"{tag}.calls"]))
         assert [[n, fl, ad, npr, ge] for n, fl, ad, npr, ge in wrapper.calls] == want_calls, tag
+
+
+# ----------------------------------------------------------------------------- Stage-2 / recon loss assemblies on device tensors
+def _cpu_draws(monkeypatch):
+    """The scenario's in-method draws (torch.randn_like / rand_like on device tensors) follow the CPU generator the fixture was written
+    with: draw there, move over."""
+    monkeypatch.setattr(torch, "randn_like", lambda t, **k: torch.randn(t.shape, dtype=t.dtype).to(t.device))
+    monkeypatch.setattr(torch, "rand_like", lambda t, **k: torch.rand(t.shape, dtype=t.dtype).to(t.device))
+    real_randint = torch.randint
+
+    def randint(*a, device=None, **k):
+        out = real_randint(*a, **k)
+        return out if device is None else out.to(device)
+    monkeypatch.setattr(torch, "randint", randint)
+
+
+def test_calc_comp_feat_distill_loss_mirror_vs_reference_on_device(dev, monkeypatch):
+    """tests/test_stage2_assembly.py's cases with every tensor on the GPU and the real (HIP) q_sample: the loss assembly of the
+    compositional-distillation iteration against the fixture the reference's calc_comp_feat_distill_loss wrote."""
+    import test_stage2_assembly as T
+    _cpu_draws(monkeypatch)
+    T.run_comp_cases(dev, 1e-4, torch_q_sample=False)
+
+
+def test_calc_normal_recon_loss_mirror_vs_reference_on_device(dev, monkeypatch):
+    import test_stage2_assembly as T
+    _cpu_draws(monkeypatch)
+    T.run_recon_cases(dev, 1e-4, torch_q_sample=False)
+
+
+def test_comp_losses_on_device_tensors_vs_reference(dev):
+    """comp_losses.py (feature matching with flow_model None, recon / suppress losses) on GPU tensors against the reference's values
+    and gradients -- the CPU suite runs the same checks on host tensors."""
+    import test_comp_losses as TC
+    from gen_golden import PRESERVE_CASES
+    g = np.load(os.path.join(GOLDEN, "comp_preserve.npz"))
+    for tag, kw, scale in PRESERVE_CASES:
+        TC.check_preserve_case(g, tag, kw, scale, device=dev, tol=2e-5)
+    TC.check_recon_and_suppress(g, device=dev, tol=2e-5)

@@ -5,7 +5,14 @@ CFG = dict(in_channels=4, model_channels=64, out_channels=4, num_res_blocks=2, a
            channel_mult=[1, 2, 4, 4], num_heads=8, use_spatial_transformer=True, transformer_depth=1, context_dim=64, legacy=False)
 
 
-def trainer_setup(dev, accum=1, process_group=None, ffn_lora=False, embedding_manager=False, stage2=False):
+def fixed_face_detector(image_np, T=20):
+    """Stands where the reference runs RetinaFace on a decoded image: one face, a box of 5/8 x 5/8 of the frame (39 % of the area:
+    past the reference's 'too-large' bound of 36 %, so the face-suppression branch is live too), confidence 0.995."""
+    H, W = image_np.shape[:2]
+    return [(W * 0.25, H * 0.1875, W * 0.625, H * 0.625, 0.995)]
+
+
+def trainer_setup(dev, accum=1, process_group=None, ffn_lora=False, embedding_manager=False, stage2=False, faces=False):
     """Reduced-width replica of the whole Stage-1 stack: CLIP encoders hidden 128 / 3 layers, U-Nets model_channels 64."""
     from adaface_dev_amd import rng
     from adaface_dev_amd.adaface.arc2face_models import CLIPTextModelWrapper, clip_text_config
@@ -60,6 +67,20 @@ def trainer_setup(dev, accum=1, process_group=None, ffn_lora=False, embedding_ma
                     p.copy_(rng.synth_input(n, p.shape, seed=84, scale=0.2))
                 elif "lora_A" in n:
                     p.copy_(rng.synth_input(n, p.shape, seed=84, scale=p[0].numel() ** -0.5))
+    if stage2 or faces:
+        # what the face-gated loss terms need: a first-stage decoder (reduced width) and the ArcFace wrapper around a detector; the
+        # detector here "finds" one fixed face box in every decoded image (RetinaFace itself is an external package)
+        from adaface_dev_amd.evaluation.arcface_resnet import resnet_face18
+        from adaface_dev_amd.ldm.modules.arcface_wrapper import ArcFaceWrapper, FaceCropper
+        vae = ld.instantiate_first_stage(dict(ch=32, out_ch=3, ch_mult=(1, 2, 4, 4), num_res_blocks=2, attn_resolutions=[], dropout=0.0, in_channels=3,
+                                              resolution=128, z_channels=4, double_z=True))
+        with torch.no_grad():
+            for n, p in vae.named_parameters():
+                p.copy_(rng.synth_tensor(n, p.shape, seed=90))
+        net = resnet_face18()
+        rng.load_synth_weights(net, seed=47)
+        ld.arcface = ArcFaceWrapper(net.to(dev).eval(), FaceCropper(fixed_face_detector))
+        ld = ld.to(dev)
     tr = DistillTrainer(ld, id2ada.to(dev), text_enc.to(dev), accumulate_grad_batches=accum, warm_up_steps=0,
                         loss_scaler=LossScaler(init_scale=2.0 ** 10), process_group=process_group, stage=2 if stage2 else 1)
     return tr, sds, ucfg
