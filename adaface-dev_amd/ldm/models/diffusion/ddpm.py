@@ -24,6 +24,21 @@ from ...util import calc_recon_loss
 from .ddpm_losses import CompReconLossesMixin
 
 
+class _QSampleGrad(torch.autograd.Function):
+    """Attaches the value computed by the q_sample kernel to the graph of x_start."""
+
+    @staticmethod
+    def forward(ctx, x_start, xt, sa):
+        ctx.save_for_backward(sa)
+        ctx.dt = x_start.dtype
+        return xt.view_as(xt)
+
+    @staticmethod
+    def backward(ctx, g):
+        (sa,) = ctx.saved_tensors
+        return (g * sa.view(-1, *([1] * (g.dim() - 1)))).to(ctx.dt), None, None
+
+
 class UNetWrapper(nn.Module):
     """``self.model`` of LatentDiffusion: forward(x, t, cond_context, out_dtype=float32) with
     cond_context = (prompt_emb [b,L,768], prompt_in list[str], extra_info dict).  extra_info is
@@ -349,7 +364,13 @@ class LatentDiffusion(CompReconLossesMixin, nn.Module):
 
     def q_sample(self, x_start, t, noise=None):
         noise = torch.randn_like(x_start) if noise is None else noise
-        return ops.q_sample(x_start, noise, self.sqrt_alphas_cumprod[t], self.sqrt_one_minus_alphas_cumprod[t])
+        sa = self.sqrt_alphas_cumprod[t]
+        xt = ops.q_sample(x_start.detach(), noise, sa, self.sqrt_one_minus_alphas_cumprod[t])
+        if torch.is_grad_enabled() and x_start.requires_grad:
+            # recon on pure noise chains the denoising steps WITH gradients (ddpm.py:1815-1823: the x0 prediction of one step is the
+            # x_start of the next): d x_t / d x_start = sqrt(alpha_bar_t)
+            xt = _QSampleGrad.apply(x_start, xt, sa)
+        return xt
 
     def predict_start_from_noise(self, x_t, t, noise):
         return (extract_into_tensor(self.sqrt_recip_alphas_cumprod, t, x_t.shape) * x_t

@@ -203,7 +203,7 @@ class CompReconLossesMixin:
             use_attn_lora=use_attn_lora, use_ffn_lora=use_ffn_lora, ffn_lora_adapter_name="comp_distill", BLKS=1, batch_part_has_grad="none")
         pixels = self.decode_first_stage(torch.cat(x_recons_ss, dim=0))
         crops2, _, boxes2, conf2, found2 = self.arcface.retinaface.crop_faces(pixels, out_size=(128, 128), T=20)
-        pixel_steps, found_steps = pixels.chunk(S, dim=0), found2.chunk(S, dim=0)
+        found_steps = found2.chunk(S, dim=0)
         boxes_list, replaced = [ss_fg_face_bboxes] * S, 0
         if (1 - found_steps[-1]).sum() == 0:
             lap1 = [v.mean() for v in CL.var_of_laplacian(ss_fg_face_crops_collate).chunk(S, dim=0)]
@@ -212,8 +212,6 @@ class CompReconLossesMixin:
             boxes2_steps = chunk_list(CL.map_bboxes_coords(boxes2, pixels.shape[-1], latent_w), S)
             for step in range(S):
                 good = bool(conf_steps[step] >= comp_ss_face_confidence_thres) and bool(lap2[step] >= lap1[step] * lap_vars_tolerance)
-                colors = torch.ones(pixel_steps[step].shape[0], dtype=int, device=pixels.device) * (step % 4) + (0 if good else 4)
-                self.cache_and_log_generations(pixel_steps[step], colors, f"redenoise-ss_{step}", ss_context[1], do_normalize=True)
                 if good:
                     replaced += 1
                     _, ca_sc, ca_sr, ca_mc = split_dict(ca_layers_activations_list[step], 4)
@@ -427,7 +425,7 @@ class CompReconLossesMixin:
                 img_mask, fg_mask = None, torch.ones_like(fg_mask)
         else:
             uncond_emb, cfg_scale = None, -1
-        self.cache_and_log_generations(self.decode_first_stage(x_start), None, "recon-input", None, do_normalize=True)
+        # (the reference decodes the inputs and every step's x0 predictions here for its image log, :2633-2694: pure logging, skipped)
         noise_preds, noise_preds_cls, x_starts, x_recons, x_recons_cls, noises, ts, acts_list = self.recon_multistep_denoise(
             mon_loss_dict, P, x_start0, noise, t, subj_context, cls_context, uncond_emb, img_mask, fg_mask, cfg_scale, num_denoising_steps,
             num_recon_priming_steps, normal_recon_on_pure_noise, enable_unet_attn_lora, enable_unet_ffn_lora, ffn_lora_adapter_name,
@@ -436,11 +434,7 @@ class CompReconLossesMixin:
         face_stats = self.normal_recon_face_images_on_noise_stats if normal_recon_on_pure_noise else self.normal_recon_face_images_on_image_stats
         for i in range(num_recon_priming_steps, num_denoising_steps):
             noise, noise_pred, x_recon, acts = noises[i], noise_preds[i], x_recons[i], acts_list[i]
-            self.cache_and_log_generations(self.decode_first_stage(x_recon), None, f"recon_{i}", subj_context[1], do_normalize=True)
-            noise_pred_cls = None
-            if cls_context is not None:
-                noise_pred_cls = noise_preds_cls[i]
-                self.cache_and_log_generations(self.decode_first_stage(x_recons_cls[i]), None, f"recon-cls_{i}", cls_context[1], do_normalize=True)
+            noise_pred_cls = noise_preds_cls[i] if cls_context is not None else None
             pred_l2s.append((noise_pred ** 2).mean())
             if self.arcface_align_loss_weight > 0:
                 la, _, lb, boxes, _, found = self.calc_arcface_align_loss(x_start, x_recon, fg_faces_grad_mask_ratios=(1, 0.3))

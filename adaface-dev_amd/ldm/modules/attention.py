@@ -291,9 +291,12 @@ class BasicTransformerBlock(nn.Module):
     def hip(self, x2d, B, N, context=None, keybias=None):
         """attention.py:242-252 with the three residual adds fused into GEMM epilogues."""
         if FOLD_LAYERNORM and x2d.shape[1] % 64 == 0:
-            # the three LayerNorms never run as kernels: each is folded into the projection GEMM that consumes it
-            x1 = self.attn1.hip(x2d, B, N, None, keybias, residual=x2d, ln=self.norm1)
-            x2 = self.attn2.hip(x1, B, N, context, None, residual=x1, ln=self.norm2)
+            # the LayerNorms do not run as kernels: each is folded into the projection GEMM that consumes it.  Below ~1,000 rows (the
+            # 8 x 8 level) the q | k | v and to_q GEMMs sit on the register-staged 64 x 64 tile, which has no fold, and a 3.8 us LayerNorm
+            # is cheaper than moving them to a whole-line tile (profiles/r03d_lnfold_runtime_flag.txt: +2.5 .. +4.0 us folded)
+            small = x2d.shape[0] < 1024
+            x1 = self.attn1.hip(self.norm1.hip(x2d) if small else x2d, B, N, None, keybias, residual=x2d, ln=None if small else self.norm1)
+            x2 = self.attn2.hip(self.norm2.hip(x1) if small else x1, B, N, context, None, residual=x1, ln=None if small else self.norm2)
             return self.ff.hip(x2, residual=x2, ln=self.norm3)
         x1 = self.attn1.hip(self.norm1.hip(x2d), B, N, None, keybias, residual=x2d)
         x2 = self.attn2.hip(self.norm2.hip(x1), B, N, context, None, residual=x1)

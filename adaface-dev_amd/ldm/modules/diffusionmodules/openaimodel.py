@@ -681,13 +681,14 @@ class _UNetFunction(torch.autograd.Function):
                        tuple(id(a) for _, _, _, a in lora_param_order(lora)), ctx.need_dx)
             # a second forward of the same signature before this node's backward (batch_student_steps=False: one student call per
             # denoising step) must not replay into the buffers this node still needs: GraphedSegment.busy -> that call runs eagerly
-            busy = graphs[0].busy(ctx.key)
+            from_graph = not graphs[0].busy(ctx.key) and graphs[0].entries.get(ctx.key, {}).get("state") in ("warm", "graph")
             out, ctx.saved = graphs[0].run(ctx.key, body, [x.detach(), timesteps, context.detach(), img_mask],
                                            refresh=lambda: _refresh_adapter_packs(lora))
-            if busy:
-                ctx.key = None                                    # an eager fallback runs its backward eagerly too
+            if not from_graph:
+                ctx.key = None                # eager forward (first call of a signature, or the graph's buffers were held): its saved
+                                              # activations are ordinary tensors, so its backward must not be captured / replayed either
             elif any(ctx.needs_input_grad):
-                graphs[0].claim(ctx.key, ctx)                     # (no-op until the key is a captured graph)
+                graphs[0].claim(ctx.key, ctx)
         else:
             ctx.key = None
             out, ctx.saved = body(x.detach(), timesteps, context.detach(), img_mask)

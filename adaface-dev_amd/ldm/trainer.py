@@ -377,16 +377,17 @@ class DistillTrainer:
 
     # ------------------------------------------------------------------ which iteration a micro-batch is (ddpm.py:451-470)
     comp_distill_iter_gap = 0          # reference default 5 (ddpm.py:82) when Stage 2 is on; 0 = never, as DDPM treats <= 0
-    unet_distill_iter_gap = 0          # v1-distill-arc2face-ada.yaml:28 sets 2 (every 2nd non-comp iteration distils, the others reconstruct);
+    unet_distill_iter_gap = 0          # v1-distill-arc2face-ada.yaml:28 sets 2 (every 2nd non-comp micro-batch distils, the others reconstruct);
                                        # 0 here = this trainer's historical behaviour: the ``stage`` argument fixes one iteration type
     non_comp_iters_count = 0
     normal_recon_iters_count = 0
 
     def schedule_iteration(self):
-        """The reference's iteration typing, keyed on the OPTIMIZER step like the reference (so the two micro-batches of an accumulation
-        window share a type): every ``comp_distill_iter_gap``-th step is compositional distillation; of the others every
-        ``unet_distill_iter_gap``-th is U-Net distillation and the rest normal recon.  With both gaps 0 the constructor's ``stage``
-        decides (iter_type)."""
+        """The reference's iteration typing (ddpm.py:451-470): a micro-batch whose OPTIMIZER step is a multiple of
+        ``comp_distill_iter_gap`` is compositional distillation (so both micro-batches of such an accumulation window are); every other
+        micro-batch bumps ``non_comp_iters_count``, and every ``unet_distill_iter_gap``-th of THOSE is U-Net distillation, the rest
+        normal recon -- with the yaml's gap of 2 recon and distillation micro-batches alternate, one of each per accumulation window.
+        With both gaps 0 the constructor's ``stage`` decides (iter_type)."""
         if self.comp_distill_iter_gap <= 0 and self.unet_distill_iter_gap <= 0:
             return self.iter_type
         if self.comp_distill_iter_gap > 0 and self.global_step % self.comp_distill_iter_gap == 0:

@@ -142,8 +142,25 @@ def run_train(args, ctx, dev, stage=1):
         rng.load_synth_weights(vae, seed=6, on_device=True)
         rng.load_synth_weights(face_net.to(dev), seed=7, on_device=True)
         ldm.arcface = ArcFaceWrapper(face_net.eval(), FaceCropper(lambda img, T=20: [(144.0, 128.0, 224.0, 224.0, 0.995)]))
+    if stage == 1 and not args.distill_only:
+        # the reference's Stage-1 iteration mix (v1-distill-arc2face-ada.yaml:28 unet_distill_iter_gap: 2): micro-batches alternate
+        # do_normal_recon / do_unet_distill.  A recon iteration needs the null-prompt embedding (CFG), and -- arcface_align_loss_weight
+        # 0.01, the reference default, without which its per-step losses do not exist (ddpm.py:2702) -- the VAE decoder and the
+        # ArcFace wrapper; a fixed face box stands in for the RetinaFace detector network (an external package)
+        from adaface_dev_amd.evaluation.arcface_resnet import resnet_face18
+        from adaface_dev_amd.ldm.modules.arcface_wrapper import ArcFaceWrapper, FaceCropper
+        ldm.uncond_context = (rng.synth_input("bench.uncond", (1, 97, 768), seed=5).to(dev), [""], {})
+        with rng.skip_default_init():
+            vae = ldm.instantiate_first_stage()
+            face_net = resnet_face18()
+        vae.to(dev)
+        rng.load_synth_weights(vae, seed=6, on_device=True)
+        rng.load_synth_weights(face_net.to(dev), seed=7, on_device=True)
+        ldm.arcface = ArcFaceWrapper(face_net.eval(), FaceCropper(lambda img, T=20: [(144.0, 128.0, 224.0, 224.0, 0.995)]))
     tr = DistillTrainer(ldm, id2ada.to(dev), text_enc.to(dev), batch_size=B, accumulate_grad_batches=2, prompt_len=97, stage=stage,
                         use_graphs=not args.no_train_graphs)
+    if stage == 1 and not args.distill_only:
+        tr.unet_distill_iter_gap = 2
     n_train = sum(a.numel for a in tr.arenas)
 
     def batch(i):
@@ -171,6 +188,17 @@ def run_train(args, ctx, dev, stage=1):
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    per_type = None
+    if stage == 1 and not args.distill_only:
+        # the mix's two iteration types timed one micro-batch at a time (synchronised), after the timed region: 8 more micro-batches
+        acc = {}
+        for i in range(8):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            tr.training_step(batches[i % 4], warm + steps + i)
+            torch.cuda.synchronize()
+            acc.setdefault(tr.last_iter_type, []).append((time.perf_counter() - t1) * 1e3)
+        per_type = {k: {"micro_batches": len(v), "ms_per_micro_batch": round(sum(v) / len(v), 2)} for k, v in acc.items()}
     fam = None
     if not args.no_roofline:
         # every rank runs the instrumented micro-batches (the gradient exchange is a collective); rank 0 reports its families
@@ -178,7 +206,7 @@ def run_train(args, ctx, dev, stage=1):
         ops.prof_reset()
         ops.prof_enable(True)
         for i in range(6):                             # one full 2,3,4-step cycle twice over (6 micro-batches)
-            tr.training_step(batches[i % 4], warm + steps + i, **step_kw)
+            tr.training_step(batches[i % 4], warm + steps + 8 + i, **step_kw)
         torch.cuda.synchronize()
         ops.prof_enable(False)
         fam = {}
@@ -201,6 +229,17 @@ def run_train(args, ctx, dev, stage=1):
         workload = (f"stage1_unet_distill micro-batch: bs={B}/GPU, 512x512 (latent 64x64), 97 context tokens, denoising steps cycle 2,3,4 "
                     "with HALF_BS=ceil(bs/steps), teacher+student SD-1.5 U-Nets, 3 CLIP-L encoders, "
                     f"{n_train} trainable fp32 params, accumulate_grad_batches=2, CAdamW")
+        if stage == 1 and not args.distill_only:
+            # a recon micro-batch on images: 2 denoising steps x (student fwd + bwd on bs 4, its CFG null pass, the class-prompt pass and
+            # its null pass) = 2 x 20 sample-forward equivalents; on pure noise (p = 0.4) four no-grad priming steps (16 each) come first
+            recon_fwd = 0.6 * 40 + 0.4 * (4 * 16 + 40)
+            train_tflop = 0.5 * train_tflop + 0.5 * recon_fwd * 0.80496
+            what = (f"mean over the reference's Stage-1 iteration mix (micro-batches alternate normal recon / U-Net distillation): "
+                    f"{train_tflop:.1f} TFLOP algorithmic per micro-batch on average (U-Net passes only; the recon iterations' VAE decodes and "
+                    "ResNetFace-18 passes are not counted) / wall time")
+            workload = ("the reference's Stage-1 iteration mix, unet_distill_iter_gap = 2 (v1-distill-arc2face-ada.yaml:28): micro-batches alternate "
+                        f"do_normal_recon (bs {B}: 2 denoising steps with CFG + class-prompt passes + capture of layers 22-24, on the images or, p = 0.4, "
+                        "from pure noise after 4 priming steps; x0 decoded for the face pipeline) and do_unet_distill (" + workload + ")")
         if stage == 2:
             # priming: 3.5 steps x (positive + negative pass at batch 2) = 14 sample forwards; student: 4 steps x (SS + SR + SC + MC
             # + 4 unconditional = 8 sample forwards, the SC pass -- SC and MC when the scores are mixed -- also backward: ~1.5)
@@ -219,7 +258,8 @@ def run_train(args, ctx, dev, stage=1):
                           "parallelism": f"dp{world} (RCCL bucketed all-reduce overlapped with backward)" if world > 1 else "single GPU",
                           "hipgraph_segments": [f"{g.name}: {sum(1 for e in g.entries.values() if e.get('state') == 'graph')} captured" for g in tr.graph_segments],
                           "optimizer_steps": tr.global_step, "skipped_steps": tr.skipped_steps, "loss_scale": tr.scaler.scale,
-                          "last_loss": float(losses[-1]), "finite": bool(all(torch.isfinite(l) for l in losses))},
+                          "last_loss": float(losses[-1]), "finite": bool(all(torch.isfinite(l) for l in losses)),
+                          "per_iteration_type": per_type},
                "roofline": {"bound": "mfma", "achieved": round(train_tflop / (ms * 1e-3), 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                             "frac": round(train_tflop / (ms * 1e-3) / MFMA_PEAK_TFLOPS, 4), "traffic": None,
                             "what": what},
@@ -238,7 +278,7 @@ def cross_attn_block_time(unet, ctx2, B, dev):
     ``CrossAttention.hip`` launches per layer) are timed in isolation -- 10 calls captured in a hipGraph, inputs resident -- plus ONE
     launch of the batched k / v projection of all layers.  The algorithmic work (32.1 GFLOP per U-Net sample) over the summed time
     is priced against the dense fp16 MFMA peak; the core alone is the HBM-bound ``cross_attn_core`` entry above."""
-    from adaface_dev_amd.ldm.modules.attention import SpatialTransformer
+    from adaface_dev_amd.ldm.modules.attention import FOLD_LAYERNORM, SpatialTransformer
 
     def timed(fn, reps=10):
         fn()
@@ -275,14 +315,15 @@ def cross_attn_block_time(unet, ctx2, B, dev):
                         if C == 1280 and module is unet.middle_block:
                             N = 64
                         x = torch.randn(n * N, C, device=dev).half()
-                        ms = timed(lambda a2=a2, x=x, N=N: a2.hip(x, n, N, ctx2, None, residual=x))
+                        ln = layer.transformer_blocks[0].norm2 if FOLD_LAYERNORM else None       # what the step launches: norm2 folded into to_q
+                        ms = timed(lambda a2=a2, x=x, N=N, ln=ln: a2.hip(x, n, N, ctx2, None, residual=x, ln=ln))
                         per_layer.append((C, N, round(ms * 1e3, 1)))
                         tot += ms
         for m in layers:
             m._kv_pre = None
     tf = XATTN_BLOCK_GFLOP_PER_SAMPLE * 1e9 * n / (tot * 1e-3) / 1e12
     return {"ms_per_step": round(tot, 4), "kv_projection_ms": round(t_kv, 4), "tflops": round(tf, 1), "mfma_frac": round(tf / MFMA_PEAK_TFLOPS, 4),
-            "definition": "sum over the 16 attn2 blocks of [to_q GEMM + 77-key attention core + to_out GEMM with residual] + one batched "
+            "definition": "sum over the 16 attn2 blocks of [to_q GEMM (norm2 folded in) + 77-key attention core + to_out GEMM with residual] + one batched "
                           "k/v projection, each timed in isolation (hipGraph of 10 calls); 32.1 GFLOP per U-Net sample (SURVEY.md 8d)",
             "layers_C_N_us": per_layer}
 
@@ -524,6 +565,7 @@ def main():
     ap.add_argument("--no-ffn-lora", action="store_true", help="train leg: without the U-Net's trainable FFN DoRA adapters")
     ap.add_argument("--train-steps", type=int, default=12, help="timed micro-batches of the train leg")
     ap.add_argument("--train-warmup", type=int, default=12, help="untimed micro-batches (the hipGraph segments of every signature are captured in here)")
+    ap.add_argument("--distill-only", action="store_true", help="train leg: every micro-batch a U-Net distillation iteration (rounds 1-2's leg) instead of the reference's recon / distill mix")
     ap.add_argument("--no-train-graphs", action="store_true", help="train leg: launch every kernel from Python instead of replaying captured segments")
     ap.add_argument("--mode", choices=["all", "denoise", "train", "train2"], default="all",
                     help="all (default): the headline denoise line (BASELINE configs[1]) carrying the Stage-1 training leg "

@@ -627,8 +627,8 @@ def test_graph_replay_is_not_reentered_while_its_buffers_are_held(dev):
 
 def test_iteration_scheduler_and_normal_recon_iteration(dev):
     """The reference's iteration typing (ddpm.py:451-470) and the do_normal_recon iteration (ddpm.py:2296-2352, 2593-2883) on the HIP
-    path at reduced width.  With unet_distill_iter_gap = 2 (v1-distill-arc2face-ada.yaml:28) non-compositional optimizer steps
-    alternate normal recon / U-Net distillation, both micro-batches of an accumulation window sharing the type; a recon micro-batch
+    path at reduced width.  With unet_distill_iter_gap = 2 (v1-distill-arc2face-ada.yaml:28) non-compositional micro-batches
+    alternate normal recon / U-Net distillation (non_comp_iters_count counts micro-batches); a recon micro-batch
     (two denoising steps with CFG against the null prompt, class-prompt passes, captured attention for the subject-attention
     suppression, the decoded x0 handed to the face pipeline) gives a finite loss with its monitors and moves the parameters."""
     from adaface_dev_amd import rng
@@ -640,7 +640,7 @@ def test_iteration_scheduler_and_normal_recon_iteration(dev):
     for i in range(8):
         b = dict(x_start=rng.synth_input(f"dp.x{i % 2}", (4, 4, 32, 32), seed=48).to(dev), face_id_embs=rng.synth_input(f"dp.id{i % 2}", (4, 512), seed=48).to(dev),
                  fg_mask=torch.ones(4, 1, 32, 32, device=dev))
-        kw = dict(on_pure_noise=(i == 5)) if (i // 2) % 2 == 0 else {}
+        kw = dict(on_pure_noise=(i == 4)) if i % 2 == 0 else {}             # even micro-batches are the recon ones (asserted below)
         l = tr.training_step(b, i, **kw)
         kinds.append(tr.last_iter_type)
         assert torch.isfinite(l), (i, kinds)
@@ -648,7 +648,7 @@ def test_iteration_scheduler_and_normal_recon_iteration(dev):
             mon = tr.mon_loss_dict
             for k in ("pred_l2", "loss_recon_cls", "normal_recon_total", "recon_face_images_on_image_frac"):
                 assert f"train/{k}" in mon, (k, sorted(mon))
-    assert kinds == ["normal_recon"] * 2 + ["unet_distill"] * 2 + ["normal_recon"] * 2 + ["unet_distill"] * 2, kinds
+    assert kinds == ["normal_recon", "unet_distill"] * 4, kinds
     assert tr.global_step + tr.skipped_steps == 4 and tr.global_step >= 2
     assert float((tr.arenas[0].flat_p - p0).abs().sum()) > 0
 
@@ -734,12 +734,28 @@ def test_full_size_bs4_train_step_of_the_bench_leg(dev):
     taken, none skipped, graphs captured."""
     import argparse
     import bench
-    ns = argparse.Namespace(batch=4, no_ffn_lora=False, no_train_graphs=False, train_steps=4, train_warmup=2, no_roofline=True)
+    ns = argparse.Namespace(batch=4, no_ffn_lora=False, no_train_graphs=False, train_steps=4, train_warmup=2, no_roofline=True, distill_only=True)
     out = bench.run_train(ns, (1, 0, 0, False), dev, stage=1)
     cfg = out["config"]
     assert cfg["finite"] and cfg["skipped_steps"] == 0 and cfg["optimizer_steps"] == 3, cfg
     assert out["n_gpus"] == 1 and out["steps"] == 4 and out["value"] > 0
     assert any("captured" in s and not s.endswith(" 0 captured") for s in cfg["hipgraph_segments"]), cfg["hipgraph_segments"]
+
+
+def test_full_size_stage1_iteration_mix_and_stage2_step_of_the_bench_legs(dev):
+    """BASELINE configs[2] with the reference's iteration mix (normal recon / U-Net distillation alternating per optimizer step) and
+    configs[4] (Stage-2 compositional distillation, bs 3, dual U-Net, the whole loss assembly with decoded x0 predictions) at FULL size
+    through bench.py's own construction code: finite losses, optimizer steps taken, both iteration types met."""
+    import argparse
+    import bench
+    ns = argparse.Namespace(batch=4, no_ffn_lora=False, no_train_graphs=False, train_steps=4, train_warmup=4, no_roofline=True, distill_only=False)
+    out = bench.run_train(ns, (1, 0, 0, False), dev, stage=1)
+    cfg = out["config"]
+    assert cfg["finite"] and cfg["optimizer_steps"] + cfg["skipped_steps"] == 8, cfg
+    assert cfg["optimizer_steps"] >= 6 and set(cfg["per_iteration_type"]) == {"normal_recon", "unet_distill"}, cfg
+    out2 = bench.run_train(ns, (1, 0, 0, False), dev, stage=2)
+    cfg2 = out2["config"]
+    assert cfg2["finite"] and out2["value"] > 0 and cfg2["optimizer_steps"] >= 3, cfg2
 
 
 def test_bench_train_leg_under_the_launcher_with_rccl_and_graph_replay(dev):

@@ -169,7 +169,7 @@ def main():
     for stage in [s for s, on in ((1, args.bench_train), (2, args.bench_train2)) if on]:
         # exactly the micro-batches bench.py times (its own model construction), eager, six of them = two 2,3,4-step cycles
         import bench
-        ns = argparse.Namespace(batch=4, no_ffn_lora=False, no_train_graphs=True, train_steps=6, train_warmup=2, no_roofline=True)
+        ns = argparse.Namespace(batch=4, no_ffn_lora=False, no_train_graphs=True, train_steps=6, train_warmup=2, no_roofline=True, distill_only=False)
         bench.run_train(ns, (1, 0, 0, False), dev, stage=stage)
         torch.cuda.synchronize()
     if args.vae:

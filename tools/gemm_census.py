@@ -62,7 +62,7 @@ def main():
             unet(x, torch.full((8,), 500, device=dev), ctx, extra_info=None)
             on[0] = False
     else:
-        ns = argparse.Namespace(batch=4, no_ffn_lora=False, no_train_graphs=True, train_steps=n_mb, train_warmup=2, no_roofline=True)
+        ns = argparse.Namespace(batch=4, no_ffn_lora=False, no_train_graphs=True, train_steps=n_mb, train_warmup=2, no_roofline=True, distill_only=False)
         bench.run_train(ns, (1, 0, 0, False), torch.device("cuda:0"), stage=args.stage)
     tot_us = 0.0
     rows = []
