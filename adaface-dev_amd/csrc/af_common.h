@@ -77,3 +77,38 @@ __device__ __forceinline__ float af_wave_max(float v) {
   for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
   return v;
 }
+
+// ---- weight-tile prefetch into the XCD's L2 (used by the GEMM kernels at kernel start) ---------------------------------------------------
+// Inside a denoise / training step every GEMM meets its weights cold in HBM (1.72 GB of weights are read once per U-Net pass) while
+// the operand pipelines request a K stage only ~one stage (~0.3 us) before it is needed, so the first workgroup of an XCD to touch a
+// weight line pays the HBM latency at EVERY stage (profiles/r01w_cold_operands.txt: 7.99 ms with hot operands vs 9.41 ms with cold
+// weights per step).  The workgroups that share a weight tile (same tile_n, consecutive tile_m: neighbours on one XCD under the
+// XCD-aware tile mapping) each touch a 1 / coop share of its 128-byte lines once, right at kernel start: one dword per line, 64 lines
+// per wave instruction, earliest K stages first, at most `budget` instructions per wave.  The loads are older than the first
+// stage's operand loads, so that stage's wait covers them; their data is never used, but the destination registers (`sink`) must
+// stay allocated until then (the caller keeps them alive past its main loop).  Measured: 12.31 -> 11.61 ms per denoise step
+// (profiles/r03h_weight_prefetch.txt).
+constexpr int AF_WPF_MAX = 8;
+__device__ __forceinline__ void af_prefetch_weight_tile(const half_t* wt, int kpad, int npad, int row0, int rows, int kt0, int nk, int coop, int me,
+                                                        int budget, int nw, int wave, int lane, unsigned (&sink)[AF_WPF_MAX]) {
+  const int total = rows * nk;                                   // 128-byte lines (64 halves) of these weight rows over this K range
+  const int per = (total + coop - 1) / coop;
+  const int begin = me * per;
+  const int end = min(total, begin + min(per, budget * nw * 64));
+#pragma unroll
+  for (int j = 0; j < AF_WPF_MAX; ++j) {
+    const int line = begin + (j * nw + wave) * 64 + lane;
+    if (j < budget && line < end) {
+      const int st = line / rows, row = line - st * rows;        // stage-major: the first lines cover stage 0 of every row
+      const int n = row0 + row;
+      if (n < npad) {
+        const half_t* a = wt + (size_t)n * kpad + (size_t)(kt0 + st) * 64;
+        asm volatile("global_load_dword %0, %1, off" : "+v"(sink[j]) : "v"(a) : "memory");
+      }
+    }
+  }
+}
+__device__ __forceinline__ void af_prefetch_keep(unsigned (&sink)[AF_WPF_MAX]) {
+#pragma unroll
+  for (int j = 0; j < AF_WPF_MAX; ++j) asm volatile("" ::"v"(sink[j]));
+}

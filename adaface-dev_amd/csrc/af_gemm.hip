@@ -50,6 +50,7 @@ struct GemmDev {
   float* ws;                 // fp32 partials [splits][M][N] when splits > 1
   int* counters;             // in-kernel split-K reduction: per-tile arrival counters (zero between launches); nullptr = reduce pass
   int out_f32;               // AF_OUT_F32: the reduce pass stores fp32
+  int wpf, wpf_coop;         // weight-tile L2 prefetch at kernel start (af_common.h): instructions per wave (0 = off), sharing workgroups
 };
 
 constexpr int BK = 64;
@@ -248,6 +249,10 @@ __global__ __launch_bounds__(256, 2) void af_gemm_kernel(GemmDev p) {
     }
   };
 
+  unsigned wpf_sink[AF_WPF_MAX] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+  if (p.wpf > 0)
+    af_prefetch_weight_tile(p.wt, p.kpad, (p.N + 127) / 128 * 128, tile_n * BN, BN, kt_begin, kt_end - kt_begin, p.wpf_coop, tile_m % p.wpf_coop,
+                            p.wpf, 4, tid >> 6, tid & 63, wpf_sink);
   load_tile(kt_begin);
   store_tile(0);
   __syncthreads();
@@ -259,6 +264,7 @@ __global__ __launch_bounds__(256, 2) void af_gemm_kernel(GemmDev p) {
     if (more) store_tile(buf ^ 1);
     __syncthreads();
   }
+  af_prefetch_keep(wpf_sink);
 
   // ---- split-K: raw fp32 partial tile to the workspace; af_splitk_reduce applies the epilogue
   if (EPI == EPI_STD && p.splits > 1) {
@@ -455,6 +461,12 @@ int launch(const GemmDev& p0, hipStream_t stream) {
   p.tiles_n = (p.N + BN - 1) / BN;
   p.tiles_m = tiles_m;
   p.n_major = af_gemm_n_major(p.M, p.N, p.K, TAPS == 9 ? p.c1 + p.c2 : p.K);
+  {
+    static const int wpf_env = getenv("AF_GEMM3_WPREFETCH") ? atoi(getenv("AF_GEMM3_WPREFETCH")) : 4;
+    static const int coop_env = getenv("AF_GEMM3_WPF_COOP") ? atoi(getenv("AF_GEMM3_WPF_COOP")) : 32;
+    p.wpf = wpf_env > AF_WPF_MAX ? AF_WPF_MAX : wpf_env;
+    p.wpf_coop = tiles_m < coop_env ? tiles_m : coop_env;
+  }
   const int nk = p.kpad / BK;
   if (p.splits > nk) p.splits = nk;
   p.kt_per_split = (nk + p.splits - 1) / p.splits;

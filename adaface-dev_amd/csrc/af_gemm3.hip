@@ -685,32 +685,11 @@ __global__ __launch_bounds__(64 * NWM * NWN, (NWM * NWN == 4 && NSLOT == 2) ? 2 
   const int kt_end = min(nk_total, kt_begin + p.kt_per_split);
   const int nk = kt_end - kt_begin;
 
-  // Weight-tile prefetch into this XCD's L2.  Inside the step every GEMM meets its weights cold in HBM (1.72 GB are read once per
-  // step) and the two-slot ring requests a stage only one stage (~0.3 us) before it is needed, so the first workgroup of an XCD to
-  // touch a weight line pays the HBM latency at EVERY stage (profiles/r01w: 7.99 ms hot vs 9.41 ms with cold weights per step).  The
-  // workgroups that share a weight tile (same tile_n, consecutive tile_m: neighbours on one XCD under the tile mapping above) each
-  // touch a 1/coop share of its lines once, right now: one dword per 128-byte line, 64 lines per wave instruction, earliest K stages
-  // first.  The loads land before the first stage's wait (they are older than its DMA pieces); their data is never used.
-  constexpr int WPF_MAX = 2;
-  unsigned wpf_sink[WPF_MAX] = {0u, 0u};                         // destinations of the prefetch loads: must stay allocated until they have landed
-  if (p.wpf > 0) {
-    const int total = BN * nk;                                   // 128-byte lines of this tile's weight rows over this K split
-    const int per = (total + p.wpf_coop - 1) / p.wpf_coop;
-    const int begin = (tile_m % p.wpf_coop) * per;
-    const int end = min(total, begin + min(per, p.wpf * NW * 64));
-#pragma unroll
-    for (int j = 0; j < WPF_MAX; ++j) {
-      const int line = begin + (j * NW + wave) * 64 + lane;
-      if (j < p.wpf && line < end) {
-        const int st = line / BN, row = line - st * BN;          // stage-major: the first lines cover stage 0 of every row
-        const int n = tile_n * BN + row;
-        if (n < p.npad) {
-          const half_t* a = p.wt + (size_t)n * p.kpad + (size_t)(kt_begin + st) * BKW;
-          asm volatile("global_load_dword %0, %1, off" : "+v"(wpf_sink[j]) : "v"(a) : "memory");
-        }
-      }
-    }
-  }
+  // weight-tile prefetch into this XCD's L2 (af_common.h): the tile's weight rows over this K split, shared out among the
+  // workgroups with the same tile_n
+  unsigned wpf_sink[AF_WPF_MAX] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+  if (p.wpf > 0)
+    af_prefetch_weight_tile(p.wt, p.kpad, p.npad, tile_n * BN, BN, kt_begin, nk, p.wpf_coop, tile_m % p.wpf_coop, p.wpf, NW, wave, lane, wpf_sink);
 
   // NSLOT - 1 stages are in flight ahead of the one being computed (NSLOT = 2: the shipped tiles; NSLOT = 4: the deep-ring variants for
   // grids of at most one workgroup per CU, where nothing else hides the L2 / HBM latency of a stage -- the 16x16 level's GEMMs)
@@ -796,8 +775,7 @@ __global__ __launch_bounds__(64 * NWM * NWN, (NWM * NWN == 4 && NSLOT == 2) ? 2 
       if (kk == 0 && late_dma && i + NSLOT - 1 < nk) issue_stage(kt_begin + i + NSLOT - 1, (i + NSLOT - 1) % NSLOT);
     }
   }
-#pragma unroll
-  for (int j = 0; j < WPF_MAX; ++j) asm volatile("" ::"v"(wpf_sink[j]));     // (the loop's waits drained the prefetch loads long ago)
+  af_prefetch_keep(wpf_sink);                  // (the loop's waits drained the prefetch loads long ago)
   const float* lnst = nullptr;
   if (ln_on) {
     // row statistics -> LDS behind the ring (BM x (mean, rstd)); every wave of the row group reads them in the epilogue
@@ -833,7 +811,11 @@ bool launch3w(const Gemm3Dev& p0, hipStream_t stream) {
   static_assert(NSLOT == 2 || NSLOT == 4, "ring depths built: 2 and 4 (the counted waits cover at most two younger stages)");
   p.tiles_n = (p.N + BN - 1) / BN;
   p.tiles_m = (p.M + BM - 1) / BM;
-  p.wpf_coop = p.tiles_m < 32 ? p.tiles_m : 32;
+  {
+    static const int coop_env = getenv("AF_GEMM3_WPF_COOP") ? atoi(getenv("AF_GEMM3_WPF_COOP")) : 32;
+    p.wpf_coop = p.tiles_m < coop_env ? p.tiles_m : coop_env;
+    if (p.wpf > AF_WPF_MAX) p.wpf = AF_WPF_MAX;
+  }
   if (p.counters && (TN > 5 || p.splits <= 1 || p.splits > 4 || p.tiles_m * p.tiles_n > AF_SPLITK_MAX_TILES)) p.counters = nullptr;
   p.n_major = af_gemm_n_major(p.M, p.N, p.K, TAPS == 9 ? p.c1 + p.c2 : p.K);
   static bool attr_set = false;
@@ -919,9 +901,9 @@ int af_gemm3_try_launch(const af_gemm_desc* d, int splits, int wide, hipStream_t
   // in-kernel split-K reduction (af_gemm_desc.splitk_fused): the last AF_SPLITK_COUNTER_BYTES of the workspace are the tile counters
   p.counters = (d->splitk_fused && d->workspace && d->workspace_bytes > AF_SPLITK_COUNTER_BYTES)
                    ? reinterpret_cast<int*>(static_cast<char*>(d->workspace) + d->workspace_bytes - AF_SPLITK_COUNTER_BYTES) : nullptr;
-  static const int wpf_env = getenv("AF_GEMM3_WPREFETCH") ? atoi(getenv("AF_GEMM3_WPREFETCH")) : 0;
+  static const int wpf_env = getenv("AF_GEMM3_WPREFETCH") ? atoi(getenv("AF_GEMM3_WPREFETCH")) : 4;
   static const bool wpf_dynamic = getenv("AF_GEMM3_ABLATE_DYNAMIC") != nullptr;
-  p.wpf = wpf_dynamic ? (getenv("AF_GEMM3_WPREFETCH") ? atoi(getenv("AF_GEMM3_WPREFETCH")) : 0) : wpf_env;
+  p.wpf = wpf_dynamic ? (getenv("AF_GEMM3_WPREFETCH") ? atoi(getenv("AF_GEMM3_WPREFETCH")) : 4) : wpf_env;
   p.wpf_coop = 1;
   static const int ablate = getenv("AF_GEMM3_ABLATE") ? atoi(getenv("AF_GEMM3_ABLATE")) : 0;
   static const bool ablate_dynamic = getenv("AF_GEMM3_ABLATE_DYNAMIC") != nullptr;   // experiments: re-read per call (in-process A/B)

@@ -10,7 +10,11 @@ Replaces what Lightning's ``strategy="ddp"`` (reference main.py:618) does implic
   default 32 MB -- 0.48 GB of gradients = 15 collectives of ~0.2 ms each at ring bandwidth, large enough to be
   bandwidth- rather than latency-bound, small enough that the first one starts early in the backward;
 * a bucket's all-reduce is launched (async, on RCCL's own stream) from the post-accumulate-grad hook of the LAST
-  of its parameters to become ready, i.e. while the U-Net's activation-gradient backward is still running;
+  of its parameters to become ready.  What that overlaps with, precisely: the trainable set sits at the END of the backward --
+  the U-Net's activation-gradient walk is one autograd node, its FFN-adapter gradients leave it only when it finishes, and the
+  85 M SubjBasisGenerator weights receive theirs while the text encoder / generator layers behind it are being walked -- so the
+  collectives hide under that encoder tail (a few ms) and the rest is waited for in ``finish()``.  At 0.36 GB per optimizer step
+  (~2.5 ms of ring time at xGMI bandwidth, once per two micro-batches of ~60 ms) the exposed part is small either way;
 * collectives are ISSUED IN BUCKET-INDEX ORDER on every rank (bucket b only after buckets 0..b-1; buckets are numbered
   from the end of the arena, the order gradients become ready in): ranks whose graphs differ for one iteration
   (per-rank RNG flags, unused parameters) still pair the same buffers, the rest is flushed in order by ``finish()``;

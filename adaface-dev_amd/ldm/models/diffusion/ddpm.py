@@ -51,6 +51,9 @@ class UNetWrapper(nn.Module):
     def __init__(self, unet_config):
         super().__init__()
         self.diffusion_model = UNetModel(**unet_config)
+        for m in self.diffusion_model.modules():              # this wrapper is the LIVE path's seam: its processor's key-mask rule
+            if hasattr(m, "live_mask_rule"):
+                m.live_mask_rule = True
         self.use_attn_lora = False
         self.use_ffn_lora = False
         self.unet_lora_modules = nn.ModuleDict()

@@ -344,6 +344,19 @@ class SpatialTransformer(nn.Module):
         )
         self.proj_out = zero_module(Conv2d(inner_dim, in_channels, kernel_size=1, stride=1, padding=0))
 
+    # The LIVE attention processor (adaface/diffusers_attn_lora_capture.py:254-260) drops the self-attention key mask for the whole batch
+    # when, at this layer's resolution, ANY instance's mask is empty; the in-tree LDM U-Net (attention.py:188-194) keeps it and such
+    # an instance attends uniformly.  UNetWrapper (the live path's seam) switches this on; a bare UNetModel keeps LDM semantics.
+    live_mask_rule = False
+
+    def _keybias(self, mask, B, H, W):
+        m2 = F.interpolate(mask.float(), size=(H, W), mode="nearest")       # attention.py:298 / diffusers_attn_lora_capture.py:256-258
+        kb = ops.make_keybias(m2.reshape(B, H * W), H * W)
+        if self.live_mask_rule:
+            any_empty = (m2.sum(dim=(2, 3)) == 0).any()                      # stays on the device: no host decision, graph-capturable
+            kb = torch.where(any_empty, torch.zeros_like(kb), kb)
+        return kb
+
     def hip(self, x, context=None, mask=None):
         """x [B,H,W,C] fp16; context [B,L,Cc] fp16; mask [B,1,h0,w0] (nonzero = keep) or None."""
         B, H, W, Cn = x.shape
@@ -352,8 +365,7 @@ class SpatialTransformer(nn.Module):
         y = self.proj_in.hip(y).reshape(B * N, -1)
         kb = None
         if mask is not None:
-            m2 = F.interpolate(mask.float(), size=(H, W), mode="nearest")  # attention.py:298
-            kb = ops.make_keybias(m2.reshape(B, N), N)
+            kb = self._keybias(mask, B, H, W)
         for block in self.transformer_blocks:
             block.attn2.infeat_size = (H, W)
             y = block.hip(y, B, N, context, kb)
@@ -367,7 +379,7 @@ class SpatialTransformer(nn.Module):
         y = self.proj_in.hip(y).reshape(B * N, -1)
         kb = None
         if mask is not None:
-            kb = ops.make_keybias(F.interpolate(mask.float(), size=(H, W), mode="nearest").reshape(B, N), N)
+            kb = self._keybias(mask, B, H, W)
         bs = []
         for block in self.transformer_blocks:
             block.attn2.infeat_size = (H, W)

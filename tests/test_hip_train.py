@@ -758,6 +758,27 @@ def test_full_size_stage1_iteration_mix_and_stage2_step_of_the_bench_legs(dev):
     assert cfg2["finite"] and out2["value"] > 0 and cfg2["optimizer_steps"] >= 3, cfg2
 
 
+def test_bench_train_leg_on_two_gpus_over_rccl(dev):
+    """`bench.py --gpus 2 --mode train`: the launcher parent starts two ranks (one per GPU) under torch.distributed.run, RCCL with more
+    than one rank -- start-up broadcast, bucketed gradient all-reduces from the backward hooks, overflow all-reduce.  Skips on boxes
+    with a single GPU (every box this build has had); the first multi-GPU box exercises the N > 1 exchange."""
+    import json
+    import subprocess
+    import sys
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--mode", "train", "--train-steps", "4", "--train-warmup", "4",
+                        "--no-roofline", "--distill-only"], env=env, capture_output=True, text=True, timeout=1500, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["finite"] and out["config"]["parallelism"].startswith("dp2"), out
+    assert out["value"] > 0 and out["config"]["optimizer_steps"] >= 3
+
+
 def test_bench_train_leg_under_the_launcher_with_rccl_and_graph_replay(dev):
     """`bench.py --mode train` as the driver starts it for N > 1 -- under torch.distributed.run, backend nccl (= RCCL), here with one
     rank: process-group init, start-up broadcast, the gradient buckets' all-reduces issued from the backward hooks WHILE the student /
@@ -769,7 +790,7 @@ def test_bench_train_leg_under_the_launcher_with_rccl_and_graph_replay(dev):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
                         "--master-port", "29623", os.path.join(root, "bench.py"), "--gpus", "1", "--mode", "train", "--train-steps", "6",
-                        "--train-warmup", "6", "--no-roofline"], env=env, capture_output=True, text=True, timeout=900, cwd=root)
+                        "--train-warmup", "6", "--no-roofline", "--distill-only"], env=env, capture_output=True, text=True, timeout=900, cwd=root)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]

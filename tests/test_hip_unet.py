@@ -433,6 +433,39 @@ def test_guided_denoise_cfg_x0_grad_modes_vs_oracle(dev):
         ld.guided_denoise(x0.to(dev), noise.to(dev), t.to(dev), (ctx.to(dev), ["a", "b"], {}), normalize_cross_attn=True)
 
 
+def test_live_processor_drops_the_key_mask_when_an_instance_is_fully_masked(dev):
+    """The live attention processor (adaface/diffusers_attn_lora_capture.py:254-260) drops the self-attention key mask for the WHOLE
+    batch when, at a layer's resolution, any instance's mask is empty; the in-tree LDM U-Net keeps it (that instance then attends
+    uniformly, attention.py:188-194).  UNetWrapper -- the live path's seam -- follows the processor: with an all-zero mask on one
+    instance its eps equals the unmasked eps, while a bare UNetModel (LDM semantics, the oracle's) gives something else; a mask that
+    leaves every instance some keys is applied by both."""
+    from adaface_dev_amd import rng
+    from adaface_dev_amd.ldm.models.diffusion.ddpm import LatentDiffusion
+    ld = LatentDiffusion(GPU_TINY_CONFIG)
+    rng.load_synth_weights(ld.model.diffusion_model, seed=11)
+    ld = ld.to(dev)
+    x = rng.synth_input("t64.x", (2, 4, 32, 32), seed=11).to(dev)
+    ctx = rng.synth_input("t64.ctx", (2, 77, 64), seed=11).to(dev)
+    t = torch.tensor([10, 500], device=dev)
+    empty = torch.ones(2, 1, 32, 32, device=dev)
+    empty[1] = 0
+    partial = torch.ones(2, 1, 32, 32, device=dev)
+    partial[1, :, 16:, :] = 0
+    with torch.no_grad():
+        plain = ld.model(x, t, (ctx, ["a", "b"], {}))
+        live_empty = ld.model(x, t, (ctx, ["a", "b"], {"img_mask": empty}))
+        live_partial = ld.model(x, t, (ctx, ["a", "b"], {"img_mask": partial}))
+        unet = ld.model.diffusion_model
+        for m in unet.modules():
+            if hasattr(m, "live_mask_rule"):
+                m.live_mask_rule = False
+        ldm_empty = unet(x, t, ctx, extra_info={"img_mask": empty})
+        ldm_partial = unet(x, t, ctx, extra_info={"img_mask": partial})
+    assert rel_l2(live_empty.cpu().numpy(), plain.cpu().numpy()) < 5e-4     # mask dropped batch-wide (an all-zero bias: the general kernel, same values)
+    assert rel_l2(ldm_empty.float().cpu().numpy(), plain.float().cpu().numpy()) > 1e-2        # LDM semantics: uniform attention on instance 1
+    assert torch.equal(live_partial.float(), ldm_partial.float()) and rel_l2(live_partial.cpu().numpy(), plain.cpu().numpy()) > 1e-3
+
+
 def test_unet_wrapper_ffn_lora_flags_merge_and_restore(dev):
     """apply_model(use_ffn_lora=True, ffn_lora_adapter_name=...) runs the U-Net with the DoRA adapters of the six
     up_blocks.3 conv layers merged in (adaface/lora.py; merged weight == peft's branch form is pinned on CPU in

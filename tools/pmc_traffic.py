@@ -7,8 +7,8 @@ import json
 import sqlite3
 import sys
 
-FAMILIES = (("gemm", ("af_gemm", "af_splitk_reduce")), ("attn", ("af_attn", "af_xattn")), ("gnorm", ("gn_partial", "gn_apply")),
-            ("lnorm", ("layernorm_kernel",)))
+FAMILIES = (("gemm", ("af_gemm", "af_splitk_reduce")), ("attn", ("af_attn", "af_xattn", "attn_bwd", "attn_delta", "xattn_")),
+            ("gnorm", ("gn_partial", "gn_apply", "gn_small", "gn_pair", "gn_bwd")), ("lnorm", ("layernorm_kernel", "layernorm_bwd", "layernorm_param")))
 
 
 def per_family(db, counter):
@@ -34,6 +34,9 @@ def main():
     for f, _ in FAMILIES:
         n = fe[f][0]
         assert n == wr[f][0], (f, n, wr[f][0])
+        if n == 0:                            # e.g. lnorm once every LayerNorm is folded into its GEMM
+            res[f] = {"kernel_dispatches_per_step": 0.0, "read_bytes_per_step": 0.0, "write_bytes_per_step": 0.0, "bytes_per_step": 0.0}
+            continue
         rd = 2.0 * fe[f][1] * 1024.0          # gfx950: FETCH_SIZE reports half of a wide streaming read
         w = wr[f][1] * 1024.0
         res[f] = {"kernel_dispatches_per_step": n / steps, "read_bytes_per_step": rd / steps, "write_bytes_per_step": w / steps,
