@@ -461,7 +461,8 @@ def test_live_processor_drops_the_key_mask_when_an_instance_is_fully_masked(dev)
                 m.live_mask_rule = False
         ldm_empty = unet(x, t, ctx, extra_info={"img_mask": empty})
         ldm_partial = unet(x, t, ctx, extra_info={"img_mask": partial})
-    assert rel_l2(live_empty.cpu().numpy(), plain.cpu().numpy()) < 5e-4     # mask dropped batch-wide (an all-zero bias: the general kernel, same values)
+    # mask dropped batch-wide: an all-zero bias through the general attention kernel against the mask-free kernel -- two fp16 passes
+    assert rel_l2(live_empty.cpu().numpy(), plain.cpu().numpy()) < NET_TOL
     assert rel_l2(ldm_empty.float().cpu().numpy(), plain.float().cpu().numpy()) > 1e-2        # LDM semantics: uniform attention on instance 1
     assert torch.equal(live_partial.float(), ldm_partial.float()) and rel_l2(live_partial.cpu().numpy(), plain.cpu().numpy()) > 1e-3
 
