@@ -191,3 +191,40 @@ def linear(mod, x, residual=None):
 
 def layer_norm(mod, x):
     return LayerNormFn.apply(x, mod.weight, mod.bias, mod.eps)
+
+
+class MatmulNTFn(torch.autograd.Function):
+    """C [M, N] (fp32) = A [M, K] @ Bt [N, K]^T on the MFMA GEMM kernel (fp16 operands, fp32 accumulation and output, AF_OUT_F32), with
+    both input gradients: dA = dC @ Bt (af_gemm on the transposed pack), dBt = dC^T @ A (``wgrad``).  The incoming dC is a loss
+    gradient of arbitrary size, so it is normalised by a power of two on the device before its fp16 cast (largest entry ~ 256) and the
+    results are unscaled in fp32, as the U-Net's backward node does.  The Stage-2 feature-matching losses' [4096 x C] x [C x 4096]
+    products (reference ldm/util.py:2336-2344, 2269-2281) run through this on the GPU."""
+
+    @staticmethod
+    def forward(ctx, a, bt):
+        a16, bt16 = a.detach().to(F16).contiguous(), bt.detach().to(F16).contiguous()
+        ctx.save_for_backward(a16, bt16)
+        ctx.dtypes = (a.dtype, bt.dtype)
+        return ops.gemm(a16, ops.pack_matrix(bt16, None, a.device), out_f32=True)
+
+    @staticmethod
+    def backward(ctx, dc):
+        a16, bt16 = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        amax = dc.abs().amax().float().clamp_min(1e-30)
+        scale = torch.exp2(torch.floor(torch.log2(256.0 / amax)))
+        d16 = (dc.float() * scale).to(F16).contiguous()
+        da = dbt = None
+        if need[0]:
+            da = (ops.gemm(d16, ops.pack_matrix(bt16.t(), None, dc.device), out_f32=True) / scale).to(ctx.dtypes[0])
+        if need[1]:
+            dbt = (wgrad(d16, a16) / scale).to(ctx.dtypes[1])
+        return da, dbt
+
+
+def matmul_nt(a: torch.Tensor, bt: torch.Tensor) -> torch.Tensor:
+    """a [M, K] @ bt[N, K]^T -> fp32 [M, N]: the MFMA kernel for device tensors whose sizes it takes (K % 8 == 0, N % 4 == 0), plain torch
+    otherwise (host tensors: the CPU test-suite of the loss functions)."""
+    if a.is_cuda and a.shape[1] % 8 == 0 and bt.shape[0] % 4 == 0:
+        return MatmulNTFn.apply(a, bt)
+    return a.float() @ bt.float().t()

@@ -90,20 +90,20 @@ __device__ __forceinline__ float af_wave_max(float v) {
 // (profiles/r03h_weight_prefetch.txt).
 constexpr int AF_WPF_MAX = 8;
 __device__ __forceinline__ void af_prefetch_weight_tile(const half_t* wt, int kpad, int npad, int row0, int rows, int kt0, int nk, int coop, int me,
-                                                        int budget, int nw, int wave, int lane, unsigned (&sink)[AF_WPF_MAX]) {
+                                                        int budget, int nw, int wave, int lane, unsigned (&sink)[AF_WPF_MAX], int sink0 = 0) {
   const int total = rows * nk;                                   // 128-byte lines (64 halves) of these weight rows over this K range
   const int per = (total + coop - 1) / coop;
   const int begin = me * per;
   const int end = min(total, begin + min(per, budget * nw * 64));
 #pragma unroll
-  for (int j = 0; j < AF_WPF_MAX; ++j) {
+  for (int j = 0; j + sink0 < AF_WPF_MAX; ++j) {                  // (sink0: a second tile's loads use the sinks behind the first's)
     const int line = begin + (j * nw + wave) * 64 + lane;
     if (j < budget && line < end) {
       const int st = line / rows, row = line - st * rows;        // stage-major: the first lines cover stage 0 of every row
       const int n = row0 + row;
       if (n < npad) {
         const half_t* a = wt + (size_t)n * kpad + (size_t)(kt0 + st) * 64;
-        asm volatile("global_load_dword %0, %1, off" : "+v"(sink[j]) : "v"(a) : "memory");
+        asm volatile("global_load_dword %0, %1, off" : "+v"(sink[sink0 + j]) : "v"(a) : "memory");
       }
     }
   }

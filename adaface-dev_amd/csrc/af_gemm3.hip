@@ -829,6 +829,225 @@ bool launch3w(const Gemm3Dev& p0, hipStream_t stream) {
   return p.counters != nullptr;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Fused feed-forward of a transformer block at C = 320 (the 64 x 64 level: 4096 tokens per image):
+//     out = x + b2 + W2 ( v * gelu(g) ),   [v | g] = W1 LN(x) + b1                 (attention.py:31-58, 242-252)
+// in ONE launch per layer.  Unfused, the GEGLU projection writes a [tokens, 1280] intermediate (84 MB at U-Net batch 8) that the
+// second GEMM reads straight back, and both GEMMs are short-K (K = 320 / epilogue-heavy): 111 + 35 us per block in the step.
+// Here a workgroup owns 128 tokens for the whole feed-forward:
+//   * the token tile X [128 x 320] is brought into LDS once (80 KB, the five 64-wide K chunks of the whole-line layout) and its
+//     LayerNorm statistics are taken from it once (the norm itself is folded into W1 as in af_gemm_desc.ln_colsum);
+//   * the hidden dimension is walked in 20 chunks of 64 GEGLU outputs (128 interleaved W1 rows = per wave one value and one gate
+//     MFMA tile): GEMM1 streams the chunk's W1 rows through a two-slot ring (5 stages of 16 KB), its GEGLU epilogue leaves the
+//     chunk's activations G [128 x 64] in LDS as the next MFMA operand (in the ring slot the last stage has just left), and GEMM2
+//     accumulates OUT [128 x 320] += G W2[:, chunk]^T from a 40 KB tile of W2 that arrived under GEMM1;
+//   * OUT lives in registers across the chunks (80 VGPRs per wave) and leaves through the staged epilogue (bias, residual).
+// LDS: 80 (X) + 32 (W1 ring / G) + 40 (W2 tile) + 1 (row statistics) = 153 KB; 8 waves as 2 x 4.
+constexpr int FF_C = 320, FF_BM = 128, FF_HC = 64;              // channels, tokens per workgroup, GEGLU outputs per hidden chunk
+constexpr int FF_XS = 5 * FF_BM * 128, FF_W1S = 2 * FF_HC * 128, FF_W2B = FF_C * 128;
+constexpr int FF_LDS = FF_XS + 2 * FF_W1S + FF_W2B + FF_BM * 8;
+
+struct FfDev {
+  const half_t* x;
+  const half_t* w1;      // packed, GEGLU-interleaved [2 * inner][kpad1]
+  const float* b1;       // [2 * inner] (interleaved; the folded LayerNorm's beta term included)
+  const float* cs1;      // column sums of the packed W1 rows (folded LayerNorm); any readable [2 * inner] floats when ln_on = 0
+  int ln_on;
+  const half_t* w2;      // packed [npad >= 320][kpad2]
+  const half_t* zeros;
+  int M, inner, kpad1, kpad2;
+  float ln_eps;
+  Gemm3Dev epi;          // what the final (standard, staged) epilogue reads: bias = b2, residual, out, M, N = 320, ld_out
+};
+
+__global__ __launch_bounds__(512, 1) void af_ff320_kernel(FfDev p) {
+  constexpr int NW = 8, NWM = 2, TM = 4;
+  extern __shared__ __attribute__((aligned(16))) char af_smem[];
+  char* Xs = af_smem;
+  char* W1r = af_smem + FF_XS;
+  char* W2b = W1r + 2 * FF_W1S;
+  float* st = reinterpret_cast<float*>(W2b + FF_W2B);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave % NWM, wn = wave / NWM;
+  const int tile_m = blockIdx.x;
+  const int prow = lane >> 3, slot = lane & 7;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int rd0 = fr * 128 + (((0 * 4 + fq) ^ (fr >> 1)) * 16);
+  const int rd1 = fr * 128 + (((1 * 4 + fq) ^ (fr >> 1)) * 16);
+  const int nchunk = p.inner / FF_HC;
+
+  // weights of both GEMMs towards this XCD's L2 (af_common.h): 1/32 of each per workgroup
+  unsigned sink[AF_WPF_MAX] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+  {
+    const int coop = gridDim.x < 32 ? gridDim.x : 32;
+    af_prefetch_weight_tile(p.w1, p.kpad1, 2 * p.inner, 0, 2 * p.inner, 0, FF_C / 64, coop, tile_m % coop, 1, NW, wave, lane, sink);
+    af_prefetch_weight_tile(p.w2, p.kpad2, FF_C, 0, FF_C, 0, p.inner / 64, coop, tile_m % coop, 1, NW, wave, lane, sink, 4);
+  }
+
+  // ---- X tile: chunk c = rows x 64 halves, 16 pieces of 8 rows; wave w takes pieces {2w, 2w+1} of every chunk
+#pragma unroll
+  for (int c = 0; c < 5; ++c)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row = (wave * 2 + j) * 8 + prow;
+      const int m = tile_m * FF_BM + row;
+      const int lc = slot ^ ((row >> 1) & 7);
+      const half_t* g = m < p.M ? p.x + (size_t)m * FF_C + c * 64 + lc * 8 : p.zeros;
+      glds16(g, Xs + c * (FF_BM * 128) + (wave * 2 + j) * 1024);
+    }
+  // ---- W1 / W2 loaders: a W1 stage is 128 rows x 64 halves (16 pieces: 2 per wave), the W2 tile 320 rows x 64 halves (40 pieces: 5 per wave)
+  auto issue_w1 = [&](int g) {                                   // global stage g = chunk * 5 + K chunk
+    const int jc = g / 5, sc = g - jc * 5;
+    char* dst = W1r + (g & 1) * FF_W1S;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row = (wave * 2 + j) * 8 + prow;
+      const int lc = slot ^ ((row >> 1) & 7);
+      glds16(p.w1 + (size_t)(jc * 2 * FF_HC + row) * p.kpad1 + sc * 64 + lc * 8, dst + (wave * 2 + j) * 1024);
+    }
+  };
+  auto issue_w2 = [&](int jc) {
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const int row = (wave * 5 + j) * 8 + prow;
+      const int lc = slot ^ ((row >> 1) & 7);
+      glds16(p.w2 + (size_t)row * p.kpad2 + jc * 64 + lc * 8, W2b + (wave * 5 + j) * 1024);
+    }
+  };
+  issue_w1(0);
+  asm volatile("s_waitcnt vmcnt(2)" ::: "memory");               // the X tile (and the L2 touches) have landed; stage 0 of W1 may still fly
+  __builtin_amdgcn_s_barrier();
+
+  // ---- LayerNorm statistics of the 128 rows, once: wave w takes rows 16 w .. 16 w + 15
+  {
+    const half2_t one2 = {(half_t)1.0f, (half_t)1.0f};
+    float s = 0.f, q = 0.f;
+    const char* row = Xs + (wave * 16) * 128;
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+      const half8_t f0 = *reinterpret_cast<const half8_t*>(row + c * (FF_BM * 128) + rd0), f1 = *reinterpret_cast<const half8_t*>(row + c * (FF_BM * 128) + rd1);
+#pragma unroll
+      for (int e = 0; e < 8; e += 2) {
+        const half2_t a = {f0[e], f0[e + 1]}, b = {f1[e], f1[e + 1]};
+        s = __builtin_amdgcn_fdot2(a, one2, s, false);
+        q = __builtin_amdgcn_fdot2(a, a, q, false);
+        s = __builtin_amdgcn_fdot2(b, one2, s, false);
+        q = __builtin_amdgcn_fdot2(b, b, q, false);
+      }
+    }
+    s += __shfl_xor(s, 16, 64);
+    q += __shfl_xor(q, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    q += __shfl_xor(q, 32, 64);
+    if (fq == 0) {
+      const float mean = s * (1.0f / FF_C), var = fmaxf(q * (1.0f / FF_C) - mean * mean, 0.f);
+      st[2 * (wave * 16 + fr)] = p.ln_on ? mean : 0.f;
+      st[2 * (wave * 16 + fr) + 1] = p.ln_on ? rsqrtf(var + p.ln_eps) : 1.f;
+    }
+  }
+  __syncthreads();
+  float mean[TM], rstd[TM];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    const int row = wm * 64 + tm * 16 + fr;
+    mean[tm] = st[2 * row];
+    rstd[tm] = st[2 * row + 1];
+  }
+
+  floatx4 acc2[5][TM];
+#pragma unroll
+  for (int tn = 0; tn < 5; ++tn)
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) acc2[tn][tm] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+  for (int jc = 0; jc < nchunk; ++jc) {
+    floatx4 acc1[2][TM];
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) acc1[tn][tm] = floatx4{0.f, 0.f, 0.f, 0.f};
+    const int nv = jc * 2 * FF_HC + wn * 32 + 4 * fq;            // packed W1 row of the lane's value columns; their gates are 16 rows further
+    floatx4 bv, bg, cv, cg;
+    // ---- GEMM1: H [128 x 128 W1 rows] = X W1_chunk^T over the five K chunks
+#pragma unroll
+    for (int sc = 0; sc < 5; ++sc) {
+      const int g = jc * 5 + sc;
+      // stage g was issued one stage ago.  In stage 0 it is followed by the chunk's bias / column-sum loads and the 5 pieces of the W2
+      // tile, which may stay in flight through stage 1 (counted wait); from stage 2 on everything older must have landed
+      if (sc == 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                              // ... for every wave; everyone is done with the slot refilled next
+      if (g + 1 < nchunk * 5) issue_w1(g + 1);
+      if (sc == 0) {
+        // this chunk's GEGLU bias / column sums for the lane's four value and four gate columns, then the W2 tile: both land under
+        // GEMM1 (the previous chunk's GEMM2, which read the W2 buffer, is behind the barrier above)
+        bv = *reinterpret_cast<const floatx4*>(p.b1 + nv);
+        bg = *reinterpret_cast<const floatx4*>(p.b1 + nv + 16);
+        cv = *reinterpret_cast<const floatx4*>(p.cs1 + nv);
+        cg = *reinterpret_cast<const floatx4*>(p.cs1 + nv + 16);
+        issue_w2(jc);
+      }
+      const char* As = Xs + sc * (FF_BM * 128);
+      const char* Ws = W1r + (g & 1) * FF_W1S;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int rd = kk ? rd1 : rd0;
+        half8_t wf[2], xf[TM];
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) wf[tn] = *reinterpret_cast<const half8_t*>(Ws + (wn * 32 + tn * 16) * 128 + rd);
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) xf[tm] = *reinterpret_cast<const half8_t*>(As + (wm * 64 + tm * 16) * 128 + rd);
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+          for (int tm = 0; tm < TM; ++tm) acc1[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[tn], xf[tm], acc1[tn][tm], 0, 0, 0);
+      }
+    }
+    // ---- GEGLU epilogue of the chunk -> G [128 x 64] in the ring slot the last stage has just left (every wave must be out of it)
+    __builtin_amdgcn_s_barrier();
+    {
+      char* G = W1r + ((jc * 5 + 4) & 1) * FF_W1S;
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        const int row = wm * 64 + tm * 16 + fr;
+        half4_t h;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float xv = rstd[tm] * (acc1[0][tm][e] - mean[tm] * cv[e]) + bv[e];
+          const float gv = rstd[tm] * (acc1[1][tm][e] - mean[tm] * cg[e]) + bg[e];
+          h[e] = (half_t)(xv * af_gelu_erf(gv));
+        }
+        // column wn * 16 + 4 fq + e of the chunk: 16-byte slot (wn * 2 + fq / 2), swizzled as the readers expect, low / high half by fq & 1
+        const int sl = (wn * 2 + (fq >> 1)) ^ ((row >> 1) & 7);
+        *reinterpret_cast<half4_t*>(G + row * 128 + sl * 16 + (fq & 1) * 8) = h;
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");             // the W2 tile is older than the stage issued last (2 pieces): landed
+    __syncthreads();                                             // G complete, W2 tile complete for every wave
+    // ---- GEMM2: OUT [128 x 320] += G W2[:, chunk]^T
+    {
+      const char* G = W1r + ((jc * 5 + 4) & 1) * FF_W1S;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int rd = kk ? rd1 : rd0;
+        half8_t wf[5], xf[TM];
+#pragma unroll
+        for (int tn = 0; tn < 5; ++tn) wf[tn] = *reinterpret_cast<const half8_t*>(W2b + (wn * 80 + tn * 16) * 128 + rd);
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) xf[tm] = *reinterpret_cast<const half8_t*>(G + (wm * 64 + tm * 16) * 128 + rd);
+#pragma unroll
+        for (int tn = 0; tn < 5; ++tn)
+#pragma unroll
+          for (int tm = 0; tm < TM; ++tm) acc2[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[tn], xf[tm], acc2[tn][tm], 0, 0, 0);
+      }
+    }
+  }
+  af_prefetch_keep(sink);
+  gemm3_epilogue<E3_STD, 2, 4, 5, FF_XS + 2 * FF_W1S + FF_W2B>(p.epi, acc2, af_smem, tile_m, 0, wm, wn, fr, fq, tid, nullptr);
+}
+
 }  // namespace
 
 // Called by af_gemm (af_gemm.hip) for tile == 3 after the common argument validation.  Returns 1 if the shape is
@@ -962,4 +1181,48 @@ int af_gemm3_effective_splits(const af_gemm_desc* d, int splits, int wide) {
   if (s > nk) s = nk;
   const int per = (nk + s - 1) / s;
   return (nk + per - 1) / per;
+}
+
+// Fused LayerNorm -> GEGLU projection -> output projection (+ bias, + residual) of a transformer block's feed-forward at C = 320
+// (af_ff320_kernel above).  w1 / b1 / ln_colsum as a GEGLU GEMM with a folded LayerNorm would take them (ln_colsum may be NULL: x is
+// then used as it is); w2 the packed second projection; out = residual + b2 + W2 (v * gelu(g)).
+extern "C" int af_ff_fused(const void* x, const void* w1, const void* b1, const void* ln_colsum, float ln_eps, int kpad1, const void* w2, const void* b2,
+                           int kpad2, const void* residual, void* out, int M, int C, int inner, const void* zeros, void* stream) {
+  AF_REQUIRE(x && w1 && b1 && w2 && out && zeros, "af_ff_fused: null pointer");
+  AF_SUPPORTED(C == FF_C, "af_ff_fused: built for C = 320 (the 64 x 64 level of SD-1.5)");
+  AF_REQUIRE(M > 0 && inner > 0 && inner % FF_HC == 0, "af_ff_fused: inner must be a positive multiple of 64");
+  AF_REQUIRE(kpad1 >= C && kpad1 % 64 == 0 && kpad2 >= inner && kpad2 % 64 == 0, "af_ff_fused: weight row strides must be 64-multiples covering K");
+  FfDev p;
+  p.x = (const half_t*)x;
+  p.w1 = (const half_t*)w1;
+  p.b1 = (const float*)b1;
+  p.cs1 = ln_colsum ? (const float*)ln_colsum : (const float*)b1;
+  p.ln_on = ln_colsum != nullptr;
+  p.w2 = (const half_t*)w2;
+  p.zeros = (const half_t*)zeros;
+  p.M = M;
+  p.inner = inner;
+  p.kpad1 = kpad1;
+  p.kpad2 = kpad2;
+  p.ln_eps = ln_eps;
+  Gemm3Dev& e = p.epi;
+  e = Gemm3Dev{};
+  e.bias = (const float*)b2;
+  e.residual = (const half_t*)residual;
+  e.out = (half_t*)out;
+  e.M = M;
+  e.N = C;
+  e.K = inner;
+  e.ld_out = C;
+  e.splits = 1;
+  e.rows_per_batch = M;
+  e.stage_ok = (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+  AfLaunchScope scope(AF_FAM_GEMM, stream);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&af_ff320_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(af_ff320_kernel, dim3((M + FF_BM - 1) / FF_BM), dim3(512), FF_LDS, (hipStream_t)stream, p);
+  return af_check_launch("af_ff_fused");
 }

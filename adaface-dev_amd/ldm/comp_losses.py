@@ -224,9 +224,15 @@ def var_of_laplacian(images):
 MATCHING_TYPES = ("attn", "flow", "sameloc")
 
 
+def _bmm_nt(a, bt):
+    """Batched a [B, M, K] @ bt [B, N, K]^T -> fp32 [B, M, N] through autograd_ops.matmul_nt (the MFMA GEMM for device tensors)."""
+    from ..autograd_ops import matmul_nt
+    return torch.stack([matmul_nt(a[i], bt[i]) for i in range(a.shape[0])], dim=0)
+
+
 def reconstruct_feat_with_attn_aggregation(sc_feat, sc_to_ss_prob):
     """[B, C, N_sc] x [B, N_sc, N_t] -> [B, N_t, C]: every target token as the probability-weighted sum of the subject-comp tokens."""
-    return torch.matmul(sc_feat, sc_to_ss_prob).permute(0, 2, 1)
+    return _bmm_nt(sc_to_ss_prob.transpose(1, 2), sc_feat).to(sc_feat.dtype)
 
 
 def calc_sc_recon_ssfg_mc_losses(layer_idx, flow_model, target_feats, scfg_feat, scbg_feat, ssfg_q, scfg_q, scbg_q, mc_q, ss2sc_flow, mc2sc_flow,
@@ -241,8 +247,8 @@ def calc_sc_recon_ssfg_mc_losses(layer_idx, flow_model, target_feats, scfg_feat,
         raise NotImplementedError("calc_sc_recon_ssfg_mc_losses: the GMA optical-flow network (use_face_flow_for_sc_matching_loss) is an "
                                   "external model; the reference's default flow_model=None path is what is built")
     device, B, N = scbg_feat.device, scbg_feat.shape[0], H * W
-    probs = {"ssfg": F.softmax(torch.matmul(scfg_q.transpose(1, 2).contiguous(), ssfg_q), dim=1),
-             "mc": F.softmax(torch.matmul(scbg_q.transpose(1, 2).contiguous(), mc_q), dim=1)}
+    probs = {"ssfg": F.softmax(_bmm_nt(scfg_q.transpose(1, 2), ssfg_q.transpose(1, 2)).to(scfg_q.dtype), dim=1),
+             "mc": F.softmax(_bmm_nt(scbg_q.transpose(1, 2), mc_q.transpose(1, 2)).to(scbg_q.dtype), dim=1)}
     sources = {"ssfg": scfg_feat, "mc": scbg_feat}
     eye = torch.eye(N, device=device, dtype=scbg_feat.dtype).repeat(B, 1, 1)
     losses, sparse_distill, stats = {}, {}, {}
@@ -260,7 +266,7 @@ def calc_sc_recon_ssfg_mc_losses(layer_idx, flow_model, target_feats, scfg_feat,
         best_adv = best_adv.unsqueeze(1)
         tok_w = (5 * F.layer_norm(best_adv, (best_adv.shape[2],), weight=None, bias=None, eps=1e-5)).sigmoid()
         sparse = torch.cat([eye, eye], dim=0).gather(0, best_type.view(B, 1, -1).expand(-1, N, -1))
-        sc_w = torch.matmul(tok_w, (sparse + probs[name]).permute(0, 2, 1)).permute(0, 2, 1).detach()
+        sc_w = ((sparse + probs[name]).detach() * tok_w.detach()).sum(dim=2, keepdim=True)      # tok_w [B,1,N_t] x ensemble [B,N_sc,N_t]^T -> [B,N_sc,1]
         sparse_distill[name] = ((sparse - probs[name]).abs() * sc_w).mean()
         for i in range(adv.shape[0]):
             stats[f"{name}_{MATCHING_TYPES[i + 1]}_win_rate"] = torch.logical_and(adv[i] > 0, best_type == i).float().mean(dim=1)

@@ -31,6 +31,7 @@ from .diffusionmodules.util import (Conv2d, GroupNorm32, LayerNorm, Linear, _Pac
 
 # LayerNorm -> Linear pairs of the inference pass run as ONE GEMM (ops.pack_matrix_ln); AF_FOLD_LAYERNORM=0 keeps the separate kernels (A/B runs)
 FOLD_LAYERNORM = _os.environ.get("AF_FOLD_LAYERNORM", "1") != "0"
+FUSE_FF = _os.environ.get("AF_FUSE_FF", "1") != "0"          # the C = 320 feed-forward as one launch (af_ff_fused); 0 = the two GEMMs (A/B runs)
 
 
 def exists(val):
@@ -80,9 +81,9 @@ class GEGLU(nn.Module):
     def hip(self, x2d, ln=None):
         return ops.gemm(x2d, self.packed() if ln is None else self.packed_ln(ln), act=AF_ACT_GEGLU)
 
-    def hip_train(self, x2d):
-        """Un-fused: keeps the (interleaved) pre-activation for the backward.  -> (out, hp)."""
-        hp = ops.gemm(x2d, self.packed())
+    def hip_train(self, x2d, ln=None):
+        """Un-fused: keeps the (interleaved) pre-activation for the backward.  -> (out, hp).  ``ln``: as in hip()."""
+        hp = ops.gemm(x2d, self.packed() if ln is None else self.packed_ln(ln))
         return ops.geglu_fwd(hp), hp
 
     def packed_bwd(self):
@@ -115,10 +116,15 @@ class FeedForward(nn.Module):
         self.net = nn.Sequential(GEGLU(dim, inner_dim), nn.Dropout(dropout), Linear(inner_dim, dim_out))
 
     def hip(self, x2d, residual=None, ln=None):
+        if FUSE_FF and ln is not None and x2d.shape[1] == 320 and x2d.shape[0] >= 24576:
+            # the 64 x 64 level: LayerNorm, GEGLU projection, output projection and residual as ONE launch (af_ff_fused): the
+            # [tokens, 1280] intermediate never leaves the compute unit.  One workgroup per 128 tokens: worth it once they fill the chip
+            # (U-Net batch >= 6: 121.9 vs 166.5 us at batch 8, 105.1 vs 98.4 at batch 4 -- profiles/r03p_ff_fused.txt)
+            return ops.ff_fused(x2d, self.net[0].packed_ln(ln), self.net[2].packed(), residual=residual)
         return self.net[2].hip(self.net[0].hip(x2d, ln=ln), residual=residual)
 
-    def hip_train(self, x2d, residual=None):
-        g, hp = self.net[0].hip_train(x2d)
+    def hip_train(self, x2d, residual=None, ln=None):
+        g, hp = self.net[0].hip_train(x2d, ln=ln)
         return self.net[2].hip(g, residual=residual), hp
 
     def hip_bwd(self, hp, dy):
@@ -230,18 +236,19 @@ class CrossAttention(nn.Module):
             self._kv_cache_bwd = _PackCache()
         return self._kv_cache_bwd.get(ws, lambda: ops.pack_matrix(torch.cat([w.detach() for w in ws], 0).t().contiguous(), None, ws[0].device))
 
-    def hip_train(self, x2d, B, N, context=None, keybias=None, residual=None):
-        """As hip(), returning (out, saved) where `saved` feeds hip_bwd."""
+    def hip_train(self, x2d, B, N, context=None, keybias=None, residual=None, ln=None):
+        """As hip(), returning (out, saved) where `saved` feeds hip_bwd.  With ``ln`` the projections take the un-normalised rows (the
+        backward is unchanged: it differentiates the projection w.r.t. LN's output and the caller's LayerNorm backward does the rest)."""
         Ci, h, d = self.inner_dim, self.heads, self.dim_head
         if context is None:
-            qkv = ops.gemm(x2d, self._packed_qkv())                                   # [M, 3C] row-major
+            qkv = ops.gemm(x2d, self._packed_qkv() if ln is None else self._packed_qkv_ln(ln))       # [M, 3C] row-major
             vt = ops.transpose_tokens(qkv[:, 2 * Ci:], B, N, Ci, 3 * Ci)
             o, lse = ops.attention(qkv, qkv[:, Ci:], vt, B=B, Nq=N, L=N, heads=h, d=d, ldq=3 * Ci, ldk=3 * Ci, keybias=keybias,
                                    scale=self.scale, want_lse=True)
             saved = ("self", qkv, o, lse, keybias, B, N, N)
         else:
             L = context.shape[1]
-            q = self.to_q.hip(x2d)
+            q = self.to_q.hip(x2d) if ln is None else ops.gemm(x2d, self._packed_q_ln(ln))
             kv = ops.gemm(context.reshape(B * L, context.shape[-1]), self._packed_kv())  # [B*L, 2C]
             vt = ops.transpose_tokens(kv[:, Ci:], B, L, Ci, 2 * Ci)
             o, lse = ops.attention(q, kv, vt, B=B, Nq=N, L=L, heads=h, d=d, ldq=Ci, ldk=2 * Ci, scale=self.scale, want_lse=True)
@@ -303,6 +310,12 @@ class BasicTransformerBlock(nn.Module):
         return self.ff.hip(self.norm3.hip(x2), residual=x2)
 
     def hip_train(self, x2d, B, N, context=None, keybias=None):
+        if FOLD_LAYERNORM and x2d.shape[1] % 64 == 0 and x2d.shape[0] >= 1024:
+            # the LayerNorm outputs are not needed by the backward (it re-normalises from the saved inputs): fold them as in hip()
+            x1, s1 = self.attn1.hip_train(x2d, B, N, None, keybias, residual=x2d, ln=self.norm1)
+            x2, s2 = self.attn2.hip_train(x1, B, N, context, None, residual=x1, ln=self.norm2)
+            x3, hp = self.ff.hip_train(x2, residual=x2, ln=self.norm3)
+            return x3, (x2d, x1, x2, s1, s2, hp)
         x1, s1 = self.attn1.hip_train(self.norm1.hip(x2d), B, N, None, keybias, residual=x2d)
         x2, s2 = self.attn2.hip_train(self.norm2.hip(x1), B, N, context, None, residual=x1)
         x3, hp = self.ff.hip_train(self.norm3.hip(x2), residual=x2)

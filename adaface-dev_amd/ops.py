@@ -294,6 +294,22 @@ def conv3x3(x: torch.Tensor, pw: PackedWeight, *, x2: Optional[torch.Tensor] = N
     return out
 
 
+def ff_fused(x2d: torch.Tensor, pw1: PackedWeight, pw2: PackedWeight, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = residual + b2 + W2 (v * gelu(g)), [v | g] = W1 LN(x) + b1 in one launch (af_ff_fused; C = 320 only).  pw1: the GEGLU-
+    interleaved first projection, normally with the LayerNorm folded in (GEGLU.packed_ln); pw2: the second projection."""
+    _chk_f16(x2d, "ff_fused.x")
+    M, Cn = x2d.shape
+    assert pw1.K == Cn and pw2.N == Cn and pw2.K * 2 == pw1.N and pw1.bias is not None
+    out = torch.empty((M, Cn), dtype=F16, device=x2d.device)
+    if residual is not None:
+        _chk_f16(residual, "ff_fused.residual")
+        assert residual.shape == out.shape
+    rc = _lib.lib().af_ff_fused(_p(x2d), _p(pw1.wt), _p(pw1.bias), _p(pw1.ln_cs), float(pw1.ln_eps), pw1.kpad, _p(pw2.wt), _p(pw2.bias), pw2.kpad,
+                                _p(residual), _p(out), M, Cn, pw2.K, _p(_zero_page(x2d.device)), _stream())
+    _lib.check(rc, "af_ff_fused")
+    return out
+
+
 # ----------------------------------------------------------------------------- norms
 _gn_ws = {}
 

@@ -147,6 +147,16 @@ typedef struct af_gemm_desc {
 
 int af_gemm(const af_gemm_desc* d, void* stream);
 
+/* ---- fused feed-forward of a transformer block at C = 320 ------------------------------------------------
+ * Replaces, in ONE launch, BasicTransformerBlock's  x + ff(norm3(x))  (attention.py:31-58 FeedForward / GEGLU, :242-252) at the
+ * 64 x 64 level of SD-1.5:  out = residual + b2 + W2 (v * gelu_erf(g)),  [v | g] = W1 LN(x) + b1, without the [M, inner]
+ * intermediate ever leaving the compute unit.  x / residual / out: fp16 [M, C] (C = 320); w1: fp16 packed GEGLU-interleaved
+ * [2 * inner][kpad1] with the LayerNorm's gamma folded in, b1 fp32 [2 * inner] (interleaved, + W1 beta), ln_colsum fp32 [2 * inner]
+ * column sums of the packed rows (NULL: no LayerNorm in front); w2: fp16 packed [>= C rows][kpad2], b2 fp32 [C] (may be NULL);
+ * zeros as af_gemm_desc.zeros.  AF_E_UNSUPPORTED for any other C.                                                              */
+int af_ff_fused(const void* x, const void* w1, const void* b1, const void* ln_colsum, float ln_eps, int kpad1, const void* w2, const void* b2,
+                int kpad2, const void* residual, void* out, int M, int C, int inner, const void* zeros, void* stream);
+
 /* ---- GroupNorm(32) [+ SiLU], NHWC -----------------------------------------------------
  * Replaces GroupNorm32 + nn.SiLU (util.py:195-212; openaimodel.py:202-233,686-690; eps 1e-5)
  * and Normalize (attention.py:70-71; eps 1e-6).  x = concat(x1[.., c1], x2[.., c2]) along

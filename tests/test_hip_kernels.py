@@ -398,6 +398,43 @@ def test_gemm_folded_layernorm_split_transposed(dev, tokens, tile, C):
     assert rel_l2(out2[:, :, :tokens].float().cpu().numpy(), vt.numpy()) < TOL
 
 
+@pytest.mark.parametrize("M,with_ln,with_res", [(256, True, True), (1000, True, True), (4096, True, False), (130, False, True), (24576, True, True)])
+def test_ff_fused_c320(dev, M, with_ln, with_res):
+    """af_ff_fused: LayerNorm -> GEGLU projection -> output projection (+ bias, + residual) of a C = 320 transformer block in one
+    launch == the same chain in fp32 (attention.py:31-58, 242-252).  Ragged token counts, with / without the LayerNorm and residual."""
+    from adaface_dev_amd import ops
+    from adaface_dev_amd.ldm.modules.attention import FeedForward
+    from adaface_dev_amd.ldm.modules.diffusionmodules.util import LayerNorm
+    C = 320
+    x, g, b = _ln_inputs(M, C)
+    ff, ln = FeedForward(C, glu=True).to(dev), LayerNorm(C).to(dev)
+    with torch.no_grad():
+        ff.net[0].proj.weight.copy_(rnd((8 * C, C), 2, C ** -0.5).float())
+        ff.net[0].proj.bias.copy_(torch.randn(8 * C, generator=torch.Generator().manual_seed(3)) * 0.1)
+        ff.net[2].weight.copy_(rnd((C, 4 * C), 4, (4 * C) ** -0.5).float())
+        ff.net[2].bias.copy_(torch.randn(C, generator=torch.Generator().manual_seed(5)) * 0.1)
+        ln.weight.copy_(g)
+        ln.bias.copy_(b)
+    res = x.to(dev) if with_res else None
+    if with_ln:
+        pw1 = ff.net[0].packed_ln(ln)
+    else:
+        pw1 = ff.net[0].packed()
+    out = ops.ff_fused(x.to(dev), pw1, ff.net[2].packed(), residual=res)
+    xin = F.layer_norm(x.float(), (C,), g, b, 1e-5) if with_ln else x.float()
+    h = xin @ ff.net[0].proj.weight.detach().float().cpu().t() + ff.net[0].proj.bias.detach().float().cpu()
+    xv, gv = h.chunk(2, dim=-1)
+    ref = (xv * F.gelu(gv)) @ ff.net[2].weight.detach().float().cpu().t() + ff.net[2].bias.detach().float().cpu()
+    if with_res:
+        ref = ref + x.float()
+    assert out.shape == (M, C)
+    assert rel_l2(out.float().cpu().numpy(), ref.numpy()) < TOL
+    # and it is what FeedForward.hip launches for a 64 x 64-level batch
+    if with_ln and with_res and M >= 24576:
+        y = ff.hip(x.to(dev), residual=res, ln=ln)
+        assert torch.equal(y, out)
+
+
 def test_gemm_folded_layernorm_refuses_other_kernels(dev):
     from adaface_dev_amd import ops
     x, g, b = _ln_inputs(64, 64)

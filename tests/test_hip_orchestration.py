@@ -203,7 +203,8 @@ def test_calc_comp_feat_distill_loss_mirror_vs_reference_on_device(dev, monkeypa
     compositional-distillation iteration against the fixture the reference's calc_comp_feat_distill_loss wrote."""
     import test_stage2_assembly as T
     _cpu_draws(monkeypatch)
-    T.run_comp_cases(dev, 1e-4, torch_q_sample=False)
+    # on the device the feature-matching products run on the MFMA kernel (fp16 operands, autograd_ops.MatmulNTFn): fp16-operand tolerance
+    T.run_comp_cases(dev, 3e-3, torch_q_sample=False)
 
 
 def test_calc_normal_recon_loss_mirror_vs_reference_on_device(dev, monkeypatch):
@@ -219,5 +220,5 @@ def test_comp_losses_on_device_tensors_vs_reference(dev):
     from gen_golden import PRESERVE_CASES
     g = np.load(os.path.join(GOLDEN, "comp_preserve.npz"))
     for tag, kw, scale in PRESERVE_CASES:
-        TC.check_preserve_case(g, tag, kw, scale, device=dev, tol=2e-5)
+        TC.check_preserve_case(g, tag, kw, scale, device=dev, tol=2e-3)      # the matmuls are MFMA GEMMs on fp16 operands here (MatmulNTFn)
     TC.check_recon_and_suppress(g, device=dev, tol=2e-5)

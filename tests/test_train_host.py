@@ -178,3 +178,37 @@ def test_grad_reducer_issues_collectives_in_bucket_order_when_rank_graphs_differ
         heads[r](torch.tanh(trunk(data[r]))).pow(2).mean().backward()
         tot += torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
     assert np.allclose(g0, (tot / 2).numpy(), rtol=1e-5, atol=1e-7)
+
+
+def test_iteration_scheduler_follows_the_reference_typing():
+    """DistillTrainer.schedule_iteration against the reference's rule (ddpm.py:451-470), restated here literally: a micro-batch is
+    compositional when global_step % comp_distill_iter_gap == 0 (global_step = optimizer steps, so both micro-batches of such an
+    accumulation window are); every other micro-batch bumps non_comp_iters_count and distils when that count is a multiple of
+    unet_distill_iter_gap, else reconstructs."""
+    from adaface_dev_amd.ldm.trainer import DistillTrainer
+
+    def reference_kinds(comp_gap, distill_gap, n, accum=2):
+        kinds, non_comp = [], 0
+        for i in range(n):
+            global_step = i // accum
+            if comp_gap > 0 and global_step % comp_gap == 0:
+                kinds.append("comp_distill")
+                continue
+            non_comp += 1
+            kinds.append("unet_distill" if (distill_gap > 0 and non_comp % distill_gap == 0) else "normal_recon")
+        return kinds
+
+    for comp_gap, distill_gap in ((0, 2), (5, 2), (3, 3), (2, 0)):
+        tr = DistillTrainer.__new__(DistillTrainer)
+        tr.iter_type, tr.comp_distill_iter_gap, tr.unet_distill_iter_gap = "unet_distill", comp_gap, distill_gap
+        tr.non_comp_iters_count = tr.normal_recon_iters_count = 0
+        got = []
+        for i in range(24):
+            tr.global_step = i // 2
+            got.append(tr.schedule_iteration())
+        assert got == reference_kinds(comp_gap, distill_gap, 24), (comp_gap, distill_gap, got)
+    tr = DistillTrainer.__new__(DistillTrainer)
+    tr.iter_type, tr.comp_distill_iter_gap, tr.unet_distill_iter_gap = "comp_distill", 0, 0
+    assert tr.schedule_iteration() == "comp_distill"              # both gaps off: the constructor's stage decides
+    yaml_mix = reference_kinds(0, 2, 8)
+    assert yaml_mix == ["normal_recon", "unet_distill"] * 4        # v1-distill-arc2face-ada.yaml:28
