@@ -28,6 +28,7 @@ EXPORTS = (
     "af_scale_f32", "af_affine_prelu", "af_maxpool2x2", "af_global_avgpool", "af_se_residual_prelu", "af_axpy_f16", "af_dora_combine", "af_mul_f16", "af_im2col3x3", "af_colsum_tall", "af_softmax_rows", "af_attention_strided", "af_clamp_f32", "af_mask_pairs", "af_prefetch",
     "af_xattn_scores", "af_xattn_softmax_pv", "af_xattn_softmax_pv_bwd", "af_xattn_rowmix", "af_xattn_colmix_ws_bytes", "af_xattn_colmix",
     "af_layernorm_param_grads", "af_transpose_tokens_pair", "af_ff_fused",
+    "af_softmax_rows_bwd", "af_affine_prelu_bwd", "af_maxpool2x2_bwd", "af_se_gate_grad", "af_se_residual_prelu_bwd",
 )
 
 
@@ -155,6 +156,11 @@ def lib() -> C.CDLL:
     L.af_maxpool2x2.argtypes = [vp, vp, i32, i32, i32, i32, vp]
     L.af_global_avgpool.argtypes = [vp, vp, i32, i32, i32, vp]
     L.af_se_residual_prelu.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp]
+    L.af_softmax_rows_bwd.argtypes = [vp, vp, vp, i64, i32, vp]
+    L.af_affine_prelu_bwd.argtypes = [vp, vp, vp, vp, vp, vp, i64, i32, vp]
+    L.af_maxpool2x2_bwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp]
+    L.af_se_gate_grad.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]
+    L.af_se_residual_prelu_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]
     L.af_groupnorm_bwd.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]
     L.af_layernorm_bwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, f32, vp]
     L.af_layernorm_param_grads.argtypes = [vp, vp, vp, vp, vp, i32, i32, f32, vp]

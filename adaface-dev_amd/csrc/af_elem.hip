@@ -184,6 +184,40 @@ extern "C" int af_q_sample(const void* x0, const void* noise, const void* sa, co
   return af_check_launch("af_q_sample");
 }
 
+// dS = P * (dP - rowsum(P * dP)): the softmax backward of the VAE decoder's single-head attention (rows like af_softmax_rows)
+template <int RS>
+__global__ __launch_bounds__(256) void softmax_rows_bwd_kernel(const half_t* __restrict__ p, const half_t* __restrict__ dp,
+                                                               half_t* __restrict__ ds, long rows, int L) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const half_t *pr = p + row * L, *dr = dp + row * L;
+  half8_t pv[RS], dv[RS];
+  float dot = 0.f;
+#pragma unroll
+  for (int j = 0; j < RS; ++j) {
+    const int c = (lane + 64 * j) * 8;
+    if (c < L) {
+      pv[j] = *reinterpret_cast<const half8_t*>(pr + c);
+      dv[j] = *reinterpret_cast<const half8_t*>(dr + c);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dot += (float)pv[j][e] * (float)dv[j][e];
+    }
+  }
+  dot = af_wave_sum(dot);
+  half_t* sr = ds + row * L;
+#pragma unroll
+  for (int j = 0; j < RS; ++j) {
+    const int c = (lane + 64 * j) * 8;
+    if (c < L) {
+      half8_t o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)pv[j][e] * ((float)dv[j][e] - dot));
+      *reinterpret_cast<half8_t*>(sr + c) = o;
+    }
+  }
+}
+
 extern "C" int af_softmax_rows(const void* x, void* y, int64_t rows, int L, void* stream) {
   AF_REQUIRE(x && y && rows > 0 && L > 0 && L % 8 == 0, "af_softmax_rows: L must be a positive multiple of 8");
   AF_SUPPORTED(L <= 64 * 8 * 8, "af_softmax_rows: L > 4096");
@@ -195,6 +229,20 @@ extern "C" int af_softmax_rows(const void* x, void* y, int64_t rows, int L, void
   else if (L <= 2048) hipLaunchKernelGGL(softmax_rows_kernel<4>, grid, blk, 0, s, (const half_t*)x, (half_t*)y, (long)rows, L);
   else hipLaunchKernelGGL(softmax_rows_kernel<8>, grid, blk, 0, s, (const half_t*)x, (half_t*)y, (long)rows, L);
   return af_check_launch("af_softmax_rows");
+}
+
+extern "C" int af_softmax_rows_bwd(const void* p, const void* dp, void* ds, int64_t rows, int L, void* stream) {
+  AF_REQUIRE(p && dp && ds && rows > 0 && L > 0 && L % 8 == 0, "af_softmax_rows_bwd: L must be a positive multiple of 8");
+  AF_SUPPORTED(L <= 64 * 8 * 8, "af_softmax_rows_bwd: L > 4096");
+  AfLaunchScope scope(AF_FAM_ELEM, stream);
+  dim3 grid((unsigned)((rows + 3) / 4)), blk(256);
+  hipStream_t s = (hipStream_t)stream;
+  const half_t *pp = (const half_t*)p, *dd = (const half_t*)dp;
+  if (L <= 512) hipLaunchKernelGGL(softmax_rows_bwd_kernel<1>, grid, blk, 0, s, pp, dd, (half_t*)ds, (long)rows, L);
+  else if (L <= 1024) hipLaunchKernelGGL(softmax_rows_bwd_kernel<2>, grid, blk, 0, s, pp, dd, (half_t*)ds, (long)rows, L);
+  else if (L <= 2048) hipLaunchKernelGGL(softmax_rows_bwd_kernel<4>, grid, blk, 0, s, pp, dd, (half_t*)ds, (long)rows, L);
+  else hipLaunchKernelGGL(softmax_rows_bwd_kernel<8>, grid, blk, 0, s, pp, dd, (half_t*)ds, (long)rows, L);
+  return af_check_launch("af_softmax_rows_bwd");
 }
 
 // Pull a byte range (the next layers' packed weights) toward the GPU's caches: every 128-byte line is read once, nothing is written.

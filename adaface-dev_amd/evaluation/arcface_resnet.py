@@ -12,8 +12,12 @@ only hold parameters; execution is NHWC fp16 through the C ABI:
   final PReLU in ONE pass (``af_se_residual_prelu``);
 * ``bn4`` -> flatten (NCHW order) -> ``fc5`` -> ``bn5`` collapses into one GEMM on NHWC-ordered, pre-scaled weights.
 
-Inference only, like the reference uses it (``arcface_wrapper.py:65-76`` runs it frozen in eval mode, fp16): training-mode
-BatchNorm statistics / Dropout are not part of the hot path and raise."""
+Frozen and in eval mode, like the reference uses it (``arcface_wrapper.py:65-76``, fp16): training-mode BatchNorm statistics / Dropout
+are not part of the hot path and raise.  The ArcFace alignment loss differentiates THROUGH the frozen encoder into the decoded image
+(``arcface_wrapper.py:89-166``; ``ddpm.py:2511-2535``), so ``forward`` is a ``torch.autograd`` node with an INPUT gradient
+(``FaceEncodeFn``): transposed / flipped packs of the same folded weights for the convolutions' dgrad (stride 2 as the zero-inserted
+implicit GEMM the U-Net's Downsample uses), ``af_affine_prelu_bwd`` / ``af_maxpool2x2_bwd`` / ``af_se_gate_grad`` /
+``af_se_residual_prelu_bwd`` for the rest.  Parameter gradients are never formed."""
 import torch
 import torch.nn as nn
 
@@ -45,6 +49,22 @@ def _fold_conv(conv, bn, dev, cin_pad=0):
     return ops.pack_conv3x3(w, t, dev, cin_pad=cin_pad)
 
 
+def _fold_conv_bwd(conv, bn, dev, n_pad=0):
+    """Pack of the input-gradient convolution of ``_fold_conv(conv, bn)``: spatially flipped, in/out channels swapped, no bias;
+    n_pad zero-pads the gradient's channel count (the grey input's 1 -> 8)."""
+    w = conv.weight.detach().float()
+    if bn is not None:
+        w = w * _bn_affine(bn)[0][:, None, None, None]
+    if w.shape[-1] == 1:
+        w3 = torch.zeros((w.shape[0], w.shape[1], 3, 3), dtype=w.dtype, device=w.device)
+        w3[:, :, 1, 1] = w[:, :, 0, 0]
+        w = w3
+    wd = w.flip(2, 3).permute(1, 0, 2, 3).contiguous()                  # [Cin, Cout, 3, 3]
+    if n_pad > wd.shape[0]:
+        wd = torch.cat([wd, torch.zeros((n_pad - wd.shape[0],) + tuple(wd.shape[1:]), dtype=wd.dtype, device=wd.device)])
+    return ops.pack_conv3x3(wd, None, dev)
+
+
 class SEBlock(nn.Module):
     def __init__(self, channel, reduction=16):
         super().__init__()
@@ -62,10 +82,27 @@ class SEBlock(nn.Module):
         w2[:, :f2.in_features] = f2.weight.detach().float()
         return ops.pack_matrix(w0, b0, dev), ops.pack_matrix(w2, f2.bias, dev)
 
-    def logits(self, x, packs):
-        """x NHWC fp16 -> pre-sigmoid channel gates [B, C]."""
+    def pack_bwd(self, dev):
+        """Transposes of ``pack``'s two matrices (same zero padding), for the squeeze branch's input gradient."""
+        f0, f2 = self.fc[0], self.fc[2]
+        hid = ops.round_up(f0.out_features, 8)
+        w0t = torch.zeros((f0.in_features, hid), device=f0.weight.device)
+        w0t[:, :f0.out_features] = f0.weight.detach().float().t()
+        w2t = torch.zeros((hid, f2.out_features), device=f2.weight.device)
+        w2t[:f2.in_features] = f2.weight.detach().float().t()
+        return ops.pack_matrix(w0t, None, dev), ops.pack_matrix(w2t, None, dev)
+
+    def logits(self, x, packs, keep=None):
+        """x NHWC fp16 -> pre-sigmoid channel gates [B, C]; keep (a list) receives the hidden pre-activation for ``logits_bwd``."""
         s = ops.gemm(ops.global_avgpool(x), packs[0])
+        if keep is not None:
+            keep.append(s)
         return ops.gemm(ops.affine_prelu(s, slope=self.fc[1].weight), packs[1])
+
+    def logits_bwd(self, dgl, s, packs_bwd):
+        """dgl [B, C] (gate-logit gradient / HW) -> gradient of the pooled input [B, C] (/ HW: what every pixel of x receives)."""
+        ds = ops.affine_prelu_bwd(ops.gemm(dgl, packs_bwd[1]), s, slope=self.fc[1].weight)
+        return ops.gemm(ds, packs_bwd[0])
 
 
 class IRBlock(nn.Module):
@@ -91,6 +128,39 @@ class IRBlock(nn.Module):
                     conv2=_fold_conv(self.conv2, self.bn2, dev), se=self.se.pack(dev) if self.use_se else None,
                     down=None if self.downsample is None else _fold_conv(self.downsample[0], self.downsample[1], dev))
 
+    def pack_bwd(self, dev):
+        return dict(conv1=_fold_conv_bwd(self.conv1, self.bn1, dev), conv2=_fold_conv_bwd(self.conv2, self.bn2, dev),
+                    se=self.se.pack_bwd(dev) if self.use_se else None,
+                    down=None if self.downsample is None else _fold_conv_bwd(self.downsample[0], self.downsample[1], dev))
+
+    def hip_train(self, x, P):
+        """``hip`` that also returns what ``hip_bwd`` reads."""
+        c1 = ops.conv3x3(ops.affine_prelu(x, P["bn0"][0], P["bn0"][1]), P["conv1"])
+        c2 = ops.conv3x3(ops.affine_prelu(c1, slope=self.prelu.weight), P["conv2"], stride=self.stride)
+        keep = []
+        gates = self.se.logits(c2, P["se"], keep) if self.use_se else None
+        res = x if P["down"] is None else ops.conv3x3(x, P["down"], stride=self.stride)
+        y = ops.se_residual_prelu(c2, gates, res, self.prelu.weight)
+        return y, (c1, c2, gates, res, keep[0] if keep else None, (x.shape[1], x.shape[2]))
+
+    def hip_bwd(self, saved, dy, P, Pb):
+        """dy [B, Ho, Wo, planes] -> gradient of the block input."""
+        c1, c2, gates, res, s, in_hw = saved
+        sl = self.prelu.weight
+        dpool = None
+        if self.use_se:
+            dpool = self.se.logits_bwd(ops.se_gate_grad(c2, gates, res, sl, dy), s, Pb["se"])
+        dc2, dres = ops.se_residual_prelu_bwd(c2, gates, res, sl, dy, dpool)
+        if self.stride == 2:
+            da = ops.conv3x3(dc2, Pb["conv2"], upsample=2, out_hw=in_hw)
+        else:
+            da = ops.conv3x3(dc2, Pb["conv2"])
+        dc1 = ops.affine_prelu_bwd(da, c1, slope=sl)
+        dx = ops.affine_prelu_bwd(ops.conv3x3(dc1, Pb["conv1"]), None, P["bn0"][0], P["bn0"][1])
+        if Pb["down"] is not None:
+            dres = ops.conv3x3(dres, Pb["down"], upsample=2, out_hw=in_hw) if self.stride == 2 else ops.conv3x3(dres, Pb["down"])
+        return ops.add(dx, dres)
+
     def hip(self, x, P):
         out = ops.affine_prelu(x, P["bn0"][0], P["bn0"][1])
         out = ops.affine_prelu(ops.conv3x3(out, P["conv1"]), slope=self.prelu.weight)
@@ -100,8 +170,27 @@ class IRBlock(nn.Module):
         return ops.se_residual_prelu(out, gates, res, self.prelu.weight)
 
 
+class FaceEncodeFn(torch.autograd.Function):
+    """grey crops [B, 1, 128, 128] -> embeddings [B, 512] with the input gradient (see the module docstring).  The incoming gradient is
+    normalised by a power of two before its fp16 cast (largest entry ~ 256, like the U-Net's backward node) and the result unscaled."""
+
+    @staticmethod
+    def forward(ctx, x, net):
+        y, saved = net.hip_train(x.detach())
+        ctx.net, ctx.saved, ctx.dtype = net, saved, x.dtype
+        return y if x.dtype == F16 else y.to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        amax = dy.detach().abs().amax().float().clamp_min(1e-30)
+        scale = torch.exp2(torch.floor(torch.log2(256.0 / amax)))
+        dx = ctx.net.hip_bwd(ctx.saved, (dy.float() * scale).to(F16).contiguous())
+        ctx.saved = None
+        return (dx / scale).to(ctx.dtype), None
+
+
 class ResNetFace(nn.Module):
-    inference_only = True        # forward kernels only (ldm/modules/arcface_wrapper.py refuses a call that would need its backward)
+    inference_only = False       # forward() carries an input gradient (FaceEncodeFn); parameters stay frozen
 
     def __init__(self, block, layers, use_se=True):
         self.inplanes = 64
@@ -129,6 +218,7 @@ class ResNetFace(nn.Module):
                 nn.init.xavier_normal_(m.weight)
                 nn.init.constant_(m.bias, 0)
         self._packs, self._packs_key = None, None
+        self._packs_bwd, self._packs_bwd_key = None, None
 
     def _make_layer(self, block, planes, blocks, stride=1):
         downsample = None
@@ -162,13 +252,53 @@ class ResNetFace(nn.Module):
             self._packs_key = key
         return self._packs
 
-    def forward(self, x):
+    def _prepared_bwd(self):
+        P = self._prepared()
+        if self._packs_bwd_key != self._packs_key:
+            dev = self.conv1.weight.device
+            self._packs_bwd = dict(conv1=_fold_conv_bwd(self.conv1, self.bn1, dev, n_pad=8), blocks=[b.pack_bwd(dev) for b in self.blocks()],
+                                   fc5=ops.pack_matrix(P["fc5"].wt[:512, :8 * 8 * 512].t(), None, dev))
+            self._packs_bwd_key = self._packs_key
+        return self._packs_bwd
+
+    def _check(self, x):
         if self.training:
             raise NotImplementedError("ResNetFace runs frozen in eval mode on the AdaFace path (arcface_wrapper.py:65-76); "
                                       "training-mode BatchNorm / Dropout are not implemented")
+        assert x.shape[1:] == (1, 128, 128), "ResNetFace-18 takes [B, 1, 128, 128] grey crops (fc5 is 512*8*8 wide)"
+
+    def hip_train(self, x):
+        """forward -> (embeddings fp16 [B, 512], activations kept for ``hip_bwd``)."""
+        self._check(x)
         P = self._prepared()
         B = x.shape[0]
-        assert x.shape[1:] == (1, 128, 128), "ResNetFace-18 takes [B, 1, 128, 128] grey crops (fc5 is 512*8*8 wide)"
+        c1 = ops.conv3x3(ops.nchw_f32_to_nhwc_f16(x.float().contiguous(), cpad=8), P["conv1"])
+        a1 = ops.affine_prelu(c1, slope=self.prelu.weight)
+        h = ops.maxpool2x2(a1)
+        saved = []
+        for blk, bp in zip(self.blocks(), P["blocks"]):
+            h, sv = blk.hip_train(h, bp)
+            saved.append(sv)
+        return ops.gemm(h.reshape(B, 8 * 8 * 512), P["fc5"]), (c1, a1, saved)
+
+    def hip_bwd(self, saved, dy):
+        """dy fp16 [B, 512] -> fp32 [B, 1, 128, 128]."""
+        P, Pb = self._prepared(), self._prepared_bwd()
+        c1, a1, per_block = saved
+        B = dy.shape[0]
+        dh = ops.gemm(dy, Pb["fc5"]).reshape(B, 8, 8, 512)
+        for blk, bp, bpb, sv in reversed(list(zip(self.blocks(), P["blocks"], Pb["blocks"], per_block))):
+            dh = blk.hip_bwd(sv, dh, bp, bpb)
+        dc1 = ops.affine_prelu_bwd(ops.maxpool2x2_bwd(a1, dh), c1, slope=self.prelu.weight)
+        return ops.nhwc_f16_to_nchw_f32(ops.conv3x3(dc1, Pb["conv1"]), 1)
+
+    def forward(self, x):
+        if x.requires_grad and torch.is_grad_enabled():
+            self._check(x)
+            return FaceEncodeFn.apply(x, self)
+        self._check(x)
+        P = self._prepared()
+        B = x.shape[0]
         h = ops.nchw_f32_to_nhwc_f16(x.float().contiguous(), cpad=8)
         h = ops.affine_prelu(ops.conv3x3(h, P["conv1"]), slope=self.prelu.weight)
         h = ops.maxpool2x2(h)

@@ -10,11 +10,12 @@ gen_normal_recon) with the face detector, the ArcFace embedding step and the log
 sides: the sum, every monitor entry and the gradients w.r.t. the captured tensors.
 
 Deviations, stated: (1) the RetinaFace detector network is an external package -- ``self.arcface.retinaface`` is a
-``modules/arcface_wrapper.FaceCropper`` around a caller-supplied detector; (2) the VAE decoder and ResNetFace-18 of this package are
-forward kernels, so ``decode_first_stage_with_grad`` returns a tensor that is NOT attached to the graph and the ArcFace alignment /
-face-suppression terms contribute their VALUE (monitors, gating, face boxes, loss scales) but no gradient; ``arcface_align_grad = True``
-asks for the real thing and raises; (3) image logging (``cache_and_log_generations``) is a no-op hook; (4) the adversarial edit of
-the recon iteration (``do_adv_attack``, probability 0 in the reference's defaults) needs that same backward and raises."""
+``modules/arcface_wrapper.FaceCropper`` around a caller-supplied detector; (2) image logging (``cache_and_log_generations``) is a
+no-op hook; (3) the adversarial edit of the recon iteration (``do_adv_attack``, probability 0 in the reference's defaults) is not built and raises.
+
+The ArcFace alignment / face-suppression terms carry their gradient like the reference's: ``decode_first_stage_with_grad`` is the VAE
+decoder's autograd node (``diffusionmodules/model.VAEDecodeFn``), the crops / grey / resize are torch ops, the embedding is
+``evaluation/arcface_resnet.FaceEncodeFn`` -- both frozen networks with input-gradient kernels only."""
 import copy
 from collections import deque
 
@@ -79,7 +80,6 @@ class CompReconLossesMixin:
     p_do_adv_attack_when_recon_on_images = 0
     # instance attributes set by LatentDiffusion.__init__ (modules must not be shadowed by class attributes): ``arcface`` -- a
     # modules/arcface_wrapper.ArcFaceWrapper, ``flow_model`` -- None (ddpm.py:652-662: only with use_face_flow_for_sc_matching_loss)
-    arcface_align_grad = False        # see the module docstring, deviation (2)
     comp_iters_count = 0
     comp_iters_bg_has_face_count = 0
 
@@ -107,10 +107,10 @@ class CompReconLossesMixin:
         """Image logging hook of the reference (ddpm.py:3775-3800): nothing to do here."""
 
     def decode_first_stage_with_grad(self, z):
-        if self.arcface_align_grad and z.requires_grad and torch.is_grad_enabled():
-            raise NotImplementedError("decode_first_stage_with_grad: the VAE decoder of this package has no backward kernels; the ArcFace "
-                                      "alignment terms are value-only (arcface_align_grad = False)")
-        return self.decode_first_stage(z.detach())
+        """``decode_first_stage`` attached to the graph (ddpm.py:899-908): the decoder's input-gradient node when z requires grad."""
+        if self.first_stage_model is None:
+            raise RuntimeError("no first-stage decoder: call instantiate_first_stage() and load its weights")
+        return self.first_stage_model.decode(z / self.scale_factor)
 
     # ------------------------------------------------------------------ face alignment (ddpm.py:2511-2534)
     def calc_arcface_align_loss(self, x_start, x_recon, fg_faces_grad_mask_ratios=(1, 0.3)):

@@ -108,11 +108,10 @@ class ArcFaceWrapper(nn.Module):
             p.requires_grad_(False)
 
     def _embed(self, grey, enable_grad):
-        if getattr(self.arcface, "inference_only", False):          # evaluation/arcface_resnet.py of this package: forward kernels only
+        if getattr(self.arcface, "inference_only", False):          # an embedding module that declares it has no backward
             if enable_grad and grey.requires_grad and torch.is_grad_enabled():
-                raise NotImplementedError("ArcFaceWrapper: a face was found in a tensor that requires grad -- the alignment loss would need "
-                                          "the backward of ResNetFace-18 (and of the VAE decoder in front of it), which this package does "
-                                          "not have yet; run with arcface_align_loss_weight = 0 or a detector that reports no faces")
+                raise NotImplementedError("ArcFaceWrapper: a face was found in a tensor that requires grad, but the embedding module is "
+                                          "inference_only; the alignment loss needs its input gradient")
             with torch.no_grad():
                 return self.arcface(grey)
         with torch.set_grad_enabled(enable_grad):                   # any differentiable embedding module

@@ -9,8 +9,14 @@ keys load with ``load_state_dict``.
 Execution is NHWC fp16 through the C ABI, with the kernels the U-Net already uses: GroupNorm(32, eps 1e-6)+swish fused, 3x3 convs as
 implicit GEMM (the nearest x2 upsample folded into the following conv's gather, the residual / 1x1 ``nin_shortcut`` in the epilogue), and
 the one attention layer (single head, 512 channels, 4096 tokens at 512x512) as  q.k^T GEMM -> ``af_softmax_rows`` -> P.v GEMM per
-image: its head dim is beyond the flash kernel's register budget and the layer is ~2 % of the decoder.  Inference only (the reference
-decodes under no_grad: ddpm.py:889-896); the encoder half / masked attention (training-time image encoding) is not built."""
+image: its head dim is beyond the flash kernel's register budget and the layer is ~2 % of the decoder.
+
+The weights are frozen, but the ArcFace alignment terms differentiate through the decoder into the latent
+(``decode_first_stage_with_grad``, ddpm.py:899-908 -> ``calc_arcface_align_loss``, ddpm.py:2511-2535), so ``decode`` of a latent that
+requires grad is a ``torch.autograd`` node (``VAEDecodeFn``) with the INPUT gradient only: every layer has ``hip_train`` (forward that
+keeps the GroupNorm inputs + statistics) and ``hip_bwd`` (``af_groupnorm_bwd``, the flipped-weight dgrad convolutions -- a folded nearest
+x2 upsample becomes ``af_sumpool2x2`` of the dgrad --, and for the attention layer the explicit P recomputed, ``af_softmax_rows_bwd`` and
+four GEMMs per image).  No parameter gradient is formed."""
 import torch
 import torch.nn as nn
 
@@ -33,6 +39,12 @@ class Upsample(nn.Module):
 
     def hip(self, x):
         return self.conv.hip(x, upsample=True)
+
+    def hip_train(self, x):
+        return self.hip(x), None
+
+    def hip_bwd(self, saved, dy):
+        return self.conv.hip_dgrad(dy, upsampled=True)
 
 
 class Downsample(nn.Module):
@@ -79,6 +91,23 @@ class ResnetBlock(nn.Module):
         if self.in_channels != self.out_channels:
             x = self.conv_shortcut.hip(x) if self.use_conv_shortcut else self.nin_shortcut.hip(x)
         return self.conv2.hip(h, residual=x)
+
+    def hip_train(self, x):
+        n1, st1 = self.norm1.hip_train(x, silu=True)
+        h = self.conv1.hip(n1)
+        n2, st2 = self.norm2.hip_train(h, silu=True)
+        xs = x
+        if self.in_channels != self.out_channels:
+            xs = self.conv_shortcut.hip(x) if self.use_conv_shortcut else self.nin_shortcut.hip(x)
+        return self.conv2.hip(n2, residual=xs), (x, st1, h, st2)
+
+    def hip_bwd(self, saved, dy):
+        x, st1, h, st2 = saved
+        dh = self.norm2.hip_bwd(h, st2, self.conv2.hip_dgrad(dy), silu=True)
+        dxs = dy
+        if self.in_channels != self.out_channels:
+            dxs = (self.conv_shortcut if self.use_conv_shortcut else self.nin_shortcut).hip_dgrad(dy)
+        return self.norm1.hip_bwd(x, st1, self.conv1.hip_dgrad(dh), silu=True, add=dxs)
 
 
 class AttnBlock(nn.Module):
@@ -140,6 +169,48 @@ class AttnBlock(nn.Module):
             out[b * N:(b + 1) * N] = ops.gemm(p, vb)
         y = ops.gemm(out, self.proj_out.packed(), residual=x.reshape(B * N, C))
         return y.reshape(B, H, W, C)
+
+    def _q_scaled_pack_bwd(self):
+        key = (self.q.weight._version, self.q.weight.data_ptr())
+        if key != getattr(self, "_qsb_key", None):
+            sc = float(self.in_channels) ** -0.5
+            self._qsb = ops.pack_matrix(self.q.weight.detach().float().reshape(self.in_channels, -1).t() * sc, None, self.q.weight.device)
+            self._qsb_key = key
+        return self._qsb
+
+    def hip_train(self, x, mask=None):
+        if mask is not None:
+            raise NotImplementedError("the masked AttnBlock belongs to the encoder, which is never differentiated")
+        B, H, W, C = x.shape
+        hn, st = self.norm.hip_train(x)
+        return self.hip(x), (x, st, hn.reshape(B * H * W, C))
+
+    def hip_bwd(self, saved, dy):
+        """Per image: P recomputed (q.k^T GEMM + row softmax), dV = P^T dO, dP = dO V^T, dS = softmax_bwd(P, dP), dQ = dS K, dK = dS^T Q;
+        then the three projections' dgrad summed into d(hn) and the GroupNorm backward with the residual gradient added."""
+        from ....autograd_ops import wgrad
+        x, st, hn = saved
+        B, H, W, C = x.shape
+        N = H * W
+        dy2 = dy.reshape(B * N, C)
+        q = ops.gemm(hn, self._q_scaled_pack())
+        k = ops.gemm(hn, self.k.packed())
+        v = ops.gemm(hn, self.v.packed())
+        kt = ops.transpose_tokens(k, B, N, C, C)                                  # [B, C, N]
+        do = ops.gemm(dy2, self.proj_out.packed_bwd())
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
+        for b in range(B):
+            sl = slice(b * N, (b + 1) * N)
+            p = ops.softmax_rows(ops.gemm(q[sl], ops.PackedWeight(k[sl], None, N, C, C, 1, C)))
+            dv[sl] = wgrad(p, do[sl]).to(F16)
+            dp = ops.gemm(do[sl], ops.PackedWeight(v[sl], None, N, C, C, 1, C))
+            ds = ops.softmax_rows_bwd(p, dp)
+            dq[sl] = ops.gemm(ds, ops.PackedWeight(kt[b], None, C, N, N, 1, N))
+            dk[sl] = wgrad(ds, q[sl]).to(F16)
+        dhn = ops.gemm(dq, self._q_scaled_pack_bwd())
+        dhn = ops.gemm(dk, self.k.packed_bwd(), residual=dhn)
+        dhn = ops.gemm(dv, self.v.packed_bwd(), residual=dhn)
+        return self.norm.hip_bwd(x, st, dhn.reshape(B, H, W, C), add=dy)
 
 
 class Decoder(nn.Module):
@@ -209,6 +280,51 @@ class Decoder(nn.Module):
         h = self.norm_out.hip(h, silu=True)
         return ops.conv3x3(h, self._conv_out_pack())
 
+    def _layers(self):
+        """The decoder as the flat layer sequence ``hip`` runs between conv_in and norm_out."""
+        seq = [self.mid.block_1, self.mid.attn_1, self.mid.block_2]
+        for i_level in reversed(range(self.num_resolutions)):
+            for i_block in range(self.num_res_blocks + 1):
+                seq.append(self.up[i_level].block[i_block])
+                if len(self.up[i_level].attn) > 0:
+                    seq.append(self.up[i_level].attn[i_block])
+            if i_level != 0:
+                seq.append(self.up[i_level].upsample)
+        return seq
+
+    def _bwd_packs(self):
+        """dgrad packs of the two end convolutions, whose narrow sides (z_channels / out_ch) are zero padded to 8."""
+        ci, co = self.conv_in, self.conv_out
+        key = (ci.weight._version, co.weight._version, ci.weight.data_ptr(), co.weight.data_ptr())
+        if key != getattr(self, "_bwd_key", None):
+            dev = ci.weight.device
+            wi = ci.weight.detach().float().flip(2, 3).permute(1, 0, 2, 3)           # [z_channels, block_in, 3, 3]
+            z8 = ops.round_up(wi.shape[0], 8)
+            wi = torch.cat([wi, torch.zeros((z8 - wi.shape[0],) + tuple(wi.shape[1:]), device=dev)]) if z8 != wi.shape[0] else wi
+            wo = co.weight.detach().float().flip(2, 3).permute(1, 0, 2, 3)           # [block_out, out_ch, 3, 3]
+            self._bwd = (ops.pack_conv3x3(wi.contiguous(), None, dev), ops.pack_conv3x3(wo.contiguous(), None, dev, ops.round_up(self.out_ch, 8)))
+            self._bwd_key = key
+        return self._bwd
+
+    def hip_train(self, z):
+        """``hip`` -> (image, what ``hip_bwd`` reads)."""
+        h = self.conv_in.hip(z)
+        saved = []
+        for layer in self._layers():
+            h, sv = layer.hip_train(h)
+            saved.append(sv)
+        n, st = self.norm_out.hip_train(h, silu=True)
+        return ops.conv3x3(n, self._conv_out_pack()), (saved, h, st)
+
+    def hip_bwd(self, saved, dy):
+        """dy [B, 8h, 8w, roundup(out_ch, 8)] fp16 -> [B, h, w, roundup(z_channels, 8)] fp16."""
+        per_layer, h, st = saved
+        p_in, p_out = self._bwd_packs()
+        d = self.norm_out.hip_bwd(h, st, ops.conv3x3(dy, p_out), silu=True)
+        for layer, sv in reversed(list(zip(self._layers(), per_layer))):
+            d = layer.hip_bwd(sv, d)
+        return ops.conv3x3(d, p_in)
+
     def forward(self, z):
         _require_cuda(self.conv_in.weight, "VAE Decoder")
         y = self.hip(to_nhwc_f16(z, ops.round_up(z.shape[1], 8)))
@@ -277,6 +393,33 @@ class Encoder(nn.Module):
         return from_nhwc_f16(y, x.dtype, self.out_channels)
 
 
+class VAEDecodeFn(torch.autograd.Function):
+    """image = decoder(post_quant_conv(z)) with the gradient w.r.t. z (frozen weights).  The incoming image gradient is normalised by a
+    power of two to a largest entry ~ 1 before its fp16 cast -- the backward amplifies towards the latent (three 2x2 sum-pools, GroupNorm
+    rstd), so the headroom is spent upwards -- and the result is unscaled in fp32."""
+
+    @staticmethod
+    def forward(ctx, z, model):
+        zh = to_nhwc_f16(z.detach(), ops.round_up(z.shape[1], 8))
+        B, H, W, c8 = zh.shape
+        zq = ops.gemm(zh.reshape(B * H * W, c8), model._pq_pack()).reshape(B, H, W, -1)
+        y, saved = model.decoder.hip_train(zq)
+        ctx.model, ctx.saved, ctx.zshape, ctx.dtype = model, saved, tuple(z.shape), z.dtype
+        return from_nhwc_f16(y, z.dtype, model.decoder.out_ch)
+
+    @staticmethod
+    def backward(ctx, dy):
+        model = ctx.model
+        amax = dy.detach().abs().amax().float().clamp_min(1e-30)
+        scale = torch.exp2(torch.floor(torch.log2(1.0 / amax)))
+        d = to_nhwc_f16((dy.float() * scale).contiguous(), ops.round_up(dy.shape[1], 8))
+        dzq = model.decoder.hip_bwd(ctx.saved, d)
+        ctx.saved = None
+        B, H, W, c8 = dzq.shape
+        dz = ops.gemm(dzq.reshape(B * H * W, c8), model._pq_pack_bwd()).reshape(B, H, W, -1)
+        return (from_nhwc_f16(dz, torch.float32, ctx.zshape[1]) / scale).to(ctx.dtype), None
+
+
 class AutoencoderKLDecoder(nn.Module):
     """``first_stage_model`` restricted to what inference needs: ``decode(z) = decoder(post_quant_conv(z))``
     (ldm/models/autoencoder.py:29, 56-59).  SD-1.5: embed_dim 4, ddconfig below."""
@@ -307,14 +450,27 @@ class AutoencoderKLDecoder(nn.Module):
             self._pq_key = key
         return self._pq
 
-    @torch.no_grad()
+    def _pq_pack_bwd(self):
+        c = self.post_quant_conv
+        key = (c.weight._version, c.weight.data_ptr())
+        if key != getattr(self, "_pqb_key", None):
+            n8, k8 = ops.round_up(c.out_channels, 8), ops.round_up(c.in_channels, 8)
+            w = torch.zeros((k8, n8), device=c.weight.device)
+            w[:c.in_channels, :c.out_channels] = c.weight.detach().float().reshape(c.out_channels, c.in_channels).t()
+            self._pqb, self._pqb_key = ops.pack_matrix(w, None, c.weight.device), key
+        return self._pqb
+
     def decode(self, z):
-        """z [B, 4, h, w] (already divided by the 0.18215 scale factor) -> image [B, 3, 8h, 8w] in z.dtype, roughly [-1, 1]."""
+        """z [B, 4, h, w] (already divided by the 0.18215 scale factor) -> image [B, 3, 8h, 8w] in z.dtype, roughly [-1, 1].  A latent that
+        requires grad (``decode_first_stage_with_grad``, ddpm.py:899-908) gets the autograd node with the input gradient."""
         _require_cuda(self.post_quant_conv.weight, "AutoencoderKLDecoder")
-        zh = to_nhwc_f16(z, ops.round_up(z.shape[1], 8))
-        B, H, W, c8 = zh.shape
-        zq = ops.gemm(zh.reshape(B * H * W, c8), self._pq_pack()).reshape(B, H, W, -1)
-        return from_nhwc_f16(self.decoder.hip(zq), z.dtype, self.decoder.out_ch)
+        if z.requires_grad and torch.is_grad_enabled():
+            return VAEDecodeFn.apply(z, self)
+        with torch.no_grad():
+            zh = to_nhwc_f16(z, ops.round_up(z.shape[1], 8))
+            B, H, W, c8 = zh.shape
+            zq = ops.gemm(zh.reshape(B * H * W, c8), self._pq_pack()).reshape(B, H, W, -1)
+            return from_nhwc_f16(self.decoder.hip(zq), z.dtype, self.decoder.out_ch)
 
 
 class AutoencoderKL(AutoencoderKLDecoder):

@@ -681,6 +681,16 @@ def softmax_rows(x):
     return y
 
 
+def softmax_rows_bwd(p, dp):
+    """ds = p * (dp - rowsum(p * dp)) for fp16 [rows, L] probabilities and their gradient."""
+    _chk_f16(p, "softmax_rows_bwd.p")
+    _chk_f16(dp, "softmax_rows_bwd.dp")
+    assert p.shape == dp.shape
+    ds = torch.empty_like(p)
+    _lib.check(_lib.lib().af_softmax_rows_bwd(_p(p), _p(dp), _p(ds), p.shape[0], p.shape[1], _stream()), "af_softmax_rows_bwd")
+    return ds
+
+
 def mask_pairs_(p, cls):
     """In place: p [N, N] fp16 *= ((cls[i] & cls[j]) != 0); cls uint8 [N] (bit 0 foreground, bit 1 background)."""
     assert p.shape[0] == p.shape[1] == cls.numel() and cls.dtype == torch.uint8
@@ -744,6 +754,44 @@ def se_residual_prelu(x, se_logits, residual, slope):
     _lib.check(_lib.lib().af_se_residual_prelu(_p(x), _p(se_logits), _p(residual), _p(slope), _p(y), B, H * W, Cn, _stream()),
                "af_se_residual_prelu")
     return y
+
+
+def affine_prelu_bwd(dy, x=None, scale=None, shift=None, slope=None):
+    """Input gradient of ``affine_prelu``; x (the forward input) is only read when there is a PReLU."""
+    _chk_f16(dy, "affine_prelu_bwd.dy")
+    Cn = dy.shape[-1]
+    dx = torch.empty_like(dy)
+    _lib.check(_lib.lib().af_affine_prelu_bwd(_p(x), _p(scale), _p(shift), _p(slope), _p(dy), _p(dx), dy.numel() // Cn, Cn, _stream()),
+               "af_affine_prelu_bwd")
+    return dx
+
+
+def maxpool2x2_bwd(x, dy):
+    _chk_f16(dy, "maxpool2x2_bwd.dy")
+    B, H2, W2, Cn = x.shape
+    dx = torch.empty_like(x)
+    _lib.check(_lib.lib().af_maxpool2x2_bwd(_p(x), _p(dy), _p(dx), B, H2 // 2, W2 // 2, Cn, _stream()), "af_maxpool2x2_bwd")
+    return dx
+
+
+def se_gate_grad(x, se_logits, residual, slope, dy):
+    """-> fp16 [B, C]: gradient of the SE logits divided by H*W (see include/adaface_hip.h)."""
+    _chk_f16(dy, "se_gate_grad.dy")
+    B, H, W, Cn = x.shape
+    dgl = torch.empty((B, Cn), dtype=F16, device=x.device)
+    _lib.check(_lib.lib().af_se_gate_grad(_p(x), _p(se_logits), _p(residual), _p(slope), _p(dy), _p(dgl), B, H * W, Cn, _stream()),
+               "af_se_gate_grad")
+    return dgl
+
+
+def se_residual_prelu_bwd(x, se_logits, residual, slope, dy, dpool=None):
+    """-> (dx, dresidual) of ``se_residual_prelu``; dpool [B, C] is the squeeze branch's gradient (1/HW included)."""
+    _chk_f16(dy, "se_residual_prelu_bwd.dy")
+    B, H, W, Cn = x.shape
+    dx, dres = torch.empty_like(x), torch.empty_like(x)
+    _lib.check(_lib.lib().af_se_residual_prelu_bwd(_p(x), _p(se_logits), _p(residual), _p(slope), _p(dy), _p(dpool), _p(dx), _p(dres), B,
+                                                   H * W, Cn, _stream()), "af_se_residual_prelu_bwd")
+    return dx, dres
 
 
 # ----------------------------------------------------------------------------- profiling hook

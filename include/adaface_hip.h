@@ -313,6 +313,9 @@ int af_clamp_f32(void* a, float lo, float hi, int64_t n, void* stream);
 /* ---- VAE decoder (ldm/modules/diffusionmodules/model.py:151-243 AttnBlock): row softmax of an explicit fp16 score matrix
  * [rows, L], L % 8 == 0, L <= 4096 (single-head 512-dim attention runs as af_gemm -> af_softmax_rows -> af_gemm) */
 int af_softmax_rows(const void* x, void* y, int64_t rows, int L, void* stream);
+/* its backward, ds = p * (dp - rowsum(p * dp)), for the decode-with-grad path of the ArcFace alignment loss (ddpm.py:2511-2535
+ * differentiates through decode_first_stage_with_grad, ddpm.py:899-908) */
+int af_softmax_rows_bwd(const void* p, const void* dp, void* ds, int64_t rows, int L, void* stream);
 /* masked VAE-encoder attention (model.py:191-209): p fp16 [N, N] (post-softmax) *= ((cls[i] & cls[j]) != 0); cls uint8 [N]: bit 0 fg*aug != 0, bit 1 (1-fg)*aug != 0 */
 int af_mask_pairs(void* p, const void* cls, int N, void* stream);
 /* read every 128-byte line of [ptr, ptr + bytes) once (no writes): cache warm-up of packed weights ahead of the GEMM that streams them,
@@ -330,6 +333,20 @@ int af_global_avgpool(const void* x, void* out, int B, int HW, int C, void* stre
 /* y = prelu(x * sigmoid(se_logits[b, c]) + residual); se_logits fp16 [B, C] or NULL (use_se = False) (arcface_resnet.py:88-95,153) */
 int af_se_residual_prelu(const void* x, const void* se_logits, const void* residual, const void* slope, void* y, int B, int HW, int C,
                          void* stream);
+/* Input-gradient kernels of the same layers.  The encoder is frozen (arcface_wrapper.py:65-76) but calc_arcface_align_loss
+ * (arcface_wrapper.py:89-166) back-propagates through it into the decoded image, so d/dx is needed and parameter gradients are not.
+ * dx = dy * prelu'(x * scale + shift) * scale; x may be NULL when slope is NULL (pure affine) */
+int af_affine_prelu_bwd(const void* x, const void* scale, const void* shift, const void* slope, const void* dy, void* dx, int64_t rows,
+                        int C, void* stream);
+/* x [B, 2Ho, 2Wo, C] (the forward input), dy [B, Ho, Wo, C] -> dx [B, 2Ho, 2Wo, C]: dy to the first maximum of each window */
+int af_maxpool2x2_bwd(const void* x, const void* dy, void* dx, int B, int Ho, int Wo, int C, void* stream);
+/* dgl fp16 [B, C] = sigmoid'(se_logits) * mean_hw(dpre * x), dpre = dy * prelu'(x * sigmoid(se_logits) + residual): the gradient of
+ * the SE logits ALREADY divided by HW (the squeeze's 1/HW, applied early so the fp16 value stays in range; the chain between is linear) */
+int af_se_gate_grad(const void* x, const void* se_logits, const void* residual, const void* slope, const void* dy, void* dgl, int B, int HW,
+                    int C, void* stream);
+/* dx = dpre * sigmoid(se_logits) + dpool[b, c];  dres = dpre.  dpool fp16 [B, C] (the squeeze-branch gradient, 1/HW included) or NULL */
+int af_se_residual_prelu_bwd(const void* x, const void* se_logits, const void* residual, const void* slope, const void* dy,
+                             const void* dpool, void* dx, void* dres, int B, int HW, int C, void* stream);
 
 /* ---- trainable DoRA adapters on the U-Net's up_blocks.3 convolutions (adaface/diffusers_attn_lora_capture.py:541-591; peft
  * DoraConv2dLayer.forward: y = base(x) + (s - 1) * conv(xd, W) + s * scaling * B(A(xd)), xd = dropout(x)) ---------------------

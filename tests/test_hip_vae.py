@@ -32,6 +32,18 @@ def test_softmax_rows_vs_torch(dev, rows, L):
     assert float((y.float().sum(1) - 1).abs().max()) < 5e-3
 
 
+@pytest.mark.parametrize("rows,L", [(37, 64), (64, 1024), (130, 4096), (5, 1800)])
+def test_softmax_rows_bwd_vs_torch(dev, rows, L):
+    from adaface_dev_amd import ops
+    g = torch.Generator().manual_seed(L + 1)
+    p = torch.softmax(torch.randn(rows, L, generator=g) * 3, dim=1).half()
+    dp = torch.randn(rows, L, generator=g).half()
+    ds = ops.softmax_rows_bwd(p.to(dev), dp.to(dev))
+    pf, df = p.float(), dp.float()
+    ref = pf * (df - (pf * df).sum(1, keepdim=True))
+    assert rel_l2(ds.float().cpu().numpy(), ref.numpy()) < 2e-3
+
+
 def _decoder(cfg, dev):
     from adaface_dev_amd import rng
     from adaface_dev_amd.ldm.modules.diffusionmodules.model import Decoder
@@ -158,3 +170,47 @@ def test_encoder_masked_attention_vs_reference(dev):
         want = VO.encoder(sd, img, mask={"fg_mask": fgf, "aug_mask": aug})
         got = e(img.to(dev), {"fg_mask": fgf, "aug_mask": aug}).cpu().numpy()
     assert rel_l2(got, want.numpy()) < 1e-2
+
+
+@pytest.mark.parametrize("size", ["reduced", "sd15"])
+def test_vae_decode_input_gradient_vs_oracle_autograd(dev, size):
+    """d(loss)/dz through the frozen decoder (decode_first_stage_with_grad, ddpm.py:899-908 -- what the ArcFace alignment loss
+    back-propagates into the x0 prediction) against torch autograd through the CPU oracle on the same weights: reduced width on a
+    16x16 latent, the SD-1.5 decoder on a 16x16 latent (128x128 image; the mid attention over 256 tokens) and, SD-1.5 only, a gradient
+    that lives in one 24x24 image window, as a face crop's does.  fp16 through ~30 convolutions each way: 2e-2 rel-L2."""
+    from adaface_dev_amd import rng
+    from adaface_dev_amd.ldm.modules.diffusionmodules.model import AutoencoderKLDecoder
+    from oracle import vae_oracle as VO
+    cfg = dict(AutoencoderKLDecoder.SD15_DDCONFIG)
+    kw = {}
+    if size == "reduced":
+        cfg.update({k: v for k, v in VAE_SMALL.items() if k in cfg})
+        kw = dict(num_resolutions=len(cfg["ch_mult"]), num_res_blocks=cfg["num_res_blocks"])
+    ae = AutoencoderKLDecoder(cfg)
+    with torch.no_grad():
+        for n, p in ae.named_parameters():
+            p.copy_(rng.synth_tensor(n, p.shape, seed=92))
+    ae = ae.to(dev).eval()
+    sd = {k: v.detach().float().cpu() for k, v in ae.state_dict().items()}
+    z = rng.synth_input("vae.gz", (2, 4, 16, 16), seed=92)
+    up = 2 ** (len(cfg["ch_mult"]) - 1)
+    wgt = rng.synth_input("vae.gw", (2, 3, 16 * up, 16 * up), seed=92)
+    cases = [wgt]
+    if size == "sd15":
+        win = torch.zeros_like(wgt)
+        win[:, :, 40:64, 70:94] = wgt[:, :, 40:64, 70:94] * 1e-4             # a small, local gradient: exercises the power-of-two rescale
+        cases.append(win)
+    for w in cases:
+        zr = z.clone().requires_grad_(True)
+        ref_img = VO.decode(sd, zr, **kw)
+        (ref_img * w).sum().backward()
+        zd = z.to(dev).requires_grad_(True)
+        img = ae.decode(zd)
+        assert img.requires_grad and rel_l2(img.detach().cpu().numpy(), ref_img.detach().numpy()) < 1e-2
+        (img * w.to(dev)).sum().backward()
+        e = rel_l2(zd.grad.cpu().numpy(), zr.grad.numpy())
+        print(f"VAE decode ({size}) latent-gradient rel-L2 vs oracle autograd: {e:.3e}")
+        assert e < 2e-2
+    assert all(p.grad is None for p in ae.parameters())
+    with torch.no_grad():
+        assert not ae.decode(z.to(dev)).requires_grad

@@ -74,12 +74,26 @@ def test_calc_normal_recon_loss_mirror_vs_reference_cpu():
     run_recon_cases("cpu", 2e-5, torch_q_sample=True)
 
 
-def test_value_only_arcface_terms_are_stated_not_silent():
-    """With the package's own forward-only VAE decoder / ResNetFace the alignment terms carry no gradient; asking for it must raise."""
+def test_decode_with_grad_needs_the_first_stage_and_embedding_modules_may_opt_out():
+    """decode_first_stage_with_grad is the decoder's autograd node: without a first-stage model it raises instead of detaching; an
+    embedding module that declares ``inference_only`` is refused for a tensor that needs its input gradient (never silently detached)."""
     from adaface_dev_amd.ldm.models.diffusion.ddpm import LatentDiffusion
+    from adaface_dev_amd.ldm.modules.arcface_wrapper import ArcFaceWrapper
     ld = LatentDiffusion.__new__(LatentDiffusion)
     torch.nn.Module.__init__(ld)
-    ld.arcface_align_grad = True
+    ld.first_stage_model = None
     z = torch.zeros(1, 4, 8, 8, requires_grad=True)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(RuntimeError):
         ld.decode_first_stage_with_grad(z)
+
+    class Frozen(torch.nn.Module):
+        inference_only = True
+
+        def forward(self, g):
+            return g.flatten(1)[:, :512] * 2.0
+
+    w = ArcFaceWrapper(Frozen(), dtype=torch.float32)
+    grey = torch.zeros(1, 1, 128, 128, requires_grad=True)
+    with pytest.raises(NotImplementedError):
+        w._embed(grey, True)
+    assert not w._embed(grey, False).requires_grad
