@@ -9,10 +9,12 @@ callable from the caller -- a real detector, boxes known to the data pipeline, o
 client does around it (largest face per instance, clipping, minimum size T, crops resized on the INPUT tensor so the graph is kept,
 background faces flattened, full-frame box + mask 0 for instances without a face).
 
-The embedding network is ``evaluation/arcface_resnet.py`` of this package (HIP kernels, frozen, fp16).  It is an inference module: the
-alignment loss VALUE and the boxes / masks are computed on the device, but there is no backward through ResNetFace and the VAE decoder
-yet, so a face-alignment term that would need a gradient (a face was found in a tensor that requires grad) raises instead of silently
-contributing nothing.  With ``no_faces`` (synthetic data) every face-gated term is exactly zero, as in the reference."""
+The embedding network is ``evaluation/arcface_resnet.py`` of this package (HIP kernels, frozen, fp16) with its input-gradient node
+(``FaceEncodeFn``); the decoded image comes from the VAE decoder's node (``VAEDecodeFn``), so the alignment / suppression losses
+back-propagate into the x0 prediction exactly as in the reference: decode -> crop -> bilinear resize -> grey -> ``MaskedGrad`` ->
+ResNetFace-18 -> cosine / squared-embedding losses.  An embedding module without a backward may declare ``inference_only = True``; it
+is then refused for a tensor that needs its gradient rather than silently detached.  With ``no_faces`` (synthetic data) every
+face-gated term is exactly zero, as in the reference."""
 import numpy as np
 import torch
 import torch.nn as nn

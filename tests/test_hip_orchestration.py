@@ -222,3 +222,61 @@ def test_comp_losses_on_device_tensors_vs_reference(dev):
     for tag, kw, scale in PRESERVE_CASES:
         TC.check_preserve_case(g, tag, kw, scale, device=dev, tol=2e-3)      # the matmuls are MFMA GEMMs on fp16 operands here (MatmulNTFn)
     TC.check_recon_and_suppress(g, device=dev, tol=2e-5)
+
+
+def test_arcface_align_loss_gradient_into_the_latent_vs_oracle_pipeline(dev):
+    """``LatentDiffusion.calc_arcface_align_loss`` (ddpm.py:2511-2535) with its gradient, end to end on the device: the x0 prediction is
+    decoded by the VAE decoder's autograd node, cropped at the detector's box, resized, greyed, gradient-masked, embedded by ResNetFace-18's
+    node and aligned to the reference face.  Checked against the SAME wrapper code on the CPU with the torch-functional oracles standing
+    for the two networks (autograd through them = the reference's gradient): the three losses to 2e-2, d(loss)/d(x_recon) to 8e-2
+    rel-L2 / cosine > 0.995 (fp16 sign decisions through both networks, see test_hip_face.py)."""
+    import torch.nn.functional as F
+    from adaface_dev_amd import rng
+    from adaface_dev_amd.evaluation.arcface_resnet import resnet_face18
+    from adaface_dev_amd.ldm.models.diffusion.ddpm import LatentDiffusion
+    from adaface_dev_amd.ldm.modules.arcface_wrapper import ArcFaceWrapper, FaceCropper
+    from adaface_dev_amd.ldm.modules.diffusionmodules.model import AutoencoderKLDecoder
+    from oracle import face_oracle as FO, vae_oracle as VO
+    from trainer_util import fixed_face_detector
+    cfg = dict(AutoencoderKLDecoder.SD15_DDCONFIG, ch=32, resolution=128)
+    ae = AutoencoderKLDecoder(cfg)
+    with torch.no_grad():
+        for n, p in ae.named_parameters():
+            p.copy_(rng.synth_tensor(n, p.shape, seed=90))
+    net = resnet_face18().eval()
+    fsd = rng.synth_face_state_dict(net.state_dict(), seed=50)
+    net.load_state_dict(fsd)
+    vsd = {k: v.detach().float() for k, v in ae.state_dict().items()}
+
+    class OracleFace(torch.nn.Module):
+        def forward(self, g):
+            return FO.resnet_face18(fsd, g.float())
+
+    class OracleVAE(torch.nn.Module):
+        def decode(self, z):
+            return VO.decode(vsd, z)
+
+    def shell(first_stage, arcface):
+        ld = LatentDiffusion.__new__(LatentDiffusion)
+        torch.nn.Module.__init__(ld)
+        ld.first_stage_model, ld.arcface, ld.scale_factor = first_stage, arcface, 0.18215
+        return ld
+
+    x_start = 0.18215 * rng.synth_input("afl.x0", (2, 4, 32, 32), seed=93)
+    x_recon = 0.18215 * rng.synth_input("afl.xr", (2, 4, 32, 32), seed=94)
+    res = {}
+    for name, d, ld in (("cpu", torch.device("cpu"), shell(OracleVAE(), ArcFaceWrapper(OracleFace(), FaceCropper(fixed_face_detector), dtype=torch.float32))),
+                        ("hip", dev, shell(ae.to(dev).eval(), ArcFaceWrapper(net.to(dev), FaceCropper(fixed_face_detector))))):
+        xr = x_recon.to(d).detach().requires_grad_(True)
+        l_align, l_fg, l_bg, boxes, conf, found = ld.calc_arcface_align_loss(x_start.to(d), xr, fg_faces_grad_mask_ratios=(0.9, 0.3))
+        assert int(found.sum()) == 2 and boxes is not None
+        (l_align + 10.0 * l_fg).backward()
+        res[name] = (float(l_align.detach()), float(l_fg.detach()), xr.grad.float().cpu(), boxes.cpu())
+    assert torch.equal(res["cpu"][3], res["hip"][3])
+    for i in (0, 1):
+        assert abs(res["hip"][i] - res["cpu"][i]) < 2e-2 * abs(res["cpu"][i]) + 1e-5, (i, res["hip"][i], res["cpu"][i])
+    g, r = res["hip"][2], res["cpu"][2]
+    e = rel_l2(g.numpy(), r.numpy())
+    cos = float(F.cosine_similarity(g.flatten(), r.flatten(), dim=0))
+    print(f"calc_arcface_align_loss: d/d(x_recon) rel-L2 {e:.3e} cosine {cos:.5f} (|g| {float(r.norm()):.3e})")
+    assert float(r.norm()) > 0 and e < 8e-2 and cos > 0.995
