@@ -1,7 +1,7 @@
 """The loss assemblies of the compositional-distillation and normal-recon iterations of ``LatentDiffusion`` (reference
 ``ldm/models/diffusion/ddpm.py``): ``calc_comp_feat_distill_loss`` :3190-3600, ``calc_comp_face_align_and_mb_suppress_losses`` :3602-3732,
 ``redenoise_subj_single`` :2093-2266, ``calc_arcface_align_loss`` :2511-2534, ``recon_multistep_denoise`` :1753-1917,
-``calc_normal_recon_loss`` :2593-2883, with the reference's signatures, gating and loss weights.  A mixin of
+``calc_normal_recon_loss`` :2593-2883, ``calc_arcface_adv_grad`` :2536-2582 (the adversarial face edit), with the reference's signatures, gating and loss weights.  A mixin of
 ``ddpm.LatentDiffusion`` (kept in its own file: host orchestration only -- every tensor op below runs on device tensors, the U-Net /
 VAE / ResNetFace passes they trigger are the HIP paths).
 
@@ -11,7 +11,7 @@ sides: the sum, every monitor entry and the gradients w.r.t. the captured tensor
 
 Deviations, stated: (1) the RetinaFace detector network is an external package -- ``self.arcface.retinaface`` is a
 ``modules/arcface_wrapper.FaceCropper`` around a caller-supplied detector; (2) image logging (``cache_and_log_generations``) is a
-no-op hook; (3) the adversarial edit of the recon iteration (``do_adv_attack``, probability 0 in the reference's defaults) is not built and raises.
+no-op hook.
 
 The ArcFace alignment / face-suppression terms carry their gradient like the reference's: ``decode_first_stage_with_grad`` is the VAE
 decoder's autograd node (``diffusionmodules/model.VAEDecodeFn``), the crops / grey / resize are torch ops, the embedding is
@@ -78,6 +78,9 @@ class CompReconLossesMixin:
     recon_bg_pixel_weight = 0.025
     arcface_align_loss_weight = 1e-2
     p_do_adv_attack_when_recon_on_images = 0
+    recon_adv_mod_mag_range = (0.001, 0.003)
+    adaface_adv_iters_count = 0
+    adaface_adv_success_iters_count = 0
     # instance attributes set by LatentDiffusion.__init__ (modules must not be shadowed by class attributes): ``arcface`` -- a
     # modules/arcface_wrapper.ArcFaceWrapper, ``flow_model`` -- None (ddpm.py:652-662: only with use_face_flow_for_sc_matching_loss)
     comp_iters_count = 0
@@ -360,6 +363,27 @@ class CompReconLossesMixin:
         mon_loss_dict[f"{P}/pred_l2"] = torch.stack(pred_l2s).mean().detach().item()
         return loss
 
+    # ------------------------------------------------------------------ adversarial face edit (ddpm.py:2536-2582)
+    def calc_arcface_adv_grad(self, x_start):
+        """Gradient, w.r.t. the latents, of the mean squared (30 %-dropped) face embedding of their decoded faces -- through the VAE
+        decoder's and ResNetFace-18's input-gradient nodes -- kept inside the detected face boxes (latent coordinates); None when any
+        instance shows no face."""
+        x = x_start.detach().requires_grad_(True)
+        with torch.enable_grad():
+            image = self.decode_first_stage_with_grad(x)
+            emb_centre, _, _, boxes, _, found = self.arcface.embed_image_tensor(image, T=20, enable_grad=True, fg_faces_grad_mask_ratios=(0.9, 0.9))
+            if (1 - found).sum() > 0:
+                print(f"Failed to detect faces in {int((1 - found).sum())} image, unable to compute adv_grad.")
+                return None
+            loss = (F.dropout(emb_centre, p=0.3, training=True) ** 2).mean()
+            (adv_grad,) = torch.autograd.grad(loss, x)
+        boxes = CL.map_bboxes_coords(boxes, image.shape[-1], x_start.shape[-1])
+        face_mask = torch.zeros_like(adv_grad)
+        for i in range(x_start.shape[0]):
+            x1, y1, x2, y2 = boxes[i]
+            face_mask[i, :, y1:y2, x1:x2] = 1
+        return adv_grad * face_mask
+
     # ------------------------------------------------------------------ do_normal_recon iteration (ddpm.py:1753-1917, 2593-2883)
     def recon_multistep_denoise(self, mon_loss_dict, session_prefix, x_start0, noise, t, subj_context, cls_context, uncond_emb, img_mask, fg_mask,
                                 cfg_scale, num_denoising_steps, num_priming_steps, normal_recon_on_pure_noise, enable_unet_attn_lora,
@@ -368,9 +392,6 @@ class CompReconLossesMixin:
         pure noise each step continues from the previous x0 prediction, the first ``num_priming_steps`` without gradient and
         alternating class / subject prompt.  Every step also gets a no-grad pass under the class prompt (the background target)."""
         assert num_denoising_steps <= 10
-        if do_adv_attack:
-            raise NotImplementedError("recon_multistep_denoise: the adversarial face edit (p_do_adv_attack_when_recon_on_images, 0 in the "
-                                      "reference's defaults) needs the backward of the VAE decoder and ResNetFace-18")
         x_starts, noises, ts = [x_start0], [noise], [t]
         noise_preds, x_recons, acts_list = [], [], []
         noise_preds_cls, x_recons_cls = ([], []) if cls_context is not None else (None, None)
@@ -399,7 +420,20 @@ class CompReconLossesMixin:
                 p = np.power(num_denoising_steps - 1, -0.3)
                 t_lb, t_ub = t * np.power(0.5, p), t * np.power(0.7, p)
                 ts.append(((t_ub - t_lb) * torch.rand_like(t.float()) + t_lb).long())
-                noises.append(torch.randn_like(x_start))
+                noise = torch.randn_like(x_start)
+                if do_adv_attack:                       # the adversarial face edit of the NEXT step's noise (ddpm.py:1879-1913)
+                    adv_grad = self.calc_arcface_adv_grad(x_start[:DO_ADV_BS])
+                    self.adaface_adv_iters_count += 1
+                    if adv_grad is not None:
+                        adv_max = adv_grad.abs().max().detach().item()
+                        adv_fg_mean = adv_grad[fg_mask[:DO_ADV_BS].repeat(1, 4, 1, 1).bool()].abs().mean().detach().item()
+                        mod_mag = CL.torch_uniform(*self.recon_adv_mod_mag_range).item()
+                        scale = mod_mag / (np.sqrt(adv_max * adv_fg_mean) + 1e-6)
+                        mon_loss_dict.update({f"{session_prefix}/adv_grad_max": adv_max, f"{session_prefix}/adv_grad_fg_mean": adv_fg_mean,
+                                              f"{session_prefix}/adv_grad_scale": scale})
+                        noise[:DO_ADV_BS] -= adv_grad * min(scale, 10)
+                        self.adaface_adv_success_iters_count += 1
+                noises.append(noise)
         return noise_preds, noise_preds_cls, x_starts, x_recons, x_recons_cls, noises, ts, acts_list
 
     def calc_normal_recon_loss(self, mon_loss_dict, session_prefix, num_denoising_steps, num_recon_priming_steps, x_start, noise, subj_context,
@@ -407,7 +441,7 @@ class CompReconLossesMixin:
                                enable_unet_attn_lora, enable_unet_ffn_lora, ffn_lora_adapter_name, do_adv_attack, DO_ADV_BS):
         """eps-reconstruction of the input images under the subject prompt (fg weight 1, bg ``recon_bg_pixel_weight``; restricted to the
         detected face box when one is found, x0.1 when none is), the background pulled to the class-prompt prediction, the subject
-        attention kept off the background, plus the ArcFace alignment of the x0 prediction (value-only here, see the module docstring).
+        attention kept off the background, plus the ArcFace alignment of the x0 prediction.
         Like the reference, the per-step losses only exist when ``arcface_align_loss_weight > 0`` (:2702)."""
         P, dev = session_prefix, x_start.device
         loss = torch.tensor(0.0, device=dev)

@@ -958,6 +958,13 @@ def gen_stage2_assembly(out):
             r = SC.run_normal_recon(shell(detect), "cpu", on_pure_noise=pure, steps=steps)
             for k, v in r.items():
                 res[f"recon.{dname}.pure{int(pure)}.steps{steps}.{k}"] = v
+        # the adversarial face edit between the two steps (do_adv_attack, ddpm.py:1879-1913 + calc_arcface_adv_grad :2536-2582)
+        ld = shell(detect)
+        ld.adaface_adv_iters_count, ld.adaface_adv_success_iters_count, ld.recon_adv_mod_mag_range = 0, 0, [0.001, 0.003]
+        r = SC.run_normal_recon(ld, "cpu", on_pure_noise=False, steps=2, do_adv=True)
+        r["adv_iters"], r["adv_success"] = np.asarray(float(ld.adaface_adv_iters_count)), np.asarray(float(ld.adaface_adv_success_iters_count))
+        for k, v in r.items():
+            res[f"recon_adv.{dname}.{k}"] = v
     np.savez_compressed(os.path.join(out, "stage2_assembly.npz"), **res)
     print("stage2_assembly:", {k: float(v) for k, v in res.items() if k.endswith(".loss")})
     print("  monitors of the first case:", sorted(k.split(".mon.")[1] for k in res if k.startswith("comp.standin_detect.mix0.mon.")))

@@ -92,7 +92,7 @@ def recon_inputs(device):
     return x0, noise, emb, cls_emb, fg, img_mask, subj
 
 
-def run_normal_recon(ld, device, on_pure_noise=False, steps=2):
+def run_normal_recon(ld, device, on_pure_noise=False, steps=2, do_adv=False):
     x0, noise, emb, cls_emb, fg, img_mask, subj = recon_inputs(device)
     extra = {}
     subj_context, cls_context = (emb, ["a", "b"], extra), (cls_emb, ["a", "b"], extra)
@@ -100,7 +100,7 @@ def run_normal_recon(ld, device, on_pure_noise=False, steps=2):
     torch.manual_seed(2468)
     with contextlib.redirect_stdout(io.StringIO()):
         loss = ld.calc_normal_recon_loss(mon, "train", steps, 4 if on_pure_noise else 0, x0, noise, subj_context, cls_context, img_mask, fg, subj, 0.025,
-                                         on_pure_noise, True, False, "recon_loss", False, 2)
+                                         on_pure_noise, True, False, "recon_loss", do_adv, 2)
     res = {"loss": np.asarray(float(loss.detach()))}
     loss.backward()
     res["demb"] = emb.grad.detach().cpu().numpy()

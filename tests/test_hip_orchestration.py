@@ -196,6 +196,9 @@ def _cpu_draws(monkeypatch):
         out = real_randint(*a, **k)
         return out if device is None else out.to(device)
     monkeypatch.setattr(torch, "randint", randint)
+    import torch.nn.functional as F
+    real_dropout = F.dropout
+    monkeypatch.setattr(F, "dropout", lambda x, p=0.5, training=True, inplace=False: x * real_dropout(torch.ones(x.shape), p, training).to(x.device))
 
 
 def test_calc_comp_feat_distill_loss_mirror_vs_reference_on_device(dev, monkeypatch):

@@ -64,6 +64,13 @@ def run_recon_cases(device, tol, torch_q_sample):
         for pure, steps in ((False, 2), (False, 1), (True, 2)):
             res = SC.run_normal_recon(mirror_shell(device, dname, torch_q_sample), device, on_pure_noise=pure, steps=steps)
             check_case(g, f"recon.{dname}.pure{int(pure)}.steps{steps}.", res, tol)
+        # with the adversarial face edit of the second step's noise (the gradient of the decoded faces' embedding w.r.t. the latents)
+        ld = mirror_shell(device, dname, torch_q_sample)
+        res = SC.run_normal_recon(ld, device, on_pure_noise=False, steps=2, do_adv=True)
+        res["adv_iters"], res["adv_success"] = np.asarray(float(ld.adaface_adv_iters_count)), np.asarray(float(ld.adaface_adv_success_iters_count))
+        check_case(g, f"recon_adv.{dname}.", res, tol)
+        if dname == "standin_detect":
+            assert "mon.train__adv_grad_scale" in res and float(res["adv_iters"]) == float(res["adv_success"]) == 1
 
 
 def test_calc_comp_feat_distill_loss_mirror_vs_reference_cpu():
