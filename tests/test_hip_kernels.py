@@ -310,6 +310,9 @@ def test_conv3x3_padded_input_channels(dev):
     (2, 4096, 320, 0, 1e-6, False), (2, 64, 640, 320, 1e-5, True), (2, 49, 64, 64, 1e-5, True),
     (8, 256, 1280, 0, 1e-5, True), (3, 256, 1280, 1280, 1e-5, True), (2, 64, 1280, 1280, 1e-6, False), (2, 144, 1280, 0, 1e-5, False),   # single-launch path
     (8, 1024, 640, 0, 1e-5, True), (3, 256, 1280, 640, 1e-5, True), (9, 256, 640, 0, 1e-6, False), (2, 1024, 320, 320, 1e-5, True),   # pair-granularity path
+    (8, 4096, 320, 0, 1e-5, True), (8, 4096, 640, 0, 1e-5, True), (8, 4096, 640, 320, 1e-5, True), (8, 1024, 640, 320, 1e-5, True),     # the denoise step's
+    (8, 1024, 1280, 0, 1e-5, False), (4, 4096, 640, 320, 1e-5, True), (5, 4000, 320, 0, 1e-6, True), (1, 4096, 128, 0, 1e-6, True),    # two-launch shapes ...
+    (2, 16384, 256, 0, 1e-6, True), (1, 65536, 128, 0, 1e-6, True),                                                                   # ... and the VAE decoder's
 ])
 def test_groupnorm(dev, B, HW, c1, c2, eps, silu):
     from adaface_dev_amd import ops
