@@ -594,7 +594,7 @@ extern "C" int af_gemm(const af_gemm_desc* d, void* stream) {
     const long t128 = (long)((d->M + 127) / 128) * ((d->N + 127) / 128);
     tile = (t128 >= 192 && d->N >= 96) ? 1 : 2;
   }
-  AF_REQUIRE(tile >= 1 && tile <= 13, "af_gemm: tile must be 0 .. 13");
+  AF_REQUIRE(tile >= 1 && tile <= 14, "af_gemm: tile must be 0 .. 14");
 
   AfLaunchScope scope(AF_FAM_GEMM, stream);
   hipStream_t s = (hipStream_t)stream;

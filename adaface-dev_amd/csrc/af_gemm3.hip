@@ -831,6 +831,213 @@ bool launch3w(const Gemm3Dev& p0, hipStream_t stream) {
 
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Halo-resident 3x3 convolution ("tile 14"): stride 1, pad 1, one source, W in {16, 32, 64}.
+// The tap-by-tap implicit GEMM above fetches a tile's activation rows NINE times per 64 input channels (once per tap, shifted), and with the
+// 128 x 320 tile every 64-wide K stage moves 16 KB of activations + 40 KB of weights from L2 into LDS for 0.7 us of MFMA work -- the L2 -> LDS
+// path is what the kernel waits for (profiles/r01r_gemm_diagnosis.txt: 20 of 89 us with real addresses).  Here a workgroup owns R = 256 / W
+// WHOLE image rows (256 output pixels) x 160 output channels, and for each 64-channel chunk of the input:
+//   * the (R + 2) x (W + 2) halo of those rows is brought into LDS ONCE (<= 396 pixels x 128 B = 50 KB; out-of-image pixels come from the
+//     zero page), double-buffered: the next chunk's halo streams in, one 1-KB piece per wave per stage, under this chunk's nine taps;
+//   * the nine taps are nine K stages over the SAME halo: tap (ky, kx) of output pixel (r, c) is halo pixel (r + ky, c + kx), i.e. the
+//     MFMA fragment address plus a workgroup-uniform offset; only the tap's 160 x 64 weight tile (20 KB) is new per stage.
+// Per stage 26 KB instead of 56 KB cross from L2 for the same 40 MFMAs per wave, and 3.5 instead of 7 LDS-DMA instructions per wave.
+// LDS rows are 128 B with the 16-byte chunk index XOR-ed with (pixel >> 1) & 7 on the DMA source side: 16 consecutive halo pixels (a
+// fragment's rows, at ANY start) hit 16 distinct (half, chunk) slots, so the ds_read_b128 fragment reads stay conflict-free under
+// every tap shift.  K is walked chunk-major (k = tap * Cin + chunk * 64 in the packed weight), split-K slices are chunk ranges.
+// The tile is 256 consecutive output rows of the [M, N] result, so the staged epilogue is the shared one.
+constexpr int CH_BM = 256, CH_BN = 160, CH_NP_MAX = 50;          // output pixels, output channels, 8-pixel DMA pieces of the largest halo
+constexpr int CH_ASZ = CH_NP_MAX * 1024, CH_WSZ = CH_BN * 128;   // one halo buffer, one weight stage
+constexpr int CH_LDS = 2 * CH_ASZ + 2 * CH_WSZ;                  // 143,360 B
+// (A three-slot weight ring with counted waits -- two weight stages in flight -- measured 5 - 9 % SLOWER in the same process,
+// profiles/r03aa_halo_conv.txt: like the deep rings of the tap-by-tap kernel, look-ahead is not what the loop is short of.)
+
+__global__ __launch_bounds__(512) void af_conv3h_kernel(const Gemm3Dev p) {
+  constexpr int NWS = 2;
+  constexpr int NWM = 4, NWN = 2, TN = 5, TM = 4, NW = 8, BM = CH_BM, BN = CH_BN;
+  constexpr int APW = (CH_NP_MAX + NW - 1) / NW;                 // 7 halo pieces per wave at most
+  constexpr int WPW = (BN / 8 + NW - 1) / NW;                    // 3 weight pieces per wave at most (20 pieces)
+  extern __shared__ __attribute__((aligned(16))) char af_smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave % NWM, wn = wave / NWM;
+  int tile_m, tile_n;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    if (p.n_major) {
+      tile_n = lid / p.tiles_m;
+      tile_m = lid - tile_n * p.tiles_m;
+    } else {
+      tile_m = lid / p.tiles_n;
+      tile_n = lid - tile_m * p.tiles_n;
+    }
+  }
+  const int Wd = p.W, Wh = Wd + 2, R = BM / Wd;
+  const int halo_px = (R + 2) * Wh, NP = (halo_px + 7) >> 3;
+  const int m0 = tile_m * BM;
+  const int bimg = m0 / p.HoWo;
+  const int y0 = (m0 - bimg * p.HoWo) / Wd;
+  const int Cin = p.c1;
+  const int prow = lane >> 3, slot = lane & 7;
+
+  // ---- loaders: wave w owns halo pieces {w + 8 j} and weight pieces {w + 8 j}; lane = (pixel / row in the piece, physical chunk)
+  int a_off[APW];
+#pragma unroll
+  for (int j = 0; j < APW; ++j) {
+    const int hp = (wave + NW * j) * 8 + prow;
+    const int hy = hp / Wh, hx = hp - hy * Wh;
+    const int iy = y0 - 1 + hy, ix = hx - 1;
+    const bool ok = hp < halo_px && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)Wd;
+    a_off[j] = ok ? ((bimg * p.H + iy) * Wd + ix) * Cin + (slot ^ ((hp >> 1) & 7)) * 8 : -1;
+  }
+  const half_t* wptr[WPW];
+  bool wok[WPW];
+#pragma unroll
+  for (int j = 0; j < WPW; ++j) {
+    const int row = (wave + NW * j) * 8 + prow;
+    const int n = tile_n * BN + row;
+    wok[j] = row < BN && n < p.npad;
+    wptr[j] = p.wt + (size_t)(wok[j] ? n : 0) * p.kpad + (slot ^ ((row >> 1) & 7)) * 8;
+  }
+  auto issue_halo_piece = [&](int j, int chunk, int buf) {
+    if (wave + NW * j < NP) glds16(a_off[j] >= 0 ? p.a1 + a_off[j] + chunk * 64 : p.zeros, af_smem + buf * CH_ASZ + (wave + NW * j) * 1024);
+  };
+  auto issue_weights = [&](int chunk, int tap, int sl) {
+    const int k0 = tap * Cin + chunk * 64;
+    char* Ws = af_smem + 2 * CH_ASZ + sl * CH_WSZ;
+#pragma unroll
+    for (int j = 0; j < WPW; ++j)
+      if (wave + NW * j < BN / 8) glds16(wok[j] ? wptr[j] + k0 : p.zeros, Ws + (wave + NW * j) * 1024);
+  };
+
+  floatx4 acc[TN][TM];
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) acc[tn][tm] = floatx4{0.f, 0.f, 0.f, 0.f};
+  const int fr = lane & 15, fq = lane >> 4;
+  const int rd0 = fr * 128 + (((0 * 4 + fq) ^ (fr >> 1)) * 16);      // weight fragments: 16-row groups are aligned
+  const int rd1 = fr * 128 + (((1 * 4 + fq) ^ (fr >> 1)) * 16);
+  int hpb[TM];                                                       // halo pixel of this lane's row for tap (0, 0), per 16-row group
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    const int q0 = wm * 64 + tm * 16;
+    const int r = q0 / Wd;
+    hpb[tm] = r * Wh + (q0 - r * Wd) + fr;
+  }
+
+  const int nchunk = Cin >> 6;
+  const int cb = blockIdx.y * p.kt_per_split;                         // split-K over chunk ranges
+  const int ce = min(nchunk, cb + p.kt_per_split);
+  const int nst = (ce - cb) * 9;
+
+  unsigned wpf_sink[AF_WPF_MAX] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+  if (p.wpf > 0 && p.splits == 1)
+    af_prefetch_weight_tile(p.wt, p.kpad, p.npad, tile_n * BN, BN, 0, p.kpad >> 6, p.wpf_coop, tile_m % p.wpf_coop, p.wpf, NW, wave, lane, wpf_sink);
+
+  if (nst > 0) {
+#pragma unroll
+    for (int j = 0; j < APW; ++j) issue_halo_piece(j, cb, 0);
+    issue_weights(cb, 0, 0);
+  }
+  half8_t wf[TN], xf[TM];
+  int chunk = cb, tap = 0;
+  for (int s = 0; s < nst; ++s) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // this stage's weights (and, at tap 0, the chunk's halo) have landed
+    __builtin_amdgcn_s_barrier();                                    // ... for every wave; everyone is done with the slot / buffer refilled next
+    auto issue_next = [&]() {
+      if (chunk + 1 < ce) {                                          // next chunk's halo: piece j under tap j (APW = 7 of the nine taps)
+#pragma unroll
+        for (int j = 0; j < APW; ++j)
+          if (tap == j) issue_halo_piece(j, chunk + 1, (chunk + 1 - cb) & 1);
+      }
+      int nchunk_ = chunk, ntap = tap + (NWS - 1);
+      if (ntap >= 9) ntap -= 9, ++nchunk_;
+      if (s + NWS - 1 < nst) issue_weights(nchunk_, ntap, (s + NWS - 1) % NWS);
+    };
+    const bool late = wave >= NW / 2;                                // as in the whole-line kernel: the SIMD partners issue their DMA between the two MFMA clusters
+    if (!late) issue_next();
+    const char* As = af_smem + ((chunk - cb) & 1) * CH_ASZ;
+    const char* Ws = af_smem + 2 * CH_ASZ + (s % NWS) * CH_WSZ;
+    const int ty = tap / 3;
+    const int toff = ty * Wh + (tap - ty * 3);
+    {
+      // both K halves' fragments are requested up front (18 ds_read_b128 in flight); the first MFMA cluster waits for its nine only, the
+      // second cluster's operands arrive under it
+      half8_t wf1[TN], xf1[TM];
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) wf[tn] = *reinterpret_cast<const half8_t*>(Ws + (wn * TN * 16 + tn * 16) * 128 + rd0);
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        const int hp = hpb[tm] + toff;
+        xf[tm] = *reinterpret_cast<const half8_t*>(As + hp * 128 + (((0 * 4 + fq) ^ ((hp >> 1) & 7)) * 16));
+      }
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) wf1[tn] = *reinterpret_cast<const half8_t*>(Ws + (wn * TN * 16 + tn * 16) * 128 + rd1);
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        const int hp = hpb[tm] + toff;
+        xf1[tm] = *reinterpret_cast<const half8_t*>(As + hp * 128 + (((1 * 4 + fq) ^ ((hp >> 1) & 7)) * 16));
+      }
+      asm volatile("s_waitcnt lgkmcnt(9)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+          acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[tn], xf[tm], acc[tn][tm], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      if (late) issue_next();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+          acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf1[tn], xf1[tm], acc[tn][tm], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    }
+    if (++tap == 9) tap = 0, ++chunk;
+  }
+  af_prefetch_keep(wpf_sink);
+  gemm3_epilogue<E3_STD, NWM, NWN, TN, CH_LDS>(p, acc, af_smem, tile_m, tile_n, wm, wn, fr, fq, tid);
+}
+
+// scope of the halo-resident kernel
+static bool conv3h_eligible(const af_gemm_desc* d) {
+  if (d->taps != 9 || d->upsample || d->tap_shift || d->c2 != 0 || d->c1 % 64 != 0 || d->N % CH_BN != 0) return false;
+  if ((d->stride ? d->stride : 1) != 1 || d->Ho != d->H || d->Wo != d->W) return false;
+  if (d->W != 16 && d->W != 32 && d->W != 64) return false;
+  if (d->H % (CH_BM / d->W) != 0 || d->M % CH_BM != 0 || d->M != d->B * d->H * d->W) return false;
+  if (d->act == AF_ACT_GEGLU || d->out_mode == AF_OUT_SPLIT_T || d->ln_colsum != nullptr) return false;
+  return d->kpad == 9 * d->c1 || d->kpad % 64 == 0;
+}
+
+static bool launch_conv3h(const Gemm3Dev& p0, hipStream_t stream) {
+  Gemm3Dev p = p0;
+  p.tiles_n = p.N / CH_BN;
+  p.tiles_m = p.M / CH_BM;
+  {
+    static const int coop_env = getenv("AF_GEMM3_WPF_COOP") ? atoi(getenv("AF_GEMM3_WPF_COOP")) : 32;
+    p.wpf_coop = p.tiles_m < coop_env ? p.tiles_m : coop_env;
+    if (p.wpf > AF_WPF_MAX) p.wpf = AF_WPF_MAX;
+  }
+  if (p.counters && (p.splits <= 1 || p.splits > 4 || p.tiles_m * p.tiles_n > AF_SPLITK_MAX_TILES)) p.counters = nullptr;
+  p.n_major = af_gemm_n_major(p.M, p.N, p.K, p.c1);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&af_conv3h_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS);
+    attr_set = true;
+  }
+  dim3 grid(p.tiles_m * p.tiles_n, p.splits), block(512);
+  hipLaunchKernelGGL(af_conv3h_kernel, grid, block, CH_LDS, stream, p);
+  return p.counters != nullptr;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Fused feed-forward of a transformer block at C = 320 (the 64 x 64 level: 4096 tokens per image):
 //     out = x + b2 + W2 ( v * gelu(g) ),   [v | g] = W1 LN(x) + b1                 (attention.py:31-58, 242-252)
 // in ONE launch per layer.  Unfused, the GEGLU projection writes a [tokens, 1280] intermediate (84 MB at U-Net batch 8) that the
@@ -1057,6 +1264,7 @@ int af_gemm3_try_launch(const af_gemm_desc* d, int splits, int wide, hipStream_t
   // 4 = 128 x 320 (GEGLU 128 x 256), 5 = 128 x 128, 6 = GEGLU 256 x 320, 7 = GEGLU 256 x 256, 8 = 128 x 160 (4 waves, 2 workgroups per CU),
   // 9 / 10 = 128 x 128 / 128 x 160 with a four-slot ring (three stages in flight, one workgroup per CU)
   const bool geglu = d->act == AF_ACT_GEGLU, split_t = d->out_mode == AF_OUT_SPLIT_T;
+  if (wide == 11 && !conv3h_eligible(d)) return 1;              // halo-resident 3x3 kernel (tile 14)
   if (d->upsample && !((wide == 4 || wide == 5 || wide >= 8) && d->upsample == 1 && d->taps == 9)) return 1;   // nearest x2: whole-line kernel only
   if (d->c1 % BK3 != 0 || d->c2 % BK3 != 0 || d->zeros == nullptr) return 1;
   if ((geglu || split_t) && (d->taps != 1 || splits > 1)) return 1;
@@ -1070,7 +1278,7 @@ int af_gemm3_try_launch(const af_gemm_desc* d, int splits, int wide, hipStream_t
     if (wide == 7 && (!geglu || d->N % 256 != 0)) return 1;
     if ((wide == 8 || wide == 10) && (geglu || split_t || d->N % 160 != 0)) return 1;
     if (wide == 9 && (geglu || split_t)) return 1;
-    if (wide > 10) return 1;
+    if (wide > 11) return 1;
   }
   if (wide == 2 && (d->N % 256 != 0 || d->taps != 1 || split_t || splits > 1)) return 1;
   if (wide == 3 && (d->N % 320 != 0 || d->taps != 1 || split_t || splits > 1)) return 1;
@@ -1131,6 +1339,15 @@ int af_gemm3_try_launch(const af_gemm_desc* d, int splits, int wide, hipStream_t
     const int ncols = geglu ? d->N / 2 : d->N;
     p.stage_ok = ncols % 8 == 0 && p.ld_out % 8 == 0 && (reinterpret_cast<uintptr_t>(p.out) & 15) == 0;
   }
+  if (wide == 11) {                                            // split-K slices are ranges of 64-channel chunks (nine taps each)
+    const int nchunk = p.c1 / 64;
+    p.splits = splits > 1 ? splits : 1;
+    if (p.splits > nchunk) p.splits = nchunk;
+    p.kt_per_split = (nchunk + p.splits - 1) / p.splits;
+    p.splits = (nchunk + p.kt_per_split - 1) / p.kt_per_split;
+    fused = launch_conv3h(p, stream);
+    return (p.splits > 1 && !fused) ? 2 : 0;
+  }
   if (wide >= 4) {
     // whole-line variants (64-wide K stages): 4 = 128 x 320 (GEGLU: 128 x 256), 5 = 128 x 128 (4 waves), 6 / 7 = GEGLU 256 x 320 / 256 x 256
     const int nk64 = p.kpad / 64;
@@ -1176,7 +1393,7 @@ int af_gemm3_try_launch(const af_gemm_desc* d, int splits, int wide, hipStream_t
 }
 
 int af_gemm3_effective_splits(const af_gemm_desc* d, int splits, int wide) {
-  const int nk = d->kpad / (wide >= 4 ? 64 : BK3);
+  const int nk = (wide == 11 && conv3h_eligible(d)) ? d->c1 / 64 : d->kpad / (wide >= 4 ? 64 : BK3);
   int s = splits > 1 ? splits : 1;
   if (s > nk) s = nk;
   const int per = (nk + s - 1) / s;

@@ -122,6 +122,10 @@ typedef struct af_gemm_desc {
                         /* 12 / 13 = the 128x128 / 128x160 whole-line tiles with a FOUR-slot ring: three K stages in flight ahead of the MFMAs
                            instead of one (128 / 147 KB of LDS, one workgroup per CU): for grids of at most ~one workgroup per CU, where
                            nothing else covers a stage's L2 / HBM latency (the 16x16 level: weights read once, 160 tiles) */
+                        /* 14 = halo-resident 3x3 kernel: 256 output pixels (whole image rows) x 160 channels per workgroup; per 64 input
+                           channels the rows' (R+2) x (W+2) halo is loaded into LDS once and the nine taps read it at shifted addresses
+                           (stride 1, pad 1, c2 == 0, c1 % 64 == 0, N % 160 == 0, W in {16, 32, 64}, H % (256 / W) == 0; split-K over
+                           64-channel chunks).  Outside that scope it falls back to tile 1 */
   int32_t splits;       /* split-K factor (<=1: none).  >1 needs the standard epilogue and a workspace:
                            each split writes an fp32 partial [M][N], a second launch reduces + applies the epilogue */
   void* workspace;      /* fp32, >= splits*M*N*4 bytes when splits > 1 */

@@ -124,6 +124,44 @@ def test_conv3x3_tile3_pipelined(dev, B, H, W, c1, c2, cout, stride, splits):
     assert rel_l2(out.float().cpu().permute(0, 3, 1, 2).numpy(), ref.numpy()) < TOL
 
 
+@pytest.mark.parametrize("B,H,W,cin,cout,splits,extras", [
+    (1, 64, 64, 320, 320, 1, True), (2, 64, 64, 64, 160, 1, False), (2, 32, 32, 640, 640, 2, True), (3, 16, 16, 1280, 320, 4, True),
+    (1, 32, 32, 192, 160, 3, False), (2, 16, 16, 128, 160, 1, True), (1, 96, 64, 128, 320, 1, True), (2, 8, 32, 64, 160, 1, False)])
+def test_conv3x3_tile14_halo_resident(dev, B, H, W, cin, cout, splits, extras):
+    """Halo-resident 3x3 kernel (tile 14): whole image rows per workgroup, nine taps off one LDS halo per 64-channel chunk; every level's
+    width (64 / 32 / 16), image borders (zero padding from the zero page), several images per launch, split-K over channel chunks (incl.
+    an uneven 3-way split of 3 chunks), bias / per-image row bias / residual epilogue -- against torch conv2d in fp32."""
+    from adaface_dev_amd import ops
+    x = rnd((B, H, W, cin), 1)
+    w = rnd((cout, cin, 3, 3), 3, (9 * cin) ** -0.5)
+    bias = torch.randn(cout, generator=torch.Generator().manual_seed(4))
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.float(), bias, padding=1)
+    rowb = res = None
+    if extras:
+        rowb = rnd((B, cout), 5)
+        res = rnd((B, H, W, cout), 6)
+        ref = ref + rowb.float()[:, :, None, None] + res.float().permute(0, 3, 1, 2)
+    out = ops.conv3x3(x.to(dev), ops.pack_conv3x3(w, bias, dev), rowbias=None if rowb is None else rowb.to(dev),
+                      residual=None if res is None else res.to(dev), tile=14, splits=splits)
+    assert rel_l2(out.float().cpu().permute(0, 3, 1, 2).numpy(), ref.numpy()) < TOL
+    # same launch against the tap-by-tap kernel: identical products, different summation order
+    out7 = ops.conv3x3(x.to(dev), ops.pack_conv3x3(w, bias, dev), rowbias=None if rowb is None else rowb.to(dev),
+                       residual=None if res is None else res.to(dev), tile=8, splits=1)
+    assert rel_l2(out.float().cpu().numpy(), out7.float().cpu().numpy()) < 2e-3
+
+
+def test_conv3x3_tile14_falls_back_outside_its_scope(dev):
+    """stride 2 / two sources / widths it does not take: the descriptor's fallback (tile 1) computes the same convolution."""
+    from adaface_dev_amd import ops
+    for (B, H, W, c1, c2, cout, stride) in ((1, 16, 16, 64, 0, 160, 2), (1, 16, 16, 64, 64, 160, 1), (1, 12, 24, 64, 0, 160, 1)):
+        x1, x2 = rnd((B, H, W, c1), 1), (rnd((B, H, W, c2), 2) if c2 else None)
+        w = rnd((cout, c1 + c2, 3, 3), 3, (9 * (c1 + c2)) ** -0.5)
+        xin = (x1 if x2 is None else torch.cat([x1, x2], -1)).float().permute(0, 3, 1, 2)
+        ref = F.conv2d(xin, w.float(), None, stride=stride, padding=1)
+        out = ops.conv3x3(x1.to(dev), ops.pack_conv3x3(w, None, dev), x2=None if x2 is None else x2.to(dev), stride=stride, tile=14)
+        assert rel_l2(out.float().cpu().permute(0, 3, 1, 2).numpy(), ref.numpy()) < TOL
+
+
 @pytest.mark.parametrize("M,N,K,splits", [(300, 320, 320, 1), (4096, 640, 1280, 2), (130, 960, 64, 1)])
 def test_gemm_tile4_wide(dev, M, N, K, splits):
     """128 x 320 / 8-wave variant of the LDS-DMA ring kernel (N % 320 == 0)."""

@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--fresh", action="store_true", help="ignore the existing table instead of extending it")
     ap.add_argument("--cold-weights", action="store_true", help="time single launches after evicting the caches (weights cold, 1x1 activations re-read): what a GEMM meets inside the real step")
     ap.add_argument("--retune", action="store_true", help="re-time every shape this run meets; entries of shapes it does not meet are kept")
+    ap.add_argument("--retune-halo", action="store_true", help="re-time only the 3x3 shapes in the scope of the halo-resident kernel (tile 14)")
     args = ap.parse_args()
     from adaface_dev_amd import SD15_UNET_CONFIG, _lib, ops, rng
     from adaface_dev_amd.ldm.modules.diffusionmodules.openaimodel import UNetModel
@@ -92,13 +93,16 @@ def main():
     retuned = set()
 
     def recorder(key, d, device):
-        if key in table and (not args.retune or key in retuned):
+        again = args.retune or (args.retune_halo and ops.conv_halo_eligible(d))
+        if key in table and (not again or key in retuned):
             return table[key]
         retuned.add(key)
         nk = d.kpad // 64
         best, best_t, res = (0, 1), None, {}
-        for tile in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13):
+        for tile in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14):
             geglu = d.act == _lib.AF_ACT_GEGLU
+            if tile == 14 and not ops.conv_halo_eligible(d):
+                continue                        # halo-resident 3x3 kernel: its split-K slices are 64-channel chunks
             if tile >= 7 and (d.upsample not in (0, 1) or (d.upsample and tile not in (7, 8, 11, 12, 13)) or d.c1 % 64 or d.c2 % 64):
                 continue                        # whole-line kernel: 64-multiples of channels; nearest-x2 upsample in the non-GEGLU tiles
             if tile in (11, 13) and (geglu or d.out_mode == _lib.AF_OUT_SPLIT_T or d.N % 160 != 0):
@@ -120,6 +124,8 @@ def main():
                 if f32 and splits == 1 and tile > 2:
                     continue
                 if splits > 1 and (d.act == _lib.AF_ACT_GEGLU or d.out_mode == _lib.AF_OUT_SPLIT_T or nk < 4 * splits):
+                    continue
+                if tile == 14 and splits > d.c1 // 64:
                     continue
                 t = timed(d, device, tile, splits)
                 if t is None:
