@@ -85,30 +85,28 @@ __device__ __forceinline__ float af_wave_max(float v) {
 // weights per step).  The workgroups that share a weight tile (same tile_n, consecutive tile_m: neighbours on one XCD under the
 // XCD-aware tile mapping) each touch a 1 / coop share of its 128-byte lines once, right at kernel start: one dword per line, 64 lines
 // per wave instruction, earliest K stages first, at most `budget` instructions per wave.  The loads are older than the first
-// stage's operand loads, so that stage's wait covers them; their data is never used, but the destination registers (`sink`) must
-// stay allocated until then (the caller keeps them alive past its main loop).  Measured: 12.31 -> 11.61 ms per denoise step
-// (profiles/r03h_weight_prefetch.txt).
+// stage's operand loads, so that stage's wait covers them.  Their data is never used: they are LDS-DMA loads (no destination VGPR) into
+// a 256-byte dump area of the kernel's LDS that nothing reads.  (The first form loaded into "sink" VGPRs by inline asm; the compiler does
+// not know such a load completes later, so under register pressure it could spill the sink and re-use the register before the data
+// landed -- the folded-LayerNorm 256 x 320 GEGLU tile faulted that way, tools/probes/r03ae_ln_geglu_fault.py.)  Measured: 12.31 -> 11.61 ms
+// per denoise step (profiles/r03h_weight_prefetch.txt).
 constexpr int AF_WPF_MAX = 8;
+constexpr int AF_WPF_DUMP_BYTES = 256;                             // LDS the caller sets aside: 64 lanes x 4 bytes
 __device__ __forceinline__ void af_prefetch_weight_tile(const half_t* wt, int kpad, int npad, int row0, int rows, int kt0, int nk, int coop, int me,
-                                                        int budget, int nw, int wave, int lane, unsigned (&sink)[AF_WPF_MAX], int sink0 = 0) {
+                                                        int budget, int nw, int wave, int lane, char* lds_dump) {
   const int total = rows * nk;                                   // 128-byte lines (64 halves) of these weight rows over this K range
   const int per = (total + coop - 1) / coop;
   const int begin = me * per;
   const int end = min(total, begin + min(per, budget * nw * 64));
 #pragma unroll
-  for (int j = 0; j + sink0 < AF_WPF_MAX; ++j) {                  // (sink0: a second tile's loads use the sinks behind the first's)
+  for (int j = 0; j < AF_WPF_MAX; ++j) {
     const int line = begin + (j * nw + wave) * 64 + lane;
     if (j < budget && line < end) {
       const int st = line / rows, row = line - st * rows;        // stage-major: the first lines cover stage 0 of every row
       const int n = row0 + row;
-      if (n < npad) {
-        const half_t* a = wt + (size_t)n * kpad + (size_t)(kt0 + st) * 64;
-        asm volatile("global_load_dword %0, %1, off" : "+v"(sink[sink0 + j]) : "v"(a) : "memory");
-      }
+      if (n < npad)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wt + (size_t)n * kpad + (size_t)(kt0 + st) * 64),
+                                         (__attribute__((address_space(3))) void*)lds_dump, 4, 0, 0);
     }
   }
-}
-__device__ __forceinline__ void af_prefetch_keep(unsigned (&sink)[AF_WPF_MAX]) {
-#pragma unroll
-  for (int j = 0; j < AF_WPF_MAX; ++j) asm volatile("" ::"v"(sink[j]));
 }

@@ -249,10 +249,11 @@ __global__ __launch_bounds__(256, 2) void af_gemm_kernel(GemmDev p) {
     }
   };
 
-  unsigned wpf_sink[AF_WPF_MAX] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
-  if (p.wpf > 0)
+  // (the 64 x 64 tile only: the 128 x 128 tile's staging buffers fill the 64 KB a launch gets without opting in, and the dump area must not
+  // alias them -- another wave's ds_write may precede this wave's late-landing prefetch)
+  if (p.wpf > 0 && BM == 64)
     af_prefetch_weight_tile(p.wt, p.kpad, (p.N + 127) / 128 * 128, tile_n * BN, BN, kt_begin, kt_end - kt_begin, p.wpf_coop, tile_m % p.wpf_coop,
-                            p.wpf, 4, tid >> 6, tid & 63, wpf_sink);
+                            p.wpf, 4, tid >> 6, tid & 63, af_smem + (size_t)2 * (BM + BN) * BK * sizeof(half_t));
   load_tile(kt_begin);
   store_tile(0);
   __syncthreads();
@@ -264,7 +265,6 @@ __global__ __launch_bounds__(256, 2) void af_gemm_kernel(GemmDev p) {
     if (more) store_tile(buf ^ 1);
     __syncthreads();
   }
-  af_prefetch_keep(wpf_sink);
 
   // ---- split-K: raw fp32 partial tile to the workspace; af_splitk_reduce applies the epilogue
   if (EPI == EPI_STD && p.splits > 1) {
@@ -471,7 +471,7 @@ int launch(const GemmDev& p0, hipStream_t stream) {
   if (p.splits > nk) p.splits = nk;
   p.kt_per_split = (nk + p.splits - 1) / p.splits;
   p.splits = (nk + p.kt_per_split - 1) / p.kt_per_split;  // no empty split
-  const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(half_t);
+  const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(half_t) + (BM == 64 ? AF_WPF_DUMP_BYTES : 0);   // staging buffers (+ the weight prefetch's dump area)
   if (p.counters && (EPI != EPI_STD || p.splits <= 1 || p.splits > 4 || tiles_m * p.tiles_n > AF_SPLITK_MAX_TILES)) p.counters = nullptr;
   dim3 grid(tiles_m * p.tiles_n, p.splits), block(256);
   hipLaunchKernelGGL((af_gemm_kernel<BM, BN, TAPS, EPI, FAST>), grid, block, lds, stream, p);

@@ -687,9 +687,9 @@ __global__ __launch_bounds__(64 * NWM * NWN, (NWM * NWN == 4 && NSLOT == 2) ? 2 
 
   // weight-tile prefetch into this XCD's L2 (af_common.h): the tile's weight rows over this K split, shared out among the
   // workgroups with the same tile_n
-  unsigned wpf_sink[AF_WPF_MAX] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
   if (p.wpf > 0)
-    af_prefetch_weight_tile(p.wt, p.kpad, p.npad, tile_n * BN, BN, kt_begin, nk, p.wpf_coop, tile_m % p.wpf_coop, p.wpf, NW, wave, lane, wpf_sink);
+    af_prefetch_weight_tile(p.wt, p.kpad, p.npad, tile_n * BN, BN, kt_begin, nk, p.wpf_coop, tile_m % p.wpf_coop, p.wpf, NW, wave, lane,
+                            af_smem + NSLOT * STAGE + BM * 8 + BN * 4);
 
   // NSLOT - 1 stages are in flight ahead of the one being computed (NSLOT = 2: the shipped tiles; NSLOT = 4: the deep-ring variants for
   // grids of at most one workgroup per CU, where nothing else hides the L2 / HBM latency of a stage -- the 16x16 level's GEMMs)
@@ -775,7 +775,6 @@ __global__ __launch_bounds__(64 * NWM * NWN, (NWM * NWN == 4 && NSLOT == 2) ? 2 
       if (kk == 0 && late_dma && i + NSLOT - 1 < nk) issue_stage(kt_begin + i + NSLOT - 1, (i + NSLOT - 1) % NSLOT);
     }
   }
-  af_prefetch_keep(wpf_sink);                  // (the loop's waits drained the prefetch loads long ago)
   const float* lnst = nullptr;
   if (ln_on) {
     // row statistics -> LDS behind the ring (BM x (mean, rstd)); every wave of the row group reads them in the epilogue
@@ -807,7 +806,7 @@ template <int TAPS, int NWM, int NWN, int TN, int EPI = E3_STD, int NSLOT = 2>
 bool launch3w(const Gemm3Dev& p0, hipStream_t stream) {
   Gemm3Dev p = p0;
   constexpr int NW = NWM * NWN, BM = NWM * 64, BN = NWN * TN * 16;
-  constexpr size_t lds = NSLOT * (size_t)(BM + BN) * 128 + (size_t)BM * 8 + (size_t)BN * 4;   // ring + the folded LayerNorm's row statistics and column sums
+  constexpr size_t lds = NSLOT * (size_t)(BM + BN) * 128 + (size_t)BM * 8 + (size_t)BN * 4 + AF_WPF_DUMP_BYTES;   // ring + the folded LayerNorm's row statistics and column sums + the prefetch dump
   static_assert(NSLOT == 2 || NSLOT == 4, "ring depths built: 2 and 4 (the counted waits cover at most two younger stages)");
   p.tiles_n = (p.N + BN - 1) / BN;
   p.tiles_m = (p.M + BM - 1) / BM;
@@ -932,9 +931,8 @@ __global__ __launch_bounds__(512) void af_conv3h_kernel(const Gemm3Dev p) {
   const int ce = min(nchunk, cb + p.kt_per_split);
   const int nst = (ce - cb) * 9;
 
-  unsigned wpf_sink[AF_WPF_MAX] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
   if (p.wpf > 0 && p.splits == 1)
-    af_prefetch_weight_tile(p.wt, p.kpad, p.npad, tile_n * BN, BN, 0, p.kpad >> 6, p.wpf_coop, tile_m % p.wpf_coop, p.wpf, NW, wave, lane, wpf_sink);
+    af_prefetch_weight_tile(p.wt, p.kpad, p.npad, tile_n * BN, BN, 0, p.kpad >> 6, p.wpf_coop, tile_m % p.wpf_coop, p.wpf, NW, wave, lane, af_smem + CH_LDS);
 
   if (nst > 0) {
 #pragma unroll
@@ -1002,7 +1000,6 @@ __global__ __launch_bounds__(512) void af_conv3h_kernel(const Gemm3Dev p) {
     }
     if (++tap == 9) tap = 0, ++chunk;
   }
-  af_prefetch_keep(wpf_sink);
   gemm3_epilogue<E3_STD, NWM, NWN, TN, CH_LDS>(p, acc, af_smem, tile_m, tile_n, wm, wn, fr, fq, tid);
 }
 
@@ -1029,11 +1026,11 @@ static bool launch_conv3h(const Gemm3Dev& p0, hipStream_t stream) {
   p.n_major = af_gemm_n_major(p.M, p.N, p.K, p.c1);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&af_conv3h_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&af_conv3h_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS + AF_WPF_DUMP_BYTES);
     attr_set = true;
   }
   dim3 grid(p.tiles_m * p.tiles_n, p.splits), block(512);
-  hipLaunchKernelGGL(af_conv3h_kernel, grid, block, CH_LDS, stream, p);
+  hipLaunchKernelGGL(af_conv3h_kernel, grid, block, CH_LDS + AF_WPF_DUMP_BYTES, stream, p);
   return p.counters != nullptr;
 }
 
@@ -1086,11 +1083,10 @@ __global__ __launch_bounds__(512, 1) void af_ff320_kernel(FfDev p) {
   const int nchunk = p.inner / FF_HC;
 
   // weights of both GEMMs towards this XCD's L2 (af_common.h): 1/32 of each per workgroup
-  unsigned sink[AF_WPF_MAX] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
   {
     const int coop = gridDim.x < 32 ? gridDim.x : 32;
-    af_prefetch_weight_tile(p.w1, p.kpad1, 2 * p.inner, 0, 2 * p.inner, 0, FF_C / 64, coop, tile_m % coop, 1, NW, wave, lane, sink);
-    af_prefetch_weight_tile(p.w2, p.kpad2, FF_C, 0, FF_C, 0, p.inner / 64, coop, tile_m % coop, 1, NW, wave, lane, sink, 4);
+    af_prefetch_weight_tile(p.w1, p.kpad1, 2 * p.inner, 0, 2 * p.inner, 0, FF_C / 64, coop, tile_m % coop, 1, NW, wave, lane, af_smem + FF_LDS);
+    af_prefetch_weight_tile(p.w2, p.kpad2, FF_C, 0, FF_C, 0, p.inner / 64, coop, tile_m % coop, 1, NW, wave, lane, af_smem + FF_LDS);
   }
 
   // ---- X tile: chunk c = rows x 64 halves, 16 pieces of 8 rows; wave w takes pieces {2w, 2w+1} of every chunk
@@ -1251,7 +1247,6 @@ __global__ __launch_bounds__(512, 1) void af_ff320_kernel(FfDev p) {
       }
     }
   }
-  af_prefetch_keep(sink);
   gemm3_epilogue<E3_STD, 2, 4, 5, FF_XS + 2 * FF_W1S + FF_W2B>(p.epi, acc2, af_smem, tile_m, 0, wm, wn, fr, fq, tid, nullptr);
 }
 
@@ -1437,9 +1432,9 @@ extern "C" int af_ff_fused(const void* x, const void* w1, const void* b1, const 
   AfLaunchScope scope(AF_FAM_GEMM, stream);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&af_ff320_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&af_ff320_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS + AF_WPF_DUMP_BYTES);
     attr_set = true;
   }
-  hipLaunchKernelGGL(af_ff320_kernel, dim3((M + FF_BM - 1) / FF_BM), dim3(512), FF_LDS, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(af_ff320_kernel, dim3((M + FF_BM - 1) / FF_BM), dim3(512), FF_LDS + AF_WPF_DUMP_BYTES, (hipStream_t)stream, p);
   return af_check_launch("af_ff_fused");
 }

@@ -404,12 +404,14 @@ def test_gemm_folded_layernorm(dev, rows, C, N, tile):
     assert rel_l2(out.float().cpu().numpy(), ref.numpy()) < TOL
 
 
-@pytest.mark.parametrize("tile,C", [(7, 64), (8, 64), (9, 320), (10, 320), (8, 320), (0, 320)])
-def test_gemm_folded_layernorm_geglu(dev, tile, C):
+@pytest.mark.parametrize("tile,C,M", [(7, 64, 520), (8, 64, 520), (9, 320, 520), (10, 320, 520), (8, 320, 520), (0, 320, 520),
+                                      (9, 320, 128), (9, 1280, 128), (9, 1280, 520), (10, 1280, 128)])
+def test_gemm_folded_layernorm_geglu(dev, tile, C, M):
+    """(The M = 128 / C = 1280 cases of tile 9 -- the 256 x 320 tile at its register limit -- faulted while the weight prefetch parked its
+    loads in VGPRs the compiler could spill and re-use before they landed; tools/probes/r03ae_ln_geglu_fault.py.)"""
     from adaface_dev_amd import ops
     from adaface_dev_amd.ldm.modules.attention import GEGLU
     from adaface_dev_amd.ldm.modules.diffusionmodules.util import LayerNorm
-    M = 520
     x, g, b = _ln_inputs(M, C)
     m, ln = GEGLU(C, 4 * C).to(dev), LayerNorm(C).to(dev)
     with torch.no_grad():

@@ -36,6 +36,8 @@ def main():
     ap.add_argument("--fresh", action="store_true", help="ignore the existing table instead of extending it")
     ap.add_argument("--cold-weights", action="store_true", help="time single launches after evicting the caches (weights cold, 1x1 activations re-read): what a GEMM meets inside the real step")
     ap.add_argument("--retune", action="store_true", help="re-time every shape this run meets; entries of shapes it does not meet are kept")
+    ap.add_argument("--tiles", default="", help="comma-separated tile ids to time (default: all)")
+    ap.add_argument("--trace", action="store_true", help="print every configuration before it is launched (to find one that faults)")
     ap.add_argument("--retune-halo", action="store_true", help="re-time only the 3x3 shapes in the scope of the halo-resident kernel (tile 14)")
     args = ap.parse_args()
     from adaface_dev_amd import SD15_UNET_CONFIG, _lib, ops, rng
@@ -65,6 +67,8 @@ def main():
         st = torch.cuda.current_stream().cuda_stream
         for _ in range(2):
             if L.af_gemm(C.byref(d), st) < 0:
+                if args.trace:
+                    print("  refused:", _lib.last_error() if hasattr(_lib, "last_error") else "", flush=True)
                 return None
         if args.cold_weights:
             # the real step meets every weight cold in HBM (1.7 GB read once per step) while activations were just produced: evict
@@ -101,6 +105,8 @@ def main():
         best, best_t, res = (0, 1), None, {}
         for tile in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14):
             geglu = d.act == _lib.AF_ACT_GEGLU
+            if args.tiles and str(tile) not in args.tiles.split(","):
+                continue
             if tile == 14 and not ops.conv_halo_eligible(d):
                 continue                        # halo-resident 3x3 kernel: its split-K slices are 64-channel chunks
             if tile >= 7 and (d.upsample not in (0, 1) or (d.upsample and tile not in (7, 8, 11, 12, 13)) or d.c1 % 64 or d.c2 % 64):
@@ -127,12 +133,16 @@ def main():
                     continue
                 if tile == 14 and splits > d.c1 // 64:
                     continue
+                if args.trace:
+                    print("timing", key, tile, splits, flush=True)
                 t = timed(d, device, tile, splits)
                 if t is None:
                     continue
                 res[f"{tile}x{splits}"] = round(t * 1e3, 1)
                 if best_t is None or t < best_t:
                     best, best_t = (tile, splits), t
+        if best_t is None:                      # nothing in the requested tile set takes this launch: keep what the table has
+            return table.get(key, (0, 1))
         table[key] = best
         gf = 2.0 * d.M * d.N * d.K / (best_t * 1e-3) / 1e12
         log.append((key, best, round(best_t * 1e3, 1), round(gf, 1), res))
