@@ -247,15 +247,20 @@ def calc_sc_recon_ssfg_mc_losses(layer_idx, flow_model, target_feats, scfg_feat,
         raise NotImplementedError("calc_sc_recon_ssfg_mc_losses: the GMA optical-flow network (use_face_flow_for_sc_matching_loss) is an "
                                   "external model; the reference's default flow_model=None path is what is built")
     device, B, N = scbg_feat.device, scbg_feat.shape[0], H * W
-    probs = {"ssfg": F.softmax(_bmm_nt(scfg_q.transpose(1, 2), ssfg_q.transpose(1, 2)).to(scfg_q.dtype), dim=1),
-             "mc": F.softmax(_bmm_nt(scbg_q.transpose(1, 2), mc_q.transpose(1, 2)).to(scbg_q.dtype), dim=1)}
+    # The reference holds the matching probabilities as [B, N_sc, N_t] and normalises over dim 1 (:2336-2344).  Here they are held
+    # TRANSPOSED, [B, N_t, N_sc], computed that way round (target queries x SC queries): the softmax then runs over the contiguous axis
+    # (torch's strided-softmax kernel took 4.2 + 2.6 ms forward + backward per 4096 x 4096 matrix, 15 % of a Stage-2 micro-batch,
+    # profiles/r03w_train2_kernel_stats.txt) and the aggregation GEMM reads them without a transposed copy.  Everything below is
+    # element-wise or a sum, so it is the same arithmetic with the two token axes swapped.
+    probs_t = {"ssfg": F.softmax(_bmm_nt(ssfg_q.transpose(1, 2), scfg_q.transpose(1, 2)).to(scfg_q.dtype), dim=2),
+               "mc": F.softmax(_bmm_nt(mc_q.transpose(1, 2), scbg_q.transpose(1, 2)).to(scbg_q.dtype), dim=2)}
     sources = {"ssfg": scfg_feat, "mc": scbg_feat}
     eye = torch.eye(N, device=device, dtype=scbg_feat.dtype).repeat(B, 1, 1)
     losses, sparse_distill, stats = {}, {}, {}
     for name in ("ssfg", "mc"):
         target = target_feats[name].permute(0, 2, 1)
         sameloc = sources[name].permute(0, 2, 1)
-        candidates = (reconstruct_feat_with_attn_aggregation(sources[name], probs[name]), sameloc, sameloc)
+        candidates = (_bmm_nt(probs_t[name], sources[name]).to(sources[name].dtype), sameloc, sameloc)   # reconstruct_feat_with_attn_aggregation
         tok = [F.mse_loss(c, target, reduction="none").mean(dim=2) for c in candidates]           # each [B, N_t]
         losses[name] = [t.mean() for t in tok]
         scaled = torch.stack([tok[0] * 10, tok[1] * (1.1 if name == "mc" else 1.02), tok[2]], dim=0)
@@ -265,9 +270,10 @@ def calc_sc_recon_ssfg_mc_losses(layer_idx, flow_model, target_feats, scfg_feat,
         best_adv, best_type = adv.max(dim=0)
         best_adv = best_adv.unsqueeze(1)
         tok_w = (5 * F.layer_norm(best_adv, (best_adv.shape[2],), weight=None, bias=None, eps=1e-5)).sigmoid()
-        sparse = torch.cat([eye, eye], dim=0).gather(0, best_type.view(B, 1, -1).expand(-1, N, -1))
-        sc_w = ((sparse + probs[name]).detach() * tok_w.detach()).sum(dim=2, keepdim=True)      # tok_w [B,1,N_t] x ensemble [B,N_sc,N_t]^T -> [B,N_sc,1]
-        sparse_distill[name] = ((sparse - probs[name]).abs() * sc_w).mean()
+        # the sparse matching of the winning candidate, as [B, N_t, N_sc] like probs_t (both candidates are the identity without a flow model)
+        sparse_t = torch.cat([eye, eye], dim=0).gather(0, best_type.view(B, -1, 1).expand(-1, -1, N))
+        sc_w = ((sparse_t + probs_t[name]).detach() * tok_w.detach().transpose(1, 2)).sum(dim=1, keepdim=True)   # tok_w [B,N_t,1] x ensemble [B,N_t,N_sc] -> [B,1,N_sc]
+        sparse_distill[name] = ((sparse_t - probs_t[name]).abs() * sc_w).mean()
         for i in range(adv.shape[0]):
             stats[f"{name}_{MATCHING_TYPES[i + 1]}_win_rate"] = torch.logical_and(adv[i] > 0, best_type == i).float().mean(dim=1)
         stats[f"{name}_avg_sparse_distill_weight"] = sc_w.mean()
