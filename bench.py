@@ -261,12 +261,29 @@ def run_train(args, ctx, dev, stage=1):
                           "last_loss": float(losses[-1]), "finite": bool(all(torch.isfinite(l) for l in losses)),
                           "per_iteration_type": per_type},
                "roofline": {"bound": "mfma", "achieved": round(train_tflop / (ms * 1e-3), 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                            "frac": round(train_tflop / (ms * 1e-3) / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                            "frac": round(train_tflop / (ms * 1e-3) / MFMA_PEAK_TFLOPS, 4), **train_traffic(stage, args),
                             "what": what},
                "families_per_micro_batch": fam}
     del tr, ldm, teacher, id2ada, text_enc
     torch.cuda.empty_cache()
     return out
+
+
+def train_traffic(stage, args):
+    """HBM-side bytes per Stage-1 distillation micro-batch, per kernel family, from the committed rocprofv3 --pmc passes of the distill-only
+    train leg (tools/profile_round.sh -> profiles/r*_train_traffic.json; FETCH_SIZE x 2 + WRITE_SIZE as for the denoise leg).  Reported only
+    for the tree it was measured on (sources_sha) and for the leg it was measured on; null otherwise."""
+    import glob
+    from adaface_dev_amd import _lib
+    if stage == 1:
+        for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_train_traffic.json")), reverse=True):
+            with open(tpath) as f:
+                tj = json.load(f)
+            if tj.get("sources_sha") == _lib.sources_sha():
+                fams = {k: round(v["bytes_per_step"]) for k, v in tj.items() if isinstance(v, dict)}
+                return {"traffic": float(sum(fams.values())), "traffic_unit": "bytes per distillation micro-batch (families below; the mix's recon "
+                        "micro-batches are not in this measurement)", "traffic_families": fams, "traffic_source": os.path.basename(tpath)}
+    return {"traffic": None}
 
 
 XATTN_BLOCK_GFLOP_PER_SAMPLE = 32.1        # SURVEY.md 8d: to_q + to_k + to_v + core + to_out of the 16 attn2 blocks

@@ -4,6 +4,7 @@
 #   <tag>_bench_kernel_stats.txt rocprofv3 --kernel-trace --stats of the denoise leg, last 10 steps
 #   <tag>_train_kernel_stats.txt, <tag>_train2_kernel_stats.txt   rocprofv3 --kernel-trace --stats of the Stage-1 / Stage-2 training legs, last 6 micro-batches
 #   <tag>_hbm_traffic.json       two separate --pmc passes (FETCH_SIZE, WRITE_SIZE) of 6 eager denoise steps, per kernel family
+#   <tag>_train_traffic.json     the same two passes over four eager Stage-1 distillation micro-batches
 set -u
 TAG=${1:-r02}
 OUT=$PWD/gpurun_out
@@ -42,4 +43,9 @@ rocprofv3 --pmc FETCH_SIZE -d $OUT/${TAG}_pmc_f -- python3 bench.py --mode denoi
 rocprofv3 --pmc WRITE_SIZE -d $OUT/${TAG}_pmc_w -- python3 bench.py --mode denoise --steps 5 --warmup 0 --no-graph --no-cpu-baseline --no-roofline > $OUT/${TAG}_pmc_w.log 2>&1
 python3 tools/pmc_traffic.py $(find $OUT/${TAG}_pmc_f -name "*_results.db" | head -1) $(find $OUT/${TAG}_pmc_w -name "*_results.db" | head -1) --steps 6 --json $OUT/${TAG}_hbm_traffic.json > $OUT/${TAG}_hbm_traffic.txt 2>&1
 rm -rf $OUT/${TAG}_trace $OUT/${TAG}_pmc_f $OUT/${TAG}_pmc_w
+# the same two passes over four eager Stage-1 distillation micro-batches (denoising steps 2, 3, 4, 2): per-family bytes per micro-batch
+rocprofv3 --pmc FETCH_SIZE -d $OUT/${TAG}_pmc_tf -- python3 bench.py --mode train --distill-only --train-steps 4 --train-warmup 0 --no-train-graphs --no-cpu-baseline --no-roofline > $OUT/${TAG}_pmc_tf.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $OUT/${TAG}_pmc_tw -- python3 bench.py --mode train --distill-only --train-steps 4 --train-warmup 0 --no-train-graphs --no-cpu-baseline --no-roofline > $OUT/${TAG}_pmc_tw.log 2>&1
+python3 tools/pmc_traffic.py $(find $OUT/${TAG}_pmc_tf -name "*_results.db" | head -1) $(find $OUT/${TAG}_pmc_tw -name "*_results.db" | head -1) --steps 4 --json $OUT/${TAG}_train_traffic.json > $OUT/${TAG}_train_traffic.txt 2>&1
+rm -rf $OUT/${TAG}_pmc_tf $OUT/${TAG}_pmc_tw
 tail -3 $OUT/${TAG}_hbm_traffic.txt; head -12 $OUT/${TAG}_bench_kernel_stats.txt
