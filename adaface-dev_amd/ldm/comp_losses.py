@@ -216,8 +216,11 @@ def map_bboxes_coords(bboxes, W1, W2):
 def var_of_laplacian(images):
     """Sharpness score per image (reference ldm/util.py ``var_of_laplacian``): variance of the 3x3 Laplacian of the grey image."""
     grey = images.mean(dim=1, keepdim=True) if images.shape[1] > 1 else images
-    k = torch.tensor([[0.0, 1.0, 0.0], [1.0, -4.0, 1.0], [0.0, 1.0, 0.0]], device=images.device, dtype=grey.dtype).view(1, 1, 3, 3)
-    return F.conv2d(grey, k, padding=1).var(dim=(1, 2, 3))
+    # the reference's F.conv2d with the [[0,1,0],[1,-4,1],[0,1,0]] kernel and padding 1, written as the five-point stencil on the zero-padded
+    # image: element-wise ops only (a library convolution of a 1-channel image lowers to a vendor-BLAS GEMM on the device)
+    p = F.pad(grey, (1, 1, 1, 1))
+    lap = p[:, :, :-2, 1:-1] + p[:, :, 2:, 1:-1] + p[:, :, 1:-1, :-2] + p[:, :, 1:-1, 2:] - 4.0 * grey
+    return lap.var(dim=(1, 2, 3))
 
 
 # ----------------------------------------------------------------------------- feature matching between the four blocks (flow_model = None)
