@@ -542,6 +542,38 @@ def test_comp_distill_iteration_reduced_width(dev, attn_aug):
     assert float((tr.arenas[0].flat_p - p0[0]).abs().sum()) > 0
 
 
+def test_arcface_terms_back_propagate_into_the_trainable_parameters(dev):
+    """The Stage-2 iteration twice from identical state and seeds: as built, and with the decoded x0 prediction detached in front of the
+    face pipeline (what the package did before the VAE decoder / ResNetFace-18 had input-gradient kernels).  Same loss value, same
+    monitors -- but the SubjBasisGenerator's gradient differs, by the ArcFace alignment / face-suppression terms' contribution
+    (ddpm.py:2511-2535 through decode_first_stage_with_grad, :899-908)."""
+    from adaface_dev_amd import rng
+
+    def run(sever):
+        tr, _, _ = trainer_setup(dev, accum=1, ffn_lora=True, stage2=True)
+        b = dict(x_start=rng.synth_input("s2.x", (2, 4, 32, 32), seed=49).to(dev), face_id_embs=rng.synth_input("s2.id", (2, 512), seed=49).to(dev))
+        ld = tr.ldm
+        ld.arcface_align_loss_weight = 1.0           # 100 x the default: the terms' gradient share becomes percents instead of 5e-4
+        if sever:
+            attached = ld.decode_first_stage_with_grad
+            ld.decode_first_stage_with_grad = lambda z: attached(z.detach())
+        tr.optimizer.zero_grad()
+        torch.manual_seed(5)
+        loss = tr.comp_distill_step(b, attn_aug="normalize_cross_attn")
+        (loss * tr.scaler.scale).backward()
+        return float(loss.detach()), dict(tr.mon_loss_dict), tr.arenas[0].flat_g.clone()
+    l1, m1, g1 = run(False)
+    l0, m0, g0 = run(True)
+    # (the attached decode keeps GroupNorm statistics for its backward and so runs the two-launch GroupNorm where the plain decode uses the
+    # one-launch forms: the decoded images agree to fp16 rounding, which the face embedding's cosine amplifies to ~1 % of the alignment loss)
+    assert abs(l1 - l0) <= 2e-2 * abs(l0) and "train/arcface_align_comp" in m1
+    assert abs(m1["train/arcface_align_comp"] - m0["train/arcface_align_comp"]) <= 5e-2 * abs(m0["train/arcface_align_comp"])
+    assert torch.isfinite(g1).all() and torch.isfinite(g0).all()
+    d = float((g1 - g0).norm()) / float(g0.norm())
+    print(f"SubjBasisGenerator gradient: relative change by the ArcFace terms' gradient {d:.3e}")
+    assert d > 1e-2
+
+
 def test_graph_replayed_segments_reproduce_the_eager_micro_batch(dev):
     """use_graphs: the teacher's forward and the student U-Net's forward / backward walks are captured into hipGraphs on their second
     call per signature and replayed afterwards.  Six micro-batches of one signature (explicit timesteps / noise, one denoising step, no
