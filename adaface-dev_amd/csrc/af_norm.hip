@@ -125,12 +125,46 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(GnArgs a) {
   }
 }
 
-// pass 2: fold partials, normalise (+ SiLU), write
+// pass 2: fold partials, normalise (+ SiLU), write.  The launch is short (two pixel iterations per thread at [8, 4096, 320]), so its
+// latency chain matters more than its bytes: the first iteration's loads and the thread's gamma / beta are requested BEFORE the partial
+// sums are folded (they do not depend on the statistics), and each iteration's loads are issued ahead of the previous one's arithmetic.
 template <int CT>
 __global__ __launch_bounds__(256) void gn_apply_kernel(GnArgs a) {
   __shared__ float mr[GN_MAXG][2];
   __shared__ float fold[8][GN_MAXG][2];
   const int t = threadIdx.x, b = blockIdx.y;
+  const int slots = CT == 1 ? a.ppb : 1;
+  const int slot = CT == 1 ? t / a.CP : 0;
+  const int chunk0 = CT == 1 ? t - slot * a.CP : t;
+  const bool active = !(CT == 1 && slot >= slots);
+  const int per = (a.HW + gridDim.x - 1) / gridDim.x;
+  const int p0 = blockIdx.x * per, p1 = min(a.HW, p0 + per);
+  constexpr int PF = CT == 1 ? 4 : 2;
+  const int step = slots * PF;
+  half8_t v[PF][CT];
+  auto load = [&](int pix, half8_t (&dst)[PF][CT]) {
+#pragma unroll
+    for (int u = 0; u < PF; ++u)
+#pragma unroll
+      for (int j = 0; j < CT; ++j) {
+        const int ch = chunk0 + 256 * j;
+        const int px = pix + u * slots;
+        if (px < p1 && ch < a.CP) dst[u][j] = gn_load(a, b, px, ch * 8);
+      }
+  };
+  int pix = p0 + slot;
+  floatx4 gm[CT][2], bt[CT][2];
+  if (active) {
+    if (pix < p1) load(pix, v);
+#pragma unroll
+    for (int j = 0; j < CT; ++j) {
+      const int c8 = min((chunk0 + 256 * j) * 8, a.C - 8);
+      gm[j][0] = *reinterpret_cast<const floatx4*>(a.gamma + c8);
+      gm[j][1] = *reinterpret_cast<const floatx4*>(a.gamma + c8 + 4);
+      bt[j][0] = *reinterpret_cast<const floatx4*>(a.beta + c8);
+      bt[j][1] = *reinterpret_cast<const floatx4*>(a.beta + c8 + 4);
+    }
+  }
   {
     // 8 lanes of partial blocks x 32 groups: every thread folds nblk / 8 partials, then 8 -> 1 through LDS
     const int g = t & 31, kl = t >> 5;
@@ -163,37 +197,23 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnArgs a) {
     }
   }
   __syncthreads();
-  const int slots = CT == 1 ? a.ppb : 1;
-  const int slot = CT == 1 ? t / a.CP : 0;
-  const int chunk0 = CT == 1 ? t - slot * a.CP : t;
-  if (CT == 1 && slot >= slots) return;
+  if (!active) return;
 
   float sc[CT][8], sh[CT][8];
 #pragma unroll
   for (int j = 0; j < CT; ++j) {
-    const int ch = chunk0 + 256 * j;
+    const int c8 = min((chunk0 + 256 * j) * 8, a.C - 8);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const int c = min(ch * 8 + e, a.C - 1);
-      const int g = c / a.cpg;
-      const float k = mr[g][1] * a.gamma[c];
+      const int g = (c8 + e) / a.cpg;
+      const float k = mr[g][1] * gm[j][e >> 2][e & 3];
       sc[j][e] = k;
-      sh[j][e] = a.beta[c] - mr[g][0] * k;
+      sh[j][e] = bt[j][e >> 2][e & 3] - mr[g][0] * k;
     }
   }
-  const int per = (a.HW + gridDim.x - 1) / gridDim.x;
-  const int p0 = blockIdx.x * per, p1 = min(a.HW, p0 + per);
-  constexpr int PF = CT == 1 ? 4 : 2;
-  for (int pix = p0 + slot; pix < p1; pix += slots * PF) {
-    half8_t v[PF][CT];
-#pragma unroll
-    for (int u = 0; u < PF; ++u)
-#pragma unroll
-      for (int j = 0; j < CT; ++j) {
-        const int ch = chunk0 + 256 * j;
-        const int px = pix + u * slots;
-        if (px < p1 && ch < a.CP) v[u][j] = gn_load(a, b, px, ch * 8);
-      }
+  for (; pix < p1; pix += step) {
+    half8_t vn[PF][CT];
+    if (pix + step < p1) load(pix + step, vn);
 #pragma unroll
     for (int u = 0; u < PF; ++u)
 #pragma unroll
@@ -211,6 +231,10 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnArgs a) {
           *reinterpret_cast<half8_t*>(a.y + ((size_t)b * a.HW + px) * a.C + ch * 8) = o;
         }
       }
+#pragma unroll
+    for (int u = 0; u < PF; ++u)
+#pragma unroll
+      for (int j = 0; j < CT; ++j) v[u][j] = vn[u][j];
   }
 }
 

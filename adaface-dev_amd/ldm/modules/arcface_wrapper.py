@@ -50,6 +50,14 @@ def image_to_uint8(image_ts):
     return ((a + 1) * 127.5).astype(np.uint8)
 
 
+def images_to_uint8(images_ts):
+    """``image_to_uint8`` of a whole batch [B, 3, H, W] -> uint8 [B, H, W, 3] with ONE device-to-host copy: clip, scale and the truncating
+    cast run on the device (same fp32 arithmetic), so a Stage-2 micro-batch hands its 16 decoded images to the detector after one
+    synchronisation instead of sixteen 3 MB float copies."""
+    u8 = ((images_ts.detach().float().clamp(-1, 1) + 1) * 127.5).to(torch.uint8)
+    return u8.permute(0, 2, 3, 1).contiguous().cpu().numpy()
+
+
 class FaceCropper(nn.Module):
     """``RetinaFaceClient`` around a caller-supplied detector: ``crop_faces(images, out_size, T)`` -> (fg crops [BS, 3, *out_size],
     bg crops [N, 3, *out_size] or None, fg boxes long [BS, 4] as (x1, y1, x2, y2), confidences [BS], detected mask [BS])."""
@@ -62,9 +70,10 @@ class FaceCropper(nn.Module):
         H, W = images_ts.shape[2], images_ts.shape[3]
         resize = lambda c: F.interpolate(c.unsqueeze(0), size=out_size, mode="bilinear", align_corners=False)
         fg, bg, boxes, conf, found = [], [], [], [], []
-        for image in images_ts:
+        images_u8 = images_to_uint8(images_ts)
+        for image, image_u8 in zip(images_ts, images_u8):
             cands = []
-            for (x, y, w, h, c) in self.detect_faces(image_to_uint8(image), T):
+            for (x, y, w, h, c) in self.detect_faces(image_u8, T):
                 if h <= T or w <= T:
                     continue
                 x0, y0 = max(0, int(x)), max(0, int(y))
