@@ -36,7 +36,7 @@ __device__ __forceinline__ half8_t gb_load(const GnBwdArgs& a, int b, int pix, i
 
 // d/du [u * sigmoid(u)]
 __device__ __forceinline__ float silu_grad(float u) {
-  const float s = 1.0f / (1.0f + __expf(-u));
+  const float s = af_sigmoid(u);
   return s * (1.0f + u * (1.0f - s));
 }
 
@@ -589,7 +589,7 @@ __global__ __launch_bounds__(256) void quickgelu_fwd_kernel(const half_t* __rest
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const float f = (float)v[e];
-    o[e] = (half_t)(f / (1.0f + __expf(-1.702f * f)));
+    o[e] = (half_t)(f * af_sigmoid(1.702f * f));
   }
   *reinterpret_cast<half8_t*>(y + i * 8) = o;
 }
@@ -603,7 +603,7 @@ __global__ __launch_bounds__(256) void quickgelu_bwd_kernel(const half_t* __rest
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const float f = (float)v[e];
-    const float sg = 1.0f / (1.0f + __expf(-1.702f * f));
+    const float sg = af_sigmoid(1.702f * f);
     o[e] = (half_t)((float)g[e] * sg * (1.0f + 1.702f * f * (1.0f - sg)));
   }
   *reinterpret_cast<half8_t*>(dx + i * 8) = o;

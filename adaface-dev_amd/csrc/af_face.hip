@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void se_residual_prelu_kernel(const half_t* __
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     float g = 1.0f;
-    if (se) g = 1.0f / (1.0f + __expf(-(float)se[b * C8 * 8 + c0 + e]));
+    if (se) g = af_sigmoid((float)se[b * C8 * 8 + c0 + e]);
     o[e] = (half_t)prelu((float)v[e] * g + (float)r[e], sl);
   }
   *reinterpret_cast<half8_t*>(y + i * 8) = o;
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256) void se_gate_grad_kernel(const half_t* __restr
   const float sl = slope[0];
   float s = 0.f, g = 0.f;
   if (c < C) {
-    g = 1.0f / (1.0f + __expf(-(float)se[(size_t)b * C + c]));
+    g = af_sigmoid((float)se[(size_t)b * C + c]);
     for (int p = w; p < HW; p += 4) {
       const size_t o = ((size_t)b * HW + p) * C + c;
       const float xv = (float)x[o];
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void se_residual_prelu_bwd_kernel(const half_t
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     float g = 1.0f, dp = 0.f;
-    if (se) g = 1.0f / (1.0f + __expf(-(float)se[b * C8 * 8 + c0 + e]));
+    if (se) g = af_sigmoid((float)se[b * C8 * 8 + c0 + e]);
     if (dpool) dp = (float)dpool[b * C8 * 8 + c0 + e];
     const float pre = (float)v[e] * g + (float)r[e];
     const float d = pre > 0.f ? (float)gy[e] : (float)gy[e] * sl;

@@ -394,7 +394,7 @@ __global__ __launch_bounds__(256, 2) void af_gemm_kernel(GemmDev p) {
           for (int i = 0; i < 4; ++i) v[i] = af_silu(v[i]);
         } else if (p.act_silu == 3) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) v[i] = v[i] / (1.0f + __expf(-1.702f * v[i]));  // x * sigmoid(1.702 x)
+          for (int i = 0; i < 4; ++i) v[i] = v[i] * af_sigmoid(1.702f * v[i]);  // x * sigmoid(1.702 x)
         }
         if (EPI == EPI_SPLIT_T && n0 >= p.split_col) {
           const int tok = m - bidx * p.rows_per_batch;
@@ -439,7 +439,7 @@ __global__ __launch_bounds__(256) void af_splitk_reduce_kernel(GemmDev p) {
     for (int i = 0; i < 4; ++i) v[i] = af_silu(v[i]);
   } else if (p.act_silu == 3) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = v[i] / (1.0f + __expf(-1.702f * v[i]));
+    for (int i = 0; i < 4; ++i) v[i] = v[i] * af_sigmoid(1.702f * v[i]);
   }
   if (p.residual) {
     const half4_t rv = *reinterpret_cast<const half4_t*>(p.residual + (size_t)m * p.N + n0);

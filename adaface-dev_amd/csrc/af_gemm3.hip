@@ -240,7 +240,7 @@ __device__ __forceinline__ void gemm3_epilogue(const Gemm3Dev& p, floatx4 (&acc)
               for (int e = 0; e < 4; ++e) v[e] = af_silu(v[e]);
             } else if (p.act == 3) {
 #pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = v[e] / (1.0f + __expf(-1.702f * v[e]));
+              for (int e = 0; e < 4; ++e) v[e] = v[e] * af_sigmoid(1.702f * v[e]);
             }
             if (p.residual) {
               const half4_t rv = *reinterpret_cast<const half4_t*>(p.residual + (size_t)m * p.N + n0);
@@ -318,7 +318,7 @@ __device__ __forceinline__ void gemm3_epilogue(const Gemm3Dev& p, floatx4 (&acc)
         for (int e = 0; e < 4; ++e) v[e] = af_silu(v[e]);
       } else if (p.act == 3) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = v[e] / (1.0f + __expf(-1.702f * v[e]));
+        for (int e = 0; e < 4; ++e) v[e] = v[e] * af_sigmoid(1.702f * v[e]);
       }
       if (EPI == E3_SPLIT_T && n0 >= p.split_col) {   // V columns: written transposed [B][N - split_col][ld_out2]
         const int tok = m - bidx * p.rows_per_batch;
