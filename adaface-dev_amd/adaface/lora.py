@@ -38,7 +38,8 @@ def dora_merged_weight(weight, lora_A, lora_B, magnitude=None, scaling=16 / 192)
     """weight [Cout, Cin, kh, kw] or [Cout, Cin]; lora_A [r, Cin, kh, kw] / [r, Cin]; lora_B [Cout, r, 1, 1] / [Cout, r];
     magnitude [Cout] (any shape with Cout elements) or None (plain LoRA).  Returns W' (fp32, weight's shape)."""
     w = weight.detach().float()
-    delta = (lora_B.detach().float().flatten(1) @ lora_A.detach().float().flatten(1)).reshape(w.shape)
+    from ..autograd_ops import low_rank_product
+    delta = low_rank_product(lora_B.detach().flatten(1), lora_A.detach().flatten(1)).reshape(w.shape)
     merged = w + scaling * delta
     if magnitude is None:
         return merged

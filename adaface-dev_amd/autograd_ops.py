@@ -228,3 +228,13 @@ def matmul_nt(a: torch.Tensor, bt: torch.Tensor) -> torch.Tensor:
     if a.is_cuda and a.shape[1] % 8 == 0 and bt.shape[0] % 4 == 0:
         return MatmulNTFn.apply(a, bt)
     return a.float() @ bt.float().t()
+
+
+def low_rank_product(b: torch.Tensor, a: torch.Tensor) -> torch.Tensor:
+    """B [Cout, r] @ A [r, Cin] -> fp32: the LoRA / DoRA weight delta that is re-evaluated every step (DoRA's weight norm ||W + s B A||, the
+    merged weights of the no-grad passes).  On the device it is the MFMA GEMM of this package (fp16 operands, fp32 accumulation: the
+    product is a small correction to W, which is itself packed to fp16 afterwards) instead of a vendor-BLAS sgemm under torch's ``@``;
+    host tensors (CPU tests of the adapter algebra, offline merging) use torch."""
+    if b.is_cuda and a.shape[0] % 8 == 0 and a.shape[1] % 4 == 0:
+        return matmul_nt(b.detach(), a.detach().t().contiguous())
+    return b.float() @ a.float()

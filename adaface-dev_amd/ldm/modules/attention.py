@@ -68,7 +68,7 @@ class GEGLU(nn.Module):
         """The projection with the LayerNorm in front of it folded in (ops.pack_matrix_ln): takes the un-normalised rows."""
         def build():
             w = self.proj.weight.detach().float()
-            b = self.proj.bias.detach().float() + w @ ln.bias.detach().float()
+            b = self.proj.bias.detach().float() + (w * ln.bias.detach().float()[None, :]).sum(dim=1)
             wi, bi = ops.interleave_geglu(w * ln.weight.detach().float()[None, :], b)
             pw = ops.pack_matrix(wi, bi, self.proj.weight.device)
             pw.ln_cs, pw.ln_eps = pw.wt.float().sum(dim=1).contiguous(), float(ln.eps)

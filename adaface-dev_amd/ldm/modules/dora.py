@@ -17,19 +17,8 @@ import torch
 import torch.nn as nn
 
 from ... import ops
-from ...autograd_ops import wgrad
+from ...autograd_ops import low_rank_product, wgrad
 from ...ops import F16
-
-
-
-def _low_rank_product(b, a):
-    """B [Cout, r] @ A [r, Cin] -> fp32, for the weight norm ||W + scaling * B A|| that DoRA re-evaluates every step: on the device it is the
-    MFMA GEMM of this package (fp16 operands, fp32 accumulation; the product is a small correction to W, so the operand rounding moves the
-    norm by ~1e-6 relative) instead of a vendor-BLAS sgemm under torch's ``@``; host tensors (CPU tests of the adapter algebra) use torch."""
-    if b.is_cuda and a.shape[0] % 8 == 0 and a.shape[1] % 4 == 0:
-        from ...autograd_ops import matmul_nt
-        return matmul_nt(b, a.t().contiguous())
-    return b.float() @ a.float()
 
 
 class DoRAConvAdapter(nn.Module):
@@ -68,7 +57,7 @@ class DoRAConvAdapter(nn.Module):
     def scales(self, conv):
         """(u = s - 1, v = s * scaling, norm) fp32 [Cout]; s = m / ||W + scaling * B A|| with the norm detached (peft)."""
         w = conv.weight.detach().float()
-        delta = _low_rank_product(self.lora_B.detach().flatten(1), self.lora_A.detach().flatten(1)).reshape(w.shape)
+        delta = low_rank_product(self.lora_B.detach().flatten(1), self.lora_A.detach().flatten(1)).reshape(w.shape)
         norm = (w + self.scaling * delta).flatten(1).norm(dim=1)
         s = self.lora_magnitude_vector.detach().float() / norm
         return (s - 1).contiguous(), (s * self.scaling).contiguous(), norm
@@ -224,7 +213,7 @@ class DoRALinearAdapter(nn.Module):
 
     def scales(self, linear):
         w = linear.weight.detach().float()
-        norm = (w + self.scaling * _low_rank_product(self.lora_B.detach(), self.lora_A.detach())).norm(dim=1)
+        norm = (w + self.scaling * low_rank_product(self.lora_B.detach(), self.lora_A.detach())).norm(dim=1)
         s = self.lora_magnitude_vector.detach().float() / norm
         return (s - 1).contiguous(), (s * self.scaling).contiguous(), norm
 

@@ -87,7 +87,7 @@ def pack_matrix_ln(w2d: torch.Tensor, bias: Optional[torch.Tensor], gamma: torch
     taken over the fp16-rounded packed rows, so the rank-one correction cancels the mean term exactly as the MFMAs saw it."""
     w = w2d.detach().to(device=device, dtype=torch.float32)
     g, bt = gamma.detach().to(device=device, dtype=torch.float32), beta.detach().to(device=device, dtype=torch.float32)
-    b = w @ bt
+    b = (w * bt[None, :]).sum(dim=1)                       # W beta (element-wise: no vendor gemv for a one-off pack)
     if bias is not None:
         b = b + bias.detach().to(device=device, dtype=torch.float32)
     pw = pack_matrix(w * g[None, :], b, device)

@@ -574,6 +574,43 @@ def test_arcface_terms_back_propagate_into_the_trainable_parameters(dev):
     assert d > 1e-2
 
 
+def test_no_vendor_gemm_or_convolution_on_the_training_path(dev):
+    """One micro-batch of every iteration type (distillation, normal recon with the face pipeline, compositional distillation) under a
+    dispatch spy: no aten mm / addmm / bmm / mv / convolution may run on a device tensor -- every matrix product of the path is one of this
+    package's kernels (torch's ``@`` / ``F.conv2d`` on the GPU are rocBLAS / hipBLASLt / MIOpen calls).  Found three such call sites in
+    round 3 (the DoRA weight norm, the merged LoRA weights of the no-grad passes, a 3x3 Laplacian)."""
+    import traceback
+    from torch.utils._python_dispatch import TorchDispatchMode
+    from adaface_dev_amd import rng
+    hits = []
+
+    class Spy(TorchDispatchMode):
+        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+            name = str(func)
+            if any(k in name for k in ("aten.mm", "aten.addmm", "aten.bmm", "aten.baddbmm", "aten.convolution", "aten.mv", "aten.addmv", "aten._scaled_mm")):
+                if any(isinstance(a, torch.Tensor) and a.is_cuda for a in args):
+                    where = [f"{os.path.basename(f.filename)}:{f.lineno}" for f in traceback.extract_stack()[:-1] if "adaface" in f.filename]
+                    hits.append((name, where[-3:]))
+            return func(*args, **(kwargs or {}))
+
+    tr, _, _ = trainer_setup(dev, accum=2, ffn_lora=True, faces=True)
+    tr.ldm.uncond_context = (rng.synth_input("s2.uncond", (1, 77, 128), seed=46).to(dev), [""], {})
+    tr.unet_distill_iter_gap = 2
+    b = dict(x_start=rng.synth_input("nv.x", (2, 4, 32, 32), seed=61).to(dev), face_id_embs=rng.synth_input("nv.id", (2, 512), seed=61).to(dev),
+             fg_mask=torch.ones(2, 1, 32, 32, device=dev))
+    kinds = []
+    with Spy():
+        for i in range(2):                                   # a recon micro-batch, then a distillation one (+ the optimizer step)
+            tr.training_step(b, i, **(dict(on_pure_noise=False) if i == 0 else {}))
+            kinds.append(tr.last_iter_type)
+    assert kinds == ["normal_recon", "unet_distill"]
+    tr2, _, _ = trainer_setup(dev, accum=1, ffn_lora=True, stage2=True)
+    with Spy():
+        tr2.training_step(b, 0)
+    assert tr2.last_iter_type == "comp_distill"
+    assert not hits, hits[:5]
+
+
 def test_graph_replayed_segments_reproduce_the_eager_micro_batch(dev):
     """use_graphs: the teacher's forward and the student U-Net's forward / backward walks are captured into hipGraphs on their second
     call per signature and replayed afterwards.  Six micro-batches of one signature (explicit timesteps / noise, one denoising step, no
