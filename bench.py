@@ -176,6 +176,11 @@ def run_train(args, ctx, dev, stage=1):
         tr.training_step(batches[i % 4], i, **step_kw)
     if world > 1:
         dist.barrier()
+    # a generational collection of the host's object graph (models, graphs, autograd nodes of three legs) inside the timed region showed up as
+    # one ~0.4 s stall in one run of four: collect now, keep the collector off while timing
+    import gc
+    gc.collect()
+    gc.disable()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(steps):
@@ -184,6 +189,7 @@ def run_train(args, ctx, dev, stage=1):
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
