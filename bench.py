@@ -176,8 +176,8 @@ def run_train(args, ctx, dev, stage=1):
         tr.training_step(batches[i % 4], i, **step_kw)
     if world > 1:
         dist.barrier()
-    # a generational collection of the host's object graph (models, graphs, autograd nodes of three legs) inside the timed region showed up as
-    # one ~0.4 s stall in one run of four: collect now, keep the collector off while timing
+    # one all-legs run in four showed a ~0.4 s stall somewhere in this loop that the per-micro-batch timings below did not; a generational
+    # collection of the host's object graph (models, graphs, autograd nodes of three legs) is the likely cause: collect now, collector off while timing
     import gc
     gc.collect()
     gc.disable()
