@@ -256,14 +256,22 @@ __global__ __launch_bounds__(256) void gn_small_kernel(GnArgs a) {
   const int items = a.HW * cpb;
   half8_t v[GS_IT];
   float s = 0.f, q = 0.f;
+  // item i = t + 256 u -> (pixel, chunk) = divmod(i, cpb): ONE integer division per thread, then steps of divmod(256, cpb) -- a runtime
+  // integer division costs ~25 VALU instructions, as much as the arithmetic of a whole 8-element chunk
+  const int pix0 = t / cpb, ch0 = t - pix0 * cpb;
+  const int dq = 256 / cpb, dr = 256 - dq * cpb;
+  {
+    int pix = pix0, ch = ch0;
 #pragma unroll
-  for (int u = 0; u < GS_IT; ++u) {
-    const int i = t + 256 * u;
-    if (i < items) {
-      const int pix = i / cpb, ch = i - pix * cpb;
-      v[u] = *reinterpret_cast<const half8_t*>(src + ((size_t)b * a.HW + pix) * ld + ch * 8);
-    } else {
-      v[u] = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+    for (int u = 0; u < GS_IT; ++u) {
+      if (t + 256 * u < items) {
+        v[u] = *reinterpret_cast<const half8_t*>(src + ((size_t)b * a.HW + pix) * ld + ch * 8);
+      } else {
+        v[u] = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+      }
+      pix += dq;
+      ch += dr;
+      if (ch >= cpb) ch -= cpb, ++pix;
     }
   }
 #pragma unroll
@@ -290,22 +298,26 @@ __global__ __launch_bounds__(256) void gn_small_kernel(GnArgs a) {
     a.stats[((size_t)b * a.groups + g) * 2 + 0] = mean;
     a.stats[((size_t)b * a.groups + g) * 2 + 1] = rstd;
   }
+  int pix = pix0, ch = ch0;
 #pragma unroll
   for (int u = 0; u < GS_IT; ++u) {
-    const int i = t + 256 * u;
-    if (i < items) {
-      const int pix = i / cpb, ch = i - pix * cpb;
+    if (t + 256 * u < items) {
       const int c = c0 + ch * 8;
+      const floatx4 g0 = *reinterpret_cast<const floatx4*>(a.gamma + c), g1 = *reinterpret_cast<const floatx4*>(a.gamma + c + 4);
+      const floatx4 b0 = *reinterpret_cast<const floatx4*>(a.beta + c), b1 = *reinterpret_cast<const floatx4*>(a.beta + c + 4);
       half8_t o;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const float k = rstd * a.gamma[c + e];
-        float f = (float)v[u][e] * k + (a.beta[c + e] - mean * k);
+        const float k = rstd * (e < 4 ? g0[e & 3] : g1[e & 3]);
+        float f = (float)v[u][e] * k + ((e < 4 ? b0[e & 3] : b1[e & 3]) - mean * k);
         if (a.silu) f = af_silu(f);
         o[e] = (half_t)f;
       }
       *reinterpret_cast<half8_t*>(a.y + ((size_t)b * a.HW + pix) * a.C + c) = o;
     }
+    pix += dq;
+    ch += dr;
+    if (ch >= cpb) ch -= cpb, ++pix;
   }
 }
 
@@ -327,17 +339,25 @@ __global__ __launch_bounds__(1024) void gn_pair_kernel(GnArgs a) {
   const int items = a.HW * ppp;
   unsigned int v[IT];                                   // fully unrolled below: stays in registers
   float s = 0.f, q = 0.f;
+  // (pixel, pair) of item t + 1024 u by steps of divmod(1024, ppp): one integer division per thread instead of one per item and phase
+  const int pix0 = t / ppp, pr0 = t - pix0 * ppp;
+  const int dq = 1024 / ppp, dr = 1024 - dq * ppp;
+  {
+    int pix = pix0, pr = pr0;
 #pragma unroll
-  for (int u = 0; u < IT; ++u) {
-    const int i = t + 1024 * u;
-    unsigned int x = 0;
-    if (i < items) {
-      const int pix = i / ppp, c = c0 + 2 * (i - pix * ppp);
-      const size_t row = (size_t)b * a.HW + pix;
-      x = c < a.c1 ? *reinterpret_cast<const unsigned int*>(a.x1 + row * a.c1 + c)
-                   : *reinterpret_cast<const unsigned int*>(a.x2 + row * a.c2 + (c - a.c1));
+    for (int u = 0; u < IT; ++u) {
+      unsigned int x = 0;
+      if (t + 1024 * u < items) {
+        const int c = c0 + 2 * pr;
+        const size_t row = (size_t)b * a.HW + pix;
+        x = c < a.c1 ? *reinterpret_cast<const unsigned int*>(a.x1 + row * a.c1 + c)
+                     : *reinterpret_cast<const unsigned int*>(a.x2 + row * a.c2 + (c - a.c1));
+      }
+      v[u] = x;
+      pix += dq;
+      pr += dr;
+      if (pr >= ppp) pr -= ppp, ++pix;
     }
-    v[u] = x;
   }
 #pragma unroll
   for (int u = 0; u < IT; ++u) {
@@ -367,15 +387,17 @@ __global__ __launch_bounds__(1024) void gn_pair_kernel(GnArgs a) {
     a.stats[((size_t)b * a.groups + g) * 2 + 0] = mean;
     a.stats[((size_t)b * a.groups + g) * 2 + 1] = rstd;
   }
+  int pix = pix0, pr = pr0;
 #pragma unroll
-  for (int u = 0; u < IT; ++u) {
-    const int i = t + 1024 * u;
-    if (i < items) {
-      const int pix = i / ppp, c = c0 + 2 * (i - pix * ppp);
+  for (int u = 0; u < IT; ++u, pix += dq, pr += dr) {
+    if (pr >= ppp) pr -= ppp, ++pix;
+    if (t + 1024 * u < items) {
+      const int c = c0 + 2 * pr;
       const half2_t h = *reinterpret_cast<const half2_t*>(&v[u]);
-      const float k0 = rstd * a.gamma[c], k1 = rstd * a.gamma[c + 1];
-      float f0 = (float)h[0] * k0 + (a.beta[c] - mean * k0);
-      float f1 = (float)h[1] * k1 + (a.beta[c + 1] - mean * k1);
+      const float2 gm = *reinterpret_cast<const float2*>(a.gamma + c), bt = *reinterpret_cast<const float2*>(a.beta + c);   // c is even
+      const float k0 = rstd * gm.x, k1 = rstd * gm.y;
+      float f0 = (float)h[0] * k0 + (bt.x - mean * k0);
+      float f1 = (float)h[1] * k1 + (bt.y - mean * k1);
       if (a.silu) {
         f0 = af_silu(f0);
         f1 = af_silu(f1);
