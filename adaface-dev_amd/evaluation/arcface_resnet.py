@@ -182,6 +182,9 @@ class FaceEncodeFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        if ctx.saved is None:
+            raise RuntimeError("FaceEncodeFn: the saved activations were released by the first backward; a second backward through the same "
+                               "embedding call is not supported")
         amax = dy.detach().abs().amax().float().clamp_min(1e-30)
         scale = torch.exp2(torch.floor(torch.log2(256.0 / amax)))
         dx = ctx.net.hip_bwd(ctx.saved, (dy.float() * scale).to(F16).contiguous())

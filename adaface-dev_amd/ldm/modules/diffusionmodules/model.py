@@ -410,6 +410,9 @@ class VAEDecodeFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         model = ctx.model
+        if ctx.saved is None:
+            raise RuntimeError("VAEDecodeFn: the saved activations were released by the first backward (they are ~0.5 GB per 512x512 image); "
+                               "a second backward through the same decode is not supported")
         amax = dy.detach().abs().amax().float().clamp_min(1e-30)
         scale = torch.exp2(torch.floor(torch.log2(1.0 / amax)))
         d = to_nhwc_f16((dy.float() * scale).contiguous(), ops.round_up(dy.shape[1], 8))
