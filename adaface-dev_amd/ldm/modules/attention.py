@@ -31,6 +31,8 @@ from .diffusionmodules.util import (Conv2d, GroupNorm32, LayerNorm, Linear, _Pac
 
 # LayerNorm -> Linear pairs of the inference pass run as ONE GEMM (ops.pack_matrix_ln); AF_FOLD_LAYERNORM=0 keeps the separate kernels (A/B runs)
 FOLD_LAYERNORM = _os.environ.get("AF_FOLD_LAYERNORM", "1") != "0"
+FUSE_XATTN = _os.environ.get("AF_FUSE_XATTN", "0") == "1"      # the C = 320 cross-attention block as ONE launch (af_xattn_fused): built, parity-green,
+                                                                # 8 % slower than the three launches (LDS-bound, csrc/af_gemm3.hip) -> off by default
 FUSE_FF = _os.environ.get("AF_FUSE_FF", "1") != "0"          # the C = 320 feed-forward as one launch (af_ff_fused); 0 = the two GEMMs (A/B runs)
 
 
@@ -194,12 +196,19 @@ class CrossAttention(nn.Module):
             q, k, ldq, ldk = qk, qk[:, Ci:], 2 * Ci, 2 * Ci
         else:
             L = context.shape[1]
-            q = self.to_q.hip(x2d) if ln is None else ops.gemm(x2d, self._packed_q_ln(ln))
-            ldq = ldk = Ci
+            ldk = Ci
             if self._kv_pre is not None:                     # projected for all layers at once by UNetModel._project_context_all
                 k, vt, ldk = self._kv_pre
             else:
                 k, vt = ops.gemm(context.reshape(B * L, context.shape[-1]), self._packed_kv(), rows_per_batch=L, split_col=Ci)
+            if (FUSE_XATTN and ln is not None and Ci == 320 and x2d.shape[1] == 320 and h == 8 and keybias is None and not self.save_cross_attn_vars
+                    and N % 128 == 0 and L <= 80 and B * N >= 24576):
+                # the 64 x 64 level: q projection (norm2 folded in), the 77-key core, to_out and the residual as ONE launch in which every
+                # wave keeps its 16 tokens from x to out (af_xattn_fused); worth it once 128-token workgroups fill the chip
+                return ops.xattn_fused(x2d, self._packed_q_ln(ln), k, vt, self.to_out[0].packed(), B=B, N=N, L=L, heads=h, scale=self.scale,
+                                       ldk=ldk, residual=residual)
+            q = self.to_q.hip(x2d) if ln is None else ops.gemm(x2d, self._packed_q_ln(ln))
+            ldq = Ci
         o = ops.attention(q, k, vt, B=B, Nq=N, L=L, heads=h, d=d, ldq=ldq, ldk=ldk, keybias=keybias, scale=self.scale)
         if self.save_cross_attn_vars:
             # attention.py:207-220 -- explicit score / prob only on the (rare) capture path

@@ -322,6 +322,25 @@ def ff_fused(x2d: torch.Tensor, pw1: PackedWeight, pw2: PackedWeight, residual: 
 _gn_ws = {}
 
 
+def xattn_fused(x2d: torch.Tensor, pw_q: PackedWeight, k: torch.Tensor, vt: torch.Tensor, pw_o: PackedWeight, *, B: int, N: int, L: int, heads: int,
+                scale: float, ldk: int, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The whole cross-attention block of a C = 320 transformer layer in one launch (af_xattn_fused): q projection (pw_q: normally with
+    the LayerNorm folded in, ops.pack_matrix_ln), 77-key attention over k [B*L, >= C] (row stride ldk) / vt [B, C, ld], output projection
+    pw_o with its bias, residual."""
+    _chk_f16(x2d, "xattn_fused.x")
+    M, Cn = x2d.shape
+    assert M == B * N and pw_q.N == Cn and pw_o.N == Cn and pw_o.K == Cn and vt.stride(2) == 1 and k.stride(1) == 1
+    out = torch.empty_like(x2d)
+    if residual is not None:
+        _chk_f16(residual, "xattn_fused.residual")
+        assert residual.shape == x2d.shape
+    rc = _lib.lib().af_xattn_fused(_p(x2d), _p(pw_q.wt), _p(pw_q.bias), _p(pw_q.ln_cs), float(pw_q.ln_eps), pw_q.kpad, _p(k), int(ldk), _p(vt), int(vt.stride(0)),
+                                   int(vt.stride(1)), _p(pw_o.wt), _p(pw_o.bias), pw_o.kpad, _p(residual), _p(out), B, N, L, Cn, heads, float(scale),
+                                   _zero_page(x2d.device).data_ptr(), _stream())
+    _lib.check(rc, "af_xattn_fused")
+    return out
+
+
 def _grow_scratch(cache: dict, device, need: int, dtype, floor: int = 0) -> torch.Tensor:
     """Per-device scratch that grows on demand.  A hipGraph bakes in the address of whatever buffer a captured launch was given, and
     growing the cached buffer frees the old one -- so while the current stream is CAPTURING the scratch comes from the capturing graph's

@@ -161,6 +161,15 @@ int af_gemm(const af_gemm_desc* d, void* stream);
 int af_ff_fused(const void* x, const void* w1, const void* b1, const void* ln_colsum, float ln_eps, int kpad1, const void* w2, const void* b2,
                 int kpad2, const void* residual, void* out, int M, int C, int inner, const void* zeros, void* stream);
 
+/* Whole cross-attention block of a transformer layer at C = 320, 8 heads (the 64 x 64 level of SD-1.5) in ONE launch (replaces
+ * attention.py:168-222 + the norm2 of :242-252): out = residual + bo + Wo . concat_h(softmax(q_h K_h^T scale) V_h), q = LN(x) Wq^T.
+ * wq / bq / ln_colsum: the q projection packed with the LayerNorm folded in (as af_gemm_desc.ln_colsum takes it; ln_colsum NULL = x is
+ * used as it is, bq NULL = no shift).  k [B * L][ldk] and vt [B][C][ldv] (batch stride vt_batch_stride, keys L .. ldv-1 zero) are this
+ * layer's slices of the context projection (head h at columns / rows 40 h ..).  N (tokens per image) % 128 == 0, L <= 80. */
+int af_xattn_fused(const void* x, const void* wq, const void* bq, const void* ln_colsum, float ln_eps, int kpad_q, const void* k, int ldk,
+                   const void* vt, int64_t vt_batch_stride, int ldv, const void* wo, const void* bo, int kpad_o, const void* residual,
+                   void* out, int B, int N, int L, int C, int heads, float scale, const void* zeros, void* stream);
+
 /* ---- GroupNorm(32) [+ SiLU], NHWC -----------------------------------------------------
  * Replaces GroupNorm32 + nn.SiLU (util.py:195-212; openaimodel.py:202-233,686-690; eps 1e-5)
  * and Normalize (attention.py:70-71; eps 1e-6).  x = concat(x1[.., c1], x2[.., c2]) along

@@ -478,6 +478,61 @@ def test_ff_fused_c320(dev, M, with_ln, with_res):
         assert torch.equal(y, out)
 
 
+@pytest.mark.parametrize("B,N,L,with_ln,with_res", [(2, 256, 77, True, True), (1, 128, 77, False, False), (3, 384, 80, True, False), (2, 128, 40, True, True)])
+def test_xattn_fused_c320(dev, B, N, L, with_ln, with_res):
+    """af_xattn_fused (the whole C = 320 cross-attention block in one launch: LayerNorm-folded q projection, 77-key softmax attention on
+    the context projection's K / V^T slices, to_out, bias, residual) against fp32 torch AND against the three-launch path of
+    CrossAttention.hip on the same weights; K / V^T handed over exactly as the U-Net does (column / row slices of a wider batched
+    projection, so the strides are not the layer's own)."""
+    from adaface_dev_amd import ops
+    from adaface_dev_amd.ldm.modules import attention as A
+    from adaface_dev_amd.ldm.modules.diffusionmodules.util import LayerNorm
+    C, Cc, heads = 320, 768, 8
+    m = A.CrossAttention(C, Cc, heads=heads, dim_head=40).to(dev)
+    ln = LayerNorm(C).to(dev)
+    with torch.no_grad():
+        for i, w in enumerate((m.to_q.weight, m.to_k.weight, m.to_v.weight, m.to_out[0].weight)):
+            w.copy_(rnd(tuple(w.shape), 30 + i, w.shape[1] ** -0.5).float())
+        m.to_out[0].bias.copy_(torch.randn(C, generator=torch.Generator().manual_seed(3)) * 0.1)
+        ln.weight.copy_(torch.randn(C, generator=torch.Generator().manual_seed(4)) * 0.2 + 1)
+        ln.bias.copy_(torch.randn(C, generator=torch.Generator().manual_seed(5)) * 0.2)
+    x, _, _ = _ln_inputs(B * N, C, seed=7)
+    ctx = rnd((B, L, Cc), 8)
+    res = rnd((B * N, C), 9) if with_res else None
+    # reference in fp32
+    xf = x.float()
+    xn = F.layer_norm(xf, (C,), ln.weight.detach().float().cpu(), ln.bias.detach().float().cpu(), 1e-5) if with_ln else xf
+    W = [w.detach().float().cpu() for w in (m.to_q.weight, m.to_k.weight, m.to_v.weight, m.to_out[0].weight)]
+    q = (xn @ W[0].t()).reshape(B, N, heads, 40).permute(0, 2, 1, 3)
+    kk = (ctx.float() @ W[1].t()).reshape(B, L, heads, 40).permute(0, 2, 1, 3)
+    vv = (ctx.float() @ W[2].t()).reshape(B, L, heads, 40).permute(0, 2, 1, 3)
+    o = torch.softmax(q @ kk.transpose(-1, -2) * 40 ** -0.5, dim=-1) @ vv
+    ref = o.permute(0, 2, 1, 3).reshape(B * N, C) @ W[3].t() + m.to_out[0].bias.detach().float().cpu()
+    if with_res:
+        ref = ref + res.float()
+    # K / V^T as slices of a wider batched projection (another layer's 640 columns in front, 320 behind)
+    pad_w = [rnd((640, Cc), 40, Cc ** -0.5), rnd((320, Cc), 41, Cc ** -0.5)]
+    wk = torch.cat([pad_w[0], m.to_k.weight.detach().cpu().half(), pad_w[1]], 0)
+    wv = torch.cat([pad_w[0], m.to_v.weight.detach().cpu().half(), pad_w[1]], 0)
+    pack = ops.pack_matrix(torch.cat([wk, wv], 0), None, dev)
+    k_all, vt_all = ops.gemm(ctx.to(dev).reshape(B * L, Cc), pack, rows_per_batch=L, split_col=wk.shape[0])
+    k, vt = k_all[:, 640:960], vt_all[:, 640:960, :]
+    pq = m._packed_q_ln(ln) if with_ln else m.to_q.packed()
+    out = ops.xattn_fused(x.to(dev), pq, k, vt, m.to_out[0].packed(), B=B, N=N, L=L, heads=heads, scale=40 ** -0.5, ldk=wk.shape[0],
+                          residual=None if res is None else res.to(dev))
+    assert rel_l2(out.float().cpu().numpy(), ref.numpy()) < TOL
+    # the three-launch path of the module on the same operands
+    m._kv_pre = (k, vt, wk.shape[0])
+    old = A.FUSE_XATTN
+    A.FUSE_XATTN = False
+    try:
+        out3 = m.hip(x.to(dev), B, N, context=ctx.to(dev), residual=None if res is None else res.to(dev), ln=ln if with_ln else None)
+    finally:
+        A.FUSE_XATTN = old
+        m._kv_pre = None
+    assert rel_l2(out.float().cpu().numpy(), out3.float().cpu().numpy()) < TOL
+
+
 def test_gemm_folded_layernorm_refuses_other_kernels(dev):
     from adaface_dev_amd import ops
     x, g, b = _ln_inputs(64, 64)
