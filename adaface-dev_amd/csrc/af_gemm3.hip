@@ -1250,266 +1250,6 @@ __global__ __launch_bounds__(512, 1) void af_ff320_kernel(FfDev p) {
   gemm3_epilogue<E3_STD, 2, 4, 5, FF_XS + 2 * FF_W1S + FF_W2B>(p.epi, acc2, af_smem, tile_m, 0, wm, wn, fr, fq, tid, nullptr);
 }
 
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Whole cross-attention block of a transformer layer at C = 320 (8 heads of 40; the 64 x 64 level) in ONE launch:
-//     out = x + b_o + W_o concat_h( softmax(q_h K_h^T * scale) V_h ),   q = LN(x) W_q^T          (attention.py:168-222, 242-252)
-// K / V^T come from the forward's one batched context projection (77 keys).  Unfused this is three launches per layer (to_q with the
-// LayerNorm folded in, the 77-key core, to_out with the residual: 21 + 23 + 21 us at U-Net batch 8), each too short to fill the chip.
-// A workgroup owns 128 tokens, and inside it EVERY WAVE OWNS 16 TOKENS FOR THE WHOLE BLOCK -- no data is exchanged between waves:
-//   * the wave's 16 x 320 slice of x sits in registers as the ten B-operand fragments of the q projection (its LayerNorm statistics are
-//     taken from them);
-//   * per head: Q^T [48 x 16] = W_q,h x^T (30 MFMAs; W_q,h rows in LDS, LayerNorm folded as in af_gemm_desc.ln_colsum, softmax scale folded
-//     in), S^T [80 keys x 16] = K_h Q^T, softmax over the keys of a token (the token is the lane's column: two shuffles), O^T [48 x 16] =
-//     V_h^T P^T, OUT^T [320 x 16] += W_o,h O^T (40 MFMAs, accumulated in registers over the heads) -- each product's accumulator layout
-//     (lane = token, four consecutive rows per register quad) IS the next product's B operand once the K index of that product is
-//     permuted accordingly (k slot 8 fq + j <-> row 4 fq + j of tile a for j < 4, of tile b for j >= 4), so the A operands (K_h, V_h^T,
-//     W_o,h rows in LDS) are read as two 8-byte halves per fragment and nothing goes through LDS between the four products;
-//   * LDS holds only weights / keys / values: W_q,h (30 KB), and double-buffered W_o,h (40 KB), K_h (10 KB), V_h^T (12 KB) whose next
-//     head's copies stream in under the current head; two workgroup barriers per head.
-// MEASURED (profiles/r03at_xattn_fused.txt): parity-green, 68 us per layer at U-Net batch 8 against 63.5 us for the three launches -- NOT
-// faster, so the module keeps the three-launch path by default (AF_FUSE_XATTN=1 selects this kernel).  Why: a wave that owns 16 tokens has ONE
-// B tile, so every weight / key / value fragment it reads from LDS (1 KB) feeds exactly one 16-cycle MFMA -- 64 B per cycle per wave, 512 B
-// per cycle for the eight waves of a CU against the LDS's 128 B per clock: 712 MFMAs x 1 KB x 8 waves = 5.8 MB of LDS reads per workgroup =
-// >= 19 us of LDS time before any latency, against ~5 us of MFMA issue.  (With the per-head DMA removed the kernel still takes 59.6 us.)
-// The tiled GEMMs of the three-launch path reuse each fragment across 4 - 5 tiles; a fused block would need 64+ tokens per wave to match,
-// which the 320-column output accumulator does not leave registers for.
-constexpr int XA_C = 320, XA_H = 8, XA_D = 40, XA_BM = 128;
-constexpr int XA_WQ = 5 * 48 * 128, XA_WO = XA_C * 128, XA_KB = 80 * 128, XA_VB = 2 * 48 * 128;
-constexpr int XA_LDS = XA_WQ + 2 * (XA_WO + XA_KB + XA_VB);      // 157,696 B
-
-struct XaDev {
-  const half_t* x;         // [M][320] un-normalised rows
-  const half_t* wq;        // packed [>= 320][kpad_q], LayerNorm-folded (gamma * W_q); rows head-major
-  const float* bq;         // [320] W_q beta (the folded LayerNorm's shift) or nullptr
-  const float* cs;         // [320] column sums of the packed rows
-  const half_t* k;         // [B * L][ldk]: this layer's keys, head h at columns 40 h
-  const half_t* vt;        // [B][320][ldv] (batch stride vbs): values transposed, keys L .. ldv-1 zero
-  const half_t* wo;        // packed [>= 320][kpad_o]
-  const float* bo;         // [320] or nullptr
-  const half_t* residual;  // [M][320] or nullptr
-  half_t* out;             // [M][320]
-  const half_t* zeros;
-  int M, N, L, kpad_q, kpad_o, ldk, ldv, ln_on;
-  long vbs;
-  float ln_eps, scale_log2e;
-};
-
-__global__ __launch_bounds__(512, 1) void af_xattn320_kernel(const XaDev p) {
-  constexpr int NW = 8;
-  extern __shared__ __attribute__((aligned(16))) char af_smem[];
-  char* WQ = af_smem;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int prow = lane >> 3, slot = lane & 7;
-  const int fr = lane & 15, fq = lane >> 4;
-  const int tile_m = blockIdx.x;
-  const int bimg = (tile_m * XA_BM) / p.N;                       // 128 | N: the tile's tokens belong to one image
-  auto WO = [&](int par) { return af_smem + XA_WQ + par * (XA_WO + XA_KB + XA_VB); };
-  auto KB_ = [&](int par) { return WO(par) + XA_WO; };
-  auto VB = [&](int par) { return WO(par) + XA_WO + XA_KB; };
-
-  // ---- loaders (1-KB LDS-DMA pieces of 8 rows x 128 B, chunk index XOR-ed with (row >> 1) & 7 on the source side)
-  auto issue_wq = [&](int h) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int pc = wave + NW * j;                              // 30 pieces: K chunk pc / 6, rows 8 (pc % 6) ..
-      if (pc < 30) {
-        const int c = pc / 6, row = (pc - c * 6) * 8 + prow;
-        const int lc = slot ^ ((row >> 1) & 7);
-        glds16(row < XA_D ? p.wq + (size_t)(h * XA_D + row) * p.kpad_q + c * 64 + lc * 8 : p.zeros, WQ + c * (48 * 128) + (pc - c * 6) * 1024);
-      }
-    }
-  };
-  auto issue_wo_k_v = [&](int h, int par) {
-    char* wo = WO(par);
-#pragma unroll
-    for (int j = 0; j < 5; ++j) {                                // 40 pieces: rows 8 pc ..
-      const int pc = wave + NW * j, row = pc * 8 + prow;
-      const int lc = slot ^ ((row >> 1) & 7);
-      glds16(lc < 5 ? p.wo + (size_t)row * p.kpad_o + h * XA_D + lc * 8 : p.zeros, wo + pc * 1024);
-    }
-    char* kb = KB_(par);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {                                // 10 pieces: keys 8 pc ..
-      const int pc = wave + NW * j;
-      if (pc < 10) {
-        const int key = pc * 8 + prow;
-        const int lc = slot ^ ((key >> 1) & 7);
-        glds16(key < p.L && lc < 5 ? p.k + ((size_t)bimg * p.L + key) * p.ldk + h * XA_D + lc * 8 : p.zeros, kb + pc * 1024);
-      }
-    }
-    char* vb = VB(par);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {                                // 12 pieces: key chunk pc / 6 (64 keys), rows 8 (pc % 6) ..
-      const int pc = wave + NW * j;
-      if (pc < 12) {
-        const int kc = pc / 6, row = (pc - kc * 6) * 8 + prow;
-        const int lc = slot ^ ((row >> 1) & 7);
-        const int key0 = kc * 64 + lc * 8;
-        glds16(row < XA_D && key0 + 8 <= p.ldv ? p.vt + (size_t)bimg * p.vbs + (size_t)(h * XA_D + row) * p.ldv + key0 : p.zeros, vb + kc * (48 * 128) + (pc - kc * 6) * 1024);
-      }
-    }
-  };
-  issue_wq(0);
-  issue_wo_k_v(0, 0);
-
-  // ---- this wave's 16 tokens: x^T fragments of the ten 32-wide K steps (lane = token fr, K chunk fq), LayerNorm statistics from them
-  const int m = tile_m * XA_BM + wave * 16 + fr;
-  half8_t xf[10];
-  {
-    const half_t* xr = p.x + (size_t)(m < p.M ? m : 0) * XA_C + fq * 8;
-#pragma unroll
-    for (int ks = 0; ks < 10; ++ks) xf[ks] = *reinterpret_cast<const half8_t*>(xr + ks * 32);
-  }
-  float mean = 0.f, rstd = 1.f;
-  if (p.ln_on) {
-    const half2_t one2 = {(half_t)1.0f, (half_t)1.0f};
-    float s = 0.f, q = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < 10; ++ks)
-#pragma unroll
-      for (int e = 0; e < 8; e += 2) {
-        const half2_t a = {xf[ks][e], xf[ks][e + 1]};
-        s = __builtin_amdgcn_fdot2(a, one2, s, false);
-        q = __builtin_amdgcn_fdot2(a, a, q, false);
-      }
-    s += __shfl_xor(s, 16, 64);
-    q += __shfl_xor(q, 16, 64);
-    s += __shfl_xor(s, 32, 64);
-    q += __shfl_xor(q, 32, 64);
-    mean = s * (1.0f / XA_C);
-    rstd = rsqrtf(fmaxf(q * (1.0f / XA_C) - mean * mean, 0.f) + p.ln_eps);
-  }
-
-  floatx4 acc2[20];
-#pragma unroll
-  for (int nt = 0; nt < 20; ++nt) acc2[nt] = floatx4{0.f, 0.f, 0.f, 0.f};
-  // fragment offsets inside a [rows x 128 B] region (rows are 16-aligned per tile: (row >> 1) & 7 == fr >> 1)
-  const int rd0 = fr * 128 + (((0 * 4 + fq) ^ (fr >> 1)) * 16);   // 16-byte fragments of the q projection's weights
-  const int rd1 = fr * 128 + (((1 * 4 + fq) ^ (fr >> 1)) * 16);
-  // two 8-byte halves of a permuted-K fragment: rows' elements 4 fq .. 4 fq + 3 of 16-element group g (g = 0 .. 3 -> elements 16 g ..)
-  auto off8 = [&](int g) { return fr * 128 + ((((2 * g) + (fq >> 1)) ^ (fr >> 1)) * 16) + (fq & 1) * 8; };
-  const int o8[4] = {off8(0), off8(1), off8(2), off8(3)};
-  auto frag8 = [&](const char* base, int ga, int gb) {
-    const half4_t lo = *reinterpret_cast<const half4_t*>(base + o8[ga]), hi = *reinterpret_cast<const half4_t*>(base + o8[gb]);
-    return half8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-  };
-  const half4_t z4 = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
-  auto pack8 = [&](const floatx4& a, const floatx4& b) {
-    return half8_t{(half_t)a[0], (half_t)a[1], (half_t)a[2], (half_t)a[3], (half_t)b[0], (half_t)b[1], (half_t)b[2], (half_t)b[3]};
-  };
-  const floatx4 zf = {0.f, 0.f, 0.f, 0.f};
-
-  for (int h = 0; h < XA_H; ++h) {
-    const int par = h & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // W_q,h and head h's W_o / K / V^T (issued a head ago) have landed
-    __builtin_amdgcn_s_barrier();                                // ... for every wave; everyone has left head h - 1
-    if (h + 1 < XA_H) issue_wo_k_v(h + 1, par ^ 1);
-    // ---- Q^T [48 x 16] = W_q,h x^T
-    floatx4 qa[3] = {zf, zf, zf};
-#pragma unroll
-    for (int c = 0; c < 5; ++c)
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-        for (int t = 0; t < 3; ++t) {
-          const half8_t wf = *reinterpret_cast<const half8_t*>(WQ + c * (48 * 128) + t * (16 * 128) + (kk ? rd1 : rd0));
-          qa[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf[2 * c + kk], qa[t], 0, 0, 0);
-        }
-    __builtin_amdgcn_s_barrier();                                // every wave is done with W_q,h
-    if (h + 1 < XA_H) issue_wq(h + 1);
-    // folded LayerNorm, projection shift, softmax scale (in log2 units); rows 40 .. 47 of the head are padding: exactly zero
-#pragma unroll
-    for (int t = 0; t < 3; ++t) {
-      const int n = t * 16 + 4 * fq;                             // head dimension of element 0
-      floatx4 cs = zf, bq = zf;
-      if (n < XA_D) {
-        if (p.ln_on) cs = *reinterpret_cast<const floatx4*>(p.cs + h * XA_D + n);
-        if (p.bq) bq = *reinterpret_cast<const floatx4*>(p.bq + h * XA_D + n);
-      }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) qa[t][e] = n < XA_D ? (rstd * (qa[t][e] - mean * cs[e]) + bq[e]) * p.scale_log2e : 0.f;
-    }
-    const half8_t q0 = pack8(qa[0], qa[1]), q1 = pack8(qa[2], zf);
-    // ---- S^T [80 keys x 16] = K_h Q^T (K index = head dimension, permuted as the accumulators of Q^T lie)
-    const char* kb = KB_(par);
-    floatx4 sa[5];
-#pragma unroll
-    for (int kt = 0; kt < 5; ++kt) {
-      const char* base = kb + kt * (16 * 128);
-      sa[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(frag8(base, 0, 1), q0, zf, 0, 0, 0);
-      sa[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(frag8(base, 2, 3), q1, sa[kt], 0, 0, 0);
-    }
-    // ---- softmax over the keys of token fr: this lane holds keys 16 kt + 4 fq + e
-    float mx = -3.0e38f;
-#pragma unroll
-    for (int kt = 0; kt < 5; ++kt)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        if (kt * 16 + 4 * fq + e >= p.L) sa[kt][e] = -3.0e38f;
-        mx = fmaxf(mx, sa[kt][e]);
-      }
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    float sum = 0.f;
-#pragma unroll
-    for (int kt = 0; kt < 5; ++kt)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        sa[kt][e] = __builtin_amdgcn_exp2f(sa[kt][e] - mx);
-        sum += sa[kt][e];
-      }
-    sum += __shfl_xor(sum, 16, 64);
-    sum += __shfl_xor(sum, 32, 64);
-    const float inv = __builtin_amdgcn_rcpf(sum);
-    // ---- O^T [48 x 16] = V_h^T P^T (K index = key, permuted as the accumulators of S^T lie: K step s = key tiles 2 s, 2 s + 1)
-    const char* vb = VB(par);
-    const half8_t p0 = pack8(sa[0], sa[1]), p1 = pack8(sa[2], sa[3]), p2 = pack8(sa[4], zf);
-    floatx4 oa[3];
-#pragma unroll
-    for (int t = 0; t < 3; ++t) {
-      const char* base = vb + t * (16 * 128);
-      oa[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(frag8(base, 0, 1), p0, zf, 0, 0, 0);
-      oa[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(frag8(base, 2, 3), p1, oa[t], 0, 0, 0);
-      oa[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(frag8(base + 48 * 128, 0, 1), p2, oa[t], 0, 0, 0);
-    }
-#pragma unroll
-    for (int t = 0; t < 3; ++t)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) oa[t][e] *= inv;
-    const half8_t o0 = pack8(oa[0], oa[1]), o1 = pack8(oa[2], zf);
-    // ---- OUT^T [320 x 16] += W_o,h O^T
-    const char* wo = WO(par);
-#pragma unroll
-    for (int nt = 0; nt < 20; ++nt) {
-      const char* base = wo + nt * (16 * 128);
-      acc2[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(frag8(base, 0, 1), o0, acc2[nt], 0, 0, 0);
-      acc2[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(frag8(base, 2, 3), o1, acc2[nt], 0, 0, 0);
-    }
-  }
-  // ---- epilogue: output bias, residual; this lane holds channels 16 nt + 4 fq + e of token fr
-  if (m < p.M) {
-#pragma unroll
-    for (int nt = 0; nt < 20; ++nt) {
-      const int c = nt * 16 + 4 * fq;
-      floatx4 v = acc2[nt];
-      if (p.bo) {
-        const floatx4 b = *reinterpret_cast<const floatx4*>(p.bo + c);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] += b[e];
-      }
-      if (p.residual) {
-        const half4_t r = *reinterpret_cast<const half4_t*>(p.residual + (size_t)m * XA_C + c);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] += (float)r[e];
-      }
-      const half4_t o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-      *reinterpret_cast<half4_t*>(p.out + (size_t)m * XA_C + c) = o;
-    }
-  }
-}
-
 }  // namespace
 
 // Called by af_gemm (af_gemm.hip) for tile == 3 after the common argument validation.  Returns 1 if the shape is
@@ -1697,49 +1437,4 @@ extern "C" int af_ff_fused(const void* x, const void* w1, const void* b1, const 
   }
   hipLaunchKernelGGL(af_ff320_kernel, dim3((M + FF_BM - 1) / FF_BM), dim3(512), FF_LDS + AF_WPF_DUMP_BYTES, (hipStream_t)stream, p);
   return af_check_launch("af_ff_fused");
-}
-
-// Whole cross-attention block at C = 320 (af_xattn320_kernel above): q projection with the LayerNorm folded in (wq / bq / ln_colsum as
-// ops.pack_matrix_ln packs them; ln_colsum NULL = x is used as it is), 77-key attention over this layer's slices of the batched K / V^T
-// projection, output projection, bias and residual.
-extern "C" int af_xattn_fused(const void* x, const void* wq, const void* bq, const void* ln_colsum, float ln_eps, int kpad_q, const void* k, int ldk,
-                              const void* vt, int64_t vt_batch_stride, int ldv, const void* wo, const void* bo, int kpad_o, const void* residual,
-                              void* out, int B, int N, int L, int C, int heads, float scale, const void* zeros, void* stream) {
-  AF_REQUIRE(x && wq && k && vt && wo && out && zeros, "af_xattn_fused: null pointer");
-  AF_SUPPORTED(C == XA_C && heads == XA_H, "af_xattn_fused: built for C = 320, 8 heads (the 64 x 64 level of SD-1.5)");
-  AF_REQUIRE(B > 0 && N > 0 && N % XA_BM == 0, "af_xattn_fused: tokens per image must be a positive multiple of 128");
-  AF_SUPPORTED(L > 0 && L <= 80, "af_xattn_fused: at most 80 keys");
-  AF_REQUIRE(kpad_q >= C && kpad_q % 64 == 0 && kpad_o >= C && kpad_o % 64 == 0, "af_xattn_fused: weight row strides must be 64-multiples covering C");
-  AF_REQUIRE(ldk >= C && ldk % 8 == 0 && ldv >= L && ldv % 8 == 0 && vt_batch_stride % 8 == 0, "af_xattn_fused: K / V^T strides must keep 16-byte alignment");
-  XaDev p;
-  p.x = (const half_t*)x;
-  p.wq = (const half_t*)wq;
-  p.bq = (const float*)bq;
-  p.cs = (const float*)ln_colsum;
-  p.ln_on = ln_colsum != nullptr;
-  p.k = (const half_t*)k;
-  p.vt = (const half_t*)vt;
-  p.wo = (const half_t*)wo;
-  p.bo = (const float*)bo;
-  p.residual = (const half_t*)residual;
-  p.out = (half_t*)out;
-  p.zeros = (const half_t*)zeros;
-  p.M = B * N;
-  p.N = N;
-  p.L = L;
-  p.kpad_q = kpad_q;
-  p.kpad_o = kpad_o;
-  p.ldk = ldk;
-  p.ldv = ldv;
-  p.vbs = (long)vt_batch_stride;
-  p.ln_eps = ln_eps;
-  p.scale_log2e = scale * 1.4426950408889634f;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&af_xattn320_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, XA_LDS);
-    attr_set = true;
-  }
-  AfLaunchScope scope(AF_FAM_XATTN, stream);
-  hipLaunchKernelGGL(af_xattn320_kernel, dim3(p.M / XA_BM), dim3(512), XA_LDS, (hipStream_t)stream, p);
-  return af_check_launch("af_xattn_fused");
 }
