@@ -26,16 +26,16 @@ __device__ __forceinline__ void glds16(const half_t* src, char* lds_dst) {
 //     W_o,h rows in LDS) are read as two 8-byte halves per fragment and nothing goes through LDS between the four products;
 //   * LDS holds only weights / keys / values: W_q,h (30 KB), and double-buffered W_o,h (40 KB), K_h (10 KB), V_h^T (12 KB) whose next
 //     head's copies stream in under the current head; two workgroup barriers per head.
-// MEASURED (profiles/r03at_xattn_fused.txt): parity-green, 68 us per layer at U-Net batch 8 against 63.5 us for the three launches -- NOT
-// faster, so the module keeps the three-launch path by default (AF_FUSE_XATTN=1 selects this kernel).  Why: a wave that owns 16 tokens has ONE
-// B tile, so every weight / key / value fragment it reads from LDS (1 KB) feeds exactly one 16-cycle MFMA -- 64 B per cycle per wave, 512 B
-// per cycle for the eight waves of a CU against the LDS's 128 B per clock: 712 MFMAs x 1 KB x 8 waves = 5.8 MB of LDS reads per workgroup =
-// >= 19 us of LDS time before any latency, against ~5 us of MFMA issue.  (With the per-head DMA removed the kernel still takes 59.6 us.)
-// The tiled GEMMs of the three-launch path reuse each fragment across 4 - 5 tiles; a fused block would need 64+ tokens per wave to match,
-// which the 320-column output accumulator does not leave registers for.
+// MEASURED (profiles/r03at_xattn_fused.txt): parity-green; 63.2 us per layer at U-Net batch 8 against 63.6 us for the three launches, -0.03 ms per
+// denoise step (three alternating runs each) -- on par alone, marginally ahead in the step (two launches fewer per layer).  First form 68 us:
+// the folded LayerNorm's column sums were loaded from global memory inside the head loop (an L2 round trip on every head's critical path) --
+// staged in LDS once: 64.0; W_o fragments requested a pair of output tiles ahead, dependent MFMAs spaced: 63.2.  What bounds it: a wave that owns
+// 16 tokens has ONE B tile, so every 1-KB weight / key / value fragment read from LDS feeds exactly one MFMA (the tiled GEMMs reuse a fragment
+// over 4 - 5 tiles): 5.8 MB of LDS reads per workgroup, and the four products of a head are a dependent chain inside the wave (Q -> S -> P -> O ->
+// OUT) that only the SIMD's second wave can overlap.  With the per-head DMA removed it still takes 59.6 us.
 constexpr int XA_C = 320, XA_H = 8, XA_D = 40, XA_BM = 128;
 constexpr int XA_WQ = 5 * 48 * 128, XA_WO = XA_C * 128, XA_KB = 80 * 128, XA_VB = 2 * 48 * 128;
-constexpr int XA_LDS = XA_WQ + 2 * (XA_WO + XA_KB + XA_VB);      // 157,696 B
+constexpr int XA_LDS = XA_WQ + 2 * (XA_WO + XA_KB + XA_VB) + 2 * XA_C * 4;      // 157,696 B + the folded LayerNorm's column sums and shift (2,560 B)
 
 struct XaDev {
   const half_t* x;         // [M][320] un-normalised rows
@@ -112,6 +112,13 @@ __global__ __launch_bounds__(512, 1) void af_xattn320_kernel(const XaDev p) {
   };
   issue_wq(0);
   issue_wo_k_v(0, 0);
+  // the folded LayerNorm's column sums and the projection shift of all 320 q columns: staged in LDS once (a global load per head inside the
+  // loop would put an L2 round trip on every head's critical path -- and, next to LDS-DMA loads in flight, a full vmcnt(0) drain)
+  float* csb = reinterpret_cast<float*>(af_smem + XA_WQ + 2 * (XA_WO + XA_KB + XA_VB));
+  if (tid < XA_C) {
+    csb[tid] = p.ln_on ? p.cs[tid] : 0.f;
+    csb[XA_C + tid] = p.bq ? p.bq[tid] : 0.f;
+  }
 
   // ---- this wave's 16 tokens: x^T fragments of the ten 32-wide K steps (lane = token fr, K chunk fq), LayerNorm statistics from them
   const int m = tile_m * XA_BM + wave * 16 + fr;
@@ -184,8 +191,8 @@ __global__ __launch_bounds__(512, 1) void af_xattn320_kernel(const XaDev p) {
       const int n = t * 16 + 4 * fq;                             // head dimension of element 0
       floatx4 cs = zf, bq = zf;
       if (n < XA_D) {
-        if (p.ln_on) cs = *reinterpret_cast<const floatx4*>(p.cs + h * XA_D + n);
-        if (p.bq) bq = *reinterpret_cast<const floatx4*>(p.bq + h * XA_D + n);
+        cs = *reinterpret_cast<const floatx4*>(csb + h * XA_D + n);
+        bq = *reinterpret_cast<const floatx4*>(csb + XA_C + h * XA_D + n);
       }
 #pragma unroll
       for (int e = 0; e < 4; ++e) qa[t][e] = n < XA_D ? (rstd * (qa[t][e] - mean * cs[e]) + bq[e]) * p.scale_log2e : 0.f;
@@ -194,12 +201,11 @@ __global__ __launch_bounds__(512, 1) void af_xattn320_kernel(const XaDev p) {
     // ---- S^T [80 keys x 16] = K_h Q^T (K index = head dimension, permuted as the accumulators of Q^T lie)
     const char* kb = KB_(par);
     floatx4 sa[5];
+    // (independent accumulators back to back: a dependent MFMA right behind its predecessor waits out the pipeline)
 #pragma unroll
-    for (int kt = 0; kt < 5; ++kt) {
-      const char* base = kb + kt * (16 * 128);
-      sa[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(frag8(base, 0, 1), q0, zf, 0, 0, 0);
-      sa[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(frag8(base, 2, 3), q1, sa[kt], 0, 0, 0);
-    }
+    for (int kt = 0; kt < 5; ++kt) sa[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(frag8(kb + kt * (16 * 128), 0, 1), q0, zf, 0, 0, 0);
+#pragma unroll
+    for (int kt = 0; kt < 5; ++kt) sa[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(frag8(kb + kt * (16 * 128), 2, 3), q1, sa[kt], 0, 0, 0);
     // ---- softmax over the keys of token fr: this lane holds keys 16 kt + 4 fq + e
     float mx = -3.0e38f;
 #pragma unroll
@@ -227,24 +233,42 @@ __global__ __launch_bounds__(512, 1) void af_xattn320_kernel(const XaDev p) {
     const half8_t p0 = pack8(sa[0], sa[1]), p1 = pack8(sa[2], sa[3]), p2 = pack8(sa[4], zf);
     floatx4 oa[3];
 #pragma unroll
-    for (int t = 0; t < 3; ++t) {
-      const char* base = vb + t * (16 * 128);
-      oa[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(frag8(base, 0, 1), p0, zf, 0, 0, 0);
-      oa[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(frag8(base, 2, 3), p1, oa[t], 0, 0, 0);
-      oa[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(frag8(base + 48 * 128, 0, 1), p2, oa[t], 0, 0, 0);
-    }
+    for (int t = 0; t < 3; ++t) oa[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(frag8(vb + t * (16 * 128), 0, 1), p0, zf, 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) oa[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(frag8(vb + t * (16 * 128), 2, 3), p1, oa[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) oa[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(frag8(vb + 48 * 128 + t * (16 * 128), 0, 1), p2, oa[t], 0, 0, 0);
 #pragma unroll
     for (int t = 0; t < 3; ++t)
 #pragma unroll
       for (int e = 0; e < 4; ++e) oa[t][e] *= inv;
     const half8_t o0 = pack8(oa[0], oa[1]), o1 = pack8(oa[2], zf);
-    // ---- OUT^T [320 x 16] += W_o,h O^T
+    // ---- OUT^T [320 x 16] += W_o,h O^T   (fragments of the next two output tiles are requested before this pair's MFMAs)
     const char* wo = WO(par);
+    half8_t wa[2][2], wb[2][2];
 #pragma unroll
-    for (int nt = 0; nt < 20; ++nt) {
-      const char* base = wo + nt * (16 * 128);
-      acc2[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(frag8(base, 0, 1), o0, acc2[nt], 0, 0, 0);
-      acc2[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(frag8(base, 2, 3), o1, acc2[nt], 0, 0, 0);
+    for (int u = 0; u < 2; ++u) {
+      wa[u][0] = frag8(wo + u * (16 * 128), 0, 1);
+      wa[u][1] = frag8(wo + u * (16 * 128), 2, 3);
+    }
+#pragma unroll
+    for (int nt = 0; nt < 20; nt += 2) {
+      if (nt + 2 < 20) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          wb[u][0] = frag8(wo + (nt + 2 + u) * (16 * 128), 0, 1);
+          wb[u][1] = frag8(wo + (nt + 2 + u) * (16 * 128), 2, 3);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) acc2[nt + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[u][0], o0, acc2[nt + u], 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) acc2[nt + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[u][1], o1, acc2[nt + u], 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        wa[u][0] = wb[u][0];
+        wa[u][1] = wb[u][1];
+      }
     }
   }
   // ---- epilogue: output bias, residual; this lane holds channels 16 nt + 4 fq + e of token fr

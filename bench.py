@@ -346,8 +346,9 @@ def cross_attn_block_time(unet, ctx2, B, dev):
             m._kv_pre = None
     tf = XATTN_BLOCK_GFLOP_PER_SAMPLE * 1e9 * n / (tot * 1e-3) / 1e12
     return {"ms_per_step": round(tot, 4), "kv_projection_ms": round(t_kv, 4), "tflops": round(tf, 1), "mfma_frac": round(tf / MFMA_PEAK_TFLOPS, 4),
-            "definition": "sum over the 16 attn2 blocks of [to_q GEMM (norm2 folded in) + 77-key attention core + to_out GEMM with residual] + one batched "
-                          "k/v projection, each timed in isolation (hipGraph of 10 calls); 32.1 GFLOP per U-Net sample (SURVEY.md 8d)",
+            "definition": "sum over the 16 attn2 blocks of [to_q (norm2 folded in) + 77-key attention core + to_out with residual: ONE launch (af_xattn_fused) at "
+                          "C = 320 / U-Net batch >= 6, three launches otherwise] + one batched k/v projection, each block timed in isolation (hipGraph of 10 calls); "
+                          "32.1 GFLOP per U-Net sample (SURVEY.md 8d)",
             "layers_C_N_us": per_layer}
 
 
@@ -444,8 +445,12 @@ def run_denoise(args, ctx, dev):
 
     roofline = None
     if not args.no_roofline and rank == 0:
-        # instrumented pass: same steps, eager launches, hipEvents around every launch of each family
+        # instrumented pass: same steps, eager launches, hipEvents around every launch of each family.  The C = 320 cross-attention blocks
+        # run here in their three-launch form (to_q GEMM, core, to_out GEMM) so that the families keep their definitions -- every projection
+        # in the GEMM family, the 16 cores in `xattn`; the timed region above ran them as one launch each (af_xattn_fused, on par: profiles/r03at)
+        from adaface_dev_amd.ldm.modules import attention as _attn_mod
         state["graph"] = None
+        fused_xattn, _attn_mod.FUSE_XATTN = _attn_mod.FUSE_XATTN, False
         with torch.no_grad():
             ops.prof_reset()
             ops.prof_enable(True)
@@ -454,6 +459,7 @@ def run_denoise(args, ctx, dev):
                 step(args.warmup + i)
             torch.cuda.synchronize()
             ops.prof_enable(False)
+        _attn_mod.FUSE_XATTN = fused_xattn
         fam = {}
         for name, f in (("gemm", _lib.AF_FAM_GEMM), ("attn", _lib.AF_FAM_ATTN), ("gnorm", _lib.AF_FAM_GNORM),
                         ("lnorm", _lib.AF_FAM_LNORM), ("elem", _lib.AF_FAM_ELEM), ("xattn", _lib.AF_FAM_XATTN)):

@@ -7,7 +7,7 @@ import json
 import sqlite3
 import sys
 
-FAMILIES = (("gemm", ("af_gemm", "af_splitk_reduce")), ("attn", ("af_attn", "af_xattn", "attn_bwd", "attn_delta", "xattn_")),
+FAMILIES = (("gemm", ("af_gemm", "af_splitk_reduce", "af_ff320", "af_conv3h")), ("attn", ("af_attn", "af_xattn", "attn_bwd", "attn_delta", "xattn_")),
             ("gnorm", ("gn_partial", "gn_apply", "gn_small", "gn_pair", "gn_bwd")), ("lnorm", ("layernorm_kernel", "layernorm_bwd", "layernorm_param")))
 
 
