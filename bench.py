@@ -183,8 +183,11 @@ def run_train(args, ctx, dev, stage=1):
     gc.disable()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    host_ms = []
     for i in range(steps):
+        th = time.perf_counter()
         losses.append(tr.training_step(batches[i % 4], warm + i, **step_kw))
+        host_ms.append(round((time.perf_counter() - th) * 1e3, 1))
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -265,7 +268,8 @@ def run_train(args, ctx, dev, stage=1):
                           "hipgraph_segments": [f"{g.name}: {sum(1 for e in g.entries.values() if e.get('state') == 'graph')} captured" for g in tr.graph_segments],
                           "optimizer_steps": tr.global_step, "skipped_steps": tr.skipped_steps, "loss_scale": tr.scaler.scale,
                           "last_loss": float(losses[-1]), "finite": bool(all(torch.isfinite(l) for l in losses)),
-                          "per_iteration_type": per_type},
+                          "per_iteration_type": per_type,
+                          "host_ms_per_micro_batch_in_timed_region": host_ms},
                "roofline": {"bound": "mfma", "achieved": round(train_tflop / (ms * 1e-3), 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                             "frac": round(train_tflop / (ms * 1e-3) / MFMA_PEAK_TFLOPS, 4), **train_traffic(stage, args),
                             "what": what},
