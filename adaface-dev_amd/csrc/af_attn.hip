@@ -595,13 +595,8 @@ template <int DS, bool ONES>
 int launch_attn2chain(const AttnArgs& a, hipStream_t stream) {
   constexpr int DP = 16 * DS, DT = (DS + 1) / 2, DV = 32 * DT;
   constexpr size_t lds = (size_t)2 * (KB * (DP + 8) + 2 * DV * VST) * sizeof(half_t);
-  static bool attr_set = false;
-  if (lds > 65536 && !attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&af_attn2_kernel<DS, ONES>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return af_fail(AF_E_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
-    attr_set = true;
-  }
+  static bool attr_set = false;  // benign race: idempotent attribute
+  if (!af_allow_dyn_lds(reinterpret_cast<const void*>(&af_attn2_kernel<DS, ONES>), lds, attr_set, "af_attention")) return af_check_launch("af_attention");
   const int qblocks = (a.Nq + 255) / 256, bh8 = (a.B * a.heads + 7) / 8 * 8;
   hipLaunchKernelGGL((af_attn2_kernel<DS, ONES>), dim3(qblocks * bh8), dim3(256), lds, stream, a);
   return af_check_launch("af_attention(two-chain)");
@@ -804,13 +799,8 @@ template <int DS, bool ONES>
 int launch_xattn(const AttnArgs& a, hipStream_t stream) {
   constexpr int DP = 16 * DS, DT = (DS + 1) / 2, DV = 32 * DT;
   constexpr size_t lds = (size_t)(128 * (DP + 8) + 4 * DV * VST) * sizeof(half_t);
-  static bool attr_set = false;
-  if (lds > 65536 && !attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&af_xattn_kernel<DS, ONES>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return af_fail(AF_E_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
-    attr_set = true;
-  }
+  static bool attr_set = false;  // benign race: idempotent attribute
+  if (!af_allow_dyn_lds(reinterpret_cast<const void*>(&af_xattn_kernel<DS, ONES>), lds, attr_set, "af_attention")) return af_check_launch("af_attention");
   const int groups = (a.Nq + 31) / 32;                       // 32-query groups per (batch, head)
   // a workgroup = 4 waves x groups_per_wave groups; aim at >= 512 workgroups while K / V^T staging stays amortised
   int gpw = groups / 32;                                      // N = 4096 -> 4 groups per wave, 8 workgroups per (b, h)
@@ -826,12 +816,7 @@ int launch_attn2(const AttnArgs& a, hipStream_t stream) {
   constexpr int DP = 16 * DS, DT = (DS + 1) / 2, DV = 32 * DT;
   constexpr size_t lds = (size_t)2 * (KB * (DP + 8) + 2 * DV * VST) * sizeof(half_t);
   static bool attr_set = false;  // benign race: idempotent attribute
-  if (lds > 65536 && !attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&af_attn_kernel<DS, ONES, GENERAL>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return af_fail(AF_E_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
-    attr_set = true;
-  }
+  if (!af_allow_dyn_lds(reinterpret_cast<const void*>(&af_attn_kernel<DS, ONES, GENERAL>), lds, attr_set, "af_attention")) return af_check_launch("af_attention");
   const int qblocks = (a.Nq + 127) / 128, bh8 = (a.B * a.heads + 7) / 8 * 8;
   dim3 grid(qblocks * bh8), block(256);
   hipLaunchKernelGGL((af_attn_kernel<DS, ONES, GENERAL>), grid, block, lds, stream, a);

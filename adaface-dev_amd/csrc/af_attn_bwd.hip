@@ -410,11 +410,11 @@ int launch_bwd(const BwdArgs& a, hipStream_t s) {
   constexpr size_t lds_dq = 2 * (size_t)(2 * 32 * RST + DV * TST) * sizeof(half_t);          // two copies of the stage tiles
   constexpr size_t lds_dkv = 2 * (size_t)(2 * 32 * RST + 2 * DV * TST) * sizeof(half_t);
   static_assert(lds_dkv <= 160 * 1024, "LDS budget");
-  static bool attr_set = false;
-  if (lds_dkv > 65536 && !attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<DS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dkv);
-    attr_set = true;
-  }
+  static_assert(lds_dq <= 160 * 1024, "LDS budget");
+  static bool attr_dkv = false, attr_dq = false;
+  if (!af_allow_dyn_lds(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<DS>), lds_dkv, attr_dkv, "af_attention_bwd(dkv)") ||
+      !af_allow_dyn_lds(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<DS>), lds_dq, attr_dq, "af_attention_bwd(dq)"))
+    return af_check_launch("af_attention_bwd");
   hipLaunchKernelGGL(attn_bwd_dq_kernel<DS>, dim3((a.Nq + 127) / 128, a.heads, a.B), dim3(256), lds_dq, s, a);
   hipLaunchKernelGGL(attn_bwd_dkv_kernel<DS>, dim3((a.L + 127) / 128, a.heads, a.B), dim3(256), lds_dkv, s, a);
   return af_check_launch("af_attention_bwd");

@@ -31,6 +31,9 @@ struct AfLaunchScope {
   ~AfLaunchScope();
 };
 int af_check_launch(const char* what);
+// Dynamic LDS above the 64 KB default needs hipFuncAttributeMaxDynamicSharedMemorySize once per kernel.  `done` is the caller's static flag (set only on
+// success).  A refusal is remembered per thread and reported by the next af_check_launch(); callers skip the launch when this returns false.
+bool af_allow_dyn_lds(const void* kernel, size_t bytes, bool& done, const char* what);
 // af_bwd.hip: [B, N, C (row stride ldx)] -> [B, C, ldy], token index contiguous, tokens N .. ldy zero-filled (16-byte accesses when aligned)
 void af_launch_transpose_tokens(const _Float16* x, _Float16* y, int B, int N, int C, int ldx, int ldy, hipStream_t stream);
 struct AfTransposeJob {

@@ -401,6 +401,11 @@ __global__ __launch_bounds__(256, 2) void af_gemm_kernel(GemmDev p) {
           half_t* o2 = p.out2 + ((size_t)bidx * (p.N - p.split_col) + (n0 - p.split_col)) * p.ld_out2 + tok;
 #pragma unroll
           for (int i = 0; i < 4; ++i) o2[(size_t)i * p.ld_out2] = (half_t)v[i];
+          if (tok == p.rows_per_batch - 1) {          // the row pad tok + 1 .. ld_out2 - 1 is part of the output: zero
+            for (int t = 1; tok + t < p.ld_out2; ++t)
+#pragma unroll
+              for (int i = 0; i < 4; ++i) o2[(size_t)i * p.ld_out2 + t] = (half_t)0.f;
+          }
         } else {
           if (p.residual) {
             const half4_t rv = *reinterpret_cast<const half4_t*>(p.residual + (size_t)m * p.N + n0);

@@ -325,6 +325,11 @@ __device__ __forceinline__ void gemm3_epilogue(const Gemm3Dev& p, floatx4 (&acc)
         half_t* o2 = p.out2 + ((size_t)bidx * (p.N - p.split_col) + (n0 - p.split_col)) * p.ld_out2 + tok;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o2[(size_t)e * p.ld_out2] = (half_t)v[e];
+        if (tok == p.rows_per_batch - 1) {            // the row pad tok + 1 .. ld_out2 - 1 is part of the output: zero (consumers multiply it by P = 0)
+          for (int t = 1; tok + t < p.ld_out2; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o2[(size_t)e * p.ld_out2 + t] = (half_t)0.f;
+        }
         continue;
       }
       if (p.residual) {
@@ -538,13 +543,9 @@ bool launch3(const Gemm3Dev& p0, hipStream_t stream) {
   if (p.counters && (TN > 5 || p.splits <= 1 || p.splits > 4 || tiles_m * p.tiles_n > AF_SPLITK_MAX_TILES)) p.counters = nullptr;
   p.n_major = af_gemm_n_major(p.M, p.N, p.K, TAPS == 9 ? p.c1 + p.c2 : p.K);
   static bool attr_set = false;
-  if (lds > 65536 && !attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&af_gemm3_kernel<TAPS, NWM, NWN, TN, EPI, NST>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  const bool lds_ok = af_allow_dyn_lds(reinterpret_cast<const void*>(&af_gemm3_kernel<TAPS, NWM, NWN, TN, EPI, NST>), lds, attr_set, "af_gemm");
   dim3 grid(tiles_m * p.tiles_n, p.splits), block(64 * NW);
-  hipLaunchKernelGGL((af_gemm3_kernel<TAPS, NWM, NWN, TN, EPI, NST>), grid, block, lds, stream, p);
+  if (lds_ok) hipLaunchKernelGGL((af_gemm3_kernel<TAPS, NWM, NWN, TN, EPI, NST>), grid, block, lds, stream, p);
   return p.counters != nullptr;      // true: the kernel reduced the K-slices itself
 }
 
@@ -818,13 +819,9 @@ bool launch3w(const Gemm3Dev& p0, hipStream_t stream) {
   if (p.counters && (TN > 5 || p.splits <= 1 || p.splits > 4 || p.tiles_m * p.tiles_n > AF_SPLITK_MAX_TILES)) p.counters = nullptr;
   p.n_major = af_gemm_n_major(p.M, p.N, p.K, TAPS == 9 ? p.c1 + p.c2 : p.K);
   static bool attr_set = false;
-  if (lds > 65536 && !attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&af_gemm3w_kernel<TAPS, NWM, NWN, TN, EPI, NSLOT>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  const bool lds_ok = af_allow_dyn_lds(reinterpret_cast<const void*>(&af_gemm3w_kernel<TAPS, NWM, NWN, TN, EPI, NSLOT>), lds, attr_set, "af_gemm");
   dim3 grid(p.tiles_m * p.tiles_n, p.splits), block(64 * NW);
-  hipLaunchKernelGGL((af_gemm3w_kernel<TAPS, NWM, NWN, TN, EPI, NSLOT>), grid, block, lds, stream, p);
+  if (lds_ok) hipLaunchKernelGGL((af_gemm3w_kernel<TAPS, NWM, NWN, TN, EPI, NSLOT>), grid, block, lds, stream, p);
   return p.counters != nullptr;
 }
 
@@ -1025,12 +1022,9 @@ static bool launch_conv3h(const Gemm3Dev& p0, hipStream_t stream) {
   if (p.counters && (p.splits <= 1 || p.splits > 4 || p.tiles_m * p.tiles_n > AF_SPLITK_MAX_TILES)) p.counters = nullptr;
   p.n_major = af_gemm_n_major(p.M, p.N, p.K, p.c1);
   static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&af_conv3h_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS + AF_WPF_DUMP_BYTES);
-    attr_set = true;
-  }
+  const bool lds_ok = af_allow_dyn_lds(reinterpret_cast<const void*>(&af_conv3h_kernel), CH_LDS + AF_WPF_DUMP_BYTES, attr_set, "af_gemm");
   dim3 grid(p.tiles_m * p.tiles_n, p.splits), block(512);
-  hipLaunchKernelGGL(af_conv3h_kernel, grid, block, CH_LDS + AF_WPF_DUMP_BYTES, stream, p);
+  if (lds_ok) hipLaunchKernelGGL(af_conv3h_kernel, grid, block, CH_LDS + AF_WPF_DUMP_BYTES, stream, p);
   return p.counters != nullptr;
 }
 
@@ -1431,10 +1425,7 @@ extern "C" int af_ff_fused(const void* x, const void* w1, const void* b1, const 
   e.stage_ok = (reinterpret_cast<uintptr_t>(out) & 15) == 0;
   AfLaunchScope scope(AF_FAM_GEMM, stream);
   static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&af_ff320_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS + AF_WPF_DUMP_BYTES);
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(af_ff320_kernel, dim3((M + FF_BM - 1) / FF_BM), dim3(512), FF_LDS + AF_WPF_DUMP_BYTES, (hipStream_t)stream, p);
+  const bool lds_ok = af_allow_dyn_lds(reinterpret_cast<const void*>(&af_ff320_kernel), FF_LDS + AF_WPF_DUMP_BYTES, attr_set, "af_gemm");
+  if (lds_ok) hipLaunchKernelGGL(af_ff320_kernel, dim3((M + FF_BM - 1) / FF_BM), dim3(512), FF_LDS + AF_WPF_DUMP_BYTES, (hipStream_t)stream, p);
   return af_check_launch("af_ff_fused");
 }

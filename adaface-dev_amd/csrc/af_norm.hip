@@ -479,6 +479,9 @@ extern "C" int af_groupnorm_stats(const void* x1, const void* x2, int c1, int c2
   AF_REQUIRE(B > 0 && HW > 0 && c1 > 0 && c2 >= 0, "af_groupnorm: bad sizes");
   AF_REQUIRE(c1 % 8 == 0 && c2 % 8 == 0, "af_groupnorm: c1/c2 must be multiples of 8");
   AF_REQUIRE(c2 == 0 || x2 != nullptr, "af_groupnorm: x2 is null but c2 > 0");
+  // the kernels read x / y in 16-byte chunks and gamma / beta as float4: state-dict slices at 4-byte offsets would be misaligned vector loads
+  AF_REQUIRE((((uintptr_t)x1 | (uintptr_t)x2 | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0,
+             "af_groupnorm: x1 / x2 / y / gamma / beta must be 16-byte aligned");
   const int C = c1 + c2;
   AF_REQUIRE(groups > 0 && groups <= GN_MAXG && C % groups == 0, "af_groupnorm: groups must divide C and be <= 32");
   AF_SUPPORTED(C <= 4096, "af_groupnorm: C > 4096");

@@ -23,7 +23,27 @@ extern "C" int af_device_count(void) {
   return n;
 }
 
+static thread_local std::string g_pending_error;      // a refused attribute, reported by the next af_check_launch()
+
+bool af_allow_dyn_lds(const void* kernel, size_t bytes, bool& done, const char* what) {
+  if (done || bytes <= 65536) return true;
+  hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    g_pending_error = std::string(what) + ": hipFuncSetAttribute(MaxDynamicSharedMemorySize = " + std::to_string(bytes) + "): " + hipGetErrorString(e);
+    return false;
+  }
+  done = true;
+  return true;
+}
+
 int af_check_launch(const char* what) {
+  if (!g_pending_error.empty()) {
+    std::string m;
+    m.swap(g_pending_error);
+    (void)hipGetLastError();
+    return af_fail(AF_E_HIP, m);
+  }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return af_fail(AF_E_HIP, std::string(what) + ": " + hipGetErrorString(e));
   return AF_OK;

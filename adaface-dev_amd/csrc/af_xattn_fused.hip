@@ -43,7 +43,7 @@ struct XaDev {
   const float* bq;         // [320] W_q beta (the folded LayerNorm's shift) or nullptr
   const float* cs;         // [320] column sums of the packed rows
   const half_t* k;         // [B * L][ldk]: this layer's keys, head h at columns 40 h
-  const half_t* vt;        // [B][320][ldv] (batch stride vbs): values transposed, keys L .. ldv-1 zero
+  const half_t* vt;        // [B][320][ldv] (batch stride vbs): values transposed; keys L .. ldv-1 may hold ANYTHING (masked after the LDS read)
   const half_t* wo;        // packed [>= 320][kpad_o]
   const float* bo;         // [320] or nullptr
   const half_t* residual;  // [M][320] or nullptr
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(512, 1) void af_xattn320_kernel(const XaDev p) {
         const int kc = pc / 6, row = (pc - kc * 6) * 8 + prow;
         const int lc = slot ^ ((row >> 1) & 7);
         const int key0 = kc * 64 + lc * 8;
-        glds16(row < XA_D && key0 + 8 <= p.ldv ? p.vt + (size_t)bimg * p.vbs + (size_t)(h * XA_D + row) * p.ldv + key0 : p.zeros, vb + kc * (48 * 128) + (pc - kc * 6) * 1024);
+        glds16(row < XA_D && key0 < p.L && key0 + 8 <= p.ldv ? p.vt + (size_t)bimg * p.vbs + (size_t)(h * XA_D + row) * p.ldv + key0 : p.zeros, vb + kc * (48 * 128) + (pc - kc * 6) * 1024);
       }
     }
   };
@@ -119,6 +119,7 @@ __global__ __launch_bounds__(512, 1) void af_xattn320_kernel(const XaDev p) {
     csb[tid] = p.ln_on ? p.cs[tid] : 0.f;
     csb[XA_C + tid] = p.bq ? p.bq[tid] : 0.f;
   }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // the ds_writes above are complete before this wave reaches the loop's first barrier
 
   // ---- this wave's 16 tokens: x^T fragments of the ten 32-wide K steps (lane = token fr, K chunk fq), LayerNorm statistics from them
   const int m = tile_m * XA_BM + wave * 16 + fr;
@@ -161,11 +162,25 @@ __global__ __launch_bounds__(512, 1) void af_xattn320_kernel(const XaDev p) {
     const half4_t lo = *reinterpret_cast<const half4_t*>(base + o8[ga]), hi = *reinterpret_cast<const half4_t*>(base + o8[gb]);
     return half8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   };
-  const half4_t z4 = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
   auto pack8 = [&](const floatx4& a, const floatx4& b) {
     return half8_t{(half_t)a[0], (half_t)a[1], (half_t)a[2], (half_t)a[3], (half_t)b[0], (half_t)b[1], (half_t)b[2], (half_t)b[3]};
   };
   const floatx4 zf = {0.f, 0.f, 0.f, 0.f};
+  // V^T pad: the 8-key chunk that straddles L arrives with whatever the caller's buffer holds behind key L - 1, and P = 0 does not silence an Inf / NaN
+  // there (0 x NaN = NaN in the MFMA).  Masked keys contribute NOTHING (attention.py:196-202): the halves of a V^T fragment are AND-ed with a per-lane
+  // bit mask of the live keys of its 16-key group (this lane reads keys 16 g + 4 fq + e of group g).
+  unsigned long long vmask[5];
+#pragma unroll
+  for (int g = 0; g < 5; ++g) {
+    const int live = p.L - (16 * g + 4 * fq);                    // number of live keys among this lane's four
+    vmask[g] = live >= 4 ? ~0ull : (live <= 0 ? 0ull : ((1ull << (16 * live)) - 1ull));
+  }
+  auto vfrag8 = [&](const char* base, int ga, int gb, unsigned long long ma, unsigned long long mb) {
+    unsigned long long lo = *reinterpret_cast<const unsigned long long*>(base + o8[ga]) & ma;
+    unsigned long long hi = *reinterpret_cast<const unsigned long long*>(base + o8[gb]) & mb;
+    const half4_t l4 = __builtin_bit_cast(half4_t, lo), h4 = __builtin_bit_cast(half4_t, hi);
+    return half8_t{l4[0], l4[1], l4[2], l4[3], h4[0], h4[1], h4[2], h4[3]};
+  };
 
   for (int h = 0; h < XA_H; ++h) {
     const int par = h & 1;
@@ -233,11 +248,11 @@ __global__ __launch_bounds__(512, 1) void af_xattn320_kernel(const XaDev p) {
     const half8_t p0 = pack8(sa[0], sa[1]), p1 = pack8(sa[2], sa[3]), p2 = pack8(sa[4], zf);
     floatx4 oa[3];
 #pragma unroll
-    for (int t = 0; t < 3; ++t) oa[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(frag8(vb + t * (16 * 128), 0, 1), p0, zf, 0, 0, 0);
+    for (int t = 0; t < 3; ++t) oa[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vfrag8(vb + t * (16 * 128), 0, 1, vmask[0], vmask[1]), p0, zf, 0, 0, 0);
 #pragma unroll
-    for (int t = 0; t < 3; ++t) oa[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(frag8(vb + t * (16 * 128), 2, 3), p1, oa[t], 0, 0, 0);
+    for (int t = 0; t < 3; ++t) oa[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vfrag8(vb + t * (16 * 128), 2, 3, vmask[2], vmask[3]), p1, oa[t], 0, 0, 0);
 #pragma unroll
-    for (int t = 0; t < 3; ++t) oa[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(frag8(vb + 48 * 128 + t * (16 * 128), 0, 1), p2, oa[t], 0, 0, 0);
+    for (int t = 0; t < 3; ++t) oa[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vfrag8(vb + 48 * 128 + t * (16 * 128), 0, 1, vmask[4], 0ull), p2, oa[t], 0, 0, 0);
 #pragma unroll
     for (int t = 0; t < 3; ++t)
 #pragma unroll
@@ -331,10 +346,7 @@ extern "C" int af_xattn_fused(const void* x, const void* wq, const void* bq, con
   p.ln_eps = ln_eps;
   p.scale_log2e = scale * 1.4426950408889634f;
   static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&af_xattn320_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, XA_LDS);
-    attr_set = true;
-  }
+  if (!af_allow_dyn_lds(reinterpret_cast<const void*>(&af_xattn320_kernel), XA_LDS, attr_set, "af_xattn_fused")) return af_check_launch("af_xattn_fused");
   AfLaunchScope scope(AF_FAM_XATTN, stream);
   hipLaunchKernelGGL(af_xattn320_kernel, dim3(p.M / XA_BM), dim3(512), XA_LDS, (hipStream_t)stream, p);
   return af_check_launch("af_xattn_fused");

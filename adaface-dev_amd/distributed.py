@@ -49,9 +49,11 @@ class GradReducer:
                 dist.broadcast(a.flat_p, src=0, group=self.pg)
                 if hasattr(a, "bump_generation"):
                     a.bump_generation()                # the arena was written outside autograd: cached weight packs are stale
-        for ai, a in enumerate(self.arenas):
+        # Buckets are numbered in GLOBAL readiness order, because collectives are issued strictly by bucket index: the backward reaches the
+        # LAST arena first (the U-Net's adapters sit behind the encoder's parameters in the forward, so their gradients exist while the encoder
+        # layers are still running), and inside an arena gradients become ready roughly in reverse parameter order.
+        for a in reversed(self.arenas):
             per = max(1, bucket_bytes // 4)
-            # gradients become ready roughly in reverse parameter order: build buckets from the end of the arena
             idx = len(a.params) - 1
             while idx >= 0:
                 hi = a.offsets[idx + 1]

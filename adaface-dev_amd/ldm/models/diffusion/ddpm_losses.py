@@ -479,7 +479,9 @@ class CompReconLossesMixin:
                         l_align.append(la)
                     self.normal_recon_face_align_loss_kept_frac.update(1 if keep else 0)
                     l_align_stat.append(la)
-                    inst_w = found.clone().to(torch.float32)
+                    # the reference's arithmetic, kept literally (ddpm.py:2738-2739): the mask is a LONG tensor (retinaface_pytorch.py:236), so the
+                    # 0.1 its comment intends for instances without a face truncates to 0 -- those instances get weight 0, not 0.1
+                    inst_w = found.clone()
                     inst_w[found == 0] = 0.1
                     scale = 1.0
                     box_mask = torch.zeros(BS, 1, x_start.shape[-2], x_start.shape[-1], device=dev)

@@ -348,6 +348,12 @@ class DistillTrainer:
         images themselves or -- with probability ``p_normal_recon_on_pure_noise`` (ddpm.py:1166-1169) -- from pure noise after four
         priming steps; attention LoRAs on half of the time, the FFN adapter per ``recon_uses_ffn_lora`` (:2305-2326)."""
         ldm = self.ldm
+        # the recon iteration's losses are all face-gated (ddpm.py:2702-2790): without the face pipeline, or with its weight at 0, the reference
+        # reaches a stack of an empty list -- refuse with a message instead
+        if getattr(ldm, "arcface", None) is None or getattr(ldm, "first_stage_model", None) is None:
+            raise RuntimeError("normal_recon_step: the do_normal_recon iteration needs ldm.arcface (ArcFaceWrapper) and ldm.first_stage_model (the VAE)")
+        if not ldm.arcface_align_loss_weight > 0:
+            raise RuntimeError("normal_recon_step: arcface_align_loss_weight must be > 0 for do_normal_recon iterations (every recon term is gated on detected faces)")
         x_start = batch["x_start"]
         BS = x_start.shape[0]
         fg_mask = batch.get("fg_mask")

@@ -164,17 +164,24 @@ int af_ff_fused(const void* x, const void* w1, const void* b1, const void* ln_co
 /* Whole cross-attention block of a transformer layer at C = 320, 8 heads (the 64 x 64 level of SD-1.5) in ONE launch (replaces
  * attention.py:168-222 + the norm2 of :242-252): out = residual + bo + Wo . concat_h(softmax(q_h K_h^T scale) V_h), q = LN(x) Wq^T.
  * wq / bq / ln_colsum: the q projection packed with the LayerNorm folded in (as af_gemm_desc.ln_colsum takes it; ln_colsum NULL = x is
- * used as it is, bq NULL = no shift).  k [B * L][ldk] and vt [B][C][ldv] (batch stride vt_batch_stride, keys L .. ldv-1 zero) are this
+ * used as it is, bq NULL = no shift).  k [B * L][ldk] and vt [B][C][ldv] (batch stride vt_batch_stride; the row pad, keys L .. ldv-1, may hold ANYTHING: masked keys contribute nothing) are this
  * layer's slices of the context projection (head h at columns / rows 40 h ..).  N (tokens per image) % 128 == 0, L <= 80. */
 int af_xattn_fused(const void* x, const void* wq, const void* bq, const void* ln_colsum, float ln_eps, int kpad_q, const void* k, int ldk,
                    const void* vt, int64_t vt_batch_stride, int ldv, const void* wo, const void* bo, int kpad_o, const void* residual,
                    void* out, int B, int N, int L, int C, int heads, float scale, const void* zeros, void* stream);
 
+/* PADDED LEADING DIMENSIONS -- the contract for every entry point that takes an ld larger than the logical extent (k / q rows wider than heads*d,
+ * vt rows of ldv >= L keys, keybias rows of ldb >= L, out2 rows of ld_out2 >= rows_per_batch): a consumer NEVER lets bytes outside the logical
+ * extent reach a result -- they may be uninitialised memory (NaN, Inf) -- and a producer that owns a padded output row (af_gemm's AF_OUT_SPLIT_T
+ * out2, af_transpose_tokens) writes zeros into the pad.  Packed weights (wt) are different: the caller zero-pads them to [npad][kpad] when packing,
+ * and the kernels rely on that.  tests/conftest.py runs every GPU test with NaN-filled torch.empty buffers to hold this.                        */
+
 /* ---- GroupNorm(32) [+ SiLU], NHWC -----------------------------------------------------
  * Replaces GroupNorm32 + nn.SiLU (util.py:195-212; openaimodel.py:202-233,686-690; eps 1e-5)
  * and Normalize (attention.py:70-71; eps 1e-6).  x = concat(x1[.., c1], x2[.., c2]) along
  * channels (x2 may be NULL).  Two launches: partial sums -> normalise.
- * workspace: fp32, at least af_groupnorm_ws_floats(B) floats.                              */
+ * workspace: fp32, at least af_groupnorm_ws_floats(B) floats.  x1 / x2 / y / gamma / beta must
+ * be 16-byte aligned (vector accesses); AF_E_BADARG otherwise.                              */
 int af_groupnorm_ws_floats(int B);
 int af_groupnorm(const void* x1, const void* x2, int c1, int c2, const void* gamma, const void* beta,
                  void* y, int B, int HW, int groups, float eps, int silu, void* workspace, void* stream);

@@ -19,6 +19,67 @@ def golden_dir():
     return GOLDEN
 
 
+# ---- hostile memory for the GPU tests ---------------------------------------------------------------------------------------
+# Round 3 shipped a kernel that read the pad of a torch.empty() buffer (V^T keys L .. ld-1) and multiplied it by P = 0: green on fresh
+# pages, NaN on a recycled allocator block.  Every GPU test therefore runs with (a) torch.empty / empty_like / new_empty returning
+# floating-point CUDA tensors FILLED WITH NaN and (b) the caching allocator's free list seeded with NaN-filled blocks, so a kernel that
+# reads anything it (or its producer) did not write shows up as a NaN instead of passing by luck.  AF_TEST_POISON=0 switches it off.
+_POISON = os.environ.get("AF_TEST_POISON", "1") != "0"
+
+
+def _install_poison():
+    import torch
+    if getattr(torch, "_af_poisoned", False):
+        return
+    orig_empty, orig_empty_like, orig_new_empty = torch.empty, torch.empty_like, torch.Tensor.new_empty
+
+    def _poison(t):
+        if t.is_cuda and t.is_floating_point() and t.numel() and not torch.cuda.is_current_stream_capturing():
+            t.fill_(float("nan"))
+        return t
+
+    def empty(*a, **k):
+        return _poison(orig_empty(*a, **k))
+
+    def empty_like(*a, **k):
+        return _poison(orig_empty_like(*a, **k))
+
+    def new_empty(self, *a, **k):
+        return _poison(orig_new_empty(self, *a, **k))
+
+    torch.empty, torch.empty_like, torch.Tensor.new_empty = empty, empty_like, new_empty
+    torch._af_poisoned = True
+
+
+def _seed_allocator_with_nan():
+    """Large and small free blocks of the caching allocator hold NaN (what a recycled torch.empty would hand out)."""
+    import torch
+    big = [torch.full((256 << 20,), float("nan"), dtype=torch.float32, device="cuda:0") for _ in range(2)]      # 2 x 1 GiB
+    small = [torch.full((n,), float("nan"), dtype=torch.float16, device="cuda:0") for n in (1 << 8, 1 << 12, 1 << 16, 1 << 19) for _ in range(16)]
+    del big, small
+
+
+def pytest_collection_modifyitems(config, items):
+    if _POISON and any(it.get_closest_marker("gpu") is not None for it in items):
+        import torch
+        if torch.cuda.is_available():
+            _install_poison()          # before any module-scoped fixture builds a model
+
+
+@pytest.fixture(autouse=True)
+def _hostile_memory(request):
+    if not _POISON or request.node.get_closest_marker("gpu") is None:
+        yield
+        return
+    import torch
+    if not torch.cuda.is_available():
+        yield
+        return
+    _install_poison()
+    _seed_allocator_with_nan()
+    yield
+
+
 def rel_l2(a, b):
     """||a-b|| / ||b|| in fp64."""
     import numpy as np

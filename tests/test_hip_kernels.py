@@ -478,8 +478,10 @@ def test_ff_fused_c320(dev, M, with_ln, with_res):
         assert torch.equal(y, out)
 
 
-@pytest.mark.parametrize("B,N,L,with_ln,with_res", [(2, 256, 77, True, True), (1, 128, 77, False, False), (3, 384, 80, True, False), (2, 128, 40, True, True)])
-def test_xattn_fused_c320(dev, B, N, L, with_ln, with_res):
+@pytest.mark.parametrize("B,N,L,with_ln,with_res,ld_extra", [(2, 256, 77, True, True, 0), (1, 128, 77, False, False, 0), (3, 384, 80, True, False, 0),
+                                                             (2, 128, 40, True, True, 0), (2, 128, 37, True, True, 0), (2, 256, 77, True, True, 16),
+                                                             (1, 128, 5, False, True, 8), (2, 128, 64, True, False, 8)])
+def test_xattn_fused_c320(dev, B, N, L, with_ln, with_res, ld_extra):
     """af_xattn_fused (the whole C = 320 cross-attention block in one launch: LayerNorm-folded q projection, 77-key softmax attention on
     the context projection's K / V^T slices, to_out, bias, residual) against fp32 torch AND against the three-launch path of
     CrossAttention.hip on the same weights; K / V^T handed over exactly as the U-Net does (column / row slices of a wider batched
@@ -515,7 +517,10 @@ def test_xattn_fused_c320(dev, B, N, L, with_ln, with_res):
     wk = torch.cat([pad_w[0], m.to_k.weight.detach().cpu().half(), pad_w[1]], 0)
     wv = torch.cat([pad_w[0], m.to_v.weight.detach().cpu().half(), pad_w[1]], 0)
     pack = ops.pack_matrix(torch.cat([wk, wv], 0), None, dev)
-    k_all, vt_all = ops.gemm(ctx.to(dev).reshape(B * L, Cc), pack, rows_per_batch=L, split_col=wk.shape[0])
+    ldv = (L + 7) // 8 * 8 + ld_extra
+    k_all, vt_all = ops.gemm(ctx.to(dev).reshape(B * L, Cc), pack, rows_per_batch=L, split_col=wk.shape[0], ld_out2=ldv)
+    # the projection's transposed output owns its row pad: zero, although the buffer came from a (NaN-poisoned, see conftest) torch.empty
+    assert vt_all.shape[-1] == ldv and torch.isfinite(vt_all).all() and (vt_all[..., L:] == 0).all()
     k, vt = k_all[:, 640:960], vt_all[:, 640:960, :]
     pq = m._packed_q_ln(ln) if with_ln else m.to_q.packed()
     out = ops.xattn_fused(x.to(dev), pq, k, vt, m.to_out[0].packed(), B=B, N=N, L=L, heads=heads, scale=40 ** -0.5, ldk=wk.shape[0],
@@ -531,6 +536,24 @@ def test_xattn_fused_c320(dev, B, N, L, with_ln, with_res):
         A.FUSE_XATTN = old
         m._kv_pre = None
     assert rel_l2(out.float().cpu().numpy(), out3.float().cpu().numpy()) < TOL
+    # masked keys contribute NOTHING whatever the pad holds (attention.py:196-202; 0 x NaN = NaN in an MFMA): NaN / Inf behind key L - 1 of every V^T
+    # row, in a caller-owned buffer that no producer of ours has cleaned -- both the one-launch kernel and the three-launch core must not see it
+    if ldv > L:
+        for bad in (float("nan"), float("inf"), -65504.0):
+            vt_h = vt_all.clone()
+            vt_h[..., L:] = bad
+            out_h = ops.xattn_fused(x.to(dev), pq, k, vt_h[:, 640:960, :], m.to_out[0].packed(), B=B, N=N, L=L, heads=heads, scale=40 ** -0.5,
+                                    ldk=wk.shape[0], residual=None if res is None else res.to(dev))
+            assert torch.isfinite(out_h).all(), f"pad = {bad}"
+            assert torch.equal(out_h, out), f"pad = {bad}"
+            m._kv_pre = (k, vt_h[:, 640:960, :], wk.shape[0])
+            A.FUSE_XATTN = False
+            try:
+                out3_h = m.hip(x.to(dev), B, N, context=ctx.to(dev), residual=None if res is None else res.to(dev), ln=ln if with_ln else None)
+            finally:
+                A.FUSE_XATTN = old
+                m._kv_pre = None
+            assert torch.isfinite(out3_h).all() and torch.equal(out3_h, out3), f"pad = {bad} (three launches)"
 
 
 def test_gemm_folded_layernorm_refuses_other_kernels(dev):
