@@ -632,6 +632,11 @@ def test_attention_online_softmax_rescale_branch(dev, N):
     L = 320
     q, k, v = rnd((B, N, C), 1), rnd((B, L, C), 2, 0.3), rnd((B, L, C), 3)
     k[0, L - 3] = (q[0, 5] * 4).half()  # large positive score against query 5 (and others) in the final stage
+    if N >= 512:
+        # the pipelined two-chain kernel (d = 40) keeps two skewed chains per wave: also move the reference of a chain-B query (40) in a MIDDLE
+        # stage, and start a query (70) from a strongly NEGATIVE first stage (its reference must start at that maximum, not at 0)
+        k[0, 130] = (q[0, 40] * 4).half()
+        k[0, :64] = -(q[0, 70] * 2).half()
     ldv = ops.round_up(L, 8)
     vt = torch.zeros((B, C, ldv), dtype=torch.float16)
     vt[:, :, :L] = v.permute(0, 2, 1)
