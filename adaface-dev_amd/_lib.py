@@ -45,6 +45,7 @@ class GemmDesc(C.Structure):
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64), ("zeros", C.c_void_p),
         ("tap_shift", C.c_int32), ("splitk_fused", C.c_int32),
         ("ln_colsum", C.c_void_p), ("ln_eps", C.c_float),
+        ("a3", C.c_void_p), ("a4", C.c_void_p), ("c3", C.c_int32), ("c4", C.c_int32), ("lda3", C.c_int32), ("lda4", C.c_int32),
     ]
 
 

@@ -513,7 +513,15 @@ extern "C" int af_gemm(const af_gemm_desc* d, void* stream) {
   AF_REQUIRE(d->N % 4 == 0, "af_gemm: N must be a multiple of 4");
   AF_REQUIRE(d->c1 > 0 && d->c1 % 8 == 0 && d->c2 >= 0 && d->c2 % 8 == 0, "af_gemm: c1/c2 must be multiples of 8");
   AF_REQUIRE(d->c2 == 0 || d->a2 != nullptr, "af_gemm: a2 is null but c2 > 0");
-  AF_REQUIRE(d->K == d->taps * (d->c1 + d->c2), "af_gemm: K != taps*(c1+c2)");
+  const bool ktail = d->c3 > 0 || d->c4 > 0;         // K-concatenated 1x1 tail (the ResBlock's shortcut inside its second convolution)
+  if (ktail) {
+    AF_REQUIRE(d->taps == 9 && d->c3 > 0 && d->a3 != nullptr && d->c4 >= 0 && (d->c4 == 0 || d->a4 != nullptr), "af_gemm: the K tail needs taps == 9 and a3 (a4 when c4 > 0)");
+    AF_REQUIRE(d->c3 % 64 == 0 && d->c4 % 64 == 0, "af_gemm: c3 / c4 must be multiples of 64");
+    AF_REQUIRE((d->lda3 == 0 || (d->lda3 >= d->c3 && d->lda3 % 8 == 0)) && (d->lda4 == 0 || (d->lda4 >= d->c4 && d->lda4 % 8 == 0)), "af_gemm: bad lda3 / lda4");
+    AF_REQUIRE((d->stride == 0 || d->stride == 1) && d->upsample == 0 && d->tap_shift == 0, "af_gemm: the K tail needs stride 1, no upsample, no tap_shift");
+    AF_SUPPORTED(d->tile >= 7 && d->tile <= 13, "af_gemm: the K tail runs on the whole-line tiles 7 .. 13 only");
+  }
+  AF_REQUIRE(d->K == d->taps * (d->c1 + d->c2) + d->c3 + d->c4, "af_gemm: K != taps*(c1+c2) (+ c3 + c4)");
   GemmDev p;
   p.a1 = (const half_t*)d->a1;
   p.a2 = (const half_t*)d->a2;
@@ -617,6 +625,7 @@ extern "C" int af_gemm(const af_gemm_desc* d, void* stream) {
       hipLaunchKernelGGL(af_splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p);
       return af_check_launch("af_gemm(tile 3, split-K)");
     }
+    AF_SUPPORTED(!ktail, "af_gemm: the K tail is outside the chosen tile's scope");
     tile = 1;  // outside the pipelined kernel's scope
   }
   AF_SUPPORTED(d->ln_colsum == nullptr, "af_gemm: a folded LayerNorm (ln_colsum) needs a whole-line tile (7 .. 13) whose scope covers the shape, "

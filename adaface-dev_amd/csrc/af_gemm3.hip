@@ -36,6 +36,9 @@ struct Gemm3Dev {
   int split_col, ld_out2;
   int M, N, K, kpad, npad;
   int c1, c2, lda1, lda2;
+  const half_t* a3;      // K-concatenated 1x1 tail of a 3x3 convolution (af_gemm_desc.a3 / a4): plain rows behind the nine tap blocks
+  const half_t* a4;
+  int c3, c4, lda3, lda4;
   int H, W, Ho, Wo, HoWo, stride;
   int upsample;   // 1: nearest x2 folded into the 3x3 gather (whole-line kernel only): Ho = 2H, Wo = 2W
   int rows_per_batch, ld_rowbias, act, ld_out;
@@ -638,7 +641,21 @@ __global__ __launch_bounds__(64 * NWM * NWN, (NWM * NWN == 4 && NSLOT == 2) ? 2 
     char* As = af_smem + sl * STAGE;
     char* Ws = As + BM * 128;
     const int k0 = kt * BKW;
-    if (TAPS == 9) {
+    if (TAPS == 9 && p.c3 > 0 && k0 >= 9 * Cin) {
+      // K tail: a 1x1 convolution of a second image on the output grid (stride 1: the tile row's pixel index IS its output row), c3 | c4 columns
+      const int kt0 = k0 - 9 * Cin;
+      const bool first = kt0 < p.c3;                // uniform: 64 | c3
+      const half_t* src = first ? p.a3 : p.a4;
+      const int ld = first ? p.lda3 : p.lda4;
+      const int koff = first ? kt0 : kt0 - p.c3;
+      const bool inside = kt0 < p.c3 + p.c4;        // K padding behind the tail: zeros
+#pragma unroll
+      for (int j = 0; j < APW; ++j) {
+        const bool ok = inside && ((a_mask[j] >> 4) & 1u);          // the centre tap is valid exactly for the rows m < M
+        const half_t* g = ok ? src + (size_t)a_base[j] * ld + koff + a_lc[j] * 8 : p.zeros;
+        glds16(g, As + (wave * APW + j) * 1024);
+      }
+    } else if (TAPS == 9) {
       const int tp = k0 / Cin;                      // workgroup-uniform (64 | c1, c2)
       const int c0 = k0 - tp * Cin;
       const bool first = c0 < p.c1;
@@ -1256,6 +1273,7 @@ int af_gemm3_try_launch(const af_gemm_desc* d, int splits, int wide, hipStream_t
   if (wide == 11 && !conv3h_eligible(d)) return 1;              // halo-resident 3x3 kernel (tile 14)
   if (d->upsample && !((wide == 4 || wide == 5 || wide >= 8) && d->upsample == 1 && d->taps == 9)) return 1;   // nearest x2: whole-line kernel only
   if (d->c1 % BK3 != 0 || d->c2 % BK3 != 0 || d->zeros == nullptr) return 1;
+  if (d->c3 > 0 && (wide < 4 || wide > 10 || d->taps != 9 || d->upsample || (d->stride != 0 && d->stride != 1))) return 1;   // K tail: whole-line tap-by-tap tiles
   if ((geglu || split_t) && (d->taps != 1 || splits > 1)) return 1;
   if (geglu && (!wide || d->N % (wide == 5 ? 128 : 256) != 0)) return 1;   // GEGLU: 128 x 256 tile, the 256-row tiles, or 128 x 128 whole-line
   if (!geglu && wide == 1 && d->N % 320 != 0) return 1;
@@ -1296,6 +1314,12 @@ int af_gemm3_try_launch(const af_gemm_desc* d, int splits, int wide, hipStream_t
   p.c2 = d->c2;
   p.lda1 = d->lda1 ? d->lda1 : d->c1;
   p.lda2 = d->lda2 ? d->lda2 : d->c2;
+  p.a3 = (const half_t*)d->a3;
+  p.a4 = (const half_t*)d->a4;
+  p.c3 = d->c3;
+  p.c4 = d->c4;
+  p.lda3 = d->lda3 ? d->lda3 : d->c3;
+  p.lda4 = d->lda4 ? d->lda4 : d->c4;
   p.H = d->H;
   p.W = d->W;
   p.Ho = d->Ho;

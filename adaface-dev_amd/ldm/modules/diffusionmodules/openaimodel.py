@@ -15,6 +15,7 @@ Execution plan of one epsilon-prediction (what differs from the reference's op-b
   GEMM per forward (weights concatenated at pack time), SiLU fused into the epilogue of
   ``time_embed.2``.
 """
+import os
 from abc import abstractmethod
 
 import torch
@@ -31,6 +32,10 @@ class TimestepBlock(nn.Module):
     @abstractmethod
     def forward(self, x, emb):
         """Apply the module to `x` given `emb` timestep embeddings."""
+
+
+# AF_FUSE_SKIP=0: the ResBlock's 1x1 skip_connection as its own launch (A/B runs); default: K-concatenated into the second convolution
+FUSE_SKIP = os.environ.get("AF_FUSE_SKIP", "1") != "0"
 
 
 class SkipCat(tuple):
@@ -191,9 +196,25 @@ class ResBlock(TimestepBlock):
         h = self.out_layers[0].hip(h, silu=True)
         if isinstance(self.skip_connection, nn.Identity):
             skip = x1 if x2 is None else torch.cat([x1, x2], dim=-1)
+        elif self._skip_fusable(x1, x2):
+            return ops.conv3x3(h, self._packed_conv2_skip(), skip=(x1, x2))
         else:
             skip = self.skip_connection.hip(x1, x2=x2)
         return self.out_layers[3].hip(h, residual=skip)
+
+    # ---- out_layers convolution + channel-changing 1x1 skip_connection as ONE K-concatenated implicit GEMM (ops.pack_conv3x3_skip): the block's
+    # `skip_connection(x) + h` (openaimodel.py:256-276) costs no launch, no [B,H,W,Cout] round trip and no residual read of its own
+    def _skip_fusable(self, x1, x2) -> bool:
+        sc = self.skip_connection
+        return (FUSE_SKIP and isinstance(sc, nn.Conv2d) and sc.kernel_size == (1, 1) and self.out_channels % 64 == 0 and x1.shape[-1] % 64 == 0
+                and (x2 is None or x2.shape[-1] % 64 == 0))
+
+    def _packed_conv2_skip(self) -> ops.PackedWeight:
+        c2, sc = self.out_layers[3], self.skip_connection
+        if not hasattr(self, "_cache_c2s"):
+            self._cache_c2s = _PackCache()
+        return self._cache_c2s.get((c2.weight, c2.bias, sc.weight, sc.bias),
+                                   lambda: ops.pack_conv3x3_skip(c2.weight, c2.bias, sc.weight, sc.bias, c2.weight.device))
 
     def _emb_out(self, emb):
         if isinstance(emb, EmbPack) and emb.all_out is not None and self._emb_slice is not None:
@@ -220,7 +241,10 @@ class ResBlock(TimestepBlock):
         else:
             h1 = self.in_layers[2].hip(a, rowbias=self._emb_out(emb))
         b, st2 = self.out_layers[0].hip_train(h1, silu=True)
-        if isinstance(self.skip_connection, nn.Identity):
+        fuse = "conv2" not in lora and "conv_shortcut" not in lora and not isinstance(self.skip_connection, nn.Identity) and self._skip_fusable(x1, x2)
+        if fuse:
+            skip = None                               # the shortcut runs inside the second convolution (see hip())
+        elif isinstance(self.skip_connection, nn.Identity):
             skip = x1 if x2 is None else torch.cat([x1, x2], dim=-1)
         elif "conv_shortcut" in lora:
             ad = lora["conv_shortcut"]
@@ -228,7 +252,9 @@ class ResBlock(TimestepBlock):
             skip, ssc = dora_conv_fwd(self.skip_connection, ad, x1, x2=x2, mask=ad.draw_mask(x1.shape[:-1] + (cin,), x1.device))
         else:
             skip = self.skip_connection.hip(x1, x2=x2)
-        if "conv2" in lora:
+        if fuse:
+            out = ops.conv3x3(b, self._packed_conv2_skip(), skip=(x1, x2))
+        elif "conv2" in lora:
             ad = lora["conv2"]
             out, s2 = dora_conv_fwd(self.out_layers[3], ad, b, residual=skip, mask=ad.draw_mask(b.shape, b.device))
         else:

@@ -67,6 +67,7 @@ class PackedWeight:
     cin: int = 0  # channels per tap as seen by the kernel (after any channel padding)
     ln_cs: Optional[torch.Tensor] = None   # folded LayerNorm (pack_matrix_ln): fp32 [Npad] column sums of the fp16 rows
     ln_eps: float = 0.0
+    k_tail: int = 0   # pack_conv3x3_skip: plain K columns behind the nine tap blocks (the ResBlock's 1x1 shortcut inside its second convolution)
 
 
 def pack_matrix(w2d: torch.Tensor, bias: Optional[torch.Tensor], device, taps: int = 1, cin: int = 0) -> PackedWeight:
@@ -105,6 +106,27 @@ def pack_conv3x3(w: torch.Tensor, bias: Optional[torch.Tensor], device, cin_pad:
     if cinp != cin:
         w = torch.nn.functional.pad(w, (0, cinp - cin))
     return pack_matrix(w.reshape(cout, 9 * cinp), bias, device, taps=9, cin=cinp)
+
+
+def pack_conv3x3_skip(w3: torch.Tensor, b3: Optional[torch.Tensor], w1: torch.Tensor, b1: Optional[torch.Tensor], device) -> PackedWeight:
+    """out = conv3x3(h; w3, b3) + conv1x1(x; w1, b1) as ONE K-concatenated implicit GEMM (af_gemm_desc.a3 / a4): [Cout, 9 Cin | Cs] with the 3x3
+    block in (ky, kx, cin) order and the 1x1 weights behind it; the biases add up.  The ResBlock's out_layers convolution + skip_connection
+    (openaimodel.py:256-276).  Cin and Cs must be multiples of 64 (every SD-1.5 block is)."""
+    cout, cin, kh, kw = w3.shape
+    assert kh == 3 and kw == 3 and w1.shape[0] == cout and w1.shape[2:] == (1, 1)
+    cs = w1.shape[1]
+    assert cin % 64 == 0 and cs % 64 == 0, "pack_conv3x3_skip: channel counts must be multiples of 64"
+    w = torch.cat([w3.detach().permute(0, 2, 3, 1).reshape(cout, 9 * cin).float(), w1.detach().reshape(cout, cs).float().to(w3.device)], dim=1)
+    b = None
+    if b3 is not None or b1 is not None:
+        b = torch.zeros(cout, dtype=torch.float32, device=w3.device)
+        if b3 is not None:
+            b = b + b3.detach().float()
+        if b1 is not None:
+            b = b + b1.detach().float().to(b.device)
+    pw = pack_matrix(w, b, device, taps=9, cin=cin)
+    pw.k_tail = cs
+    return pw
 
 
 def interleave_geglu(w: torch.Tensor, b: torch.Tensor):
@@ -266,9 +288,19 @@ def gemm(a1: torch.Tensor, pw: PackedWeight, *, a2: Optional[torch.Tensor] = Non
     return (out, out2) if split_col else out
 
 
+def conv3x3_skip_tile(M: int, N: int, cin: int, ktail: int):
+    """(tile, splits) for a 3x3 convolution with a K-concatenated 1x1 tail: its own tuned entry when the table has one on a whole-line tile,
+    else what the table says for the plain convolution of the same shape (the tail only lengthens K), else a whole-line default."""
+    for K in (9 * cin + ktail, 9 * cin):
+        t = tune_table().get(f"9,{M},{N},{K},0,0,1,0")
+        if t is not None and 7 <= t[0] <= 13:
+            return t
+    return (7 if (N % 320 == 0 and M >= 8192) else (11 if N % 160 == 0 else 8)), 1
+
+
 def conv3x3(x: torch.Tensor, pw: PackedWeight, *, x2: Optional[torch.Tensor] = None, stride: int = 1, upsample: bool = False,
             rowbias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, tile: int = 0,
-            splits: int = 0, out_hw=None, tap_shift: int = 0) -> torch.Tensor:
+            splits: int = 0, out_hw=None, tap_shift: int = 0, skip=None) -> torch.Tensor:
     """3x3 / pad 1 convolution as implicit GEMM (tap_shift=1: padding (0, 1, 0, 1) instead, the VAE encoder's Downsample).  x [B,H,W,C1] (+ x2 [B,H,W,C2] channel-concat)
     -> [B,Ho,Wo,Cout].  rowbias [B, >=Cout] is added per batch item (time-embedding), residual
     [B,Ho,Wo,Cout] after it."""
@@ -280,6 +312,7 @@ def conv3x3(x: torch.Tensor, pw: PackedWeight, *, x2: Optional[torch.Tensor] = N
         assert x2.shape[:3] == x.shape[:3]
         c2 = x2.shape[3]
     assert pw.taps == 9 and pw.cin == c1 + c2, f"conv3x3: channel mismatch {c1}+{c2} vs {pw.cin}"
+    assert (pw.k_tail > 0) == (skip is not None), "conv3x3: a weight packed with a 1x1 tail (pack_conv3x3_skip) needs skip=(s1, s2 | None), and vice versa"
     he, we = (2 * H, 2 * W) if upsample else (H, W)
     ho, wo = (he + 2 - 3) // stride + 1, (we + 2 - 3) // stride + 1
     if int(upsample) == 2:      # zero-inserted image (stride-2 dgrad): output size = forward input size
@@ -298,6 +331,21 @@ def conv3x3(x: torch.Tensor, pw: PackedWeight, *, x2: Optional[torch.Tensor] = N
     if residual is not None:
         _chk_f16(residual, "conv3x3.residual")
         assert residual.shape == out.shape
+    if skip is not None:
+        # the 1x1 tail reads s1 (| s2) at the output pixel: same grid as the output, stride 1
+        s1, s2 = skip
+        assert stride == 1 and not upsample and not tap_shift and (ho, wo) == (H, W)
+        _chk_f16(s1, "conv3x3.skip")
+        assert s1.shape[:3] == out.shape[:3]
+        c3, c4 = s1.shape[3], 0
+        if s2 is not None:
+            _chk_f16(s2, "conv3x3.skip2")
+            assert s2.shape[:3] == out.shape[:3]
+            c4 = s2.shape[3]
+        assert c3 + c4 == pw.k_tail, f"conv3x3: skip channels {c3}+{c4} vs the packed tail {pw.k_tail}"
+        d.a3, d.a4, d.c3, d.c4, d.lda3, d.lda4 = _p(s1), _p(s2), c3, c4, c3, c4
+        if tile == 0 and splits == 0 and _tune_recorder is None:
+            tile, splits = conv3x3_skip_tile(d.M, d.N, c1 + c2, pw.k_tail)
     _launch_gemm(d, x.device, "af_gemm(conv3x3)", tile, splits)
     return out
 

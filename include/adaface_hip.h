@@ -145,6 +145,14 @@ typedef struct af_gemm_desc {
                            K = c1 columns, eps = ln_eps) accumulated from the A fragments inside the main loop.  Whole-line tiles (7 .. 13)
                            only, taps == 1, c2 == 0, no split-K; anything else is AF_E_UNSUPPORTED */
   float ln_eps;
+  /* K-concatenated 1x1 tail of a 3x3 convolution (taps == 9 only; all NULL / 0 otherwise): behind the nine tap blocks K continues with c3 (+ c4)
+   * PLAIN columns read from a3 [M][lda3] (| a4 [M][lda4]) at the OUTPUT pixel's row, K = 9 (c1 + c2) + c3 + c4 -- out = conv3x3(a1 | a2) + conv1x1(a3 | a4)
+   * in one launch: the ResBlock's out_layers convolution and its channel-changing skip_connection (openaimodel.py:256-276; wt = [3x3 weights in
+   * (ky, kx, cin) order | 1x1 weights], bias = the two biases added up).  stride 1, no upsample, no tap_shift, c3 / c4 multiples of 64, whole-line
+   * tiles 7 .. 13 only (AF_E_UNSUPPORTED otherwise: the caller keeps the two-launch form for such shapes). */
+  const void* a3;
+  const void* a4;
+  int32_t c3, c4, lda3, lda4;
 } af_gemm_desc;
 #define AF_SPLITK_MAX_TILES 4096
 #define AF_SPLITK_COUNTER_BYTES (AF_SPLITK_MAX_TILES * 4)

@@ -150,6 +150,41 @@ def test_conv3x3_tile14_halo_resident(dev, B, H, W, cin, cout, splits, extras):
     assert rel_l2(out.float().cpu().numpy(), out7.float().cpu().numpy()) < 2e-3
 
 
+@pytest.mark.parametrize("B,H,W,cin,cs1,cs2,cout,tile,splits", [
+    (1, 64, 64, 320, 640, 320, 320, 7, 1), (2, 32, 32, 640, 640, 640, 640, 7, 2), (2, 16, 16, 1280, 1280, 1280, 1280, 7, 4), (2, 32, 32, 640, 320, 0, 640, 8, 1),
+    (2, 16, 16, 128, 64, 64, 160, 11, 1), (1, 12, 20, 64, 128, 0, 128, 8, 3), (2, 16, 16, 128, 64, 64, 160, 13, 2), (2, 8, 8, 192, 64, 0, 128, 12, 1),
+    (3, 8, 8, 1280, 1280, 1280, 1280, 8, 4)])
+def test_conv3x3_with_k_concatenated_1x1_skip(dev, B, H, W, cin, cs1, cs2, cout, tile, splits):
+    """out = conv3x3(h) + conv1x1(cat(x1, x2)) as ONE launch (af_gemm_desc.a3 / a4: the ResBlock's second convolution with its channel-changing
+    skip_connection K-concatenated behind the nine tap blocks, openaimodel.py:256-276) against torch in fp32 and against the two-launch form;
+    one / two skip sources, every whole-line tile form, split-K, ragged M (image border rows and a tile that overhangs M)."""
+    from adaface_dev_amd import ops
+    h = rnd((B, H, W, cin), 1)
+    x1 = rnd((B, H, W, cs1), 2)
+    x2 = rnd((B, H, W, cs2), 3) if cs2 else None
+    w3 = rnd((cout, cin, 3, 3), 4, (9 * cin) ** -0.5)
+    w1 = rnd((cout, cs1 + cs2, 1, 1), 5, (cs1 + cs2) ** -0.5)
+    b3, b1 = torch.randn(cout, generator=torch.Generator().manual_seed(6)), torch.randn(cout, generator=torch.Generator().manual_seed(7))
+    xs = (x1 if x2 is None else torch.cat([x1, x2], -1)).float().permute(0, 3, 1, 2)
+    ref = F.conv2d(h.float().permute(0, 3, 1, 2), w3.float(), b3, padding=1) + F.conv2d(xs, w1.float(), b1)
+    pw = ops.pack_conv3x3_skip(w3, b3, w1, b1, dev)
+    assert pw.K == 9 * cin + cs1 + cs2 and pw.k_tail == cs1 + cs2
+    x2d = None if x2 is None else x2.to(dev)
+    out = ops.conv3x3(h.to(dev), pw, skip=(x1.to(dev), x2d), tile=tile, splits=splits)
+    assert rel_l2(out.float().cpu().permute(0, 3, 1, 2).numpy(), ref.numpy()) < TOL
+    # the table-driven choice (no explicit tile) lands on a whole-line tile too
+    out_auto = ops.conv3x3(h.to(dev), pw, skip=(x1.to(dev), x2d))
+    assert rel_l2(out_auto.float().cpu().permute(0, 3, 1, 2).numpy(), ref.numpy()) < TOL
+    # two launches: 1x1 GEMM, then the 3x3 with it as residual (one more fp16 rounding)
+    sk = ops.gemm(x1.to(dev).reshape(B * H * W, cs1), ops.pack_matrix(w1.reshape(cout, cs1 + cs2), b1, dev),
+                  a2=None if x2 is None else x2d.reshape(B * H * W, cs2))
+    out2 = ops.conv3x3(h.to(dev), ops.pack_conv3x3(w3, b3, dev), residual=sk.reshape(B, H, W, cout), tile=8)
+    assert rel_l2(out.float().cpu().numpy(), out2.float().cpu().numpy()) < 2e-3
+    # outside the whole-line tiles the descriptor is refused, never silently mis-computed
+    with pytest.raises(RuntimeError, match="K tail"):
+        ops.conv3x3(h.to(dev), pw, skip=(x1.to(dev), x2d), tile=2)
+
+
 def test_conv3x3_tile14_falls_back_outside_its_scope(dev):
     """stride 2 / two sources / widths it does not take: the descriptor's fallback (tile 1) computes the same convolution."""
     from adaface_dev_amd import ops
