@@ -267,6 +267,97 @@ __device__ __forceinline__ void gemm3_epilogue(const Gemm3Dev& p, floatx4 (&acc)
     }
     return;
   }
+  if constexpr (EPI == E3_SPLIT_T) {
+    // Staged forms of the transposed-V split (round 4).  The direct form below writes q | k with 8-byte stores that touch 16 rows x 32 bytes per wave
+    // instruction and V^T with 2-BYTE stores (a lane's four channels are four different V^T rows) -- at M 32768, N 960, K 320 (the C = 320 q | k | v
+    // projection, 63 MB of output) that epilogue is most of the kernel.  When a tile lies on one side of split_col it is assembled in the idle ring
+    // instead: q / k tiles as rows (the standard staged form), V tiles TRANSPOSED ([channel][token]) and written as 16-byte runs of 8 tokens along
+    // each V^T row.  Needs a tile's rows to be tokens of ONE batch item (rows_per_batch % BM == 0) and aligned outputs; anything else stays direct.
+    constexpr int TS = BN + 8;                                  // row staging stride (halves)
+    constexpr int TT = BM + 8;                                  // transposed staging stride: BM tokens + 16 bytes
+    constexpr bool kFits = (size_t)BM * TS * 2 <= (size_t)LDSB && (size_t)BN * TT * 2 <= (size_t)LDSB;
+    const int tile_lo = tile_n * BN;
+    const bool rows_side = tile_lo + BN <= p.split_col;
+    const bool vt_side = tile_lo >= p.split_col;
+    const int nv = p.N - p.split_col;
+    const bool ok_rows = rows_side && p.split_col % 8 == 0 && p.ld_out % 8 == 0 && (reinterpret_cast<uintptr_t>(p.out) & 15) == 0;
+    const bool ok_vt = vt_side && p.rows_per_batch % BM == 0 && p.ld_out2 % 8 == 0 && (reinterpret_cast<uintptr_t>(p.out2) & 15) == 0 &&
+                       p.ld_out2 >= p.rows_per_batch;
+    if (kFits && (ok_rows || ok_vt) && !(p.ablate & 32)) {
+      __syncthreads();                                          // every wave is done reading the last ring slot
+      half_t* T = reinterpret_cast<half_t*>(af_smem);
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        const int row = wm * 64 + tm * 16 + fr;
+        const int m = tile_m * BM + row;
+        const bool mok = m < p.M;
+        const int bidx = (p.rowbias && mok) ? m / p.rows_per_batch : 0;
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+          const int col = wn * TN * 16 + tn * 16 + 4 * fq;
+          const int n0 = tile_lo + col;
+          float v[4] = {0.f, 0.f, 0.f, 0.f};
+          if (mok && n0 < p.N) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[tn][tm][e];
+            if (p.bias) {
+              const floatx4 bv = *reinterpret_cast<const floatx4*>(p.bias + n0);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] += bv[e];
+            }
+            if (p.rowbias) {
+              const half4_t rv = *reinterpret_cast<const half4_t*>(p.rowbias + (size_t)bidx * p.ld_rowbias + n0);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
+            }
+            if (p.act == 1) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = af_silu(v[e]);
+            } else if (p.act == 3) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = v[e] * af_sigmoid(1.702f * v[e]);
+            }
+          }
+          if (ok_rows) {
+            const half4_t h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+            *reinterpret_cast<half4_t*>(T + row * TS + col) = h;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) T[(col + e) * TT + row] = (half_t)v[e];
+          }
+        }
+      }
+      __syncthreads();
+      if (ok_rows) {
+        constexpr int CPR = BN / 8;                             // 16-byte chunks per output row
+        for (int c = tid; c < BM * CPR; c += 64 * NW) {
+          const int row = c / CPR, cc = c - row * CPR;
+          const int m = tile_m * BM + row, n = tile_lo + cc * 8;
+          if (m < p.M && n < p.split_col)
+            *reinterpret_cast<half8_t*>(p.out + (size_t)m * p.ld_out + n) = *reinterpret_cast<const half8_t*>(T + row * TS + cc * 8);
+        }
+      } else {
+        constexpr int CPC = BM / 8;                             // 16-byte chunks (8 tokens) per V^T row of the tile
+        const int m0 = tile_m * BM;                             // the tile's rows are tokens tok0 .. tok0 + BM - 1 of batch item bt
+        const int bt = m0 / p.rows_per_batch, tok0 = m0 - bt * p.rows_per_batch;
+        half_t* o2 = p.out2 + ((size_t)bt * nv + (tile_lo - p.split_col)) * p.ld_out2 + tok0;
+        for (int c = tid; c < BN * CPC; c += 64 * NW) {
+          const int col = c / CPC, cc = c - col * CPC;
+          if (tile_lo + col < p.N && m0 + cc * 8 < p.M)
+            *reinterpret_cast<half8_t*>(o2 + (size_t)col * p.ld_out2 + cc * 8) = *reinterpret_cast<const half8_t*>(T + col * TT + cc * 8);
+        }
+        // the row pad tok rows_per_batch .. ld_out2 - 1 belongs to this output: zero (consumers multiply it by P = 0)
+        if (tok0 + BM == p.rows_per_batch && p.ld_out2 > p.rows_per_batch) {
+          const int padn = p.ld_out2 - p.rows_per_batch;
+          for (int c = tid; c < BN * padn; c += 64 * NW) {
+            const int col = c / padn, t = c - col * padn;
+            if (tile_lo + col < p.N) o2[(size_t)col * p.ld_out2 + BM + t] = (half_t)0.f;
+          }
+        }
+      }
+      return;
+    }
+  }
   if (EPI == E3_GEGLU) {
     // W rows interleaved [16 value | 16 gate]: adjacent MFMA n-tiles pair up in the same lane / register
 #pragma unroll

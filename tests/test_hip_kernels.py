@@ -295,16 +295,23 @@ def test_gemm_concat_k_and_silu(dev):
     assert rel_l2(out.float().cpu().numpy(), ref.numpy()) < TOL
 
 
-@pytest.mark.parametrize("tile", [4, 7])
-def test_gemm_split_transposed_wide_tile4(dev, tile):
+@pytest.mark.parametrize("tile,tokens,pad", [(4, 100, 0), (7, 100, 0), (7, 256, 0), (7, 384, 8), (8, 256, 16), (8, 1024, 0), (7, 128, 8)])
+def test_gemm_split_transposed_wide_tile4(dev, tile, tokens, pad):
+    """q | k | v projection with V written transposed.  tokens % 128 == 0 takes the whole-line kernel's STAGED epilogues (q | k tiles as 16-byte row
+    chunks, V tiles transposed in LDS and written as 16-byte token runs); other token counts the direct one.  With a padded ld_out2 the row pad of
+    V^T is part of the output: zero, although the buffer came from a NaN-poisoned torch.empty (conftest)."""
     from adaface_dev_amd import ops
-    B, C, K, tokens = 2, 320, 320, 100
+    B, C, K = 2, 320, 320
     a, w = rnd((B * tokens, K), 1), rnd((3 * C, K), 2, K ** -0.5)
-    out, out2 = ops.gemm(a.to(dev), ops.pack_matrix(w, None, dev), rows_per_batch=tokens, split_col=2 * C, tile=tile)
-    ref = a.float() @ w.float().t()
+    b = torch.randn(3 * C, generator=torch.Generator().manual_seed(3)) * 0.3
+    ld2 = ops.round_up(tokens, 8) + pad
+    out, out2 = ops.gemm(a.to(dev), ops.pack_matrix(w, b, dev), rows_per_batch=tokens, split_col=2 * C, tile=tile, ld_out2=ld2)
+    ref = a.float() @ w.float().t() + b
     assert rel_l2(out.float().cpu().numpy(), ref[:, :2 * C].numpy()) < TOL
     vt = ref[:, 2 * C:].reshape(B, tokens, C).permute(0, 2, 1)
+    assert out2.shape == (B, C, ld2) and torch.isfinite(out2).all()
     assert rel_l2(out2[:, :, :tokens].float().cpu().numpy(), vt.numpy()) < TOL
+    assert (out2[:, :, tokens:] == 0).all()
 
 
 @pytest.mark.parametrize("tile,C", [(1, 64), (2, 64), (4, 64), (7, 64), (8, 64), (10, 64), (9, 320), (10, 320), (8, 320)])
