@@ -308,6 +308,335 @@ __global__ __launch_bounds__(512, 1) void af_xattn320_kernel(const XaDev p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// TILED form of the same block (round 4): the wave-owns-16-tokens kernel above reads a 1-KB fragment from LDS for every single MFMA of all four
+// products (5.8 MB per workgroup).  Here the two projections are ordinary tiled GEMMs over a token tile that stays in LDS, and the core runs
+// out of registers:
+//   * R = the workgroup's 128 x 320 fp16 tile (80 KB, five 64-channel blocks of 128-byte rows, chunk index XOR (row >> 1) & 7): first x, then the
+//     attention output O in place (wave h overwrites columns 40 h .. of its own rows only after every wave has finished reading x);
+//   * phase A -- Q_h^T [48 x 128] = W_q,h x^T: WAVE h OWNS HEAD h for all 128 tokens.  W_q streams through a two-slot ring of 64-wide K stages
+//     (320 rows x 128 B = 40 KB, the whole-line GEMM's stage); a wave reads its head's 48 rows (3 A fragments) and the tile's 8 token fragments
+//     per K half: 24 MFMAs per 11 fragment reads.  LayerNorm statistics from the token fragments (folded norm2, as af_gemm_desc.ln_colsum);
+//   * phase B -- per 64-token half: S^T = K_h Q_h^T, softmax over the lane's token column, O_h^T = V_h^T P^T with the accumulators as the next
+//     product's B operand (k index permuted as in the kernel above; the 8-wide tails of d = 40 and of the 80 keys on 16x16x16 MFMAs).  K_h / V_h^T
+//     fragments are this wave's alone: loaded ONCE from global memory into 60 registers, masked to the live keys there -- no LDS traffic at all;
+//   * phase C -- out [128 x 320] = O W_o^T + b_o + residual as a 2 x 4 wave GEMM (64 x 80 per wave) on the same ring; W_o's first two stages
+//     arrive during phase B.
+// LDS 160 KB = R + ring exactly; 1.6 MB of LDS reads per workgroup instead of 5.8.
+constexpr int XT_R = XA_BM * XA_C * 2;                 // 81,920
+constexpr int XT_STAGE = XA_C * 128;                   // 40,960: 320 weight rows x 64 K
+constexpr int XT_LDS = XT_R + 2 * XT_STAGE;            // 163,840
+
+// a 16-deep k tail (the 8 head dimensions 32 .. 39, the keys 64 .. 79) as a 32-deep MFMA whose upper k half is zero on both sides.
+// NOT v_mfma_f32_16x16x16_f16 (-DAF_XATTN_K16 builds it): accumulating onto the result of a 16x16x32 MFMA with the 16-deep form gave results that
+// changed from run to run on the same inputs (hipcc 7.2, gfx950: tools/probes/r04g_xattn_debug.py localised it -- the q projection exact, single
+// (token tile, head) cells of the attention output wrong at random); with the zero-padded 32-deep form every cell is exact.
+__device__ __forceinline__ floatx4 mfma_k16(const half4_t& a, const half4_t& b, const floatx4& c) {
+#ifdef AF_XATTN_K16
+  return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0);
+#else
+  const half8_t a8 = {a[0], a[1], a[2], a[3], (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+  const half8_t b8 = {b[0], b[1], b[2], b[3], (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a8, b8, c, 0, 0, 0);
+#endif
+}
+
+template <int NT>
+__global__ __launch_bounds__(512, 1) void af_xattn320t_kernel(const XaDev p) {
+  constexpr int NW = 8;
+  extern __shared__ __attribute__((aligned(16))) char af_smem[];
+  char* R = af_smem;
+  char* RING = af_smem + XT_R;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int prow = lane >> 3, slot = lane & 7;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int tile_m = blockIdx.x;
+  const int m0 = tile_m * XA_BM;
+  const int bimg = m0 / p.N;
+  const int h = wave;                                   // phases A / B: this wave's head
+  const floatx4 zf = {0.f, 0.f, 0.f, 0.f};
+
+  // ---- loaders: 1-KB LDS-DMA pieces of 8 rows x 128 B, chunk index XOR (row >> 1) & 7 on the source side
+  auto issue_x = [&]() {                                // 80 pieces: block c (64 channels) x 16 row groups
+#pragma unroll
+    for (int j = 0; j < 10; ++j) {
+      const int pc = wave + NW * j, c = pc >> 4, row = (pc & 15) * 8 + prow;
+      const int lc = slot ^ ((row >> 1) & 7);
+      const int m = m0 + row;
+      glds16(m < p.M ? p.x + (size_t)m * XA_C + c * 64 + lc * 8 : p.zeros, R + c * (XA_BM * 128) + (pc & 15) * 1024);
+    }
+  };
+  auto issue_w = [&](const half_t* w, int kpad, int st, int sl) {   // stage st (64 K) of a packed [>= 320][kpad] weight: 40 pieces
+    char* dst = RING + sl * XT_STAGE;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const int pc = wave + NW * j, row = pc * 8 + prow;
+      const int lc = slot ^ ((row >> 1) & 7);
+      glds16(w + (size_t)row * kpad + st * 64 + lc * 8, dst + pc * 1024);
+    }
+  };
+  issue_x();
+  issue_w(p.wq, p.kpad_q, 0, 0);
+  issue_w(p.wq, p.kpad_q, 1, 1);
+
+  // fragment offsets inside a [rows x 128 B] block whose 16-row groups start at EVEN rows ((row >> 1) & 7 == ((row0 >> 1) + (fr >> 1)) & 7)
+  auto frag_off = [&](int row0, int kk) { return (row0 + fr) * 128 + (((kk * 4 + fq) ^ (((row0 + fr) >> 1) & 7)) * 16); };
+
+  // ================= phase A: Q_h^T [48 x 128] = W_q,h x^T
+  floatx4 qa[3][8];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int tt = 0; tt < 8; ++tt) qa[t][tt] = zf;
+  float ls[8], lq[8];
+#pragma unroll
+  for (int tt = 0; tt < 8; ++tt) ls[tt] = lq[tt] = 0.f;
+  const half2_t one2 = {(half_t)1.0f, (half_t)1.0f};
+  for (int st = 0; st < 5; ++st) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // x (first pass) and stage st have landed (everything this wave issued)
+    __builtin_amdgcn_s_barrier();                         // ... for every wave; the other slot is free
+    if (st >= 1 && st + 1 < 5) issue_w(p.wq, p.kpad_q, st + 1, (st + 1) & 1);
+    const char* Ws = RING + (st & 1) * XT_STAGE;
+    const char* Xs = R + st * (XA_BM * 128);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      half8_t wf[3], xf[8];
+#pragma unroll
+      for (int t = 0; t < 3; ++t) wf[t] = *reinterpret_cast<const half8_t*>(Ws + frag_off(h * XA_D + t * 16, kk));
+#pragma unroll
+      for (int tt = 0; tt < 8; ++tt) xf[tt] = *reinterpret_cast<const half8_t*>(Xs + frag_off(tt * 16, kk));
+      if (p.ln_on) {
+#pragma unroll
+        for (int tt = 0; tt < 8; ++tt)
+#pragma unroll
+          for (int e = 0; e < 8; e += 2) {
+            const half2_t a = {xf[tt][e], xf[tt][e + 1]};
+            ls[tt] = __builtin_amdgcn_fdot2(a, one2, ls[tt], false);
+            lq[tt] = __builtin_amdgcn_fdot2(a, a, lq[tt], false);
+          }
+      }
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int tt = 0; tt < 8; ++tt) qa[t][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[t], xf[tt], qa[t][tt], 0, 0, 0);
+    }
+  }
+  // folded LayerNorm: column sums / shift of this lane's q rows (head dimension 16 t + 4 fq + e)
+  floatx4 csv[3], bqv[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const int n = t * 16 + 4 * fq;
+    csv[t] = (p.ln_on && n < XA_D) ? *reinterpret_cast<const floatx4*>(p.cs + h * XA_D + n) : zf;
+    bqv[t] = (p.bq && n < XA_D) ? *reinterpret_cast<const floatx4*>(p.bq + h * XA_D + n) : zf;
+  }
+
+  // ---- this head's K / V^T fragments, straight from global memory (each wave's own: nothing to share through LDS), masked to the live keys;
+  // requested here, behind phase A's main loop (60 registers that loop has no room for), they arrive under the projection's epilogue arithmetic
+  half8_t kA32[5], vA32[3][2];
+  half4_t kA16[5], vA16[3];
+  typedef unsigned long long u64;
+  auto ld8 = [](const half_t* ptr) { return *reinterpret_cast<const u64*>(ptr); };
+  {
+    // every load is issued unconditionally from an in-range address and masked afterwards by a per-lane bit mask (a select in front of a load
+    // becomes an exec-masked branch with its own s_waitcnt: serialised L2 round trips).  K_h here, V_h^T behind the projection's epilogue (the
+    // q accumulators leave no room for both).
+    u64 klo[5], khi[5], kt8[5];
+#pragma unroll
+    for (int kt = 0; kt < 5; ++kt) {
+      const int key = kt * 16 + fr;
+      const half_t* kp = p.k + ((size_t)bimg * p.L + (key < p.L ? key : 0)) * p.ldk + h * XA_D;
+      klo[kt] = ld8(kp + 4 * fq);
+      khi[kt] = ld8(kp + 16 + 4 * fq);
+      kt8[kt] = ld8(kp + 32 + 4 * (fq & 1));           // d 32 .. 39 (fq < 2; the other lanes read a valid address and are masked)
+    }
+#pragma unroll
+    for (int kt = 0; kt < 5; ++kt) {
+      const u64 km = (kt * 16 + fr) < p.L ? ~0ull : 0ull;
+      const half4_t lo = __builtin_bit_cast(half4_t, klo[kt] & km), hi = __builtin_bit_cast(half4_t, khi[kt] & km);
+      kA32[kt] = half8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      kA16[kt] = __builtin_bit_cast(half4_t, kt8[kt] & (fq < 2 ? km : 0ull));
+    }
+  }
+  __builtin_amdgcn_s_barrier();                           // every wave is done with x and with the W_q ring: R may take O, the ring W_o
+  issue_w(p.wo, p.kpad_o, 0, 0);
+  issue_w(p.wo, p.kpad_o, 1, 1);
+  // folded LayerNorm, shift, softmax scale (log2 units); padding rows of the head exactly zero; packed as the B operands of S^T
+  half8_t q0[8];
+  half4_t q1[8];
+#pragma unroll
+  for (int tt = 0; tt < 8; ++tt) {
+    float mean = 0.f, rstd = 1.f;
+    if (p.ln_on) {
+      float s = ls[tt], q = lq[tt];
+      s += __shfl_xor(s, 16, 64);
+      q += __shfl_xor(q, 16, 64);
+      s += __shfl_xor(s, 32, 64);
+      q += __shfl_xor(q, 32, 64);
+      mean = s * (1.0f / XA_C);
+      rstd = rsqrtf(fmaxf(q * (1.0f / XA_C) - mean * mean, 0.f) + p.ln_eps);
+    }
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const int n = t * 16 + 4 * fq;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) qa[t][tt][e] = n < XA_D ? (rstd * (qa[t][tt][e] - mean * csv[t][e]) + bqv[t][e]) * p.scale_log2e : 0.f;
+    }
+    q0[tt] = half8_t{(half_t)qa[0][tt][0], (half_t)qa[0][tt][1], (half_t)qa[0][tt][2], (half_t)qa[0][tt][3],
+                     (half_t)qa[1][tt][0], (half_t)qa[1][tt][1], (half_t)qa[1][tt][2], (half_t)qa[1][tt][3]};
+    q1[tt] = half4_t{(half_t)qa[2][tt][0], (half_t)qa[2][tt][1], (half_t)qa[2][tt][2], (half_t)qa[2][tt][3]};
+  }
+
+  {
+    auto live_mask = [&](int first) {                  // keys first .. first + 3: bits of those < L
+      const int live = p.L - first;
+      return live >= 4 ? ~0ull : (live <= 0 ? 0ull : ((1ull << (16 * live)) - 1ull));
+    };
+    u64 vlo[3][2], vhi[3][2], vt8[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const int row = t * 16 + fr;                     // head dimension; rows 40 .. 47 are padding: zero
+      const half_t* vp = p.vt + (size_t)bimg * p.vbs + (size_t)(h * XA_D + (row < XA_D ? row : 0)) * p.ldv;
+      auto at = [&](int key0) { return vp + (key0 + 4 <= p.ldv ? key0 : 0); };     // key0 % 4 == 0 and ldv % 8 == 0: the 8 bytes stay inside the row
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        vlo[t][s2] = ld8(at(32 * s2 + 4 * fq));
+        vhi[t][s2] = ld8(at(32 * s2 + 16 + 4 * fq));
+      }
+      vt8[t] = ld8(at(64 + 4 * fq));
+    }
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const u64 rm = (t * 16 + fr) < XA_D ? ~0ull : 0ull;
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const half4_t lo = __builtin_bit_cast(half4_t, vlo[t][s2] & rm & live_mask(32 * s2 + 4 * fq));
+        const half4_t hi = __builtin_bit_cast(half4_t, vhi[t][s2] & rm & live_mask(32 * s2 + 16 + 4 * fq));
+        vA32[t][s2] = half8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+      vA16[t] = __builtin_bit_cast(half4_t, vt8[t] & rm & live_mask(64 + 4 * fq));
+    }
+  }
+  // ================= phase B: the 77-key core of head h, NT 16-token tiles at a time (everything in registers: the K / V^T fragments are reused
+  // from registers; NT independent chains give the MFMA -> softmax -> MFMA sequence its instruction-level parallelism.  Measured per layer at U-Net
+  // batch 8: NT = 1 80.6 us (one dependent chain), NT = 2 46.9, NT = 4 49.6 (208 bytes of spills: 80 accumulators next to 108 fragment registers))
+#pragma unroll
+  for (int t0 = 0; t0 < 8; t0 += NT) {
+    floatx4 sa[5][NT];
+#pragma unroll
+    for (int kt = 0; kt < 5; ++kt)
+#pragma unroll
+      for (int u = 0; u < NT; ++u) sa[kt][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kA32[kt], q0[t0 + u], zf, 0, 0, 0);
+#pragma unroll
+    for (int kt = 0; kt < 5; ++kt)
+#pragma unroll
+      for (int u = 0; u < NT; ++u) sa[kt][u] = mfma_k16(kA16[kt], q1[t0 + u], sa[kt][u]);
+    float inv[NT];
+    half8_t p0[NT], p1[NT];
+    half4_t p2[NT];
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+      // softmax over the keys of token (t0 + u, fr): this lane holds keys 16 kt + 4 fq + e
+      float mx = -3.0e38f;
+#pragma unroll
+      for (int kt = 0; kt < 5; ++kt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (kt * 16 + 4 * fq + e >= p.L) sa[kt][u][e] = -3.0e38f;
+          mx = fmaxf(mx, sa[kt][u][e]);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      float sum = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 5; ++kt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          sa[kt][u][e] = __builtin_amdgcn_exp2f(sa[kt][u][e] - mx);
+          sum += sa[kt][u][e];
+        }
+      sum += __shfl_xor(sum, 16, 64);
+      sum += __shfl_xor(sum, 32, 64);
+      inv[u] = __builtin_amdgcn_rcpf(sum);
+      p0[u] = half8_t{(half_t)sa[0][u][0], (half_t)sa[0][u][1], (half_t)sa[0][u][2], (half_t)sa[0][u][3],
+                      (half_t)sa[1][u][0], (half_t)sa[1][u][1], (half_t)sa[1][u][2], (half_t)sa[1][u][3]};
+      p1[u] = half8_t{(half_t)sa[2][u][0], (half_t)sa[2][u][1], (half_t)sa[2][u][2], (half_t)sa[2][u][3],
+                      (half_t)sa[3][u][0], (half_t)sa[3][u][1], (half_t)sa[3][u][2], (half_t)sa[3][u][3]};
+      p2[u] = half4_t{(half_t)sa[4][u][0], (half_t)sa[4][u][1], (half_t)sa[4][u][2], (half_t)sa[4][u][3]};
+    }
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      floatx4 o[NT];
+#pragma unroll
+      for (int u = 0; u < NT; ++u) o[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vA32[t][0], p0[u], zf, 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < NT; ++u) o[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vA32[t][1], p1[u], o[u], 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < NT; ++u) o[u] = mfma_k16(vA16[t], p2[u], o[u]);
+      // O_h -> R, columns 40 h + 16 t + 4 fq + e of the token rows: this wave's own columns, 8 bytes per lane
+      const int n = t * 16 + 4 * fq;
+      if (n < XA_D) {
+        const int c = h * XA_D + n;                     // channel: block c >> 6, 16-byte chunk (c & 63) >> 3, 8-byte half (c >> 2) & 1
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+          const int row = (t0 + u) * 16 + fr;
+          const half4_t o4 = {(half_t)(o[u][0] * inv[u]), (half_t)(o[u][1] * inv[u]), (half_t)(o[u][2] * inv[u]), (half_t)(o[u][3] * inv[u])};
+          *reinterpret_cast<half4_t*>(R + (c >> 6) * (XA_BM * 128) + row * 128 + ((((c & 63) >> 3) ^ ((row >> 1) & 7)) * 16) + ((c >> 2) & 1) * 8) = o4;
+        }
+      }
+    }
+  }
+
+  // ================= phase C: out = O W_o^T + b_o + residual, 2 x 4 waves of 64 x 80
+  const int wm = wave & 1, wn = wave >> 1;
+  floatx4 acc[5][4];
+#pragma unroll
+  for (int tn = 0; tn < 5; ++tn)
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm) acc[tn][tm] = zf;
+  for (int st = 0; st < 5; ++st) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // W_o stage st has landed; (first pass) this wave's O stores are in LDS
+    __builtin_amdgcn_s_barrier();
+    if (st >= 1 && st + 1 < 5) issue_w(p.wo, p.kpad_o, st + 1, (st + 1) & 1);
+    const char* Ws = RING + (st & 1) * XT_STAGE;
+    const char* Os = R + st * (XA_BM * 128);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      half8_t wf[5], xf[4];
+#pragma unroll
+      for (int tn = 0; tn < 5; ++tn) wf[tn] = *reinterpret_cast<const half8_t*>(Ws + frag_off(wn * 80 + tn * 16, kk));
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm) xf[tm] = *reinterpret_cast<const half8_t*>(Os + frag_off(wm * 64 + tm * 16, kk));
+#pragma unroll
+      for (int tn = 0; tn < 5; ++tn)
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm) acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[tn], xf[tm], acc[tn][tm], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int tm = 0; tm < 4; ++tm) {
+    const int m = m0 + wm * 64 + tm * 16 + fr;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int tn = 0; tn < 5; ++tn) {
+      const int c = wn * 80 + tn * 16 + 4 * fq;
+      floatx4 v = acc[tn][tm];
+      if (p.bo) {
+        const floatx4 b = *reinterpret_cast<const floatx4*>(p.bo + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += b[e];
+      }
+      if (p.residual) {
+        const half4_t rr = *reinterpret_cast<const half4_t*>(p.residual + (size_t)m * XA_C + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += (float)rr[e];
+      }
+      const half4_t o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+      *reinterpret_cast<half4_t*>(p.out + (size_t)m * XA_C + c) = o;
+    }
+  }
+}
+
 }  // namespace
 
 // Whole cross-attention block at C = 320 (af_xattn320_kernel above): q projection with the LayerNorm folded in (wq / bq / ln_colsum as
@@ -348,6 +677,16 @@ extern "C" int af_xattn_fused(const void* x, const void* wq, const void* bq, con
   static bool attr_set = false;
   if (!af_allow_dyn_lds(reinterpret_cast<const void*>(&af_xattn320_kernel), XA_LDS, attr_set, "af_xattn_fused")) return af_check_launch("af_xattn_fused");
   AfLaunchScope scope(AF_FAM_XATTN, stream);
+  // AF_XATTN_TILED (default 1): the tiled form (af_xattn320t_kernel); 0 = the wave-owns-16-tokens form.  Re-read per call under AF_GEMM3_ABLATE_DYNAMIC (A/B runs).
+  static const int tiled_env = getenv("AF_XATTN_TILED") ? atoi(getenv("AF_XATTN_TILED")) : 1;
+  static const bool dyn = getenv("AF_GEMM3_ABLATE_DYNAMIC") != nullptr;
+  const int tiled = dyn ? (getenv("AF_XATTN_TILED") ? atoi(getenv("AF_XATTN_TILED")) : 1) : tiled_env;
+  if (tiled) {
+    static bool attr_t = false;
+    if (!af_allow_dyn_lds(reinterpret_cast<const void*>(&af_xattn320t_kernel<2>), XT_LDS, attr_t, "af_xattn_fused")) return af_check_launch("af_xattn_fused");
+    hipLaunchKernelGGL(af_xattn320t_kernel<2>, dim3(p.M / XA_BM), dim3(512), XT_LDS, (hipStream_t)stream, p);
+    return af_check_launch("af_xattn_fused(tiled)");
+  }
   hipLaunchKernelGGL(af_xattn320_kernel, dim3(p.M / XA_BM), dim3(512), XA_LDS, (hipStream_t)stream, p);
   return af_check_launch("af_xattn_fused");
 }

@@ -31,6 +31,7 @@ from .diffusionmodules.util import (Conv2d, GroupNorm32, LayerNorm, Linear, _Pac
 
 # LayerNorm -> Linear pairs of the inference pass run as ONE GEMM (ops.pack_matrix_ln); AF_FOLD_LAYERNORM=0 keeps the separate kernels (A/B runs)
 FOLD_LAYERNORM = _os.environ.get("AF_FOLD_LAYERNORM", "1") != "0"
+XATTN_FUSE_MIN_TOKENS = int(_os.environ.get("AF_XATTN_FUSE_MIN_TOKENS", "8192"))   # U-Net batch x tokens from which the one-launch block is used
 FUSE_XATTN = _os.environ.get("AF_FUSE_XATTN", "1") != "0"      # the C = 320 cross-attention block as ONE launch (af_xattn_fused): on par with the
                                                                 # three launches alone, -0.03 ms per denoise step (csrc/af_xattn_fused.hip); 0 = three launches
 FUSE_FF = _os.environ.get("AF_FUSE_FF", "1") != "0"          # the C = 320 feed-forward as one launch (af_ff_fused); 0 = the two GEMMs (A/B runs)
@@ -202,9 +203,9 @@ class CrossAttention(nn.Module):
             else:
                 k, vt = ops.gemm(context.reshape(B * L, context.shape[-1]), self._packed_kv(), rows_per_batch=L, split_col=Ci)
             if (FUSE_XATTN and ln is not None and Ci == 320 and x2d.shape[1] == 320 and h == 8 and keybias is None and not self.save_cross_attn_vars
-                    and N % 128 == 0 and L <= 80 and B * N >= 24576):
-                # the 64 x 64 level: q projection (norm2 folded in), the 77-key core, to_out and the residual as ONE launch in which every
-                # wave keeps its 16 tokens from x to out (af_xattn_fused); worth it once 128-token workgroups fill the chip
+                    and N % 128 == 0 and L <= 80 and B * N >= XATTN_FUSE_MIN_TOKENS):
+                # the 64 x 64 level: q projection (norm2 folded in), the 77-key core, to_out and the residual as ONE launch over 128-token tiles
+                # that stay in LDS (af_xattn_fused, tiled form); worth it once the 128-token workgroups cover enough of the chip
                 return ops.xattn_fused(x2d, self._packed_q_ln(ln), k, vt, self.to_out[0].packed(), B=B, N=N, L=L, heads=h, scale=self.scale,
                                        ldk=ldk, residual=residual)
             q = self.to_q.hip(x2d) if ln is None else ops.gemm(x2d, self._packed_q_ln(ln))

@@ -22,6 +22,7 @@ for B in ([int(sys.argv[1])] if len(sys.argv) > 1 else [8, 4, 2]):
 
     def graph(fused):
         A.FUSE_XATTN = fused
+        A.XATTN_FUSE_MIN_TOKENS = 0          # the comparison itself decides from which batch on the one-launch form pays
         for _ in range(2):
             m.hip(x, B, N, context=ctx, residual=x, ln=ln)
         torch.cuda.synchronize()
