@@ -29,6 +29,7 @@ EXPORTS = (
     "af_xattn_scores", "af_xattn_softmax_pv", "af_xattn_softmax_pv_bwd", "af_xattn_rowmix", "af_xattn_colmix_ws_bytes", "af_xattn_colmix",
     "af_layernorm_param_grads", "af_transpose_tokens_pair", "af_ff_fused", "af_xattn_fused",
     "af_softmax_rows_bwd", "af_affine_prelu_bwd", "af_maxpool2x2_bwd", "af_se_gate_grad", "af_se_residual_prelu_bwd",
+    "af_groupnorm_apply", "af_gemm_gn_stats_ok",
 )
 
 
@@ -46,6 +47,7 @@ class GemmDesc(C.Structure):
         ("tap_shift", C.c_int32), ("splitk_fused", C.c_int32),
         ("ln_colsum", C.c_void_p), ("ln_eps", C.c_float),
         ("a3", C.c_void_p), ("a4", C.c_void_p), ("c3", C.c_int32), ("c4", C.c_int32), ("lda3", C.c_int32), ("lda4", C.c_int32),
+        ("gn_partials", C.c_void_p), ("gn_cpg", C.c_int32),
     ]
 
 
@@ -119,6 +121,8 @@ def lib() -> C.CDLL:
     L.af_gemm.argtypes = [C.POINTER(GemmDesc), vp]
     L.af_groupnorm_ws_floats.argtypes = [i32]
     L.af_groupnorm.argtypes = [vp, vp, i32, i32, vp, vp, vp, i32, i32, i32, f32, i32, vp, vp]
+    L.af_groupnorm_apply.argtypes = [vp, i32, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp, i32, vp]
+    L.af_gemm_gn_stats_ok.argtypes = [i32, i32, i32, i32, i32, i32, i32, i32]
     L.af_layernorm.argtypes = [vp, vp, vp, vp, i32, i32, f32, vp]
     L.af_attention.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp]
     L.af_attention_scores.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp]

@@ -504,6 +504,14 @@ int launch_tile(const GemmDev& p, int tile, hipStream_t stream) {
 int af_gemm3_try_launch(const af_gemm_desc* d, int splits, int wide, hipStream_t stream);
 int af_gemm3_effective_splits(const af_gemm_desc* d, int splits, int wide);
 
+extern "C" int af_gemm_gn_stats_ok(int tile, int splits, int taps, int act, int out_mode, int N, int cpg, int rows_per_batch) {
+  const int bn = tile == 7 ? 320 : ((tile == 11 || tile == 13) ? 160 : 0);
+  if (bn == 0 || splits > 1 || (taps != 1 && taps != 9) || act == AF_ACT_GEGLU || out_mode != AF_OUT_NORMAL) return 0;
+  if (cpg <= 0 || cpg % 2 != 0 || bn % cpg != 0 || N % cpg != 0 || N / cpg > 32 || N % bn != 0 || N % 8 != 0) return 0;
+  if (rows_per_batch <= 0 || rows_per_batch % 128 != 0 || rows_per_batch / 128 > 128) return 0;
+  return 1;
+}
+
 extern "C" int af_gemm(const af_gemm_desc* d, void* stream) {
   AF_REQUIRE(d != nullptr, "af_gemm: null descriptor");
   AF_REQUIRE(d->a1 && d->wt && d->out, "af_gemm: a1/wt/out must be non-null");
@@ -522,6 +530,14 @@ extern "C" int af_gemm(const af_gemm_desc* d, void* stream) {
     AF_SUPPORTED(d->tile >= 7 && d->tile <= 13, "af_gemm: the K tail runs on the whole-line tiles 7 .. 13 only");
   }
   AF_REQUIRE(d->K == d->taps * (d->c1 + d->c2) + d->c3 + d->c4, "af_gemm: K != taps*(c1+c2) (+ c3 + c4)");
+  const bool gnp = d->gn_partials != nullptr;
+  if (gnp) {
+    const int rpb = d->rows_per_batch > 0 ? d->rows_per_batch : d->M;
+    AF_SUPPORTED(af_gemm_gn_stats_ok(d->tile, d->splits, d->taps, d->act, d->out_mode, d->N, d->gn_cpg, rpb) == 1,
+                 "af_gemm: gn_partials needs a whole-line tile whose width is a multiple of gn_cpg, the standard fp16 epilogue, whole 128-row tiles per "
+                 "batch item and no split-K (af_gemm_gn_stats_ok)");
+    AF_REQUIRE(d->M % rpb == 0 && (d->ld_out == 0 || d->ld_out == d->N) && ((uintptr_t)d->out & 15) == 0, "af_gemm: gn_partials needs M = B * rows_per_batch and a dense, 16-byte aligned output");
+  }
   GemmDev p;
   p.a1 = (const half_t*)d->a1;
   p.a2 = (const half_t*)d->a2;
@@ -626,6 +642,7 @@ extern "C" int af_gemm(const af_gemm_desc* d, void* stream) {
       return af_check_launch("af_gemm(tile 3, split-K)");
     }
     AF_SUPPORTED(!ktail, "af_gemm: the K tail is outside the chosen tile's scope");
+    AF_SUPPORTED(!gnp, "af_gemm: gn_partials is outside the chosen tile's scope");
     tile = 1;  // outside the pipelined kernel's scope
   }
   AF_SUPPORTED(d->ln_colsum == nullptr, "af_gemm: a folded LayerNorm (ln_colsum) needs a whole-line tile (7 .. 13) whose scope covers the shape, "

@@ -50,6 +50,8 @@ struct Gemm3Dev {
   int stage_ok;  // output rows can be written as 16-byte chunks (N, ld_out multiples of 8, 16-byte aligned base)
   const float* ln_cs;   // LayerNorm folded into the GEMM (af_gemm_desc.ln_colsum): column sums of the packed weight, or nullptr
   float ln_eps;
+  float* gn_ws;         // af_gemm_desc.gn_partials: GroupNorm partial statistics of the output tile from the staged standard epilogue, or nullptr
+  int gn_cpg;
   int wpf;              // whole-line kernel: weight-tile L2 prefetch at kernel start, wave instructions per wave (0 = off; AF_GEMM3_WPREFETCH)
   int wpf_coop;         // workgroups that share one weight tile and split its prefetch (min(tiles_m, 32))
 };
@@ -257,6 +259,48 @@ __device__ __forceinline__ void gemm3_epilogue(const Gemm3Dev& p, floatx4 (&acc)
       }
     }
     __syncthreads();
+    constexpr bool kGnFits = EPI == E3_STD && BM == 128 && (size_t)BM * TS * 2 + 2 * ((64 * NW) / 32) * 32 * 4 <= (size_t)LDSB;
+    if constexpr (kGnFits) if (p.gn_ws != nullptr) {
+      // GroupNorm partial statistics of THIS tile from the staged fp16 values (what the consumer's normalisation will read): thread (group g,
+      // row slice rs) sums its rows x cpg / 2 channel pairs, the slices meet in LDS behind the tile, one (sum, sumsq) per group leaves for
+      // af_groupnorm's partial workspace [B][128][32][2] at this tile's block index inside its image.  BM = 128 rows of ONE batch item; the tile's
+      // width is a multiple of the group width (validated by the host).  Rows beyond M hold zeros in T.
+      constexpr int NSL = (64 * NW) / 32;                        // row slices: 32 threads (groups) per slice
+      constexpr int RPS = BM / NSL;
+      float* red = reinterpret_cast<float*>(af_smem + (size_t)BM * TS * 2);
+      const int g = tid & 31, rs = tid >> 5;
+      const int ng = BNO / p.gn_cpg;
+      float s = 0.f, q = 0.f;
+      if (g < ng) {
+        const int hp = p.gn_cpg >> 1;
+        for (int r = rs * RPS; r < (rs + 1) * RPS; ++r) {
+          const half2_t* tp = reinterpret_cast<const half2_t*>(T + r * TS + g * p.gn_cpg);
+          for (int j = 0; j < hp; ++j) {
+            const half2_t v = tp[j];
+            const float a0 = (float)v[0], a1 = (float)v[1];
+            s += a0 + a1;
+            q += a0 * a0 + a1 * a1;
+          }
+        }
+      }
+      red[rs * 32 + g] = s;
+      red[NSL * 32 + rs * 32 + g] = q;
+      __syncthreads();
+      if (tid < ng) {
+        float ss = 0.f, qq = 0.f;
+#pragma unroll
+        for (int k = 0; k < NSL; ++k) {
+          ss += red[k * 32 + tid];
+          qq += red[NSL * 32 + k * 32 + tid];
+        }
+        const int m0 = tile_m * BM;
+        const int bt = m0 / p.rows_per_batch, blk = (m0 - bt * p.rows_per_batch) / BM;
+        const int g0 = (tile_n * BNO) / p.gn_cpg;
+        float* w = p.gn_ws + (((size_t)bt * 128 + blk) * 32 + g0 + tid) * 2;
+        w[0] = ss;
+        w[1] = qq;
+      }
+    }
     constexpr int CPR = BNO / 8;                                // 16-byte chunks per output row
     const int ncols = EPI == E3_GEGLU ? (p.N >> 1) : p.N;
     for (int c = tid; c < BM * CPR; c += 64 * NW) {
@@ -1381,6 +1425,7 @@ int af_gemm3_try_launch(const af_gemm_desc* d, int splits, int wide, hipStream_t
   if (wide == 2 && (d->N % 256 != 0 || d->taps != 1 || split_t || splits > 1)) return 1;
   if (wide == 3 && (d->N % 320 != 0 || d->taps != 1 || split_t || splits > 1)) return 1;
   if (d->ln_colsum != nullptr && (wide < 4 || d->taps != 1 || d->c2 != 0 || splits > 1)) return 1;   // folded LayerNorm: whole-line tiles only
+  if (d->gn_partials != nullptr && !((wide == 4 || wide == 8 || wide == 10) && !geglu && !split_t && splits <= 1)) return 1;   // GroupNorm partials: staged standard epilogue
   Gemm3Dev p;
   bool fused = false;
   p.ln_cs = (const float*)d->ln_colsum;
@@ -1405,6 +1450,8 @@ int af_gemm3_try_launch(const af_gemm_desc* d, int splits, int wide, hipStream_t
   p.c2 = d->c2;
   p.lda1 = d->lda1 ? d->lda1 : d->c1;
   p.lda2 = d->lda2 ? d->lda2 : d->c2;
+  p.gn_ws = (float*)d->gn_partials;
+  p.gn_cpg = d->gn_cpg;
   p.a3 = (const half_t*)d->a3;
   p.a4 = (const half_t*)d->a4;
   p.c3 = d->c3;

@@ -548,6 +548,47 @@ extern "C" int af_groupnorm_stats(const void* x1, const void* x2, int c1, int c2
   return af_check_launch("af_groupnorm");
 }
 
+extern "C" int af_groupnorm_apply(const void* x, int C, const void* gamma, const void* beta, void* y, void* stats, int B, int HW, int groups,
+                                  float eps, int silu, const void* partials, int nblk, void* stream) {
+  AF_REQUIRE(x && gamma && beta && y && partials, "af_groupnorm_apply: null pointer");
+  AF_REQUIRE(B > 0 && HW > 0 && C > 0 && C % 8 == 0, "af_groupnorm_apply: bad sizes");
+  AF_REQUIRE((((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0, "af_groupnorm_apply: x / y / gamma / beta must be 16-byte aligned");
+  AF_REQUIRE(groups > 0 && groups <= GN_MAXG && C % groups == 0, "af_groupnorm_apply: groups must divide C and be <= 32");
+  AF_REQUIRE(nblk > 0 && nblk <= GN_NBLK, "af_groupnorm_apply: nblk must be 1 .. 128");
+  AF_SUPPORTED(C <= 4096, "af_groupnorm_apply: C > 4096");
+  GnArgs a;
+  a.x1 = (const half_t*)x;
+  a.x2 = nullptr;
+  a.c1 = C;
+  a.c2 = 0;
+  a.C = C;
+  a.CP = C / 8;
+  a.gamma = (const float*)gamma;
+  a.beta = (const float*)beta;
+  a.y = (half_t*)y;
+  a.B = B;
+  a.HW = HW;
+  a.groups = groups;
+  a.cpg = C / groups;
+  a.eps = eps;
+  a.silu = silu;
+  a.ws = const_cast<float*>((const float*)partials);
+  a.stats = (float*)stats;
+  a.nblk = nblk;
+  const int ct = (a.CP + 255) / 256;
+  a.ppb = ct == 1 ? 256 / a.CP : 1;
+  const int slots = ct == 1 ? a.ppb : 1;
+  const int iters = (HW + slots - 1) / slots;
+  int nb2 = (iters + 7) / 8;
+  nb2 = nb2 < 1 ? 1 : (nb2 > 256 ? 256 : nb2);
+  AfLaunchScope scope(AF_FAM_GNORM, stream);
+  hipStream_t s = (hipStream_t)stream;
+  if (ct == 1) hipLaunchKernelGGL(gn_apply_kernel<1>, dim3(nb2, B), dim3(256), 0, s, a);
+  else if (ct == 2) hipLaunchKernelGGL(gn_apply_kernel<2>, dim3(nb2, B), dim3(256), 0, s, a);
+  else return af_fail(AF_E_UNSUPPORTED, "af_groupnorm_apply: C > 4096");
+  return af_check_launch("af_groupnorm_apply");
+}
+
 extern "C" int af_layernorm(const void* x, const void* gamma, const void* beta, void* y, int rows, int C, float eps,
                             void* stream) {
   AF_REQUIRE(x && gamma && beta && y, "af_layernorm: null pointer");

@@ -392,8 +392,13 @@ class SpatialTransformer(nn.Module):
         for block in self.transformer_blocks:
             block.attn2.infeat_size = (H, W)
             y = block.hip(y, B, N, context, kb)
-        out = ops.gemm(y, self.proj_out.packed(), residual=x.reshape(B * N, Cn))
-        return out.reshape(B, H, W, Cn)
+        # the block's output feeds the next GroupNorm(32) (a ResBlock's first norm or the output norm) when it is not concatenated first: leave
+        # the partial statistics with it (ops.GnPartials)
+        out = ops.gemm(y, self.proj_out.packed(), residual=x.reshape(B * N, Cn), rows_per_batch=N, gn_cpg=Cn // 32 if Cn % 32 == 0 else 0)
+        out4 = out.reshape(B, H, W, Cn)
+        if hasattr(out, "_gn_partials"):
+            out4._gn_partials = out._gn_partials
+        return out4
 
     def hip_train(self, x, context=None, mask=None):
         B, H, W, Cn = x.shape

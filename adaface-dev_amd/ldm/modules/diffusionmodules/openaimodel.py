@@ -192,15 +192,17 @@ class ResBlock(TimestepBlock):
             se = emb.silu_emb if isinstance(emb, EmbPack) else ops.silu(emb.to(F16).contiguous())
             e = self.emb_layers[1].hip(se)
         h = self.in_layers[0].hip(x1, silu=True, x2=x2)
-        h = self.in_layers[2].hip(h, rowbias=e)
+        # both convolutions feed a GroupNorm(32) (this block's second norm; the next block's first norm, a transformer's norm or the output
+        # norm): they leave the partial statistics of what they store (Conv2d.hip gn_groups)
+        h = self.in_layers[2].hip(h, rowbias=e, gn_groups=32)
         h = self.out_layers[0].hip(h, silu=True)
         if isinstance(self.skip_connection, nn.Identity):
             skip = x1 if x2 is None else torch.cat([x1, x2], dim=-1)
         elif self._skip_fusable(x1, x2):
-            return ops.conv3x3(h, self._packed_conv2_skip(), skip=(x1, x2))
+            return ops.conv3x3(h, self._packed_conv2_skip(), skip=(x1, x2), gn_cpg=self.out_channels // 32)
         else:
             skip = self.skip_connection.hip(x1, x2=x2)
-        return self.out_layers[3].hip(h, residual=skip)
+        return self.out_layers[3].hip(h, residual=skip, gn_groups=32)
 
     # ---- out_layers convolution + channel-changing 1x1 skip_connection as ONE K-concatenated implicit GEMM (ops.pack_conv3x3_skip): the block's
     # `skip_connection(x) + h` (openaimodel.py:256-276) costs no launch, no [B,H,W,Cout] round trip and no residual read of its own

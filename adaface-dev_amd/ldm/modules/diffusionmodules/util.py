@@ -81,16 +81,21 @@ class Conv2d(nn.Conv2d):
 
         return self._cache.get((self.weight, self.bias), build)
 
-    def hip(self, x, x2=None, upsample=False, rowbias=None, residual=None):
-        """x [B,H,W,C1] (+x2 [B,H,W,C2]) fp16 -> [B,Ho,Wo,Cout] fp16."""
+    def hip(self, x, x2=None, upsample=False, rowbias=None, residual=None, gn_groups=0):
+        """x [B,H,W,C1] (+x2 [B,H,W,C2]) fp16 -> [B,Ho,Wo,Cout] fp16.  gn_groups > 0: the output feeds a GroupNorm of that many groups -- where
+        the launch can, it leaves the partial statistics with the tensor (ops.GnPartials) and the GroupNorm skips its statistics pass."""
         pw = self.packed()
+        cpg = self.out_channels // gn_groups if gn_groups and self.out_channels % gn_groups == 0 else 0
         if self.kernel_size == (3, 3):
-            return ops.conv3x3(x, pw, x2=x2, stride=self.stride[0], upsample=upsample, rowbias=rowbias, residual=residual)
+            return ops.conv3x3(x, pw, x2=x2, stride=self.stride[0], upsample=upsample, rowbias=rowbias, residual=residual, gn_cpg=cpg)
         B, H, W, c1 = x.shape
         a2 = None if x2 is None else x2.reshape(B * H * W, x2.shape[-1])
         res = None if residual is None else residual.reshape(B * H * W, -1)
-        out = ops.gemm(x.reshape(B * H * W, c1), pw, a2=a2, rowbias=rowbias, rows_per_batch=H * W, residual=res)
-        return out.reshape(B, H, W, -1)
+        out = ops.gemm(x.reshape(B * H * W, c1), pw, a2=a2, rowbias=rowbias, rows_per_batch=H * W, residual=res, gn_cpg=cpg)
+        out4 = out.reshape(B, H, W, -1)
+        if hasattr(out, "_gn_partials"):
+            out4._gn_partials = out._gn_partials
+        return out4
 
     def packed_bwd(self) -> ops.PackedWeight:
         """Weights of the input-gradient convolution: spatially flipped, in/out channels swapped

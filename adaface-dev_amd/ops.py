@@ -204,8 +204,21 @@ def _splitk_workspace(device) -> torch.Tensor:
 SPLITK_FUSED_MAX = int(_os.environ.get("AF_SPLITK_FUSED_MAX", "0"))
 
 
-def _launch_gemm(d: "GemmDesc", device, what: str, tile: int = 0, splits: int = 0):
-    """Pick (tile, splits) -- explicit args > recorder (autotune) > table > heuristic -- and launch."""
+GN_FROM_PRODUCER = _os.environ.get("AF_GN_FROM_PRODUCER", "1") != "0"   # GroupNorm statistics from the producing GEMM's epilogue (0: always a statistics pass)
+
+
+class GnPartials:
+    """Partial GroupNorm statistics of a tensor, written by the GEMM launch that produced it (af_gemm_desc.gn_partials)."""
+    __slots__ = ("ws", "nblk", "cpg", "B", "hw", "C")
+
+    def __init__(self, ws, nblk, cpg, B, hw, C):
+        self.ws, self.nblk, self.cpg, self.B, self.hw, self.C = ws, nblk, cpg, B, hw, C
+
+
+def _launch_gemm(d: "GemmDesc", device, what: str, tile: int = 0, splits: int = 0, gn_cpg: int = 0):
+    """Pick (tile, splits) -- explicit args > recorder (autotune) > table > heuristic -- and launch.  gn_cpg > 0: the caller's output feeds a
+    GroupNorm with groups of gn_cpg channels; when the chosen launch can (af_gemm_gn_stats_ok) it also writes the partial statistics and a
+    GnPartials is returned (None otherwise)."""
     if tile == 0 and splits == 0:
         key = f"{d.taps},{d.M},{d.N},{d.K},{d.act},{d.out_mode},{d.stride},{d.upsample}"
         if d.ln_colsum:
@@ -236,13 +249,22 @@ def _launch_gemm(d: "GemmDesc", device, what: str, tile: int = 0, splits: int = 
             d.splits = max(1, min(d.splits, (ws.numel() * 4 - _lib.AF_SPLITK_COUNTER_BYTES) // (d.M * d.N * 4)))
             d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
             d.splitk_fused = int(d.splits <= SPLITK_FUSED_MAX and not f32)
+    gn = None
+    if gn_cpg and GN_FROM_PRODUCER and _tune_recorder is None:
+        rpb = d.rows_per_batch if d.rows_per_batch > 0 else d.M
+        if d.M % rpb == 0 and d.ld_out in (0, d.N) and _lib.lib().af_gemm_gn_stats_ok(d.tile, d.splits, d.taps, d.act, d.out_mode, d.N, gn_cpg, rpb) == 1:
+            nb = d.M // rpb
+            ws = torch.empty((nb, 128, 32, 2), dtype=torch.float32, device=device)
+            d.gn_partials, d.gn_cpg = ws.data_ptr(), gn_cpg
+            gn = GnPartials(ws, rpb // 128, gn_cpg, nb, rpb, d.N)
     _lib.check(_lib.lib().af_gemm(C.byref(d), _stream()), what)
+    return gn
 
 
 # ----------------------------------------------------------------------------- gemm / conv
 def gemm(a1: torch.Tensor, pw: PackedWeight, *, a2: Optional[torch.Tensor] = None, rowbias: Optional[torch.Tensor] = None,
          rows_per_batch: int = 0, residual: Optional[torch.Tensor] = None, act: int = AF_ACT_NONE,
-         split_col: int = 0, ld_out2: int = 0, tile: int = 0, splits: int = 0, out_f32: bool = False):
+         split_col: int = 0, ld_out2: int = 0, tile: int = 0, splits: int = 0, out_f32: bool = False, gn_cpg: int = 0):
     """Plain-rows GEMM: a1 [M, K1] (+ a2 [M, K2], concatenated along K) x pw.  Returns out
     ([M, N], or [M, N/2] for GEGLU), or (out [M, split_col], out2 [B, N-split_col, ld_out2]).  out_f32: the fp32 accumulator is
     returned (AF_OUT_F32; weight gradients)."""
@@ -284,7 +306,9 @@ def gemm(a1: torch.Tensor, pw: PackedWeight, *, a2: Optional[torch.Tensor] = Non
         _chk_f16(residual, "gemm.residual")
         assert residual.shape == out.shape
     d.out = _p(out)
-    _launch_gemm(d, a1.device, "af_gemm", tile, splits)
+    gn = _launch_gemm(d, a1.device, "af_gemm", tile, splits, gn_cpg=0 if (split_col or out_f32) else gn_cpg)
+    if gn is not None:
+        out._gn_partials = gn            # rides on the tensor object: GroupNorm32.hip picks it up (ops.groupnorm)
     return (out, out2) if split_col else out
 
 
@@ -300,7 +324,7 @@ def conv3x3_skip_tile(M: int, N: int, cin: int, ktail: int):
 
 def conv3x3(x: torch.Tensor, pw: PackedWeight, *, x2: Optional[torch.Tensor] = None, stride: int = 1, upsample: bool = False,
             rowbias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, tile: int = 0,
-            splits: int = 0, out_hw=None, tap_shift: int = 0, skip=None) -> torch.Tensor:
+            splits: int = 0, out_hw=None, tap_shift: int = 0, skip=None, gn_cpg: int = 0) -> torch.Tensor:
     """3x3 / pad 1 convolution as implicit GEMM (tap_shift=1: padding (0, 1, 0, 1) instead, the VAE encoder's Downsample).  x [B,H,W,C1] (+ x2 [B,H,W,C2] channel-concat)
     -> [B,Ho,Wo,Cout].  rowbias [B, >=Cout] is added per batch item (time-embedding), residual
     [B,Ho,Wo,Cout] after it."""
@@ -346,7 +370,9 @@ def conv3x3(x: torch.Tensor, pw: PackedWeight, *, x2: Optional[torch.Tensor] = N
         d.a3, d.a4, d.c3, d.c4, d.lda3, d.lda4 = _p(s1), _p(s2), c3, c4, c3, c4
         if tile == 0 and splits == 0 and _tune_recorder is None:
             tile, splits = conv3x3_skip_tile(d.M, d.N, c1 + c2, pw.k_tail)
-    _launch_gemm(d, x.device, "af_gemm(conv3x3)", tile, splits)
+    gn = _launch_gemm(d, x.device, "af_gemm(conv3x3)", tile, splits, gn_cpg=gn_cpg)
+    if gn is not None:
+        out._gn_partials = gn
     return out
 
 
@@ -417,6 +443,12 @@ def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
         _chk_f16(x2, "groupnorm.x2")
         c2 = x2.shape[-1]
     y = torch.empty(tuple(x.shape[:-1]) + (c1 + c2,), dtype=F16, device=x.device)
+    gn = getattr(x, "_gn_partials", None) if x2 is None else None
+    if gn is not None and gn.B == B and gn.hw == hw and gn.C == c1 and gn.cpg * groups == c1 and x.is_contiguous():
+        # the launch that produced x left its partial statistics: normalise in one pass, no statistics pass (af_groupnorm_apply)
+        rc = _lib.lib().af_groupnorm_apply(_p(x), c1, _p(gamma), _p(beta), _p(y), None, B, hw, groups, float(eps), int(silu), _p(gn.ws), gn.nblk, _stream())
+        _lib.check(rc, "af_groupnorm_apply")
+        return y
     ws = _gn_workspace(x.device, B)
     rc = _lib.lib().af_groupnorm(_p(x), _p(x2), c1, c2, _p(gamma), _p(beta), _p(y), B, hw, groups, float(eps), int(silu),
                                  _p(ws), _stream())

@@ -153,6 +153,15 @@ typedef struct af_gemm_desc {
   const void* a3;
   const void* a4;
   int32_t c3, c4, lda3, lda4;
+  /* GroupNorm statistics of the OUTPUT from the producing GEMM's epilogue (all 0 / NULL otherwise): gn_partials != NULL makes the launch also write,
+   * per (batch item b, 128-row tile blk of that item, group g of gn_cpg output channels), the partial (sum, sum of squares) of the fp16 values it
+   * stores, as fp32 [B][128][32][2] -- exactly the partial-sum workspace of af_groupnorm, so af_groupnorm_apply can normalise the tensor without a
+   * statistics pass of its own (GroupNorm32 behind a convolution: openaimodel.py:202-233, 256-276; attention.py:283-291).  Needs the standard
+   * epilogue on a whole-line tile whose width is a multiple of gn_cpg (tile 7: 128 x 320, tile 11 / 13: 128 x 160), gn_cpg even, N % gn_cpg == 0,
+   * N / gn_cpg <= 32, rows_per_batch % 128 == 0 (or M % 128 == 0 when rows_per_batch is 0), rows_per_batch / 128 <= 128, fp16 output, no split-K;
+   * anything else is AF_E_UNSUPPORTED (callers check af_gemm_gn_stats_ok first). */
+  void* gn_partials;
+  int32_t gn_cpg;
 } af_gemm_desc;
 #define AF_SPLITK_MAX_TILES 4096
 #define AF_SPLITK_COUNTER_BYTES (AF_SPLITK_MAX_TILES * 4)
@@ -191,6 +200,13 @@ int af_xattn_fused(const void* x, const void* wq, const void* bq, const void* ln
  * workspace: fp32, at least af_groupnorm_ws_floats(B) floats.  x1 / x2 / y / gamma / beta must
  * be 16-byte aligned (vector accesses); AF_E_BADARG otherwise.                              */
 int af_groupnorm_ws_floats(int B);
+/* GroupNorm(32) [+ SiLU] of a single-source tensor whose partial statistics already exist (af_gemm_desc.gn_partials of the launch that produced x):
+ * partials fp32 [B][128][32][2] with nblk valid blocks per batch item; one launch (the normalising pass of af_groupnorm).  stats (optional) as
+ * af_groupnorm_stats. */
+int af_groupnorm_apply(const void* x, int C, const void* gamma, const void* beta, void* y, void* stats, int B, int HW, int groups, float eps,
+                       int silu, const void* partials, int nblk, void* stream);
+/* 1 when af_gemm with this (tile, splits) takes gn_partials for an output of N channels in groups of cpg and rows_per_batch rows per batch item */
+int af_gemm_gn_stats_ok(int tile, int splits, int taps, int act, int out_mode, int N, int cpg, int rows_per_batch);
 int af_groupnorm(const void* x1, const void* x2, int c1, int c2, const void* gamma, const void* beta,
                  void* y, int B, int HW, int groups, float eps, int silu, void* workspace, void* stream);
 

@@ -185,6 +185,54 @@ def test_conv3x3_with_k_concatenated_1x1_skip(dev, B, H, W, cin, cs1, cs2, cout,
         ops.conv3x3(h.to(dev), pw, skip=(x1.to(dev), x2d), tile=2)
 
 
+@pytest.mark.parametrize("kind,B,H,W,cin,cout,tile", [("conv", 2, 16, 16, 128, 320, 7), ("conv", 1, 64, 64, 320, 320, 7), ("conv", 2, 32, 32, 64, 640, 7),
+                                                       ("conv", 3, 16, 8, 64, 320, 11), ("gemm", 2, 16, 16, 320, 320, 7), ("gemm", 2, 32, 32, 128, 1280, 11),
+                                                       ("skip", 2, 16, 16, 128, 320, 7), ("conv", 2, 16, 16, 64, 960, 7)])
+def test_groupnorm_statistics_from_the_producing_gemm(dev, kind, B, H, W, cin, cout, tile):
+    """A convolution / 1x1 GEMM / K-concatenated convolution whose output feeds a GroupNorm(32) leaves the partial (sum, sumsq) of the fp16 values
+    it stores (af_gemm_desc.gn_partials); af_groupnorm_apply then normalises without a statistics pass.  Same result as the two-pass GroupNorm
+    on the same tensor (identical statistics up to summation order) and as torch's group_norm in fp32 (util.py:195-212)."""
+    from adaface_dev_amd import ops
+    x = rnd((B, H, W, cin), 1)
+    gam = torch.randn(cout, generator=torch.Generator().manual_seed(2)) * 0.3 + 1
+    bet = torch.randn(cout, generator=torch.Generator().manual_seed(3)) * 0.3
+    cpg = cout // 32
+    if kind == "conv":
+        pw = ops.pack_conv3x3(rnd((cout, cin, 3, 3), 4, (9 * cin) ** -0.5), torch.randn(cout, generator=torch.Generator().manual_seed(5)), dev)
+        y = ops.conv3x3(x.to(dev), pw, rowbias=rnd((B, cout), 6).to(dev), tile=tile, gn_cpg=cpg)
+    elif kind == "skip":
+        pw = ops.pack_conv3x3_skip(rnd((cout, cin, 3, 3), 4, (9 * cin) ** -0.5), None, rnd((cout, 64, 1, 1), 7, 0.1), None, dev)
+        y = ops.conv3x3(x.to(dev), pw, skip=(rnd((B, H, W, 64), 8).to(dev), None), tile=tile, gn_cpg=cpg)
+    else:
+        pw = ops.pack_matrix(rnd((cout, cin), 4, cin ** -0.5), None, dev)
+        y = ops.gemm(x.to(dev).reshape(B * H * W, cin), pw, residual=rnd((B * H * W, cout), 9).to(dev), rows_per_batch=H * W, tile=tile, gn_cpg=cpg)
+        y4 = y.reshape(B, H, W, cout)
+        y4._gn_partials = y._gn_partials
+        y = y4
+    gn = getattr(y, "_gn_partials", None)
+    if (320 if tile == 7 else 160) % cpg != 0:          # groups that straddle tiles (C = 960: 30 channels per group): no statistics, plain launch
+        assert gn is None
+        return
+    assert gn is not None and gn.nblk == H * W // 128 and gn.cpg == cpg, "the launch was expected to leave its statistics"
+    # the partials themselves: per (batch item, 128-row block, group) sums of the stored fp16 values
+    yf = y.float().reshape(B, H * W // 128, 128, 32, cpg)
+    want = torch.stack([yf.sum(dim=(2, 4)), (yf * yf).sum(dim=(2, 4))], dim=-1)
+    got = gn.ws[:, :gn.nblk]
+    assert torch.allclose(got, want, rtol=2e-4, atol=2e-2)
+    for silu in (False, True):
+        out = ops.groupnorm(y, gam.to(dev), bet.to(dev), 1e-5, silu)                       # picks the partials up
+        y_plain = y.clone()                                                                  # no partials attached: statistics pass + normalise
+        out2 = ops.groupnorm(y_plain, gam.to(dev), bet.to(dev), 1e-5, silu)
+        ref = F.group_norm(y.float().cpu().permute(0, 3, 1, 2), 32, gam, bet, 1e-5)
+        ref = F.silu(ref) if silu else ref
+        assert rel_l2(out.float().cpu().permute(0, 3, 1, 2).numpy(), ref.numpy()) < TOL
+        assert rel_l2(out.float().cpu().numpy(), out2.float().cpu().numpy()) < 1e-3
+    # outside the scope (a 128-wide tile, split-K) no statistics are left and the launch is unchanged
+    if kind == "conv":
+        y8 = ops.conv3x3(x.to(dev), pw, rowbias=rnd((B, cout), 6).to(dev), tile=8, gn_cpg=cpg)
+        assert getattr(y8, "_gn_partials", None) is None and rel_l2(y8.float().cpu().numpy(), y.float().cpu().numpy()) < 2e-3
+
+
 def test_conv3x3_tile14_falls_back_outside_its_scope(dev):
     """stride 2 / two sources / widths it does not take: the descriptor's fallback (tile 1) computes the same convolution."""
     from adaface_dev_amd import ops
