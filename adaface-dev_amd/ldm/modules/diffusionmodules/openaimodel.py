@@ -241,7 +241,7 @@ class ResBlock(TimestepBlock):
             ad = lora["conv1"]
             h1, s1 = dora_conv_fwd(self.in_layers[2], ad, a, rowbias=self._emb_out(emb), mask=ad.draw_mask(a.shape, a.device))
         else:
-            h1 = self.in_layers[2].hip(a, rowbias=self._emb_out(emb))
+            h1 = self.in_layers[2].hip(a, rowbias=self._emb_out(emb), gn_groups=32)
         b, st2 = self.out_layers[0].hip_train(h1, silu=True)
         fuse = "conv2" not in lora and "conv_shortcut" not in lora and not isinstance(self.skip_connection, nn.Identity) and self._skip_fusable(x1, x2)
         if fuse:
@@ -255,12 +255,12 @@ class ResBlock(TimestepBlock):
         else:
             skip = self.skip_connection.hip(x1, x2=x2)
         if fuse:
-            out = ops.conv3x3(b, self._packed_conv2_skip(), skip=(x1, x2))
+            out = ops.conv3x3(b, self._packed_conv2_skip(), skip=(x1, x2), gn_cpg=self.out_channels // 32)
         elif "conv2" in lora:
             ad = lora["conv2"]
             out, s2 = dora_conv_fwd(self.out_layers[3], ad, b, residual=skip, mask=ad.draw_mask(b.shape, b.device))
         else:
-            out = self.out_layers[3].hip(b, residual=skip)
+            out = self.out_layers[3].hip(b, residual=skip, gn_groups=32)
         return out, (x1, x2, st1, h1, st2, (lora, s1, s2, ssc, {}) if lora else None)
 
     def hip_bwd(self, saved, dy):

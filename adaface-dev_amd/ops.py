@@ -647,6 +647,11 @@ def groupnorm_train(x, gamma, beta, eps, silu, *, x2=None, groups=32):
     c2 = 0 if x2 is None else x2.shape[-1]
     y = torch.empty(tuple(x.shape[:-1]) + (c1 + c2,), dtype=F16, device=x.device)
     stats = torch.empty((B, groups, 2), dtype=torch.float32, device=x.device)
+    gn = getattr(x, "_gn_partials", None) if x2 is None else None
+    if gn is not None and gn.B == B and gn.hw == hw and gn.C == c1 and gn.cpg * groups == c1 and x.is_contiguous():
+        rc = _lib.lib().af_groupnorm_apply(_p(x), c1, _p(gamma), _p(beta), _p(y), _p(stats), B, hw, groups, float(eps), int(silu), _p(gn.ws), gn.nblk, _stream())
+        _lib.check(rc, "af_groupnorm_apply")
+        return y, stats
     rc = _lib.lib().af_groupnorm_stats(_p(x), _p(x2), c1, c2, _p(gamma), _p(beta), _p(y), _p(stats), B, hw, groups, float(eps),
                                        int(silu), _p(_gn_workspace(x.device, B)), _stream())
     _lib.check(rc, "af_groupnorm_stats")
