@@ -363,7 +363,11 @@ __global__ __launch_bounds__(256) void af_attn_kernel(AttnArgs a) {
 //     S^T(A), S^T(B) [MFMA]  ->  softmax(A) [VALU, under S^T(B)]  ->  PV(A) [MFMA]  ->  softmax(B) [VALU, under PV(A)]  ->  PV(B)
 // so an MFMA batch of one chain is always in flight under the other chain's softmax, and the K / V^T fragments read from LDS are
 // shared by both chains (half the LDS reads per query: the LDS pipe was ~54 % busy).
-template <int DS, bool ONES>
+// SLOT (round 4; needs d = 16 DS - 8, i.e. d = 40): the softmax reference rides in a spare k slot of the S^T product -- K column d holds 1.0, element d of
+// the Q fragment holds -m as fp16 (any per-query constant cancels in the normalisation as long as every key sees the same one) -- so the S^T
+// accumulators start from the inline constant 0 instead of 32 v_mov of -m per chain and stage; the half-wave maximum is exchanged by
+// v_permlane32_swap instead of a ds_bpermute round trip.
+template <int DS, bool ONES, bool SLOT = false>
 __global__ __launch_bounds__(256) void af_attn2_kernel(AttnArgs a) {
   constexpr int DP = 16 * DS, DT = (DS + 1) / 2, DV = 32 * DT;
   constexpr int KST = DP + 8, KBUF = KB * KST, VBUF = 2 * DV * VST, STAGE = KBUF + VBUF;
@@ -397,14 +401,16 @@ __global__ __launch_bounds__(256) void af_attn2_kernel(AttnArgs a) {
 
   half8_t rk[NKC], rv[NVC];
   const half_t* kptr[NKC];
-  bool kok[NKC];
+  bool kok[NKC], kone[NKC];
 #pragma unroll
   for (int j = 0; j < NKC; ++j) {
     const int i = tid + 256 * j;
     const int row = i / (DP / 8), ch = i - row * (DP / 8);
     kok[j] = i < KCH && ch * 8 < a.d;
+    kone[j] = SLOT && i < KCH && ch * 8 == a.d;      // K column d = 1.0: multiplies the -m slot of Q
     kptr[j] = a.k + ((size_t)b * a.L + row) * a.ldk + h * a.d + ch * 8;
   }
+  const half8_t one1 = {1, 0, 0, 0, 0, 0, 0, 0};
   const half_t* vptr[NVC];
   bool vok[NVC], vones[NVC];
 #pragma unroll
@@ -418,7 +424,7 @@ __global__ __launch_bounds__(256) void af_attn2_kernel(AttnArgs a) {
   const half8_t ones8 = {1, 1, 1, 1, 1, 1, 1, 1};
   auto load_stage = [&](int key0) {
 #pragma unroll
-    for (int j = 0; j < NKC; ++j) rk[j] = kok[j] ? *reinterpret_cast<const half8_t*>(kptr[j] + (size_t)key0 * a.ldk) : zero8;
+    for (int j = 0; j < NKC; ++j) rk[j] = kok[j] ? *reinterpret_cast<const half8_t*>(kptr[j] + (size_t)key0 * a.ldk) : (kone[j] ? one1 : zero8);
 #pragma unroll
     for (int j = 0; j < NVC; ++j) rv[j] = vok[j] ? *reinterpret_cast<const half8_t*>(vptr[j] + key0) : (vones[j] ? ones8 : zero8);
   };
@@ -464,13 +470,26 @@ __global__ __launch_bounds__(256) void af_attn2_kernel(AttnArgs a) {
       mx = fmaxf(fmaxf(mx, sT[0][i]), sT[0][i + 1]);
       mx = fmaxf(fmaxf(mx, sT[1][i]), sT[1][i + 1]);
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    if constexpr (SLOT) {
+      const unsigned mb = __builtin_bit_cast(unsigned, mx);
+      const auto sw = __builtin_amdgcn_permlane32_swap(mb, mb, false, false);
+      mx = fmaxf(__builtin_bit_cast(float, (unsigned)sw[0]), __builtin_bit_cast(float, (unsigned)sw[1]));
+    } else {
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    }
     if (st == 0) {
-      m[c] = mx;
-      sT[0] = sT[0] - mx;
-      sT[1] = sT[1] - mx;
+      const float m0 = SLOT ? (float)(half_t)mx : mx;              // SLOT: the reference is what fp16 holds
+      m[c] = m0;
+      sT[0] = sT[0] - m0;
+      sT[1] = sT[1] - m0;
+      if (SLOT && hh) qf[c][DS - 1][0] = (half_t)(-m0);
     } else if (__builtin_amdgcn_ballot_w64(mx > kLazy) != 0) {       // lazy reference, see af_attn_kernel
-      const float delta = fmaxf(mx, 0.f);
+      float delta = fmaxf(mx, 0.f);
+      if constexpr (SLOT) {
+        const float mn = (float)(half_t)(m[c] + delta);
+        delta = mn - m[c];
+        if (hh) qf[c][DS - 1][0] = (half_t)(-mn);
+      }
       const float alpha = __builtin_amdgcn_exp2f(-delta);
       m[c] += delta;
       if (!ONES) l[c] *= alpha;
@@ -505,13 +524,16 @@ __global__ __launch_bounds__(256) void af_attn2_kernel(AttnArgs a) {
 
     // ---- S^T of both chains from shared K fragments
     floatx16 sA[2], sB[2];
-    const float ca = st == 0 ? 0.f : -m[0], cb = st == 0 ? 0.f : -m[1];
+    const floatx16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if constexpr (!SLOT) {
+      const float ca = st == 0 ? 0.f : -m[0], cb = st == 0 ? 0.f : -m[1];
 #pragma unroll
-    for (int sub = 0; sub < 2; ++sub) {
+      for (int sub = 0; sub < 2; ++sub) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        sA[sub][i] = ca;
-        sB[sub][i] = cb;
+        for (int i = 0; i < 16; ++i) {
+          sA[sub][i] = ca;
+          sB[sub][i] = cb;
+        }
       }
     }
 #pragma unroll
@@ -519,14 +541,14 @@ __global__ __launch_bounds__(256) void af_attn2_kernel(AttnArgs a) {
 #pragma unroll
       for (int s = 0; s < DS; ++s) {
         const half8_t kf = *reinterpret_cast<const half8_t*>(Ks + (sub * 32 + r) * KST + 16 * s + 8 * hh);
-        sA[sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[0][s], sA[sub], 0, 0, 0);
+        sA[sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[0][s], (SLOT && s == 0) ? zero16 : sA[sub], 0, 0, 0);
       }
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
       for (int s = 0; s < DS; ++s) {
         const half8_t kf = *reinterpret_cast<const half8_t*>(Ks + (sub * 32 + r) * KST + 16 * s + 8 * hh);
-        sB[sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[1][s], sB[sub], 0, 0, 0);
+        sB[sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[1][s], (SLOT && s == 0) ? zero16 : sB[sub], 0, 0, 0);
       }
     // ---- chain A softmax (its scores are done first; chain B's MFMAs are still running)
     half8_t pA[2][2], pB[2][2];
@@ -591,14 +613,14 @@ __global__ __launch_bounds__(256) void af_attn2_kernel(AttnArgs a) {
   }
 }
 
-template <int DS, bool ONES>
+template <int DS, bool ONES, bool SLOT = false>
 int launch_attn2chain(const AttnArgs& a, hipStream_t stream) {
   constexpr int DP = 16 * DS, DT = (DS + 1) / 2, DV = 32 * DT;
   constexpr size_t lds = (size_t)2 * (KB * (DP + 8) + 2 * DV * VST) * sizeof(half_t);
   static bool attr_set = false;  // benign race: idempotent attribute
-  if (!af_allow_dyn_lds(reinterpret_cast<const void*>(&af_attn2_kernel<DS, ONES>), lds, attr_set, "af_attention")) return af_check_launch("af_attention");
+  if (!af_allow_dyn_lds(reinterpret_cast<const void*>(&af_attn2_kernel<DS, ONES, SLOT>), lds, attr_set, "af_attention")) return af_check_launch("af_attention");
   const int qblocks = (a.Nq + 255) / 256, bh8 = (a.B * a.heads + 7) / 8 * 8;
-  hipLaunchKernelGGL((af_attn2_kernel<DS, ONES>), dim3(qblocks * bh8), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL((af_attn2_kernel<DS, ONES, SLOT>), dim3(qblocks * bh8), dim3(256), lds, stream, a);
   return af_check_launch("af_attention(two-chain)");
 }
 
@@ -832,6 +854,9 @@ int launch_attn(const AttnArgs& a, hipStream_t stream) {
   const bool general = a.kbias != nullptr || a.causal_m > 0 || a.L % KB != 0;
   static const int two_chain = getenv("AF_ATTN_TWO_CHAIN") ? atoi(getenv("AF_ATTN_TWO_CHAIN")) : 1;
   if constexpr (DS <= 3) {      // d <= 48: two chains fit the register file at 2 waves per SIMD
+    // AF_ATTN_SLOT (default 1): the reference in a spare k slot where the head dim leaves one (d = 16 DS - 8: the 64 x 64 level's d = 40)
+    static const int slot_env = getenv("AF_ATTN_SLOT") ? atoi(getenv("AF_ATTN_SLOT")) : 1;
+    if (!general && two_chain && slot_env && a.Nq >= 512 && a.d == 16 * DS - 8 && DV > a.d) return launch_attn2chain<DS, true, true>(a, stream);
     if (!general && two_chain && a.Nq >= 512) return DV > a.d ? launch_attn2chain<DS, true>(a, stream) : launch_attn2chain<DS, false>(a, stream);
   }
   if (DV > a.d) return general ? launch_attn2<DS, true, true>(a, stream) : launch_attn2<DS, true, false>(a, stream);
