@@ -351,7 +351,7 @@ def cross_attn_block_time(unet, ctx2, B, dev):
     tf = XATTN_BLOCK_GFLOP_PER_SAMPLE * 1e9 * n / (tot * 1e-3) / 1e12
     return {"ms_per_step": round(tot, 4), "kv_projection_ms": round(t_kv, 4), "tflops": round(tf, 1), "mfma_frac": round(tf / MFMA_PEAK_TFLOPS, 4),
             "definition": "sum over the 16 attn2 blocks of [to_q (norm2 folded in) + 77-key attention core + to_out with residual: ONE launch (af_xattn_fused) at "
-                          "C = 320 / U-Net batch >= 6, three launches otherwise] + one batched k/v projection, each block timed in isolation (hipGraph of 10 calls); "
+                          "C = 320 / U-Net batch >= 2 (tiled kernel, round 4), three launches otherwise] + one batched k/v projection, each block timed in isolation (hipGraph of 10 calls); "
                           "32.1 GFLOP per U-Net sample (SURVEY.md 8d)",
             "layers_C_N_us": per_layer}
 
@@ -451,7 +451,7 @@ def run_denoise(args, ctx, dev):
     if not args.no_roofline and rank == 0:
         # instrumented pass: same steps, eager launches, hipEvents around every launch of each family.  The C = 320 cross-attention blocks
         # run here in their three-launch form (to_q GEMM, core, to_out GEMM) so that the families keep their definitions -- every projection
-        # in the GEMM family, the 16 cores in `xattn`; the timed region above ran them as one launch each (af_xattn_fused, on par: profiles/r03at)
+        # in the GEMM family, the 16 cores in `xattn`; the timed region above ran them as one launch each (af_xattn_fused, tiled form: profiles/r04g)
         from adaface_dev_amd.ldm.modules import attention as _attn_mod
         state["graph"] = None
         fused_xattn, _attn_mod.FUSE_XATTN = _attn_mod.FUSE_XATTN, False
