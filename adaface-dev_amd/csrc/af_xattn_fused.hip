@@ -637,6 +637,165 @@ __global__ __launch_bounds__(512, 1) void af_xattn320t_kernel(const XaDev p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// GroupNorm's normalising pass + the 1x1 convolution behind it at C = 320, ONE launch (af_gn_proj_fused; round 4): the SpatialTransformer's
+// `proj_in(norm(x))` (attention.py:283-291).  Unfused: af_groupnorm_apply writes the normalised [M, 320] tensor (42 MB of traffic at U-Net
+// batch 8, 14 us) and a 16.6 us GEMM reads it back.  Here a workgroup normalises its 128-token tile straight into the LDS tile R (the layout of
+// af_xattn320t_kernel: five 64-channel blocks of 128-byte rows, swizzled) -- statistics from the PARTIAL sums the producing convolution left
+// (af_gemm_desc.gn_partials), folded by every workgroup for its batch item -- and runs the projection as a 2 x 4 wave GEMM over R on the two-slot
+// weight ring; the first two weight stages stream in under the normalisation.  The normalised tensor never exists in memory.
+struct GpDev {
+  const half_t* x;          // [M][320]
+  const float* partials;    // [B][128][32][2] (sum, sumsq) per 128-row block and group
+  const float* gamma;
+  const float* beta;
+  const half_t* w;          // packed [>= 320][kpad]
+  const float* bias;        // [320] or nullptr
+  half_t* out;              // [M][320]
+  const half_t* zeros;
+  int M, HW, nblk, kpad;
+  float eps;
+};
+
+__global__ __launch_bounds__(512, 1) void af_gn_proj320_kernel(const GpDev p) {
+  constexpr int NW = 8, G = 32, CPG = XA_C / G;
+  extern __shared__ __attribute__((aligned(16))) char af_smem[];
+  char* R = af_smem;
+  char* RING = af_smem + XT_R;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int prow = lane >> 3, slot = lane & 7;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int m0 = blockIdx.x * XA_BM;
+  const int bimg = m0 / p.HW;
+  const floatx4 zf = {0.f, 0.f, 0.f, 0.f};
+  auto issue_w = [&](int st, int sl) {
+    char* dst = RING + sl * XT_STAGE;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const int pc = wave + NW * j, row = pc * 8 + prow;
+      const int lc = slot ^ ((row >> 1) & 7);
+      glds16(p.w + (size_t)row * p.kpad + st * 64 + lc * 8, dst + pc * 1024);
+    }
+  };
+  issue_w(0, 0);
+  issue_w(1, 1);
+  // ---- this thread's share of the tile: chunk ch (8 channels) of rows r0, r0 + 12, ...; its loads are requested before the statistics fold
+  const bool act = tid < 480;
+  const int ch = tid % 40, r0 = tid / 40;
+  half8_t xv[11];
+#pragma unroll
+  for (int k = 0; k < 11; ++k) {
+    const int r = r0 + 12 * k;
+    if (act && r < XA_BM && m0 + r < p.M) xv[k] = *reinterpret_cast<const half8_t*>(p.x + (size_t)(m0 + r) * XA_C + ch * 8);
+  }
+  floatx4 gm[2], bt[2];
+  if (act) {
+    gm[0] = *reinterpret_cast<const floatx4*>(p.gamma + ch * 8);
+    gm[1] = *reinterpret_cast<const floatx4*>(p.gamma + ch * 8 + 4);
+    bt[0] = *reinterpret_cast<const floatx4*>(p.beta + ch * 8);
+    bt[1] = *reinterpret_cast<const floatx4*>(p.beta + ch * 8 + 4);
+  }
+  // ---- fold the producer's partial sums of this batch item: 16 lanes of blocks x 32 groups, then 16 -> 1 through LDS (inside R, which is still free)
+  float* fold = reinterpret_cast<float*>(R);                 // [16][32][2]
+  float* mr = fold + 16 * G * 2;                             // [32][2] (mean, rstd)
+  {
+    const int g = tid & 31, kl = tid >> 5;
+    float ss = 0.f, qq = 0.f;
+    for (int k = kl; k < p.nblk; k += 16) {
+      const float* w = p.partials + (((size_t)bimg * 128 + k) * G + g) * 2;
+      ss += w[0];
+      qq += w[1];
+    }
+    fold[(kl * G + g) * 2] = ss;
+    fold[(kl * G + g) * 2 + 1] = qq;
+  }
+  __syncthreads();
+  if (tid < G) {
+    float ss = 0.f, qq = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      ss += fold[(k * G + tid) * 2];
+      qq += fold[(k * G + tid) * 2 + 1];
+    }
+    const float inv_n = 1.0f / ((float)p.HW * (float)CPG);
+    const float mean = ss * inv_n;
+    const float var = fmaxf(qq * inv_n - mean * mean, 0.f);
+    mr[tid * 2] = mean;
+    mr[tid * 2 + 1] = rsqrtf(var + p.eps);
+  }
+  __syncthreads();
+  float sc[8], sh[8];
+  if (act) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int g = (ch * 8 + e) / CPG;
+      const float k = mr[g * 2 + 1] * gm[e >> 2][e & 3];
+      sc[e] = k;
+      sh[e] = bt[e >> 2][e & 3] - mr[g * 2] * k;
+    }
+  }
+  __syncthreads();                                           // everyone has read the statistics: R may take the tile
+  if (act) {
+#pragma unroll
+    for (int k = 0; k < 11; ++k) {
+      const int r = r0 + 12 * k;
+      if (r < XA_BM) {
+        half8_t o = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (m0 + r < p.M) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)xv[k][e] * sc[e] + sh[e]);
+        }
+        *reinterpret_cast<half8_t*>(R + (ch >> 3) * (XA_BM * 128) + r * 128 + (((ch & 7) ^ ((r >> 1) & 7)) * 16)) = o;
+      }
+    }
+  }
+  // ---- out = R W^T + b: 2 x 4 waves of 64 x 80 over the five 64-wide stages
+  auto frag_off = [&](int row0, int kk) { return (row0 + fr) * 128 + (((kk * 4 + fq) ^ (((row0 + fr) >> 1) & 7)) * 16); };
+  const int wm = wave & 1, wn = wave >> 1;
+  floatx4 acc[5][4];
+#pragma unroll
+  for (int tn = 0; tn < 5; ++tn)
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm) acc[tn][tm] = zf;
+  for (int st = 0; st < 5; ++st) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // weight stage st has landed; (first pass) this thread's tile rows are in LDS
+    __builtin_amdgcn_s_barrier();
+    if (st >= 1 && st + 1 < 5) issue_w(st + 1, (st + 1) & 1);
+    const char* Ws = RING + (st & 1) * XT_STAGE;
+    const char* Xs = R + st * (XA_BM * 128);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      half8_t wf[5], xf[4];
+#pragma unroll
+      for (int tn = 0; tn < 5; ++tn) wf[tn] = *reinterpret_cast<const half8_t*>(Ws + frag_off(wn * 80 + tn * 16, kk));
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm) xf[tm] = *reinterpret_cast<const half8_t*>(Xs + frag_off(wm * 64 + tm * 16, kk));
+#pragma unroll
+      for (int tn = 0; tn < 5; ++tn)
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm) acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[tn], xf[tm], acc[tn][tm], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int tm = 0; tm < 4; ++tm) {
+    const int m = m0 + wm * 64 + tm * 16 + fr;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int tn = 0; tn < 5; ++tn) {
+      const int c = wn * 80 + tn * 16 + 4 * fq;
+      floatx4 v = acc[tn][tm];
+      if (p.bias) {
+        const floatx4 b = *reinterpret_cast<const floatx4*>(p.bias + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += b[e];
+      }
+      const half4_t o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+      *reinterpret_cast<half4_t*>(p.out + (size_t)m * XA_C + c) = o;
+    }
+  }
+}
+
 }  // namespace
 
 // Whole cross-attention block at C = 320 (af_xattn320_kernel above): q projection with the LayerNorm folded in (wq / bq / ln_colsum as
@@ -689,4 +848,34 @@ extern "C" int af_xattn_fused(const void* x, const void* wq, const void* bq, con
   }
   hipLaunchKernelGGL(af_xattn320_kernel, dim3(p.M / XA_BM), dim3(512), XA_LDS, (hipStream_t)stream, p);
   return af_check_launch("af_xattn_fused");
+}
+
+// GroupNorm(32) of a single-source tensor whose partial statistics exist (af_gemm_desc.gn_partials) + the 1x1 convolution / Linear behind it at
+// C = 320, one launch (af_gn_proj320_kernel above): out [M][320] = GN(x) W^T + bias.  HW = rows per batch item (a multiple of 128), nblk = HW / 128.
+extern "C" int af_gn_proj_fused(const void* x, const void* partials, int nblk, const void* gamma, const void* beta, float eps, const void* w, const void* bias,
+                                int kpad, void* out, int B, int HW, int C, int groups, const void* zeros, void* stream) {
+  AF_REQUIRE(x && partials && gamma && beta && w && out && zeros, "af_gn_proj_fused: null pointer");
+  AF_SUPPORTED(C == XA_C && groups == 32, "af_gn_proj_fused: built for C = 320 in 32 groups (the 64 x 64 level of SD-1.5)");
+  AF_REQUIRE(B > 0 && HW > 0 && HW % XA_BM == 0 && nblk == HW / XA_BM && nblk <= 128, "af_gn_proj_fused: HW must be a multiple of 128 (at most 128 blocks) and nblk = HW / 128");
+  AF_REQUIRE(kpad >= C && kpad % 64 == 0, "af_gn_proj_fused: the weight row stride must be a 64-multiple covering C");
+  AF_REQUIRE((((uintptr_t)x | (uintptr_t)out | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)w) & 15) == 0, "af_gn_proj_fused: x / out / gamma / beta / w must be 16-byte aligned");
+  GpDev p;
+  p.x = (const half_t*)x;
+  p.partials = (const float*)partials;
+  p.gamma = (const float*)gamma;
+  p.beta = (const float*)beta;
+  p.w = (const half_t*)w;
+  p.bias = (const float*)bias;
+  p.out = (half_t*)out;
+  p.zeros = (const half_t*)zeros;
+  p.M = B * HW;
+  p.HW = HW;
+  p.nblk = nblk;
+  p.kpad = kpad;
+  p.eps = eps;
+  static bool attr_set = false;
+  if (!af_allow_dyn_lds(reinterpret_cast<const void*>(&af_gn_proj320_kernel), XT_LDS, attr_set, "af_gn_proj_fused")) return af_check_launch("af_gn_proj_fused");
+  AfLaunchScope scope(AF_FAM_GEMM, stream);
+  hipLaunchKernelGGL(af_gn_proj320_kernel, dim3(p.M / XA_BM), dim3(512), XT_LDS, (hipStream_t)stream, p);
+  return af_check_launch("af_gn_proj_fused");
 }

@@ -31,6 +31,7 @@ from .diffusionmodules.util import (Conv2d, GroupNorm32, LayerNorm, Linear, _Pac
 
 # LayerNorm -> Linear pairs of the inference pass run as ONE GEMM (ops.pack_matrix_ln); AF_FOLD_LAYERNORM=0 keeps the separate kernels (A/B runs)
 FOLD_LAYERNORM = _os.environ.get("AF_FOLD_LAYERNORM", "1") != "0"
+FUSE_GN_PROJ = _os.environ.get("AF_FUSE_GN_PROJ", "1") != "0"      # SpatialTransformer: GroupNorm's normalising pass + proj_in in one launch at C = 320 (af_gn_proj_fused)
 XATTN_FUSE_MIN_TOKENS = int(_os.environ.get("AF_XATTN_FUSE_MIN_TOKENS", "8192"))   # U-Net batch x tokens from which the one-launch block is used
 FUSE_XATTN = _os.environ.get("AF_FUSE_XATTN", "1") != "0"      # the C = 320 cross-attention block as ONE launch (af_xattn_fused): on par with the
                                                                 # three launches alone, -0.03 ms per denoise step (csrc/af_xattn_fused.hip); 0 = three launches
@@ -384,8 +385,11 @@ class SpatialTransformer(nn.Module):
         """x [B,H,W,C] fp16; context [B,L,Cc] fp16; mask [B,1,h0,w0] (nonzero = keep) or None."""
         B, H, W, Cn = x.shape
         N = H * W
-        y = self.norm.hip(x)
-        y = self.proj_in.hip(y).reshape(B * N, -1)
+        # norm + proj_in as ONE launch where the producer of x left its GroupNorm partials (C = 320: ops.gn_proj_fused); else two launches
+        y = ops.gn_proj_fused(x, self.norm.weight, self.norm.bias, self.norm.eps, self.proj_in.packed(), self.norm.num_groups) if FUSE_GN_PROJ else None
+        if y is None:
+            y = self.norm.hip(x)
+            y = self.proj_in.hip(y).reshape(B * N, -1)
         kb = None
         if mask is not None:
             kb = self._keybias(mask, B, H, W)

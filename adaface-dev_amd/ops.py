@@ -456,6 +456,24 @@ def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
     return y
 
 
+def gn_proj_fused(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, pw: PackedWeight, groups: int = 32) -> Optional[torch.Tensor]:
+    """GroupNorm(x) followed by a 1x1 convolution / Linear at C = 320 in ONE launch (af_gn_proj_fused): x [B, ..., 320] carrying the partial
+    statistics its producer left (x._gn_partials) -> [B * HW, N = 320] token-major.  Returns None when x does not qualify (no partials, another
+    width, ragged image size): the caller then runs the two launches."""
+    gn = getattr(x, "_gn_partials", None)
+    B, c = x.shape[0], x.shape[-1]
+    hw = x.numel() // (B * c)
+    if (gn is None or c != 320 or groups != 32 or pw.N != 320 or pw.K != 320 or pw.ln_cs is not None or hw % 128 != 0 or gn.B != B or gn.hw != hw or gn.C != c
+            or gn.cpg * groups != c or not x.is_contiguous()):
+        return None
+    _chk_f16(x, "gn_proj_fused.x")
+    out = torch.empty((B * hw, pw.N), dtype=F16, device=x.device)
+    rc = _lib.lib().af_gn_proj_fused(_p(x), _p(gn.ws), gn.nblk, _p(gamma), _p(beta), float(eps), _p(pw.wt), _p(pw.bias), pw.kpad, _p(out), B, hw, c, groups,
+                                     _zero_page(x.device).data_ptr(), _stream())
+    _lib.check(rc, "af_gn_proj_fused")
+    return out
+
+
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
     _chk_f16(x, "layernorm.x")
     Cn = x.shape[-1]

@@ -193,6 +193,13 @@ int af_xattn_fused(const void* x, const void* wq, const void* bq, const void* ln
  * out2, af_transpose_tokens) writes zeros into the pad.  Packed weights (wt) are different: the caller zero-pads them to [npad][kpad] when packing,
  * and the kernels rely on that.  tests/conftest.py runs every GPU test with NaN-filled torch.empty buffers to hold this.                        */
 
+/* GroupNorm(32) of a single-source tensor whose partial statistics already exist (af_gemm_desc.gn_partials) + the 1x1 convolution behind it at C = 320
+ * in ONE launch: out [B*HW][320] = GroupNorm(x) W^T + bias -- the SpatialTransformer's proj_in(norm(x)) (attention.py:283-291); the normalised
+ * tensor never exists in memory.  partials fp32 [B][128][32][2], nblk = HW / 128 valid blocks per batch item; w packed as for af_gemm
+ * ([>= 320][kpad]).  HW % 128 == 0.  AF_E_UNSUPPORTED for any other C / group count. */
+int af_gn_proj_fused(const void* x, const void* partials, int nblk, const void* gamma, const void* beta, float eps, const void* w, const void* bias,
+                     int kpad, void* out, int B, int HW, int C, int groups, const void* zeros, void* stream);
+
 /* ---- GroupNorm(32) [+ SiLU], NHWC -----------------------------------------------------
  * Replaces GroupNorm32 + nn.SiLU (util.py:195-212; openaimodel.py:202-233,686-690; eps 1e-5)
  * and Normalize (attention.py:70-71; eps 1e-6).  x = concat(x1[.., c1], x2[.., c2]) along

@@ -233,6 +233,33 @@ def test_groupnorm_statistics_from_the_producing_gemm(dev, kind, B, H, W, cin, c
         assert getattr(y8, "_gn_partials", None) is None and rel_l2(y8.float().cpu().numpy(), y.float().cpu().numpy()) < 2e-3
 
 
+@pytest.mark.parametrize("B,H,W,with_bias", [(2, 16, 16, True), (1, 64, 64, True), (3, 16, 8, False), (8, 32, 32, True)])
+def test_groupnorm_proj_fused_c320(dev, B, H, W, with_bias):
+    """af_gn_proj_fused: GroupNorm(32, eps 1e-6) of a tensor that carries its producer's partial statistics + the 1x1 convolution behind it
+    (SpatialTransformer norm -> proj_in, attention.py:283-291) in one launch, against torch in fp32 and against the two-launch form."""
+    from adaface_dev_amd import ops
+    C = 320
+    x0 = rnd((B, H, W, C), 1)
+    pwc = ops.pack_conv3x3(rnd((C, C, 3, 3), 2, (9 * C) ** -0.5), torch.randn(C, generator=torch.Generator().manual_seed(3)), dev)
+    x = ops.conv3x3(x0.to(dev), pwc, tile=7, gn_cpg=C // 32)                      # the producer leaves the partials
+    assert getattr(x, "_gn_partials", None) is not None
+    gam = torch.randn(C, generator=torch.Generator().manual_seed(4)) * 0.3 + 1
+    bet = torch.randn(C, generator=torch.Generator().manual_seed(5)) * 0.3
+    w = rnd((C, C), 6, C ** -0.5)
+    b = torch.randn(C, generator=torch.Generator().manual_seed(7)) if with_bias else None
+    pw = ops.pack_matrix(w, b, dev)
+    out = ops.gn_proj_fused(x, gam.to(dev), bet.to(dev), 1e-6, pw)
+    assert out is not None and out.shape == (B * H * W, C)
+    xn = F.group_norm(x.float().cpu().permute(0, 3, 1, 2), 32, gam, bet, 1e-6).permute(0, 2, 3, 1).reshape(B * H * W, C)
+    ref = xn @ w.float().t() + (b if b is not None else 0)
+    assert rel_l2(out.float().cpu().numpy(), ref.numpy()) < TOL
+    y = ops.groupnorm(x, gam.to(dev), bet.to(dev), 1e-6, False)
+    out2 = ops.gemm(y.reshape(B * H * W, C), pw)
+    assert rel_l2(out.float().cpu().numpy(), out2.float().cpu().numpy()) < 2e-3
+    # a tensor without partials (or another width) is not taken: the caller falls back
+    assert ops.gn_proj_fused(x.clone(), gam.to(dev), bet.to(dev), 1e-6, pw) is None
+
+
 def test_conv3x3_tile14_falls_back_outside_its_scope(dev):
     """stride 2 / two sources / widths it does not take: the descriptor's fallback (tile 1) computes the same convolution."""
     from adaface_dev_amd import ops
