@@ -527,7 +527,7 @@ extern "C" int af_gemm(const af_gemm_desc* d, void* stream) {
     AF_REQUIRE(d->c3 % 64 == 0 && d->c4 % 64 == 0, "af_gemm: c3 / c4 must be multiples of 64");
     AF_REQUIRE((d->lda3 == 0 || (d->lda3 >= d->c3 && d->lda3 % 8 == 0)) && (d->lda4 == 0 || (d->lda4 >= d->c4 && d->lda4 % 8 == 0)), "af_gemm: bad lda3 / lda4");
     AF_REQUIRE((d->stride == 0 || d->stride == 1) && d->upsample == 0 && d->tap_shift == 0, "af_gemm: the K tail needs stride 1, no upsample, no tap_shift");
-    AF_SUPPORTED(d->tile >= 7 && d->tile <= 13, "af_gemm: the K tail runs on the whole-line tiles 7 .. 13 only");
+    AF_SUPPORTED((d->tile >= 7 && d->tile <= 13) || d->tile == 15, "af_gemm: the K tail runs on the whole-line tiles 7 .. 13 and 15 only");
   }
   AF_REQUIRE(d->K == d->taps * (d->c1 + d->c2) + d->c3 + d->c4, "af_gemm: K != taps*(c1+c2) (+ c3 + c4)");
   const bool gnp = d->gn_partials != nullptr;
@@ -623,7 +623,7 @@ extern "C" int af_gemm(const af_gemm_desc* d, void* stream) {
     const long t128 = (long)((d->M + 127) / 128) * ((d->N + 127) / 128);
     tile = (t128 >= 192 && d->N >= 96) ? 1 : 2;
   }
-  AF_REQUIRE(tile >= 1 && tile <= 14, "af_gemm: tile must be 0 .. 14");
+  AF_REQUIRE(tile >= 1 && tile <= 15, "af_gemm: tile must be 0 .. 15");
 
   AfLaunchScope scope(AF_FAM_GEMM, stream);
   hipStream_t s = (hipStream_t)stream;

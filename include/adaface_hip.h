@@ -126,6 +126,8 @@ typedef struct af_gemm_desc {
                            channels the rows' (R+2) x (W+2) halo is loaded into LDS once and the nine taps read it at shifted addresses
                            (stride 1, pad 1, c2 == 0, c1 % 64 == 0, N % 160 == 0, W in {16, 32, 64}, H % (256 / W) == 0; split-K over
                            64-channel chunks).  Outside that scope it falls back to tile 1 */
+                        /* 15 = whole-line kernel, 256 x 128 tile of eight waves (4 x 2; N % 128 == 0; standard epilogue, taps 1 / 9, nearest x2): 85 instead of
+                           64 FLOP per operand byte for narrow outputs over many rows (the VAE decoder's 128- / 256-channel convolutions at 256^2 / 512^2) */
   int32_t splits;       /* split-K factor (<=1: none).  >1 needs the standard epilogue and a workspace:
                            each split writes an fp32 partial [M][N], a second launch reduces + applies the epilogue */
   void* workspace;      /* fp32, >= splits*M*N*4 bytes when splits > 1 */

@@ -260,6 +260,32 @@ def test_groupnorm_proj_fused_c320(dev, B, H, W, with_bias):
     assert ops.gn_proj_fused(x.clone(), gam.to(dev), bet.to(dev), 1e-6, pw) is None
 
 
+@pytest.mark.parametrize("B,H,W,c1,c2,cout,ups,splits", [(1, 64, 64, 128, 0, 128, False, 1), (2, 32, 32, 256, 0, 256, False, 2), (1, 32, 32, 128, 0, 128, True, 1),
+                                                         (1, 24, 40, 64, 64, 128, False, 1), (2, 16, 16, 512, 0, 384, False, 3)])
+def test_conv3x3_and_gemm_tile15_256x128(dev, B, H, W, c1, c2, cout, ups, splits):
+    """Tile 15 of the whole-line kernel (256 x 128, eight waves as 4 x 2: narrow outputs over many rows, the VAE decoder's convolutions): 3x3 with
+    bias / row bias / residual, two sources, nearest-x2 upsampling folded into the gather, split-K, M not a multiple of 256; and a plain GEMM."""
+    from adaface_dev_amd import ops
+    cin = c1 + c2
+    x1 = rnd((B, H, W, c1), 1)
+    x2 = rnd((B, H, W, c2), 2) if c2 else None
+    w = rnd((cout, cin, 3, 3), 3, (9 * cin) ** -0.5)
+    bias, rowb = torch.randn(cout, generator=torch.Generator().manual_seed(4)), rnd((B, cout), 5)
+    xin = (x1 if x2 is None else torch.cat([x1, x2], -1)).float().permute(0, 3, 1, 2)
+    if ups:
+        xin = F.interpolate(xin, scale_factor=2, mode="nearest")
+    ref = F.conv2d(xin, w.float(), bias, padding=1) + rowb.float()[:, :, None, None]
+    res = rnd(tuple(ref.permute(0, 2, 3, 1).shape), 6)
+    ref = ref + res.float().permute(0, 3, 1, 2)
+    out = ops.conv3x3(x1.to(dev), ops.pack_conv3x3(w, bias, dev), x2=None if x2 is None else x2.to(dev), upsample=ups, rowbias=rowb.to(dev),
+                      residual=res.to(dev), tile=15, splits=splits)
+    assert rel_l2(out.float().cpu().permute(0, 3, 1, 2).numpy(), ref.numpy()) < TOL
+    M, K = B * H * W + 24, cin
+    a, wm = rnd((M, K), 7), rnd((cout, K), 8, K ** -0.5)
+    og = ops.gemm(a.to(dev), ops.pack_matrix(wm, bias, dev), act=ops.AF_ACT_SILU, tile=15)
+    assert rel_l2(og.float().cpu().numpy(), F.silu(a.float() @ wm.float().t() + bias).numpy()) < TOL
+
+
 def test_conv3x3_tile14_falls_back_outside_its_scope(dev):
     """stride 2 / two sources / widths it does not take: the descriptor's fallback (tile 1) computes the same convolution."""
     from adaface_dev_amd import ops

@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--retune", action="store_true", help="re-time every shape this run meets; entries of shapes it does not meet are kept")
     ap.add_argument("--tiles", default="", help="comma-separated tile ids to time (default: all)")
     ap.add_argument("--trace", action="store_true", help="print every configuration before it is launched (to find one that faults)")
+    ap.add_argument("--try-tile", type=int, default=0, help="for every shape this run meets that is ALREADY in the table: time the table's choice against this tile (splits 1, 2) and take the tile only where it is > 2 %% faster")
     ap.add_argument("--retune-halo", action="store_true", help="re-time only the 3x3 shapes in the scope of the halo-resident kernel (tile 14)")
     args = ap.parse_args()
     from adaface_dev_amd import SD15_UNET_CONFIG, _lib, ops, rng
@@ -97,22 +98,46 @@ def main():
     retuned = set()
 
     def recorder(key, d, device):
+        if args.try_tile and key in table and key not in retuned:
+            retuned.add(key)
+            tl = args.try_tile
+            ok = not (tl == 15 and (d.act == _lib.AF_ACT_GEGLU or d.out_mode != 0 or d.N % 128 != 0 or d.M < 16384 or d.c1 % 64 or d.c2 % 64 or d.upsample not in (0, 1)))
+            if ok:
+                cur = table[key]
+                t_cur = timed(d, device, cur[0], cur[1])
+                res = {f"{cur[0]}x{cur[1]}": None if t_cur is None else round(t_cur * 1e3, 1)}
+                best, best_t = cur, t_cur
+                for sp in (1, 2):
+                    if sp > 1 and d.kpad // 64 < 8:
+                        continue
+                    t = timed(d, device, tl, sp)
+                    if t is None:
+                        continue
+                    res[f"{tl}x{sp}"] = round(t * 1e3, 1)
+                    if best_t is None or t < 0.98 * best_t:
+                        best, best_t = (tl, sp), t
+                if best != cur:
+                    table[key] = best
+                log.append((key, best, None if best_t is None else round(best_t * 1e3, 1), 0.0, res))
+            return table[key]
         again = args.retune or (args.retune_halo and ops.conv_halo_eligible(d))
         if key in table and (not again or key in retuned):
             return table[key]
         retuned.add(key)
         nk = d.kpad // 64
         best, best_t, res = (0, 1), None, {}
-        for tile in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14):
+        for tile in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15):
             geglu = d.act == _lib.AF_ACT_GEGLU
             if args.tiles and str(tile) not in args.tiles.split(","):
                 continue
             if tile == 14 and not ops.conv_halo_eligible(d):
                 continue                        # halo-resident 3x3 kernel: its split-K slices are 64-channel chunks
-            if tile >= 7 and (d.upsample not in (0, 1) or (d.upsample and tile not in (7, 8, 11, 12, 13)) or d.c1 % 64 or d.c2 % 64):
+            if tile >= 7 and (d.upsample not in (0, 1) or (d.upsample and tile not in (7, 8, 11, 12, 13, 15)) or d.c1 % 64 or d.c2 % 64):
                 continue                        # whole-line kernel: 64-multiples of channels; nearest-x2 upsample in the non-GEGLU tiles
             if tile in (11, 13) and (geglu or d.out_mode == _lib.AF_OUT_SPLIT_T or d.N % 160 != 0):
                 continue                        # 128 x 160, four waves (11: two workgroups per CU; 13: four-slot ring)
+            if tile == 15 and (geglu or d.out_mode == _lib.AF_OUT_SPLIT_T or d.N % 128 != 0 or d.M < 32768):
+                continue                        # 256 x 128, eight waves: narrow outputs over many rows
             if tile == 12 and (geglu or d.out_mode == _lib.AF_OUT_SPLIT_T):
                 continue                        # 128 x 128 with a four-slot ring
             if tile == 7 and (d.N % (256 if geglu else 320) != 0):
