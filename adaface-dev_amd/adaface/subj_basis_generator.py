@@ -17,10 +17,19 @@ CLIP_BOS, CLIP_EOS = 49406, 49407
 CLIP_IDS = {"photo": 1125, "of": 539, "a": 320, ",": 267, "id": 1014, "person": 2533}
 
 
+_TEMPLATE_IDS = {}
+
+
 def template_ids(words, max_length, device=None):
-    ids = [CLIP_BOS] + [CLIP_IDS[w] for w in words] + [CLIP_EOS]
-    ids = ids[:max_length] + [CLIP_EOS] * (max_length - len(ids))          # pad token of the CLIP tokenizer is EOS
-    return torch.tensor([ids], dtype=torch.long, device=device)
+    """Token ids [1, max_length] of a template prompt.  Kept per (words, length, device): a training iteration asks for the same few
+    templates every time, and making a device tensor from a Python list is a blocking copy."""
+    key = (tuple(words), max_length, str(device))
+    t = _TEMPLATE_IDS.get(key)
+    if t is None:
+        ids = [CLIP_BOS] + [CLIP_IDS[w] for w in words] + [CLIP_EOS]
+        ids = ids[:max_length] + [CLIP_EOS] * (max_length - len(ids))          # pad token of the CLIP tokenizer is EOS
+        t = _TEMPLATE_IDS[key] = torch.tensor([ids], dtype=torch.long, device=device)
+    return t.clone()
 
 
 class ScaleGrad(torch.autograd.Function):

@@ -60,8 +60,31 @@ def masked_l2_loss(predictions, targets, mask):
 
 
 def split_indices_by_instance(indices):
+    """(b, n) -> [(b of instance u, n of instance u) for the instances u present].  ``torch.unique`` and the boolean selections each make
+    the host wait for the device; the same index pair comes back many times per iteration (every layer of every step), so the split is
+    kept on the tensor OBJECT it was made from (index tensors are never written in place)."""
     b, n = indices
-    return [(b[b == u], n[b == u]) for u in torch.unique(b)]
+    memo = getattr(b, "af_split", None)
+    if memo is not None and memo[0] is n:
+        return memo[1]
+    out = [(b[b == u], n[b == u]) for u in torch.unique(b)]
+    try:
+        b.af_split = (n, out)
+    except AttributeError:
+        pass
+    return out
+
+
+def count_instances(b):
+    """len(torch.unique(b)), remembered on the tensor object like ``split_indices_by_instance``."""
+    k = getattr(b, "af_n_unique", None)
+    if k is None:
+        k = len(torch.unique(b))
+        try:
+            b.af_n_unique = k
+        except AttributeError:
+            pass
+    return k
 
 
 def extend_indices_B_by_n_times(indices, n, block_offset):
@@ -140,7 +163,7 @@ def calc_attn_norm_loss(ca_outfeats, ca_attns, subj_indices_2b, BLOCK_SIZE):
     """L1 between the mean |attention| the subject tokens receive in the subject instances and in the (detached) class instances,
     for the single and the compositional prompt, per head."""
     weights = normalize_dict_values(dict(DISTILL_LAYERS))
-    k_subj = len(subj_indices_2b[0]) // len(torch.unique(subj_indices_2b[0]))
+    k_subj = len(subj_indices_2b[0]) // count_instances(subj_indices_2b[0])
     idx4 = extend_indices_B_by_n_times(subj_indices_2b, 2, BLOCK_SIZE * 2)
     terms = []
     for li in ca_outfeats:
@@ -158,10 +181,14 @@ def calc_subj_masked_bg_suppress_loss(ca_attn, subj_indices, BLOCK_SIZE, fg_mask
     """Attention of the subject tokens that lands on BACKGROUND pixels of the first block, above a tolerance of 0.02, averaged over the
     offending (head, pixel) entries."""
     device = next(iter(ca_attn.values())).device
-    if subj_indices is None or len(subj_indices) == 0 or fg_mask is None or fg_mask.chunk(4)[0].float().mean() >= 0.998:
-        return torch.tensor(0.0, device=device)
+    # a mask made from host boxes (ddpm_losses.box_mask) carries its host copy: the three decisions on the mask below are then taken on
+    # that copy (same arithmetic on 0 / 1 values) instead of reading the device
+    fg_host = getattr(fg_mask, "af_host", None) if fg_mask is not None else None
+    decide_on = fg_host if fg_host is not None else fg_mask
+    if subj_indices is None or len(subj_indices) == 0 or fg_mask is None or decide_on.chunk(4)[0].float().mean() >= 0.998:
+        return torch.zeros((), device=device)
     weights = normalize_dict_values(dict(DISTILL_LAYERS))
-    k_subj = len(subj_indices[0]) // len(torch.unique(subj_indices[0]))
+    k_subj = len(subj_indices[0]) // count_instances(subj_indices[0])
     idx = (subj_indices[0][:BLOCK_SIZE * k_subj], subj_indices[1][:BLOCK_SIZE * k_subj])
     tol = 0.02
     terms = []
@@ -172,11 +199,16 @@ def calc_subj_masked_bg_suppress_loss(ca_attn, subj_indices, BLOCK_SIZE, fg_mask
         m = resize_mask_to_target_size(fg_mask, subj.shape[-1]).reshape(BLOCK_SIZE, 1, -1).repeat(1, subj.shape[1], 1)
         fg = (m > 1e-6).to(m.dtype)
         bg = 1 - fg
-        if (fg.sum(dim=(1, 2)) == 0).any() or (bg.sum(dim=(1, 2)) == 0).any():
+        if fg_host is not None:
+            fg_d = (resize_mask_to_target_size(fg_host, subj.shape[-1]).reshape(BLOCK_SIZE, 1, -1) > 1e-6).float()
+            empty = bool((fg_d.sum(dim=(1, 2)) == 0).any() or ((1 - fg_d).sum(dim=(1, 2)) == 0).any())
+        else:
+            empty = bool((fg.sum(dim=(1, 2)) == 0).any() or (bg.sum(dim=(1, 2)) == 0).any())
+        if empty:
             continue
         excess = subj * bg - tol
         terms.append(masked_mean(excess, excess > 0) * weights[li])
-    return sum(terms) if terms else torch.tensor(0.0, device=device)
+    return sum(terms) if terms else torch.zeros((), device=device)
 
 
 def comp_rep_distill_total(losses, sc_fg_mask_percent, rep_dist_fg_bounds=(0.1, 0.20, 0.25)):
@@ -361,7 +393,7 @@ def calc_comp_subj_bg_preserve_loss(mon_loss_dict, session_prefix, device, flow_
     distillation terms are monitored at weight 0 (:2032-2043).  Adds its monitors to ``mon_loss_dict`` under ``session_prefix/``."""
     outfeats, attn_outs, qs = ca_layers_activations["outfeat"], ca_layers_activations["attn_out"], ca_layers_activations["q2"]
     layer_w = normalize_dict_values({22: 1, 23: 1, 24: 1})
-    opt = {k: torch.tensor(0.0, device=device) for k in ("loss_sc_recon_ssfg_min", "loss_sc_recon_mc_min",
+    opt = {k: torch.zeros((), device=device) for k in ("loss_sc_recon_ssfg_min", "loss_sc_recon_mc_min",
                                                          "loss_sc_to_ssfg_sparse_attns_distill", "loss_sc_to_mc_sparse_attns_distill")}
     for li, outfeat in outfeats.items():
         if li not in layer_w:
@@ -398,7 +430,7 @@ def calc_recon_and_suppress_losses(noise_gt, noise_pred, noise_pred_cls, face_de
         loss_recon, _ = calc_recon_loss(F.mse_loss, noise_pred, noise_gt, img_mask, fg_mask, face_detected_inst_weights,
                                         fg_pixel_weight=1, bg_pixel_weight=bg_pixel_weight)
     else:
-        loss_recon = torch.tensor(0.0, device=dev)
+        loss_recon = torch.zeros((), device=dev)
     if noise_pred_cls is not None:
         bg_mask = 1 - fg_mask
         if bg_mask.sum() == 0:
@@ -408,5 +440,5 @@ def calc_recon_and_suppress_losses(noise_gt, noise_pred, noise_pred_cls, face_de
         loss_recon_cls, _ = calc_recon_loss(F.mse_loss, noise_pred, noise_pred_cls, img_mask, bg_mask, face_detected_inst_weights,
                                             fg_pixel_weight=1, bg_pixel_weight=bg_pixel_weight)
     else:
-        loss_recon_cls = torch.tensor(0.0, device=dev)
+        loss_recon_cls = torch.zeros((), device=dev)
     return loss_recon, loss_recon_cls, calc_subj_masked_bg_suppress_loss(ca_layers_activations["attn"], all_subj_indices, BLOCK_SIZE, fg_mask)

@@ -527,9 +527,16 @@ class LatentDiffusion(CompReconLossesMixin, nn.Module):
                            ffn_lora_adapter_name=None):
         """apply_model on the instances ``slice_indices`` of the batch, with or without gradient (reference ddpm.py:1572-1587)."""
         prompt_emb, prompt_in, extra_info = cond_context
-        ctx = (prompt_emb[slice_indices], [prompt_in[i] for i in slice_indices], extra_info)
+        # an index LIST becomes a device index tensor through a blocking host-to-device copy (the host then waits for everything it has
+        # queued, three times per call); the lists used here are arithmetic progressions, which a slice takes without any copy
+        idx = slice_indices
+        if len(idx) == 1:
+            idx = slice(idx[0], idx[0] + 1)
+        elif len(idx) > 1 and len({b - a for a, b in zip(idx, idx[1:])}) == 1 and idx[1] > idx[0]:
+            idx = slice(idx[0], idx[-1] + 1, idx[1] - idx[0])
+        ctx = (prompt_emb[idx], [prompt_in[i] for i in slice_indices], extra_info)
         with torch.set_grad_enabled(enable_grad):
-            return self.apply_model(x_noisy[slice_indices], t[slice_indices], ctx, use_attn_lora=use_attn_lora, use_ffn_lora=use_ffn_lora,
+            return self.apply_model(x_noisy[idx], t[idx], ctx, use_attn_lora=use_attn_lora, use_ffn_lora=use_ffn_lora,
                                     ffn_lora_adapter_name=ffn_lora_adapter_name)
 
     def prepare_unet_teacher_context(self, subj_context, uncond_context, BLOCK_SIZE, id2img_prompt_embs, id2img_neg_prompt_embs,

@@ -52,6 +52,41 @@ class RollingStats:
         return self.means if self.stat_type == "mean" else self.sums
 
 
+def box_mask(boxes, B, H, W, device, dtype=torch.float32):
+    """[B, 1, H, W] with ones inside the (x1, y1, x2, y2) boxes.  The boxes are host data (FaceCropper): the mask is filled on the host
+    and copied over without waiting for the device; the host copy rides along as ``.af_host`` for the decisions taken on it."""
+    from ...modules.arcface_wrapper import to_device_async
+    m = torch.zeros(B, 1, H, W, dtype=dtype)
+    for i in range(len(boxes)):
+        x1, y1, x2, y2 = (int(v) for v in boxes[i])
+        m[i, :, y1:y2, x1:x2] = 1
+    d = to_device_async(m, device)
+    d.af_host = m
+    return d
+
+
+def host_of(mask):
+    """The host copy of a ``box_mask`` (the mask itself when it has none)."""
+    return getattr(mask, "af_host", mask)
+
+
+def resolve_monitors(mon_loss_dict, extra=()):
+    """The loss assemblies leave 0-dim DEVICE tensors in ``mon_loss_dict`` while they run; this turns them all into Python floats with
+    ONE device read (the reference reads each with ``.item()`` where it is produced: ~20 waits per call).  ``extra``: more tensors to
+    read in the same go -> their values."""
+    for k, v in mon_loss_dict.items():
+        if torch.is_tensor(v) and not v.is_cuda:
+            mon_loss_dict[k] = v.detach().float().mean().item()                            # host tensors: nothing to wait for
+    keys = [k for k, v in mon_loss_dict.items() if torch.is_tensor(v)]
+    ts = [mon_loss_dict[k].detach().float().mean() for k in keys] + [t.detach().float().mean() for t in extra]
+    if not ts:
+        return []
+    vals = torch.stack(ts).tolist()
+    for k, v in zip(keys, vals):
+        mon_loss_dict[k] = v
+    return vals[len(keys):]
+
+
 def chunk_list(lst, num_chunks):
     n = int(np.ceil(len(lst) / num_chunks))
     return [lst[i:i + n] for i in range(0, len(lst), n)]
@@ -116,11 +151,20 @@ class CompReconLossesMixin:
         return self.first_stage_model.decode(z / self.scale_factor)
 
     # ------------------------------------------------------------------ face alignment (ddpm.py:2511-2534)
-    def calc_arcface_align_loss(self, x_start, x_recon, fg_faces_grad_mask_ratios=(1, 0.3)):
-        x_start_pixels = self.decode_first_stage(x_start)
+    def calc_arcface_align_loss(self, x_start, x_recon, fg_faces_grad_mask_ratios=(1, 0.3), ref_cache=None):
+        """``ref_cache``: a dict the caller keeps while it aligns several x0 predictions to the SAME ``x_start`` (the compositional
+        iteration does, once per denoising step, ddpm.py:3241-3247): the decoded reference and its face embedding -- deterministic
+        functions of ``x_start`` -- are then computed once instead of once per call."""
+        if ref_cache is not None and ref_cache.get("x_start") is x_start:
+            x_start_pixels, ref = ref_cache["pixels"], ref_cache["ref"]
+        else:
+            x_start_pixels = self.decode_first_stage(x_start)
+            ref = self.arcface.embed_reference(x_start_pixels)
+            if ref_cache is not None:
+                ref_cache.update(x_start=x_start, pixels=x_start_pixels, ref=ref)
         subj_recon_pixels = self.decode_first_stage_with_grad(x_recon)
         l_align, l_fg, l_bg, boxes, conf, found = self.arcface.calc_arcface_align_loss(x_start_pixels, subj_recon_pixels,
-                                                                                       fg_faces_grad_mask_ratios=fg_faces_grad_mask_ratios)
+                                                                                       fg_faces_grad_mask_ratios=fg_faces_grad_mask_ratios, ref=ref)
         boxes = CL.map_bboxes_coords(boxes, x_start_pixels.shape[-1], x_start.shape[-1])
         return l_align.to(x_start.dtype), l_fg, l_bg.to(x_start.dtype), boxes, conf, found
 
@@ -131,18 +175,24 @@ class CompReconLossesMixin:
         (at most three steps are optimised; a step above the threshold only feeds the statistics), the SC face mask from the first
         step that shows a face, and from then on the subject-attention background suppression of every earlier step."""
         dev, dt = x_start0_ss.device, x_start0_ss.dtype
-        zero = lambda: torch.tensor(0.0, device=dev, dtype=dt)
+        zero = lambda: torch.zeros((), device=dev, dtype=dt)
         l_mb, l_align, l_align_stat, l_fg, l_bg = zero(), zero(), zero(), zero(), zero()
         n_align = n_stat = n_mb = n_fg = n_bg = 0
         sc_fg_mask = sc_boxes = None
         first_step = -1
+        ref_cache = {}
         if self.arcface_align_loss_weight > 0:
             for step in range(len(x_recons) - 1, -1, -1):
                 sc_recon = x_recons[step].chunk(4)[1]
                 if n_align < 3:
-                    la, lf, lb, boxes, _, _ = self.calc_arcface_align_loss(x_start0_ss, sc_recon, fg_faces_grad_mask_ratios)
-                    if la > 0:
-                        keep = comp_sc_face_align_loss_thres <= 0 or la <= comp_sc_face_align_loss_thres
+                    la, lf, lb, boxes, _, _ = self.calc_arcface_align_loss(x_start0_ss, sc_recon, fg_faces_grad_mask_ratios, ref_cache=ref_cache)
+                    # the branches below are on the VALUES of the three losses: ONE read of all three (one wait for the device) instead of
+                    # one per comparison; without a face they are exact zeros and nothing needs reading
+                    la_v = lf_v = lb_v = 0.0
+                    if boxes is not None:
+                        la_v, lf_v, lb_v = torch.stack([la.detach().float(), lf.detach().float(), lb.detach().float()]).tolist()
+                    if la_v > 0:
+                        keep = comp_sc_face_align_loss_thres <= 0 or la_v <= float(np.float32(comp_sc_face_align_loss_thres))
                         if keep:
                             l_align = l_align + la
                             n_align += 1
@@ -153,14 +203,11 @@ class CompReconLossesMixin:
                             first_step = step
                         if sc_fg_mask is None:
                             sc_boxes = boxes
-                            sc_fg_mask = torch.zeros_like(sc_recon[:, :1])
-                            for i in range(len(sc_boxes)):
-                                x1, y1, x2, y2 = sc_boxes[i]
-                                sc_fg_mask[i, :, y1:y2, x1:x2] = 1
-                        if lf > 0:
+                            sc_fg_mask = box_mask(sc_boxes, sc_recon.shape[0], sc_recon.shape[2], sc_recon.shape[3], dev, sc_recon.dtype)
+                        if lf_v > 0:
                             l_fg = l_fg + lf
                             n_fg += 1
-                        if lb > 0:
+                        if lb_v > 0:
                             l_bg = l_bg + lb
                             n_bg += 1
                 if sc_fg_mask is not None:
@@ -171,7 +218,8 @@ class CompReconLossesMixin:
                                  ("comp_sc_subj_mb_suppress", l_mb, n_mb), ("comp_fg_faces_suppress", l_fg, n_fg),
                                  ("comp_bg_faces_suppress", l_bg, n_bg)):
                 if n > 0:
-                    mon_loss_dict[f"{session_prefix}/{name}"] = (tot / n).mean().detach().item()
+                    mon_loss_dict[f"{session_prefix}/{name}"] = (tot / n).mean().detach()
+            self._host_pos = {"l_align": n_align > 0, "l_fg": n_fg > 0, "l_bg": n_bg > 0}     # sums of positive terms: their signs, known without a read
             l_align = l_align / n_align if n_align else l_align
             l_mb = l_mb / n_mb if n_mb else l_mb
             l_fg = l_fg / n_fg if n_fg else l_fg
@@ -213,8 +261,9 @@ class CompReconLossesMixin:
             lap2 = [v.mean() for v in CL.var_of_laplacian(crops2).chunk(S, dim=0)]
             conf_steps = [c.mean() for c in conf2.chunk(S, dim=0)]
             boxes2_steps = chunk_list(CL.map_bboxes_coords(boxes2, pixels.shape[-1], latent_w), S)
+            sharp = (torch.stack(lap2) >= torch.stack(lap1) * lap_vars_tolerance).tolist()          # one device read for all steps
             for step in range(S):
-                good = bool(conf_steps[step] >= comp_ss_face_confidence_thres) and bool(lap2[step] >= lap1[step] * lap_vars_tolerance)
+                good = bool(conf_steps[step] >= comp_ss_face_confidence_thres) and sharp[step]         # the confidences are host data
                 if good:
                     replaced += 1
                     _, ca_sc, ca_sr, ca_mc = split_dict(ca_layers_activations_list[step], 4)
@@ -229,16 +278,18 @@ class CompReconLossesMixin:
         dev, dt = x_start0_ss.device, x_start0_ss.dtype
         latent_shape, S = x_start0_ss.shape, len(x_recons)
         P = session_prefix
-        zero = lambda: torch.tensor(0.0, device=dev, dtype=dt)
+        zero = lambda: torch.zeros((), device=dev, dtype=dt)
         loss = zero()
         l_fg_suppress, l_align = zero(), zero()
         sc_fg_mask = mc_fg_mask = ss_boxes = sc_boxes = ss_crops_collate = None
         all_ss_contain_faces, first_step = False, -1
+        pos = {"l_align": False, "l_fg": False, "l_bg": False}       # signs of the face losses, known on the host
         rep_dist_fg_bounds = (0.1, 0.20, 0.25)
 
         if self.arcface_align_loss_weight > 0:
             # faces of the subject-single instances of every step (the last step decides), then of the class-comp instance
-            ss_pixels = torch.cat([x_recons_pixel_allsteps[i].chunk(4)[0] for i in range(len(x_recons_pixel_allsteps))], dim=0)
+            # (x_recons_pixel_allsteps[i] holds the decoded blocks of step i, subject-single first: all four, or that block alone)
+            ss_pixels = torch.cat([x_recons_pixel_allsteps[i][:BLOCK_SIZE] for i in range(len(x_recons_pixel_allsteps))], dim=0)
             ss_crops_collate, _, boxes_c, conf_c, found_c = self.arcface.retinaface.crop_faces(ss_pixels, out_size=(128, 128), T=20)
             ss_boxes, ss_conf, ss_found = boxes_c.chunk(S)[-1], conf_c.chunk(S)[-1], found_c.chunk(S)[-1]
             if (1 - ss_found).sum() == 0 and ss_conf.min() >= self.comp_ss_face_confidence_thres:
@@ -250,27 +301,25 @@ class CompReconLossesMixin:
                         fg_faces_grad_mask_ratios=(0.9, sc_fg_face_suppress_mask_shrink_ratio), BLOCK_SIZE=BLOCK_SIZE,
                         comp_sc_face_align_loss_kept_frac=self.comp_sc_face_align_loss_kept_frac,
                         comp_sc_face_align_loss_thres=self.comp_sc_face_align_loss_thres)
+                pos = self._host_pos
                 loss = loss + l_bg_suppress * 400 * self.arcface_align_loss_weight + l_mb * self.comp_sc_subj_mb_suppress_loss_weight
-                if l_bg_suppress > 0:
+                if pos["l_bg"]:
                     self.comp_iters_bg_has_face_count += 1
                     mon_loss_dict[f"{P}/comp_iters_bg_has_face_frac"] = self.comp_iters_bg_has_face_count / self.comp_iters_count
             mc_pixels = self.decode_first_stage(x_recons[-1].chunk(4)[3])
             _, _, mc_boxes, _, mc_found = self.arcface.retinaface.crop_faces(mc_pixels, out_size=(128, 128), T=20)
             if (1 - mc_found).sum() == 0:
                 mc_boxes = CL.map_bboxes_coords(mc_boxes, mc_pixels.shape[-1], latent_shape[-1])
-                mc_fg_mask = torch.zeros(BLOCK_SIZE, 1, latent_shape[-2], latent_shape[-1], device=dev)
-                for i in range(len(mc_boxes)):
-                    x1, y1, x2, y2 = mc_boxes[i]
-                    mc_fg_mask[i, :, y1:y2, x1:x2] = 1
+                mc_fg_mask = box_mask(mc_boxes, BLOCK_SIZE, latent_shape[-2], latent_shape[-1], dev)
 
         for name in COMP_MONITOR_NAMES:
             mon_loss_dict[f"{P}/{name}"] = 0
         sc_pct = mc_pct = 0
         if sc_fg_mask is not None:
-            sc_pct = sc_fg_mask.float().mean().item()
+            sc_pct = host_of(sc_fg_mask).float().mean().item()
             mon_loss_dict[f"{P}/sc_fg_mask_percent"] = sc_pct
         if mc_fg_mask is not None:
-            mc_pct = mc_fg_mask.float().mean().item()
+            mc_pct = host_of(mc_fg_mask).float().mean().item()
             mon_loss_dict[f"{P}/mc_fg_mask_percent"] = mc_pct
         mon_loss_dict[f"{P}/comp_mc_face_detected_frac"] = self.comp_mc_face_detected_frac.update(1 if mc_fg_mask is not None else 0)
         mon_loss_dict[f"{P}/comp_sc_face_align_loss_kept_frac"] = self.comp_sc_face_align_loss_kept_frac.mean
@@ -280,7 +329,7 @@ class CompReconLossesMixin:
             kind = "sc-noface"
         elif mc_pct == 0 and sc_pct >= 0.16 * hi:
             kind = "mc-no-sc-large"
-        elif mc_pct > 0 and ((sc_fg_mask * mc_fg_mask).sum() / sc_fg_mask.sum()) < 0.16:
+        elif mc_pct > 0 and ((host_of(sc_fg_mask) * host_of(mc_fg_mask)).sum() / host_of(sc_fg_mask).sum()) < 0.16:
             kind = "little-no-overlap"
         elif sc_pct <= lo:
             kind = "too-small"
@@ -290,7 +339,7 @@ class CompReconLossesMixin:
             kind = "good"
         self.sc_face_proportion_type = kind
 
-        if l_align > 0:
+        if pos["l_align"]:                                         # l_align > 0, known from the values read step by step
             frac = self.comp_sc_face_detected_frac.update(1)
             scale = (3 if kind in ("too-small", "good") else 1.5) * min(4, 1 / (frac ** 2 + 0.01))
             l_align_scaled = l_align * scale
@@ -313,19 +362,25 @@ class CompReconLossesMixin:
         suppress = kind in ("mc-no-sc-large", "little-no-overlap", "too-large")
         if suppress:
             scale = {"mc-no-sc-large": 5, "little-no-overlap": 10, "too-large": 10}[kind]
-            if l_align_scaled > 0 and l_fg_suppress > 0:
+            if pos["l_align"] and pos["l_fg"]:                     # l_align_scaled > 0 and l_fg_suppress > 0
                 ratio = l_align_scaled.detach() / l_fg_suppress.detach()
                 mon_loss_dict[f"{P}/align_suppress_loss_ratio"] = ratio
-                scale = CL.clamp(ratio * 0.1, scale / 2, scale)
+                scale = torch.clamp(ratio * 0.1, scale / 2, scale)              # CL.clamp's value, without reading ratio
             loss = loss + l_fg_suppress * scale * self.arcface_align_loss_weight
         mon_loss_dict[f"{P}/comp_sc_face_suppressed_frac"] = self.comp_sc_face_suppressed_frac.update(1 if suppress else 0)
         bg_match_shrink = sc_fg_face_suppress_mask_shrink_ratio if suppress else 1
 
         reps, preserve, cross_t, pred_l2s = [], [], [], []
+        rep_steps = [CL.calc_sc_rep_attn_distill_loss(acts, all_subj_indices_1b, prompt_emb_mask_4b, prompt_pad_mask_4b, sc_pct, FG_THRES=rep_dist_fg_bounds[0])
+                     for acts in ca_layers_activations_list]
+        live = [i for i, ls in enumerate(rep_steps) if torch.is_tensor(ls[0])]                  # (a skipped step returns plain zeros)
+        rep_is_zero = [True] * len(rep_steps)
+        if live:
+            for i, z in zip(live, (torch.stack([rep_steps[i][0].detach() for i in live]) == 0).tolist()):      # one read for all steps
+                rep_is_zero[i] = z
         for step, acts in enumerate(ca_layers_activations_list):
             pred_l2s.append((noise_preds[step] ** 2).mean())
-            ls = CL.calc_sc_rep_attn_distill_loss(acts, all_subj_indices_1b, prompt_emb_mask_4b, prompt_pad_mask_4b, sc_pct, FG_THRES=rep_dist_fg_bounds[0])
-            reps.append([zero() for _ in range(5)] if ls[0] == 0 else list(ls))
+            reps.append([zero() for _ in range(5)] if rep_is_zero[step] else list(rep_steps[step]))
             if not all_ss_contain_faces or first_step == -1:
                 continue
             if step < len(ca_layers_activations_list) - 1 and step >= first_step - 1:
@@ -337,6 +392,24 @@ class CompReconLossesMixin:
                 recon_scaled_loss_threses={"mc": 0.4, "ssfg": 0.4}, recon_max_scale_of_threses=5, do_sc_fg_faces_suppress=suppress))
 
         n_preserve = len(preserve) + 1e-6
+        rep = [torch.stack([r[i] for r in reps]).mean() for i in range(5)]
+        if preserve:
+            l_preserve = torch.stack(preserve).mean()
+            mon_loss_dict[f"{P}/comp_fg_bg_preserve"] = l_preserve.mean().detach()
+            loss = loss + l_preserve
+        if cross_t:
+            mon_loss_dict[f"{P}/subj_attn_cross_t_diff"] = torch.stack(cross_t).mean().detach()       # monitored, weight 0
+        if not all(rep_is_zero):                                  # rep[0] > 0: the mean of the steps' attention terms, each >= 0
+            for name, v in zip(("subj_attn", "subj_k", "nonsubj_k", "subj_v", "nonsubj_v"), rep):
+                mon_loss_dict[f"{P}/comp_rep_distill_{name}"] = v.detach()
+            l_rep = CL.comp_rep_distill_total(rep, sc_pct, rep_dist_fg_bounds)
+            mon_loss_dict[f"{P}/comp_rep_distill_total"] = l_rep.mean().detach()
+            loss = loss + l_rep
+        mon_loss_dict[f"{P}/pred_l2"] = torch.stack(pred_l2s).mean().detach()
+        # every monitor left as a device tensor above, and the total, read in ONE go
+        (v,) = resolve_monitors(mon_loss_dict, extra=[loss])
+        if v > 0:
+            mon_loss_dict[f"{P}/comp_feat_distill_total"] = v
         for name in COMP_MONITOR_NAMES:                           # per-step sums -> means, 'loss_' dropped from the key, zeros removed
             key = f"{P}/{name}"
             if key in mon_loss_dict:
@@ -344,23 +417,6 @@ class CompReconLossesMixin:
                     mon_loss_dict[key.replace("loss_", "")] = mon_loss_dict.pop(key) / n_preserve
                 else:
                     del mon_loss_dict[key]
-        rep = [torch.stack([r[i] for r in reps]).mean() for i in range(5)]
-        if preserve:
-            l_preserve = torch.stack(preserve).mean()
-            mon_loss_dict[f"{P}/comp_fg_bg_preserve"] = l_preserve.mean().detach().item()
-            loss = loss + l_preserve
-        if cross_t:
-            mon_loss_dict[f"{P}/subj_attn_cross_t_diff"] = torch.stack(cross_t).mean().detach().item()       # monitored, weight 0
-        if rep[0] > 0:
-            for name, v in zip(("subj_attn", "subj_k", "nonsubj_k", "subj_v", "nonsubj_v"), rep):
-                mon_loss_dict[f"{P}/comp_rep_distill_{name}"] = v.detach().item()
-            l_rep = CL.comp_rep_distill_total(rep, sc_pct, rep_dist_fg_bounds)
-            mon_loss_dict[f"{P}/comp_rep_distill_total"] = l_rep.mean().detach().item()
-            loss = loss + l_rep
-        v = loss.mean().detach().item()
-        if v > 0:
-            mon_loss_dict[f"{P}/comp_feat_distill_total"] = v
-        mon_loss_dict[f"{P}/pred_l2"] = torch.stack(pred_l2s).mean().detach().item()
         return loss
 
     # ------------------------------------------------------------------ adversarial face edit (ddpm.py:2536-2582)
@@ -443,9 +499,11 @@ class CompReconLossesMixin:
         detected face box when one is found, x0.1 when none is), the background pulled to the class-prompt prediction, the subject
         attention kept off the background, plus the ArcFace alignment of the x0 prediction.
         Like the reference, the per-step losses only exist when ``arcface_align_loss_weight > 0`` (:2702)."""
+        from ...modules.arcface_wrapper import to_device_async
         P, dev = session_prefix, x_start.device
-        loss = torch.tensor(0.0, device=dev)
+        loss = torch.zeros((), device=dev)
         BS = x_start.shape[0]
+        ref_cache = {}                               # the decoded inputs and their face embeddings: the same for every step
         if normal_recon_on_pure_noise:
             t = torch.randint(int(self.num_timesteps * 0.7), int(self.num_timesteps * 0.9), (BS,), device=dev).long()
             x_start0 = torch.randn_like(x_start)
@@ -471,10 +529,13 @@ class CompReconLossesMixin:
             noise_pred_cls = noise_preds_cls[i] if cls_context is not None else None
             pred_l2s.append((noise_pred ** 2).mean())
             if self.arcface_align_loss_weight > 0:
-                la, _, lb, boxes, _, found = self.calc_arcface_align_loss(x_start, x_recon, fg_faces_grad_mask_ratios=(1, 0.3))
-                face_stats.update([found.sum().item(), found.shape[0]])
-                if la > 0:
-                    keep = self.recon_face_align_loss_thres <= 0 or la < self.recon_face_align_loss_thres
+                la, _, lb, boxes, _, found = self.calc_arcface_align_loss(x_start, x_recon, fg_faces_grad_mask_ratios=(1, 0.3), ref_cache=ref_cache)
+                face_stats.update([found.sum().item(), found.shape[0]])                       # (host data)
+                la_v = lb_v = 0.0
+                if boxes is not None:                # one read of the two values the branches below are on (exact zeros without a face)
+                    la_v, lb_v = torch.stack([la.detach().float(), lb.detach().float()]).tolist()
+                if la_v > 0:
+                    keep = self.recon_face_align_loss_thres <= 0 or la_v < float(np.float32(self.recon_face_align_loss_thres))
                     if keep:
                         l_align.append(la)
                     self.normal_recon_face_align_loss_kept_frac.update(1 if keep else 0)
@@ -483,21 +544,18 @@ class CompReconLossesMixin:
                     # 0.1 its comment intends for instances without a face truncates to 0 -- those instances get weight 0, not 0.1
                     inst_w = found.clone()
                     inst_w[found == 0] = 0.1
+                    inst_w = to_device_async(inst_w, dev)
                     scale = 1.0
-                    box_mask = torch.zeros(BS, 1, x_start.shape[-2], x_start.shape[-1], device=dev)
-                    for j in range(len(boxes)):
-                        x1, y1, x2, y2 = boxes[j]
-                        box_mask[j, :, y1:y2, x1:x2] = 1
-                    fg_mask2 = fg_mask * box_mask
+                    fg_mask2 = fg_mask * box_mask(boxes, BS, x_start.shape[-2], x_start.shape[-1], dev)
                 else:
-                    scale, inst_w, fg_mask2 = 0.1, torch.ones_like(found).to(torch.float32), fg_mask
+                    scale, inst_w, fg_mask2 = 0.1, torch.ones(found.shape, dtype=torch.float32, device=dev), fg_mask
                 a, b, c = CL.calc_recon_and_suppress_losses(noise, noise_pred, noise_pred_cls, inst_w, acts, all_subj_indices, None, fg_mask2,
                                                             recon_bg_pixel_weight, BS, normal_recon_on_pure_noise)
                 l_recon.append(a)
                 l_cls.append(b)
                 scales.append(scale)
                 l_mb.append(c)
-                if lb > 0:
+                if lb_v > 0:
                     l_bgf.append(lb)
         kind = "noise" if normal_recon_on_pure_noise else "image"
         on_noise, on_image = self.normal_recon_face_images_on_noise_stats, self.normal_recon_face_images_on_image_stats
@@ -505,31 +563,31 @@ class CompReconLossesMixin:
         mon_loss_dict[f"{P}/recon_face_images_on_image_frac"] = on_image.sums[0] / (on_image.sums[1] + 1e-2)
         mon_loss_dict[f"{P}/recon_face_align_loss_kept_frac"] = self.normal_recon_face_align_loss_kept_frac.mean
         align_scale = 1
-        if l_align:
+        if l_align:                                  # (every entry was read > 0 above, so is their mean: no 'if la > 0' read)
             la = torch.stack(l_align).mean()
-            if la > 0:
-                mon_loss_dict[f"{P}/arcface_align_recon_on_{kind}_opt"] = la.mean().detach().item()
-                align_scale = 4 if normal_recon_on_pure_noise else 1
-                loss = loss + la * self.arcface_align_loss_weight * align_scale
+            mon_loss_dict[f"{P}/arcface_align_recon_on_{kind}_opt"] = la.mean().detach()
+            align_scale = 4 if normal_recon_on_pure_noise else 1
+            loss = loss + la * self.arcface_align_loss_weight * align_scale
         if l_align_stat:
-            mon_loss_dict[f"{P}/arcface_align_recon_on_{kind}"] = torch.stack(l_align_stat).mean().detach().item()
+            mon_loss_dict[f"{P}/arcface_align_recon_on_{kind}"] = torch.stack(l_align_stat).mean().detach()
         if l_bgf:
             lb = torch.stack(l_bgf).mean()
-            if lb > 0:
-                mon_loss_dict[f"{P}/recon_bg_faces_suppress"] = lb.mean().detach().item()
-                loss = loss + lb * 2 * align_scale
-        mon_loss_dict[f"{P}/pred_l2"] = torch.stack(pred_l2s).mean().detach().item()
+            mon_loss_dict[f"{P}/recon_bg_faces_suppress"] = lb.mean().detach()
+            loss = loss + lb * 2 * align_scale
+        mon_loss_dict[f"{P}/pred_l2"] = torch.stack(pred_l2s).mean().detach()
         l_mb = torch.stack(l_mb).mean()
-        if l_mb > 0:
-            mon_loss_dict[f"{P}/recon_subj_mb_suppress"] = l_mb.mean().detach().item()
-        scales = torch.tensor(scales, device=dev)
+        mon_loss_dict[f"{P}/recon_subj_mb_suppress"] = l_mb.mean().detach()               # kept below only if > 0
+        scales = to_device_async(torch.tensor(scales, dtype=torch.float32), dev)
         if not normal_recon_on_pure_noise:
             l_recon = torch.stack(l_recon)
-            mon_loss_dict[f"{P}/loss_recon"] = l_recon.mean().detach().item()
+            mon_loss_dict[f"{P}/loss_recon"] = l_recon.mean().detach()
             loss = loss + (l_recon * scales).mean() + l_mb * self.recon_subj_mb_suppress_loss_weight
         if cls_context is not None:
             l_cls = torch.stack(l_cls)
             loss = loss + (l_cls * scales).mean()
-            mon_loss_dict[f"{P}/loss_recon_cls"] = l_cls.mean().detach().item()
-        mon_loss_dict[f"{P}/normal_recon_total"] = loss.mean().detach().item()
+            mon_loss_dict[f"{P}/loss_recon_cls"] = l_cls.mean().detach()
+        mon_loss_dict[f"{P}/normal_recon_total"] = loss.mean().detach()
+        resolve_monitors(mon_loss_dict)                                                    # all of the above in one device read
+        if not mon_loss_dict[f"{P}/recon_subj_mb_suppress"] > 0:
+            del mon_loss_dict[f"{P}/recon_subj_mb_suppress"]
         return loss

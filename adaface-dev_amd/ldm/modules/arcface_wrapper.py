@@ -58,9 +58,20 @@ def images_to_uint8(images_ts):
     return u8.permute(0, 2, 3, 1).contiguous().cpu().numpy()
 
 
+def to_device_async(t, device):
+    """A small HOST tensor onto ``device`` without stopping the host: through pinned memory and a non-blocking copy (a plain ``.to(device)`` /
+    ``torch.tensor(..., device=device)`` of pageable memory waits until everything queued on the stream has run)."""
+    if t.device == torch.device(device) or torch.device(device).type == "cpu":
+        return t.to(device)
+    return t.pin_memory().to(device, non_blocking=True)
+
+
 class FaceCropper(nn.Module):
     """``RetinaFaceClient`` around a caller-supplied detector: ``crop_faces(images, out_size, T)`` -> (fg crops [BS, 3, *out_size],
-    bg crops [N, 3, *out_size] or None, fg boxes long [BS, 4] as (x1, y1, x2, y2), confidences [BS], detected mask [BS])."""
+    bg crops [N, 3, *out_size] or None, fg boxes long [BS, 4] as (x1, y1, x2, y2), confidences [BS], detected mask [BS]).
+    The boxes, confidences and detected mask are what the (host-side) detector said and stay HOST tensors: the loss assembly slices
+    with the boxes and branches on the other two, and every such read of a device tensor would make the host wait for the device
+    (a Stage-2 micro-batch did that ~480 times, profiles/r04p_host_syncs.txt); ``to_device_async`` moves one where arithmetic needs it."""
 
     def __init__(self, detect_faces=no_faces):
         super().__init__()
@@ -94,9 +105,8 @@ class FaceCropper(nn.Module):
             boxes.append(cands[0][2:])
             conf.append(float(cands[0][1]))
             found.append(1)
-        dev = images_ts.device
-        return (torch.cat(fg, dim=0), torch.cat(bg, dim=0) if bg else None, torch.tensor(boxes, device=dev),
-                torch.tensor(conf, device=dev), torch.tensor(found, device=dev))
+        return (torch.cat(fg, dim=0), torch.cat(bg, dim=0) if bg else None, torch.tensor(boxes, dtype=torch.long),
+                torch.tensor(conf, dtype=torch.float32), torch.tensor(found, dtype=torch.long))
 
 
 GREY = (0.299, 0.587, 0.114)
@@ -115,8 +125,15 @@ class ArcFaceWrapper(nn.Module):
         self.arcface = arcface
         self.retinaface = retinaface if retinaface is not None else FaceCropper()
         self.dtype = dtype
+        self._grey = {}                                             # device -> the grey-conversion weights [1, 3, 1, 1]
         for p in self.arcface.parameters():
             p.requires_grad_(False)
+
+    def grey_weights(self, device):
+        w = self._grey.get(device)
+        if w is None:
+            w = self._grey[device] = torch.tensor(GREY, device=device).view(1, 3, 1, 1)
+        return w
 
     def _embed(self, grey, enable_grad):
         if getattr(self.arcface, "inference_only", False):          # an embedding module that declares it has no backward
@@ -134,7 +151,7 @@ class ArcFaceWrapper(nn.Module):
         fg_crops, bg_crops, boxes, conf, found = self.retinaface.crop_faces(images_ts, out_size=(128, 128), T=T)
         if found.sum() == 0:
             return None, None, None, None, conf, found
-        w = torch.tensor(GREY, device=images_ts.device).view(1, 3, 1, 1)
+        w = self.grey_weights(images_ts.device)
         grey = F.interpolate((fg_crops * w).sum(dim=1, keepdim=True).to(self.dtype), size=(128, 128), mode="bilinear", align_corners=False)
         centre_ratio, border_ratio = fg_faces_grad_mask_ratios
         grey_centre, grey_border = grey, None
@@ -156,21 +173,30 @@ class ArcFaceWrapper(nn.Module):
             emb_bg = self._embed(g, enable_grad)
         return emb_centre, emb_border, emb_bg, boxes, conf, found
 
-    def calc_arcface_align_loss(self, ref_images, aligned_images, T=20, fg_faces_grad_mask_ratios=(1, 0.3)):
-        """(cosine-embedding alignment of the generated faces to the reference faces, mean squared border-masked embedding, mean squared
-        background-face embedding, boxes of the generated faces or None, their confidences, their detected mask); zero losses when any
-        reference instance, or every generated instance, has no face (arcface_wrapper.py:171-240)."""
+    def embed_reference(self, ref_images, T=20):
+        """(embeddings, detected mask) of reference images: the first half of ``calc_arcface_align_loss``; a caller that aligns
+        several generations to the SAME references computes it once and passes it as ``ref``."""
         ref_emb, _, _, _, _, ref_found = self.embed_image_tensor(ref_images, T, embed_bg_faces=False, enable_grad=False,
                                                                  fg_faces_grad_mask_ratios=(-1, -1))
+        return ref_emb, ref_found
+
+    def calc_arcface_align_loss(self, ref_images, aligned_images, T=20, fg_faces_grad_mask_ratios=(1, 0.3), ref=None):
+        """(cosine-embedding alignment of the generated faces to the reference faces, mean squared border-masked embedding, mean squared
+        background-face embedding, boxes of the generated faces or None, their confidences, their detected mask); zero losses when any
+        reference instance, or every generated instance, has no face (arcface_wrapper.py:171-240).  ``ref``: ``embed_reference(ref_images)``
+        when the caller already has it."""
+        ref_emb, ref_found = ref if ref is not None else self.embed_reference(ref_images, T)
         emb_c, emb_b, emb_bg, boxes, conf, found = self.embed_image_tensor(aligned_images, T, embed_bg_faces=True, enable_grad=True,
                                                                            fg_faces_grad_mask_ratios=fg_faces_grad_mask_ratios)
-        zero = lambda: torch.tensor(0.0, dtype=ref_images.dtype, device=ref_images.device)
-        if (1 - ref_found).sum() > 0 or found.sum() == 0:
+        zero = lambda: torch.zeros((), dtype=ref_images.dtype, device=ref_images.device)
+        if (1 - ref_found).sum() > 0 or found.sum() == 0:                       # host tensors: no device round trip
             return zero(), zero(), zero(), None, conf, found
         if len(ref_emb) < len(emb_c):
             ref_emb = ref_emb.repeat(len(emb_c) // len(ref_emb), 1)
         per = F.cosine_embedding_loss(ref_emb, emb_c, torch.ones(ref_emb.shape[0], device=ref_emb.device), reduction="none")
-        loss_align = (per * found).sum() / found.sum()
-        loss_fg_suppress = ((emb_b ** 2).mean(dim=1) * found).sum() / found.sum()
+        found_d = to_device_async(found, per.device)
+        n_found = found_d.sum()
+        loss_align = (per * found_d).sum() / n_found
+        loss_fg_suppress = ((emb_b ** 2).mean(dim=1) * found_d).sum() / n_found
         loss_bg_suppress = (emb_bg ** 2).mean() if emb_bg is not None else zero()
         return loss_align, loss_fg_suppress, loss_bg_suppress, boxes, conf, found

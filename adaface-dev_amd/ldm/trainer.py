@@ -34,6 +34,7 @@ from .. import ops
 from ..adaface.subj_basis_generator import template_ids
 from ..distributed import GradReducer
 from .c_adamw import AdamW as CAdamW
+from .modules.arcface_wrapper import to_device_async
 from .modules.lr_scheduler import LambdaWarmUpCosineScheduler
 from .util import set_seed_per_rank_and_batch
 
@@ -272,7 +273,7 @@ class DistillTrainer:
         ada = ada_embs.float()
         tok = torch.cat([torch.cat([tok[:3, :s], ada.expand(3, -1, -1), tok[:3, s + n_id:]], dim=1), tok[3:]], dim=0)
         ctx = self.text_encoder(input_ids=ids, input_token_embs=tok)[0]
-        lens = torch.tensor([len(w) + 2 for w in word_lists], device=dev)
+        lens = to_device_async(torch.tensor([len(w) + 2 for w in word_lists]), dev)
         pos = torch.arange(T, device=dev)[None, :]
         emb_mask = ((pos >= 1) & (pos < (lens - 1)[:, None])).float().unsqueeze(2)          # real tokens (no BOS / EOS / padding)
         pad_mask = (pos >= lens[:, None]).float().unsqueeze(2)
@@ -318,12 +319,18 @@ class DistillTrainer:
                 raise RuntimeError("a compositional-distillation iteration with arcface_align_loss_weight > 0 looks for faces in the decoded x0 "
                                    "predictions: set ldm.arcface (modules/arcface_wrapper.ArcFaceWrapper around your face detector) and "
                                    "instantiate the first-stage decoder, or set ldm.arcface_align_loss_weight = 0")
-            pixels = ldm.decode_first_stage(torch.cat(x_recons, dim=0).detach()).chunk(S)                  # ddpm.py:2454-2457
+            # ddpm.py:2454-2457 decodes all four blocks of every step -- for its image logger (:2459-2465); the loss reads the
+            # subject-single block only (ddpm_losses.calc_comp_feat_distill_loss), and this trainer logs no images: decode what is consumed
+            # (4 images instead of 16) unless a logger asks for the rest
+            blocks = x_recons if self.decode_all_blocks_for_logging else [x.chunk(4)[0] for x in x_recons]
+            pixels = ldm.decode_first_stage(torch.cat(blocks, dim=0).detach()).chunk(S)
         ss_context = (ctx.chunk(4)[0], prompts[:1], {})
         self.mon_loss_dict = {}
         return ldm.calc_comp_feat_distill_loss(self.mon_loss_dict, "train", x_start, x_starts, x_recons, pixels, noise_preds, noises, ts, acts, subj_1b,
                                                ss_context, ldm.uncond_context[0], emb_mask, pad_mask, 1, ldm.sc_fg_face_suppress_mask_shrink_ratio,
                                                use_attn_lora=has_attn_lora, use_ffn_lora=has_ffn_lora)
+
+    decode_all_blocks_for_logging = False        # comp_distill_step: also decode the SC / SR / MC x0 predictions of every step (nothing here reads them)
 
     # ------------------------------------------------------------------ do_normal_recon iteration (ddpm.py:2296-2352, 2593-2883)
     p_normal_recon_on_pure_noise = 0.4            # reference ctor defaults (ddpm.py:116, 126-130)

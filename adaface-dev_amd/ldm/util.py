@@ -22,7 +22,7 @@ def calc_recon_loss(loss_func, noise_pred, noise_gt, img_mask, fg_mask, instance
         instance_weights = torch.ones_like(noise_pred)
     else:
         if instance_weights.sum() == 0:
-            z = torch.tensor(0.0, device=noise_pred.device)
+            z = torch.zeros((), device=noise_pred.device)
             return z, z
         instance_weights = instance_weights.float().reshape(-1, 1, 1, 1)
     fg_mask = fg_mask * instance_weights

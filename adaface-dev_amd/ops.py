@@ -38,7 +38,9 @@ def param_key(p):
 
 
 def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    # the raw handle of torch's current stream on the current device: two C calls (~0.3 us) instead of the ~3 us of
+    # torch.cuda.current_stream().cuda_stream -- this runs once per launch, ~11,000 times in a Stage-2 micro-batch
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
 
 def _p(t: Optional[torch.Tensor]):

@@ -182,12 +182,27 @@ def run_train(args, ctx, dev, stage=1):
     gc.collect()
     gc.disable()
     torch.cuda.synchronize()
+    sync_debug = getattr(args, "sync_debug", None)
+    if sync_debug:
+        import traceback
+        import warnings
+        sync_log = open(sync_debug, "w")
+
+        def show(message, category, filename, lineno, file=None, line=None):
+            stack = [f for f in traceback.extract_stack()[:-1] if "adaface" in f.filename or "bench.py" in f.filename]
+            sync_log.write(f"SYNC {message}\n" + "".join(f"    {f.filename.split('/')[-1]}:{f.lineno} {f.name}: {f.line}\n" for f in stack[-6:]))
+        warnings.showwarning = show
+        warnings.simplefilter("always")
+        torch.cuda.set_sync_debug_mode("warn")
     t0 = time.perf_counter()
     host_ms = []
     for i in range(steps):
         th = time.perf_counter()
         losses.append(tr.training_step(batches[i % 4], warm + i, **step_kw))
         host_ms.append(round((time.perf_counter() - th) * 1e3, 1))
+    if sync_debug:
+        torch.cuda.set_sync_debug_mode("default")
+        sync_log.close()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -600,6 +615,8 @@ def main():
     ap.add_argument("--train-warmup", type=int, default=12, help="untimed micro-batches (the hipGraph segments of every signature are captured in here)")
     ap.add_argument("--distill-only", action="store_true", help="train leg: every micro-batch a U-Net distillation iteration (rounds 1-2's leg) instead of the reference's recon / distill mix")
     ap.add_argument("--no-train-graphs", action="store_true", help="train leg: launch every kernel from Python instead of replaying captured segments")
+    ap.add_argument("--sync-debug", default=None, metavar="FILE", help="train legs: write the Python stack of every host<->device synchronisation "
+                    "of the timed micro-batches to FILE (torch.cuda.set_sync_debug_mode); the timing of such a run is not a result")
     ap.add_argument("--mode", choices=["all", "denoise", "train", "train2"], default="all",
                     help="all (default): the headline denoise line (BASELINE configs[1]) carrying the Stage-1 training leg "
                          "(configs[2]/[3]) as its `train` object; denoise / train: one leg only (train prints its own line)")
