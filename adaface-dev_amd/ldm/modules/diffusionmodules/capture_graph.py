@@ -25,6 +25,7 @@ Activations between nodes are fp16 (NHWC / token-major), their gradients too; as
 scaled by the trainer's LossScaler.  Captured tensors are returned in the reference's layouts ([B, C, N] for q / q2 / k / v / attn_out,
 [B, heads, N, L] for attn / attnscore, [B, C, H, W] for outfeat) as ordinary autograd tensors."""
 import math
+import os
 
 import torch
 import torch.nn.functional as F
@@ -34,6 +35,7 @@ from ....ops import F16
 from .util import from_nhwc_f16, to_nhwc_f16
 
 CAPTURE_KEYS = ("outfeat", "attn", "attnscore", "q", "q2", "k", "v", "attn_out")
+INFER_TRUNK = os.environ.get("AF_INFER_TRUNK", "1") != "0"      # A/B switch: 0 = the activation-saving trunk for every captured pass
 
 
 class ScaleGrad(torch.autograd.Function):
@@ -331,8 +333,14 @@ def unet_forward_captured(unet, x, timesteps, context, extra_info, n_tail=3):
     n_out = len(unet.output_blocks)
     first_layer = len(unet.input_blocks) + 1 + n_out - n_tail          # layer index of the first tail block (22 for SD-1.5)
     emb = unet._embed(timesteps)
-    outs = _TrunkFn.apply(unet, x, emb, context, img_mask, n_tail, gs)
-    h, skips = outs[0], outs[1:]
+    if not INFER_TRUNK or (torch.is_grad_enabled() and (x.requires_grad or context.requires_grad)):
+        outs = _TrunkFn.apply(unet, x, emb, context, img_mask, n_tail, gs)
+        h, skips = outs[0], outs[1:]
+    else:
+        # nothing below the tail needs a gradient (the no-grad instances of a compositional step, the class-prompt pass of a recon
+        # step): the inference walk instead of the activation-saving one
+        with torch.no_grad():
+            h, skips = unet.hip_trunk(to_nhwc_f16(x.detach(), ops.round_up(unet.in_channels, 8)), emb, context.detach().to(F16).contiguous(), img_mask, n_tail)
     B = x.shape[0]
     ctx2d = context.to(F16).reshape(B * context.shape[1], context.shape[2])
     acts = {k: {} for k in CAPTURE_KEYS}

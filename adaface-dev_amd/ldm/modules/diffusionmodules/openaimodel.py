@@ -585,6 +585,27 @@ class UNetModel(nn.Module):
         assert not hs
         return h, skips, (saved_in, saved_mid, saved_out, context.shape)
 
+    def hip_trunk(self, x_nhwc, emb, context, img_mask, n_tail):
+        """``hip_train_trunk`` for a pass that needs NO gradient below the tail (a no-grad instance of a compositional step, or one whose
+        input and context carry none): the inference walk -- every cross-attention layer's k / v from one GEMM, the fused C = 320 blocks,
+        nothing saved -- up to the last ``n_tail`` decoder blocks.  -> (h, [the skips those blocks pop, in pop order])."""
+        kv_layers = self._project_context_all(context)
+        try:
+            hs = []
+            h = x_nhwc
+            for module in self.input_blocks:
+                h = module.hip(h, emb, context, img_mask)
+                hs.append(h)
+            h = self.middle_block.hip(h, emb, context, img_mask)
+            for module in list(self.output_blocks)[:len(self.output_blocks) - n_tail]:
+                h = module.hip(SkipCat((h, hs.pop())), emb, context, img_mask)
+            skips = [hs.pop() for _ in range(n_tail)]
+            assert not hs
+            return h, skips
+        finally:
+            for m in kv_layers:
+                m._kv_pre = None
+
     def hip_bwd_trunk(self, saved, dh, dskips_tail, need_dx=True, res_gradscale=1.0):
         """Backward of hip_train_trunk: dh = gradient of h, dskips_tail[i] = gradient of the i-th popped skip (already scaled by the
         tail where the live path scales it) or None.  Same walk as hip_bwd."""
