@@ -88,7 +88,8 @@ def run_train(args, ctx, dev, stage=1):
     the bs-3 batch (the reference fixes it, :2372-2374), latents primed from pure noise by the second (teacher) U-Net with
     classifier-free guidance over 3-4 steps, then 4 subject-compos denoising steps of the student on the four-prompt batch with
     activation capture (explicit attention in layers 22-24, score mixing / normalisation, trainable attention + FFN DoRA adapters),
-    guidance passes, the x0 predictions decoded for the face pipeline (a fixed face box stands in for the RetinaFace detector network), the
+    guidance passes, the subject-single x0 predictions of every step decoded for the face pipeline (what the loss consumes; the reference also decodes the
+    other three blocks, for its image logger, ddpm.py:2454-2465; a fixed face box stands in for the RetinaFace detector network), the
     whole loss assembly incl. the re-denoising of the subject-single instance and the feature-matching loss, backward, CAdamW."""
     world, rank, local_rank, launched = ctx
     import torch.distributed as dist
@@ -273,7 +274,8 @@ def run_train(args, ctx, dev, stage=1):
                     f"~6 backward) = {train_tflop:.1f} TFLOP algorithmic / wall time")
             metric = "train-images/sec Stage-2 compositional distillation bs=3/GPU"
             workload = ("stage2_comp_distill micro-batch: bs=3/GPU of which BLOCK_SIZE=1 is denoised (reference ddpm.py:2372-2374), 512x512, 97 tokens, "
-                        "priming U-Net 3-4 CFG steps + student 4 subject-compos steps x 4 prompts with capture of layers 22-24 + guidance passes, "
+                        "priming U-Net 3-4 CFG steps + student 4 subject-compos steps x 4 prompts with capture of layers 22-24 + guidance passes + re-denoising of the subject-single instance, "
+                        "x0 of the subject-single block decoded per step (the blocks the loss reads; image logging is out of scope), VAE decoder + ResNetFace-18 with input gradients, "
                         f"attention + FFN DoRA adapters, {n_train} trainable fp32 params, accumulate_grad_batches=2, CAdamW")
         out = {"metric": metric, "value": round(world * B * steps / elapsed, 3),
                "unit": "images/s", "n_gpus": world, "steps": steps, "warmup": warm, "ms_per_step": round(ms, 3),

@@ -501,6 +501,65 @@ def test_rccl_world1_train_step_under_launcher(dev, tmp_path):
     assert same > 0.999, float(same)
 
 
+def test_comp_distill_iteration_does_not_stall_the_host(dev):
+    """A compositional-distillation micro-batch used to make the host wait for the device ~480 times (slices indexed by device-resident
+    face boxes, index lists, one read per monitor / per `if loss > 0`): every wait drains the launch queue, and the leg was host-bound
+    because of it (profiles/r04p_host_syncs_train2_before.txt).  The detector's boxes / confidences / masks are host data now and the
+    values the assembly branches on are read in batches: count the synchronisations of one micro-batch (torch's sync-debug mode reports
+    each blocking copy / .item() / nonzero as a warning) and hold the line at 80 (51 at full size, profiles/r04q_host_syncs_train2_after.txt)."""
+    import warnings
+    from adaface_dev_amd import rng
+    tr, sds, ucfg = trainer_setup(dev, accum=1, ffn_lora=True, stage2=True)
+    b = dict(x_start=rng.synth_input("s2.x", (2, 4, 32, 32), seed=49).to(dev), face_id_embs=rng.synth_input("s2.id", (2, 512), seed=49).to(dev))
+    for aug in ("normalize_cross_attn", "mix_sc_mc_attn"):                     # warm: packs, template ids, grey weights
+        tr.optimizer.zero_grad()
+        tr.comp_distill_step(b, attn_aug=aug)
+    counts = {}
+    for aug in ("normalize_cross_attn", "mix_sc_mc_attn"):
+        tr.optimizer.zero_grad()
+        torch.cuda.synchronize()
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            torch.cuda.set_sync_debug_mode("warn")
+            try:
+                loss = tr.comp_distill_step(b, attn_aug=aug)
+            finally:
+                torch.cuda.set_sync_debug_mode("default")
+        counts[aug] = sum(1 for x in w if "synchroniz" in str(x.message).lower())
+        assert torch.isfinite(loss)
+    print("host<->device synchronisations per compositional micro-batch:", counts)
+    assert max(counts.values()) <= 80, counts
+
+
+def test_gradient_free_captured_pass_takes_the_inference_trunk(dev):
+    """`unet_forward_captured` of an instance that needs no gradient below the captured layers (the no-grad SS / SR instances, the
+    re-denoising pass) walks the trunk with the inference kernels (`UNetModel.hip_trunk`) instead of the activation-saving walk: same
+    function, different launches -- eps and every captured tensor agree within the fp16 tolerance of two kernel paths."""
+    from adaface_dev_amd import rng
+    from adaface_dev_amd.ldm.modules.diffusionmodules import capture_graph as CG
+    tr, sds, ucfg = trainer_setup(dev, accum=1, ffn_lora=True, stage2=True)
+    unet = tr.ldm.model.diffusion_model
+    x = rng.synth_input("trunk.x", (2, 4, 32, 32), seed=51).to(dev)
+    ctx = rng.synth_input("trunk.c", (2, 77, ucfg["context_dim"]), seed=52).to(dev)
+    t = torch.tensor([500, 300], device=dev)
+    outs = []
+    for flag in (True, False):
+        CG.INFER_TRUNK = flag
+        try:
+            ei = {"capture_ca_activations": True, "normalize_cross_attn": False, "subj_indices": None}
+            with torch.no_grad():
+                eps = CG.unet_forward_captured(unet, x, t, ctx, ei)
+            outs.append((eps.float(), ei["ca_layers_activations"]))
+        finally:
+            CG.INFER_TRUNK = True
+    (e1, a1), (e0, a0) = outs
+    assert torch.isfinite(e1).all()
+    assert rel_l2(e1.cpu().numpy(), e0.cpu().numpy()) < 5e-3
+    for key in ("outfeat", "attn", "q", "k", "v", "attn_out"):
+        for li in a0[key]:
+            assert rel_l2(a1[key][li].float().cpu().numpy(), a0[key][li].float().cpu().numpy()) < 5e-3, (key, li)
+
+
 @pytest.mark.parametrize("attn_aug", ["normalize_cross_attn", "mix_sc_mc_attn"])
 def test_comp_distill_iteration_reduced_width(dev, attn_aug):
     """One Stage-2 compositional-distillation micro-batch end to end on the HIP path (reference ddpm.py:2371-2480): priming by the
