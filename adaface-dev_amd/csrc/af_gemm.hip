@@ -505,8 +505,9 @@ int af_gemm3_try_launch(const af_gemm_desc* d, int splits, int wide, hipStream_t
 int af_gemm3_effective_splits(const af_gemm_desc* d, int splits, int wide);
 
 extern "C" int af_gemm_gn_stats_ok(int tile, int splits, int taps, int act, int out_mode, int N, int cpg, int rows_per_batch) {
-  const int bn = tile == 7 ? 320 : ((tile == 11 || tile == 13) ? 160 : 0);
+  const int bn = tile == 7 ? 320 : ((tile == 11 || tile == 13 || tile == 14) ? 160 : 0);
   if (bn == 0 || splits > 1 || (taps != 1 && taps != 9) || act == AF_ACT_GEGLU || out_mode != AF_OUT_NORMAL) return 0;
+  if (tile == 14 && (taps != 9 || rows_per_batch % 256 != 0)) return 0;      // the halo-resident kernel's tile is 256 rows of one image
   if (cpg <= 0 || cpg % 2 != 0 || bn % cpg != 0 || N % cpg != 0 || N / cpg > 32 || N % bn != 0 || N % 8 != 0) return 0;
   if (rows_per_batch <= 0 || rows_per_batch % 128 != 0 || rows_per_batch / 128 > 128) return 0;
   return 1;

@@ -259,11 +259,12 @@ __device__ __forceinline__ void gemm3_epilogue(const Gemm3Dev& p, floatx4 (&acc)
       }
     }
     __syncthreads();
-    constexpr bool kGnFits = EPI == E3_STD && BM == 128 && (size_t)BM * TS * 2 + 2 * ((64 * NW) / 32) * 32 * 4 <= (size_t)LDSB;
+    constexpr bool kGnFits = EPI == E3_STD && (BM == 128 || BM == 256) && (size_t)BM * TS * 2 + 2 * ((64 * NW) / 32) * 32 * 4 <= (size_t)LDSB;
     if constexpr (kGnFits) if (p.gn_ws != nullptr) {
       // GroupNorm partial statistics of THIS tile from the staged fp16 values (what the consumer's normalisation will read): thread (group g,
       // row slice rs) sums its rows x cpg / 2 channel pairs, the slices meet in LDS behind the tile, one (sum, sumsq) per group leaves for
-      // af_groupnorm's partial workspace [B][128][32][2] at this tile's block index inside its image.  BM = 128 rows of ONE batch item; the tile's
+      // af_groupnorm's partial workspace [B][128][32][2] at this tile's block index inside its image.  BM = 128 rows of ONE batch item (a 256-row
+      // tile -- the halo-resident convolution -- fills the first of its two 128-row blocks and zeroes the second); the tile's
       // width is a multiple of the group width (validated by the host).  Rows beyond M hold zeros in T.
       constexpr int NSL = (64 * NW) / 32;                        // row slices: 32 threads (groups) per slice
       constexpr int RPS = BM / NSL;
@@ -294,11 +295,12 @@ __device__ __forceinline__ void gemm3_epilogue(const Gemm3Dev& p, floatx4 (&acc)
           qq += red[NSL * 32 + k * 32 + tid];
         }
         const int m0 = tile_m * BM;
-        const int bt = m0 / p.rows_per_batch, blk = (m0 - bt * p.rows_per_batch) / BM;
+        const int bt = m0 / p.rows_per_batch, blk = (m0 - bt * p.rows_per_batch) / 128;
         const int g0 = (tile_n * BNO) / p.gn_cpg;
         float* w = p.gn_ws + (((size_t)bt * 128 + blk) * 32 + g0 + tid) * 2;
         w[0] = ss;
         w[1] = qq;
+        if constexpr (BM == 256) w[64] = w[65] = 0.f;             // the consumer sums rows_per_batch / 128 blocks
       }
     }
     constexpr int CPR = BNO / 8;                                // 16-byte chunks per output row
@@ -1426,7 +1428,7 @@ int af_gemm3_try_launch(const af_gemm_desc* d, int splits, int wide, hipStream_t
   if (wide == 2 && (d->N % 256 != 0 || d->taps != 1 || split_t || splits > 1)) return 1;
   if (wide == 3 && (d->N % 320 != 0 || d->taps != 1 || split_t || splits > 1)) return 1;
   if (d->ln_colsum != nullptr && (wide < 4 || d->taps != 1 || d->c2 != 0 || splits > 1)) return 1;   // folded LayerNorm: whole-line tiles only
-  if (d->gn_partials != nullptr && !((wide == 4 || wide == 8 || wide == 10) && !geglu && !split_t && splits <= 1)) return 1;   // GroupNorm partials: staged standard epilogue
+  if (d->gn_partials != nullptr && !((wide == 4 || wide == 8 || wide == 10 || wide == 11) && !geglu && !split_t && splits <= 1)) return 1;   // GroupNorm partials: staged standard epilogue
   Gemm3Dev p;
   bool fused = false;
   p.ln_cs = (const float*)d->ln_colsum;

@@ -187,7 +187,8 @@ def test_conv3x3_with_k_concatenated_1x1_skip(dev, B, H, W, cin, cs1, cs2, cout,
 
 @pytest.mark.parametrize("kind,B,H,W,cin,cout,tile", [("conv", 2, 16, 16, 128, 320, 7), ("conv", 1, 64, 64, 320, 320, 7), ("conv", 2, 32, 32, 64, 640, 7),
                                                        ("conv", 3, 16, 8, 64, 320, 11), ("gemm", 2, 16, 16, 320, 320, 7), ("gemm", 2, 32, 32, 128, 1280, 11),
-                                                       ("skip", 2, 16, 16, 128, 320, 7), ("conv", 2, 16, 16, 64, 960, 7)])
+                                                       ("skip", 2, 16, 16, 128, 320, 7), ("conv", 2, 16, 16, 64, 960, 7),
+                                                       ("conv", 1, 64, 64, 320, 320, 14), ("conv", 2, 32, 32, 64, 640, 14), ("conv", 2, 16, 16, 128, 320, 14)])
 def test_groupnorm_statistics_from_the_producing_gemm(dev, kind, B, H, W, cin, cout, tile):
     """A convolution / 1x1 GEMM / K-concatenated convolution whose output feeds a GroupNorm(32) leaves the partial (sum, sumsq) of the fp16 values
     it stores (af_gemm_desc.gn_partials); af_groupnorm_apply then normalises without a statistics pass.  Same result as the two-pass GroupNorm
@@ -218,6 +219,9 @@ def test_groupnorm_statistics_from_the_producing_gemm(dev, kind, B, H, W, cin, c
     yf = y.float().reshape(B, H * W // 128, 128, 32, cpg)
     want = torch.stack([yf.sum(dim=(2, 4)), (yf * yf).sum(dim=(2, 4))], dim=-1)
     got = gn.ws[:, :gn.nblk]
+    if tile == 14:                                      # the halo-resident kernel's tile is 256 rows: one sum per PAIR of blocks, the second block zero
+        assert float(got[:, 1::2].abs().max()) == 0.0
+        got, want = got[:, 0::2], want[:, 0::2] + want[:, 1::2]
     assert torch.allclose(got, want, rtol=2e-4, atol=2e-2)
     for silu in (False, True):
         out = ops.groupnorm(y, gam.to(dev), bet.to(dev), 1e-5, silu)                       # picks the partials up

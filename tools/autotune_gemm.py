@@ -23,6 +23,42 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 
+def candidate_ok(d, tile, splits, _lib, ops):
+    """Whether af_gemm takes descriptor ``d`` on (tile, splits): the scope rules of include/adaface_hip.h, as the tuners apply them."""
+    geglu = d.act == _lib.AF_ACT_GEGLU
+    nk = d.kpad // 64
+    if tile == 14 and not ops.conv_halo_eligible(d):
+        return False                        # halo-resident 3x3 kernel: its split-K slices are 64-channel chunks
+    if tile >= 7 and (d.upsample not in (0, 1) or (d.upsample and tile not in (7, 8, 11, 12, 13, 15)) or d.c1 % 64 or d.c2 % 64):
+        return False                        # whole-line kernel: 64-multiples of channels; nearest-x2 upsample in the non-GEGLU tiles
+    if tile in (11, 13) and (geglu or d.out_mode == _lib.AF_OUT_SPLIT_T or d.N % 160 != 0):
+        return False                        # 128 x 160, four waves (11: two workgroups per CU; 13: four-slot ring)
+    if tile == 15 and (geglu or d.out_mode == _lib.AF_OUT_SPLIT_T or d.N % 128 != 0 or d.M < 16384):
+        return False                        # 256 x 128, eight waves: narrow outputs over many rows
+    if tile == 12 and (geglu or d.out_mode == _lib.AF_OUT_SPLIT_T):
+        return False                        # 128 x 128 with a four-slot ring
+    if tile == 7 and (d.N % (256 if geglu else 320) != 0):
+        return False
+    if tile == 8 and geglu:
+        return False
+    if tile in (9, 10) and (not geglu or d.N % (320 if tile == 9 else 256) != 0):
+        return False
+    if tile in (5, 6) and (d.taps != 1 or d.out_mode != 0 or d.M * d.N < 256 * 256 * 128 or splits > 1):
+        return False                        # 256-row ring tiles: plain / GEGLU 1x1 GEMMs with at least ~128 tiles
+    if (d.c3 or d.c4) and not (7 <= tile <= 13 or tile == 15):
+        return False                        # the K-concatenated 1x1 tail lives in the whole-line tiles
+    if d.ln_colsum and (tile < 7 or tile > 13 or splits > 1 or (tile in (9, 10) and not geglu)):
+        return False                        # folded LayerNorm: whole-line tiles, unsplit
+    f32 = d.out_mode == _lib.AF_OUT_F32     # weight gradients: fp32 from the reduce pass, or unsplit from tiles 1 / 2
+    if f32 and splits == 1 and tile > 2:
+        return False
+    if splits > 1 and (geglu or d.out_mode == _lib.AF_OUT_SPLIT_T or nk < 4 * splits):
+        return False
+    if tile == 14 and splits > d.c1 // 64:
+        return False
+    return True
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batches", default="8,2")

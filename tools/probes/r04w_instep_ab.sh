@@ -1,0 +1,12 @@
+#!/bin/bash
+# In-step second-stage tuning of the GEMM table, then the denoise leg with the old and the new table alternating on this box.
+python tools/autotune_instep.py --out gpurun_out/r04w_instep_table.json --log gpurun_out/r04w_instep.log > gpurun_out/r04w_instep.out 2>&1
+tail -3 gpurun_out/r04w_instep.out
+for i in 1 2 3; do
+  for t in old new; do
+    if [ $t = new ]; then export AF_TUNE_TABLE=$PWD/gpurun_out/r04w_instep_table.json; else unset AF_TUNE_TABLE; fi
+    python bench.py --mode denoise --no-cpu-baseline --no-roofline 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$t', d['ms_per_step'])"
+  done
+done
