@@ -76,21 +76,9 @@ def init_device(ctx):
     return dev
 
 
-def run_train(args, ctx, dev, stage=1):
-    """stage 1: BASELINE configs[2] (1 GPU) / configs[3] (DDP); stage 2: configs[4] (see the end of this docstring).  One *step* = one training
-    micro-batch of bs images/GPU: face IDs -> Arc2Face encoder -> trainable SubjBasisGenerator -> frozen text encoder ->
-    teacher multi-step targets + student eps per step (HALF_BS = ceil(bs/steps) instances, steps cycling 2,3,4 as
-    ddpm.py:1270-1289) -> masked MSE -> backward to the 85 M SubjBasisGenerator weights; every 2nd micro-batch the
-    bucketed gradient all-reduce (overlapped with the backward), unscale and fused CAdamW.  Full-size models: 2 x SD-1.5
-    U-Net (student, teacher) + 3 x CLIP-L text transformers, seeded random weights.  Returns the result dict on rank 0.
-
-    stage 2 (BASELINE configs[4], reference ddpm.py:2371-2480): one *step* = one compositional-distillation micro-batch: BLOCK_SIZE 1 of
-    the bs-3 batch (the reference fixes it, :2372-2374), latents primed from pure noise by the second (teacher) U-Net with
-    classifier-free guidance over 3-4 steps, then 4 subject-compos denoising steps of the student on the four-prompt batch with
-    activation capture (explicit attention in layers 22-24, score mixing / normalisation, trainable attention + FFN DoRA adapters),
-    guidance passes, the subject-single x0 predictions of every step decoded for the face pipeline (what the loss consumes; the reference also decodes the
-    other three blocks, for its image logger, ddpm.py:2454-2465; a fixed face box stands in for the RetinaFace detector network), the
-    whole loss assembly incl. the re-denoising of the subject-single instance and the feature-matching loss, backward, CAdamW."""
+def build_train(args, ctx, dev, stage=1):
+    """The models, the trainer and the synthetic batches of a training leg (see run_train): -> (trainer, batches, step_kw, B, n_train, ldm, teacher, id2ada, text_enc).
+    Shared with tools/autotune_instep.py, which times GEMM configurations inside these micro-batches."""
     world, rank, local_rank, launched = ctx
     import torch.distributed as dist
     from adaface_dev_amd import SD15_UNET_CONFIG, _lib, ops, rng
@@ -170,6 +158,28 @@ def run_train(args, ctx, dev, stage=1):
                     face_id_embs=rng.synth_input(f"tb.id{i % 4}", (B, 512), seed=seed).to(dev),
                     fg_mask=torch.ones(B, 1, 64, 64, device=dev))
     batches = [batch(i) for i in range(4)]
+    return tr, batches, step_kw, B, n_train, ldm, teacher, id2ada, text_enc
+
+
+def run_train(args, ctx, dev, stage=1):
+    """stage 1: BASELINE configs[2] (1 GPU) / configs[3] (DDP); stage 2: configs[4] (see the end of this docstring).  One *step* = one training
+    micro-batch of bs images/GPU: face IDs -> Arc2Face encoder -> trainable SubjBasisGenerator -> frozen text encoder ->
+    teacher multi-step targets + student eps per step (HALF_BS = ceil(bs/steps) instances, steps cycling 2,3,4 as
+    ddpm.py:1270-1289) -> masked MSE -> backward to the 85 M SubjBasisGenerator weights; every 2nd micro-batch the
+    bucketed gradient all-reduce (overlapped with the backward), unscale and fused CAdamW.  Full-size models: 2 x SD-1.5
+    U-Net (student, teacher) + 3 x CLIP-L text transformers, seeded random weights.  Returns the result dict on rank 0.
+
+    stage 2 (BASELINE configs[4], reference ddpm.py:2371-2480): one *step* = one compositional-distillation micro-batch: BLOCK_SIZE 1 of
+    the bs-3 batch (the reference fixes it, :2372-2374), latents primed from pure noise by the second (teacher) U-Net with
+    classifier-free guidance over 3-4 steps, then 4 subject-compos denoising steps of the student on the four-prompt batch with
+    activation capture (explicit attention in layers 22-24, score mixing / normalisation, trainable attention + FFN DoRA adapters),
+    guidance passes, the subject-single x0 predictions of every step decoded for the face pipeline (what the loss consumes; the reference also decodes the
+    other three blocks, for its image logger, ddpm.py:2454-2465; a fixed face box stands in for the RetinaFace detector network), the
+    whole loss assembly incl. the re-denoising of the subject-single instance and the feature-matching loss, backward, CAdamW."""
+    world, rank, local_rank, launched = ctx
+    import torch.distributed as dist
+    from adaface_dev_amd import _lib, ops
+    tr, batches, step_kw, B, n_train, ldm, teacher, id2ada, text_enc = build_train(args, ctx, dev, stage)
     steps = args.train_steps + (args.train_steps % 2)            # whole accumulation windows
     warm = max(2, args.train_warmup + (args.train_warmup % 2))
     losses = []
