@@ -624,7 +624,7 @@ extern "C" int af_gemm(const af_gemm_desc* d, void* stream) {
     const long t128 = (long)((d->M + 127) / 128) * ((d->N + 127) / 128);
     tile = (t128 >= 192 && d->N >= 96) ? 1 : 2;
   }
-  AF_REQUIRE(tile >= 1 && tile <= 15, "af_gemm: tile must be 0 .. 15");
+  AF_REQUIRE(tile >= 1 && tile <= 17, "af_gemm: tile must be 0 .. 17");
 
   AfLaunchScope scope(AF_FAM_GEMM, stream);
   hipStream_t s = (hipStream_t)stream;
@@ -646,7 +646,7 @@ extern "C" int af_gemm(const af_gemm_desc* d, void* stream) {
     AF_SUPPORTED(!gnp, "af_gemm: gn_partials is outside the chosen tile's scope");
     tile = 1;  // outside the pipelined kernel's scope
   }
-  AF_SUPPORTED(d->ln_colsum == nullptr, "af_gemm: a folded LayerNorm (ln_colsum) needs a whole-line tile (7 .. 13) whose scope covers the shape, "
+  AF_SUPPORTED(d->ln_colsum == nullptr, "af_gemm: a folded LayerNorm (ln_colsum) needs a whole-line tile (7 .. 13, 16, 17) whose scope covers the shape, "
                                         "taps == 1, c2 == 0 and no split-K");
   if (geglu) return d->taps == 9 ? af_fail(AF_E_UNSUPPORTED, "af_gemm: GEGLU on a 3x3 conv")
                                  : launch_tile<1, EPI_GEGLU>(p, tile, s);

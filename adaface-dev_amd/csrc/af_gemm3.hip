@@ -1408,7 +1408,7 @@ int af_gemm3_try_launch(const af_gemm_desc* d, int splits, int wide, hipStream_t
   // 9 / 10 = 128 x 128 / 128 x 160 with a four-slot ring (three stages in flight, one workgroup per CU)
   const bool geglu = d->act == AF_ACT_GEGLU, split_t = d->out_mode == AF_OUT_SPLIT_T;
   if (wide == 11 && !conv3h_eligible(d)) return 1;              // halo-resident 3x3 kernel (tile 14)
-  if (d->upsample && !((wide == 4 || wide == 5 || wide >= 8) && d->upsample == 1 && d->taps == 9)) return 1;   // nearest x2: whole-line kernel only
+  if (d->upsample && !((wide == 4 || wide == 5 || (wide >= 8 && wide <= 12)) && d->upsample == 1 && d->taps == 9)) return 1;   // nearest x2: whole-line kernel only
   if (d->c1 % BK3 != 0 || d->c2 % BK3 != 0 || d->zeros == nullptr) return 1;
   if (d->c3 > 0 && (wide < 4 || (wide > 10 && wide != 12) || d->taps != 9 || d->upsample || (d->stride != 0 && d->stride != 1))) return 1;   // K tail: whole-line tap-by-tap tiles
   if ((geglu || split_t) && (d->taps != 1 || splits > 1)) return 1;
@@ -1423,7 +1423,9 @@ int af_gemm3_try_launch(const af_gemm_desc* d, int splits, int wide, hipStream_t
     if ((wide == 8 || wide == 10) && (geglu || split_t || d->N % 160 != 0)) return 1;
     if (wide == 9 && (geglu || split_t)) return 1;
     if (wide == 12 && (geglu || split_t || d->N % 128 != 0)) return 1;        // 256 x 128, 8 waves as 4 x 2 (tile 15): standard epilogue
-    if (wide > 12) return 1;
+    if (wide == 13 && (geglu || split_t || d->N % 128 != 0 || d->c3 > 0)) return 1;   // 64 x 128, 4 waves as 1 x 4 (tile 16): up to three workgroups per CU
+    if (wide == 14 && (geglu || split_t || d->N % 64 != 0 || d->c3 > 0)) return 1;    // 128 x 64, 4 waves as 2 x 2 (tile 17)
+    if (wide > 14) return 1;
   }
   if (wide == 2 && (d->N % 256 != 0 || d->taps != 1 || split_t || splits > 1)) return 1;
   if (wide == 3 && (d->N % 320 != 0 || d->taps != 1 || split_t || splits > 1)) return 1;
@@ -1525,6 +1527,11 @@ int af_gemm3_try_launch(const af_gemm_desc* d, int splits, int wide, hipStream_t
       if (d->taps == 9) fused = launch3w<9, 2, 2, 4, E3_STD, 4>(p, stream); else fused = launch3w<1, 2, 2, 4, E3_STD, 4>(p, stream);
     } else if (wide == 12) {                                 // 256 x 128, 8 waves as 4 x 2, one workgroup per CU: narrow outputs over many rows (the VAE decoder's convolutions)
       if (d->taps == 9) fused = launch3w<9, 4, 2, 4>(p, stream); else fused = launch3w<1, 4, 2, 4>(p, stream);
+    } else if (wide == 13) {                                 // 64 x 128, 4 waves side by side: 25 KB stages, three workgroups per CU -- short-K GEMMs whose
+                                                             // step is a memory round trip live on the OTHER workgroups' MFMAs (profiles/r04y_small_tiles.txt)
+      if (d->taps == 9) fused = launch3w<9, 1, 4, 2>(p, stream); else fused = launch3w<1, 1, 4, 2>(p, stream);
+    } else if (wide == 14) {                                 // 128 x 64, 4 waves as 2 x 2
+      if (d->taps == 9) fused = launch3w<9, 2, 2, 2>(p, stream); else fused = launch3w<1, 2, 2, 2>(p, stream);
     } else if (wide == 10) {                                 // 128 x 160, 4 waves, four slots
       if (d->taps == 9) fused = launch3w<9, 2, 2, 5, E3_STD, 4>(p, stream); else fused = launch3w<1, 2, 2, 5, E3_STD, 4>(p, stream);
     } else {

@@ -232,9 +232,9 @@ def _launch_gemm(d: "GemmDesc", device, what: str, tile: int = 0, splits: int = 
             if d.ln_colsum and tile == 0:
                 tile, splits = tune_table().get(key[:-3], (0, 1))
     if d.ln_colsum:
-        # the folded LayerNorm lives in the whole-line kernel only (tiles 7 .. 13), unsplit
+        # the folded LayerNorm lives in the whole-line kernel only (tiles 7 .. 13, 16, 17), unsplit
         splits = 1
-        if tile < 7 or tile > 13 or (tile in (9, 10) and d.act != AF_ACT_GEGLU):
+        if tile < 7 or tile in (14, 15) or tile > 17 or (tile in (9, 10) and d.act != AF_ACT_GEGLU) or (tile in (16, 17) and d.act == AF_ACT_GEGLU):
             if d.act == AF_ACT_GEGLU:
                 tile = 7 if d.N % 256 == 0 else 8
             else:

@@ -290,6 +290,38 @@ def test_conv3x3_and_gemm_tile15_256x128(dev, B, H, W, c1, c2, cout, ups, splits
     assert rel_l2(og.float().cpu().numpy(), F.silu(a.float() @ wm.float().t() + bias).numpy()) < TOL
 
 
+@pytest.mark.parametrize("tile", [16, 17])
+@pytest.mark.parametrize("M,N,K,splits,ln", [(8192, 640, 640, 1, False), (2048 + 40, 1280, 1280, 1, True), (512, 1280, 1280, 3, False), (4096, 320, 320, 1, True), (100, 128, 192, 1, False)])
+def test_gemm_and_conv_small_tiles_16_17(dev, tile, M, N, K, splits, ln):
+    """Tiles 16 / 17 of the whole-line kernel (64 x 128 / 128 x 64, four waves, three workgroups per CU): plain GEMM with bias / SiLU / residual,
+    split-K, M not a multiple of the tile, the folded LayerNorm; and a 3x3 convolution with two sources."""
+    from adaface_dev_amd import ops
+    a, w = rnd((M, K), 1), rnd((N, K), 2, K ** -0.5)
+    bias = torch.randn(N, generator=torch.Generator().manual_seed(3))
+    res = rnd((M, N), 4)
+    if N % (128 if tile == 16 else 64) != 0:            # outside the tile's scope: a folded LayerNorm is refused (nothing else could take it), a plain GEMM falls back
+        with pytest.raises(RuntimeError, match="folded LayerNorm"):
+            ops.gemm(a.to(dev), ops.pack_matrix_ln(w, bias, torch.ones(K), torch.zeros(K), 1e-5, dev), tile=tile)
+        return
+    if ln:
+        gam = torch.randn(K, generator=torch.Generator().manual_seed(5)) * 0.2 + 1
+        bet = torch.randn(K, generator=torch.Generator().manual_seed(6)) * 0.2
+        out = ops.gemm(a.to(dev), ops.pack_matrix_ln(w, bias, gam, bet, 1e-5, dev), residual=res.to(dev), tile=tile)
+        ref = F.layer_norm(a.float(), (K,), gam, bet, 1e-5) @ w.float().t() + bias + res.float()
+    else:
+        out = ops.gemm(a.to(dev), ops.pack_matrix(w, bias, dev), act=ops.AF_ACT_SILU, residual=res.to(dev), tile=tile, splits=splits)
+        ref = F.silu(a.float() @ w.float().t() + bias) + res.float()
+    assert rel_l2(out.float().cpu().numpy(), ref.numpy()) < TOL
+    if M == 8192:
+        B, H, W, c1, c2 = 2, 16, 16, 64, 64
+        x1, x2 = rnd((B, H, W, c1), 7), rnd((B, H, W, c2), 8)
+        wc = rnd((N, c1 + c2, 3, 3), 9, (9 * (c1 + c2)) ** -0.5)
+        rowb = rnd((B, N), 10)
+        y = ops.conv3x3(x1.to(dev), ops.pack_conv3x3(wc, bias, dev), x2=x2.to(dev), rowbias=rowb.to(dev), tile=tile)
+        refc = F.conv2d(torch.cat([x1, x2], -1).float().permute(0, 3, 1, 2), wc.float(), bias, padding=1) + rowb.float()[:, :, None, None]
+        assert rel_l2(y.float().cpu().permute(0, 3, 1, 2).numpy(), refc.numpy()) < TOL
+
+
 def test_conv3x3_tile14_falls_back_outside_its_scope(dev):
     """stride 2 / two sources / widths it does not take: the descriptor's fallback (tile 1) computes the same convolution."""
     from adaface_dev_amd import ops

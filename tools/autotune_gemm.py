@@ -31,6 +31,8 @@ def candidate_ok(d, tile, splits, _lib, ops):
         return False                        # halo-resident 3x3 kernel: its split-K slices are 64-channel chunks
     if tile >= 7 and (d.upsample not in (0, 1) or (d.upsample and tile not in (7, 8, 11, 12, 13, 15)) or d.c1 % 64 or d.c2 % 64):
         return False                        # whole-line kernel: 64-multiples of channels; nearest-x2 upsample in the non-GEGLU tiles
+    if tile in (16, 17) and (geglu or d.out_mode == _lib.AF_OUT_SPLIT_T or d.N % (128 if tile == 16 else 64) != 0 or d.c3 or d.c4):
+        return False                        # 64 x 128 / 128 x 64, four waves, three workgroups per CU: standard epilogue, no K tail
     if tile in (11, 13) and (geglu or d.out_mode == _lib.AF_OUT_SPLIT_T or d.N % 160 != 0):
         return False                        # 128 x 160, four waves (11: two workgroups per CU; 13: four-slot ring)
     if tile == 15 and (geglu or d.out_mode == _lib.AF_OUT_SPLIT_T or d.N % 128 != 0 or d.M < 16384):
@@ -47,7 +49,7 @@ def candidate_ok(d, tile, splits, _lib, ops):
         return False                        # 256-row ring tiles: plain / GEGLU 1x1 GEMMs with at least ~128 tiles
     if (d.c3 or d.c4) and not (7 <= tile <= 13 or tile == 15):
         return False                        # the K-concatenated 1x1 tail lives in the whole-line tiles
-    if d.ln_colsum and (tile < 7 or tile > 13 or splits > 1 or (tile in (9, 10) and not geglu)):
+    if d.ln_colsum and (tile < 7 or tile in (14, 15) or splits > 1 or (tile in (9, 10) and not geglu)):
         return False                        # folded LayerNorm: whole-line tiles, unsplit
     f32 = d.out_mode == _lib.AF_OUT_F32     # weight gradients: fp32 from the reduce pass, or unsplit from tiles 1 / 2
     if f32 and splits == 1 and tile > 2:
@@ -162,7 +164,7 @@ def main():
         retuned.add(key)
         nk = d.kpad // 64
         best, best_t, res = (0, 1), None, {}
-        for tile in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15):
+        for tile in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17):
             geglu = d.act == _lib.AF_ACT_GEGLU
             if args.tiles and str(tile) not in args.tiles.split(","):
                 continue
@@ -176,6 +178,8 @@ def main():
                 continue                        # 256 x 128, eight waves: narrow outputs over many rows
             if tile == 12 and (geglu or d.out_mode == _lib.AF_OUT_SPLIT_T):
                 continue                        # 128 x 128 with a four-slot ring
+            if tile in (16, 17) and not candidate_ok(d, tile, 1, _lib, ops):
+                continue                        # 64 x 128 / 128 x 64: three workgroups per CU
             if tile == 7 and (d.N % (256 if geglu else 320) != 0):
                 continue
             if tile == 8 and geglu:

@@ -133,7 +133,7 @@ def main():
             if key not in shortlist and key not in protected:
                 cur = (d.tile, d.splits)                           # what the live path chose for this launch (table, LayerNorm-fold rule, heuristic)
                 res = {}
-                for tile in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15):
+                for tile in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17):
                     for splits in (1, 2, 3, 4, 6, 8, 12, 16):
                         if (tile, splits) == cur or not candidate_ok(d, tile, splits, _lib, ops):
                             continue
