@@ -1,14 +1,14 @@
 #!/bin/bash
-# In-step tuning of the training legs' GEMM shapes (distillation, recon, Stage 2), the denoise step's shapes protected; then the legs with the in-tree
+# In-step tuning of the training legs' GEMM shapes (distillation, Stage 2, recon), the denoise step's shapes protected; then the legs with the in-tree
 # table and the new one alternating on this box.
-P=profiles/r04w_instep_pass1.log,profiles/r04w_instep_pass2.log
-python tools/autotune_instep.py --leg distill --keep 3 --reps 3 --protect $P --out gpurun_out/r04x_t1.json --log gpurun_out/r04x_instep_distill.log > gpurun_out/r04x_distill.out 2>&1
+P=profiles/r04w_instep_pass1.log,profiles/r04w_instep_pass2.log,profiles/r04y_instep_small_tiles.log
+python tools/autotune_instep.py --leg distill --keep 4 --reps 3 --protect $P --out gpurun_out/r04x_t1.json --log gpurun_out/r04x_instep_distill.log > gpurun_out/r04x_distill.out 2>&1
 tail -2 gpurun_out/r04x_distill.out
-AF_TUNE_TABLE=$PWD/gpurun_out/r04x_t1.json python tools/autotune_instep.py --leg train2 --keep 3 --reps 2 --protect $P,gpurun_out/r04x_instep_distill.log --out gpurun_out/r04x_t2.json --log gpurun_out/r04x_instep_train2.log > gpurun_out/r04x_train2.out 2>&1
+AF_TUNE_TABLE=$PWD/gpurun_out/r04x_t1.json python tools/autotune_instep.py --leg train2 --keep 4 --reps 2 --protect $P,gpurun_out/r04x_instep_distill.log --out gpurun_out/r04x_t2.json --log gpurun_out/r04x_instep_train2.log > gpurun_out/r04x_train2.out 2>&1
 tail -2 gpurun_out/r04x_train2.out
-AF_TUNE_TABLE=$PWD/gpurun_out/r04x_t2.json python tools/autotune_instep.py --leg recon --keep 3 --reps 2 --protect $P,gpurun_out/r04x_instep_distill.log,gpurun_out/r04x_instep_train2.log --out gpurun_out/r04x_t3.json --log gpurun_out/r04x_instep_recon.log > gpurun_out/r04x_recon.out 2>&1
+AF_TUNE_TABLE=$PWD/gpurun_out/r04x_t2.json python tools/autotune_instep.py --leg recon --keep 4 --reps 2 --protect $P,gpurun_out/r04x_instep_distill.log,gpurun_out/r04x_instep_train2.log --out gpurun_out/r04x_t3.json --log gpurun_out/r04x_instep_recon.log > gpurun_out/r04x_recon.out 2>&1
 tail -2 gpurun_out/r04x_recon.out
-for i in 1 2; do
+for i in 1 2 3; do
   for t in tree new; do
     unset AF_TUNE_TABLE
     [ $t = new ] && export AF_TUNE_TABLE=$PWD/gpurun_out/r04x_t3.json
