@@ -530,6 +530,7 @@ def test_conv3x3_padded_input_channels(dev):
     (8, 4096, 320, 0, 1e-5, True), (8, 4096, 640, 0, 1e-5, True), (8, 4096, 640, 320, 1e-5, True), (8, 1024, 640, 320, 1e-5, True),     # the denoise step's
     (8, 1024, 1280, 0, 1e-5, False), (4, 4096, 640, 320, 1e-5, True), (5, 4000, 320, 0, 1e-6, True), (1, 4096, 128, 0, 1e-6, True),    # two-launch shapes ...
     (2, 16384, 256, 0, 1e-6, True), (1, 65536, 128, 0, 1e-6, True),                                                                   # ... and the VAE decoder's
+    (1, 4096, 640, 320, 1e-5, True), (1, 4096, 320, 320, 1e-5, False), (2, 1024, 1280, 1280, 1e-5, True), (1, 4000, 320, 0, 1e-6, True),  # few batch items: the re-reading one-launch form
 ])
 def test_groupnorm(dev, B, HW, c1, c2, eps, silu):
     from adaface_dev_amd import ops

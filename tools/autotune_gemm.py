@@ -41,8 +41,8 @@ def candidate_ok(d, tile, splits, _lib, ops):
         return False                        # 128 x 128 with a four-slot ring
     if tile == 7 and (d.N % (256 if geglu else 320) != 0):
         return False
-    if tile == 8 and geglu:
-        return False
+    if tile == 8 and geglu and d.N % 128 != 0:
+        return False                        # GEGLU on the 128 x 128 tile (two workgroups per CU): value | gate pairs of 64 output columns
     if tile in (9, 10) and (not geglu or d.N % (320 if tile == 9 else 256) != 0):
         return False
     if tile in (5, 6) and (d.taps != 1 or d.out_mode != 0 or d.M * d.N < 256 * 256 * 128 or splits > 1):

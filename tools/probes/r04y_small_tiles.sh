@@ -1,7 +1,5 @@
 #!/bin/bash
-# Tiles 16 / 17 (64 x 128 / 128 x 64, three workgroups per CU): kernel tests, then an in-step pass of the denoise step with them in the candidate set,
-# then the in-tree table and the new one alternating.
-python -m pytest tests/test_hip_kernels.py -m gpu -q -x -p no:cacheprovider -k "small_tiles_16_17" 2>&1 | tail -2
+# One more in-step pass of the denoise step (GEGLU on the 128 x 128 tile admitted), then the in-tree table and the new one alternating.
 python tools/autotune_instep.py --keep 9 --out gpurun_out/r04y_table.json --log gpurun_out/r04y_instep.log > gpurun_out/r04y_instep.out 2>&1
 tail -2 gpurun_out/r04y_instep.out
 for i in 1 2 3; do
