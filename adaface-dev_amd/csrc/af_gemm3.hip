@@ -1423,8 +1423,8 @@ int af_gemm3_try_launch(const af_gemm_desc* d, int splits, int wide, hipStream_t
     if ((wide == 8 || wide == 10) && (geglu || split_t || d->N % 160 != 0)) return 1;
     if (wide == 9 && (geglu || split_t)) return 1;
     if (wide == 12 && (geglu || split_t || d->N % 128 != 0)) return 1;        // 256 x 128, 8 waves as 4 x 2 (tile 15): standard epilogue
-    if (wide == 13 && (geglu || split_t || d->N % 128 != 0 || d->c3 > 0)) return 1;   // 64 x 128, 4 waves as 1 x 4 (tile 16): up to three workgroups per CU
-    if (wide == 14 && (geglu || split_t || d->N % 64 != 0 || d->c3 > 0)) return 1;    // 128 x 64, 4 waves as 2 x 2 (tile 17)
+    if (wide == 13 && (geglu || d->N % 128 != 0 || d->c3 > 0)) return 1;   // 64 x 128, 4 waves as 1 x 4 (tile 16): up to three workgroups per CU
+    if (wide == 14 && (geglu || d->N % 64 != 0 || d->c3 > 0)) return 1;    // 128 x 64, 4 waves as 2 x 2 (tile 17)
     if (wide > 14) return 1;
   }
   if (wide == 2 && (d->N % 256 != 0 || d->taps != 1 || split_t || splits > 1)) return 1;
@@ -1529,9 +1529,11 @@ int af_gemm3_try_launch(const af_gemm_desc* d, int splits, int wide, hipStream_t
       if (d->taps == 9) fused = launch3w<9, 4, 2, 4>(p, stream); else fused = launch3w<1, 4, 2, 4>(p, stream);
     } else if (wide == 13) {                                 // 64 x 128, 4 waves side by side: 25 KB stages, three workgroups per CU -- short-K GEMMs whose
                                                              // step is a memory round trip live on the OTHER workgroups' MFMAs (profiles/r04y_small_tiles.txt)
-      if (d->taps == 9) fused = launch3w<9, 1, 4, 2>(p, stream); else fused = launch3w<1, 1, 4, 2>(p, stream);
+      if (split_t) fused = launch3w<1, 1, 4, 2, E3_SPLIT_T>(p, stream);
+      else if (d->taps == 9) fused = launch3w<9, 1, 4, 2>(p, stream); else fused = launch3w<1, 1, 4, 2>(p, stream);
     } else if (wide == 14) {                                 // 128 x 64, 4 waves as 2 x 2
-      if (d->taps == 9) fused = launch3w<9, 2, 2, 2>(p, stream); else fused = launch3w<1, 2, 2, 2>(p, stream);
+      if (split_t) fused = launch3w<1, 2, 2, 2, E3_SPLIT_T>(p, stream);
+      else if (d->taps == 9) fused = launch3w<9, 2, 2, 2>(p, stream); else fused = launch3w<1, 2, 2, 2>(p, stream);
     } else if (wide == 10) {                                 // 128 x 160, 4 waves, four slots
       if (d->taps == 9) fused = launch3w<9, 2, 2, 5, E3_STD, 4>(p, stream); else fused = launch3w<1, 2, 2, 5, E3_STD, 4>(p, stream);
     } else {

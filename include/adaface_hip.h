@@ -128,7 +128,7 @@ typedef struct af_gemm_desc {
                            64-channel chunks).  Outside that scope it falls back to tile 1 */
                         /* 15 = whole-line kernel, 256 x 128 tile of eight waves (4 x 2; N % 128 == 0; standard epilogue, taps 1 / 9, nearest x2): 85 instead of
                            64 FLOP per operand byte for narrow outputs over many rows (the VAE decoder's 128- / 256-channel convolutions at 256^2 / 512^2) */
-                        /* 16 / 17 = whole-line kernel, 64 x 128 / 128 x 64 tile of four waves (1 x 4 / 2 x 2; N % 128 / 64 == 0; standard epilogue, folded
+                        /* 16 / 17 = whole-line kernel, 64 x 128 / 128 x 64 tile of four waves (1 x 4 / 2 x 2; N % 128 / 64 == 0; standard and transposed-V-split epilogues, folded
                            LayerNorm, taps 1 / 9, no nearest x2, no K tail): 25 KB stages, so THREE workgroups share a CU -- a short-K GEMM's K step is a
                            memory round trip, and what hides it is the other workgroups' MFMAs, not a deeper ring */
   int32_t splits;       /* split-K factor (<=1: none).  >1 needs the standard epilogue and a workspace:

@@ -432,13 +432,14 @@ def test_gemm_concat_k_and_silu(dev):
     assert rel_l2(out.float().cpu().numpy(), ref.numpy()) < TOL
 
 
-@pytest.mark.parametrize("tile,tokens,pad", [(4, 100, 0), (7, 100, 0), (7, 256, 0), (7, 384, 8), (8, 256, 16), (8, 1024, 0), (7, 128, 8)])
+@pytest.mark.parametrize("tile,tokens,pad", [(4, 100, 0), (7, 100, 0), (7, 256, 0), (7, 384, 8), (8, 256, 16), (8, 1024, 0), (7, 128, 8),
+                                             (17, 256, 0), (17, 384, 8), (17, 100, 0), (16, 256, 8), (16, 192, 0), (16, 100, 0)])
 def test_gemm_split_transposed_wide_tile4(dev, tile, tokens, pad):
     """q | k | v projection with V written transposed.  tokens % 128 == 0 takes the whole-line kernel's STAGED epilogues (q | k tiles as 16-byte row
     chunks, V tiles transposed in LDS and written as 16-byte token runs); other token counts the direct one.  With a padded ld_out2 the row pad of
     V^T is part of the output: zero, although the buffer came from a NaN-poisoned torch.empty (conftest)."""
     from adaface_dev_amd import ops
-    B, C, K = 2, 320, 320
+    B, C, K = 2, (640 if tile == 16 else 320), 320          # tile 16's width is 128: C = 640 (q | k | v = 15 tiles)
     a, w = rnd((B * tokens, K), 1), rnd((3 * C, K), 2, K ** -0.5)
     b = torch.randn(3 * C, generator=torch.Generator().manual_seed(3)) * 0.3
     ld2 = ops.round_up(tokens, 8) + pad

@@ -1,5 +1,6 @@
 #!/bin/bash
-# One more in-step pass of the denoise step (GEGLU on the 128 x 128 tile admitted), then the in-tree table and the new one alternating.
+# Small tiles with the transposed-V split: tests, one more in-step pass of the denoise step, then the in-tree table and the new one alternating.
+python -m pytest tests/test_hip_kernels.py -m gpu -q -x -p no:cacheprovider -k "split_transposed or folded_layernorm" 2>&1 | tail -2
 python tools/autotune_instep.py --keep 9 --out gpurun_out/r04y_table.json --log gpurun_out/r04y_instep.log > gpurun_out/r04y_instep.out 2>&1
 tail -2 gpurun_out/r04y_instep.out
 for i in 1 2 3; do
