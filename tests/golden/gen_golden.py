@@ -925,7 +925,7 @@ def _ref_arcface_shell(detect):
     return aw
 
 
-STAGE2_DETECTORS = ("standin_detect", "no_faces", "standin_detect_small_second_face")
+STAGE2_DETECTORS = ("standin_detect", "no_faces", "standin_detect_small_second_face", "standin_detect_dark_images_faceless")
 
 
 def gen_stage2_assembly(out):

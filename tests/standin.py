@@ -170,6 +170,14 @@ def standin_detect_small_second_face(image_np, T=20):
     return standin_detect(image_np, T) + [(4.0, 4.0, 30.0, 28.0, 0.93)]
 
 
+def standin_detect_dark_images_faceless(image_np, T=20):
+    """As standin_detect, but an image whose mean brightness is below 100 shows no face.  In the recon scenario (stage2_scenario.recon_inputs) the
+    second instance's x0 prediction of the first denoising step is such an image (mean 75 against ~126 for the others): a PARTIALLY detected
+    batch, which is where the instance weights of the recon loss matter (reference ddpm.py:2738-2739: a LONG mask, so the 0.1 meant for
+    instances without a face truncates to 0)."""
+    return [] if image_np.astype("float64").mean() < 100.0 else standin_detect(image_np, T)
+
+
 def standin_decode(z):
     """Plays the VAE decoder: latent [B, 4, h, w] -> image [B, 3, 8h, 8w] in about [-1, 1], differentiable."""
     return F.interpolate(torch.tanh(z[:, :3] * 0.9 + 0.2 * z[:, 3:4]), scale_factor=8, mode="bilinear", align_corners=False)

@@ -16,7 +16,7 @@ import stage2_scenario as SC
 import standin
 from conftest import GOLDEN, rel_l2
 
-DETECTORS = ("standin_detect", "no_faces", "standin_detect_small_second_face")
+DETECTORS = ("standin_detect", "no_faces", "standin_detect_small_second_face", "standin_detect_dark_images_faceless")
 
 
 def mirror_shell(device, dname, torch_q_sample=False):
