@@ -10,6 +10,7 @@ The loss assemblies of the compositional-distillation and normal-recon iteration
 ``device``, ``q_sample``, ``apply_model``, ``model.diffusion_model``) keep working.
 """
 import copy
+import os
 from functools import partial
 
 import numpy as np
@@ -388,6 +389,7 @@ class LatentDiffusion(CompReconLossesMixin, nn.Module):
     # ------------------------------------------------------------------ Stage-1 distillation (ddpm.py:1597-1750, 2984-3184)
     unet_distill_weight = 8          # ddpm.py:2367
     batch_student_steps = True       # one student U-Net call for all denoising steps of a micro-batch
+    batch_no_grad_instances = os.environ.get("AF_BATCH_NO_GRAD", "1") != "0"   # subject-compos steps: SS + SR as one no-grad pass where their flags agree
     res_hidden_states_gradscale = 0.5   # reference ctor default (ddpm.py:140): gradient scale of the decoder's skip inputs
 
     def guided_denoise(self, x_start, noise, t, cond_context, uncond_emb=None, img_mask=None, subj_indices=None,
@@ -429,9 +431,18 @@ class LatentDiffusion(CompReconLossesMixin, nn.Module):
                 ei.update(flags)
                 return (cond_context[0], cond_context[1], ei)
             ctx_ss = context_with(normalize_cross_attn=False, mix_attn_mats_in_batch=False)
-            noise_pred_ss = self.sliced_apply_model(x_noisy, t, ctx_ss, slice_indices=[0], enable_grad=False, **lora)
             ctx_sr = context_with(normalize_cross_attn=normalize_cross_attn, mix_attn_mats_in_batch=False)
-            noise_pred_sr = self.sliced_apply_model(x_noisy, t, ctx_sr, slice_indices=[2], enable_grad=False, **lora)
+            if self.batch_no_grad_instances and not normalize_cross_attn:
+                # SS and SR run without gradient under the SAME flags whenever SR's scores are not normalised (always while SC / MC scores
+                # are mixed): one pass over the two instances instead of two passes over one -- half the launches, twice the rows per launch
+                noise_pred_2 = self.sliced_apply_model(x_noisy, t, ctx_ss, slice_indices=[0, 2], enable_grad=False, **lora)
+                noise_pred_ss, noise_pred_sr = noise_pred_2.chunk(2, dim=0)
+                if "ca_layers_activations" in ctx_ss[2]:
+                    ss_acts, sr_acts = split_dict(ctx_ss[2]["ca_layers_activations"], 2)
+                    ctx_ss[2]["ca_layers_activations"], ctx_sr[2]["ca_layers_activations"] = ss_acts, sr_acts
+            else:
+                noise_pred_ss = self.sliced_apply_model(x_noisy, t, ctx_ss, slice_indices=[0], enable_grad=False, **lora)
+                noise_pred_sr = self.sliced_apply_model(x_noisy, t, ctx_sr, slice_indices=[2], enable_grad=False, **lora)
             if mix_sc_mc_attn:
                 ctx_sm = context_with(normalize_cross_attn=False, mix_attn_mats_in_batch=True)
                 noise_pred_sm = self.sliced_apply_model(x_noisy, t, ctx_sm, slice_indices=[1, 3], enable_grad=True, use_attn_lora=False,
