@@ -455,11 +455,12 @@ class CompReconLossesMixin:
             x_start, t, noise = x_starts[i], ts[i], noises[i]
             priming = i < num_priming_steps
             context = cls_context if (priming and cls_context is not None and i % 2 == 0) else subj_context
+            uc = {} if self.cache_uncond_in_step else None      # this step's null-prompt prediction, shared by its guided passes
             noise_pred, x_recon, acts = self.guided_denoise(
                 x_start, noise, t, context, uncond_emb, img_mask, subj_indices=None, normalize_cross_attn=False, mix_sc_mc_attn=False,
                 batch_part_has_grad="none" if priming else "all", do_pixel_recon=True, cfg_scale=cfg_scale, capture_ca_activations=not priming,
                 res_hidden_states_gradscale=self.res_hidden_states_gradscale, use_attn_lora=enable_unet_attn_lora,
-                use_ffn_lora=enable_unet_ffn_lora and not priming, ffn_lora_adapter_name=ffn_lora_adapter_name)
+                use_ffn_lora=enable_unet_ffn_lora and not priming, ffn_lora_adapter_name=ffn_lora_adapter_name, uncond_cache=uc)
             noise_preds.append(noise_pred)
             acts_list.append(acts)
             x_recons.append(x_recon)
@@ -469,7 +470,7 @@ class CompReconLossesMixin:
                     x_start, noise, t, cls_context, uncond_emb, img_mask, subj_indices=None, normalize_cross_attn=False, mix_sc_mc_attn=False,
                     batch_part_has_grad="none", do_pixel_recon=True, cfg_scale=cfg_scale, capture_ca_activations=False,
                     res_hidden_states_gradscale=0, use_attn_lora=enable_unet_attn_lora, use_ffn_lora=enable_unet_ffn_lora,
-                    ffn_lora_adapter_name=ffn_lora_adapter_name)
+                    ffn_lora_adapter_name=ffn_lora_adapter_name, uncond_cache=uc)
                 noise_preds_cls.append(eps_cls)
                 x_recons_cls.append(x_cls)
             if i < num_denoising_steps - 1:

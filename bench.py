@@ -265,15 +265,17 @@ def run_train(args, ctx, dev, stage=1):
                     "with HALF_BS=ceil(bs/steps), teacher+student SD-1.5 U-Nets, 3 CLIP-L encoders, "
                     f"{n_train} trainable fp32 params, accumulate_grad_batches=2, CAdamW")
         if stage == 1 and not args.distill_only:
-            # a recon micro-batch on images: 2 denoising steps x (student fwd + bwd on bs 4, its CFG null pass, the class-prompt pass and
-            # its null pass) = 2 x 20 sample-forward equivalents; on pure noise (p = 0.4) four no-grad priming steps (16 each) come first
-            recon_fwd = 0.6 * 40 + 0.4 * (4 * 16 + 40)
+            # a recon micro-batch on images: 2 denoising steps x (student fwd + bwd on bs 4, the CFG null pass, the class-prompt pass) = 2 x 16
+            # sample-forward equivalents; on pure noise (p = 0.4) four no-grad priming steps (12 each) come first.  (The reference runs the
+            # null-prompt pass twice per step with identical arguments -- after the subject pass and after the class-prompt pass; here the
+            # second request takes the first one's tensor, ddpm.guided_denoise(uncond_cache=...), and the count below is of the passes that run.)
+            recon_fwd = 0.6 * 32 + 0.4 * (4 * 12 + 32)
             train_tflop = 0.5 * train_tflop + 0.5 * recon_fwd * 0.80496
             what = (f"mean over the reference's Stage-1 iteration mix (micro-batches alternate normal recon / U-Net distillation): "
                     f"{train_tflop:.1f} TFLOP algorithmic per micro-batch on average (U-Net passes only; the recon iterations' VAE decodes and "
                     "ResNetFace-18 passes are not counted) / wall time")
             workload = ("the reference's Stage-1 iteration mix, unet_distill_iter_gap = 2 (v1-distill-arc2face-ada.yaml:28): micro-batches alternate "
-                        f"do_normal_recon (bs {B}: 2 denoising steps with CFG + class-prompt passes + capture of layers 22-24, on the images or, p = 0.4, "
+                        f"do_normal_recon (bs {B}: 2 denoising steps with CFG + class-prompt passes + capture of layers 22-24 -- the null-prompt pass of a step computed once for both guided passes --, on the images or, p = 0.4, "
                         "from pure noise after 4 priming steps; x0 decoded for the face pipeline) and do_unet_distill (" + workload + ")")
         if stage == 2:
             # priming: 3.5 steps x (positive + negative pass at batch 2) = 14 sample forwards; student: 4 steps x (SS + SR + SC + MC
