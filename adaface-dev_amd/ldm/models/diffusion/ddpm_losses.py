@@ -465,7 +465,14 @@ class CompReconLossesMixin:
             acts_list.append(acts)
             x_recons.append(x_recon)
             x_starts.append(x_recon if (normal_recon_on_pure_noise or priming) else x_start0)
-            if cls_context is not None:
+            if cls_context is not None and self.cache_uncond_in_step and priming:
+                # the class-prompt prediction of a PRIMING step is read by nobody (the losses start at step num_priming_steps, and the chain
+                # continues from the main pass): the reference computes it all the same -- on even priming steps it even is the main pass
+                # over again, argument for argument; here the slot keeps the main pass's tensors where they are that, None otherwise
+                same = context is cls_context and not enable_unet_ffn_lora
+                noise_preds_cls.append(noise_pred if same else None)
+                x_recons_cls.append(x_recon if same else None)
+            elif cls_context is not None:
                 eps_cls, x_cls, _ = self.guided_denoise(
                     x_start, noise, t, cls_context, uncond_emb, img_mask, subj_indices=None, normalize_cross_attn=False, mix_sc_mc_attn=False,
                     batch_part_has_grad="none", do_pixel_recon=True, cfg_scale=cfg_scale, capture_ca_activations=False,

@@ -266,10 +266,11 @@ def run_train(args, ctx, dev, stage=1):
                     f"{n_train} trainable fp32 params, accumulate_grad_batches=2, CAdamW")
         if stage == 1 and not args.distill_only:
             # a recon micro-batch on images: 2 denoising steps x (student fwd + bwd on bs 4, the CFG null pass, the class-prompt pass) = 2 x 16
-            # sample-forward equivalents; on pure noise (p = 0.4) four no-grad priming steps (12 each) come first.  (The reference runs the
-            # null-prompt pass twice per step with identical arguments -- after the subject pass and after the class-prompt pass; here the
-            # second request takes the first one's tensor, ddpm.guided_denoise(uncond_cache=...), and the count below is of the passes that run.)
-            recon_fwd = 0.6 * 32 + 0.4 * (4 * 12 + 32)
+            # sample-forward equivalents; on pure noise (p = 0.4) four no-grad priming steps (8 each: the pass + its null pass) come first.
+            # (The reference runs the null-prompt pass twice per step with identical arguments -- after the subject pass and after the
+            # class-prompt pass; here the second request takes the first one's tensor, ddpm.guided_denoise(uncond_cache=...) -- and a
+            # class-prompt pass in every priming step whose result nothing reads; the count below is of the passes that run.)
+            recon_fwd = 0.6 * 32 + 0.4 * (4 * 8 + 32)
             train_tflop = 0.5 * train_tflop + 0.5 * recon_fwd * 0.80496
             what = (f"mean over the reference's Stage-1 iteration mix (micro-batches alternate normal recon / U-Net distillation): "
                     f"{train_tflop:.1f} TFLOP algorithmic per micro-batch on average (U-Net passes only; the recon iterations' VAE decodes and "
