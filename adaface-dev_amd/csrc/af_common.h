@@ -85,6 +85,36 @@ __device__ __forceinline__ float af_wave_max(float v) {
   return v;
 }
 
+// ---- GroupNorm partial statistics (round 5) --------------------------------------------------------------------------------------------------
+// A partial is (sum, M2) of a block of n values, M2 = sum of squares ABOUT THE BLOCK'S OWN MEAN.  Blocks are merged pairwise (Chan et al.):
+//     M2 = M2_a + M2_b + (mean_b - mean_a)^2 n_a n_b / (n_a + n_b)
+// so nothing of the form E[x^2] - mean^2 is ever formed across blocks: that difference loses log2((mean / sigma)^2) bits, which in fp32 is every bit of
+// the variance of a group with |mean| / sigma ~ 1000 and a 10 % error at 100 (the reference is torch's fp32 group_norm, util.py:195-212, which
+// does not cancel).  A producer gets its (sum, M2) from sums SHIFTED by a pivot p taken inside the block (any element: |p - mean| is a few sigma):
+//     s' = sum(x - p), q' = sum((x - p)^2)  ->  sum = n p + s',  M2 = q' - s'^2 / n.
+struct GnAcc {
+  float n, s, m2;
+};
+__device__ __forceinline__ GnAcc gn_acc_merge(const GnAcc a, const GnAcc b) {
+  if (b.n <= 0.f) return a;
+  if (a.n <= 0.f) return b;
+  const float n = a.n + b.n;
+  const float d = b.s * __builtin_amdgcn_rcpf(b.n) - a.s * __builtin_amdgcn_rcpf(a.n);
+  GnAcc r;
+  r.n = n;
+  r.s = a.s + b.s;
+  r.m2 = a.m2 + b.m2 + d * d * (a.n * b.n * __builtin_amdgcn_rcpf(n));
+  return r;
+}
+// shifted sums of n values about pivot p -> (sum, M2)
+__device__ __forceinline__ GnAcc gn_acc_from_shifted(float n, float p, float s1, float q1) {
+  GnAcc r;
+  r.n = n;
+  r.s = n * p + s1;
+  r.m2 = n > 0.f ? fmaxf(q1 - s1 * s1 * __builtin_amdgcn_rcpf(n), 0.f) : 0.f;
+  return r;
+}
+
 // ---- weight-tile prefetch into the XCD's L2 (used by the GEMM kernels at kernel start) ---------------------------------------------------
 // Inside a denoise / training step every GEMM meets its weights cold in HBM (1.72 GB of weights are read once per U-Net pass) while
 // the operand pipelines request a K stage only ~one stage (~0.3 us) before it is needed, so the first workgroup of an XCD to touch a

@@ -262,23 +262,26 @@ __device__ __forceinline__ void gemm3_epilogue(const Gemm3Dev& p, floatx4 (&acc)
     constexpr bool kGnFits = EPI == E3_STD && (BM == 128 || BM == 256) && (size_t)BM * TS * 2 + 2 * ((64 * NW) / 32) * 32 * 4 <= (size_t)LDSB;
     if constexpr (kGnFits) if (p.gn_ws != nullptr) {
       // GroupNorm partial statistics of THIS tile from the staged fp16 values (what the consumer's normalisation will read): thread (group g,
-      // row slice rs) sums its rows x cpg / 2 channel pairs, the slices meet in LDS behind the tile, one (sum, sumsq) per group leaves for
-      // af_groupnorm's partial workspace [B][128][32][2] at this tile's block index inside its image.  BM = 128 rows of ONE batch item (a 256-row
-      // tile -- the halo-resident convolution -- fills the first of its two 128-row blocks and zeroes the second); the tile's
-      // width is a multiple of the group width (validated by the host).  Rows beyond M hold zeros in T.
+      // row slice rs) sums its rows x cpg / 2 channel pairs, the slices meet in LDS behind the tile, one partial per (128-row block, group) leaves
+      // for af_groupnorm's partial workspace [B][128][32][2] at the block's index inside its image.  A partial is (sum, M2 about the block's own
+      // mean) -- af_common.h, GroupNorm partial statistics -- from sums shifted by the group's first element of the block (the same pivot in every
+      // slice, so the slices add up).  A 256-row tile (the halo-resident convolution) leaves its two 128-row blocks separately.  The tile's width
+      // is a multiple of the group width and M a multiple of 128 (validated by the host).
       constexpr int NSL = (64 * NW) / 32;                        // row slices: 32 threads (groups) per slice
       constexpr int RPS = BM / NSL;
+      constexpr int NBK = BM / 128, SPB = NSL / NBK;             // 128-row blocks per tile, slices per block
       float* red = reinterpret_cast<float*>(af_smem + (size_t)BM * TS * 2);
       const int g = tid & 31, rs = tid >> 5;
       const int ng = BNO / p.gn_cpg;
       float s = 0.f, q = 0.f;
       if (g < ng) {
         const int hp = p.gn_cpg >> 1;
+        const float pivot = (float)T[(rs / SPB) * 128 * TS + g * p.gn_cpg];
         for (int r = rs * RPS; r < (rs + 1) * RPS; ++r) {
           const half2_t* tp = reinterpret_cast<const half2_t*>(T + r * TS + g * p.gn_cpg);
           for (int j = 0; j < hp; ++j) {
             const half2_t v = tp[j];
-            const float a0 = (float)v[0], a1 = (float)v[1];
+            const float a0 = (float)v[0] - pivot, a1 = (float)v[1] - pivot;
             s += a0 + a1;
             q += a0 * a0 + a1 * a1;
           }
@@ -287,20 +290,21 @@ __device__ __forceinline__ void gemm3_epilogue(const Gemm3Dev& p, floatx4 (&acc)
       red[rs * 32 + g] = s;
       red[NSL * 32 + rs * 32 + g] = q;
       __syncthreads();
-      if (tid < ng) {
+      if (tid < 32 * NBK && (tid & 31) < ng) {
+        const int gg = tid & 31, bl = tid >> 5;
         float ss = 0.f, qq = 0.f;
 #pragma unroll
-        for (int k = 0; k < NSL; ++k) {
-          ss += red[k * 32 + tid];
-          qq += red[NSL * 32 + k * 32 + tid];
+        for (int k = 0; k < SPB; ++k) {
+          ss += red[(bl * SPB + k) * 32 + gg];
+          qq += red[NSL * 32 + (bl * SPB + k) * 32 + gg];
         }
+        const GnAcc acc = gn_acc_from_shifted(128.f * (float)p.gn_cpg, (float)T[bl * 128 * TS + gg * p.gn_cpg], ss, qq);
         const int m0 = tile_m * BM;
-        const int bt = m0 / p.rows_per_batch, blk = (m0 - bt * p.rows_per_batch) / 128;
+        const int bt = m0 / p.rows_per_batch, blk = (m0 - bt * p.rows_per_batch) / 128 + bl;
         const int g0 = (tile_n * BNO) / p.gn_cpg;
-        float* w = p.gn_ws + (((size_t)bt * 128 + blk) * 32 + g0 + tid) * 2;
-        w[0] = ss;
-        w[1] = qq;
-        if constexpr (BM == 256) w[64] = w[65] = 0.f;             // the consumer sums rows_per_batch / 128 blocks
+        float* w = p.gn_ws + (((size_t)bt * 128 + blk) * 32 + g0 + gg) * 2;
+        w[0] = acc.s;
+        w[1] = acc.m2;
       }
     }
     constexpr int CPR = BNO / 8;                                // 16-byte chunks per output row

@@ -42,7 +42,14 @@ __device__ __forceinline__ half8_t gn_load(const GnArgs& a, int b, int pix, int 
   return *reinterpret_cast<const half8_t*>(a.x2 + row * a.c2 + (c0 - a.c1));
 }
 
-// pass 1: per-block partial (sum, sumsq) per group
+__device__ __forceinline__ float gn_load1(const GnArgs& a, int b, int pix, int c) {
+  const size_t row = (size_t)b * a.HW + pix;
+  return c < a.c1 ? (float)a.x1[row * a.c1 + c] : (float)a.x2[row * a.c2 + (c - a.c1)];
+}
+
+// pass 1: per-block partial (sum, M2 about the block's own mean: af_common.h, GroupNorm partial statistics) per group.  The sums are taken
+// SHIFTED by a per-channel pivot -- the channel's value at the block's first pixel, the same for every thread of the block, so the per-thread
+// sums still add up -- and re-based to the group's pivot when the channels of a group are folded.
 template <int CT>
 __global__ __launch_bounds__(256) void gn_partial_kernel(GnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char af_smem[];
@@ -61,7 +68,13 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(GnArgs a) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) s[j][e] = q[j][e] = 0.f;
 
-  if (active) {
+  if (active && p0 < p1) {
+    half8_t pv[CT];                                    // pivots: this thread's channels at the block's first pixel
+#pragma unroll
+    for (int j = 0; j < CT; ++j) {
+      const int ch = chunk0 + 256 * j;
+      pv[j] = ch < a.CP ? gn_load(a, b, p0, ch * 8) : half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+    }
     // PF pixels per thread in flight: the loop is pure load -> fma, so bytes in flight per CU are what sets the rate
     constexpr int PF = CT == 1 ? 4 : 2;
     for (int pix = p0 + slot; pix < p1; pix += slots * PF) {
@@ -72,7 +85,7 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(GnArgs a) {
         for (int j = 0; j < CT; ++j) {
           const int ch = chunk0 + 256 * j;
           const int px = pix + u * slots;
-          v[u][j] = (px < p1 && ch < a.CP) ? gn_load(a, b, px, ch * 8) : half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+          v[u][j] = (px < p1 && ch < a.CP) ? gn_load(a, b, px, ch * 8) : pv[j];      // out of range: the pivot itself (adds 0 to both sums)
         }
 #pragma unroll
       for (int u = 0; u < PF; ++u)
@@ -80,7 +93,7 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(GnArgs a) {
         for (int j = 0; j < CT; ++j)
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
-            const float f = (float)v[u][j][e];
+            const float f = (float)v[u][j][e] - (float)pv[j][e];
             s[j][e] += f;
             q[j][e] += f * f;
           }
@@ -102,7 +115,7 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(GnArgs a) {
     }
   }
   __syncthreads();
-  // fold pixel slots -> per-channel (into slot 0)
+  // fold pixel slots -> per-channel (into slot 0): same pivot in every slot, plain sums
   for (int c = t; c < a.C; c += 256) {
     float ss = 0.f, qq = 0.f;
     for (int sl = 0; sl < slots; ++sl) {
@@ -114,15 +127,42 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(GnArgs a) {
   }
   __syncthreads();
   if (t < a.groups) {
+    float* w = a.ws + (((size_t)b * GN_NBLK + blk) * GN_MAXG + t) * 2;
+    if (p0 >= p1) {                                    // a block past the image (HW < nblk * per): n = 0, the consumer skips it
+      w[0] = w[1] = 0.f;
+      return;
+    }
+    // channels -> group: re-base channel c's sums from its own pivot p_c to the group's pivot P (that of the group's first channel):
+    //   sum(x - P) = s_c + n d,  sum((x - P)^2) = q_c + 2 d s_c + n d^2,  d = p_c - P
+    const float n = (float)(p1 - p0);
+    const float P = gn_load1(a, b, p0, t * a.cpg);
     float ss = 0.f, qq = 0.f;
     for (int c = t * a.cpg; c < (t + 1) * a.cpg; ++c) {
-      ss += rs[c];
-      qq += rq[c];
+      const float d = gn_load1(a, b, p0, c) - P;
+      ss += rs[c] + n * d;
+      qq += rq[c] + 2.f * d * rs[c] + n * d * d;
     }
-    float* w = a.ws + (((size_t)b * GN_NBLK + blk) * GN_MAXG + t) * 2;
-    w[0] = ss;
-    w[1] = qq;
+    const GnAcc acc = gn_acc_from_shifted(n * (float)a.cpg, P, ss, qq);
+    w[0] = acc.s;
+    w[1] = acc.m2;
   }
+}
+
+// Fold the partials of batch item b: thread (g = t & 31, kl = t >> 5) merges blocks kl, kl + NL, ...; block k of the launch that wrote them covers
+// pixels [k per, min(HW, (k + 1) per)), per = ceil(HW / nblk) (the producing GEMM's 128-row tiles: per = 128).  Returns this thread's share.
+__device__ __forceinline__ GnAcc gn_fold_partials(const float* ws_b, int nblk, int HW, int cpg, int g, int kl, int NL) {
+  const int per = (HW + nblk - 1) / nblk;
+  GnAcc acc = {0.f, 0.f, 0.f};
+  for (int k = kl; k < nblk; k += NL) {
+    const float* w = ws_b + ((size_t)k * GN_MAXG + g) * 2;
+    const int cnt = min(HW, (k + 1) * per) - k * per;
+    GnAcc pk;
+    pk.n = cnt > 0 ? (float)cnt * (float)cpg : 0.f;
+    pk.s = w[0];
+    pk.m2 = w[1];
+    acc = gn_acc_merge(acc, pk);
+  }
+  return acc;
 }
 
 // pass 2: fold partials, normalise (+ SiLU), write.  The launch is short (two pixel iterations per thread at [8, 4096, 320]), so its
@@ -131,7 +171,7 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(GnArgs a) {
 template <int CT>
 __global__ __launch_bounds__(256) void gn_apply_kernel(GnArgs a) {
   __shared__ float mr[GN_MAXG][2];
-  __shared__ float fold[8][GN_MAXG][2];
+  __shared__ float fold[8][GN_MAXG][3];
   const int t = threadIdx.x, b = blockIdx.y;
   const int slots = CT == 1 ? a.ppb : 1;
   const int slot = CT == 1 ? t / a.CP : 0;
@@ -166,29 +206,22 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnArgs a) {
     }
   }
   {
-    // 8 lanes of partial blocks x 32 groups: every thread folds nblk / 8 partials, then 8 -> 1 through LDS
+    // 8 lanes of partial blocks x 32 groups: every thread merges nblk / 8 partials, then 8 -> 1 through LDS
     const int g = t & 31, kl = t >> 5;
-    float ss = 0.f, qq = 0.f;
-    if (g < a.groups)
-      for (int k = kl; k < a.nblk; k += 8) {
-        const float* w = a.ws + (((size_t)b * GN_NBLK + k) * GN_MAXG + g) * 2;
-        ss += w[0];
-        qq += w[1];
-      }
-    fold[kl][g][0] = ss;
-    fold[kl][g][1] = qq;
+    GnAcc acc = {0.f, 0.f, 0.f};
+    if (g < a.groups) acc = gn_fold_partials(a.ws + (size_t)b * GN_NBLK * GN_MAXG * 2, a.nblk, a.HW, a.cpg, g, kl, 8);
+    fold[kl][g][0] = acc.n;
+    fold[kl][g][1] = acc.s;
+    fold[kl][g][2] = acc.m2;
   }
   __syncthreads();
   if (t < a.groups) {
-    float ss = 0.f, qq = 0.f;
+    GnAcc acc = {fold[0][t][0], fold[0][t][1], fold[0][t][2]};
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      ss += fold[k][t][0];
-      qq += fold[k][t][1];
-    }
+    for (int k = 1; k < 8; ++k) acc = gn_acc_merge(acc, GnAcc{fold[k][t][0], fold[k][t][1], fold[k][t][2]});
     const float inv_n = 1.0f / ((float)a.HW * (float)a.cpg);
-    const float mean = ss * inv_n;
-    const float var = fmaxf(qq * inv_n - mean * mean, 0.f);
+    const float mean = acc.s * inv_n;
+    const float var = fmaxf(acc.m2 * inv_n, 0.f);
     mr[t][0] = mean;
     mr[t][1] = rsqrtf(var + a.eps);
     if (a.stats && blockIdx.x == 0) {
@@ -274,13 +307,18 @@ __global__ __launch_bounds__(256) void gn_small_kernel(GnArgs a) {
       if (ch >= cpb) ch -= cpb, ++pix;
     }
   }
+  // sums shifted by a pivot (the group's first element, the same for every thread): q / n - (s / n)^2 then cancels only |pivot - mean| / sigma,
+  // not |mean| / sigma (af_common.h, GroupNorm partial statistics)
+  const float pivot = (float)src[(size_t)b * a.HW * ld];
 #pragma unroll
   for (int u = 0; u < GS_IT; ++u)
+    if (t + 256 * u < items) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float f = (float)v[u][e];
-      s += f;
-      q += f * f;
+      for (int e = 0; e < 8; ++e) {
+        const float f = (float)v[u][e] - pivot;
+        s += f;
+        q += f * f;
+      }
     }
   s = af_wave_sum(s);
   q = af_wave_sum(q);
@@ -292,8 +330,9 @@ __global__ __launch_bounds__(256) void gn_small_kernel(GnArgs a) {
   s = red[0][0] + red[0][1] + red[0][2] + red[0][3];
   q = red[1][0] + red[1][1] + red[1][2] + red[1][3];
   const float inv_n = 1.0f / ((float)a.HW * (float)a.cpg);
-  const float mean = s * inv_n;
-  const float rstd = rsqrtf(fmaxf(q * inv_n - mean * mean, 0.f) + a.eps);
+  const float dm = s * inv_n;
+  const float mean = pivot + dm;
+  const float rstd = rsqrtf(fmaxf(q * inv_n - dm * dm, 0.f) + a.eps);
   if (a.stats && t == 0) {
     a.stats[((size_t)b * a.groups + g) * 2 + 0] = mean;
     a.stats[((size_t)b * a.groups + g) * 2 + 1] = rstd;
@@ -359,12 +398,16 @@ __global__ __launch_bounds__(1024) void gn_pair_kernel(GnArgs a) {
       if (pr >= ppp) pr -= ppp, ++pix;
     }
   }
+  // shifted sums, as gn_small_kernel: the pivot is the group's first element of this batch item
+  const float pivot = c0 < a.c1 ? (float)a.x1[(size_t)b * a.HW * a.c1 + c0] : (float)a.x2[(size_t)b * a.HW * a.c2 + (c0 - a.c1)];
 #pragma unroll
   for (int u = 0; u < IT; ++u) {
-    const half2_t h = *reinterpret_cast<const half2_t*>(&v[u]);
-    const float f0 = (float)h[0], f1 = (float)h[1];
-    s += f0 + f1;
-    q += f0 * f0 + f1 * f1;
+    if (t + 1024 * u < items) {
+      const half2_t h = *reinterpret_cast<const half2_t*>(&v[u]);
+      const float f0 = (float)h[0] - pivot, f1 = (float)h[1] - pivot;
+      s += f0 + f1;
+      q += f0 * f0 + f1 * f1;
+    }
   }
   s = af_wave_sum(s);
   q = af_wave_sum(q);
@@ -381,8 +424,9 @@ __global__ __launch_bounds__(1024) void gn_pair_kernel(GnArgs a) {
     q += red[1][i];
   }
   const float inv_n = 1.0f / ((float)a.HW * (float)a.cpg);
-  const float mean = s * inv_n;
-  const float rstd = rsqrtf(fmaxf(q * inv_n - mean * mean, 0.f) + a.eps);
+  const float dm = s * inv_n;
+  const float mean = pivot + dm;
+  const float rstd = rsqrtf(fmaxf(q * inv_n - dm * dm, 0.f) + a.eps);
   if (a.stats && t == 0) {
     a.stats[((size_t)b * a.groups + g) * 2 + 0] = mean;
     a.stats[((size_t)b * a.groups + g) * 2 + 1] = rstd;

@@ -13,7 +13,8 @@
 //
 // Work per layer-sample is 0.25 GFLOP against 12.7 MB of fp32 scores: HBM / latency bound by construction, so these are plain
 // wave-per-row kernels (one wave owns one (batch, head, query) row; lane = key, two keys per lane, L <= 128), fp32 arithmetic,
-// coalesced row accesses; no MFMA.  Reductions over the 4096 queries (dk, dv) are two-pass and deterministic (no atomics).
+// coalesced row accesses; no MFMA -- except the two reductions over the 4096 queries (dk, dv), which are [L x Nq] . [Nq x d] GEMMs per head on the
+// f32-input matrix instruction (xattn_colmix_mfma_kernel), two-pass and deterministic (no atomics).
 #include "af_common.h"
 
 namespace {
@@ -149,21 +150,87 @@ __global__ __launch_bounds__(256) void xattn_rowmix_kernel(const float* __restri
 }
 
 // partial[z][b][j][h*d+c] = sum over the z-th query chunk of w[b,h,i,j] x[b,i,h*d+c]      (dv: w = prob, x = do;  dk: w = dscore, x = q)
-// grid (ceil(L*d / 256), heads, B * NZ); thread = one (j, c) output of its head.
-__global__ __launch_bounds__(256) void xattn_colmix_partial_kernel(const float* __restrict__ w, const half_t* __restrict__ x, int ldx,
-                                                                   float* __restrict__ partial, int B, int Nq, int L, int heads, int d, int NZ) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  const int h = blockIdx.y;
-  const int b = blockIdx.z / NZ, z = blockIdx.z - b * NZ;
-  if (idx >= L * d) return;
-  const int j = idx / d, c = idx - j * d;
+//
+// Per (batch item, head) this is the GEMM  [L keys x Nq queries] . [Nq queries x d channels]  with the REDUCTION over the queries -- both operands have
+// the reduction index as their slow (row) index in memory.  It runs on the f32-input matrix instruction v_mfma_f32_16x16x4_f32 (round 5; the scalar
+// loop it replaces took 343 us per call at [4, 8, 4096, 97] x d 40, one thread per (key, channel) walking the queries at stride L):
+//   * f32 in, f32 accumulate: bit for bit a k-ordered fmaf chain, so the fp32 probabilities / score gradients are NOT rounded to fp16 (they can be
+//     anywhere in fp32's range: a gradient) and the result is deterministic;
+//   * a lane holds ONE operand element per instruction -- A[key = lane & 15][query = lane >> 4], B[query = lane >> 4][channel = lane & 15] -- so the
+//     fragments are plain coalesced loads of the natural layouts: 4 rows x 16 consecutive floats of w, 4 rows x 16 consecutive halves of x; nothing
+//     is transposed, staged in LDS or shared between waves;
+//   * a WAVE owns one query chunk (Nq / 32 queries) of one (batch item, head, group of NT 16-channel tiles) and all ceil(L / 16) key tiles:
+//     up to 8 x NT accumulators, 8 + NT loads per 4 queries for 8 NT MFMAs, the next step's fragments requested before this step's MFMAs.
+// Grid (8 * ngroups, heads, B), 4 waves = 4 consecutive chunks per workgroup; the 32 chunk partials are summed by xattn_colmix_final_kernel
+// (two deterministic passes, no atomics, as before).  At full size: 256 workgroups, 21 MFMAs per step, ~0.7 M MFMAs of 32 cycles over 1024 SIMDs.
+template <int NT>
+__global__ __launch_bounds__(256) void xattn_colmix_mfma_kernel(const float* __restrict__ w, const half_t* __restrict__ x, int ldx,
+                                                                float* __restrict__ partial, int B, int Nq, int L, int heads, int d, int NZ) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int zc = (blockIdx.x & 7) * 4 + wave;                  // this wave's query chunk, 0 .. NZ - 1 (NZ = 32)
+  const int ng = blockIdx.x >> 3;                              // channel group: tiles ng * NT ..
+  const int h = blockIdx.y, b = blockIdx.z;
   const int per = (Nq + NZ - 1) / NZ;
-  const int i0 = z * per, i1 = min(Nq, i0 + per);
-  const float* wp = w + (((size_t)b * heads + h) * Nq) * L + j;
-  const half_t* xp = x + (size_t)b * Nq * ldx + h * d + c;
-  float acc = 0.f;
-  for (int i = i0; i < i1; ++i) acc += wp[(size_t)i * L] * (float)xp[(size_t)i * ldx];
-  partial[(((size_t)z * B + b) * L + j) * (heads * d) + h * d + c] = acc;
+  const int i0 = zc * per, i1 = min(Nq, i0 + per);
+  const int MT = (L + 15) >> 4;
+  const int lr = lane & 15, lk = lane >> 4;
+  const int cbase = ng * NT * 16;
+  const float* wp = w + (((size_t)b * heads + h) * Nq) * L;
+  const half_t* xp = x + (size_t)b * Nq * ldx + h * d;
+  const floatx4 zf = {0.f, 0.f, 0.f, 0.f};
+  floatx4 acc[8][NT];
+#pragma unroll
+  for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = zf;
+  auto load = [&](int i, float (&a)[8], float (&bf)[NT]) {
+    const int ii = i + lk;
+    const bool ok = ii < i1;
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) {
+      const int j = mt * 16 + lr;
+      a[mt] = (mt < MT && ok && j < L) ? wp[(size_t)ii * L + j] : 0.f;
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int c = cbase + nt * 16 + lr;
+      bf[nt] = (ok && c < d) ? (float)xp[(size_t)ii * ldx + c] : 0.f;
+    }
+  };
+  auto mma = [&](const float (&a)[8], const float (&bf)[NT]) {
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt)
+      if (mt < MT) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], bf[nt], acc[mt][nt], 0, 0, 0);
+      }
+  };
+  float a0[8], b0[NT], a1[8], b1[NT];
+  if (i0 < i1) load(i0, a0, b0);
+  for (int i = i0; i < i1; i += 8) {
+    if (i + 4 < i1) load(i + 4, a1, b1);
+    mma(a0, b0);
+    if (i + 4 < i1) {
+      if (i + 8 < i1) load(i + 8, a0, b0);
+      mma(a1, b1);
+    }
+  }
+  // D: column (channel) = lane & 15, row (key) = 4 (lane >> 4) + r.  An empty chunk still writes its zeros: the final pass sums all NZ slabs.
+  const int Cn = heads * d;
+#pragma unroll
+  for (int mt = 0; mt < 8; ++mt)
+    if (mt < MT) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int c = cbase + nt * 16 + lr;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int j = mt * 16 + 4 * lk + r;
+          if (j < L && c < d) partial[(((size_t)zc * B + b) * L + j) * Cn + h * d + c] = acc[mt][nt][r];
+        }
+      }
+    }
 }
 
 __global__ __launch_bounds__(256) void xattn_colmix_final_kernel(const float* __restrict__ partial, half_t* __restrict__ out, int ldout, float alpha,
@@ -238,9 +305,16 @@ extern "C" int af_xattn_colmix(const void* w, const void* x, int ldx, void* out,
   AF_REQUIRE(ldx >= heads * d && ldout >= heads * d, "af_xattn_colmix: bad leading dimensions");
   AF_REQUIRE(workspace_bytes >= af_xattn_colmix_ws_bytes(B, L, heads, d), "af_xattn_colmix: workspace too small (af_xattn_colmix_ws_bytes)");
   const int NZ = AF_XATTN_COLMIX_CHUNKS;
+  static_assert(AF_XATTN_COLMIX_CHUNKS == 32, "xattn_colmix_mfma_kernel: 8 workgroups x 4 waves of query chunks");
   AfLaunchScope scope(AF_FAM_XATTN, stream);
-  hipLaunchKernelGGL(xattn_colmix_partial_kernel, dim3((unsigned)((L * d + 255) / 256), heads, B * NZ), dim3(256), 0, (hipStream_t)stream,
-                     (const float*)w, (const half_t*)x, ldx, (float*)workspace, B, Nq, L, heads, d, NZ);
+  const int nt = d <= 16 ? 1 : (d <= 32 ? 2 : (d <= 48 ? 3 : 4));
+  const dim3 grid(8 * ((d + nt * 16 - 1) / (nt * 16)), heads, B);
+  switch (nt) {
+    case 1: hipLaunchKernelGGL(xattn_colmix_mfma_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)w, (const half_t*)x, ldx, (float*)workspace, B, Nq, L, heads, d, NZ); break;
+    case 2: hipLaunchKernelGGL(xattn_colmix_mfma_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)w, (const half_t*)x, ldx, (float*)workspace, B, Nq, L, heads, d, NZ); break;
+    case 3: hipLaunchKernelGGL(xattn_colmix_mfma_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)w, (const half_t*)x, ldx, (float*)workspace, B, Nq, L, heads, d, NZ); break;
+    default: hipLaunchKernelGGL(xattn_colmix_mfma_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)w, (const half_t*)x, ldx, (float*)workspace, B, Nq, L, heads, d, NZ); break;
+  }
   const long n = (long)B * L * heads * d;
   hipLaunchKernelGGL(xattn_colmix_final_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float*)workspace,
                      (half_t*)out, ldout, alpha, B * L, heads * d, NZ);

@@ -646,7 +646,7 @@ __global__ __launch_bounds__(512, 1) void af_xattn320t_kernel(const XaDev p) {
 // weight ring; the first two weight stages stream in under the normalisation.  The normalised tensor never exists in memory.
 struct GpDev {
   const half_t* x;          // [M][320]
-  const float* partials;    // [B][128][32][2] (sum, sumsq) per 128-row block and group
+  const float* partials;    // [B][128][32][2] (sum, M2 about the block's mean) per 128-row block and group
   const float* gamma;
   const float* beta;
   const half_t* w;          // packed [>= 320][kpad]
@@ -697,30 +697,28 @@ __global__ __launch_bounds__(512, 1) void af_gn_proj320_kernel(const GpDev p) {
     bt[1] = *reinterpret_cast<const floatx4*>(p.beta + ch * 8 + 4);
   }
   // ---- fold the producer's partial sums of this batch item: 16 lanes of blocks x 32 groups, then 16 -> 1 through LDS (inside R, which is still free)
-  float* fold = reinterpret_cast<float*>(R);                 // [16][32][2]
-  float* mr = fold + 16 * G * 2;                             // [32][2] (mean, rstd)
+  float* fold = reinterpret_cast<float*>(R);                 // [16][32][3] (n, sum, M2)
+  float* mr = fold + 16 * G * 3;                             // [32][2] (mean, rstd)
   {
+    // (sum, M2) partials of 128-row blocks, merged pairwise (af_common.h, GroupNorm partial statistics)
     const int g = tid & 31, kl = tid >> 5;
-    float ss = 0.f, qq = 0.f;
+    GnAcc acc = {0.f, 0.f, 0.f};
     for (int k = kl; k < p.nblk; k += 16) {
       const float* w = p.partials + (((size_t)bimg * 128 + k) * G + g) * 2;
-      ss += w[0];
-      qq += w[1];
+      acc = gn_acc_merge(acc, GnAcc{128.f * CPG, w[0], w[1]});
     }
-    fold[(kl * G + g) * 2] = ss;
-    fold[(kl * G + g) * 2 + 1] = qq;
+    fold[(kl * G + g) * 3] = acc.n;
+    fold[(kl * G + g) * 3 + 1] = acc.s;
+    fold[(kl * G + g) * 3 + 2] = acc.m2;
   }
   __syncthreads();
   if (tid < G) {
-    float ss = 0.f, qq = 0.f;
+    GnAcc acc = {fold[tid * 3], fold[tid * 3 + 1], fold[tid * 3 + 2]};
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      ss += fold[(k * G + tid) * 2];
-      qq += fold[(k * G + tid) * 2 + 1];
-    }
+    for (int k = 1; k < 16; ++k) acc = gn_acc_merge(acc, GnAcc{fold[(k * G + tid) * 3], fold[(k * G + tid) * 3 + 1], fold[(k * G + tid) * 3 + 2]});
     const float inv_n = 1.0f / ((float)p.HW * (float)CPG);
-    const float mean = ss * inv_n;
-    const float var = fmaxf(qq * inv_n - mean * mean, 0.f);
+    const float mean = acc.s * inv_n;
+    const float var = fmaxf(acc.m2 * inv_n, 0.f);
     mr[tid * 2] = mean;
     mr[tid * 2 + 1] = rsqrtf(var + p.eps);
   }

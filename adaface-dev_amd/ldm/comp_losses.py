@@ -65,11 +65,11 @@ def split_indices_by_instance(indices):
     kept on the tensor OBJECT it was made from (index tensors are never written in place)."""
     b, n = indices
     memo = getattr(b, "af_split", None)
-    if memo is not None and memo[0] is n:
+    if memo is not None and memo[0] is n and memo[2] == (b._version, n._version):      # an in-place write to either tensor voids the memo
         return memo[1]
     out = [(b[b == u], n[b == u]) for u in torch.unique(b)]
     try:
-        b.af_split = (n, out)
+        b.af_split = (n, out, (b._version, n._version))
     except AttributeError:
         pass
     return out
@@ -77,13 +77,14 @@ def split_indices_by_instance(indices):
 
 def count_instances(b):
     """len(torch.unique(b)), remembered on the tensor object like ``split_indices_by_instance``."""
-    k = getattr(b, "af_n_unique", None)
-    if k is None:
-        k = len(torch.unique(b))
-        try:
-            b.af_n_unique = k
-        except AttributeError:
-            pass
+    memo = getattr(b, "af_n_unique", None)
+    if memo is not None and memo[1] == b._version:
+        return memo[0]
+    k = len(torch.unique(b))
+    try:
+        b.af_n_unique = (k, b._version)
+    except AttributeError:
+        pass
     return k
 
 
@@ -183,7 +184,8 @@ def calc_subj_masked_bg_suppress_loss(ca_attn, subj_indices, BLOCK_SIZE, fg_mask
     device = next(iter(ca_attn.values())).device
     # a mask made from host boxes (ddpm_losses.box_mask) carries its host copy: the three decisions on the mask below are then taken on
     # that copy (same arithmetic on 0 / 1 values) instead of reading the device
-    fg_host = getattr(fg_mask, "af_host", None) if fg_mask is not None else None
+    memo = getattr(fg_mask, "af_host", None) if fg_mask is not None else None
+    fg_host = memo[0] if memo is not None and memo[1] == fg_mask._version else None            # (host copy, version at the copy): ddpm_losses.box_mask
     decide_on = fg_host if fg_host is not None else fg_mask
     if subj_indices is None or len(subj_indices) == 0 or fg_mask is None or decide_on.chunk(4)[0].float().mean() >= 0.998:
         return torch.zeros((), device=device)

@@ -390,6 +390,7 @@ class LatentDiffusion(CompReconLossesMixin, nn.Module):
     unet_distill_weight = 8          # ddpm.py:2367
     batch_student_steps = True       # one student U-Net call for all denoising steps of a micro-batch
     cache_uncond_in_step = os.environ.get("AF_CACHE_UNCOND", "1") != "0"       # recon steps: the null-prompt pass once per step, not once per guided pass
+    skip_unread_cls_priming = os.environ.get("AF_SKIP_CLS_PRIMING", "1") != "0"   # recon steps: no class-prompt pass on priming steps (nothing reads it); its own switch
     batch_no_grad_instances = os.environ.get("AF_BATCH_NO_GRAD", "1") != "0"   # subject-compos steps: SS + SR as one no-grad pass where their flags agree
     res_hidden_states_gradscale = 0.5   # reference ctor default (ddpm.py:140): gradient scale of the decoder's skip inputs
 
@@ -466,15 +467,20 @@ class LatentDiffusion(CompReconLossesMixin, nn.Module):
         else:
             raise ValueError(f"batch_part_has_grad={batch_part_has_grad!r}: 'all', 'none' or 'subject-compos'")
         if cfg_scale > 1:
+            uncond_key = uncond_emb if uncond_emb is not None else self.uncond_context[0]      # identity of the null embedding BEFORE the per-call repeat
             if uncond_emb is None:
                 uncond_emb = self.uncond_context[0].repeat(x_noisy.shape[0], 1, 1)
             uncond_context = (uncond_emb, self.uncond_context[1] * x_noisy.shape[0], copy.copy(self.uncond_context[2]))
             # ``uncond_cache`` (a dict the caller keeps for ONE denoising step): the unconditional prediction is a function of (x_start, noise, t,
             # the null embedding, the FFN-adapter state) only -- a recon step asks for it twice with the same arguments (after the subject pass
             # and after the class-prompt pass, ddpm.py:1800-1860): the second request takes the first one's tensor (same kernels, same bits)
+            # With the FFN adapters live the reference's two null passes are NOT the same computation in training mode (peft draws a fresh
+            # lora_dropout mask per pass): the cache is bypassed then and both passes run, as the reference's do.
             ck = (use_ffn_lora, ffn_lora_adapter_name if use_ffn_lora else None)
+            if use_ffn_lora:
+                uncond_cache = None
             hit = (uncond_cache is not None and uncond_cache.get("ck") == ck and uncond_cache.get("x") is x_start and uncond_cache.get("n") is noise
-                   and uncond_cache.get("t") is t and uncond_cache.get("u") is uncond_emb)
+                   and uncond_cache.get("t") is t and uncond_cache.get("u") is uncond_key)
             if hit:
                 noise_pred_uncond = uncond_cache["eps"]
             else:
@@ -482,7 +488,7 @@ class LatentDiffusion(CompReconLossesMixin, nn.Module):
                     noise_pred_uncond = self.apply_model(x_noisy, t, uncond_context, use_attn_lora=False, use_ffn_lora=use_ffn_lora,
                                                          ffn_lora_adapter_name=ffn_lora_adapter_name)
                 if uncond_cache is not None:
-                    uncond_cache.update(ck=ck, x=x_start, n=noise, t=t, u=uncond_emb, eps=noise_pred_uncond)
+                    uncond_cache.update(ck=ck, x=x_start, n=noise, t=t, u=uncond_key, eps=noise_pred_uncond)
             noise_pred = noise_pred * cfg_scale - noise_pred_uncond * (cfg_scale - 1)
         x_recon = self.predict_start_from_noise(x_noisy, t=t, noise=noise_pred) if do_pixel_recon else None
         return noise_pred, x_recon, ca_layers_activations

@@ -61,13 +61,14 @@ def box_mask(boxes, B, H, W, device, dtype=torch.float32):
         x1, y1, x2, y2 = (int(v) for v in boxes[i])
         m[i, :, y1:y2, x1:x2] = 1
     d = to_device_async(m, device)
-    d.af_host = m
+    d.af_host = (m, d._version)
     return d
 
 
 def host_of(mask):
-    """The host copy of a ``box_mask`` (the mask itself when it has none)."""
-    return getattr(mask, "af_host", mask)
+    """The host copy of a ``box_mask`` (the mask itself when it has none, or when the device mask has been written in place since)."""
+    memo = getattr(mask, "af_host", None)
+    return memo[0] if memo is not None and memo[1] == mask._version else mask
 
 
 def resolve_monitors(mon_loss_dict, extra=()):
@@ -465,10 +466,11 @@ class CompReconLossesMixin:
             acts_list.append(acts)
             x_recons.append(x_recon)
             x_starts.append(x_recon if (normal_recon_on_pure_noise or priming) else x_start0)
-            if cls_context is not None and self.cache_uncond_in_step and priming:
+            if cls_context is not None and self.skip_unread_cls_priming and priming:
                 # the class-prompt prediction of a PRIMING step is read by nobody (the losses start at step num_priming_steps, and the chain
                 # continues from the main pass): the reference computes it all the same -- on even priming steps it even is the main pass
-                # over again, argument for argument; here the slot keeps the main pass's tensors where they are that, None otherwise
+                # over again, argument for argument; here the slot keeps the main pass's tensors where they are that, None otherwise (the lists
+                # stay aligned with the step index; calc_normal_recon_loss asserts that every entry it reads exists)
                 same = context is cls_context and not enable_unet_ffn_lora
                 noise_preds_cls.append(noise_pred if same else None)
                 x_recons_cls.append(x_recon if same else None)
@@ -535,6 +537,7 @@ class CompReconLossesMixin:
         for i in range(num_recon_priming_steps, num_denoising_steps):
             noise, noise_pred, x_recon, acts = noises[i], noise_preds[i], x_recons[i], acts_list[i]
             noise_pred_cls = noise_preds_cls[i] if cls_context is not None else None
+            assert cls_context is None or noise_pred_cls is not None, "a non-priming step must carry its class-prompt prediction (skip_unread_cls_priming only drops priming steps')"
             pred_l2s.append((noise_pred ** 2).mean())
             if self.arcface_align_loss_weight > 0:
                 la, _, lb, boxes, _, found = self.calc_arcface_align_loss(x_start, x_recon, fg_faces_grad_mask_ratios=(1, 0.3), ref_cache=ref_cache)

@@ -401,7 +401,7 @@ class SpatialTransformer(nn.Module):
         out = ops.gemm(y, self.proj_out.packed(), residual=x.reshape(B * N, Cn), rows_per_batch=N, gn_cpg=Cn // 32 if Cn % 32 == 0 else 0)
         out4 = out.reshape(B, H, W, Cn)
         if hasattr(out, "_gn_partials"):
-            out4._gn_partials = out._gn_partials
+            out4._gn_partials = out._gn_partials      # a view: same storage address and version counter (ops.partials_of)
         return out4
 
     def hip_train(self, x, context=None, mask=None):

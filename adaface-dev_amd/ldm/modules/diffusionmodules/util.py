@@ -94,7 +94,7 @@ class Conv2d(nn.Conv2d):
         out = ops.gemm(x.reshape(B * H * W, c1), pw, a2=a2, rowbias=rowbias, rows_per_batch=H * W, residual=res, gn_cpg=cpg)
         out4 = out.reshape(B, H, W, -1)
         if hasattr(out, "_gn_partials"):
-            out4._gn_partials = out._gn_partials
+            out4._gn_partials = out._gn_partials      # a view: same storage address and version counter (ops.partials_of)
         return out4
 
     def packed_bwd(self) -> ops.PackedWeight:

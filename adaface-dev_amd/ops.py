@@ -210,11 +210,28 @@ GN_FROM_PRODUCER = _os.environ.get("AF_GN_FROM_PRODUCER", "1") != "0"   # GroupN
 
 
 class GnPartials:
-    """Partial GroupNorm statistics of a tensor, written by the GEMM launch that produced it (af_gemm_desc.gn_partials)."""
-    __slots__ = ("ws", "nblk", "cpg", "B", "hw", "C")
+    """Partial GroupNorm statistics of a tensor, written by the GEMM launch that produced it (af_gemm_desc.gn_partials).  They describe the
+    bytes that launch stored: `attach` records the tensor's storage address and autograd version, and `partials_of` hands them out only
+    while both still match -- an in-place write between the producer and the GroupNorm (`y.add_(1)`, `copy_`) bumps the version, the
+    statistics are dropped and the consumer runs its own statistics pass."""
+    __slots__ = ("ws", "nblk", "cpg", "B", "hw", "C", "ptr", "version")
 
     def __init__(self, ws, nblk, cpg, B, hw, C):
         self.ws, self.nblk, self.cpg, self.B, self.hw, self.C = ws, nblk, cpg, B, hw, C
+        self.ptr, self.version = 0, -1
+
+    def attach(self, t: torch.Tensor) -> torch.Tensor:
+        self.ptr, self.version = t.data_ptr(), t._version
+        t._gn_partials = self
+        return t
+
+
+def partials_of(x: torch.Tensor) -> Optional["GnPartials"]:
+    """The statistics x's producer left, or None when there are none or x has been written since (views share the version counter)."""
+    gn = getattr(x, "_gn_partials", None)
+    if gn is None or gn.ptr != x.data_ptr() or gn.version != x._version:
+        return None
+    return gn
 
 
 def _launch_gemm(d: "GemmDesc", device, what: str, tile: int = 0, splits: int = 0, gn_cpg: int = 0):
@@ -254,7 +271,10 @@ def _launch_gemm(d: "GemmDesc", device, what: str, tile: int = 0, splits: int = 
     gn = None
     if gn_cpg and GN_FROM_PRODUCER and _tune_recorder is None:
         rpb = d.rows_per_batch if d.rows_per_batch > 0 else d.M
-        if d.M % rpb == 0 and d.ld_out in (0, d.N) and _lib.lib().af_gemm_gn_stats_ok(d.tile, d.splits, d.taps, d.act, d.out_mode, d.N, gn_cpg, rpb) == 1:
+        # the table's key carries no image geometry: tile 14 (halo-resident 3x3) on a latent outside its scope (W not 16 / 32 / 64, ragged rows)
+        # falls back to a tap-by-tap tile INSIDE the library, which leaves no statistics -- ask for them only where tile 14 will really run
+        if (d.tile != 14 or conv_halo_eligible(d)) and d.M % rpb == 0 and d.ld_out in (0, d.N) \
+                and _lib.lib().af_gemm_gn_stats_ok(d.tile, d.splits, d.taps, d.act, d.out_mode, d.N, gn_cpg, rpb) == 1:
             nb = d.M // rpb
             ws = torch.empty((nb, 128, 32, 2), dtype=torch.float32, device=device)
             d.gn_partials, d.gn_cpg = ws.data_ptr(), gn_cpg
@@ -310,7 +330,7 @@ def gemm(a1: torch.Tensor, pw: PackedWeight, *, a2: Optional[torch.Tensor] = Non
     d.out = _p(out)
     gn = _launch_gemm(d, a1.device, "af_gemm", tile, splits, gn_cpg=0 if (split_col or out_f32) else gn_cpg)
     if gn is not None:
-        out._gn_partials = gn            # rides on the tensor object: GroupNorm32.hip picks it up (ops.groupnorm)
+        gn.attach(out)                   # rides on the tensor object: GroupNorm32.hip picks it up (ops.groupnorm)
     return (out, out2) if split_col else out
 
 
@@ -374,7 +394,7 @@ def conv3x3(x: torch.Tensor, pw: PackedWeight, *, x2: Optional[torch.Tensor] = N
             tile, splits = conv3x3_skip_tile(d.M, d.N, c1 + c2, pw.k_tail)
     gn = _launch_gemm(d, x.device, "af_gemm(conv3x3)", tile, splits, gn_cpg=gn_cpg)
     if gn is not None:
-        out._gn_partials = gn
+        gn.attach(out)
     return out
 
 
@@ -445,7 +465,7 @@ def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
         _chk_f16(x2, "groupnorm.x2")
         c2 = x2.shape[-1]
     y = torch.empty(tuple(x.shape[:-1]) + (c1 + c2,), dtype=F16, device=x.device)
-    gn = getattr(x, "_gn_partials", None) if x2 is None else None
+    gn = partials_of(x) if x2 is None else None
     if gn is not None and gn.B == B and gn.hw == hw and gn.C == c1 and gn.cpg * groups == c1 and x.is_contiguous():
         # the launch that produced x left its partial statistics: normalise in one pass, no statistics pass (af_groupnorm_apply)
         rc = _lib.lib().af_groupnorm_apply(_p(x), c1, _p(gamma), _p(beta), _p(y), None, B, hw, groups, float(eps), int(silu), _p(gn.ws), gn.nblk, _stream())
@@ -462,7 +482,7 @@ def gn_proj_fused(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps:
     """GroupNorm(x) followed by a 1x1 convolution / Linear at C = 320 in ONE launch (af_gn_proj_fused): x [B, ..., 320] carrying the partial
     statistics its producer left (x._gn_partials) -> [B * HW, N = 320] token-major.  Returns None when x does not qualify (no partials, another
     width, ragged image size): the caller then runs the two launches."""
-    gn = getattr(x, "_gn_partials", None)
+    gn = partials_of(x)
     B, c = x.shape[0], x.shape[-1]
     hw = x.numel() // (B * c)
     if (gn is None or c != 320 or groups != 32 or pw.N != 320 or pw.K != 320 or pw.ln_cs is not None or hw % 128 != 0 or gn.B != B or gn.hw != hw or gn.C != c
@@ -667,7 +687,7 @@ def groupnorm_train(x, gamma, beta, eps, silu, *, x2=None, groups=32):
     c2 = 0 if x2 is None else x2.shape[-1]
     y = torch.empty(tuple(x.shape[:-1]) + (c1 + c2,), dtype=F16, device=x.device)
     stats = torch.empty((B, groups, 2), dtype=torch.float32, device=x.device)
-    gn = getattr(x, "_gn_partials", None) if x2 is None else None
+    gn = partials_of(x) if x2 is None else None
     if gn is not None and gn.B == B and gn.hw == hw and gn.C == c1 and gn.cpg * groups == c1 and x.is_contiguous():
         rc = _lib.lib().af_groupnorm_apply(_p(x), c1, _p(gamma), _p(beta), _p(y), _p(stats), B, hw, groups, float(eps), int(silu), _p(gn.ws), gn.nblk, _stream())
         _lib.check(rc, "af_groupnorm_apply")

@@ -159,8 +159,10 @@ typedef struct af_gemm_desc {
   const void* a4;
   int32_t c3, c4, lda3, lda4;
   /* GroupNorm statistics of the OUTPUT from the producing GEMM's epilogue (all 0 / NULL otherwise): gn_partials != NULL makes the launch also write,
-   * per (batch item b, 128-row tile blk of that item, group g of gn_cpg output channels), the partial (sum, sum of squares) of the fp16 values it
-   * stores, as fp32 [B][128][32][2] -- exactly the partial-sum workspace of af_groupnorm, so af_groupnorm_apply can normalise the tensor without a
+   * per (batch item b, 128-row tile blk of that item, group g of gn_cpg output channels), the partial (sum, M2) of the fp16 values it stores -- M2 = the sum of
+   * squares about THAT BLOCK'S OWN MEAN; the consumer merges blocks pairwise (M2_a + M2_b + (mean_b - mean_a)^2 n_a n_b / (n_a + n_b)), so no
+   * E[x^2] - mean^2 difference is ever formed and groups with |mean| >> sigma keep their variance (torch's fp32 group_norm, util.py:195-212, is the
+   * reference) -- as fp32 [B][128][32][2]: exactly the partial workspace of af_groupnorm, so af_groupnorm_apply can normalise the tensor without a
    * statistics pass of its own (GroupNorm32 behind a convolution: openaimodel.py:202-233, 256-276; attention.py:283-291).  Needs the standard
    * epilogue on a whole-line tile whose width is a multiple of gn_cpg (tile 7: 128 x 320, tile 11 / 13: 128 x 160), gn_cpg even, N % gn_cpg == 0,
    * N / gn_cpg <= 32, rows_per_batch % 128 == 0 (or M % 128 == 0 when rows_per_batch is 0), rows_per_batch / 128 <= 128, fp16 output, no split-K;
@@ -286,8 +288,9 @@ int af_attention_scores(const void* q, const void* k, void* score, void* prob, i
  *   af_xattn_softmax_pv_bwd  dscore = prob * (dP - sum_L prob dP),  dP = dout v^T (+ dprob_ext, the gradient arriving on a captured prob; may be NULL)
  *   af_xattn_rowmix          out[B*Nq, ldout] = alpha * w x      (w fp32 [B,heads,Nq,L], x fp16 [B*L, ldx]):   dq = scale * dscore k
  *   af_xattn_colmix          out[B*L, ldout]  = alpha * w^T x    (x fp16 [B*Nq, ldx]):   dv = prob^T dout,  dk = scale * dscore^T q;
- *                            deterministic two-pass reduction over the queries through a caller-owned fp32 workspace             */
-#define AF_XATTN_COLMIX_CHUNKS 8
+ *                            per (batch item, head) a GEMM over the queries on v_mfma_f32_16x16x4_f32 (f32 in / f32 accumulate: w is not rounded);
+ *                            deterministic two-pass reduction over 32 query chunks through a caller-owned fp32 workspace          */
+#define AF_XATTN_COLMIX_CHUNKS 32
 int af_xattn_scores(const void* q, int ldq, const void* k, int ldk, void* score, int B, int Nq, int L, int heads, int d, float scale, void* stream);
 int af_xattn_softmax_pv(const void* score, const void* v, int ldv, void* prob, void* o, int ldo, int B, int Nq, int L, int heads, int d, void* stream);
 int af_xattn_softmax_pv_bwd(const void* prob, const void* v, int ldv, const void* dout, int lddo, const void* dprob_ext, void* dscore, int B, int Nq,

@@ -149,3 +149,25 @@ def check_recon_and_suppress(g, device="cpu", tol=1e-5):
 
 def test_recon_and_suppress_losses_vs_reference():
     check_recon_and_suppress(np.load(os.path.join(GOLDEN, "comp_preserve.npz")))
+
+
+def test_tensor_attached_memos_are_voided_by_in_place_writes():
+    """The index split, the instance count and the host copy of a box mask ride on tensor objects (no host<->device wait when the same
+    tensor comes back); each records the version counter it was made at, so an in-place write to the tensor voids it."""
+    from adaface_dev_amd.ldm import comp_losses as CL
+    from adaface_dev_amd.ldm.models.diffusion.ddpm_losses import box_mask, host_of
+    b, n = torch.tensor([0, 0, 1, 1, 1]), torch.tensor([4, 5, 4, 5, 6])
+    first = CL.split_indices_by_instance((b, n))
+    assert CL.split_indices_by_instance((b, n)) is first and CL.count_instances(b) == 2
+    b[4] = 2                                             # in place: three instances now
+    again = CL.split_indices_by_instance((b, n))
+    assert again is not first and len(again) == 3 and CL.count_instances(b) == 3
+    n.add_(1)
+    assert [t[1].tolist() for t in CL.split_indices_by_instance((b, n))] == [[5, 6], [5, 6], [7]]
+    host = box_mask([(1, 1, 3, 3)], 1, 4, 4, torch.device("cpu"))
+    assert float(host_of(host).sum()) == 4.0
+    m = host.clone()                                     # stands for the device copy (on the CPU box_mask returns the host tensor itself)
+    m.af_host = (host, m._version)
+    assert host_of(m) is host
+    m.mul_(0)                                            # the device mask changed: its host copy no longer describes it
+    assert host_of(m) is m
