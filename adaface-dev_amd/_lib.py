@@ -25,7 +25,7 @@ EXPORTS = (
     "af_silu_f16", "af_attention_lse", "af_groupnorm_stats", "af_attention_bwd_scratch_bytes", "af_attention_bwd",
     "af_groupnorm_bwd", "af_layernorm_bwd", "af_geglu_fwd", "af_geglu_bwd", "af_sumpool2x2", "af_add_f16",
     "af_transpose_tokens", "af_cadamw_step", "af_attention_ex", "af_colsum", "af_quickgelu_fwd", "af_quickgelu_bwd",
-    "af_scale_f32", "af_affine_prelu", "af_maxpool2x2", "af_global_avgpool", "af_se_residual_prelu", "af_axpy_f16", "af_dora_combine", "af_mul_f16", "af_im2col3x3", "af_colsum_tall", "af_softmax_rows", "af_attention_strided", "af_clamp_f32", "af_mask_pairs", "af_prefetch",
+    "af_scale_f32", "af_affine_prelu", "af_maxpool2x2", "af_global_avgpool", "af_se_residual_prelu", "af_axpy_f16", "af_dora_combine", "af_mul_f16", "af_im2col3x3", "af_colsum_tall", "af_softmax_rows", "af_attention_strided", "af_clamp_f32", "af_mask_pairs", "af_prefetch", "af_prefetch_ex",
     "af_xattn_scores", "af_xattn_softmax_pv", "af_xattn_softmax_pv_bwd", "af_xattn_rowmix", "af_xattn_colmix_ws_bytes", "af_xattn_colmix",
     "af_layernorm_param_grads", "af_transpose_tokens_pair", "af_ff_fused", "af_xattn_fused",
     "af_softmax_rows_bwd", "af_affine_prelu_bwd", "af_maxpool2x2_bwd", "af_se_gate_grad", "af_se_residual_prelu_bwd",
@@ -146,6 +146,7 @@ def lib() -> C.CDLL:
     L.af_softmax_rows.argtypes = [vp, vp, i64, i32, vp]
     L.af_mask_pairs.argtypes = [vp, vp, i32, vp]
     L.af_prefetch.argtypes = [vp, i64, vp]
+    L.af_prefetch_ex.argtypes = [vp, i64, i32, vp]
     L.af_xattn_scores.argtypes = [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, f32, vp]
     L.af_xattn_softmax_pv.argtypes = [vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, vp]
     L.af_xattn_softmax_pv_bwd.argtypes = [vp, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp]

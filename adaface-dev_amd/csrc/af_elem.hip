@@ -265,6 +265,17 @@ extern "C" int af_prefetch(const void* ptr, int64_t bytes, void* stream) {
   return af_check_launch("af_prefetch");
 }
 
+extern "C" int af_prefetch_ex(const void* ptr, int64_t bytes, int max_workgroups, void* stream) {
+  AF_REQUIRE(ptr && bytes >= 0 && max_workgroups > 0 && (reinterpret_cast<uintptr_t>(ptr) & 15) == 0, "af_prefetch_ex: 16-byte aligned range, max_workgroups > 0");
+  const long nlines = bytes / 128;
+  if (nlines == 0) return 0;
+  AfLaunchScope scope(AF_FAM_ELEM, stream);
+  const long want = (nlines + 255) / 256;
+  const unsigned grid = (unsigned)(want < max_workgroups ? want : max_workgroups);
+  hipLaunchKernelGGL(prefetch_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const unsigned*)ptr, nlines, (unsigned*)nullptr);
+  return af_check_launch("af_prefetch_ex");
+}
+
 extern "C" int af_mask_pairs(void* p, const void* cls, int N, void* stream) {
   AF_REQUIRE(p && cls && N > 0 && N % 8 == 0, "af_mask_pairs: N must be a positive multiple of 8");
   AfLaunchScope scope(AF_FAM_ELEM, stream);

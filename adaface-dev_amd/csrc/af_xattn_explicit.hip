@@ -159,20 +159,25 @@ __global__ __launch_bounds__(256) void xattn_rowmix_kernel(const float* __restri
 //   * a lane holds ONE operand element per instruction -- A[key = lane & 15][query = lane >> 4], B[query = lane >> 4][channel = lane & 15] -- so the
 //     fragments are plain coalesced loads of the natural layouts: 4 rows x 16 consecutive floats of w, 4 rows x 16 consecutive halves of x; nothing
 //     is transposed, staged in LDS or shared between waves;
-//   * a WAVE owns one query chunk (Nq / 32 queries) of one (batch item, head, group of NT 16-channel tiles) and all ceil(L / 16) key tiles:
-//     up to 8 x NT accumulators, 8 + NT loads per 4 queries for 8 NT MFMAs, the next step's fragments requested before this step's MFMAs.
-// Grid (8 * ngroups, heads, B), 4 waves = 4 consecutive chunks per workgroup; the 32 chunk partials are summed by xattn_colmix_final_kernel
-// (two deterministic passes, no atomics, as before).  At full size: 256 workgroups, 21 MFMAs per step, ~0.7 M MFMAs of 32 cycles over 1024 SIMDs.
+//   * a WORKGROUP owns one of 16 query chunks of one (batch item, head, group of NT 16-channel tiles) and all ceil(L / 16) key tiles; its four
+//     waves take a quarter of the chunk each: up to 8 x NT accumulators per wave, 8 + NT loads per 4 queries for 8 NT MFMAs, the fragments of the
+//     next TWO steps in flight under this step's MFMAs (the loads are HBM-latency bound: with one step in flight the kernel took 50 us, 5x its
+//     MFMA time); the four waves' sums meet in LDS in wave order (deterministic) and leave as one fp32 slab.
+// Grid (16 * ngroups, heads, B); the 16 chunk slabs are summed by xattn_colmix_final_kernel (two deterministic passes, no atomics, as before).
+// At full size ([4, 8, 4096, 97] x 40): 512 workgroups, 21 MFMAs per step, ~0.7 M MFMAs of 32 cycles over 1024 SIMDs.
 template <int NT>
 __global__ __launch_bounds__(256) void xattn_colmix_mfma_kernel(const float* __restrict__ w, const half_t* __restrict__ x, int ldx,
                                                                 float* __restrict__ partial, int B, int Nq, int L, int heads, int d, int NZ) {
+  __shared__ float red[128][NT * 16];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int zc = (blockIdx.x & 7) * 4 + wave;                  // this wave's query chunk, 0 .. NZ - 1 (NZ = 32)
-  const int ng = blockIdx.x >> 3;                              // channel group: tiles ng * NT ..
+  const int zc = blockIdx.x % NZ;                              // this workgroup's query chunk
+  const int ng = blockIdx.x / NZ;                              // channel group: tiles ng * NT ..
   const int h = blockIdx.y, b = blockIdx.z;
   const int per = (Nq + NZ - 1) / NZ;
-  const int i0 = zc * per, i1 = min(Nq, i0 + per);
+  const int sub = ((per + 15) >> 4) << 2;                      // queries per wave: a quarter of the chunk, rounded up to whole steps of 4
+  const int c1 = min(Nq, (zc + 1) * per);
+  const int i0 = zc * per + wave * sub, i1 = min(c1, i0 + sub);
   const int MT = (L + 15) >> 4;
   const int lr = lane & 15, lk = lane >> 4;
   const int cbase = ng * NT * 16;
@@ -206,31 +211,46 @@ __global__ __launch_bounds__(256) void xattn_colmix_mfma_kernel(const float* __r
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], bf[nt], acc[mt][nt], 0, 0, 0);
       }
   };
-  float a0[8], b0[NT], a1[8], b1[NT];
-  if (i0 < i1) load(i0, a0, b0);
-  for (int i = i0; i < i1; i += 8) {
-    if (i + 4 < i1) load(i + 4, a1, b1);
+  // three fragment sets rotate: steps beyond the wave's range load nothing (all lanes masked) and multiply zeros
+  float a0[8], b0[NT], a1[8], b1[NT], a2[8], b2[NT];
+  load(i0, a0, b0);
+  load(i0 + 4, a1, b1);
+  for (int i = i0; i < i1; i += 12) {
+    load(i + 8, a2, b2);
     mma(a0, b0);
     if (i + 4 < i1) {
-      if (i + 8 < i1) load(i + 8, a0, b0);
+      load(i + 12, a0, b0);
       mma(a1, b1);
     }
-  }
-  // D: column (channel) = lane & 15, row (key) = 4 (lane >> 4) + r.  An empty chunk still writes its zeros: the final pass sums all NZ slabs.
-  const int Cn = heads * d;
-#pragma unroll
-  for (int mt = 0; mt < 8; ++mt)
-    if (mt < MT) {
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const int c = cbase + nt * 16 + lr;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int j = mt * 16 + 4 * lk + r;
-          if (j < L && c < d) partial[(((size_t)zc * B + b) * L + j) * Cn + h * d + c] = acc[mt][nt][r];
-        }
-      }
+    if (i + 8 < i1) {
+      load(i + 16, a1, b1);
+      mma(a2, b2);
     }
+  }
+  // D: column (channel) = lane & 15, row (key) = 4 (lane >> 4) + r.  The four waves add into the LDS tile in wave order.
+  for (int wv = 0; wv < 4; ++wv) {
+    if (wave == wv) {
+#pragma unroll
+      for (int mt = 0; mt < 8; ++mt)
+        if (mt < MT) {
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float* cell = &red[mt * 16 + 4 * lk + r][nt * 16 + lr];
+              *cell = wv == 0 ? acc[mt][nt][r] : *cell + acc[mt][nt][r];
+            }
+        }
+    }
+    __syncthreads();
+  }
+  // an empty chunk still writes its zeros: the final pass sums all NZ slabs
+  const int Cn = heads * d;
+  for (int e = threadIdx.x; e < MT * 16 * NT * 16; e += 256) {
+    const int j = e / (NT * 16), cc = e - j * (NT * 16);
+    const int c = cbase + cc;
+    if (j < L && c < d) partial[(((size_t)zc * B + b) * L + j) * Cn + h * d + c] = red[j][cc];
+  }
 }
 
 __global__ __launch_bounds__(256) void xattn_colmix_final_kernel(const float* __restrict__ partial, half_t* __restrict__ out, int ldout, float alpha,
@@ -305,10 +325,9 @@ extern "C" int af_xattn_colmix(const void* w, const void* x, int ldx, void* out,
   AF_REQUIRE(ldx >= heads * d && ldout >= heads * d, "af_xattn_colmix: bad leading dimensions");
   AF_REQUIRE(workspace_bytes >= af_xattn_colmix_ws_bytes(B, L, heads, d), "af_xattn_colmix: workspace too small (af_xattn_colmix_ws_bytes)");
   const int NZ = AF_XATTN_COLMIX_CHUNKS;
-  static_assert(AF_XATTN_COLMIX_CHUNKS == 32, "xattn_colmix_mfma_kernel: 8 workgroups x 4 waves of query chunks");
-  AfLaunchScope scope(AF_FAM_XATTN, stream);
+    AfLaunchScope scope(AF_FAM_XATTN, stream);
   const int nt = d <= 16 ? 1 : (d <= 32 ? 2 : (d <= 48 ? 3 : 4));
-  const dim3 grid(8 * ((d + nt * 16 - 1) / (nt * 16)), heads, B);
+  const dim3 grid(NZ * ((d + nt * 16 - 1) / (nt * 16)), heads, B);
   switch (nt) {
     case 1: hipLaunchKernelGGL(xattn_colmix_mfma_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)w, (const half_t*)x, ldx, (float*)workspace, B, Nq, L, heads, d, NZ); break;
     case 2: hipLaunchKernelGGL(xattn_colmix_mfma_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)w, (const half_t*)x, ldx, (float*)workspace, B, Nq, L, heads, d, NZ); break;

@@ -234,6 +234,69 @@ def partials_of(x: torch.Tensor) -> Optional["GnPartials"]:
     return gn
 
 
+class WeightPrefetcher:
+    """Weight prefetch on a SECOND stream inside a captured step (round 5 experiment; bench.py --prefetch-stream).
+
+    Inside a denoise step every GEMM meets its weights cold in HBM (1.72 GB stream through once per U-Net pass; the GEMM family takes 7.0 ms
+    on warm operands and 8.6 ms in the step, profiles/r04v_*).  The in-kernel prologue touch (af_common.h) only covers the first K stages.
+    This object replays the step's own launch order: `record()` + one eager pass notes (weight pointer, bytes) of every weight-consuming
+    launch; during the capture, in front of launch i the side stream waits for the main stream's position (so it runs beside launch i) and
+    reads the weights of launch i + depth (af_prefetch_ex: one dword per 128-byte line, a capped grid), which brings them into the
+    Infinity Cache (and 1/8 of them into the consumer XCD's L2).  The main stream never waits for the side stream except once at the end
+    of the capture (`join`): the prefetch is a hint, results are bit-identical with and without it."""
+
+    def __init__(self, depth: int = 2, max_workgroups: int = 64, min_bytes: int = 1 << 18):
+        self.depth, self.max_wg, self.min_bytes = depth, max_workgroups, min_bytes
+        self.plan, self.mode, self.i, self.side, self.issued = [], None, 0, None, 0
+
+    def record(self):
+        self.plan, self.mode = [], "record"
+        return self
+
+    def play(self, side_stream):
+        self.mode, self.i, self.side, self.issued = "play", 0, side_stream, 0
+        return self
+
+    def stop(self):
+        self.mode = None
+
+    def note(self, ptr: int, nbytes: int):
+        if self.mode == "record":
+            self.plan.append((ptr, nbytes))
+        elif self.mode == "play":
+            i = self.i
+            self.i = i + 1
+            j = i + self.depth
+            if i < len(self.plan) and self.plan[i][0] != ptr:
+                raise RuntimeError("WeightPrefetcher: the captured pass does not follow the recorded launch order")
+            if j < len(self.plan) and self.plan[j][1] >= self.min_bytes and torch.cuda.is_current_stream_capturing():
+                ev = torch.cuda.Event()
+                ev.record()                                  # the main stream's position: everything before launch i
+                self.side.wait_event(ev)
+                _lib.check(_lib.lib().af_prefetch_ex(self.plan[j][0], self.plan[j][1], self.max_wg, self.side.cuda_stream), "af_prefetch_ex")
+                self.issued += 1
+
+    def join(self):
+        """End of the capture: the forked stream must rejoin the capturing one."""
+        if self.mode == "play" and self.side is not None and self.issued:
+            torch.cuda.current_stream().wait_stream(self.side)
+        self.mode = None
+
+
+_weight_prefetcher: Optional[WeightPrefetcher] = None
+
+
+def set_weight_prefetcher(p: Optional[WeightPrefetcher]):
+    global _weight_prefetcher
+    _weight_prefetcher = p
+
+
+def _pf_note(*weights):
+    if _weight_prefetcher is not None and _weight_prefetcher.mode is not None:
+        for w in weights:
+            _weight_prefetcher.note(w.data_ptr(), w.numel() * w.element_size())
+
+
 def _launch_gemm(d: "GemmDesc", device, what: str, tile: int = 0, splits: int = 0, gn_cpg: int = 0):
     """Pick (tile, splits) -- explicit args > recorder (autotune) > table > heuristic -- and launch.  gn_cpg > 0: the caller's output feeds a
     GroupNorm with groups of gn_cpg channels; when the chosen launch can (af_gemm_gn_stats_ok) it also writes the partial statistics and a
@@ -279,6 +342,8 @@ def _launch_gemm(d: "GemmDesc", device, what: str, tile: int = 0, splits: int = 
             ws = torch.empty((nb, 128, 32, 2), dtype=torch.float32, device=device)
             d.gn_partials, d.gn_cpg = ws.data_ptr(), gn_cpg
             gn = GnPartials(ws, rpb // 128, gn_cpg, nb, rpb, d.N)
+    if _weight_prefetcher is not None and _weight_prefetcher.mode is not None:
+        _weight_prefetcher.note(int(d.wt), int(d.kpad) * round_up(int(d.N), 128) * 2)
     _lib.check(_lib.lib().af_gemm(C.byref(d), _stream()), what)
     return gn
 
@@ -408,6 +473,7 @@ def ff_fused(x2d: torch.Tensor, pw1: PackedWeight, pw2: PackedWeight, residual: 
     if residual is not None:
         _chk_f16(residual, "ff_fused.residual")
         assert residual.shape == out.shape
+    _pf_note(pw1.wt, pw2.wt)
     rc = _lib.lib().af_ff_fused(_p(x2d), _p(pw1.wt), _p(pw1.bias), _p(pw1.ln_cs), float(pw1.ln_eps), pw1.kpad, _p(pw2.wt), _p(pw2.bias), pw2.kpad,
                                 _p(residual), _p(out), M, Cn, pw2.K, _p(_zero_page(x2d.device)), _stream())
     _lib.check(rc, "af_ff_fused")
@@ -430,6 +496,7 @@ def xattn_fused(x2d: torch.Tensor, pw_q: PackedWeight, k: torch.Tensor, vt: torc
     if residual is not None:
         _chk_f16(residual, "xattn_fused.residual")
         assert residual.shape == x2d.shape
+    _pf_note(pw_q.wt, pw_o.wt)
     rc = _lib.lib().af_xattn_fused(_p(x2d), _p(pw_q.wt), _p(pw_q.bias), _p(pw_q.ln_cs), float(pw_q.ln_eps), pw_q.kpad, _p(k), int(ldk), _p(vt), int(vt.stride(0)),
                                    int(vt.stride(1)), _p(pw_o.wt), _p(pw_o.bias), pw_o.kpad, _p(residual), _p(out), B, N, L, Cn, heads, float(scale),
                                    _zero_page(x2d.device).data_ptr(), _stream())
@@ -490,6 +557,7 @@ def gn_proj_fused(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps:
         return None
     _chk_f16(x, "gn_proj_fused.x")
     out = torch.empty((B * hw, pw.N), dtype=F16, device=x.device)
+    _pf_note(pw.wt)
     rc = _lib.lib().af_gn_proj_fused(_p(x), _p(gn.ws), gn.nblk, _p(gamma), _p(beta), float(eps), _p(pw.wt), _p(pw.bias), pw.kpad, _p(out), B, hw, c, groups,
                                      _zero_page(x.device).data_ptr(), _stream())
     _lib.check(rc, "af_gn_proj_fused")

@@ -451,12 +451,27 @@ def run_denoise(args, ctx, dev):
             g = torch.cuda.CUDAGraph()
             s = torch.cuda.Stream()
             s.wait_stream(torch.cuda.current_stream())
+            pf = None
+            if args.prefetch_stream > 0:
+                # weight prefetch beside the GEMMs on a second stream of the SAME graph (ops.WeightPrefetcher): record the launch order
+                # in this eager pass, replay it depth launches ahead during the capture
+                pf = ops.WeightPrefetcher(depth=args.prefetch_stream, max_workgroups=args.prefetch_wgs)
+                ops.set_weight_prefetcher(pf.record())
             with torch.cuda.stream(s):
                 unet_eps()
             torch.cuda.current_stream().wait_stream(s)
+            side = torch.cuda.Stream() if pf is not None else None
             # thread_local: with N > 1 the RCCL watchdog thread may touch the HIP runtime while this thread captures
             with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                if pf is not None:
+                    pf.play(side)
                 state["eps"] = unet_eps()
+                if pf is not None:
+                    pf.join()
+            if pf is not None:
+                print(f"[bench] weight prefetch stream: {pf.issued} prefetch launches for {len(pf.plan)} weight-consuming launches, "
+                      f"depth {pf.depth}, <= {pf.max_wg} workgroups each", file=sys.stderr)
+                ops.set_weight_prefetcher(None)
             state["graph"] = g
         state["x"] = x.clone()
         for i in range(args.warmup):
@@ -623,6 +638,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=4, help="images per GPU (U-Net batch is 2x with CFG)")
     ap.add_argument("--no-graph", action="store_true", help="launch kernels eagerly instead of replaying a hipGraph")
+    ap.add_argument("--prefetch-stream", type=int, default=int(os.environ.get("AF_PREFETCH_STREAM", "0")), metavar="DEPTH",
+                    help="denoise leg: read the weights of launch i + DEPTH on a second stream of the captured graph while launch i runs (0 = off)")
+    ap.add_argument("--prefetch-wgs", type=int, default=int(os.environ.get("AF_PREFETCH_WGS", "64")), help="workgroups per prefetch launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-ffn-lora", action="store_true", help="train leg: without the U-Net's trainable FFN DoRA adapters")

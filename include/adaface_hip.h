@@ -289,8 +289,8 @@ int af_attention_scores(const void* q, const void* k, void* score, void* prob, i
  *   af_xattn_rowmix          out[B*Nq, ldout] = alpha * w x      (w fp32 [B,heads,Nq,L], x fp16 [B*L, ldx]):   dq = scale * dscore k
  *   af_xattn_colmix          out[B*L, ldout]  = alpha * w^T x    (x fp16 [B*Nq, ldx]):   dv = prob^T dout,  dk = scale * dscore^T q;
  *                            per (batch item, head) a GEMM over the queries on v_mfma_f32_16x16x4_f32 (f32 in / f32 accumulate: w is not rounded);
- *                            deterministic two-pass reduction over 32 query chunks through a caller-owned fp32 workspace          */
-#define AF_XATTN_COLMIX_CHUNKS 32
+ *                            deterministic two-pass reduction over 16 query chunks through a caller-owned fp32 workspace          */
+#define AF_XATTN_COLMIX_CHUNKS 16
 int af_xattn_scores(const void* q, int ldq, const void* k, int ldk, void* score, int B, int Nq, int L, int heads, int d, float scale, void* stream);
 int af_xattn_softmax_pv(const void* score, const void* v, int ldv, void* prob, void* o, int ldo, int B, int Nq, int L, int heads, int d, void* stream);
 int af_xattn_softmax_pv_bwd(const void* prob, const void* v, int ldv, const void* dout, int lddo, const void* dprob_ext, void* dscore, int B, int Nq,
@@ -380,6 +380,9 @@ int af_mask_pairs(void* p, const void* cls, int N, void* stream);
 /* read every 128-byte line of [ptr, ptr + bytes) once (no writes): cache warm-up of packed weights ahead of the GEMM that streams them,
    meant for a side stream */
 int af_prefetch(const void* ptr, int64_t bytes, void* stream);
+/* the same with the grid capped at max_workgroups (256 threads each, striding over the lines): a prefetcher that runs BESIDE the GEMMs of a
+   step on a second stream must not take the chip from them (ops.WeightPrefetcher) */
+int af_prefetch_ex(const void* ptr, int64_t bytes, int max_workgroups, void* stream);
 
 /* ---- ArcFace ResNetFace-18 IR-SE face encoder (reference evaluation/arcface_resnet.py:62-97, 139-154, 157-217) ----
  * NHWC fp16 activations, C % 8 == 0.  Convolutions / FCs are af_gemm calls with eval-mode BatchNorm folded on the host.

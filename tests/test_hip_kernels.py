@@ -253,7 +253,7 @@ def test_groupnorm_drops_producer_statistics_after_an_in_place_write(dev):
     assert ops.partials_of(view) is not None, "a view shares storage address and version counter"
     fresh = ops.groupnorm(y, gam.to(dev), bet.to(dev), 1e-5, False)
     y.add_(3.0)                                          # bumps y._version (and the view's)
-    y[:, :, :, : cout // 2].mul_(2.0)
+    y[:, : H // 2].mul_(4.0)                             # (not a per-group affine map, which GroupNorm would undo: half of the PIXELS)
     assert ops.partials_of(y) is None and ops.partials_of(view) is None
     for t in (y, view):
         out = ops.groupnorm(t, gam.to(dev), bet.to(dev), 1e-5, False).reshape(B, H, W, cout)
