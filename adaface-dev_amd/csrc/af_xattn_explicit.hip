@@ -165,10 +165,12 @@ __global__ __launch_bounds__(256) void xattn_rowmix_kernel(const float* __restri
 //     MFMA time); the four waves' sums meet in LDS in wave order (deterministic) and leave as one fp32 slab.
 // Grid (16 * ngroups, heads, B); the 16 chunk slabs are summed by xattn_colmix_final_kernel (two deterministic passes, no atomics, as before).
 // At full size ([4, 8, 4096, 97] x 40): 512 workgroups, 21 MFMAs per step, ~0.7 M MFMAs of 32 cycles over 1024 SIMDs.
-template <int NT>
+// The loop is BRANCH-FREE: every load is unconditional on a clamped (always valid) address and the out-of-range lanes are zeroed by a select when the
+// step is consumed -- with `cond ? load : 0` hipcc built a branch per load and an s_waitcnt vmcnt(0) behind every one of them (50 us per call).
+template <int NT, int MT>
 __global__ __launch_bounds__(256) void xattn_colmix_mfma_kernel(const float* __restrict__ w, const half_t* __restrict__ x, int ldx,
                                                                 float* __restrict__ partial, int B, int Nq, int L, int heads, int d, int NZ) {
-  __shared__ float red[128][NT * 16];
+  __shared__ float red[MT * 16][NT * 16];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int zc = blockIdx.x % NZ;                              // this workgroup's query chunk
@@ -178,69 +180,89 @@ __global__ __launch_bounds__(256) void xattn_colmix_mfma_kernel(const float* __r
   const int sub = ((per + 15) >> 4) << 2;                      // queries per wave: a quarter of the chunk, rounded up to whole steps of 4
   const int c1 = min(Nq, (zc + 1) * per);
   const int i0 = zc * per + wave * sub, i1 = min(c1, i0 + sub);
-  const int MT = (L + 15) >> 4;
   const int lr = lane & 15, lk = lane >> 4;
   const int cbase = ng * NT * 16;
   const float* wp = w + (((size_t)b * heads + h) * Nq) * L;
   const half_t* xp = x + (size_t)b * Nq * ldx + h * d;
   const floatx4 zf = {0.f, 0.f, 0.f, 0.f};
-  floatx4 acc[8][NT];
+  floatx4 acc[MT][NT];
 #pragma unroll
-  for (int mt = 0; mt < 8; ++mt)
+  for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = zf;
-  auto load = [&](int i, float (&a)[8], float (&bf)[NT]) {
-    const int ii = i + lk;
-    const bool ok = ii < i1;
+  // per-lane column offsets (clamped) and validity, fixed for the whole kernel
+  int jo[MT], co[NT];
+  bool jv[MT], cv[NT];
 #pragma unroll
-    for (int mt = 0; mt < 8; ++mt) {
-      const int j = mt * 16 + lr;
-      a[mt] = (mt < MT && ok && j < L) ? wp[(size_t)ii * L + j] : 0.f;
-    }
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int c = cbase + nt * 16 + lr;
-      bf[nt] = (ok && c < d) ? (float)xp[(size_t)ii * ldx + c] : 0.f;
-    }
-  };
-  auto mma = [&](const float (&a)[8], const float (&bf)[NT]) {
-#pragma unroll
-    for (int mt = 0; mt < 8; ++mt)
-      if (mt < MT) {
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], bf[nt], acc[mt][nt], 0, 0, 0);
-      }
-  };
-  // three fragment sets rotate: steps beyond the wave's range load nothing (all lanes masked) and multiply zeros
-  float a0[8], b0[NT], a1[8], b1[NT], a2[8], b2[NT];
-  load(i0, a0, b0);
-  load(i0 + 4, a1, b1);
-  for (int i = i0; i < i1; i += 12) {
-    load(i + 8, a2, b2);
-    mma(a0, b0);
-    if (i + 4 < i1) {
-      load(i + 12, a0, b0);
-      mma(a1, b1);
-    }
-    if (i + 8 < i1) {
-      load(i + 16, a1, b1);
-      mma(a2, b2);
-    }
+  for (int mt = 0; mt < MT; ++mt) {
+    const int j = mt * 16 + lr;
+    jv[mt] = j < L;
+    jo[mt] = min(j, L - 1);
   }
-  // D: column (channel) = lane & 15, row (key) = 4 (lane >> 4) + r.  The four waves add into the LDS tile in wave order.
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int c = cbase + nt * 16 + lr;
+    cv[nt] = c < d;
+    co[nt] = min(c, d - 1);
+  }
+  struct Frag {
+    float a[MT];
+    half_t b[NT];
+    bool ok;
+  };
+  auto load = [&](int i, Frag& f) {
+    const int ii = i + lk;
+    f.ok = ii < i1;
+    const int ic = min(ii, Nq - 1);
+    const float* wr = wp + (size_t)ic * L;
+    const half_t* xr = xp + (size_t)ic * ldx;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) f.a[mt] = wr[jo[mt]];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) f.b[nt] = xr[co[nt]];
+  };
+  auto mma = [&](const Frag& f) {
+    float bf[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bf[nt] = (f.ok && cv[nt]) ? (float)f.b[nt] : 0.f;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const float av = (f.ok && jv[mt]) ? f.a[mt] : 0.f;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bf[nt], acc[mt][nt], 0, 0, 0);
+    }
+  };
+  // three fragment sets rotate, two steps in flight under the MFMAs of the third; steps past the wave's range read a clamped row and multiply zeros
+  // (sched_barrier: without it hipcc sinks each load group down to its consumers -- fewer live registers, and every step a full memory round trip)
+  Frag f0, f1, f2;
+  load(i0, f0);
+  load(i0 + 4, f1);
+  for (int i = i0; i < i1; i += 12) {
+    load(i + 8, f2);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(f0);
+    __builtin_amdgcn_sched_barrier(0);
+    load(i + 12, f0);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(f1);
+    __builtin_amdgcn_sched_barrier(0);
+    load(i + 16, f1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(f2);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // D: column (channel) = lane & 15, row (key) = 4 (lane >> 4) + r.  The four waves add into the LDS tile in wave order (deterministic).
   for (int wv = 0; wv < 4; ++wv) {
     if (wave == wv) {
 #pragma unroll
-      for (int mt = 0; mt < 8; ++mt)
-        if (mt < MT) {
+      for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              float* cell = &red[mt * 16 + 4 * lk + r][nt * 16 + lr];
-              *cell = wv == 0 ? acc[mt][nt][r] : *cell + acc[mt][nt][r];
-            }
-        }
+          for (int r = 0; r < 4; ++r) {
+            float* cell = &red[mt * 16 + 4 * lk + r][nt * 16 + lr];
+            *cell = wv == 0 ? acc[mt][nt][r] : *cell + acc[mt][nt][r];
+          }
     }
     __syncthreads();
   }
@@ -251,6 +273,13 @@ __global__ __launch_bounds__(256) void xattn_colmix_mfma_kernel(const float* __r
     const int c = cbase + cc;
     if (j < L && c < d) partial[(((size_t)zc * B + b) * L + j) * Cn + h * d + c] = red[j][cc];
   }
+}
+
+template <int NT>
+static void launch_colmix_mfma(dim3 grid, hipStream_t s, const float* w, const half_t* x, int ldx, float* ws, int B, int Nq, int L, int heads, int d, int NZ) {
+  if (L <= 80) hipLaunchKernelGGL((xattn_colmix_mfma_kernel<NT, 5>), grid, dim3(256), 0, s, w, x, ldx, ws, B, Nq, L, heads, d, NZ);
+  else if (L <= 112) hipLaunchKernelGGL((xattn_colmix_mfma_kernel<NT, 7>), grid, dim3(256), 0, s, w, x, ldx, ws, B, Nq, L, heads, d, NZ);
+  else hipLaunchKernelGGL((xattn_colmix_mfma_kernel<NT, 8>), grid, dim3(256), 0, s, w, x, ldx, ws, B, Nq, L, heads, d, NZ);
 }
 
 __global__ __launch_bounds__(256) void xattn_colmix_final_kernel(const float* __restrict__ partial, half_t* __restrict__ out, int ldout, float alpha,
@@ -329,10 +358,10 @@ extern "C" int af_xattn_colmix(const void* w, const void* x, int ldx, void* out,
   const int nt = d <= 16 ? 1 : (d <= 32 ? 2 : (d <= 48 ? 3 : 4));
   const dim3 grid(NZ * ((d + nt * 16 - 1) / (nt * 16)), heads, B);
   switch (nt) {
-    case 1: hipLaunchKernelGGL(xattn_colmix_mfma_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)w, (const half_t*)x, ldx, (float*)workspace, B, Nq, L, heads, d, NZ); break;
-    case 2: hipLaunchKernelGGL(xattn_colmix_mfma_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)w, (const half_t*)x, ldx, (float*)workspace, B, Nq, L, heads, d, NZ); break;
-    case 3: hipLaunchKernelGGL(xattn_colmix_mfma_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)w, (const half_t*)x, ldx, (float*)workspace, B, Nq, L, heads, d, NZ); break;
-    default: hipLaunchKernelGGL(xattn_colmix_mfma_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)w, (const half_t*)x, ldx, (float*)workspace, B, Nq, L, heads, d, NZ); break;
+    case 1: launch_colmix_mfma<1>(grid, (hipStream_t)stream, (const float*)w, (const half_t*)x, ldx, (float*)workspace, B, Nq, L, heads, d, NZ); break;
+    case 2: launch_colmix_mfma<2>(grid, (hipStream_t)stream, (const float*)w, (const half_t*)x, ldx, (float*)workspace, B, Nq, L, heads, d, NZ); break;
+    case 3: launch_colmix_mfma<3>(grid, (hipStream_t)stream, (const float*)w, (const half_t*)x, ldx, (float*)workspace, B, Nq, L, heads, d, NZ); break;
+    default: launch_colmix_mfma<4>(grid, (hipStream_t)stream, (const float*)w, (const half_t*)x, ldx, (float*)workspace, B, Nq, L, heads, d, NZ); break;
   }
   const long n = (long)B * L * heads * d;
   hipLaunchKernelGGL(xattn_colmix_final_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float*)workspace,

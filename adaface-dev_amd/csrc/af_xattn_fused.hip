@@ -331,6 +331,10 @@ constexpr int XT_LDS = XT_R + 2 * XT_STAGE;            // 163,840
 // NOT v_mfma_f32_16x16x16_f16 (-DAF_XATTN_K16 builds it): accumulating onto the result of a 16x16x32 MFMA with the 16-deep form gave results that
 // changed from run to run on the same inputs (hipcc 7.2, gfx950: tools/probes/r04g_xattn_debug.py localised it -- the q projection exact, single
 // (token tile, head) cells of the attention output wrong at random); with the zero-padded 32-deep form every cell is exact.
+// ROOT CAUSE (round 5, tools/probes/r05a_mfma_k16_probe.hip -> profiles/r05a_mfma_k16_probe.txt): a stand-alone chain of the two opcodes on one
+// accumulator, no LDS and no barriers, differs in 199 of 200 launches whenever hipcc issues them back to back -- the 4-pass opcode reads its SrcC
+// before the 8-pass one in front of it has written it, and hipcc's gfx950 hazard recogniser inserts no wait state for that pair.  A compiler hazard
+// bug, not a race in this kernel: one opcode throughout (hardware-forwarded accumulate chain) is the fix.
 __device__ __forceinline__ floatx4 mfma_k16(const half4_t& a, const half4_t& b, const floatx4& c) {
 #ifdef AF_XATTN_K16
   return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0);
