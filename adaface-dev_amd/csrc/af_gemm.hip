@@ -477,7 +477,9 @@ int launch(const GemmDev& p0, hipStream_t stream) {
   p.kt_per_split = (nk + p.splits - 1) / p.splits;
   p.splits = (nk + p.kt_per_split - 1) / p.kt_per_split;  // no empty split
   const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(half_t) + (BM == 64 ? AF_WPF_DUMP_BYTES : 0);   // staging buffers (+ the weight prefetch's dump area)
-  if (p.counters && (EPI != EPI_STD || p.splits <= 1 || p.splits > 4 || tiles_m * p.tiles_n > AF_SPLITK_MAX_TILES)) p.counters = nullptr;
+  // in-kernel reduction by the last-arriving slice: up to 16 slices here (round 5: the training legs' small outputs, where the separate reduce pass
+  // is a 5 us launch over a few KB -- ops.SPLITK_FUSED_BYTES); the caller decides WHEN (af_gemm_desc.splitk_fused), this is only what the code supports
+  if (p.counters && (EPI != EPI_STD || p.splits <= 1 || p.splits > 16 || tiles_m * p.tiles_n > AF_SPLITK_MAX_TILES)) p.counters = nullptr;
   dim3 grid(tiles_m * p.tiles_n, p.splits), block(256);
   hipLaunchKernelGGL((af_gemm_kernel<BM, BN, TAPS, EPI, FAST>), grid, block, lds, stream, p);
   if (EPI == EPI_STD && p.splits > 1 && p.counters == nullptr) {

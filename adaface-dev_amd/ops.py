@@ -206,6 +206,12 @@ def _splitk_workspace(device) -> torch.Tensor:
 SPLITK_FUSED_MAX = int(_os.environ.get("AF_SPLITK_FUSED_MAX", "0"))
 
 
+# Round 5: the same in-kernel reduction chosen by SIZE for the register-staged tiles (1 / 2): when all slabs of a launch together are at most this
+# many bytes (the training legs' batch-1 passes: M 64 ... 1024 rows, a few output tiles, 2 - 16 slices) the reduce pass is a ~5 us launch that moves
+# a few hundred KB, and the last-arriving workgroup of a tile reads its slabs in about a microsecond.  0 = off.
+SPLITK_FUSED_BYTES = int(_os.environ.get("AF_SPLITK_FUSED_BYTES", "0"))
+
+
 GN_FROM_PRODUCER = _os.environ.get("AF_GN_FROM_PRODUCER", "1") != "0"   # GroupNorm statistics from the producing GEMM's epilogue (0: always a statistics pass)
 
 
@@ -330,7 +336,8 @@ def _launch_gemm(d: "GemmDesc", device, what: str, tile: int = 0, splits: int = 
             ws = _splitk_workspace(device)
             d.splits = max(1, min(d.splits, (ws.numel() * 4 - _lib.AF_SPLITK_COUNTER_BYTES) // (d.M * d.N * 4)))
             d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
-            d.splitk_fused = int(d.splits <= SPLITK_FUSED_MAX and not f32)
+            small = d.tile in (0, 1, 2) and d.splits <= 16 and d.splits * d.M * d.N * 4 <= SPLITK_FUSED_BYTES
+            d.splitk_fused = int((d.splits <= SPLITK_FUSED_MAX or small) and not f32)
     gn = None
     if gn_cpg and GN_FROM_PRODUCER and _tune_recorder is None:
         rpb = d.rows_per_batch if d.rows_per_batch > 0 else d.M

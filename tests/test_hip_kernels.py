@@ -1023,6 +1023,22 @@ def test_split_k_in_kernel_reduction_is_bit_identical_and_repeatable(dev, tile, 
     x = rng.synth_input("skf.x", (2, 16, 16, 640), seed=5).half().to(dev)
     x2 = rng.synth_input("skf.x2", (2, 16, 16, 320), seed=5).half().to(dev)
     pc = ops.pack_conv3x3(rng.synth_input("skf.wc", (640, 960, 3, 3), seed=5) * (960 * 9) ** -0.5, rng.synth_input("skf.bc", (640,), seed=5), dev)
+    if tile in (1, 2):
+        # round 5: chosen by SIZE (ops.SPLITK_FUSED_BYTES) for the register-staged tiles, up to 16 slices: the training legs' small outputs
+        small = []
+        for M, N, K, sp in [(256, 256, 2304, 6), (64, 512, 4608, 8), (1024, 128, 1152, 3), (77, 768, 3072, 12), (256, 1280, 5120, 16)]:
+            a = rng.synth_input(f"sks.a{M}x{K}", (M, K), seed=6).half().to(dev)
+            pw = ops.pack_matrix(rng.synth_input(f"sks.w{N}x{K}", (N, K), seed=6) * K ** -0.5, rng.synth_input(f"sks.b{N}", (N,), seed=6), dev)
+            small.append((a, pw, sp))
+        monkeypatch.setattr(ops, "SPLITK_FUSED_MAX", 0)
+        monkeypatch.setattr(ops, "SPLITK_FUSED_BYTES", 0)
+        want_small = [ops.gemm(a, pw, tile=tile, splits=sp) for a, pw, sp in small]
+        monkeypatch.setattr(ops, "SPLITK_FUSED_BYTES", 4 << 20)
+        for rep in range(10):
+            for (a, pw, sp), w in zip(small, want_small):
+                assert torch.equal(ops.gemm(a, pw, tile=tile, splits=sp), w), (tile, rep, tuple(a.shape), sp)
+        assert int(ws[-(ops._lib.AF_SPLITK_COUNTER_BYTES // 4):].view(torch.int32).abs().sum()) == 0
+        monkeypatch.setattr(ops, "SPLITK_FUSED_BYTES", 0)
     monkeypatch.setattr(ops, "SPLITK_FUSED_MAX", 0)
     wc = ops.conv3x3(x, pc, x2=x2, tile=tile, splits=3)
     monkeypatch.setattr(ops, "SPLITK_FUSED_MAX", 4)
