@@ -23,9 +23,37 @@ def _stream(seed: int, name: str) -> np.random.Generator:
     return np.random.Generator(np.random.Philox(key=[int(seed) & 0xFFFFFFFFFFFFFFFF, zlib.crc32(name.encode())]))
 
 
+# Optional memo of drawn parameters (tests only: tests/conftest.py switches it on).  The GPU suite builds the same reduced-width model
+# stack dozens of times from the same (seed, name, shape) triples; on the GPU box's host a draw costs ~2 ms, 12 s per trainer set-up.
+# Entries are handed out as they are (callers copy out of them: load_synth_weights) -- synth_state_dict clones.
+_memo = None
+_MEMO_MAX_ELEMS = 1 << 22          # per tensor; full-size weights are not kept
+_MEMO_MAX_TOTAL = 1 << 29          # elements in total (2 GiB of fp32)
+_memo_total = 0
+
+
+def enable_memo(on: bool = True) -> None:
+    global _memo, _memo_total
+    _memo, _memo_total = ({} if on else None), 0
+
+
 def synth_tensor(name: str, shape, seed: int = 0) -> torch.Tensor:
     """One synthetic fp32 parameter. Rule is decided by the name suffix and rank."""
+    global _memo_total
     shape = tuple(int(s) for s in shape)
+    if _memo is not None:
+        hit = _memo.get((name, shape, int(seed)))
+        if hit is not None:
+            return hit
+        t = _synth_tensor(name, shape, seed)
+        if t.numel() <= _MEMO_MAX_ELEMS and _memo_total + t.numel() <= _MEMO_MAX_TOTAL:
+            _memo[(name, shape, int(seed))] = t
+            _memo_total += t.numel()
+        return t
+    return _synth_tensor(name, shape, seed)
+
+
+def _synth_tensor(name: str, shape, seed: int = 0) -> torch.Tensor:
     g = _stream(seed, name)
     z = g.standard_normal(size=shape, dtype=np.float32)
     if name.endswith(".bias"):
@@ -40,7 +68,7 @@ def synth_tensor(name: str, shape, seed: int = 0) -> torch.Tensor:
 
 def synth_state_dict(named_shapes, seed: int = 0):
     """named_shapes: iterable of (name, shape). Returns {name: fp32 tensor}."""
-    return {name: synth_tensor(name, shape, seed) for name, shape in named_shapes}
+    return {name: (synth_tensor(name, shape, seed).clone() if _memo is not None else synth_tensor(name, shape, seed)) for name, shape in named_shapes}
 
 
 def load_synth_weights(module: torch.nn.Module, seed: int = 0, on_device: bool = False) -> None:

@@ -59,11 +59,24 @@ def _seed_allocator_with_nan():
     del big, small
 
 
+def _host_side_speedups():
+    """The GPU box's host has hundreds of hardware threads: torch's default intra-op pool (one thread per core) makes every SMALL CPU op -- the
+    oracles' reduced-width convolutions, parameter copies, zero_() -- pay a ~2 ms fork/join (measured: 10.7 s in 6,268 copy_ calls of one
+    test).  16 threads are plenty for the oracle at the tests' sizes.  And the same (seed, name, shape) parameters are drawn dozens of times
+    per run (tests/trainer_util.py): memoised (rng.enable_memo)."""
+    import torch
+    from adaface_dev_amd import rng
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 16)))
+    rng.enable_memo(True)
+
+
 def pytest_collection_modifyitems(config, items):
-    if _POISON and any(it.get_closest_marker("gpu") is not None for it in items):
+    if any(it.get_closest_marker("gpu") is not None for it in items):
         import torch
         if torch.cuda.is_available():
-            _install_poison()          # before any module-scoped fixture builds a model
+            _host_side_speedups()
+            if _POISON:
+                _install_poison()          # before any module-scoped fixture builds a model
 
 
 @pytest.fixture(autouse=True)
