@@ -124,6 +124,21 @@ class UNetWrapper(nn.Module):
             if extra_info is not None:
                 extra_info.pop("_cross_attn_scale_factors", None)
 
+    def precompute_trunks(self, entries, n_tail=3):
+        """entries: [(key, x_noisy row [1, 4, h, w], t row [1], prompt row [1, L, D])] -> {key: (h [1, H, W, C], [skip tensors])}: the U-Net
+        below its last ``n_tail`` decoder blocks for all rows as ONE gradient-free batch (UNetModel.hip_trunk, the inference walk).  Nothing in
+        that part of the network depends on the adapter / score-rewrite / capture flags of a pass (they live in the tail: FFN adapters on
+        output blocks 10-11, attention adapters and rewrites on layers 22-24), so gradient-free passes that share (x, t, prompt) rows may share
+        it (LatentDiffusion.guided_denoise, 'subject-compos')."""
+        unet = self.diffusion_model
+        with torch.no_grad():
+            x = torch.cat([e[1] for e in entries], dim=0).detach()
+            tt = torch.cat([e[2] for e in entries], dim=0)
+            ctx = torch.cat([e[3] for e in entries], dim=0).detach().to(torch.float16).contiguous()
+            from ...modules.diffusionmodules.util import to_nhwc_f16
+            h, skips = unet.hip_trunk(to_nhwc_f16(x, ops.round_up(unet.in_channels, 8)), unet._embed(tt), ctx, None, n_tail)
+        return {e[0]: (h[i:i + 1], [sk[i:i + 1] for sk in skips]) for i, e in enumerate(entries)}
+
     def set_up_attn_loras(self, layer_names=("q", "k", "v", "out"), lora_rank=192, lora_scale_down=8, lora_dropout=0.1,
                           q_lora_updates_query=False):
         """Reference ``set_up_attn_processors`` with ``use_attn_lora`` (diffusers_attn_lora_capture.py:451-537): trainable DoRA adapters
@@ -392,6 +407,8 @@ class LatentDiffusion(CompReconLossesMixin, nn.Module):
     cache_uncond_in_step = os.environ.get("AF_CACHE_UNCOND", "1") != "0"       # recon steps: the null-prompt pass once per step, not once per guided pass
     skip_unread_cls_priming = os.environ.get("AF_SKIP_CLS_PRIMING", "1") != "0"   # recon steps: no class-prompt pass on priming steps (nothing reads it); its own switch
     batch_no_grad_instances = os.environ.get("AF_BATCH_NO_GRAD", "1") != "0"   # subject-compos steps: SS + SR as one no-grad pass where their flags agree
+    share_no_grad_trunk = os.environ.get("AF_SHARE_TRUNK", "1") != "0"        # subject-compos steps: ONE batched trunk pass for every gradient-free instance pass of the step
+    batch_cond_with_uncond = os.environ.get("AF_BATCH_UNCOND", "1") != "0"    # gradient-free guided passes: the prompt rows and the null-prompt rows as ONE U-Net call where their flags agree
     res_hidden_states_gradscale = 0.5   # reference ctor default (ddpm.py:140): gradient scale of the decoder's skip inputs
 
     def guided_denoise(self, x_start, noise, t, cond_context, uncond_emb=None, img_mask=None, subj_indices=None,
@@ -415,9 +432,29 @@ class LatentDiffusion(CompReconLossesMixin, nn.Module):
         extra_info["subj_indices"] = subj_indices
         ca_layers_activations = None
         lora = dict(use_attn_lora=use_attn_lora, use_ffn_lora=use_ffn_lora, ffn_lora_adapter_name=ffn_lora_adapter_name)
+        fused_uncond = None
         if batch_part_has_grad == "none":
+            # Round 5: a gradient-free GUIDED pass is two U-Net calls on the same (x_noisy, t) rows that differ in the prompt rows only -- when
+            # nothing else distinguishes them (no image mask, no capture, no attention adapters, no score rewrite: the priming steps and the
+            # class-prompt passes of a recon iteration), they are ONE call on 2 B rows: the kernels see twice the rows per launch instead of
+            # twice the launches.  The null half also fills the step's uncond_cache, so the step's OTHER guided pass finds it there.
+            fuse = (self.batch_cond_with_uncond and cfg_scale > 1 and img_mask is None and not capture_ca_activations and not use_attn_lora
+                    and not normalize_cross_attn and not use_ffn_lora and self.uncond_context is not None
+                    and not (uncond_cache is not None and uncond_cache.get("x") is x_start and uncond_cache.get("n") is noise and uncond_cache.get("t") is t
+                             and uncond_cache.get("u") is (uncond_emb if uncond_emb is not None else self.uncond_context[0])
+                             and uncond_cache.get("ck") == (False, None)))
+            un2 = None
+            if fuse:
+                un2 = uncond_emb if uncond_emb is not None else self.uncond_context[0].repeat(x_noisy.shape[0], 1, 1)
+                fuse = un2.shape == cond_context[0].shape
             with torch.no_grad():
-                noise_pred = self.apply_model(x_noisy, t, cond_context, **lora)
+                if fuse:
+                    both = self.apply_model(torch.cat([x_noisy, x_noisy], dim=0), torch.cat([t, t], dim=0),
+                                            (torch.cat([cond_context[0], un2.to(cond_context[0].dtype)], dim=0),
+                                             list(cond_context[1]) + list(self.uncond_context[1]) * x_noisy.shape[0], extra_info), **lora)
+                    noise_pred, fused_uncond = both.chunk(2, dim=0)
+                else:
+                    noise_pred = self.apply_model(x_noisy, t, cond_context, **lora)
             if capture_ca_activations:
                 ca_layers_activations = extra_info["ca_layers_activations"]
         elif batch_part_has_grad == "all":
@@ -432,6 +469,22 @@ class LatentDiffusion(CompReconLossesMixin, nn.Module):
                 ei = copy.copy(extra_info)
                 ei.update(flags)
                 return (cond_context[0], cond_context[1], ei)
+            # Round 5: the gradient-free passes of this step -- SS, SR, MC when it runs alone, and the four rows of the unconditional pass
+            # below -- differ only in the LAST THREE decoder blocks (score rewrites, attention / FFN adapters, capture): everything below
+            # them is a function of (x_noisy row, t, prompt row) alone.  That trunk runs ONCE here for all of those rows as one batch
+            # (UNetWrapper.precompute_trunks); the separate apply_model calls below keep the reference's call structure and pick their rows'
+            # trunk outputs up from extra_info['_trunk_cache'] (modules/diffusionmodules/capture_graph.cached_trunk).  SC (and MC while the
+            # scores are mixed) needs gradients through the trunk and runs as before.
+            trunk_cache = None
+            if self.share_no_grad_trunk and img_mask is None and hasattr(self.model, "precompute_trunks") and x_noisy.shape[0] == 4:
+                rows = [0, 2] if mix_sc_mc_attn else [0, 2, 3]
+                entries = [(r, x_noisy[r:r + 1], t[r:r + 1], cond_context[0][r:r + 1]) for r in rows]
+                if cfg_scale > 1:
+                    un = uncond_emb if uncond_emb is not None else self.uncond_context[0].repeat(x_noisy.shape[0], 1, 1)
+                    if un.shape[1:] == cond_context[0].shape[1:]:
+                        entries += [(("u", r), x_noisy[r:r + 1], t[r:r + 1], un[r:r + 1]) for r in range(4)]
+                trunk_cache = self.model.precompute_trunks(entries)
+                extra_info["_trunk_cache"] = trunk_cache
             ctx_ss = context_with(normalize_cross_attn=False, mix_attn_mats_in_batch=False)
             ctx_sr = context_with(normalize_cross_attn=normalize_cross_attn, mix_attn_mats_in_batch=False)
             if self.batch_no_grad_instances and not normalize_cross_attn:
@@ -471,6 +524,9 @@ class LatentDiffusion(CompReconLossesMixin, nn.Module):
             if uncond_emb is None:
                 uncond_emb = self.uncond_context[0].repeat(x_noisy.shape[0], 1, 1)
             uncond_context = (uncond_emb, self.uncond_context[1] * x_noisy.shape[0], copy.copy(self.uncond_context[2]))
+            if extra_info.get("_trunk_cache") is not None and all(("u", r) in extra_info["_trunk_cache"] for r in range(x_noisy.shape[0])):
+                uncond_context[2]["_trunk_cache"] = extra_info["_trunk_cache"]                     # this step's shared trunk holds the null-prompt rows too
+                uncond_context[2]["_trunk_rows"] = tuple(("u", r) for r in range(x_noisy.shape[0]))
             # ``uncond_cache`` (a dict the caller keeps for ONE denoising step): the unconditional prediction is a function of (x_start, noise, t,
             # the null embedding, the FFN-adapter state) only -- a recon step asks for it twice with the same arguments (after the subject pass
             # and after the class-prompt pass, ddpm.py:1800-1860): the second request takes the first one's tensor (same kernels, same bits)
@@ -481,7 +537,11 @@ class LatentDiffusion(CompReconLossesMixin, nn.Module):
                 uncond_cache = None
             hit = (uncond_cache is not None and uncond_cache.get("ck") == ck and uncond_cache.get("x") is x_start and uncond_cache.get("n") is noise
                    and uncond_cache.get("t") is t and uncond_cache.get("u") is uncond_key)
-            if hit:
+            if fused_uncond is not None:
+                noise_pred_uncond = fused_uncond                # came out of the prompt rows' own call (above)
+                if uncond_cache is not None:
+                    uncond_cache.update(ck=ck, x=x_start, n=noise, t=t, u=uncond_key, eps=noise_pred_uncond)
+            elif hit:
                 noise_pred_uncond = uncond_cache["eps"]
             else:
                 with torch.no_grad():
@@ -490,6 +550,7 @@ class LatentDiffusion(CompReconLossesMixin, nn.Module):
                 if uncond_cache is not None:
                     uncond_cache.update(ck=ck, x=x_start, n=noise, t=t, u=uncond_key, eps=noise_pred_uncond)
             noise_pred = noise_pred * cfg_scale - noise_pred_uncond * (cfg_scale - 1)
+        extra_info.pop("_trunk_cache", None)                                                    # the shared trunk lives for this step only
         x_recon = self.predict_start_from_noise(x_noisy, t=t, noise=noise_pred) if do_pixel_recon else None
         return noise_pred, x_recon, ca_layers_activations
 
@@ -564,6 +625,8 @@ class LatentDiffusion(CompReconLossesMixin, nn.Module):
         elif len(idx) > 1 and len({b - a for a, b in zip(idx, idx[1:])}) == 1 and idx[1] > idx[0]:
             idx = slice(idx[0], idx[-1] + 1, idx[1] - idx[0])
         ctx = (prompt_emb[idx], [prompt_in[i] for i in slice_indices], extra_info)
+        if extra_info is not None and extra_info.get("_trunk_cache") is not None:
+            extra_info["_trunk_rows"] = tuple(slice_indices)                                    # which rows of the step's shared trunk this call is (guided_denoise)
         with torch.set_grad_enabled(enable_grad):
             return self.apply_model(x_noisy[idx], t[idx], ctx, use_attn_lora=use_attn_lora, use_ffn_lora=use_ffn_lora,
                                     ffn_lora_adapter_name=ffn_lora_adapter_name)

@@ -457,6 +457,17 @@ class CompReconLossesMixin:
             priming = i < num_priming_steps
             context = cls_context if (priming and cls_context is not None and i % 2 == 0) else subj_context
             uc = {} if self.cache_uncond_in_step else None      # this step's null-prompt prediction, shared by its guided passes
+            # Round 5: on a NON-priming step the class-prompt pass (gradient-free, no capture) goes FIRST when it can take the step's null-prompt
+            # rows along in its own U-Net call (guided_denoise, batch_cond_with_uncond): the main pass -- with gradients, so it cannot -- then finds
+            # the null prediction in `uc`.  Both are pure functions of (x_start, noise, t, prompt): the order changes no value and no draw.
+            cls_first = None
+            if (cls_context is not None and not priming and uc is not None and self.batch_cond_with_uncond and cfg_scale > 1 and img_mask is None
+                    and not enable_unet_attn_lora and not enable_unet_ffn_lora):
+                cls_first = self.guided_denoise(
+                    x_start, noise, t, cls_context, uncond_emb, img_mask, subj_indices=None, normalize_cross_attn=False, mix_sc_mc_attn=False,
+                    batch_part_has_grad="none", do_pixel_recon=True, cfg_scale=cfg_scale, capture_ca_activations=False,
+                    res_hidden_states_gradscale=0, use_attn_lora=enable_unet_attn_lora, use_ffn_lora=enable_unet_ffn_lora,
+                    ffn_lora_adapter_name=ffn_lora_adapter_name, uncond_cache=uc)
             noise_pred, x_recon, acts = self.guided_denoise(
                 x_start, noise, t, context, uncond_emb, img_mask, subj_indices=None, normalize_cross_attn=False, mix_sc_mc_attn=False,
                 batch_part_has_grad="none" if priming else "all", do_pixel_recon=True, cfg_scale=cfg_scale, capture_ca_activations=not priming,
@@ -474,6 +485,9 @@ class CompReconLossesMixin:
                 same = context is cls_context and not enable_unet_ffn_lora
                 noise_preds_cls.append(noise_pred if same else None)
                 x_recons_cls.append(x_recon if same else None)
+            elif cls_first is not None:
+                noise_preds_cls.append(cls_first[0])
+                x_recons_cls.append(cls_first[1])
             elif cls_context is not None:
                 eps_cls, x_cls, _ = self.guided_denoise(
                     x_start, noise, t, cls_context, uncond_emb, img_mask, subj_indices=None, normalize_cross_attn=False, mix_sc_mc_attn=False,

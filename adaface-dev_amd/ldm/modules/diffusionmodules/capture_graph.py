@@ -322,6 +322,20 @@ def captured_cross_attention(attn2, qin, context2d, B, N, flags, loras=None):
     return out, caps
 
 
+def cached_trunk(extra_info, B):
+    """(h, skips) of this call's rows from the step's shared trunk (LatentDiffusion.guided_denoise puts ``_trunk_cache`` = {row key: (h, skips)}
+    into extra_info, each call names its rows in ``_trunk_rows``), or None when there is none / a row is missing / the batch does not match."""
+    if not extra_info:
+        return None
+    cache, rows = extra_info.get("_trunk_cache"), extra_info.get("_trunk_rows")
+    if cache is None or rows is None or len(rows) != B or any(r not in cache for r in rows):
+        return None
+    if len(rows) == 1:
+        return cache[rows[0]]
+    hs = [cache[r] for r in rows]
+    return torch.cat([c[0] for c in hs], dim=0), [torch.cat([c[1][i] for c in hs], dim=0) for i in range(len(hs[0][1]))]
+
+
 def unet_forward_captured(unet, x, timesteps, context, extra_info, n_tail=3):
     """eps [B, out_channels, H, W] in x.dtype; fills extra_info['ca_layers_activations'] = {key: {layer index: tensor}}."""
     from .openaimodel import lora_param_order  # noqa: F401  (same adapter ordering as the Stage-1 node)
@@ -339,8 +353,12 @@ def unet_forward_captured(unet, x, timesteps, context, extra_info, n_tail=3):
     else:
         # nothing below the tail needs a gradient (the no-grad instances of a compositional step, the class-prompt pass of a recon
         # step): the inference walk instead of the activation-saving one
-        with torch.no_grad():
-            h, skips = unet.hip_trunk(to_nhwc_f16(x.detach(), ops.round_up(unet.in_channels, 8)), emb, context.detach().to(F16).contiguous(), img_mask, n_tail)
+        shared = cached_trunk(ei, x.shape[0]) if img_mask is None and n_tail == 3 else None
+        if shared is not None:
+            h, skips = shared                     # this step's shared gradient-free trunk already holds these rows
+        else:
+            with torch.no_grad():
+                h, skips = unet.hip_trunk(to_nhwc_f16(x.detach(), ops.round_up(unet.in_channels, 8)), emb, context.detach().to(F16).contiguous(), img_mask, n_tail)
     B = x.shape[0]
     ctx2d = context.to(F16).reshape(B * context.shape[1], context.shape[2])
     acts = {k: {} for k in CAPTURE_KEYS}

@@ -546,6 +546,32 @@ class UNetModel(nn.Module):
         h = self.out[0].hip(h, silu=True)
         return self.out[2].hip(h), acts
 
+    def hip_tail(self, trunk, timesteps, context, capture_layers, n_tail=3):
+        """The inference walk of the last ``n_tail`` decoder blocks + the output head on trunk = (h, skips) as ``hip_trunk`` returns them
+        (a step's shared gradient-free trunk, LatentDiffusion.guided_denoise): -> (eps NHWC, captured activations) exactly as ``_hip_blocks``
+        leaves them for those layers."""
+        h, skips = trunk
+        emb = self._embed(timesteps)
+        kv_layers = self._project_context_all(context)
+        acts = {}
+        try:
+            n_out = len(self.output_blocks)
+            layer_idx = len(self.input_blocks) + 1 + n_out - n_tail
+            for k, module in enumerate(list(self.output_blocks)[n_out - n_tail:]):
+                h = module.hip(SkipCat((h, skips[k])), emb, context, None)
+                if layer_idx in capture_layers:
+                    attn2 = module[1].transformer_blocks[0].attn2
+                    a = attn2.cached_activations
+                    a["outfeat"] = from_nhwc_f16(h, torch.float32)
+                    acts[layer_idx] = a
+                    attn2.cached_activations = None
+                layer_idx += 1
+            h = self.out[0].hip(h, silu=True)
+            return self.out[2].hip(h), acts
+        finally:
+            for m in kv_layers:
+                m._kv_pre = None
+
     def _embed(self, timesteps):
         t_emb = timestep_embedding(timesteps, self.model_channels)
         e0 = ops.gemm(t_emb, self.time_embed[0].packed(), act=AF_ACT_SILU)
@@ -685,9 +711,16 @@ class UNetModel(nn.Module):
             lora = (extra_info or {}).get("_ffn_lora_adapters")           # set by UNetWrapper when use_ffn_lora is on
             return _UNetFunction.apply(self, x, timesteps, context, img_mask, gs, lora, *[t[3] for t in lora_param_order(lora)])
         try:
-            xh = to_nhwc_f16(x, ops.round_up(self.in_channels, 8))
             ctx = context.to(F16).contiguous()
-            eps, acts = self.hip(xh, timesteps, ctx, img_mask, captured)
+            shared = None
+            if img_mask is None and ei.get("_trunk_cache") is not None:
+                from .capture_graph import cached_trunk
+                shared = cached_trunk(ei, x.shape[0])
+            if shared is not None:
+                eps, acts = self.hip_tail(shared, timesteps, ctx, captured)      # the step's shared gradient-free trunk holds these rows
+            else:
+                xh = to_nhwc_f16(x, ops.round_up(self.in_channels, 8))
+                eps, acts = self.hip(xh, timesteps, ctx, img_mask, captured)
         finally:
             if capture:
                 self.set_cross_attn_flags(ca_flag_dict=old_flags, ca_layer_indices=captured)

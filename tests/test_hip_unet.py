@@ -433,6 +433,103 @@ def test_guided_denoise_cfg_x0_grad_modes_vs_oracle(dev):
         ld.guided_denoise(x0.to(dev), noise.to(dev), t.to(dev), (ctx.to(dev), ["a", "b"], {}), normalize_cross_attn=True)
 
 
+@pytest.mark.parametrize("mix", [False, True], ids=["normalize_cross_attn", "mix_sc_mc_attn"])
+def test_subject_compos_step_with_the_shared_gradient_free_trunk(dev, mix):
+    """One 'subject-compos' denoising step on the four-block batch [SS, SC, SR, MC] with classifier-free guidance and capture, twice: with every
+    gradient-free pass running its own trunk (the reference's call structure all the way down) and with the step's shared trunk (round 5:
+    LatentDiffusion.share_no_grad_trunk -- SS, SR, MC when it runs alone and the four null-prompt rows run the network below its last three
+    decoder blocks as ONE batch; the per-instance tails pick their rows up).  Same eps, x0, captured tensors and prompt gradient, up to the
+    rounding of a batch-1 against a batch-3 / -7 launch of the same kernels (the batch property tolerance); and the shared form issues fewer
+    trunk passes, counted."""
+    from adaface_dev_amd import rng
+    from adaface_dev_amd.ldm.models.diffusion.ddpm import LatentDiffusion
+    ld = LatentDiffusion(GPU_TINY_CONFIG)
+    rng.load_synth_weights(ld.model.diffusion_model, seed=11)
+    ld = ld.to(dev)
+    ld.batch_no_grad_instances = False
+    ld.uncond_context = (rng.synth_input("sc.unc", (1, 20, 64), seed=15).to(dev), [""], {})
+    x0 = rng.synth_input("sc.x0", (2, 4, 16, 16), seed=15).repeat(2, 1, 1, 1).to(dev)
+    noise = rng.synth_input("sc.noise", (1, 4, 16, 16), seed=15).repeat(4, 1, 1, 1).to(dev)
+    ctx = rng.synth_input("sc.ctx", (4, 20, 64), seed=15).to(dev)
+    t = torch.tensor([700]).repeat(4).to(dev)
+    subj = (torch.tensor([0, 0], device=dev), torch.tensor([2, 3], device=dev))
+    unet = ld.model.diffusion_model
+    counts = {"trunk": 0}                                       # walks of the network below the tail: hip_trunk, or a whole inference pass (hip)
+    real_trunk, real_hip = unet.hip_trunk, unet.hip
+
+    def counting_trunk(*a, **k):
+        counts["trunk"] += 1
+        return real_trunk(*a, **k)
+
+    def counting_hip(*a, **k):
+        counts["trunk"] += 1
+        return real_hip(*a, **k)
+    unet.hip_trunk, unet.hip = counting_trunk, counting_hip
+    out = {}
+    for shared in (False, True):
+        ld.share_no_grad_trunk = shared
+        counts["trunk"] = 0
+        cg = ctx.clone().requires_grad_(True)
+        torch.manual_seed(3)                                    # the FFN-adapter coin of the pass (CPU generator)
+        eps, rec, acts = ld.guided_denoise(x0, noise, t, (cg, ["a", "b", "c", "d"], {}), subj_indices=subj, normalize_cross_attn=not mix,
+                                           mix_sc_mc_attn=mix, batch_part_has_grad="subject-compos", do_pixel_recon=True, cfg_scale=2.5,
+                                           capture_ca_activations=True, res_hidden_states_gradscale=0.5)
+        (eps * noise).sum().backward()
+        out[shared] = (eps.detach(), rec.detach(), {k: {li: v.detach() for li, v in d.items()} for k, d in acts.items()}, cg.grad.clone(), counts["trunk"])
+    unet.hip_trunk, unet.hip = real_trunk, real_hip
+    (e0, r0, a0, g0, n0), (e1, r1, a1, g1, n1) = out[False], out[True]
+    assert n1 == 1 and n0 == (3 if mix else 4), (n0, n1)       # ONE batched gradient-free trunk pass instead of one per instance pass (SS, SR, [MC,] null)
+    tol = 2 * 3e-3                                              # batch property (3e-3), doubled under guidance like the tests above
+    assert rel_l2(e1.cpu().numpy(), e0.cpu().numpy()) < tol and rel_l2(r1.cpu().numpy(), r0.cpu().numpy()) < tol
+    assert rel_l2(g1.cpu().numpy(), g0.cpu().numpy()) < 2 * GRAD_TOL
+    for key in ("attn", "attnscore", "q", "k", "v", "attn_out", "outfeat"):
+        for li in (22, 23, 24):
+            assert rel_l2(a1[key][li].float().cpu().numpy(), a0[key][li].float().cpu().numpy()) < tol, (key, li)
+    assert torch.isfinite(e1).all()
+
+
+def test_gradient_free_guided_pass_as_one_call_on_prompt_and_null_rows(dev):
+    """guided_denoise(batch_part_has_grad='none', cfg_scale > 1) without image mask, capture or adapters -- the priming steps and class-prompt passes
+    of a recon iteration -- as ONE U-Net call on [prompt rows | null-prompt rows] (round 5: LatentDiffusion.batch_cond_with_uncond) against the
+    reference's two calls: same guided eps and x0 up to the rounding of a batch-2B against two batch-B launches; the null half lands in the
+    step's uncond_cache, so a second guided pass of the step (the main pass of a recon step) issues no null call at all; with an image mask
+    or capture the two-call form runs as before."""
+    from adaface_dev_amd import rng
+    from adaface_dev_amd.ldm.models.diffusion.ddpm import LatentDiffusion
+    ld = LatentDiffusion(GPU_TINY_CONFIG)
+    rng.load_synth_weights(ld.model.diffusion_model, seed=11)
+    ld = ld.to(dev)
+    ld.uncond_context = (rng.synth_input("fu.unc", (1, 20, 64), seed=16).to(dev), [""], {})
+    x0 = rng.synth_input("fu.x0", (2, 4, 16, 16), seed=16).to(dev)
+    noise = rng.synth_input("fu.noise", (2, 4, 16, 16), seed=16).to(dev)
+    ctx, ctx2 = rng.synth_input("fu.ctx", (2, 20, 64), seed=16).to(dev), rng.synth_input("fu.ctx2", (2, 20, 64), seed=16).to(dev)
+    t = torch.tensor([300, 820], device=dev)
+    calls = []
+    real = ld.model.forward
+    ld.model.forward = lambda x, tt, cc, *a, **k: (calls.append(x.shape[0]), real(x, tt, cc, *a, **k))[1]
+    run = lambda c, uc=None, **kw: ld.guided_denoise(x0, noise, t, (c, ["a", "b"], {}), batch_part_has_grad="none", do_pixel_recon=True,
+                                                   cfg_scale=2.5, uncond_cache=uc, **kw)
+    ld.batch_cond_with_uncond = False
+    e_ref, r_ref, _ = run(ctx)
+    e2_ref, _, _ = run(ctx2)
+    assert calls == [2, 2, 2, 2]
+    calls.clear()
+    ld.batch_cond_with_uncond = True
+    uc = {}
+    e_f, r_f, _ = run(ctx, uc)
+    assert calls == [4] and uc.get("eps") is not None
+    e2_f, _, _ = run(ctx2, uc)                                   # the step's second guided pass: its null rows are in the cache
+    assert calls == [4, 2]
+    tol = 2 * 3e-3
+    assert rel_l2(e_f.cpu().numpy(), e_ref.cpu().numpy()) < tol and rel_l2(r_f.cpu().numpy(), r_ref.cpu().numpy()) < tol
+    assert rel_l2(e2_f.cpu().numpy(), e2_ref.cpu().numpy()) < tol
+    calls.clear()
+    run(ctx, img_mask=torch.ones(2, 1, 16, 16, device=dev))      # a key mask belongs to the prompt rows only: two calls
+    run(ctx, capture_ca_activations=True)
+    assert calls == [2, 2, 2, 2]
+    ld.model.forward = real
+
+
 def test_live_processor_drops_the_key_mask_when_an_instance_is_fully_masked(dev):
     """The live attention processor (adaface/diffusers_attn_lora_capture.py:254-260) drops the self-attention key mask for the WHOLE
     batch when, at a layer's resolution, any instance's mask is empty; the in-tree LDM U-Net keeps it (that instance then attends
