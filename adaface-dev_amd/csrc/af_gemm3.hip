@@ -276,14 +276,14 @@ __device__ __forceinline__ void gemm3_epilogue(const Gemm3Dev& p, floatx4 (&acc)
       float s = 0.f, q = 0.f;
       if (g < ng) {
         const int hp = p.gn_cpg >> 1;
-        const float pivot = (float)T[(rs / SPB) * 128 * TS + g * p.gn_cpg];
+        const half_t pivot = T[(rs / SPB) * 128 * TS + g * p.gn_cpg];
+        const half2_t pivot2 = {pivot, pivot}, one2 = {(half_t)1.0f, (half_t)1.0f};
         for (int r = rs * RPS; r < (rs + 1) * RPS; ++r) {
           const half2_t* tp = reinterpret_cast<const half2_t*>(T + r * TS + g * p.gn_cpg);
           for (int j = 0; j < hp; ++j) {
-            const half2_t v = tp[j];
-            const float a0 = (float)v[0] - pivot, a1 = (float)v[1] - pivot;
-            s += a0 + a1;
-            q += a0 * a0 + a1 * a1;
+            const half2_t d2 = tp[j] - pivot2;                      // packed fp16 + dot2 (af_norm.hip, gn_partial_kernel)
+            s = __builtin_amdgcn_fdot2(d2, one2, s, false);
+            q = __builtin_amdgcn_fdot2(d2, d2, q, false);
           }
         }
       }

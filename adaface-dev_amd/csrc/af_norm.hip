@@ -48,12 +48,16 @@ __device__ __forceinline__ float gn_load1(const GnArgs& a, int b, int pix, int c
 }
 
 // pass 1: per-block partial (sum, M2 about the block's own mean: af_common.h, GroupNorm partial statistics) per group.  The sums are taken
-// SHIFTED by a per-channel pivot -- the channel's value at the block's first pixel, the same for every thread of the block, so the per-thread
-// sums still add up -- and re-based to the group's pivot when the channels of a group are folded.
-template <int CT>
+// SHIFTED by a pivot -- the value at the block's first pixel, the same for every thread of the block, so the per-thread sums still add up --
+// and re-based to the group's pivot when the units of a group are folded.  PAIR (cpg even: every SD-1.5 width): the unit is a PAIR of
+// adjacent channels sharing the first one's pivot, and the arithmetic is packed fp16 + v_dot2_f32_f16 -- d2 = x2 - p2 (exact whenever x is
+// within a factor 2 of the pivot, i.e. exactly where the shift matters; rounded to 11 bits of d otherwise), s += d2 . (1, 1), q += d2 . d2:
+// 1.5 instructions per pair of elements where the unshifted per-channel form took 6 (the pass is VALU-co-bound, af_common.h).
+template <int CT, bool PAIR>
 __global__ __launch_bounds__(256) void gn_partial_kernel(GnArgs a) {
+  constexpr int U = PAIR ? 2 : 1, NS = 8 / U;         // channels per unit, units per 8-channel chunk
   extern __shared__ __attribute__((aligned(16))) char af_smem[];
-  float* red = reinterpret_cast<float*>(af_smem);  // [2][slots][C]
+  float* red = reinterpret_cast<float*>(af_smem);  // [2][slots][C / U]
   const int t = threadIdx.x, b = blockIdx.y, blk = blockIdx.x;
   const int slots = CT == 1 ? a.ppb : 1;
   const int slot = CT == 1 ? t / a.CP : 0;
@@ -61,22 +65,28 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(GnArgs a) {
   const bool active = CT == 1 ? (slot < slots) : true;
   const int per = (a.HW + a.nblk - 1) / a.nblk;
   const int p0 = blk * per, p1 = min(a.HW, p0 + per);
+  const int CU = a.C / U;                            // units per pixel
 
-  float s[CT][8], q[CT][8];
+  float s[CT][NS], q[CT][NS];
 #pragma unroll
   for (int j = 0; j < CT; ++j)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) s[j][e] = q[j][e] = 0.f;
+    for (int e = 0; e < NS; ++e) s[j][e] = q[j][e] = 0.f;
 
   if (active && p0 < p1) {
-    half8_t pv[CT];                                    // pivots: this thread's channels at the block's first pixel
+    half8_t pv[CT];                                    // pivots: this thread's channels at the block's first pixel (PAIR: the even channel's, twice)
 #pragma unroll
     for (int j = 0; j < CT; ++j) {
       const int ch = chunk0 + 256 * j;
       pv[j] = ch < a.CP ? gn_load(a, b, p0, ch * 8) : half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+      if (PAIR) {
+#pragma unroll
+        for (int e = 1; e < 8; e += 2) pv[j][e] = pv[j][e - 1];
+      }
     }
     // PF pixels per thread in flight: the loop is pure load -> fma, so bytes in flight per CU are what sets the rate
     constexpr int PF = CT == 1 ? 4 : 2;
+    const half2_t one2 = {(half_t)1.0f, (half_t)1.0f};
     for (int pix = p0 + slot; pix < p1; pix += slots * PF) {
       half8_t v[PF][CT];
 #pragma unroll
@@ -90,37 +100,48 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(GnArgs a) {
 #pragma unroll
       for (int u = 0; u < PF; ++u)
 #pragma unroll
-        for (int j = 0; j < CT; ++j)
+        for (int j = 0; j < CT; ++j) {
+          if (PAIR) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float f = (float)v[u][j][e] - (float)pv[j][e];
-            s[j][e] += f;
-            q[j][e] += f * f;
+            for (int e = 0; e < 4; ++e) {
+              const half2_t x2 = {v[u][j][2 * e], v[u][j][2 * e + 1]}, p2 = {pv[j][2 * e], pv[j][2 * e + 1]};
+              const half2_t d2 = x2 - p2;
+              s[j][e] = __builtin_amdgcn_fdot2(d2, one2, s[j][e], false);
+              q[j][e] = __builtin_amdgcn_fdot2(d2, d2, q[j][e], false);
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float f = (float)v[u][j][e] - (float)pv[j][e];
+              s[j][e % NS] += f;
+              q[j][e % NS] += f * f;
+            }
           }
+        }
     }
   }
   float* rs = red;
-  float* rq = red + slots * a.C;
+  float* rq = red + slots * CU;
   if (active) {
 #pragma unroll
     for (int j = 0; j < CT; ++j) {
       const int ch = chunk0 + 256 * j;
       if (ch < a.CP) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          rs[slot * a.C + ch * 8 + e] = s[j][e];
-          rq[slot * a.C + ch * 8 + e] = q[j][e];
+        for (int e = 0; e < NS; ++e) {
+          rs[slot * CU + ch * NS + e] = s[j][e];
+          rq[slot * CU + ch * NS + e] = q[j][e];
         }
       }
     }
   }
   __syncthreads();
-  // fold pixel slots -> per-channel (into slot 0): same pivot in every slot, plain sums
-  for (int c = t; c < a.C; c += 256) {
+  // fold pixel slots -> per-unit (into slot 0): same pivot in every slot, plain sums
+  for (int c = t; c < CU; c += 256) {
     float ss = 0.f, qq = 0.f;
     for (int sl = 0; sl < slots; ++sl) {
-      ss += rs[sl * a.C + c];
-      qq += rq[sl * a.C + c];
+      ss += rs[sl * CU + c];
+      qq += rq[sl * CU + c];
     }
     rs[c] = ss;
     rq[c] = qq;
@@ -132,17 +153,17 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(GnArgs a) {
       w[0] = w[1] = 0.f;
       return;
     }
-    // channels -> group: re-base channel c's sums from its own pivot p_c to the group's pivot P (that of the group's first channel):
-    //   sum(x - P) = s_c + n d,  sum((x - P)^2) = q_c + 2 d s_c + n d^2,  d = p_c - P
-    const float n = (float)(p1 - p0);
+    // units -> group: re-base unit u's sums from its own pivot p_u to the group's pivot P (that of the group's first channel):
+    //   sum(x - P) = s_u + n_u d,  sum((x - P)^2) = q_u + 2 d s_u + n_u d^2,  d = p_u - P,  n_u = pixels x channels of the unit
+    const float n = (float)(p1 - p0) * (float)U;
     const float P = gn_load1(a, b, p0, t * a.cpg);
     float ss = 0.f, qq = 0.f;
-    for (int c = t * a.cpg; c < (t + 1) * a.cpg; ++c) {
-      const float d = gn_load1(a, b, p0, c) - P;
-      ss += rs[c] + n * d;
-      qq += rq[c] + 2.f * d * rs[c] + n * d * d;
+    for (int u = t * a.cpg / U; u < (t + 1) * a.cpg / U; ++u) {
+      const float d = gn_load1(a, b, p0, u * U) - P;
+      ss += rs[u] + n * d;
+      qq += rq[u] + 2.f * d * rs[u] + n * d * d;
     }
-    const GnAcc acc = gn_acc_from_shifted(n * (float)a.cpg, P, ss, qq);
+    const GnAcc acc = gn_acc_from_shifted((float)(p1 - p0) * (float)a.cpg, P, ss, qq);
     w[0] = acc.s;
     w[1] = acc.m2;
   }
@@ -310,16 +331,20 @@ __global__ __launch_bounds__(256) void gn_small_kernel(GnArgs a) {
   // sums shifted by a pivot (the group's first element, the same for every thread): q / n - (s / n)^2 then cancels only |pivot - mean| / sigma,
   // not |mean| / sigma (af_common.h, GroupNorm partial statistics)
   const float pivot = (float)src[(size_t)b * a.HW * ld];
+  {
+    const half2_t p2 = {(half_t)pivot, (half_t)pivot}, one2 = {(half_t)1.0f, (half_t)1.0f};    // packed fp16 + dot2, as gn_partial_kernel
 #pragma unroll
-  for (int u = 0; u < GS_IT; ++u)
-    if (t + 256 * u < items) {
+    for (int u = 0; u < GS_IT; ++u)
+      if (t + 256 * u < items) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float f = (float)v[u][e] - pivot;
-        s += f;
-        q += f * f;
+        for (int e = 0; e < 8; e += 2) {
+          const half2_t x2 = {v[u][e], v[u][e + 1]};
+          const half2_t d2 = x2 - p2;
+          s = __builtin_amdgcn_fdot2(d2, one2, s, false);
+          q = __builtin_amdgcn_fdot2(d2, d2, q, false);
+        }
       }
-    }
+  }
   s = af_wave_sum(s);
   q = af_wave_sum(q);
   if (lane == 0) {
@@ -404,9 +429,10 @@ __global__ __launch_bounds__(1024) void gn_pair_kernel(GnArgs a) {
   for (int u = 0; u < IT; ++u) {
     if (t + 1024 * u < items) {
       const half2_t h = *reinterpret_cast<const half2_t*>(&v[u]);
-      const float f0 = (float)h[0] - pivot, f1 = (float)h[1] - pivot;
-      s += f0 + f1;
-      q += f0 * f0 + f1 * f1;
+      const half2_t p2 = {(half_t)pivot, (half_t)pivot}, one2 = {(half_t)1.0f, (half_t)1.0f};
+      const half2_t d2 = h - p2;
+      s = __builtin_amdgcn_fdot2(d2, one2, s, false);
+      q = __builtin_amdgcn_fdot2(d2, d2, q, false);
     }
   }
   s = af_wave_sum(s);
@@ -580,11 +606,14 @@ extern "C" int af_groupnorm_stats(const void* x1, const void* x2, int c1, int c2
   int nb2 = (iters + 7) / 8;
   nb2 = nb2 < 1 ? 1 : (nb2 > 256 ? 256 : nb2);
   dim3 g2(nb2, B);
+  const bool pair = a.cpg % 2 == 0;                    // every SD-1.5 width; odd group widths keep the per-channel form
   if (ct == 1) {
-    hipLaunchKernelGGL(gn_partial_kernel<1>, g1, blk, lds, s, a);
+    if (pair) hipLaunchKernelGGL((gn_partial_kernel<1, true>), g1, blk, lds, s, a);
+    else hipLaunchKernelGGL((gn_partial_kernel<1, false>), g1, blk, lds, s, a);
     hipLaunchKernelGGL(gn_apply_kernel<1>, g2, blk, 0, s, a);
   } else if (ct == 2) {
-    hipLaunchKernelGGL(gn_partial_kernel<2>, g1, blk, lds, s, a);
+    if (pair) hipLaunchKernelGGL((gn_partial_kernel<2, true>), g1, blk, lds, s, a);
+    else hipLaunchKernelGGL((gn_partial_kernel<2, false>), g1, blk, lds, s, a);
     hipLaunchKernelGGL(gn_apply_kernel<2>, g2, blk, 0, s, a);
   } else {
     return af_fail(AF_E_UNSUPPORTED, "af_groupnorm: C > 4096");
