@@ -424,6 +424,110 @@ __global__ __launch_bounds__(256, 2) void af_gemm_kernel(GemmDev p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Tile 18 (round 5): SMALL plain GEMMs with their fragments straight from global memory -- no LDS, no barrier, no split-K.
+// The training legs issue thousands of GEMMs with a few hundred rows (the CLIP encoders' linears at 388 ... 1552 tokens and their dgrad /
+// wgrad, rank-192 adapter projections, batch-1 low-resolution projections): on the register-staged 64 x 64 tile each is a chain of
+// K / 64 dependent stages (global -> registers -> LDS -> barrier -> fragments -> MFMA), 9 - 11 us whatever the shape, and the tuned table
+// answers with split-K, i.e. a second 5 us launch (profiles/r04s_gemm_census_stage2.txt: 4,513 such GEMMs + 3,890 reduces per Stage-2 micro-batch).
+// Both operands are K-contiguous, so an MFMA fragment IS a 16-byte load per lane (row = lane & 15, 8 k = chunk lane >> 4): a wave owns
+// 16 rows x 32 columns (one A fragment, two W fragments, two MFMAs per 32-deep step) and keeps D steps of fragments in flight ahead of the
+// MFMAs -- a branch-free loop pinned with sched_barrier, as xattn_colmix_mfma_kernel: the launch is one memory round trip plus K / 32 MFMA
+// pairs, not K / 64 round trips.  Workgroup = 32 x 64 outputs (4 waves).  Out-of-range rows read a clamped (valid) row and are dropped in
+// the epilogue; K is padded by the packed weight's zero columns, against which A reads its last valid chunk again (0 x finite).
+// Scope: taps 1, one source, standard epilogue (bias, per-batch row bias, SiLU / quick-GELU, residual, fp16 or fp32 output), K % 8 == 0,
+// 16-byte aligned rows.  Operand-swapped like af_gemm_kernel: a lane owns 4 consecutive output channels of one row.
+template <int D>
+__global__ __launch_bounds__(256) void af_gemm_direct_kernel(GemmDev p) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave & 1, wn = wave >> 1;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int tile_m = blockIdx.x / p.tiles_n, tile_n = blockIdx.x - tile_m * p.tiles_n;
+  const int m = tile_m * 32 + wm * 16 + fr;
+  const int nt = tile_n * 64 + wn * 32;                      // this wave's first output channel
+  const int nk = p.kpad >> 5;                                // 32-deep steps (kpad is a multiple of 64)
+  const int kc_max = (p.K >> 3) - 1;                         // last valid 8-element chunk of an A row
+  const half_t* arow = p.a1 + (size_t)min(m, p.M - 1) * p.lda1;
+  const half_t* w0 = p.wt + (size_t)(nt + fr) * p.kpad + 8 * fq;      // rows < npad = roundup(N, 128): always in the packed weight
+  const half_t* w1 = w0 + (size_t)16 * p.kpad;
+  floatx4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  half8_t xa[D], wa[D], wb[D];
+  auto load = [&](int kt, int sl) {
+    const int kw = min(kt, nk - 1);                          // steps past the end re-read the last one (their MFMAs do not run)
+    xa[sl] = *reinterpret_cast<const half8_t*>(arow + 8 * min(kw * 4 + fq, kc_max));
+    wa[sl] = *reinterpret_cast<const half8_t*>(w0 + kw * 32);
+    wb[sl] = *reinterpret_cast<const half8_t*>(w1 + kw * 32);
+  };
+#pragma unroll
+  for (int sl = 0; sl < D; ++sl) load(sl, sl);
+  for (int kt = 0; kt < nk; kt += D) {                       // nk % D == 0 (host)
+#pragma unroll
+    for (int sl = 0; sl < D; ++sl) {
+      __builtin_amdgcn_sched_barrier(0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[sl], xa[sl], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[sl], xa[sl], acc1, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      load(kt + D + sl, sl);
+    }
+  }
+  if (m >= p.M) return;
+  const int bidx = p.rowbias != nullptr ? m / p.rows_per_batch : 0;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int n0 = nt + t * 16 + 4 * fq;
+    if (n0 >= p.N) continue;
+    const floatx4 a = t ? acc1 : acc0;
+    float v[4] = {a[0], a[1], a[2], a[3]};
+    if (p.bias) {
+      const floatx4 bv = *reinterpret_cast<const floatx4*>(p.bias + n0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] += bv[i];
+    }
+    if (p.rowbias) {
+      const half4_t rv = *reinterpret_cast<const half4_t*>(p.rowbias + (size_t)bidx * p.ld_rowbias + n0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] += (float)rv[i];
+    }
+    if (p.act_silu == 1) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = af_silu(v[i]);
+    } else if (p.act_silu == 3) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = v[i] * af_sigmoid(1.702f * v[i]);
+    }
+    if (p.residual) {
+      const half4_t rv = *reinterpret_cast<const half4_t*>(p.residual + (size_t)m * p.N + n0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] += (float)rv[i];
+    }
+    if (p.out_f32) {
+      *reinterpret_cast<floatx4*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ld_out + n0) = floatx4{v[0], v[1], v[2], v[3]};
+    } else {
+      const half4_t h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+      *reinterpret_cast<half4_t*>(p.out + (size_t)m * p.ld_out + n0) = h;
+    }
+  }
+}
+
+// tile 18's scope (af_gemm falls back to the register-staged 64 x 64 tile outside it)
+static bool gemm_direct_eligible(const af_gemm_desc* d, const GemmDev& p) {
+  return d->taps == 1 && d->a2 == nullptr && d->c2 == 0 && d->act != AF_ACT_GEGLU && d->out_mode != AF_OUT_SPLIT_T && d->ln_colsum == nullptr &&
+         d->gn_partials == nullptr && d->K % 8 == 0 && d->K >= 8 && p.lda1 % 8 == 0 && d->N % 4 == 0 && p.ld_out % 4 == 0 &&
+         (((uintptr_t)d->a1 | (uintptr_t)d->wt) & 15) == 0 && d->kpad % 64 == 0;
+}
+
+static int launch_direct(const GemmDev& p0, hipStream_t stream) {
+  GemmDev p = p0;
+  p.tiles_m = (p.M + 31) / 32;
+  p.tiles_n = (p.N + 63) / 64;
+  p.splits = 1;
+  const dim3 grid(p.tiles_m * p.tiles_n), block(256);
+  if ((p.kpad >> 5) % 4 == 0) hipLaunchKernelGGL(af_gemm_direct_kernel<4>, grid, block, 0, stream, p);
+  else hipLaunchKernelGGL(af_gemm_direct_kernel<2>, grid, block, 0, stream, p);
+  return af_check_launch("af_gemm(tile 18)");
+}
+
 // split-K second pass: sum the fp32 partials and apply the standard epilogue (4 channels per thread)
 __global__ __launch_bounds__(256) void af_splitk_reduce_kernel(GemmDev p) {
   const long i4 = (long)blockIdx.x * 256 + threadIdx.x;
@@ -626,11 +730,15 @@ extern "C" int af_gemm(const af_gemm_desc* d, void* stream) {
     const long t128 = (long)((d->M + 127) / 128) * ((d->N + 127) / 128);
     tile = (t128 >= 192 && d->N >= 96) ? 1 : 2;
   }
-  AF_REQUIRE(tile >= 1 && tile <= 17, "af_gemm: tile must be 0 .. 17");
+  AF_REQUIRE(tile >= 1 && tile <= 18, "af_gemm: tile must be 0 .. 18");
 
   AfLaunchScope scope(AF_FAM_GEMM, stream);
   hipStream_t s = (hipStream_t)stream;
   AF_REQUIRE(d->tap_shift == 0 || (d->tap_shift == 1 && d->taps == 9 && !p.upsample), "af_gemm: tap_shift is 0 or 1 (3x3, no upsample)");
+  if (tile == 18) {                                  // small GEMMs straight from global memory; outside its scope: the 64 x 64 tile
+    if (gemm_direct_eligible(d, p)) return launch_direct(p, s);
+    tile = 2;
+  }
   if (tile >= 3 && d->tap_shift) tile = 1;          // the ring kernel keeps the symmetric-padding loader only
   if (tile >= 3) {
     const int eff = af_gemm3_effective_splits(d, p.splits, tile - 3);

@@ -212,6 +212,12 @@ SPLITK_FUSED_MAX = int(_os.environ.get("AF_SPLITK_FUSED_MAX", "0"))
 SPLITK_FUSED_BYTES = int(_os.environ.get("AF_SPLITK_FUSED_BYTES", "0"))
 
 
+# Round 5: tile 18 (fragments straight from global memory, no LDS / barrier / split-K) for the SMALL plain GEMMs the table or the heuristic would
+# give to the register-staged 64 x 64 tile (tile 2, often with split-K): at most this many rows, K <= SMALL_GEMM_MAX_K.  0 rows = off.
+SMALL_GEMM_MAX_M = int(_os.environ.get("AF_SMALL_GEMM_MAX_M", "0"))
+SMALL_GEMM_MAX_K = int(_os.environ.get("AF_SMALL_GEMM_MAX_K", "3072"))
+
+
 GN_FROM_PRODUCER = _os.environ.get("AF_GN_FROM_PRODUCER", "1") != "0"   # GroupNorm statistics from the producing GEMM's epilogue (0: always a statistics pass)
 
 
@@ -317,6 +323,10 @@ def _launch_gemm(d: "GemmDesc", device, what: str, tile: int = 0, splits: int = 
             tile, splits = tune_table().get(key, (0, 1))
             if d.ln_colsum and tile == 0:
                 tile, splits = tune_table().get(key[:-3], (0, 1))
+    if (SMALL_GEMM_MAX_M and tile in (0, 2) and d.taps == 1 and d.M <= SMALL_GEMM_MAX_M and d.K <= SMALL_GEMM_MAX_K and not d.a2 and not d.ln_colsum
+            and d.act != AF_ACT_GEGLU and d.out_mode != AF_OUT_SPLIT_T and d.K % 8 == 0 and _tune_recorder is None
+            and (tile == 2 or (d.M * d.N <= (1 << 21)))):
+        tile, splits = 18, 1                                  # the library falls back to tile 2 if a stride / alignment rule is not met
     if d.ln_colsum:
         # the folded LayerNorm lives in the whole-line kernel only (tiles 7 .. 13, 16, 17), unsplit
         splits = 1

@@ -131,6 +131,10 @@ typedef struct af_gemm_desc {
                         /* 16 / 17 = whole-line kernel, 64 x 128 / 128 x 64 tile of four waves (1 x 4 / 2 x 2; N % 128 / 64 == 0; standard and transposed-V-split epilogues, folded
                            LayerNorm, taps 1 / 9, no nearest x2, no K tail): 25 KB stages, so THREE workgroups share a CU -- a short-K GEMM's K step is a
                            memory round trip, and what hides it is the other workgroups' MFMAs, not a deeper ring */
+                        /* 18 = SMALL plain GEMMs with their MFMA fragments straight from global memory (both operands are K-contiguous: a fragment is one 16-byte
+                           load per lane), 32 x 64 outputs per workgroup, no LDS, no barrier, several K steps of fragments in flight, never split: the training
+                           legs' GEMMs of a few hundred rows, which on tile 2 are chains of K / 64 dependent stages (+ a split-K reduce launch).  taps 1, one
+                           source, standard epilogue, fp16 or fp32 output, K % 8 == 0, 16-byte aligned rows; outside that scope it falls back to tile 2 */
   int32_t splits;       /* split-K factor (<=1: none).  >1 needs the standard epilogue and a workspace:
                            each split writes an fp32 partial [M][N], a second launch reduces + applies the epilogue */
   void* workspace;      /* fp32, >= splits*M*N*4 bytes when splits > 1 */

@@ -337,6 +337,46 @@ def test_conv3x3_and_gemm_tile15_256x128(dev, B, H, W, c1, c2, cout, ups, splits
     assert rel_l2(og.float().cpu().numpy(), F.silu(a.float() @ wm.float().t() + bias).numpy()) < TOL
 
 
+@pytest.mark.parametrize("M,N,K", [(388, 768, 768), (388, 3072, 768), (1552, 768, 3072), (77, 192, 320), (256, 1280, 1280), (64, 320, 192), (1, 512, 512),
+                                   (8, 1280, 320), (130, 4, 320), (33, 100, 72), (1000, 320, 328)])
+@pytest.mark.parametrize("mode", ["plain", "epilogue", "f32", "view"])
+def test_gemm_tile18_small_direct(dev, M, N, K, mode):
+    """Tile 18 (round 5): small plain GEMMs with their MFMA fragments straight from global memory, 32 x 64 outputs per workgroup, no LDS, no split-K --
+    the CLIP linears at 388 / 1552 tokens and their dgrad / wgrad shapes, rank-192 adapter projections, batch-1 projections, one-row and
+    eight-row cases, K that is not a multiple of 32 / 64 (zero columns of the packed weight against a clamped re-read of A), N that is not a multiple
+    of 16; with bias + per-batch row bias + SiLU / quick-GELU + residual; the fp32 accumulator as output (weight gradients); an A operand that is a
+    column slice of a wider buffer (lda > K) -- against the fp32 product on the same fp16 operands, and against tile 2 on the same call."""
+    from adaface_dev_amd import ops
+    a, w = rnd((M, K), 1), rnd((N, K), 2, K ** -0.5)
+    pw = ops.pack_matrix(w, torch.randn(N, generator=torch.Generator().manual_seed(3)) if mode == "epilogue" else None, dev)
+    kw, ref = {}, a.float() @ w.float().t()
+    ad = a.to(dev)
+    if mode == "epilogue":
+        rpb = -(-M // 3)
+        rowb, res = rnd((3, N), 6), rnd((M, N), 7)
+        kw = dict(rowbias=rowb.to(dev), rows_per_batch=rpb, residual=res.to(dev), act=ops.AF_ACT_QUICKGELU if M % 2 else ops.AF_ACT_SILU)
+        z = ref + pw.bias.cpu() + rowb.float()[torch.arange(M) // rpb]
+        ref = (z * torch.sigmoid(1.702 * z) if M % 2 else F.silu(z)) + res.float()
+    if mode == "f32":
+        kw = dict(out_f32=True)
+    if mode == "view":
+        wide = rnd((M, K + 24), 5).to(dev)
+        wide[:, 8:8 + K] = ad
+        ad = wide[:, 8:8 + K]                              # a column slice: rows 16-byte aligned, lda = K + 24 (the C ABI as the strided callers use it)
+        d = ops.GemmDesc()
+        out = torch.empty((M, N), dtype=torch.float16, device=dev)
+        d.a1, d.wt, d.out = ad.data_ptr(), pw.wt.data_ptr(), out.data_ptr()
+        d.M, d.N, d.K, d.kpad, d.taps, d.c1, d.lda1 = M, N, K, pw.kpad, 1, K, ad.stride(0)
+        ops._launch_gemm(d, dev, "af_gemm", 18, 1)
+    else:
+        out = ops.gemm(ad, pw, tile=18, **kw)
+    assert out.dtype == (torch.float32 if mode == "f32" else torch.float16)
+    assert rel_l2(out.float().cpu().numpy(), ref.numpy()) < (1e-5 if mode == "f32" else TOL)
+    if mode in ("plain", "epilogue"):
+        out2 = ops.gemm(a.to(dev), pw, tile=2, **kw)
+        assert rel_l2(out.float().cpu().numpy(), out2.float().cpu().numpy()) < 1e-3
+
+
 @pytest.mark.parametrize("tile", [16, 17])
 @pytest.mark.parametrize("M,N,K,splits,ln", [(8192, 640, 640, 1, False), (2048 + 40, 1280, 1280, 1, True), (512, 1280, 1280, 3, False), (4096, 320, 320, 1, True), (100, 128, 192, 1, False)])
 def test_gemm_and_conv_small_tiles_16_17(dev, tile, M, N, K, splits, ln):
@@ -672,6 +712,26 @@ def test_gemm_folded_layernorm(dev, rows, C, N, tile):
     pw = ops.pack_matrix_ln(w, bias, g, b, 1e-5, dev)
     out = ops.gemm(x.to(dev), pw, residual=r.to(dev), tile=tile)
     ref = F.layer_norm(x.float(), (C,), g, b, 1e-5) @ w.float().t() + bias + r.float()
+    assert rel_l2(out.float().cpu().numpy(), ref.numpy()) < TOL
+
+
+@pytest.mark.parametrize("ratio", [10.0, 30.0])
+@pytest.mark.parametrize("C,tile", [(320, 7), (640, 8), (1280, 16)])
+def test_gemm_folded_layernorm_rows_with_mean_above_their_spread(dev, C, tile, ratio):
+    """The folded LayerNorm takes a row's variance as q / K - mean^2 from fp32 sums of the A fragments (one pass, inside the GEMM's main loop).  Unlike a
+    GroupNorm group, a token's channel vector has |mean| / sigma below ~1 in this network (an outlier CHANNEL widens the row's spread, it does not move
+    its mean), but the form's margin is stated and held here: rows with |mean| / sigma = 10 and 30 stay inside the ordinary tolerance (the fp32 sums of
+    320 ... 1280 squares lose ~6e-8 K^0.5 (mean / sigma)^2 of the variance: 1e-4 at 10, 1e-3 at 30; 100 would be past it -- af_norm.hip's shifted
+    partials are what a group statistic needs, §4.12)."""
+    from adaface_dev_amd import ops
+    g0 = torch.Generator().manual_seed(21)
+    rows = 260
+    x = (torch.randn((rows, C), generator=g0) + ratio * torch.where(torch.arange(rows) % 2 == 0, 1.0, -1.0)[:, None]).half()
+    g = torch.randn(C, generator=g0) * 0.2 + 1
+    b = torch.randn(C, generator=g0) * 0.2
+    w = rnd((C, C), 2, C ** -0.5)
+    out = ops.gemm(x.to(dev), ops.pack_matrix_ln(w, None, g, b, 1e-5, dev), tile=tile)
+    ref = F.layer_norm(x.float(), (C,), g, b, 1e-5) @ w.float().t()
     assert rel_l2(out.float().cpu().numpy(), ref.numpy()) < TOL
 
 
