@@ -21,6 +21,25 @@ from ...autograd_ops import low_rank_product, wgrad
 from ...ops import F16
 
 
+def _cached_scales(ad, base, compute):
+    """The DoRA scale vectors of adapter ``ad`` on layer ``base`` depend on (W, A, B, m) only, yet every pass of a step asked for them again: a weight
+    cast, a rank-192 product, a row norm and five element-wise launches per adapter and pass (tools/torch_op_census.py: ~900 launches per Stage-2
+    micro-batch).  Computed once per parameter state; the buffers are REFRESHED IN PLACE when a parameter changes (as the weight packs are), so a
+    captured hipGraph that read them keeps reading the right addresses -- ``_packs`` (called before every replay) refreshes them too."""
+    key = tuple(ops.param_key(t) for t in (base.weight, ad.lora_A, ad.lora_B, ad.lora_magnitude_vector))
+    if getattr(ad, "_scale_key", None) != key:
+        new = compute()
+        old = getattr(ad, "_sc", None)
+        if old is not None and all(o.shape == n.shape and o.device == n.device for o, n in zip(old, new)):
+            for o, n in zip(old, new):
+                o.copy_(n)
+        else:
+            ad._sc = new
+        ad._scale_key = key
+        object.__setattr__(ad, "_scale_base", base)       # (a plain attribute: nn.Module.__setattr__ would register the base layer as a sub-module)
+    return ad._sc
+
+
 class DoRAConvAdapter(nn.Module):
     def __init__(self, conv, rank=192, lora_alpha=16, lora_dropout=0.1, generator=None):
         super().__init__()
@@ -52,10 +71,16 @@ class DoRAConvAdapter(nn.Module):
             else:
                 self._pk = new
             self._pack_key = key
+        if getattr(self, "_scale_base", None) is not None:
+            self.scales(self._scale_base)                  # (a graph replay follows a _packs call: the scale buffers must be current too)
         return self._pk
 
     def scales(self, conv):
-        """(u = s - 1, v = s * scaling, norm) fp32 [Cout]; s = m / ||W + scaling * B A|| with the norm detached (peft)."""
+        """(u = s - 1, v = s * scaling, norm) fp32 [Cout]; s = m / ||W + scaling * B A|| with the norm detached (peft).  A function of the
+        parameters alone: kept until one of them changes (_cached_scales)."""
+        return _cached_scales(self, conv, lambda: self._scales(conv))
+
+    def _scales(self, conv):
         w = conv.weight.detach().float()
         delta = low_rank_product(self.lora_B.detach().flatten(1), self.lora_A.detach().flatten(1)).reshape(w.shape)
         norm = (w + self.scaling * delta).flatten(1).norm(dim=1)
@@ -209,9 +234,14 @@ class DoRALinearAdapter(nn.Module):
             self._pk = (ops.pack_matrix(A, None, dev), ops.pack_matrix(A.t().contiguous(), None, dev), ops.pack_matrix(Bm, None, dev),
                         ops.pack_matrix(Bm.t().contiguous(), None, dev))
             self._pack_key = key
+        if getattr(self, "_scale_base", None) is not None:
+            self.scales(self._scale_base)                  # (a graph replay follows a _packs call: the scale buffers must be current too)
         return self._pk
 
     def scales(self, linear):
+        return _cached_scales(self, linear, lambda: self._scales(linear))
+
+    def _scales(self, linear):
         w = linear.weight.detach().float()
         norm = (w + self.scaling * low_rank_product(self.lora_B.detach(), self.lora_A.detach())).norm(dim=1)
         s = self.lora_magnitude_vector.detach().float() / norm

@@ -76,6 +76,11 @@ def pack_matrix(w2d: torch.Tensor, bias: Optional[torch.Tensor], device, taps: i
     """w2d: [N, K] (any float dtype, any device) -> zero-padded fp16 [roundup(N,128), roundup(K,64)]."""
     N, K = w2d.shape
     npad, kpad = round_up(N, 128), round_up(K, 64)
+    if (npad, kpad) == (N, K) and w2d.dtype == F16 and w2d.is_contiguous() and w2d.device == torch.device(device) and not w2d.requires_grad:
+        # already in the packed layout (an fp16 activation used as the B operand of a product: the feature-matching losses' 4096-row matrices):
+        # no zero-fill, no copy.  The pack is read-only; parameters never take this path (they are fp32 masters)
+        b = None if bias is None else bias.detach().to(device=device, dtype=torch.float32).contiguous()
+        return PackedWeight(w2d, b, N, K, kpad, taps, cin if cin else K)
     wt = torch.zeros((npad, kpad), dtype=F16, device=device)
     wt[:N, :K] = w2d.detach().to(device=device, dtype=F16)
     b = None if bias is None else bias.detach().to(device=device, dtype=torch.float32).contiguous()
