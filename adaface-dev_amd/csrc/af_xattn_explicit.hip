@@ -292,6 +292,193 @@ __global__ __launch_bounds__(256) void xattn_colmix_final_kernel(const float* __
   out[(size_t)row * ldout + c] = (half_t)(acc * alpha);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 5: the four wave-per-row kernels above as MFMA kernels (they are kept as the fallback outside the MFMA forms' scope: L > 128 never
+// reaches this file, d % 8 == 0 always holds).  On v_mfma_f32_16x16x4_f32 a lane holds ONE element of each operand (f32 in, f32 accumulate:
+// bit for bit an fmaf chain over the reduction index), so every fragment is a plain load of the natural layout -- nothing is staged or transposed
+// -- and the fp32 scores / probabilities / score gradients are never rounded.  A WAVE owns 16 queries of one (batch item, head).
+//
+//   xattn_qk_mfma_kernel<MT, MODE>   D[query][key] = sum_c a[query][c] b[key][c]  (a = q or dO rows, b = k or v rows; reduction over the head dimension)
+//       MODE 0: score = scale * D;   MODE 1: dscore = P o (dP - sum_keys P dP), dP = D (+ dprob_ext)      -- lanes = 16 consecutive keys: 64-byte runs
+//   xattn_mix_mfma_kernel<DT, S, SM> D[query][channel] = sum_key w[query][key] x[key][channel]             (reduction over the keys)
+//       SM = 1: w = softmax(score row), written out as prob;   SM = 0: w as given (dq = scale * dscore k)
+template <int MT, int MODE>
+__global__ __launch_bounds__(256) void xattn_qk_mfma_kernel(const half_t* __restrict__ a, int lda, const half_t* __restrict__ bm, int ldb,
+                                                            float* __restrict__ out, const float* __restrict__ prob, const float* __restrict__ ext,
+                                                            int B, int Nq, int L, int heads, int d, float scale) {
+  const int lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
+  const int i0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
+  const int h = blockIdx.y, b = blockIdx.z;
+  if (i0 >= Nq) return;
+  const half_t* ap = a + ((size_t)b * Nq + min(i0 + lr, Nq - 1)) * lda + h * d + lk;
+  const half_t* bp[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) bp[mt] = bm + ((size_t)b * L + min(16 * mt + lr, L - 1)) * ldb + h * d + lk;
+  const floatx4 zf = {0.f, 0.f, 0.f, 0.f};
+  floatx4 acc[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) acc[mt] = zf;
+  for (int c = 0; c < d; c += 4) {                             // unconditional loads of clamped rows; rows / keys out of range are dropped below
+    const float av = (float)ap[c];
+    float bv[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) bv[mt] = (float)bp[mt][c];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[mt], acc[mt], 0, 0, 0);
+  }
+  // D: row (query) = 4 lk + r, column (key) = lr
+  const size_t row0 = ((size_t)b * heads + h) * Nq;
+  if (MODE == 0) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int j = 16 * mt + lr;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = i0 + 4 * lk + r;
+        if (i < Nq && j < L) out[(row0 + i) * L + j] = acc[mt][r] * scale;
+      }
+    }
+  } else {
+    float p[MT][4], t[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int j = 16 * mt + lr;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = i0 + 4 * lk + r;
+        const bool ok = i < Nq && j < L;
+        const size_t o = (row0 + min(i, Nq - 1)) * L + min(j, L - 1);
+        const float pv = prob[o];
+        float dp = acc[mt][r];
+        if (ext != nullptr) dp += ext[o];
+        p[mt][r] = ok ? pv : 0.f;
+        acc[mt][r] = dp;
+        t[r] += p[mt][r] * dp;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {                              // the query's keys sit in the 16 lanes of its lk group
+      float v = t[r];
+      v += __shfl_xor(v, 1, 64);
+      v += __shfl_xor(v, 2, 64);
+      v += __shfl_xor(v, 4, 64);
+      v += __shfl_xor(v, 8, 64);
+      t[r] = v;
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int j = 16 * mt + lr;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = i0 + 4 * lk + r;
+        if (i < Nq && j < L) out[(row0 + i) * L + j] = p[mt][r] * (acc[mt][r] - t[r]);
+      }
+    }
+  }
+}
+
+template <int DT, int S, int SM>
+__global__ __launch_bounds__(256) void xattn_mix_mfma_kernel(const float* __restrict__ w, const half_t* __restrict__ x, int ldx, float* __restrict__ prob,
+                                                             half_t* __restrict__ out, int ldo, float alpha, int B, int Nq, int L, int heads, int d) {
+  const int lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
+  const int i0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
+  const int h = blockIdx.y, b = blockIdx.z;
+  if (i0 >= Nq) return;
+  // A operand: w[query = i0 + lr][key = 4 s + lk]; the query's S x 4 keys are spread over the four lanes lr, lr + 16, lr + 32, lr + 48
+  const bool qok = i0 + lr < Nq;
+  const size_t wrow = (((size_t)b * heads + h) * Nq + min(i0 + lr, Nq - 1)) * L;
+  float wv[S];
+#pragma unroll
+  for (int st = 0; st < S; ++st) {
+    const int j = 4 * st + lk;
+    const float v = w[wrow + min(j, L - 1)];
+    wv[st] = j < L ? v : (SM ? -INFINITY : 0.f);
+  }
+  if (SM) {
+    float mx = wv[0];
+#pragma unroll
+    for (int st = 1; st < S; ++st) mx = fmaxf(mx, wv[st]);
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int st = 0; st < S; ++st) {
+      wv[st] = 4 * st + lk < L ? __expf(wv[st] - mx) : 0.f;    // (a row that is -inf everywhere gives NaN, as torch.softmax does)
+      sum += wv[st];
+    }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int st = 0; st < S; ++st) {
+      wv[st] *= inv;
+      const int j = 4 * st + lk;
+      if (qok && j < L) prob[wrow + j] = wv[st];
+    }
+  }
+  const half_t* xp = x + (size_t)b * L * ldx + h * d;
+  int co[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) co[dt] = min(16 * dt + lr, d - 1);
+  const floatx4 zf = {0.f, 0.f, 0.f, 0.f};
+  floatx4 acc[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) acc[dt] = zf;
+#pragma unroll
+  for (int st = 0; st < S; ++st) {
+    const half_t* xr = xp + (size_t)min(4 * st + lk, L - 1) * ldx;          // B operand: x[key = 4 st + lk][channel = 16 dt + lr]
+    float xv[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) xv[dt] = (float)xr[co[dt]];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) acc[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[st], xv[dt], acc[dt], 0, 0, 0);
+  }
+  // D: row (query) = 4 lk + r, column (channel) = lr
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) {
+    const int c = 16 * dt + lr;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = i0 + 4 * lk + r;
+      if (i < Nq && c < d) out[((size_t)b * Nq + i) * ldo + h * d + c] = (half_t)(acc[dt][r] * alpha);
+    }
+  }
+}
+
+template <int MODE>
+static void launch_qk_mfma(hipStream_t s, const half_t* a, int lda, const half_t* bm, int ldb, float* out, const float* prob, const float* ext, int B, int Nq,
+                           int L, int heads, int d, float scale) {
+  const dim3 grid((Nq + 63) / 64, heads, B), block(256);
+  if (L <= 16) hipLaunchKernelGGL((xattn_qk_mfma_kernel<1, MODE>), grid, block, 0, s, a, lda, bm, ldb, out, prob, ext, B, Nq, L, heads, d, scale);
+  else if (L <= 80) hipLaunchKernelGGL((xattn_qk_mfma_kernel<5, MODE>), grid, block, 0, s, a, lda, bm, ldb, out, prob, ext, B, Nq, L, heads, d, scale);
+  else if (L <= 112) hipLaunchKernelGGL((xattn_qk_mfma_kernel<7, MODE>), grid, block, 0, s, a, lda, bm, ldb, out, prob, ext, B, Nq, L, heads, d, scale);
+  else hipLaunchKernelGGL((xattn_qk_mfma_kernel<8, MODE>), grid, block, 0, s, a, lda, bm, ldb, out, prob, ext, B, Nq, L, heads, d, scale);
+}
+
+template <int DT, int SM>
+static void launch_mix_mfma_s(hipStream_t s, const float* w, const half_t* x, int ldx, float* prob, half_t* out, int ldo, float alpha, int B, int Nq, int L,
+                              int heads, int d) {
+  const dim3 grid((Nq + 63) / 64, heads, B), block(256);
+  if (L <= 16) hipLaunchKernelGGL((xattn_mix_mfma_kernel<DT, 4, SM>), grid, block, 0, s, w, x, ldx, prob, out, ldo, alpha, B, Nq, L, heads, d);
+  else if (L <= 80) hipLaunchKernelGGL((xattn_mix_mfma_kernel<DT, 20, SM>), grid, block, 0, s, w, x, ldx, prob, out, ldo, alpha, B, Nq, L, heads, d);
+  else if (L <= 100) hipLaunchKernelGGL((xattn_mix_mfma_kernel<DT, 25, SM>), grid, block, 0, s, w, x, ldx, prob, out, ldo, alpha, B, Nq, L, heads, d);
+  else hipLaunchKernelGGL((xattn_mix_mfma_kernel<DT, 32, SM>), grid, block, 0, s, w, x, ldx, prob, out, ldo, alpha, B, Nq, L, heads, d);
+}
+
+template <int SM>
+static void launch_mix_mfma(hipStream_t s, const float* w, const half_t* x, int ldx, float* prob, half_t* out, int ldo, float alpha, int B, int Nq, int L,
+                            int heads, int d) {
+  if (d <= 16) launch_mix_mfma_s<1, SM>(s, w, x, ldx, prob, out, ldo, alpha, B, Nq, L, heads, d);
+  else if (d <= 48) launch_mix_mfma_s<3, SM>(s, w, x, ldx, prob, out, ldo, alpha, B, Nq, L, heads, d);
+  else if (d <= 80) launch_mix_mfma_s<5, SM>(s, w, x, ldx, prob, out, ldo, alpha, B, Nq, L, heads, d);
+  else launch_mix_mfma_s<10, SM>(s, w, x, ldx, prob, out, ldo, alpha, B, Nq, L, heads, d);
+}
+
+static bool xattn_use_mfma(int d) {
+  static const bool off = getenv("AF_XATTN_EXPLICIT_MFMA") != nullptr && atoi(getenv("AF_XATTN_EXPLICIT_MFMA")) == 0;     // A/B switch: 0 = the wave-per-row kernels
+  return !off && d <= 160;
+}
+
 bool bad_common(int B, int Nq, int L, int heads, int d) { return !(B > 0 && Nq > 0 && L > 0 && L <= 128 && heads > 0 && d > 0 && d % 8 == 0); }
 
 }  // namespace
@@ -303,6 +490,10 @@ extern "C" int af_xattn_scores(const void* q, int ldq, const void* k, int ldk, v
   AF_REQUIRE(ldq >= heads * d && ldk >= heads * d && ldq % 8 == 0 && ldk % 8 == 0, "af_xattn_scores: bad leading dimensions");
   const long rows = (long)B * heads * Nq;
   AfLaunchScope scope(AF_FAM_XATTN, stream);
+  if (xattn_use_mfma(d)) {
+    launch_qk_mfma<0>((hipStream_t)stream, (const half_t*)q, ldq, (const half_t*)k, ldk, (float*)score, nullptr, nullptr, B, Nq, L, heads, d, scale);
+    return af_check_launch("af_xattn_scores");
+  }
   hipLaunchKernelGGL(xattn_scores_kernel, dim3((unsigned)((rows + ROWS_PER_WG - 1) / ROWS_PER_WG)), dim3(256), 0, (hipStream_t)stream,
                      (const half_t*)q, ldq, (const half_t*)k, ldk, (float*)score, B, Nq, L, heads, d, scale);
   return af_check_launch("af_xattn_scores");
@@ -315,6 +506,10 @@ extern "C" int af_xattn_softmax_pv(const void* score, const void* v, int ldv, vo
   AF_REQUIRE(ldv >= heads * d && ldo >= heads * d, "af_xattn_softmax_pv: bad leading dimensions");
   const long rows = (long)B * heads * Nq;
   AfLaunchScope scope(AF_FAM_XATTN, stream);
+  if (xattn_use_mfma(d)) {
+    launch_mix_mfma<1>((hipStream_t)stream, (const float*)score, (const half_t*)v, ldv, (float*)prob, (half_t*)o, ldo, 1.0f, B, Nq, L, heads, d);
+    return af_check_launch("af_xattn_softmax_pv");
+  }
   hipLaunchKernelGGL(xattn_softmax_pv_kernel, dim3((unsigned)((rows + ROWS_PER_WG - 1) / ROWS_PER_WG)), dim3(256), 0, (hipStream_t)stream,
                      (const float*)score, (const half_t*)v, ldv, (float*)prob, (half_t*)o, ldo, B, Nq, L, heads, d);
   return af_check_launch("af_xattn_softmax_pv");
@@ -327,6 +522,11 @@ extern "C" int af_xattn_softmax_pv_bwd(const void* prob, const void* v, int ldv,
   AF_REQUIRE(ldv >= heads * d && lddo >= heads * d && ldv % 8 == 0 && lddo % 8 == 0, "af_xattn_softmax_pv_bwd: bad leading dimensions");
   const long rows = (long)B * heads * Nq;
   AfLaunchScope scope(AF_FAM_XATTN, stream);
+  if (xattn_use_mfma(d)) {
+    launch_qk_mfma<1>((hipStream_t)stream, (const half_t*)dout, lddo, (const half_t*)v, ldv, (float*)dscore, (const float*)prob, (const float*)dprob_ext, B, Nq, L,
+                      heads, d, 1.0f);
+    return af_check_launch("af_xattn_softmax_pv_bwd");
+  }
   hipLaunchKernelGGL(xattn_softmax_pv_bwd_kernel, dim3((unsigned)((rows + ROWS_PER_WG - 1) / ROWS_PER_WG)), dim3(256), 0, (hipStream_t)stream,
                      (const float*)prob, (const half_t*)v, ldv, (const half_t*)dout, lddo, (const float*)dprob_ext, (float*)dscore, B, Nq, L,
                      heads, d);
@@ -340,6 +540,10 @@ extern "C" int af_xattn_rowmix(const void* w, const void* x, int ldx, void* out,
   AF_REQUIRE(ldx >= heads * d && ldout >= heads * d, "af_xattn_rowmix: bad leading dimensions");
   const long rows = (long)B * heads * Nq;
   AfLaunchScope scope(AF_FAM_XATTN, stream);
+  if (xattn_use_mfma(d)) {
+    launch_mix_mfma<0>((hipStream_t)stream, (const float*)w, (const half_t*)x, ldx, nullptr, (half_t*)out, ldout, alpha, B, Nq, L, heads, d);
+    return af_check_launch("af_xattn_rowmix");
+  }
   hipLaunchKernelGGL(xattn_rowmix_kernel, dim3((unsigned)((rows + ROWS_PER_WG - 1) / ROWS_PER_WG)), dim3(256), 0, (hipStream_t)stream,
                      (const float*)w, (const half_t*)x, ldx, (half_t*)out, ldout, alpha, B, Nq, L, heads, d);
   return af_check_launch("af_xattn_rowmix");

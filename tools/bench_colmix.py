@@ -25,6 +25,14 @@ def main():
         err = float((got - ref).norm() / ref.norm())
         fl = 2.0 * B * H * N * L * d
         print(f"colmix B{B} H{H} N{N} L{L} d{d}: {ms * 1e3:.1f} us  {fl / ms / 1e9:.2f} TFLOP/s  ({w.numel() * 4 / ms / 1e6:.0f} GB/s of w)  rel-L2 vs fp64 {err:.2e}")
+        # the other explicit-attention kernels of the captured layers (round 5: MFMA forms; AF_XATTN_EXPLICIT_MFMA=0 = the wave-per-row kernels)
+        kw = dict(B=B, Nq=N, L=L, heads=H, d=d)
+        q, k = x, torch.randn(B * L, H * d, device=dev).half()
+        score = ops.xattn_scores(q, k, scale=d ** -0.5, **kw)
+        prob, o = ops.xattn_softmax_pv(score, k, **kw)
+        t = {"scores": timeit(lambda: ops.xattn_scores(q, k, scale=d ** -0.5, **kw), 10), "softmax_pv": timeit(lambda: ops.xattn_softmax_pv(score, k, **kw), 10),
+             "softmax_pv_bwd": timeit(lambda: ops.xattn_softmax_pv_bwd(prob, k, q, None, **kw), 10), "rowmix": timeit(lambda: ops.xattn_rowmix(prob, k, 1.0, **kw), 10)}
+        print("   " + "  ".join(f"{n} {v * 1e3:.1f} us" for n, v in t.items()))
 
 
 if __name__ == "__main__":
