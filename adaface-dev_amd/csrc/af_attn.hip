@@ -625,6 +625,282 @@ int launch_attn2chain(const AttnArgs& a, hipStream_t stream) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Software-pipelined form of the two-chain SLOT kernel above (round 5).  The ISA of af_attn2_kernel shows what its source order
+// cannot avoid: the lazy-reference branch of a chain sits between that chain's maximum and its 32 exp2, so every exp2 block lands in
+// a basic block whose only MFMAs (the chain's own P.V) DEPEND on it -- per stage the wave issues 12 S^T MFMAs, 32 exp2 with the matrix
+// pipe idle, 8 P.V MFMAs, 32 exp2, 8 P.V MFMAs, and the SIMD's two waves (VALU issue is arbitrated by age, MI355X_MICROARCH.md "Two
+// waves per SIMD") do not fill each other's holes: SIMD time per wave and stage equals the SUM of its matrix and vector time.
+// Here the two chains run half a stage apart, so that each basic block holds 14 MFMAs and 32 exp2 that do not depend on each other:
+//     block B(h):  S^T_0(h) [K(h)]   P.V_0(h-1) [V(h-1)]   ||  exp2 of chain 1's scores of stage h-1   -> max_0(h), reference branch
+//     block A(h):  S^T_1(h) [K(h)]   P.V_1(h-1) [V(h-1)]   ||  exp2 of chain 0's scores of stage h     -> max_1(h), reference branch
+// (an MFMA holds the vector issue port for 8 of its 32 cycles: 2 exp2 + 1 cvt_pk fit each gap).  A "shifted stage" h therefore reads
+// K of key block h and V^T of key block h-1 from the same double-buffered LDS slot; one barrier per shifted stage as before; the
+// first and the last shifted stage are peeled.  Per chain the arithmetic and its order are those of af_attn2_kernel<DS, true, true>:
+// the results are bit-identical (tests/test_hip_kernels.py).  Measured 1-4 % faster alone (profiles/r05q_attn_pipe.txt), like round 4's
+// af_attn3 (r04c) it does not change what bounds the kernel (vector issue per score); AF_ATTN_PIPE=1 selects it, the default is the unpipelined kernel.
+// one MFMA, then the vector work its 32 cycles leave room for (24 issue cycles: 2 exp2 + 1 cvt_pk, or 5-6 plain VALU)
+#define AF_ATTN_PIPE_GROUPS()                                                         \
+  __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                                  \
+  _Pragma("unroll") for (int g_ = 0; g_ < 14; ++g_) {                                 \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                \
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                \
+    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                                \
+  }
+template <int DS>
+__global__ __launch_bounds__(256, 2) void af_attn2p_kernel(AttnArgs a) {
+  constexpr int DP = 16 * DS, DT = (DS + 1) / 2, DV = 32 * DT;
+  constexpr int KST = DP + 8, KBUF = KB * KST, VBUF = 2 * DV * VST, STAGE = KBUF + VBUF;
+  constexpr int KCH = KB * (DP / 8), NKC = (KCH + 255) / 256, VCH = DV * 8, NVC = (VCH + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) char af_smem[];
+  half_t* lds = reinterpret_cast<half_t*>(af_smem);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const int qblocks = (a.Nq + 255) / 256;
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int bh = (idx / qblocks) * 8 + xcd;
+  if (bh >= a.B * a.heads) return;
+  const int b = bh / a.heads, h = bh - b * a.heads;
+  const int q0 = (idx % qblocks) * 256 + wave * 64 + r;          // chain c handles query q0 + 32 c
+  const half8_t zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+  half8_t qf[2][DS];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const int query = q0 + 32 * c;
+    const half_t* qp = a.q + ((size_t)b * a.Nq + (query < a.Nq ? query : 0)) * a.ldq + h * a.d;
+#pragma unroll
+    for (int s = 0; s < DS; ++s) {
+      const int dc = 16 * s + 8 * hh;
+      half8_t v = *reinterpret_cast<const half8_t*>(qp + (dc < a.d ? dc : 0));
+      if (!(query < a.Nq && dc < a.d)) v = zero8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] * a.c);
+      qf[c][s] = v;
+    }
+  }
+
+  // staging: every load is unconditional on a clamped address and the constant chunks are selected afterwards (a load under a
+  // condition compiles to a branch of its own)
+  half8_t rk[NKC], rv[NVC];
+  const half_t* kptr[NKC];
+  bool kok[NKC], kone[NKC];
+#pragma unroll
+  for (int j = 0; j < NKC; ++j) {
+    const int i = tid + 256 * j;
+    const int row = (i / (DP / 8)) & (KB - 1), ch = i % (DP / 8);
+    kok[j] = i < KCH && ch * 8 < a.d;
+    kone[j] = i < KCH && ch * 8 == a.d;             // K column d = 1.0: multiplies the -m slot of Q
+    kptr[j] = a.k + ((size_t)b * a.L + row) * a.ldk + h * a.d + (kok[j] ? ch * 8 : 0);
+  }
+  const half8_t one1 = {1, 0, 0, 0, 0, 0, 0, 0};
+  const half8_t ones8 = {1, 1, 1, 1, 1, 1, 1, 1};
+  const half_t* vptr[NVC];
+  bool vok[NVC], vones[NVC];
+#pragma unroll
+  for (int j = 0; j < NVC; ++j) {
+    const int i = tid + 256 * j;
+    const int row = i >> 3, ch = i & 7;
+    vok[j] = i < VCH && row < a.d;
+    vones[j] = i < VCH && row == DV - 1;
+    vptr[j] = a.vt + (size_t)b * a.vbs + (size_t)(h * a.d + (row < a.d ? row : 0)) * a.ldv + ch * 8;
+  }
+  auto load_stage = [&](int kkey0, int vkey0) {
+#pragma unroll
+    for (int j = 0; j < NKC; ++j) rk[j] = *reinterpret_cast<const half8_t*>(kptr[j] + (size_t)kkey0 * a.ldk);
+#pragma unroll
+    for (int j = 0; j < NVC; ++j) rv[j] = *reinterpret_cast<const half8_t*>(vptr[j] + vkey0);
+  };
+  auto store_stage = [&](int buf) {
+    half_t* Ks = lds + buf * STAGE;
+    half_t* Vs = Ks + KBUF;
+#pragma unroll
+    for (int j = 0; j < NKC; ++j) {
+      const int i = tid + 256 * j;
+      if (i < KCH) {
+        const int row = i / (DP / 8), ch = i - row * (DP / 8);
+        *reinterpret_cast<half8_t*>(Ks + row * KST + ch * 8) = kok[j] ? rk[j] : (kone[j] ? one1 : zero8);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NVC; ++j) {
+      const int i = tid + 256 * j;
+      if (i < VCH) {
+        const int row = i >> 3, ch = i & 7;
+        const half8_t v = vok[j] ? rv[j] : (vones[j] ? ones8 : zero8);
+        half_t* dst = Vs + ((ch >> 2) * DV + row) * VST + (ch & 3) * 8;
+        const half4_t lo = {v[0], v[1], v[2], v[3]};
+        const half4_t hi = {v[4], v[5], v[6], v[7]};
+        *reinterpret_cast<half4_t*>(dst) = lo;
+        *reinterpret_cast<half4_t*>(dst + 4) = hi;
+      }
+    }
+  };
+
+  floatx16 o[2][DT];
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) o[c][t][i] = 0.f;
+  float m[2] = {-FLT_MAX, -FLT_MAX};
+  const floatx16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+  // S^T of chain c against the stage's keys: scores relative to m[c] (the slot) except before the first reference is set
+  auto qk = [&](int c, const half_t* Ks, floatx16 (&sT)[2]) {
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int s = 0; s < DS; ++s) {
+        const half8_t kf = *reinterpret_cast<const half8_t*>(Ks + (sub * 32 + r) * KST + 16 * s + 8 * hh);
+        sT[sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[c][s], s == 0 ? zero16 : sT[sub], 0, 0, 0);
+      }
+  };
+  auto pv = [&](int c, const half_t* Vs, const half8_t (&pf)[2][2]) {
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const half_t* vp = Vs + (sub * DV + 32 * t + r) * VST + 16 * s2 + 4 * hh;
+          const half4_t lo = *reinterpret_cast<const half4_t*>(vp);
+          const half4_t hi = *reinterpret_cast<const half4_t*>(vp + 8);
+          const half8_t vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          o[c][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[sub][s2], o[c][t], 0, 0, 0);
+        }
+  };
+  auto exps = [&](const floatx16 (&sT)[2], half8_t (&pf)[2][2]) {
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pf[sub][s2][j] = (half_t)__builtin_amdgcn_exp2f(sT[sub][8 * s2 + j]);
+  };
+  // the chain's maximum over the stage's 64 scores and its reference: set in the first stage, moved (rarely) afterwards
+  auto head = [&](int c, bool first, floatx16 (&sT)[2]) {
+    float mx = -FLT_MAX;
+#pragma unroll
+    for (int i = 0; i < 16; i += 2) {
+      mx = fmaxf(fmaxf(mx, sT[0][i]), sT[0][i + 1]);
+      mx = fmaxf(fmaxf(mx, sT[1][i]), sT[1][i + 1]);
+    }
+    const unsigned mb = __builtin_bit_cast(unsigned, mx);
+    const auto sw = __builtin_amdgcn_permlane32_swap(mb, mb, false, false);
+    mx = fmaxf(__builtin_bit_cast(float, (unsigned)sw[0]), __builtin_bit_cast(float, (unsigned)sw[1]));
+    if (first) {
+      const float m0 = (float)(half_t)mx;              // the reference is what fp16 holds
+      m[c] = m0;
+      sT[0] = sT[0] - m0;
+      sT[1] = sT[1] - m0;
+      if (hh) qf[c][DS - 1][0] = (half_t)(-m0);
+    } else if (__builtin_amdgcn_ballot_w64(mx > kLazy) != 0) {       // lazy reference, see af_attn_kernel
+      float delta = fmaxf(mx, 0.f);
+      const float mn = (float)(half_t)(m[c] + delta);
+      delta = mn - m[c];
+      if (hh) qf[c][DS - 1][0] = (half_t)(-mn);
+      const float alpha = __builtin_amdgcn_exp2f(-delta);
+      m[c] += delta;
+#pragma unroll
+      for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[c][t][i] *= alpha;
+      sT[0] = sT[0] - delta;
+      sT[1] = sT[1] - delta;
+    }
+  };
+
+  const int nstage = a.L / KB;                     // key blocks; shifted stages 0 .. nstage
+  load_stage(0, 0);
+  store_stage(0);
+  __syncthreads();
+
+  floatx16 s0[2], s1[2];
+  half8_t p0[2][2], p1[2][2];
+  // ---- shifted stage 0: no P.V yet
+  {
+    load_stage(nstage > 1 ? KB : 0, 0);
+    const half_t* Ks = lds;
+    qk(0, Ks, s0);
+    head(0, true, s0);
+    qk(1, Ks, s1);
+    exps(s0, p0);
+    head(1, true, s1);
+    store_stage(1);
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // ---- shifted stages 1 .. nstage-1
+  for (int st = 1; st < nstage; ++st) {
+    load_stage((st + 1 < nstage ? st + 1 : st) * KB, st * KB);
+    const half_t* Ks = lds + (st & 1) * STAGE;
+    const half_t* Vs = Ks + KBUF;
+    // chain 1's scores enter the iteration through an opaque definition: without it the optimiser computes their exp2 where the scores
+    // are produced -- at the end of the previous iteration, in front of the barrier, with no MFMA beside them
+    asm volatile("; af_pin s1" : "+v"(s1[0]), "+v"(s1[1]));
+    // block B
+    qk(0, Ks, s0);
+    exps(s1, p1);
+    pv(0, Vs, p0);
+    AF_ATTN_PIPE_GROUPS();
+    asm volatile("; af_pin p1" : "+v"(p1[0][0]), "+v"(p1[0][1]), "+v"(p1[1][0]), "+v"(p1[1][1]));      // ... and are not sunk to their use either
+    head(0, false, s0);
+    // block A (chain 1's previous scores were consumed by block B's exp2)
+    qk(1, Ks, s1);
+    exps(s0, p0);
+    pv(1, Vs, p1);
+    AF_ATTN_PIPE_GROUPS();
+    asm volatile("; af_pin p0" : "+v"(p0[0][0]), "+v"(p0[0][1]), "+v"(p0[1][0]), "+v"(p0[1][1]));
+    head(1, false, s1);
+    store_stage((st + 1) & 1);
+    __syncthreads();
+  }
+  // ---- shifted stage nstage: the last key block's P.V
+  {
+    const half_t* Vs = lds + (nstage & 1) * STAGE + KBUF;
+    exps(s1, p1);
+    pv(0, Vs, p0);
+    pv(1, Vs, p1);
+  }
+
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const int query = q0 + 32 * c;
+    const float mine = o[c][DT - 1][15];
+    const float other = __shfl_xor(mine, 32, 64);
+    const float lc = hh ? mine : other;
+    const float inv = 1.0f / lc;
+    if (a.lse2 && query < a.Nq && hh == 0) a.lse2[((size_t)b * a.heads + h) * a.ld_lse + query] = m[c] + __builtin_amdgcn_logf(lc);
+    if (query < a.Nq) {
+      half_t* op = a.o + ((size_t)b * a.Nq + query) * a.ldo + h * a.d;
+#pragma unroll
+      for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int dd = 32 * t + 8 * g + 4 * hh;
+          if (dd < a.d) {
+            const half4_t v = {(half_t)(o[c][t][4 * g + 0] * inv), (half_t)(o[c][t][4 * g + 1] * inv),
+                               (half_t)(o[c][t][4 * g + 2] * inv), (half_t)(o[c][t][4 * g + 3] * inv)};
+            *reinterpret_cast<half4_t*>(op + dd) = v;
+          }
+        }
+    }
+  }
+}
+
+template <int DS>
+int launch_attn2pipe(const AttnArgs& a, hipStream_t stream) {
+  constexpr int DP = 16 * DS, DT = (DS + 1) / 2, DV = 32 * DT;
+  constexpr size_t lds = (size_t)2 * (KB * (DP + 8) + 2 * DV * VST) * sizeof(half_t);
+  static bool attr_set = false;  // benign race: idempotent attribute
+  if (!af_allow_dyn_lds(reinterpret_cast<const void*>(&af_attn2p_kernel<DS>), lds, attr_set, "af_attention")) return af_check_launch("af_attention");
+  const int qblocks = (a.Nq + 255) / 256, bh8 = (a.B * a.heads + 7) / 8 * 8;
+  hipLaunchKernelGGL((af_attn2p_kernel<DS>), dim3(qblocks * bh8), dim3(256), lds, stream, a);
+  return af_check_launch("af_attention(two-chain, pipelined)");
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Short-key variant (L <= 128, no key bias, no causal mask): the U-Net's cross-attention cores (77 context tokens).
 // These launches are HBM/latency bound (76 FLOP per algorithmic byte at C = 320): the flash kernel above spends its time
 // re-staging the same 77 keys for every 128-query workgroup (2 x 64-key stages with barriers) on the ragged-L path.
@@ -856,6 +1132,9 @@ int launch_attn(const AttnArgs& a, hipStream_t stream) {
   if constexpr (DS <= 3) {      // d <= 48: two chains fit the register file at 2 waves per SIMD
     // AF_ATTN_SLOT (default 1): the reference in a spare k slot where the head dim leaves one (d = 16 DS - 8: the 64 x 64 level's d = 40)
     static const int slot_env = getenv("AF_ATTN_SLOT") ? atoi(getenv("AF_ATTN_SLOT")) : 1;
+    const char* pipe_s = getenv("AF_ATTN_PIPE");                         // read per call: the tests compare both forms in one process
+    const int pipe_env = pipe_s ? atoi(pipe_s) : 0;                      // off: 1-4 % in isolation, < 1 % of a step (profiles/r05q_attn_pipe.txt)
+    if (!general && two_chain && slot_env && pipe_env && a.Nq >= 512 && a.d == 16 * DS - 8 && DV > a.d) return launch_attn2pipe<DS>(a, stream);
     if (!general && two_chain && slot_env && a.Nq >= 512 && a.d == 16 * DS - 8 && DV > a.d) return launch_attn2chain<DS, true, true>(a, stream);
     if (!general && two_chain && a.Nq >= 512) return DV > a.d ? launch_attn2chain<DS, true>(a, stream) : launch_attn2chain<DS, false>(a, stream);
   }
