@@ -67,6 +67,16 @@ __device__ __forceinline__ void glds16(const half_t* src, char* lds_dst) {
                                    (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
+// The same instruction as inline asm (halo-resident kernel): for the builtin, hipcc retires every pending ds_read (s_waitcnt lgkmcnt(0)) in front of an
+// LDS-DMA issue it cannot prove disjoint from them -- the ping-pong loop issues its pieces right behind its fragment reads, into a slot / buffer that
+// nobody reads (barrier-ordered, see there).  lds_dst must be wave-uniform.  M0 is named as clobbered: the compiler re-materialises it for its own uses.
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+__device__ __forceinline__ void glds16_nowait(const half_t* src, char* lds_dst) {
+  asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"((unsigned)(size_t)lds_dst) : "memory", "m0");
+}
+#pragma clang diagnostic pop
+
 // Tile shape: NWM x NWN waves, each wave 64 (M) x 16*TN (N).  Two instantiations:
 //   <2, 2, 4>: 128 x 128, 4 waves, 2 workgroups per CU             (64 FLOP per operand byte)
 //   <2, 4, 5>: 128 x 320, 8 waves, 1 workgroup per CU              (91 FLOP per operand byte)
@@ -985,7 +995,8 @@ bool launch3w(const Gemm3Dev& p0, hipStream_t stream) {
 
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Halo-resident 3x3 convolution ("tile 14"): stride 1, pad 1, one source, W in {16, 32, 64}.
+// Halo-resident 3x3 convolution ("tile 14"): stride 1, pad 1, W in {16, 32, 64}, one or two channel-concatenated sources (no K tail:
+// a one-stage chunk would have to bring a whole halo in under ONE stage -- measured 15 - 80 % slower than the tap-by-tap tile, r05r).
 // The tap-by-tap implicit GEMM above fetches a tile's activation rows NINE times per 64 input channels (once per tap, shifted), and with the
 // 128 x 320 tile every 64-wide K stage moves 16 KB of activations + 40 KB of weights from L2 into LDS for 0.7 us of MFMA work -- the L2 -> LDS
 // path is what the kernel waits for (profiles/r01r_gemm_diagnosis.txt: 20 of 89 us with real addresses).  Here a workgroup owns R = 256 / W
@@ -994,19 +1005,32 @@ bool launch3w(const Gemm3Dev& p0, hipStream_t stream) {
 //     zero page), double-buffered: the next chunk's halo streams in, one 1-KB piece per wave per stage, under this chunk's nine taps;
 //   * the nine taps are nine K stages over the SAME halo: tap (ky, kx) of output pixel (r, c) is halo pixel (r + ky, c + kx), i.e. the
 //     MFMA fragment address plus a workgroup-uniform offset; only the tap's 160 x 64 weight tile (20 KB) is new per stage.
-// Per stage 26 KB instead of 56 KB cross from L2 for the same 40 MFMAs per wave, and 3.5 instead of 7 LDS-DMA instructions per wave.
+// Per stage 26 KB instead of 56 KB cross from L2 for the same 40 MFMAs per wave, and 3.2 instead of 7 LDS-DMA instructions per wave.
 // LDS rows are 128 B with the 16-byte chunk index XOR-ed with (pixel >> 1) & 7 on the DMA source side: 16 consecutive halo pixels (a
 // fragment's rows, at ANY start) hit 16 distinct (half, chunk) slots, so the ds_read_b128 fragment reads stay conflict-free under
-// every tap shift.  K is walked chunk-major (k = tap * Cin + chunk * 64 in the packed weight), split-K slices are chunk ranges.
-// The tile is 256 consecutive output rows of the [M, N] result, so the staged epilogue is the shared one.
+// every tap shift.  K is walked chunk-major (k = tap * Cin + chunk * 64 in the packed weight; Cin = c1 + c2, a chunk lies in ONE source);
+// split-K slices are chunk ranges.  The tile is 256 consecutive output rows of the [M, N] result, so the staged epilogue is the shared one.
+//
+// Main loop (round 5): PING-PONG between the two waves of a SIMD.  The eight waves are two groups of four, one wave of each group per SIMD
+// (waves w and w + 4 share one).  In the lock-step form of rounds 3 - 4 (every wave: wait, barrier, DMA, 18 fragment reads, 40 MFMAs) both
+// waves of a SIMD want the matrix pipe right after the barrier and neither does before it (pipe busy 0.34, profiles/r05b_gemm_pmc.txt).
+// Here a group runs the 40 MFMAs of a stage while the other reads ITS 18 fragments of the same stage and issues its LDS-DMA pieces (~100
+// cycles each, during which an in-order wave issues nothing else), and the pipe is handed over at every barrier:
+//     interval 2s    : group 0  L(s)   = fragment reads, its pieces of stage s + 1      group 1  M(s-1) = 40 MFMAs
+//     interval 2s + 1: group 0  M(s)   = 40 MFMAs                                        group 1  L(s)   = fragment reads, its pieces of stage s + 2
+// one barrier per interval, THREE weight slots (stage s in slot s % 3; 2 x 50 KB halo + 3 x 20 KB = the CU's 160 KB; the weight-prefetch
+// dump aliases the second halo buffer, which nothing fills before the first barrier).  Write-after-read: slot (s + 2) % 3 held stage s - 1,
+// whose last readers (group 1, interval 2s - 1) retired their reads (lgkmcnt(0)) in front of the barrier ending that interval.  Read-after-
+// write: a wave retires its pieces (vmcnt(0)) at the end of the M part that follows their issue, i.e. in front of a barrier that precedes the
+// first read of that stage by at least one more barrier (cdna guide: read a staged buffer one phase after the wait that retires it).
+// Same accumulation order as the lock-step form: bit-identical results, 6 - 12 % faster per launch, 12 - 20 % against the tap-by-tap 128 x 320
+// tile (profiles/r05r_conv3h_pingpong.txt; in the step: r05u).
 constexpr int CH_BM = 256, CH_BN = 160, CH_NP_MAX = 50;          // output pixels, output channels, 8-pixel DMA pieces of the largest halo
 constexpr int CH_ASZ = CH_NP_MAX * 1024, CH_WSZ = CH_BN * 128;   // one halo buffer, one weight stage
-constexpr int CH_LDS = 2 * CH_ASZ + 2 * CH_WSZ;                  // 143,360 B
-// (A three-slot weight ring with counted waits -- two weight stages in flight -- measured 5 - 9 % SLOWER in the same process,
-// profiles/r03aa_halo_conv.txt: like the deep rings of the tap-by-tap kernel, look-ahead is not what the loop is short of.)
+constexpr int CH_LDS = 2 * CH_ASZ + 3 * CH_WSZ;                  // 163,840 B = 160 KB
 
+template <int ABL>                                                // ABL: profiling only (AF_GEMM3_ABLATE, compile-time): 1 no DMA in the loop, 2 fragments read once, 4 no barriers, 16 no MFMAs
 __global__ __launch_bounds__(512) void af_conv3h_kernel(const Gemm3Dev p) {
-  constexpr int NWS = 2;
   constexpr int NWM = 4, NWN = 2, TN = 5, TM = 4, NW = 8, BM = CH_BM, BN = CH_BN;
   constexpr int APW = (CH_NP_MAX + NW - 1) / NW;                 // 7 halo pieces per wave at most
   constexpr int WPW = (BN / 8 + NW - 1) / NW;                    // 3 weight pieces per wave at most (20 pieces)
@@ -1032,18 +1056,27 @@ __global__ __launch_bounds__(512) void af_conv3h_kernel(const Gemm3Dev p) {
   const int m0 = tile_m * BM;
   const int bimg = m0 / p.HoWo;
   const int y0 = (m0 - bimg * p.HoWo) / Wd;
-  const int Cin = p.c1;
+  const int Cin = p.c1 + p.c2;
   const int prow = lane >> 3, slot = lane & 7;
 
+  // ---- the chunk list: the 64-channel chunks of the (concatenated) input, nine taps (= nine stages) each; split-K slices are chunk ranges
+  const int nmain = Cin >> 6, nc1 = p.c1 >> 6;
+  const int cb = blockIdx.y * p.kt_per_split;
+  const int ce = min(nmain, cb + p.kt_per_split);
+  const int nst = (ABL & 8) ? 0 : (ce - cb) * 9;
+  struct Pos { int u, tap; };                                        // a stage = (chunk, tap)
+  auto next_pos = [&](Pos q) { return q.tap < 8 ? Pos{q.u, q.tap + 1} : Pos{q.u + 1, 0}; };
+  auto k0_of = [&](Pos q) { return q.tap * Cin + q.u * 64; };         // first weight column of the stage
+
   // ---- loaders: wave w owns halo pieces {w + 8 j} and weight pieces {w + 8 j}; lane = (pixel / row in the piece, physical chunk)
-  int a_off[APW];
+  int a_pix[APW];
 #pragma unroll
   for (int j = 0; j < APW; ++j) {
     const int hp = (wave + NW * j) * 8 + prow;
     const int hy = hp / Wh, hx = hp - hy * Wh;
     const int iy = y0 - 1 + hy, ix = hx - 1;
     const bool ok = hp < halo_px && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)Wd;
-    a_off[j] = ok ? ((bimg * p.H + iy) * Wd + ix) * Cin + (slot ^ ((hp >> 1) & 7)) * 8 : -1;
+    a_pix[j] = ok ? (((bimg * p.H + iy) * Wd + ix) << 3) | (slot ^ ((hp >> 1) & 7)) : -1;          // pixel index and the lane's logical 16-byte chunk
   }
   const half_t* wptr[WPW];
   bool wok[WPW];
@@ -1054,15 +1087,40 @@ __global__ __launch_bounds__(512) void af_conv3h_kernel(const Gemm3Dev p) {
     wok[j] = row < BN && n < p.npad;
     wptr[j] = p.wt + (size_t)(wok[j] ? n : 0) * p.kpad + (slot ^ ((row >> 1) & 7)) * 8;
   }
-  auto issue_halo_piece = [&](int j, int chunk, int buf) {
-    if (wave + NW * j < NP) glds16(a_off[j] >= 0 ? p.a1 + a_off[j] + chunk * 64 : p.zeros, af_smem + buf * CH_ASZ + (wave + NW * j) * 1024);
+  // the kernel arguments the loops' loaders use, as opaque register values: left as kernarg loads, hipcc folds `first ? p.c1 : p.c2` into a scalar
+  // load from a selected ADDRESS inside the loop, and every scalar load is waited for with lgkmcnt(0) -- i.e. behind the 18 fragment reads
+  const half_t *a1r = p.a1, *a2r = p.a2, *zr = p.zeros;
+  int c1r = p.c1, c2r = p.c2;
+  asm volatile("" : "+s"(a1r), "+s"(a2r), "+s"(zr), "+s"(c1r), "+s"(c2r));
+  auto issue_halo_piece = [&](int j, const half_t* src, int ld, int buf) {      // piece j of this wave; src = the chunk's first channel in its source
+    if (wave + NW * j < NP) {
+      const half_t* g = a_pix[j] >= 0 ? src + (size_t)(a_pix[j] >> 3) * ld + (a_pix[j] & 7) * 8 : zr;
+      glds16_nowait(g, af_smem + buf * CH_ASZ + (wave + NW * j) * 1024);
+    }
   };
-  auto issue_weights = [&](int chunk, int tap, int sl) {
-    const int k0 = tap * Cin + chunk * 64;
-    char* Ws = af_smem + 2 * CH_ASZ + sl * CH_WSZ;
+  auto chunk_src = [&](int u, const half_t*& src, int& ld) {          // workgroup-uniform: a chunk lies in one source
+    const bool first = u < nc1;
+    src = first ? a1r + u * 64 : a2r + (u - nc1) * 64;
+    ld = first ? c1r : c2r;
+  };
+  auto wslot = [&](int st) { return af_smem + 2 * CH_ASZ + (st % 3) * CH_WSZ; };
+  auto issue_w = [&](int st, Pos q) {                                // this wave's weight pieces of stage st (at position q)
+    if constexpr ((ABL & 1) != 0) return;
+    const int k0 = k0_of(q);
+    char* Ws = wslot(st);
 #pragma unroll
     for (int j = 0; j < WPW; ++j)
-      if (wave + NW * j < BN / 8) glds16(wok[j] ? wptr[j] + k0 : p.zeros, Ws + (wave + NW * j) * 1024);
+      if (wave + NW * j < BN / 8) glds16_nowait(wok[j] ? wptr[j] + k0 : zr, Ws + (wave + NW * j) * 1024);
+  };
+  auto issue_halo = [&](Pos q) {                                     // the next chunk's halo: piece j under tap j
+    if (q.u + 1 < ce && q.tap < APW && !(ABL & 1)) {
+      const half_t* src;
+      int ld;
+      chunk_src(q.u + 1, src, ld);
+#pragma unroll
+      for (int j = 0; j < APW; ++j)
+        if (q.tap == j) issue_halo_piece(j, src, ld, (q.u + 1 - cb) & 1);
+    }
   };
 
   floatx4 acc[TN][TM];
@@ -1081,92 +1139,128 @@ __global__ __launch_bounds__(512) void af_conv3h_kernel(const Gemm3Dev p) {
     hpb[tm] = r * Wh + (q0 - r * Wd) + fr;
   }
 
-  const int nchunk = Cin >> 6;
-  const int cb = blockIdx.y * p.kt_per_split;                         // split-K over chunk ranges
-  const int ce = min(nchunk, cb + p.kt_per_split);
-  const int nst = (ce - cb) * 9;
-
   if (p.wpf > 0 && p.splits == 1)
-    af_prefetch_weight_tile(p.wt, p.kpad, p.npad, tile_n * BN, BN, 0, p.kpad >> 6, p.wpf_coop, tile_m % p.wpf_coop, p.wpf, NW, wave, lane, af_smem + CH_LDS);
+    af_prefetch_weight_tile(p.wt, p.kpad, p.npad, tile_n * BN, BN, 0, p.kpad >> 6, p.wpf_coop, tile_m % p.wpf_coop, p.wpf, NW, wave, lane, af_smem + CH_ASZ);
 
+  const int grp = wave >> 2;
+  half8_t wf[TN], xf[TM], wf1[TN], xf1[TM];
+  auto read_frags = [&](int st, Pos q) {
+    if ((ABL & 2) && st > 0) return;
+    const char* As = af_smem + ((q.u - cb) & 1) * CH_ASZ;
+    const char* Ws = wslot(st);
+    const int ty = (q.tap * 11) >> 5;                                // tap / 3 for 0 .. 8 (a compare chain becomes a constant-memory table whose s_load waits on every ds_read)
+    const int toff = ty * Wh + (q.tap - ty * 3);
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) wf[tn] = *reinterpret_cast<const half8_t*>(Ws + (wn * TN * 16 + tn * 16) * 128 + rd0);
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      const int hp = hpb[tm] + toff;
+      xf[tm] = *reinterpret_cast<const half8_t*>(As + hp * 128 + (((0 * 4 + fq) ^ ((hp >> 1) & 7)) * 16));
+    }
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) wf1[tn] = *reinterpret_cast<const half8_t*>(Ws + (wn * TN * 16 + tn * 16) * 128 + rd1);
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      const int hp = hpb[tm] + toff;
+      xf1[tm] = *reinterpret_cast<const half8_t*>(As + hp * 128 + (((1 * 4 + fq) ^ ((hp >> 1) & 7)) * 16));
+    }
+  };
+  auto mfmas = [&]() {
+    if constexpr ((ABL & 16) != 0) return;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+        acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[tn], xf[tm], acc[tn][tm], 0, 0, 0);
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+        acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf1[tn], xf1[tm], acc[tn][tm], 0, 0, 0);
+  };
+  auto barrier = [&]() {
+    if constexpr ((ABL & 4) == 0) __builtin_amdgcn_s_barrier();
+  };
+
+  __builtin_amdgcn_s_setprio(1);                                     // every wave runs at priority 1 except inside its own MFMA burst: the loaders' address
+                                                                     // arithmetic is not starved by the partner's MFMA issue (profiles/r05r: 1 - 2 %)
+  Pos q0 = Pos{cb, 0}, q1 = next_pos(q0), q2 = next_pos(q1);         // positions of stages st, st + 1, st + 2
   if (nst > 0) {
+    const half_t* src;
+    int ld;
+    chunk_src(cb, src, ld);
 #pragma unroll
-    for (int j = 0; j < APW; ++j) issue_halo_piece(j, cb, 0);
-    issue_weights(cb, 0, 0);
+    for (int j = 0; j < APW; ++j) issue_halo_piece(j, src, ld, 0);
+    issue_w(0, q0);
   }
-  half8_t wf[TN], xf[TM];
-  int chunk = cb, tap = 0;
-  for (int s = 0; s < nst; ++s) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // this stage's weights (and, at tap 0, the chunk's halo) have landed
-    __builtin_amdgcn_s_barrier();                                    // ... for every wave; everyone is done with the slot / buffer refilled next
-    auto issue_next = [&]() {
-      if (chunk + 1 < ce) {                                          // next chunk's halo: piece j under tap j (APW = 7 of the nine taps)
-#pragma unroll
-        for (int j = 0; j < APW; ++j)
-          if (tap == j) issue_halo_piece(j, chunk + 1, (chunk + 1 - cb) & 1);
-      }
-      int nchunk_ = chunk, ntap = tap + (NWS - 1);
-      if (ntap >= 9) ntap -= 9, ++nchunk_;
-      if (s + NWS - 1 < nst) issue_weights(nchunk_, ntap, (s + NWS - 1) % NWS);
-    };
-    const bool late = wave >= NW / 2;                                // as in the whole-line kernel: the SIMD partners issue their DMA between the two MFMA clusters
-    if (!late) issue_next();
-    const char* As = af_smem + ((chunk - cb) & 1) * CH_ASZ;
-    const char* Ws = af_smem + 2 * CH_ASZ + (s % NWS) * CH_WSZ;
-    const int ty = tap / 3;
-    const int toff = ty * Wh + (tap - ty * 3);
-    {
-      // both K halves' fragments are requested up front (18 ds_read_b128 in flight); the first MFMA cluster waits for its nine only, the
-      // second cluster's operands arrive under it
-      half8_t wf1[TN], xf1[TM];
-#pragma unroll
-      for (int tn = 0; tn < TN; ++tn) wf[tn] = *reinterpret_cast<const half8_t*>(Ws + (wn * TN * 16 + tn * 16) * 128 + rd0);
-#pragma unroll
-      for (int tm = 0; tm < TM; ++tm) {
-        const int hp = hpb[tm] + toff;
-        xf[tm] = *reinterpret_cast<const half8_t*>(As + hp * 128 + (((0 * 4 + fq) ^ ((hp >> 1) & 7)) * 16));
-      }
-#pragma unroll
-      for (int tn = 0; tn < TN; ++tn) wf1[tn] = *reinterpret_cast<const half8_t*>(Ws + (wn * TN * 16 + tn * 16) * 128 + rd1);
-#pragma unroll
-      for (int tm = 0; tm < TM; ++tm) {
-        const int hp = hpb[tm] + toff;
-        xf1[tm] = *reinterpret_cast<const half8_t*>(As + hp * 128 + (((1 * 4 + fq) ^ ((hp >> 1) & 7)) * 16));
-      }
-      asm volatile("s_waitcnt lgkmcnt(9)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
-          acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[tn], xf[tm], acc[tn][tm], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
-      if (late) issue_next();
+  if (nst > 1) issue_w(1, q1);                                       // stage 1: every wave's pieces
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  if (grp == 0) {
+#pragma nounroll
+    for (int st = 0; st < nst; ++st) {
+      read_frags(st, q0);
+      if (st >= 1 && st + 1 < nst) issue_w(st + 1, q1);
+      issue_halo(q0);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
-          acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf1[tn], xf1[tm], acc[tn][tm], 0, 0, 0);
+      barrier();                                                     // ---- end of interval 2 st
+      __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_setprio(0);
+      mfmas();
+      __builtin_amdgcn_s_setprio(1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      barrier();                                                     // ---- end of interval 2 st + 1
+      __builtin_amdgcn_sched_barrier(0);
+      q0 = q1, q1 = next_pos(q1);
     }
-    if (++tap == 9) tap = 0, ++chunk;
+    barrier();                                                       // group 1's last interval
+  } else {
+#pragma nounroll
+    for (int st = 0; st < nst; ++st) {
+      if (st > 0) {                                                  // M(st - 1)
+        __builtin_amdgcn_s_setprio(0);
+        mfmas();
+        __builtin_amdgcn_s_setprio(1);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      barrier();                                                     // ---- end of interval 2 st
+      __builtin_amdgcn_sched_barrier(0);
+      read_frags(st, q0);
+      if (st + 2 < nst) issue_w(st + 2, q2);
+      issue_halo(q0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      barrier();                                                     // ---- end of interval 2 st + 1
+      __builtin_amdgcn_sched_barrier(0);
+      q0 = q1, q1 = q2, q2 = next_pos(q2);
+    }
+    if (nst > 0) {                                                   // M(nst - 1)
+      __builtin_amdgcn_s_setprio(0);
+      mfmas();
+      __builtin_amdgcn_s_setprio(1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    barrier();
   }
+  __builtin_amdgcn_s_setprio(0);
   gemm3_epilogue<E3_STD, NWM, NWN, TN, CH_LDS>(p, acc, af_smem, tile_m, tile_n, wm, wn, fr, fq, tid);
 }
 
 // scope of the halo-resident kernel
 static bool conv3h_eligible(const af_gemm_desc* d) {
-  if (d->taps != 9 || d->upsample || d->tap_shift || d->c2 != 0 || d->c1 % 64 != 0 || d->N % CH_BN != 0) return false;
+  if (d->taps != 9 || d->upsample || d->tap_shift || d->c1 % 64 != 0 || d->c2 % 64 != 0 || d->c3 != 0 || d->c4 != 0 || d->N % CH_BN != 0) return false;
   if ((d->stride ? d->stride : 1) != 1 || d->Ho != d->H || d->Wo != d->W) return false;
   if (d->W != 16 && d->W != 32 && d->W != 64) return false;
   if (d->H % (CH_BM / d->W) != 0 || d->M % CH_BM != 0 || d->M != d->B * d->H * d->W) return false;
   if (d->act == AF_ACT_GEGLU || d->out_mode == AF_OUT_SPLIT_T || d->ln_colsum != nullptr) return false;
-  return d->kpad == 9 * d->c1 || d->kpad % 64 == 0;
+  return d->kpad % 64 == 0;
 }
+
+static int conv3h_chunks(const af_gemm_desc* d) { return (d->c1 + d->c2) / 64; }
 
 static bool launch_conv3h(const Gemm3Dev& p0, hipStream_t stream) {
   Gemm3Dev p = p0;
@@ -1178,11 +1272,23 @@ static bool launch_conv3h(const Gemm3Dev& p0, hipStream_t stream) {
     if (p.wpf > AF_WPF_MAX) p.wpf = AF_WPF_MAX;
   }
   if (p.counters && (p.splits <= 1 || p.splits > 4 || p.tiles_m * p.tiles_n > AF_SPLITK_MAX_TILES)) p.counters = nullptr;
-  p.n_major = af_gemm_n_major(p.M, p.N, p.K, p.c1);
-  static bool attr_set = false;
-  const bool lds_ok = af_allow_dyn_lds(reinterpret_cast<const void*>(&af_conv3h_kernel), CH_LDS + AF_WPF_DUMP_BYTES, attr_set, "af_gemm");
+  p.n_major = af_gemm_n_major(p.M, p.N, p.K, p.c1 + p.c2);
   dim3 grid(p.tiles_m * p.tiles_n, p.splits), block(512);
-  if (lds_ok) hipLaunchKernelGGL(af_conv3h_kernel, grid, block, CH_LDS + AF_WPF_DUMP_BYTES, stream, p);
+#define AF_CONV3H_CASE(A)                                                                                                                     \
+  case A: {                                                                                                                                   \
+    static bool set_ = false;                                                                                                                 \
+    if (af_allow_dyn_lds(reinterpret_cast<const void*>(&af_conv3h_kernel<A>), CH_LDS, set_, "af_gemm"))                                       \
+      hipLaunchKernelGGL(af_conv3h_kernel<A>, grid, block, CH_LDS, stream, p);                                                                \
+    break;                                                                                                                                    \
+  }
+  switch (p.ablate & 31) {
+#ifdef AF_CONV3H_ABLATIONS                                         // timing experiments only (tools/probes/r05s_conv3hp_ablate.sh builds with this)
+    AF_CONV3H_CASE(1) AF_CONV3H_CASE(2) AF_CONV3H_CASE(3) AF_CONV3H_CASE(4) AF_CONV3H_CASE(7) AF_CONV3H_CASE(8) AF_CONV3H_CASE(16) AF_CONV3H_CASE(17) AF_CONV3H_CASE(18) AF_CONV3H_CASE(19)
+#endif
+    default:
+    AF_CONV3H_CASE(0)
+  }
+#undef AF_CONV3H_CASE
   return p.counters != nullptr;
 }
 
@@ -1500,7 +1606,7 @@ int af_gemm3_try_launch(const af_gemm_desc* d, int splits, int wide, hipStream_t
     p.stage_ok = ncols % 8 == 0 && p.ld_out % 8 == 0 && (reinterpret_cast<uintptr_t>(p.out) & 15) == 0;
   }
   if (wide == 11) {                                            // split-K slices are ranges of 64-channel chunks (nine taps each)
-    const int nchunk = p.c1 / 64;
+    const int nchunk = conv3h_chunks(d);
     p.splits = splits > 1 ? splits : 1;
     if (p.splits > nchunk) p.splits = nchunk;
     p.kt_per_split = (nchunk + p.splits - 1) / p.splits;
@@ -1562,7 +1668,7 @@ int af_gemm3_try_launch(const af_gemm_desc* d, int splits, int wide, hipStream_t
 }
 
 int af_gemm3_effective_splits(const af_gemm_desc* d, int splits, int wide) {
-  const int nk = (wide == 11 && conv3h_eligible(d)) ? d->c1 / 64 : d->kpad / (wide >= 4 ? 64 : BK3);
+  const int nk = (wide == 11 && conv3h_eligible(d)) ? conv3h_chunks(d) : d->kpad / (wide >= 4 ? 64 : BK3);
   int s = splits > 1 ? splits : 1;
   if (s > nk) s = nk;
   const int per = (nk + s - 1) / s;

@@ -185,6 +185,26 @@ def test_conv3x3_with_k_concatenated_1x1_skip(dev, B, H, W, cin, cs1, cs2, cout,
         ops.conv3x3(h.to(dev), pw, skip=(x1.to(dev), x2d), tile=2)
 
 
+@pytest.mark.parametrize("B,H,W,c1,c2,cout,splits", [(1, 64, 64, 320, 320, 320, 1), (2, 32, 32, 640, 320, 640, 2), (2, 16, 16, 64, 128, 160, 3), (1, 16, 16, 1280, 1280, 320, 4),
+                                                     (3, 32, 32, 64, 64, 160, 1)])
+def test_conv3x3_tile14_two_sources(dev, B, H, W, c1, c2, cout, splits):
+    """The halo-resident kernel on a channel-concatenated input (the decoder's ResBlocks: h | skip): a 64-channel chunk of the halo comes from ONE
+    of the two tensors (their own pixel strides), the weight columns stay in (tap, concatenated channel) order; split-K ranges that cut inside
+    either source; repeated launches are bit-identical (the ping-pong loop's hand-offs are ordered by barriers, not by luck)."""
+    from adaface_dev_amd import ops
+    x1, x2 = rnd((B, H, W, c1), 1), rnd((B, H, W, c2), 2)
+    w = rnd((cout, c1 + c2, 3, 3), 3, (9 * (c1 + c2)) ** -0.5)
+    bias = torch.randn(cout, generator=torch.Generator().manual_seed(4))
+    rowb, res = rnd((B, cout), 5), rnd((B, H, W, cout), 6)
+    ref = F.conv2d(torch.cat([x1, x2], -1).float().permute(0, 3, 1, 2), w.float(), bias, padding=1) + rowb.float()[:, :, None, None] + res.float().permute(0, 3, 1, 2)
+    pw = ops.pack_conv3x3(w, bias, dev)
+    run = lambda: ops.conv3x3(x1.to(dev), pw, x2=x2.to(dev), rowbias=rowb.to(dev), residual=res.to(dev), tile=14, splits=splits)
+    out = run()
+    assert rel_l2(out.float().cpu().permute(0, 3, 1, 2).numpy(), ref.numpy()) < TOL
+    for _ in range(10):
+        assert torch.equal(run(), out)
+
+
 @pytest.mark.parametrize("kind,B,H,W,cin,cout,tile", [("conv", 2, 16, 16, 128, 320, 7), ("conv", 1, 64, 64, 320, 320, 7), ("conv", 2, 32, 32, 64, 640, 7),
                                                        ("conv", 3, 16, 8, 64, 320, 11), ("gemm", 2, 16, 16, 320, 320, 7), ("gemm", 2, 32, 32, 128, 1280, 11),
                                                        ("skip", 2, 16, 16, 128, 320, 7), ("conv", 2, 16, 16, 64, 960, 7),
@@ -410,9 +430,9 @@ def test_gemm_and_conv_small_tiles_16_17(dev, tile, M, N, K, splits, ln):
 
 
 def test_conv3x3_tile14_falls_back_outside_its_scope(dev):
-    """stride 2 / two sources / widths it does not take: the descriptor's fallback (tile 1) computes the same convolution."""
+    """stride 2 / a second source that is not a multiple of 64 channels / widths it does not take: the descriptor's fallback (tile 1) computes the same convolution."""
     from adaface_dev_amd import ops
-    for (B, H, W, c1, c2, cout, stride) in ((1, 16, 16, 64, 0, 160, 2), (1, 16, 16, 64, 64, 160, 1), (1, 12, 24, 64, 0, 160, 1)):
+    for (B, H, W, c1, c2, cout, stride) in ((1, 16, 16, 64, 0, 160, 2), (1, 16, 16, 64, 32, 160, 1), (1, 12, 24, 64, 0, 160, 1)):
         x1, x2 = rnd((B, H, W, c1), 1), (rnd((B, H, W, c2), 2) if c2 else None)
         w = rnd((cout, c1 + c2, 3, 3), 3, (9 * (c1 + c2)) ** -0.5)
         xin = (x1 if x2 is None else torch.cat([x1, x2], -1)).float().permute(0, 3, 1, 2)
