@@ -56,7 +56,7 @@ def candidate_ok(d, tile, splits, _lib, ops):
         return False
     if splits > 1 and (geglu or d.out_mode == _lib.AF_OUT_SPLIT_T or nk < 4 * splits):
         return False
-    if tile == 14 and splits > d.c1 // 64:
+    if tile == 14 and splits > (d.c1 + d.c2) // 64:
         return False
     return True
 
@@ -78,6 +78,7 @@ def main():
     ap.add_argument("--trace", action="store_true", help="print every configuration before it is launched (to find one that faults)")
     ap.add_argument("--try-tile", type=int, default=0, help="for every shape this run meets that is ALREADY in the table: time the table's choice against this tile (splits 1, 2) and take the tile only where it is > 2 %% faster")
     ap.add_argument("--retune-halo", action="store_true", help="re-time only the 3x3 shapes in the scope of the halo-resident kernel (tile 14)")
+    ap.add_argument("--protect", default="", help="comma-separated logs of tools/autotune_instep.py: the shapes they decided inside a step are left alone")
     args = ap.parse_args()
     from adaface_dev_amd import SD15_UNET_CONFIG, _lib, ops, rng
     from adaface_dev_amd.ldm.modules.diffusionmodules.openaimodel import UNetModel
@@ -135,17 +136,29 @@ def main():
 
     retuned = set()
 
+    protected = set()
+    for path in filter(None, args.protect.split(",")):
+        import ast
+        for line in open(path):
+            if line.startswith("('"):
+                protected.add(ast.literal_eval(line)[0])
+
     def recorder(key, d, device):
+        if key in protected and key in table:
+            return table[key]
         if args.try_tile and key in table and key not in retuned:
             retuned.add(key)
             tl = args.try_tile
             ok = not (tl == 15 and (d.act == _lib.AF_ACT_GEGLU or d.out_mode != 0 or d.N % 128 != 0 or d.M < 16384 or d.c1 % 64 or d.c2 % 64 or d.upsample not in (0, 1)))
+            ok = ok and candidate_ok(d, tl, 1, _lib, ops)           # (outside its scope the library falls back to another tile silently)
             if ok:
                 cur = table[key]
                 t_cur = timed(d, device, cur[0], cur[1])
                 res = {f"{cur[0]}x{cur[1]}": None if t_cur is None else round(t_cur * 1e3, 1)}
                 best, best_t = cur, t_cur
-                for sp in (1, 2):
+                for sp in sorted({1, 2, cur[1], 2 * cur[1]}):
+                    if sp > 16 or not candidate_ok(d, tl, sp, _lib, ops):
+                        continue
                     if sp > 1 and d.kpad // 64 < 8:
                         continue
                     t = timed(d, device, tl, sp)
@@ -196,7 +209,7 @@ def main():
                     continue
                 if splits > 1 and (d.act == _lib.AF_ACT_GEGLU or d.out_mode == _lib.AF_OUT_SPLIT_T or nk < 4 * splits):
                     continue
-                if tile == 14 and splits > d.c1 // 64:
+                if tile == 14 and splits > (d.c1 + d.c2) // 64:
                     continue
                 if args.trace:
                     print("timing", key, tile, splits, flush=True)
