@@ -1197,45 +1197,69 @@ __global__ __launch_bounds__(512) void af_conv3h_kernel(const Gemm3Dev p) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
+  // ABL & 32 (timing experiments): waves 0 and 4 of workgroup 0 stamp s_memtime at the boundaries of their parts in stages 8 .. 15 into p.ws
+  // (s_memtime is a scalar memory read: only at points where no ds_read is pending, or its own lgkmcnt(0) would move them)
+  auto stamp = [&](int st, int slot_) {
+    if constexpr ((ABL & 32) != 0) {
+      if (blockIdx.x == 0 && blockIdx.y == 0 && (wave & 3) == 0 && st >= 8 && st < 16) {
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        if (lane == 0) reinterpret_cast<unsigned long long*>(p.ws)[((st - 8) * 2 + grp) * 8 + slot_] = t;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
   if (grp == 0) {
 #pragma nounroll
     for (int st = 0; st < nst; ++st) {
+      stamp(st, 0);
       read_frags(st, q0);
       if (st >= 1 && st + 1 < nst) issue_w(st + 1, q1);
       issue_halo(q0);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      stamp(st, 3);
       __builtin_amdgcn_sched_barrier(0);
       barrier();                                                     // ---- end of interval 2 st
       __builtin_amdgcn_sched_barrier(0);
+      stamp(st, 4);
       __builtin_amdgcn_s_setprio(0);
       mfmas();
       __builtin_amdgcn_s_setprio(1);
+      stamp(st, 5);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      stamp(st, 6);
       __builtin_amdgcn_sched_barrier(0);
       barrier();                                                     // ---- end of interval 2 st + 1
       __builtin_amdgcn_sched_barrier(0);
+      stamp(st, 7);
       q0 = q1, q1 = next_pos(q1);
     }
     barrier();                                                       // group 1's last interval
   } else {
 #pragma nounroll
     for (int st = 0; st < nst; ++st) {
+      stamp(st, 0);
       if (st > 0) {                                                  // M(st - 1)
         __builtin_amdgcn_s_setprio(0);
         mfmas();
         __builtin_amdgcn_s_setprio(1);
       }
+      stamp(st, 1);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      stamp(st, 2);
       __builtin_amdgcn_sched_barrier(0);
       barrier();                                                     // ---- end of interval 2 st
       __builtin_amdgcn_sched_barrier(0);
+      stamp(st, 3);
       read_frags(st, q0);
       if (st + 2 < nst) issue_w(st + 2, q2);
       issue_halo(q0);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      stamp(st, 6);
       __builtin_amdgcn_sched_barrier(0);
       barrier();                                                     // ---- end of interval 2 st + 1
       __builtin_amdgcn_sched_barrier(0);
+      stamp(st, 7);
       q0 = q1, q1 = q2, q2 = next_pos(q2);
     }
     if (nst > 0) {                                                   // M(nst - 1)
@@ -1281,9 +1305,9 @@ static bool launch_conv3h(const Gemm3Dev& p0, hipStream_t stream) {
       hipLaunchKernelGGL(af_conv3h_kernel<A>, grid, block, CH_LDS, stream, p);                                                                \
     break;                                                                                                                                    \
   }
-  switch (p.ablate & 31) {
+  switch (p.ablate & 63) {
 #ifdef AF_CONV3H_ABLATIONS                                         // timing experiments only (tools/probes/r05s_conv3hp_ablate.sh builds with this)
-    AF_CONV3H_CASE(1) AF_CONV3H_CASE(2) AF_CONV3H_CASE(3) AF_CONV3H_CASE(4) AF_CONV3H_CASE(7) AF_CONV3H_CASE(8) AF_CONV3H_CASE(16) AF_CONV3H_CASE(17) AF_CONV3H_CASE(18) AF_CONV3H_CASE(19)
+    AF_CONV3H_CASE(1) AF_CONV3H_CASE(2) AF_CONV3H_CASE(3) AF_CONV3H_CASE(4) AF_CONV3H_CASE(7) AF_CONV3H_CASE(8) AF_CONV3H_CASE(16) AF_CONV3H_CASE(17) AF_CONV3H_CASE(18) AF_CONV3H_CASE(19) AF_CONV3H_CASE(32)
 #endif
     default:
     AF_CONV3H_CASE(0)
