@@ -995,7 +995,8 @@ bool launch3w(const Gemm3Dev& p0, hipStream_t stream) {
 
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Halo-resident 3x3 convolution ("tile 14"): stride 1, pad 1, W in {16, 32, 64}, one or two channel-concatenated sources (no K tail:
+// Halo-resident 3x3 convolution ("tile 14"): stride 1, pad 1, output width in {16, 32, 64}, one or two channel-concatenated sources, optionally on the
+// nearest-x2 upsampled input (the halo pixel (y, x) of the 2H x 2W grid is source pixel (y >> 1, x >> 1)) (no K tail:
 // a one-stage chunk would have to bring a whole halo in under ONE stage -- measured 15 - 80 % slower than the tap-by-tap tile, r05r).
 // The tap-by-tap implicit GEMM above fetches a tile's activation rows NINE times per 64 input channels (once per tap, shifted), and with the
 // 128 x 320 tile every 64-wide K stage moves 16 KB of activations + 40 KB of weights from L2 into LDS for 0.7 us of MFMA work -- the L2 -> LDS
@@ -1051,7 +1052,7 @@ __global__ __launch_bounds__(512) void af_conv3h_kernel(const Gemm3Dev p) {
       tile_n = lid - tile_m * p.tiles_n;
     }
   }
-  const int Wd = p.W, Wh = Wd + 2, R = BM / Wd;
+  const int Wd = p.Wo, Hd = p.Ho, Wh = Wd + 2, R = BM / Wd;           // the grid the taps walk on (nearest x2 folded into the gather: Ho = 2 H, Wo = 2 W)
   const int halo_px = (R + 2) * Wh, NP = (halo_px + 7) >> 3;
   const int m0 = tile_m * BM;
   const int bimg = m0 / p.HoWo;
@@ -1075,8 +1076,9 @@ __global__ __launch_bounds__(512) void af_conv3h_kernel(const Gemm3Dev p) {
     const int hp = (wave + NW * j) * 8 + prow;
     const int hy = hp / Wh, hx = hp - hy * Wh;
     const int iy = y0 - 1 + hy, ix = hx - 1;
-    const bool ok = hp < halo_px && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)Wd;
-    a_pix[j] = ok ? (((bimg * p.H + iy) * Wd + ix) << 3) | (slot ^ ((hp >> 1) & 7)) : -1;          // pixel index and the lane's logical 16-byte chunk
+    const bool ok = hp < halo_px && (unsigned)iy < (unsigned)Hd && (unsigned)ix < (unsigned)Wd;
+    const int sy = p.upsample ? iy >> 1 : iy, sx = p.upsample ? ix >> 1 : ix;                       // source pixel of grid pixel (iy, ix)
+    a_pix[j] = ok ? (((bimg * p.H + sy) * p.W + sx) << 3) | (slot ^ ((hp >> 1) & 7)) : -1;         // pixel index and the lane's logical 16-byte chunk
   }
   const half_t* wptr[WPW];
   bool wok[WPW];
@@ -1276,10 +1278,11 @@ __global__ __launch_bounds__(512) void af_conv3h_kernel(const Gemm3Dev p) {
 
 // scope of the halo-resident kernel
 static bool conv3h_eligible(const af_gemm_desc* d) {
-  if (d->taps != 9 || d->upsample || d->tap_shift || d->c1 % 64 != 0 || d->c2 % 64 != 0 || d->c3 != 0 || d->c4 != 0 || d->N % CH_BN != 0) return false;
-  if ((d->stride ? d->stride : 1) != 1 || d->Ho != d->H || d->Wo != d->W) return false;
-  if (d->W != 16 && d->W != 32 && d->W != 64) return false;
-  if (d->H % (CH_BM / d->W) != 0 || d->M % CH_BM != 0 || d->M != d->B * d->H * d->W) return false;
+  if (d->taps != 9 || (d->upsample != 0 && d->upsample != 1) || d->tap_shift || d->c1 % 64 != 0 || d->c2 % 64 != 0 || d->c3 != 0 || d->c4 != 0 || d->N % CH_BN != 0) return false;
+  const int up = d->upsample ? 2 : 1;                              // nearest x2 folded into the halo gather
+  if ((d->stride ? d->stride : 1) != 1 || d->Ho != up * d->H || d->Wo != up * d->W) return false;
+  if (d->Wo != 16 && d->Wo != 32 && d->Wo != 64) return false;
+  if (d->Ho % (CH_BM / d->Wo) != 0 || d->M % CH_BM != 0 || d->M != d->B * d->Ho * d->Wo) return false;
   if (d->act == AF_ACT_GEGLU || d->out_mode == AF_OUT_SPLIT_T || d->ln_colsum != nullptr) return false;
   return d->kpad % 64 == 0;
 }

@@ -159,10 +159,10 @@ _tune_table = None
 def conv_halo_eligible(d) -> bool:
     """The scope of af_gemm tile 14, the halo-resident 3x3 kernel (include/adaface_hip.h); tools/autotune_gemm.py times it against the
     tap-by-tap tiles wherever this holds."""
-    return (d.taps == 9 and d.stride in (0, 1) and not d.upsample and not d.tap_shift and d.c1 % 64 == 0 and d.c2 % 64 == 0 and d.c3 == 0
-            and d.c4 == 0 and d.N % 160 == 0
-            and d.W in (16, 32, 64) and d.H % (256 // d.W) == 0 and d.Ho == d.H and d.Wo == d.W and d.act != AF_ACT_GEGLU
-            and d.out_mode == AF_OUT_NORMAL)
+    up = 2 if d.upsample else 1
+    return (d.taps == 9 and d.stride in (0, 1) and d.upsample in (0, 1) and not d.tap_shift and d.c1 % 64 == 0 and d.c2 % 64 == 0 and d.c3 == 0
+            and d.c4 == 0 and d.N % 160 == 0 and d.Wo in (16, 32, 64) and d.Ho % (256 // d.Wo) == 0 and d.Ho == up * d.H and d.Wo == up * d.W
+            and d.act != AF_ACT_GEGLU and d.out_mode == AF_OUT_NORMAL)
 
 
 _tune_recorder = None      # set by tools/autotune_gemm.py: callable(key, desc, device) -> (tile, splits)

@@ -205,6 +205,27 @@ def test_conv3x3_tile14_two_sources(dev, B, H, W, c1, c2, cout, splits):
         assert torch.equal(run(), out)
 
 
+@pytest.mark.parametrize("B,H,W,c1,c2,cout,splits", [(1, 32, 32, 640, 0, 640, 1), (2, 16, 16, 1280, 0, 320, 2), (2, 8, 8, 128, 64, 160, 3), (1, 8, 32, 64, 0, 160, 1)])
+def test_conv3x3_tile14_nearest_x2_upsample(dev, B, H, W, c1, c2, cout, splits):
+    """The halo-resident kernel on the nearest-x2 upsampled input (the U-Net's Upsample convolutions): halo pixel (y, x) of the 2H x 2W grid is source
+    pixel (y >> 1, x >> 1), out-of-grid pixels are zero -- against torch interpolate + conv2d, and bit-stable over repeated launches."""
+    from adaface_dev_amd import ops
+    x1 = rnd((B, H, W, c1), 1)
+    x2 = rnd((B, H, W, c2), 2) if c2 else None
+    w = rnd((cout, c1 + c2, 3, 3), 3, (9 * (c1 + c2)) ** -0.5)
+    bias = torch.randn(cout, generator=torch.Generator().manual_seed(4))
+    xin = (x1 if x2 is None else torch.cat([x1, x2], -1)).float().permute(0, 3, 1, 2)
+    ref = F.conv2d(F.interpolate(xin, scale_factor=2, mode="nearest"), w.float(), bias, padding=1)
+    pw = ops.pack_conv3x3(w, bias, dev)
+    run = lambda tile, sp: ops.conv3x3(x1.to(dev), pw, x2=None if x2 is None else x2.to(dev), upsample=True, tile=tile, splits=sp)
+    out = run(14, splits)
+    assert out.shape == (B, 2 * H, 2 * W, cout)
+    assert rel_l2(out.float().cpu().permute(0, 3, 1, 2).numpy(), ref.numpy()) < TOL
+    assert rel_l2(out.float().cpu().numpy(), run(8, 1).float().cpu().numpy()) < 2e-3
+    for _ in range(5):
+        assert torch.equal(run(14, splits), out)
+
+
 @pytest.mark.parametrize("kind,B,H,W,cin,cout,tile", [("conv", 2, 16, 16, 128, 320, 7), ("conv", 1, 64, 64, 320, 320, 7), ("conv", 2, 32, 32, 64, 640, 7),
                                                        ("conv", 3, 16, 8, 64, 320, 11), ("gemm", 2, 16, 16, 320, 320, 7), ("gemm", 2, 32, 32, 128, 1280, 11),
                                                        ("skip", 2, 16, 16, 128, 320, 7), ("conv", 2, 16, 16, 64, 960, 7),

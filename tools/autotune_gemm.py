@@ -29,7 +29,7 @@ def candidate_ok(d, tile, splits, _lib, ops):
     nk = d.kpad // 64
     if tile == 14 and not ops.conv_halo_eligible(d):
         return False                        # halo-resident 3x3 kernel: its split-K slices are 64-channel chunks
-    if tile >= 7 and (d.upsample not in (0, 1) or (d.upsample and tile not in (7, 8, 11, 12, 13, 15)) or d.c1 % 64 or d.c2 % 64):
+    if tile >= 7 and (d.upsample not in (0, 1) or (d.upsample and tile not in (7, 8, 11, 12, 13, 14, 15)) or d.c1 % 64 or d.c2 % 64):
         return False                        # whole-line kernel: 64-multiples of channels; nearest-x2 upsample in the non-GEGLU tiles
     if tile in (16, 17) and (geglu or d.N % (128 if tile == 16 else 64) != 0 or d.c3 or d.c4 or (d.out_mode == _lib.AF_OUT_SPLIT_T and d.taps != 1)):
         return False                        # 64 x 128 / 128 x 64, four waves, three workgroups per CU: standard epilogue, no K tail
@@ -183,7 +183,7 @@ def main():
                 continue
             if tile == 14 and not ops.conv_halo_eligible(d):
                 continue                        # halo-resident 3x3 kernel: its split-K slices are 64-channel chunks
-            if tile >= 7 and (d.upsample not in (0, 1) or (d.upsample and tile not in (7, 8, 11, 12, 13, 15)) or d.c1 % 64 or d.c2 % 64):
+            if tile >= 7 and (d.upsample not in (0, 1) or (d.upsample and tile not in (7, 8, 11, 12, 13, 14, 15)) or d.c1 % 64 or d.c2 % 64):
                 continue                        # whole-line kernel: 64-multiples of channels; nearest-x2 upsample in the non-GEGLU tiles
             if tile in (11, 13) and (geglu or d.out_mode == _lib.AF_OUT_SPLIT_T or d.N % 160 != 0):
                 continue                        # 128 x 160, four waves (11: two workgroups per CU; 13: four-slot ring)
