@@ -995,7 +995,7 @@ bool launch3w(const Gemm3Dev& p0, hipStream_t stream) {
 
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Halo-resident 3x3 convolution ("tile 14"): stride 1, pad 1, output width in {16, 32, 64}, one or two channel-concatenated sources, optionally on the
+// Halo-resident 3x3 convolution ("tile 14"): stride 1, pad 1, output width in {8, 16, 32, 64} (a tile = 256 pixels = whole rows of one image or whole images), one or two channel-concatenated sources, optionally on the
 // nearest-x2 upsampled input (the halo pixel (y, x) of the 2H x 2W grid is source pixel (y >> 1, x >> 1)) (no K tail:
 // a one-stage chunk would have to bring a whole halo in under ONE stage -- measured 15 - 80 % slower than the tap-by-tap tile, r05r).
 // The tap-by-tap implicit GEMM above fetches a tile's activation rows NINE times per 64 input channels (once per tap, shifted), and with the
@@ -1056,7 +1056,10 @@ __global__ __launch_bounds__(512) void af_conv3h_kernel(const Gemm3Dev p) {
     }
   }
   const int Wd = p.Wo, Hd = p.Ho, Wh = Wd + 2, R = BM / Wd;           // the grid the taps walk on (nearest x2 folded into the gather: Ho = 2 H, Wo = 2 W)
-  const int halo_px = (R + 2) * Wh, NP = (halo_px + 7) >> 3;
+  // A tile is R whole rows of ONE image, or -- where an image has fewer than R rows (the 8 x 8 level: R = 32) -- R / Ho whole images, each with its own
+  // halo block of (Hi + 2) x (W + 2) pixels (the tap offset ty * (W + 2) + tx stays workgroup-uniform)
+  const int Hi = min(R, Hd), nimg = R / Hi, blk_px = (Hi + 2) * Wh;
+  const int halo_px = nimg * blk_px, NP = (halo_px + 7) >> 3;
   const int m0 = tile_m * BM;
   const int bimg = m0 / p.HoWo;
   const int y0 = (m0 - bimg * p.HoWo) / Wd;
@@ -1077,11 +1080,12 @@ __global__ __launch_bounds__(512) void af_conv3h_kernel(const Gemm3Dev p) {
 #pragma unroll
   for (int j = 0; j < APW; ++j) {
     const int hp = (wave + NW * j) * 8 + prow;
-    const int hy = hp / Wh, hx = hp - hy * Wh;
+    const int im = hp / blk_px, hq = hp - im * blk_px;                                             // image of the tile, pixel of its halo block
+    const int hy = hq / Wh, hx = hq - hy * Wh;
     const int iy = y0 - 1 + hy, ix = hx - 1;
     const bool ok = hp < halo_px && (unsigned)iy < (unsigned)Hd && (unsigned)ix < (unsigned)Wd;
     const int sy = p.upsample ? iy >> 1 : iy, sx = p.upsample ? ix >> 1 : ix;                       // source pixel of grid pixel (iy, ix)
-    a_pix[j] = ok ? (((bimg * p.H + sy) * p.W + sx) << 3) | (slot ^ (hp & 7)) : -1;                // pixel index and the lane's logical 16-byte chunk
+    a_pix[j] = ok ? ((((bimg + im) * p.H + sy) * p.W + sx) << 3) | (slot ^ (hp & 7)) : -1;         // pixel index and the lane's logical 16-byte chunk
   }
   const half_t* wptr[WPW];
   bool wok[WPW];
@@ -1139,9 +1143,9 @@ __global__ __launch_bounds__(512) void af_conv3h_kernel(const Gemm3Dev p) {
   int hpb[TM];                                                       // halo pixel of this lane's row for tap (0, 0), per 16-row group
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
-    const int q0 = wm * 64 + tm * 16;
-    const int r = q0 / Wd;
-    hpb[tm] = r * Wh + (q0 - r * Wd) + fr;
+    const int q = wm * 64 + tm * 16 + fr;                            // this lane's output pixel inside the tile (16 | W except at the 8 x 8 level: per lane)
+    const int r = q / Wd, im = r / Hi;
+    hpb[tm] = im * blk_px + (r - im * Hi) * Wh + (q - r * Wd);
   }
 
   if (p.wpf > 0 && p.splits == 1)
@@ -1284,8 +1288,10 @@ static bool conv3h_eligible(const af_gemm_desc* d) {
   if (d->taps != 9 || (d->upsample != 0 && d->upsample != 1) || d->tap_shift || d->c1 % 64 != 0 || d->c2 % 64 != 0 || d->c3 != 0 || d->c4 != 0 || d->N % CH_BN != 0) return false;
   const int up = d->upsample ? 2 : 1;                              // nearest x2 folded into the halo gather
   if ((d->stride ? d->stride : 1) != 1 || d->Ho != up * d->H || d->Wo != up * d->W) return false;
-  if (d->Wo != 16 && d->Wo != 32 && d->Wo != 64) return false;
-  if (d->Ho % (CH_BM / d->Wo) != 0 || d->M % CH_BM != 0 || d->M != d->B * d->Ho * d->Wo) return false;
+  if (d->Wo != 8 && d->Wo != 16 && d->Wo != 32 && d->Wo != 64) return false;
+  const int rows = CH_BM / d->Wo;                                   // a tile: `rows` whole rows of one image, or rows / Ho whole images
+  if ((d->Ho % rows != 0 && rows % d->Ho != 0) || d->M % CH_BM != 0 || d->M != d->B * d->Ho * d->Wo) return false;
+  if (d->Ho < rows && (rows / d->Ho) * (d->Ho + 2) * (d->Wo + 2) > CH_NP_MAX * 8) return false;     // the images' halo blocks must fit one halo buffer
   if (d->act == AF_ACT_GEGLU || d->out_mode == AF_OUT_SPLIT_T || d->ln_colsum != nullptr) return false;
   return d->kpad % 64 == 0;
 }

@@ -161,8 +161,16 @@ def conv_halo_eligible(d) -> bool:
     tap-by-tap tiles wherever this holds."""
     up = 2 if d.upsample else 1
     return (d.taps == 9 and d.stride in (0, 1) and d.upsample in (0, 1) and not d.tap_shift and d.c1 % 64 == 0 and d.c2 % 64 == 0 and d.c3 == 0
-            and d.c4 == 0 and d.N % 160 == 0 and d.Wo in (16, 32, 64) and d.Ho % (256 // d.Wo) == 0 and d.Ho == up * d.H and d.Wo == up * d.W
-            and d.act != AF_ACT_GEGLU and d.out_mode == AF_OUT_NORMAL)
+            and d.c4 == 0 and d.N % 160 == 0 and d.Wo in (8, 16, 32, 64) and _halo_rows_ok(d.Ho, d.Wo) and d.M % 256 == 0 and d.Ho == up * d.H
+            and d.Wo == up * d.W and d.act != AF_ACT_GEGLU and d.out_mode == AF_OUT_NORMAL)
+
+
+def _halo_rows_ok(Ho: int, Wo: int) -> bool:
+    """A tile of the halo-resident kernel is 256 output pixels: whole rows of one image, or -- at the 8 x 8 level -- whole images whose halo blocks fit its 400-pixel buffer."""
+    rows = 256 // Wo
+    if Ho % rows == 0:
+        return True
+    return rows % Ho == 0 and (rows // Ho) * (Ho + 2) * (Wo + 2) <= 400
 
 
 _tune_recorder = None      # set by tools/autotune_gemm.py: callable(key, desc, device) -> (tile, splits)

@@ -125,7 +125,7 @@ typedef struct af_gemm_desc {
                         /* 14 = halo-resident 3x3 kernel: 256 output pixels (whole image rows) x 160 channels per workgroup; per 64 input
                            channels the rows' (R+2) x (W+2) halo is loaded into LDS once and the nine taps read it at shifted addresses
                            (stride 1, pad 1, c1 % 64 == 0, c2 % 64 == 0 -- one or two channel-concatenated sources --, no K tail, N % 160 == 0,
-                           Wo in {16, 32, 64}, Ho % (256 / Wo) == 0, upsample 0 / 1; split-K over 64-channel chunks of c1 + c2).  Main loop: ping-pong between the two
+                           Wo in {8, 16, 32, 64}, a tile = 256 / Wo whole rows of one image or whole images (the 8 x 8 level), upsample 0 / 1; split-K over 64-channel chunks of c1 + c2).  Main loop: ping-pong between the two
                            waves of a SIMD (one group issues a stage's 40 MFMAs while the other reads its fragments and issues its LDS-DMA
                            pieces; 160 KB of LDS).  Outside that scope it falls back to tile 1 */
                         /* 15 = whole-line kernel, 256 x 128 tile of eight waves (4 x 2; N % 128 == 0; standard epilogue, taps 1 / 9, nearest x2): 85 instead of

@@ -126,7 +126,8 @@ def test_conv3x3_tile3_pipelined(dev, B, H, W, c1, c2, cout, stride, splits):
 
 @pytest.mark.parametrize("B,H,W,cin,cout,splits,extras", [
     (1, 64, 64, 320, 320, 1, True), (2, 64, 64, 64, 160, 1, False), (2, 32, 32, 640, 640, 2, True), (3, 16, 16, 1280, 320, 4, True),
-    (1, 32, 32, 192, 160, 3, False), (2, 16, 16, 128, 160, 1, True), (1, 96, 64, 128, 320, 1, True), (2, 8, 32, 64, 160, 1, False)])
+    (1, 32, 32, 192, 160, 3, False), (2, 16, 16, 128, 160, 1, True), (1, 96, 64, 128, 320, 1, True), (2, 8, 32, 64, 160, 1, False),
+    (4, 8, 8, 128, 160, 1, True), (8, 8, 8, 1280, 320, 4, True), (12, 8, 8, 64, 160, 1, False)])          # the 8 x 8 level: four whole images per tile
 def test_conv3x3_tile14_halo_resident(dev, B, H, W, cin, cout, splits, extras):
     """Halo-resident 3x3 kernel (tile 14): whole image rows per workgroup, nine taps off one LDS halo per 64-channel chunk; every level's
     width (64 / 32 / 16), image borders (zero padding from the zero page), several images per launch, split-K over channel chunks (incl.
