@@ -214,12 +214,27 @@ def run_train(args, ctx, dev, stage=1):
         warnings.showwarning = show
         warnings.simplefilter("always")
         torch.cuda.set_sync_debug_mode("warn")
+    # The caching allocator hands a freed block out again only when the stream work that used it has finished; a host that runs ahead of the GPU
+    # therefore sometimes finds no free block and calls hipMalloc for a new segment inside a micro-batch (timing-dependent: 0.2 - 0.4 s in one
+    # micro-batch of a run now and then, profiles/r05ai).  Slack in the pool removes that: one large block allocated and freed here stays cached and
+    # is split on demand.  segment counts per micro-batch are reported so that a stall can be told from an allocation.
+    reserve_gb = float(os.environ.get("AF_BENCH_ALLOC_RESERVE_GB", "16"))
+    if reserve_gb > 0:
+        free_b, _ = torch.cuda.mem_get_info()
+        nbytes = int(min(reserve_gb * (1 << 30), 0.5 * free_b))
+        if nbytes > (1 << 28):
+            _slack = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            del _slack
+    seg0 = torch.cuda.memory_stats(dev).get("segment.all.allocated", 0)
     t0 = time.perf_counter()
-    host_ms = []
+    host_ms, seg_allocs = [], []
     for i in range(steps):
         th = time.perf_counter()
         losses.append(tr.training_step(batches[i % 4], warm + i, **step_kw))
         host_ms.append(round((time.perf_counter() - th) * 1e3, 1))
+        seg1 = torch.cuda.memory_stats(dev).get("segment.all.allocated", 0)
+        seg_allocs.append(int(seg1 - seg0))
+        seg0 = seg1
     if sync_debug:
         torch.cuda.set_sync_debug_mode("default")
         sync_log.close()
@@ -314,7 +329,8 @@ def run_train(args, ctx, dev, stage=1):
                           "optimizer_steps": tr.global_step, "skipped_steps": tr.skipped_steps, "loss_scale": tr.scaler.scale,
                           "last_loss": float(losses[-1]), "finite": bool(all(torch.isfinite(l) for l in losses)),
                           "per_iteration_type": per_type,
-                          "host_ms_per_micro_batch_in_timed_region": host_ms},
+                          "host_ms_per_micro_batch_in_timed_region": host_ms,
+                          "allocator_segments_per_micro_batch_in_timed_region": seg_allocs},
                "roofline": {"bound": "mfma", "achieved": round(train_tflop / (ms * 1e-3), 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                             "frac": round(train_tflop / (ms * 1e-3) / MFMA_PEAK_TFLOPS, 4), **train_traffic(stage, args),
                             "what": what},
@@ -660,7 +676,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-ffn-lora", action="store_true", help="train leg: without the U-Net's trainable FFN DoRA adapters")
     ap.add_argument("--train-steps", type=int, default=12, help="timed micro-batches of the train leg")
-    ap.add_argument("--train-warmup", type=int, default=12, help="untimed micro-batches (the hipGraph segments of every signature are captured in here)")
+    ap.add_argument("--train-warmup", type=int, default=24, help="untimed micro-batches (the hipGraph segments of every signature are captured in here: the from-noise recon variant, p = 0.4, is captured at its SECOND draw -- 12 were not always enough, profiles/r05ai)")
     ap.add_argument("--distill-only", action="store_true", help="train leg: every micro-batch a U-Net distillation iteration (rounds 1-2's leg) instead of the reference's recon / distill mix")
     ap.add_argument("--reference-pass-structure", action="store_true",
                     help="train legs: run every pass the reference runs (duplicate null-prompt pass, class-prompt pass on priming steps, SS / SR as separate "
