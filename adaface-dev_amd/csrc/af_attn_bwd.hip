@@ -205,11 +205,28 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(BwdArgs a) {
     floatx16 sT, pT;
 #pragma unroll
     for (int i = 0; i < 16; ++i) sT[i] = pT[i] = 0.f;
+    // every fragment of the group is requested before its first MFMA (round 5: hipcc otherwise issues each ds_read right in front of the MFMA that
+    // needs it and waits lgkmcnt(0) there -- one LDS round trip per MFMA in the ISA, tools/isa_seq.py)
+    // (d = 40 only: at d = 80 / 160 the extra live fragments cost the second wave per SIMD)
+    constexpr bool AHEAD = DS <= 3;
+    half8_t kfa[AHEAD ? DS : 1], vfa[AHEAD ? DS : 1], ktf[AHEAD ? DT : 1][2];
+    if constexpr (AHEAD) {
+#pragma unroll
+      for (int s = 0; s < DS; ++s) {
+        kfa[s] = *reinterpret_cast<const half8_t*>(Ks + r * RST + 16 * s + 8 * hh);
+        vfa[s] = *reinterpret_cast<const half8_t*>(Vs + r * RST + 16 * s + 8 * hh);
+      }
+#pragma unroll
+      for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) ktf[t][s2] = tr_frag(KTs, 32 * t + r, s2, hh);
+      __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int s = 0; s < DS; ++s) {
-      const half8_t kf = *reinterpret_cast<const half8_t*>(Ks + r * RST + 16 * s + 8 * hh);
+      const half8_t kf = AHEAD ? kfa[AHEAD ? s : 0] : *reinterpret_cast<const half8_t*>(Ks + r * RST + 16 * s + 8 * hh);
       sT = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], sT, 0, 0, 0);
-      const half8_t vf = *reinterpret_cast<const half8_t*>(Vs + r * RST + 16 * s + 8 * hh);
+      const half8_t vf = AHEAD ? vfa[AHEAD ? s : 0] : *reinterpret_cast<const half8_t*>(Vs + r * RST + 16 * s + 8 * hh);
       pT = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, gf[s], pT, 0, 0, 0);
     }
     half8_t zf[2];
@@ -241,7 +258,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(BwdArgs a) {
 #pragma unroll
     for (int t = 0; t < DT; ++t)
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) dq[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(tr_frag(KTs, 32 * t + r, s2, hh), zf[s2], dq[t], 0, 0, 0);
+      for (int s2 = 0; s2 < 2; ++s2) dq[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AHEAD ? ktf[AHEAD ? t : 0][s2] : tr_frag(KTs, 32 * t + r, s2, hh), zf[s2], dq[t], 0, 0, 0);
   }
   if (query < a.Nq) {
     half_t* op = a.dq + ((size_t)b * a.Nq + query) * a.lddq + hd;
@@ -340,11 +357,29 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(BwdArgs a) {
     floatx16 s, dp;
 #pragma unroll
     for (int i = 0; i < 16; ++i) s[i] = dp[i] = 0.f;
+    // fragments requested ahead of the MFMAs, as in the dQ kernel (d = 40 / 80; at d = 160 they do not fit the register file)
+    constexpr bool AHEAD = DS <= 5;
+    half8_t qaa[AHEAD ? DS : 1], gaa[AHEAD ? DS : 1], gtf[AHEAD ? DT : 1][2], qtf[AHEAD ? DT : 1][2];
+    if constexpr (AHEAD) {
+#pragma unroll
+      for (int ks = 0; ks < DS; ++ks) {
+        qaa[ks] = *reinterpret_cast<const half8_t*>(Qs + r * RST + 16 * ks + 8 * hh);
+        gaa[ks] = *reinterpret_cast<const half8_t*>(Gs + r * RST + 16 * ks + 8 * hh);
+      }
+#pragma unroll
+      for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          gtf[t][s2] = tr_frag(GTs, 32 * t + r, s2, hh);
+          qtf[t][s2] = tr_frag(QTs, 32 * t + r, s2, hh);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int ks = 0; ks < DS; ++ks) {
-      const half8_t qa = *reinterpret_cast<const half8_t*>(Qs + r * RST + 16 * ks + 8 * hh);
+      const half8_t qa = AHEAD ? qaa[AHEAD ? ks : 0] : *reinterpret_cast<const half8_t*>(Qs + r * RST + 16 * ks + 8 * hh);
       s = __builtin_amdgcn_mfma_f32_32x32x16_f16(qa, kf[ks], s, 0, 0, 0);
-      const half8_t ga = *reinterpret_cast<const half8_t*>(Gs + r * RST + 16 * ks + 8 * hh);
+      const half8_t ga = AHEAD ? gaa[AHEAD ? ks : 0] : *reinterpret_cast<const half8_t*>(Gs + r * RST + 16 * ks + 8 * hh);
       dp = __builtin_amdgcn_mfma_f32_32x32x16_f16(ga, vf[ks], dp, 0, 0, 0);
     }
     half8_t pf[2], zf[2];
@@ -381,8 +416,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(BwdArgs a) {
     for (int t = 0; t < DT; ++t)
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
-        dv[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(tr_frag(GTs, 32 * t + r, s2, hh), pf[s2], dv[t], 0, 0, 0);
-        dk[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(tr_frag(QTs, 32 * t + r, s2, hh), zf[s2], dk[t], 0, 0, 0);
+        dv[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AHEAD ? gtf[AHEAD ? t : 0][s2] : tr_frag(GTs, 32 * t + r, s2, hh), pf[s2], dv[t], 0, 0, 0);
+        dk[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AHEAD ? qtf[AHEAD ? t : 0][s2] : tr_frag(QTs, 32 * t + r, s2, hh), zf[s2], dk[t], 0, 0, 0);
       }
   }
   if (key < a.L) {
