@@ -115,6 +115,16 @@ __device__ __forceinline__ GnAcc gn_acc_from_shifted(float n, float p, float s1,
   return r;
 }
 
+// Packed-fp16 shifted difference for the statistics kernels: HALF of (x - p), formed as 0.5 x + (-0.5 p).  x - p itself overflows fp16 when an
+// outlier and the pivot have opposite signs and |x - p| > 65504 (inf -> M2 = inf - inf = NaN -> the whole group NaN; the SD fp16 VAE carries
+// activations in the 1e4 range), the halved form cannot.  Halving is exact for normal fp16 values, so 0.5 x - 0.5 p rounds to the same mantissa as
+// x - p: callers accumulate s' = sum(d), q' = sum(d^2) of the halves and scale by 2 and 4 (exact in fp32) at the end -- bit-identical to the
+// un-halved form wherever that one was finite.  nhp = -0.5 p, prepared once per pivot.
+__device__ __forceinline__ half2_t gn_half_diff(const half2_t x, const half2_t nhp) {
+  const half2_t h = {(half_t)0.5f, (half_t)0.5f};
+  return x * h + nhp;
+}
+
 // ---- weight-tile prefetch into the XCD's L2 (used by the GEMM kernels at kernel start) ---------------------------------------------------
 // Inside a denoise / training step every GEMM meets its weights cold in HBM (1.72 GB of weights are read once per U-Net pass) while
 // the operand pipelines request a K stage only ~one stage (~0.3 us) before it is needed, so the first workgroup of an XCD to touch a

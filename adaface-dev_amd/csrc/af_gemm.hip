@@ -434,7 +434,7 @@ __global__ __launch_bounds__(256, 2) void af_gemm_kernel(GemmDev p) {
 // 16 rows x 32 columns (one A fragment, two W fragments, two MFMAs per 32-deep step) and keeps D steps of fragments in flight ahead of the
 // MFMAs -- a branch-free loop pinned with sched_barrier, as xattn_colmix_mfma_kernel: the launch is one memory round trip plus K / 32 MFMA
 // pairs, not K / 64 round trips.  Workgroup = 32 x 64 outputs (4 waves).  Out-of-range rows read a clamped (valid) row and are dropped in
-// the epilogue; K is padded by the packed weight's zero columns, against which A reads its last valid chunk again (0 x finite).
+// the epilogue; K is padded by the packed weight's zero columns, against which the A fragment is zero too (clamped load, select at use).
 // Scope: taps 1, one source, standard epilogue (bias, per-batch row bias, SiLU / quick-GELU, residual, fp16 or fp32 output), K % 8 == 0,
 // 16-byte aligned rows.  Operand-swapped like af_gemm_kernel: a lane owns 4 consecutive output channels of one row.
 template <int D>
@@ -455,7 +455,11 @@ __global__ __launch_bounds__(256) void af_gemm_direct_kernel(GemmDev p) {
   half8_t xa[D], wa[D], wb[D];
   auto load = [&](int kt, int sl) {
     const int kw = min(kt, nk - 1);                          // steps past the end re-read the last one (their MFMAs do not run)
-    xa[sl] = *reinterpret_cast<const half8_t*>(arow + 8 * min(kw * 4 + fq, kc_max));
+    const int kc = kw * 4 + fq;
+    const half8_t xv = *reinterpret_cast<const half8_t*>(arow + 8 * min(kc, kc_max));
+    // chunks past K (the zero padding of the packed weight): the load is clamped to a valid address and the FRAGMENT zeroed -- against zero weights
+    // a re-read chunk holding inf / NaN would give NaN (0 x inf) where the staged tiles feed zeros (a select on a loaded value, not on the load)
+    xa[sl] = kc > kc_max ? half8_t{0, 0, 0, 0, 0, 0, 0, 0} : xv;
     wa[sl] = *reinterpret_cast<const half8_t*>(w0 + kw * 32);
     wb[sl] = *reinterpret_cast<const half8_t*>(w1 + kw * 32);
   };
@@ -514,7 +518,10 @@ __global__ __launch_bounds__(256) void af_gemm_direct_kernel(GemmDev p) {
 static bool gemm_direct_eligible(const af_gemm_desc* d, const GemmDev& p) {
   return d->taps == 1 && d->a2 == nullptr && d->c2 == 0 && d->act != AF_ACT_GEGLU && d->out_mode != AF_OUT_SPLIT_T && d->ln_colsum == nullptr &&
          d->gn_partials == nullptr && d->K % 8 == 0 && d->K >= 8 && p.lda1 % 8 == 0 && d->N % 4 == 0 && p.ld_out % 4 == 0 &&
-         (((uintptr_t)d->a1 | (uintptr_t)d->wt) & 15) == 0 && d->kpad % 64 == 0;
+         (((uintptr_t)d->a1 | (uintptr_t)d->wt) & 15) == 0 && d->kpad % 64 == 0 &&
+         // the epilogue's vector accesses: floatx4 bias loads and (fp32 output) stores, half4 row-bias / residual loads and fp16 stores
+         ((uintptr_t)d->bias & 15) == 0 && (((uintptr_t)d->rowbias | (uintptr_t)d->residual) & 7) == 0 && d->ld_rowbias % 4 == 0 &&
+         ((uintptr_t)d->out & (d->out_mode == AF_OUT_F32 ? 15 : 7)) == 0;
 }
 
 static int launch_direct(const GemmDev& p0, hipStream_t stream) {

@@ -287,15 +287,18 @@ __device__ __forceinline__ void gemm3_epilogue(const Gemm3Dev& p, floatx4 (&acc)
       if (g < ng) {
         const int hp = p.gn_cpg >> 1;
         const half_t pivot = T[(rs / SPB) * 128 * TS + g * p.gn_cpg];
-        const half2_t pivot2 = {pivot, pivot}, one2 = {(half_t)1.0f, (half_t)1.0f};
+        const half_t nhp = pivot * (half_t)-0.5f;
+        const half2_t np2 = {nhp, nhp}, one2 = {(half_t)1.0f, (half_t)1.0f};
         for (int r = rs * RPS; r < (rs + 1) * RPS; ++r) {
           const half2_t* tp = reinterpret_cast<const half2_t*>(T + r * TS + g * p.gn_cpg);
           for (int j = 0; j < hp; ++j) {
-            const half2_t d2 = tp[j] - pivot2;                      // packed fp16 + dot2 (af_norm.hip, gn_partial_kernel)
+            const half2_t d2 = gn_half_diff(tp[j], np2);            // (x - pivot) / 2 in packed fp16 + dot2 (af_common.h; af_norm.hip, gn_partial_kernel)
             s = __builtin_amdgcn_fdot2(d2, one2, s, false);
             q = __builtin_amdgcn_fdot2(d2, d2, q, false);
           }
         }
+        s *= 2.f;
+        q *= 4.f;
       }
       red[rs * 32 + g] = s;
       red[NSL * 32 + rs * 32 + g] = q;

@@ -87,6 +87,9 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(GnArgs a) {
     // PF pixels per thread in flight: the loop is pure load -> fma, so bytes in flight per CU are what sets the rate
     constexpr int PF = CT == 1 ? 4 : 2;
     const half2_t one2 = {(half_t)1.0f, (half_t)1.0f};
+    half8_t npv[CT];                                   // -0.5 pivot (PAIR)
+#pragma unroll
+    for (int j = 0; j < CT; ++j) npv[j] = pv[j] * (half_t)-0.5f;
     for (int pix = p0 + slot; pix < p1; pix += slots * PF) {
       half8_t v[PF][CT];
 #pragma unroll
@@ -104,8 +107,8 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(GnArgs a) {
           if (PAIR) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              const half2_t x2 = {v[u][j][2 * e], v[u][j][2 * e + 1]}, p2 = {pv[j][2 * e], pv[j][2 * e + 1]};
-              const half2_t d2 = x2 - p2;
+              const half2_t x2 = {v[u][j][2 * e], v[u][j][2 * e + 1]}, np2 = {npv[j][2 * e], npv[j][2 * e + 1]};
+              const half2_t d2 = gn_half_diff(x2, np2);           // (x - p) / 2: cannot overflow fp16 (af_common.h); sums rescaled below
               s[j][e] = __builtin_amdgcn_fdot2(d2, one2, s[j][e], false);
               q[j][e] = __builtin_amdgcn_fdot2(d2, d2, q[j][e], false);
             }
@@ -129,8 +132,8 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(GnArgs a) {
       if (ch < a.CP) {
 #pragma unroll
         for (int e = 0; e < NS; ++e) {
-          rs[slot * CU + ch * NS + e] = s[j][e];
-          rq[slot * CU + ch * NS + e] = q[j][e];
+          rs[slot * CU + ch * NS + e] = PAIR ? 2.f * s[j][e] : s[j][e];       // PAIR summed halves of the differences
+          rq[slot * CU + ch * NS + e] = PAIR ? 4.f * q[j][e] : q[j][e];
         }
       }
     }
@@ -332,18 +335,21 @@ __global__ __launch_bounds__(256) void gn_small_kernel(GnArgs a) {
   // not |mean| / sigma (af_common.h, GroupNorm partial statistics)
   const float pivot = (float)src[(size_t)b * a.HW * ld];
   {
-    const half2_t p2 = {(half_t)pivot, (half_t)pivot}, one2 = {(half_t)1.0f, (half_t)1.0f};    // packed fp16 + dot2, as gn_partial_kernel
+    const half_t nhp = (half_t)pivot * (half_t)-0.5f;
+    const half2_t np2 = {nhp, nhp}, one2 = {(half_t)1.0f, (half_t)1.0f};    // packed fp16 + dot2, as gn_partial_kernel
 #pragma unroll
     for (int u = 0; u < GS_IT; ++u)
       if (t + 256 * u < items) {
 #pragma unroll
         for (int e = 0; e < 8; e += 2) {
           const half2_t x2 = {v[u][e], v[u][e + 1]};
-          const half2_t d2 = x2 - p2;
+          const half2_t d2 = gn_half_diff(x2, np2);
           s = __builtin_amdgcn_fdot2(d2, one2, s, false);
           q = __builtin_amdgcn_fdot2(d2, d2, q, false);
         }
       }
+    s *= 2.f;                                           // the sums were taken over (x - p) / 2
+    q *= 4.f;
   }
   s = af_wave_sum(s);
   q = af_wave_sum(q);
@@ -429,14 +435,15 @@ __global__ __launch_bounds__(1024) void gn_pair_kernel(GnArgs a) {
   for (int u = 0; u < IT; ++u) {
     if (t + 1024 * u < items) {
       const half2_t h = *reinterpret_cast<const half2_t*>(&v[u]);
-      const half2_t p2 = {(half_t)pivot, (half_t)pivot}, one2 = {(half_t)1.0f, (half_t)1.0f};
-      const half2_t d2 = h - p2;
+      const half_t nhp = (half_t)pivot * (half_t)-0.5f;
+      const half2_t np2 = {nhp, nhp}, one2 = {(half_t)1.0f, (half_t)1.0f};
+      const half2_t d2 = gn_half_diff(h, np2);
       s = __builtin_amdgcn_fdot2(d2, one2, s, false);
       q = __builtin_amdgcn_fdot2(d2, d2, q, false);
     }
   }
-  s = af_wave_sum(s);
-  q = af_wave_sum(q);
+  s = af_wave_sum(2.f * s);                             // the sums were taken over (x - p) / 2
+  q = af_wave_sum(4.f * q);
   if (lane == 0) {
     red[0][w] = s;
     red[1][w] = q;

@@ -814,7 +814,7 @@ def _refresh_adapter_packs(lora):
     kernels read the packs at fixed addresses; modules/dora.py::DoRAConvAdapter._packs copies into the existing buffers)."""
     for bi in (lora or {}):
         for ad in lora[bi].values():
-            ad._packs()
+            ad._packs(refresh_scales=True)
 
 
 def lora_param_order(lora):

@@ -25,19 +25,29 @@ def _cached_scales(ad, base, compute):
     """The DoRA scale vectors of adapter ``ad`` on layer ``base`` depend on (W, A, B, m) only, yet every pass of a step asked for them again: a weight
     cast, a rank-192 product, a row norm and five element-wise launches per adapter and pass (tools/torch_op_census.py: ~900 launches per Stage-2
     micro-batch).  Computed once per parameter state; the buffers are REFRESHED IN PLACE when a parameter changes (as the weight packs are), so a
-    captured hipGraph that read them keeps reading the right addresses -- ``_packs`` (called before every replay) refreshes them too."""
+    captured hipGraph that read them keeps reading the right addresses -- ``_packs(refresh_scales=True)`` (called before every replay) refreshes
+    them too.  The three vectors are the rows of ONE [3, Cout] buffer.  That buffer belongs to the cache: it is rewritten whenever a parameter
+    (or the base weight -- e.g. while inference adapters are merged into it, adaface/lora.py) changes, so a forward that needs the values in its
+    backward keeps a SNAPSHOT (``snapshot_scales``: one copy launch), never the buffer itself."""
     key = tuple(ops.param_key(t) for t in (base.weight, ad.lora_A, ad.lora_B, ad.lora_magnitude_vector))
     if getattr(ad, "_scale_key", None) != key:
-        new = compute()
+        new = torch.stack(compute())
         old = getattr(ad, "_sc", None)
-        if old is not None and all(o.shape == n.shape and o.device == n.device for o, n in zip(old, new)):
-            for o, n in zip(old, new):
-                o.copy_(n)
+        if old is not None and old.shape == new.shape and old.device == new.device:
+            old.copy_(new)
         else:
             ad._sc = new
         ad._scale_key = key
         object.__setattr__(ad, "_scale_base", base)       # (a plain attribute: nn.Module.__setattr__ would register the base layer as a sub-module)
-    return ad._sc
+    return ad._sc[0], ad._sc[1], ad._sc[2]
+
+
+def snapshot_scales(ad, base):
+    """(u, v, norm) of ``ad.scales(base)`` as rows of a private copy: what a forward hands to its backward.  The cache buffer may be refreshed in
+    place between the two (a gradient-free pass with merged adapters in between changes ``base.weight``'s version twice)."""
+    ad.scales(base)
+    sc = ad._sc.clone()
+    return sc[0], sc[1], sc[2]
 
 
 class DoRAConvAdapter(nn.Module):
@@ -52,7 +62,9 @@ class DoRAConvAdapter(nn.Module):
         self.k = conv.kernel_size[0]
 
     # ---- packs (rebuilt when the parameters change: once per optimizer step)
-    def _packs(self):
+    def _packs(self, refresh_scales=False):
+        """refresh_scales: also bring the cached scale vectors up to date (the graph-replay path, where no forward code runs that would ask for
+        them).  The backward must NOT do that: between a forward and its backward the base weight may be in its merged state."""
         key = (ops.param_key(self.lora_A), ops.param_key(self.lora_B))
         if getattr(self, "_pack_key", None) != key:
             dev = self.lora_A.device
@@ -65,14 +77,14 @@ class DoRAConvAdapter(nn.Module):
                 pa_t = ops.pack_matrix(A.flatten(1).t().contiguous(), None, dev)
             new = (pa, pa_t, ops.pack_matrix(Bm, None, dev), ops.pack_matrix(Bm.t().contiguous(), None, dev))
             old = getattr(self, "_pk", None)
-            if old is not None and all(o.wt.shape == n.wt.shape and o.wt.device == n.wt.device for o, n in zip(old, new)):
+            if old is not None and all(o.wt.shape == n.wt.shape and o.wt.device == n.wt.device and not o.aliased for o, n in zip(old, new)):
                 for o, n in zip(old, new):          # same buffers, new values: captured hipGraphs keep reading these addresses
                     o.wt.copy_(n.wt)
             else:
                 self._pk = new
             self._pack_key = key
-        if getattr(self, "_scale_base", None) is not None:
-            self.scales(self._scale_base)                  # (a graph replay follows a _packs call: the scale buffers must be current too)
+        if refresh_scales and getattr(self, "_scale_base", None) is not None:
+            self.scales(self._scale_base)                  # (a graph replay follows: the scale buffers must be current too)
         return self._pk
 
     def scales(self, conv):
@@ -119,7 +131,7 @@ def dora_conv_fwd(conv, ad, x, x2=None, rowbias=None, residual=None, mask=None):
         t = ops.gemm(xd.reshape(Bn * H * W, -1), pa).reshape(Bn, H, W, -1)
     M = t.shape[0] * t.shape[1] * t.shape[2]
     lb = ops.gemm(t.reshape(M, ad.rank), pb).reshape(c2.shape)
-    u, v, norm = ad.scales(conv)
+    u, v, norm = snapshot_scales(ad, conv)              # a private copy: `saved` outlives in-place refreshes of the cache
     y = ops.dora_combine(y0, c2, lb, u, v)
     return y, (xd, c2, lb, t, mask, u, v, norm)
 
@@ -226,7 +238,7 @@ class DoRALinearAdapter(nn.Module):
         self.lora_A, self.lora_B, self.lora_magnitude_vector = nn.Parameter(a), nn.Parameter(b), nn.Parameter(m)
         self.rank, self.scaling, self.p = rank, lora_alpha / rank, lora_dropout
 
-    def _packs(self):
+    def _packs(self, refresh_scales=False):
         key = (ops.param_key(self.lora_A), ops.param_key(self.lora_B))
         if getattr(self, "_pack_key", None) != key:
             dev = self.lora_A.device
@@ -234,8 +246,8 @@ class DoRALinearAdapter(nn.Module):
             self._pk = (ops.pack_matrix(A, None, dev), ops.pack_matrix(A.t().contiguous(), None, dev), ops.pack_matrix(Bm, None, dev),
                         ops.pack_matrix(Bm.t().contiguous(), None, dev))
             self._pack_key = key
-        if getattr(self, "_scale_base", None) is not None:
-            self.scales(self._scale_base)                  # (a graph replay follows a _packs call: the scale buffers must be current too)
+        if refresh_scales and getattr(self, "_scale_base", None) is not None:
+            self.scales(self._scale_base)
         return self._pk
 
     def scales(self, linear):
@@ -268,7 +280,7 @@ class _DoRALinearFn(torch.autograd.Function):
         c2 = ops.gemm(xd, ops.PackedWeight(pw.wt, None, pw.N, pw.K, pw.kpad, pw.taps, pw.cin))
         t = ops.gemm(xd, pa)
         lb = ops.gemm(t, pb)
-        u, v, norm = ad.scales(linear)
+        u, v, norm = snapshot_scales(ad, linear)
         M, cout = c2.shape
         y = ops.dora_combine(y0.reshape(1, 1, M, cout), c2.reshape(1, 1, M, cout), lb.reshape(1, 1, M, cout), u, v).reshape(M, cout)
         ctx.linear, ctx.ad, ctx.saved = linear, ad, (xd, c2, lb, t, mask, u, v, norm)

@@ -70,17 +70,20 @@ class PackedWeight:
     ln_cs: Optional[torch.Tensor] = None   # folded LayerNorm (pack_matrix_ln): fp32 [Npad] column sums of the fp16 rows
     ln_eps: float = 0.0
     k_tail: int = 0   # pack_conv3x3_skip: plain K columns behind the nine tap blocks (the ResBlock's 1x1 shortcut inside its second convolution)
+    aliased: bool = False   # wt IS the caller's tensor (pack_matrix fast path): read-only -- in-place refresh paths must replace, never copy_ into it
 
 
 def pack_matrix(w2d: torch.Tensor, bias: Optional[torch.Tensor], device, taps: int = 1, cin: int = 0) -> PackedWeight:
     """w2d: [N, K] (any float dtype, any device) -> zero-padded fp16 [roundup(N,128), roundup(K,64)]."""
     N, K = w2d.shape
     npad, kpad = round_up(N, 128), round_up(K, 64)
-    if (npad, kpad) == (N, K) and w2d.dtype == F16 and w2d.is_contiguous() and w2d.device == torch.device(device) and not w2d.requires_grad:
+    if ((npad, kpad) == (N, K) and w2d.dtype == F16 and w2d.is_contiguous() and w2d.device == torch.device(device) and not w2d.requires_grad
+            and not isinstance(w2d, torch.nn.Parameter)):
         # already in the packed layout (an fp16 activation used as the B operand of a product: the feature-matching losses' 4096-row matrices):
-        # no zero-fill, no copy.  The pack is read-only; parameters never take this path (they are fp32 masters)
+        # no zero-fill, no copy.  The pack ALIASES the caller's tensor and is marked so (read-only: refresh-in-place code checks `aliased`);
+        # parameters never take this path, frozen fp16 ones included
         b = None if bias is None else bias.detach().to(device=device, dtype=torch.float32).contiguous()
-        return PackedWeight(w2d, b, N, K, kpad, taps, cin if cin else K)
+        return PackedWeight(w2d, b, N, K, kpad, taps, cin if cin else K, aliased=True)
     wt = torch.zeros((npad, kpad), dtype=F16, device=device)
     wt[:N, :K] = w2d.detach().to(device=device, dtype=F16)
     b = None if bias is None else bias.detach().to(device=device, dtype=torch.float32).contiguous()

@@ -257,6 +257,83 @@ def test_dora_conv_forward_backward_vs_oracle_autograd(dev, k, cin, cout, r):
     assert rel_l2(y_eval.float().cpu().permute(0, 3, 1, 2).numpy(), ref_eval.numpy()) < tol
 
 
+@pytest.mark.parametrize("k", [3, 1])
+def test_dora_saved_scales_survive_a_merged_pass_between_forward_and_backward(dev, k):
+    """The cached DoRA scale vectors are refreshed IN PLACE when the base weight changes.  A gradient-free pass with merged inference adapters
+    (adaface/lora.py::merge_unet_loras writes W' into conv.weight, runs, restores W) sits between the main pass's forward and its backward in a
+    recon step; the backward must still see the scales of ITS forward (round-5 advisor finding: with lora_B != 0 the merged weight has another
+    norm, and the backward's _packs() refreshed u / v / norm from it).  Compared with the same forward / backward with nothing in between."""
+    from adaface_dev_amd import ops, rng
+    from adaface_dev_amd.adaface.lora import dora_merged_weight
+    from adaface_dev_amd.ldm.modules.diffusionmodules.util import Conv2d, Linear
+    from adaface_dev_amd.ldm.modules.dora import DoRAConvAdapter, DoRALinearAdapter, dora_conv_bwd, dora_conv_fwd, dora_linear
+    cin, cout, r, B, H, W = 64, 64, 32, 2, 8, 8
+    conv = Conv2d(cin, cout, k, padding=k // 2)
+    with torch.no_grad():
+        conv.weight.copy_(rng.synth_input(f"ds.w{k}", conv.weight.shape, seed=81, scale=(cin * k * k) ** -0.5))
+        conv.bias.copy_(rng.synth_input(f"ds.b{k}", (cout,), seed=81, scale=0.1))
+    ad = DoRAConvAdapter(conv, rank=r, lora_alpha=16, lora_dropout=0.0)
+    with torch.no_grad():
+        ad.lora_A.copy_(rng.synth_input(f"ds.A{k}", ad.lora_A.shape, seed=81, scale=0.2))
+        ad.lora_B.copy_(rng.synth_input(f"ds.B{k}", ad.lora_B.shape, seed=81, scale=0.5))            # B != 0: ||W + s B A|| != ||W||
+        ad.lora_magnitude_vector.mul_(1.0 + 0.2 * rng.synth_input(f"ds.m{k}", (cout,), seed=81).abs())
+    conv, ad = conv.to(dev), ad.to(dev).train()
+    x = rng.synth_input(f"ds.x{k}", (B, H, W, cin), seed=81).half().to(dev)
+    cot = rng.synth_input(f"ds.cot{k}", (B, H, W, cout), seed=81).half().to(dev)
+
+    def merged_pass():
+        w0 = conv.weight.detach().clone()
+        wm = dora_merged_weight(w0.cpu(), ad.lora_A.detach().cpu(), ad.lora_B.detach().cpu(), ad.lora_magnitude_vector.detach().cpu(), 16 / r)
+        with torch.no_grad():
+            conv.weight.copy_(wm.to(dev))                       # version bump 1: merged
+            conv.hip(x)
+            ad.scales(conv)                                     # what a pass that consults the cache meanwhile would do
+            conv.weight.copy_(w0)                               # version bump 2: restored
+
+    y0, saved0 = dora_conv_fwd(conv, ad, x)
+    dx0, g0 = dora_conv_bwd(conv, ad, saved0, cot)
+    y1, saved1 = dora_conv_fwd(conv, ad, x)
+    merged_pass()
+    dx1, g1 = dora_conv_bwd(conv, ad, saved1, cot)
+    assert torch.equal(y0, y1) and torch.equal(dx0, dx1)
+    for n in g0:
+        assert torch.equal(g0[n], g1[n]), n
+    # and the cache itself is right again after the restore
+    u, v, norm = ad.scales(conv)
+    ref_norm = (conv.weight.detach().float() + (16 / r) * (ad.lora_B.detach().flatten(1) @ ad.lora_A.detach().flatten(1)).reshape(conv.weight.shape)) \
+        .flatten(1).norm(dim=1)
+    assert rel_l2(norm.cpu().numpy(), ref_norm.cpu().numpy()) < 1e-3
+
+    if k == 1:                                                  # the Linear adapter (attention DoRA) through autograd
+        lin = Linear(cin, cout)
+        with torch.no_grad():
+            lin.weight.copy_(rng.synth_input("ds.lw", lin.weight.shape, seed=82, scale=cin ** -0.5))
+        la = DoRALinearAdapter(lin, rank=r, lora_alpha=4, lora_dropout=0.0)
+        with torch.no_grad():
+            la.lora_A.copy_(rng.synth_input("ds.lA", la.lora_A.shape, seed=82, scale=0.2))
+            la.lora_B.copy_(rng.synth_input("ds.lB", la.lora_B.shape, seed=82, scale=0.5))
+        lin, la = lin.to(dev), la.to(dev).train()
+        x2 = rng.synth_input("ds.lx", (96, cin), seed=82).half().to(dev)
+        c2 = rng.synth_input("ds.lc", (96, cout), seed=82).half().to(dev)
+
+        def run(between):
+            for p in la.parameters():
+                p.grad = None
+            xr = x2.clone().requires_grad_(True)
+            y = dora_linear(lin, la, xr)
+            if between:
+                w0 = lin.weight.detach().clone()
+                with torch.no_grad():
+                    lin.weight.mul_(1.5)
+                    la.scales(lin)
+                    lin.weight.copy_(w0)
+            (y.float() * c2.float()).sum().backward()
+            return [xr.grad.clone()] + [p.grad.clone() for p in la.parameters()]
+
+        for a, b in zip(run(False), run(True)):
+            assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("rows,C", [(300, 72), (5000, 72), (24576, 320), (70000, 8)])
 def test_colsum_small_and_tall_vs_torch(dev, rows, C):
     """Column sums (bias / LayerNorm gamma / DoRA magnitude gradients): the single-workgroup-per-64-columns form and the tall

@@ -720,6 +720,51 @@ def test_groupnorm_with_group_mean_far_above_its_spread(dev, B, HW, C, path, rat
     assert rel_l2(out.float().cpu().numpy(), ref.numpy()) < TOL
 
 
+@pytest.mark.parametrize("B,HW,C,path", [
+    (2, 64, 1280, "small"), (2, 1024, 640, "pair"), (2, 4096, 320, "two-launch"), (2, 4096, 320, "producer"), (1, 1024, 640, "producer"),
+    (2, 4096, 320, "producer14"),
+])
+def test_groupnorm_with_opposite_signed_outliers_near_the_fp16_maximum(dev, B, HW, C, path):
+    """Groups that hold +6e4 and -6e4 (the SD fp16 VAE / decoder trunk carries activations in the 1e4 range): |x - pivot| reaches 1.2e5, past
+    the fp16 maximum, so a packed-fp16 `x - pivot` is inf, M2 = inf - inf = NaN and the whole group comes out NaN (round-5 advisor finding).
+    The statistics take HALF the difference, 0.5 x - 0.5 p, which cannot overflow (af_common.h gn_half_diff).  Every statistics path, against
+    torch's fp32 group_norm; the pivot (the group's first element) is one of the outliers in the odd groups."""
+    from adaface_dev_amd import ops
+    g = torch.Generator().manual_seed(13)
+    cpg = C // 32
+    x = torch.randn((B, HW, C), generator=g)
+    grp = torch.arange(C) // cpg
+    for b in range(B):
+        for gi in range(0, 32, 3):                                 # every third group: a handful of +-6e4 values
+            ch0 = gi * cpg
+            x[b, 0, ch0] = 6.0e4 if gi % 2 else -6.0e4                # the pivot itself
+            x[b, HW // 2, ch0 + 1] = -6.0e4 if gi % 2 else 6.0e4      # the opposite sign, same channel pair
+            x[b, HW - 1, ch0 + cpg - 1] = 6.0e4
+    x = x.half()
+    gam = torch.randn(C, generator=g) * 0.2 + 1
+    bet = torch.randn(C, generator=g) * 0.2
+    ref = F.group_norm(x.float().permute(0, 2, 1), 32, gam, bet, 1e-5).permute(0, 2, 1)
+    if path.startswith("producer"):
+        H = W = int(HW ** 0.5)
+        if path == "producer14":
+            w = torch.zeros(C, C, 3, 3)
+            w[torch.arange(C), torch.arange(C), 1, 1] = 1.0
+            y = ops.conv3x3(x.reshape(B, H, W, C).to(dev), ops.pack_conv3x3(w, None, dev), tile=14, gn_cpg=cpg)
+        else:
+            y = ops.gemm(x.reshape(B * HW, C).to(dev), ops.pack_matrix(torch.eye(C), None, dev), rows_per_batch=HW, tile=7 if C % 320 == 0 and C < 640 else 11, gn_cpg=cpg)
+            y4 = y.reshape(B, HW, C)
+            y4._gn_partials = y._gn_partials
+            y = y4
+        assert getattr(y, "_gn_partials", None) is not None, "the launch was expected to leave its statistics"
+        assert torch.equal(y.reshape(B, HW, C).cpu(), x), "identity weights must reproduce the input"
+        out = ops.groupnorm(y, gam.to(dev), bet.to(dev), 1e-5, False).reshape(B, HW, C)
+    else:
+        out = ops.groupnorm(x.to(dev), gam.to(dev), bet.to(dev), 1e-5, False)
+    out = out.float().cpu()
+    assert torch.isfinite(out).all(), "an overflowed statistic poisons its whole group"
+    assert rel_l2(out.numpy(), ref.numpy()) < TOL
+
+
 @pytest.mark.parametrize("rows,C", [(77, 320), (1000, 640), (513, 1280), (64, 32), (10, 2048)])
 def test_layernorm(dev, rows, C):
     from adaface_dev_amd import ops
