@@ -30,6 +30,7 @@ EXPORTS = (
     "af_layernorm_param_grads", "af_transpose_tokens_pair", "af_ff_fused", "af_xattn_fused",
     "af_softmax_rows_bwd", "af_affine_prelu_bwd", "af_maxpool2x2_bwd", "af_se_gate_grad", "af_se_residual_prelu_bwd",
     "af_groupnorm_apply", "af_gemm_gn_stats_ok", "af_gn_proj_fused",
+    "af_splitk_reduce", "af_groupnorm_splitk_ok", "af_groupnorm_splitk",
 )
 
 
@@ -48,6 +49,7 @@ class GemmDesc(C.Structure):
         ("ln_colsum", C.c_void_p), ("ln_eps", C.c_float),
         ("a3", C.c_void_p), ("a4", C.c_void_p), ("c3", C.c_int32), ("c4", C.c_int32), ("lda3", C.c_int32), ("lda4", C.c_int32),
         ("gn_partials", C.c_void_p), ("gn_cpg", C.c_int32),
+        ("defer_reduce", C.POINTER(C.c_int32)),
     ]
 
 
@@ -123,6 +125,9 @@ def lib() -> C.CDLL:
     L.af_groupnorm.argtypes = [vp, vp, i32, i32, vp, vp, vp, i32, i32, i32, f32, i32, vp, vp]
     L.af_groupnorm_apply.argtypes = [vp, i32, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp, i32, vp]
     L.af_gemm_gn_stats_ok.argtypes = [i32, i32, i32, i32, i32, i32, i32, i32]
+    L.af_splitk_reduce.argtypes = [vp, i32, vp, vp, i32, i32, vp, vp, i32, i32, vp]
+    L.af_groupnorm_splitk_ok.argtypes = [i32, i32, i32, i32]
+    L.af_groupnorm_splitk.argtypes = [vp, i32, vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp]
     L.af_gn_proj_fused.argtypes = [vp, vp, i32, vp, vp, f32, vp, vp, i32, vp, i32, i32, i32, i32, vp, vp]
     L.af_layernorm.argtypes = [vp, vp, vp, vp, i32, i32, f32, vp]
     L.af_attention.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp]

@@ -56,6 +56,10 @@ struct GemmDev {
 constexpr int BK = 64;
 enum { EPI_STD = 0, EPI_GEGLU = 1, EPI_SPLIT_T = 2 };
 
+// af_gemm_desc.defer_reduce of the call in progress (host side, per thread): where a launcher would run the separate reduce pass it stores the
+// slab count there instead
+thread_local int32_t* g_defer_reduce = nullptr;
+
 // FAST (3x3 only): both channel counts are multiples of 64 and there is no upsampling, so one 64-wide K step lies
 // inside ONE tap and ONE source for the whole workgroup: tap, channel offset and source are scalar (SGPR) values,
 // and a thread only needs a precomputed per-row centre-pixel offset and a 9-bit mask of in-bounds taps.  This
@@ -594,8 +598,12 @@ int launch(const GemmDev& p0, hipStream_t stream) {
   dim3 grid(tiles_m * p.tiles_n, p.splits), block(256);
   hipLaunchKernelGGL((af_gemm_kernel<BM, BN, TAPS, EPI, FAST>), grid, block, lds, stream, p);
   if (EPI == EPI_STD && p.splits > 1 && p.counters == nullptr) {
-    const long n = (long)p.M * (p.N >> 2);
-    hipLaunchKernelGGL(af_splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, p);
+    if (g_defer_reduce != nullptr) {
+      *g_defer_reduce = p.splits;                    // the consumer reduces the slabs (af_groupnorm_splitk / af_splitk_reduce)
+    } else {
+      const long n = (long)p.M * (p.N >> 2);
+      hipLaunchKernelGGL(af_splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, p);
+    }
   }
   return af_check_launch("af_gemm");
 }
@@ -612,6 +620,30 @@ int launch_tile(const GemmDev& p, int tile, hipStream_t stream) {
 }
 
 }  // namespace
+
+extern "C" int af_splitk_reduce(const void* slabs, int splits, const void* bias, const void* rowbias, int ld_rowbias, int rows_per_batch, const void* residual,
+                                void* out, int M, int N, void* stream) {
+  AF_REQUIRE(slabs && out && splits >= 1 && M > 0 && N > 0 && N % 4 == 0, "af_splitk_reduce: bad arguments");
+  AF_REQUIRE(rowbias == nullptr || (ld_rowbias >= N && rows_per_batch > 0), "af_splitk_reduce: rowbias needs ld_rowbias >= N and rows_per_batch > 0");
+  AF_REQUIRE((((uintptr_t)slabs | (uintptr_t)bias) & 15) == 0 && (((uintptr_t)rowbias | (uintptr_t)residual | (uintptr_t)out) & 7) == 0 && ld_rowbias % 4 == 0,
+             "af_splitk_reduce: slabs / bias must be 16-byte aligned, rowbias / residual / out 8-byte aligned");
+  GemmDev p{};
+  p.ws = const_cast<float*>((const float*)slabs);
+  p.splits = splits;
+  p.bias = (const float*)bias;
+  p.rowbias = (const half_t*)rowbias;
+  p.ld_rowbias = ld_rowbias;
+  p.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : M;
+  p.residual = (const half_t*)residual;
+  p.out = (half_t*)out;
+  p.M = M;
+  p.N = N;
+  p.ld_out = N;
+  AfLaunchScope scope(AF_FAM_GEMM, stream);
+  const long n = (long)M * (N >> 2);
+  hipLaunchKernelGGL(af_splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p);
+  return af_check_launch("af_splitk_reduce");
+}
 
 // af_gemm3.hip
 int af_gemm3_try_launch(const af_gemm_desc* d, int splits, int wide, hipStream_t stream);
@@ -644,6 +676,14 @@ extern "C" int af_gemm(const af_gemm_desc* d, void* stream) {
     AF_SUPPORTED((d->tile >= 7 && d->tile <= 13) || d->tile == 15, "af_gemm: the K tail runs on the whole-line tiles 7 .. 13 and 15 only");
   }
   AF_REQUIRE(d->K == d->taps * (d->c1 + d->c2) + d->c3 + d->c4, "af_gemm: K != taps*(c1+c2) (+ c3 + c4)");
+  g_defer_reduce = nullptr;
+  if (d->defer_reduce != nullptr) {
+    AF_REQUIRE(d->act == AF_ACT_NONE && d->out_mode == AF_OUT_NORMAL && (d->ld_out == 0 || d->ld_out == d->N) && !d->splitk_fused,
+               "af_gemm: defer_reduce needs the standard epilogue without activation, a dense fp16 output and the two-launch split-K form");
+    *d->defer_reduce = 0;
+    g_defer_reduce = d->defer_reduce;
+  }
+  struct DeferScope { ~DeferScope() { g_defer_reduce = nullptr; } } defer_scope;
   const bool gnp = d->gn_partials != nullptr;
   if (gnp) {
     const int rpb = d->rows_per_batch > 0 ? d->rows_per_batch : d->M;
@@ -753,6 +793,10 @@ extern "C" int af_gemm(const af_gemm_desc* d, void* stream) {
     const int rc3 = (p.out_f32 && eff < 2) ? 1 : af_gemm3_try_launch(d, p.splits, tile - 3, s);
     if (rc3 == 0) return af_check_launch("af_gemm(tile 3)");
     if (rc3 == 2) {
+      if (g_defer_reduce != nullptr) {
+        *g_defer_reduce = eff;
+        return af_check_launch("af_gemm(tile 3, split-K, reduce deferred)");
+      }
       p.splits = eff;
       p.ld_out = d->ld_out ? d->ld_out : d->N;
       const long n = (long)p.M * (p.N >> 2);

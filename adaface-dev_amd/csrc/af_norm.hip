@@ -34,6 +34,17 @@ struct GnArgs {
   float* stats;  // optional out [B][groups][2] = (mean, rstd)
   int ppb;    // pixel slots per iteration (CT == 1)
   int nblk;   // partial blocks per batch item in this launch
+  // split-K producer folded in (af_groupnorm_splitk; the SLAB instantiations of the one-launch kernels): x1 is not read.  The value at (row, c) is
+  // fp16(sum_sp slab[sp][row][c] + bias[c] + rowbias[b][c] + residual[row][c]) -- af_splitk_reduce_kernel's arithmetic in its order -- stored to
+  // xout and normalised.  Slabs are [splits][B * HW][C] fp32, slab_stride = B * HW * C.
+  const float* slab;
+  size_t slab_stride;
+  int splits;
+  const float* bias;
+  const half_t* rowbias;
+  int ld_rowbias;
+  const half_t* residual;
+  half_t* xout;
 };
 
 __device__ __forceinline__ half8_t gn_load(const GnArgs& a, int b, int pix, int c0) {
@@ -302,7 +313,10 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnArgs a) {
 // (cpg % 8 == 0: C = 1280 / 2560) that lie in ONE of the two sources, and HW * cpg / 8 <= 256 * GS_IT chunks.
 constexpr int GS_IT = 10;
 
+// SLAB instantiations: IT = items per thread the launch needs (2 at the 8 x 8 level, 5 at 16 x 16, at most GS_IT), UNR = slabs requested together
+template <bool SLAB, int IT = GS_IT, int UNR = 1>
 __global__ __launch_bounds__(256) void gn_small_kernel(GnArgs a) {
+  constexpr int GS_IT = IT;                           // (shadows the file-level bound inside this kernel)
   __shared__ float red[2][4];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int g = blockIdx.x, b = blockIdx.y;
@@ -317,7 +331,7 @@ __global__ __launch_bounds__(256) void gn_small_kernel(GnArgs a) {
   // integer division costs ~25 VALU instructions, as much as the arithmetic of a whole 8-element chunk
   const int pix0 = t / cpb, ch0 = t - pix0 * cpb;
   const int dq = 256 / cpb, dr = 256 - dq * cpb;
-  {
+  if constexpr (!SLAB) {
     int pix = pix0, ch = ch0;
 #pragma unroll
     for (int u = 0; u < GS_IT; ++u) {
@@ -330,10 +344,100 @@ __global__ __launch_bounds__(256) void gn_small_kernel(GnArgs a) {
       ch += dr;
       if (ch >= cpb) ch -= cpb, ++pix;
     }
+  } else {
+    // the producer's split-K slabs: every item's two float4 of a slab are requested before any is used (a slab is one memory round trip for the
+    // whole thread, not one per item), slabs are added in slice order starting from 0 (0 + s0 == s0), then bias, row bias, residual -- exactly
+    // af_splitk_reduce_kernel -- and the fp16 value is stored (the convolution's output) and kept for the statistics
+    size_t off[GS_IT];
+    floatx4 lo[GS_IT], hi[GS_IT];
+    {
+      int pix = pix0, ch = ch0;
+#pragma unroll
+      for (int u = 0; u < GS_IT; ++u) {
+        off[u] = t + 256 * u < items ? ((size_t)b * a.HW + pix) * a.C + c0 + ch * 8 : (size_t)b * a.HW * a.C + c0;   // out of range: the group's first chunk (loaded, dropped)
+        lo[u] = hi[u] = floatx4{0.f, 0.f, 0.f, 0.f};
+        pix += dq;
+        ch += dr;
+        if (ch >= cpb) ch -= cpb, ++pix;
+      }
+    }
+    // UNR slabs are requested together (one memory round trip per UNR slabs, not per slab: at the 8 x 8 level a launch has 12 - 16 of them) and
+    // added in slice order; out-of-range items read item 0's address (always valid) and are dropped below
+    int sp = 0;
+    for (; sp + UNR <= a.splits; sp += UNR) {
+      floatx4 l0[UNR][GS_IT], l1[UNR][GS_IT];
+#pragma unroll
+      for (int k = 0; k < UNR; ++k) {
+        const float* sl = a.slab + (size_t)(sp + k) * a.slab_stride;
+#pragma unroll
+        for (int u = 0; u < GS_IT; ++u) {
+          l0[k][u] = *reinterpret_cast<const floatx4*>(sl + off[u]);
+          l1[k][u] = *reinterpret_cast<const floatx4*>(sl + off[u] + 4);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < UNR; ++k)
+#pragma unroll
+        for (int u = 0; u < GS_IT; ++u) {
+          lo[u] += l0[k][u];
+          hi[u] += l1[k][u];
+        }
+    }
+    for (; sp < a.splits; ++sp) {
+      const float* sl = a.slab + (size_t)sp * a.slab_stride;
+      floatx4 l0[GS_IT], l1[GS_IT];
+#pragma unroll
+      for (int u = 0; u < GS_IT; ++u) {
+        l0[u] = *reinterpret_cast<const floatx4*>(sl + off[u]);
+        l1[u] = *reinterpret_cast<const floatx4*>(sl + off[u] + 4);
+      }
+#pragma unroll
+      for (int u = 0; u < GS_IT; ++u) {
+        lo[u] += l0[u];
+        hi[u] += l1[u];
+      }
+    }
+    int ch = ch0;
+#pragma unroll
+    for (int u = 0; u < GS_IT; ++u) {
+      if (t + 256 * u < items) {
+        const int c = c0 + ch * 8;
+        if (a.bias) {
+          lo[u] += *reinterpret_cast<const floatx4*>(a.bias + c);
+          hi[u] += *reinterpret_cast<const floatx4*>(a.bias + c + 4);
+        }
+        if (a.rowbias) {
+          const half8_t rv = *reinterpret_cast<const half8_t*>(a.rowbias + (size_t)b * a.ld_rowbias + c);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) lo[u][e] += (float)rv[e], hi[u][e] += (float)rv[e + 4];
+        }
+        if (a.residual) {
+          const half8_t rv = *reinterpret_cast<const half8_t*>(a.residual + off[u]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) lo[u][e] += (float)rv[e], hi[u][e] += (float)rv[e + 4];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[u][e] = (half_t)lo[u][e], v[u][e + 4] = (half_t)hi[u][e];
+        *reinterpret_cast<half8_t*>(a.xout + off[u]) = v[u];
+      } else {
+        v[u] = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+      }
+      ch += dr;
+      if (ch >= cpb) ch -= cpb;
+    }
   }
   // sums shifted by a pivot (the group's first element, the same for every thread): q / n - (s / n)^2 then cancels only |pivot - mean| / sigma,
   // not |mean| / sigma (af_common.h, GroupNorm partial statistics)
-  const float pivot = (float)src[(size_t)b * a.HW * ld];
+  float pivot;
+  if constexpr (SLAB) {
+    // the group's first element of this batch item is item 0's first channel: thread 0 holds it
+    if (t == 0) red[0][0] = (float)v[0][0];
+    __syncthreads();
+    pivot = red[0][0];
+    __syncthreads();
+  } else {
+    pivot = (float)src[(size_t)b * a.HW * ld];
+  }
   {
     const half_t nhp = (half_t)pivot * (half_t)-0.5f;
     const half2_t np2 = {nhp, nhp}, one2 = {(half_t)1.0f, (half_t)1.0f};    // packed fp16 + dot2, as gn_partial_kernel
@@ -396,7 +500,7 @@ __global__ __launch_bounds__(256) void gn_small_kernel(GnArgs a) {
 // 128-byte line that the neighbouring groups' workgroups read too, so all 32 groups of a batch item are mapped to ONE XCD
 // (bid % 8 picks the batch item's XCD) and share those lines in its L2 instead of each XCD fetching them again.
 
-template <int IT>
+template <int IT, bool SLAB>
 __global__ __launch_bounds__(1024) void gn_pair_kernel(GnArgs a) {
   __shared__ float red[2][16];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
@@ -412,7 +516,8 @@ __global__ __launch_bounds__(1024) void gn_pair_kernel(GnArgs a) {
   // (pixel, pair) of item t + 1024 u by steps of divmod(1024, ppp): one integer division per thread instead of one per item and phase
   const int pix0 = t / ppp, pr0 = t - pix0 * ppp;
   const int dq = 1024 / ppp, dr = 1024 - dq * ppp;
-  {
+  float pivot;
+  if constexpr (!SLAB) {
     int pix = pix0, pr = pr0;
 #pragma unroll
     for (int u = 0; u < IT; ++u) {
@@ -428,9 +533,78 @@ __global__ __launch_bounds__(1024) void gn_pair_kernel(GnArgs a) {
       pr += dr;
       if (pr >= ppp) pr -= ppp, ++pix;
     }
+    // shifted sums, as gn_small_kernel: the pivot is the group's first element of this batch item
+    pivot = c0 < a.c1 ? (float)a.x1[(size_t)b * a.HW * a.c1 + c0] : (float)a.x2[(size_t)b * a.HW * a.c2 + (c0 - a.c1)];
+  } else {
+    // the producer's split-K slabs at 8-byte granularity (gn_small_kernel<true> has the scheme): all items of a slab in flight together,
+    // slice order, then bias / row bias / residual, the fp16 pair stored and kept
+    typedef float floatx2 __attribute__((ext_vector_type(2)));
+    size_t off[IT];
+    floatx2 acc[IT];
+    {
+      int pix = pix0, pr = pr0;
+#pragma unroll
+      for (int u = 0; u < IT; ++u) {
+        off[u] = t + 1024 * u < items ? ((size_t)b * a.HW + pix) * a.C + c0 + 2 * pr : (size_t)b * a.HW * a.C + c0;   // out of range: the group's first pair (loaded, dropped)
+        acc[u] = floatx2{0.f, 0.f};
+        pix += dq;
+        pr += dr;
+        if (pr >= ppp) pr -= ppp, ++pix;
+      }
+    }
+    int sp = 0;
+    constexpr int UNR = IT > 8 ? 1 : 2;                 // slabs per memory round trip (1024 threads: 128 registers each), added in slice order
+    for (; UNR > 1 && sp + UNR <= a.splits; sp += UNR) {
+      const float* sl = a.slab + (size_t)sp * a.slab_stride;
+      floatx2 l[UNR][IT];
+#pragma unroll
+      for (int k = 0; k < UNR; ++k)
+#pragma unroll
+        for (int u = 0; u < IT; ++u) l[k][u] = *reinterpret_cast<const floatx2*>(sl + (size_t)k * a.slab_stride + off[u]);
+#pragma unroll
+      for (int k = 0; k < UNR; ++k)
+#pragma unroll
+        for (int u = 0; u < IT; ++u) acc[u] += l[k][u];
+    }
+    for (; sp < a.splits; ++sp) {
+      const float* sl = a.slab + (size_t)sp * a.slab_stride;
+      floatx2 l[IT];
+#pragma unroll
+      for (int u = 0; u < IT; ++u) l[u] = *reinterpret_cast<const floatx2*>(sl + off[u]);
+#pragma unroll
+      for (int u = 0; u < IT; ++u) acc[u] += l[u];
+    }
+    int pr = pr0;
+#pragma unroll
+    for (int u = 0; u < IT; ++u) {
+      unsigned int x = 0;
+      if (t + 1024 * u < items) {
+        const int c = c0 + 2 * pr;
+        if (a.bias) acc[u] += *reinterpret_cast<const floatx2*>(a.bias + c);
+        if (a.rowbias) {
+          const half2_t rv = *reinterpret_cast<const half2_t*>(a.rowbias + (size_t)b * a.ld_rowbias + c);
+          acc[u][0] += (float)rv[0], acc[u][1] += (float)rv[1];
+        }
+        if (a.residual) {
+          const half2_t rv = *reinterpret_cast<const half2_t*>(a.residual + off[u]);
+          acc[u][0] += (float)rv[0], acc[u][1] += (float)rv[1];
+        }
+        const half2_t h = {(half_t)acc[u][0], (half_t)acc[u][1]};
+        x = *reinterpret_cast<const unsigned int*>(&h);
+        *reinterpret_cast<unsigned int*>(a.xout + off[u]) = x;
+      }
+      v[u] = x;
+      pr += dr;
+      if (pr >= ppp) pr -= ppp;
+    }
+    if (t == 0) {
+      const half2_t h = *reinterpret_cast<const half2_t*>(&v[0]);
+      red[0][0] = (float)h[0];
+    }
+    __syncthreads();
+    pivot = red[0][0];
+    __syncthreads();
   }
-  // shifted sums, as gn_small_kernel: the pivot is the group's first element of this batch item
-  const float pivot = c0 < a.c1 ? (float)a.x1[(size_t)b * a.HW * a.c1 + c0] : (float)a.x2[(size_t)b * a.HW * a.c2 + (c0 - a.c1)];
 #pragma unroll
   for (int u = 0; u < IT; ++u) {
     if (t + 1024 * u < items) {
@@ -589,7 +763,7 @@ extern "C" int af_groupnorm_stats(const void* x1, const void* x2, int c1, int c2
   // small tensors: one launch, one workgroup per (batch item, group)
   static const bool no_small = getenv("AF_GN_NO_SMALL") != nullptr;      // A/B switch
   if (!no_small && a.cpg % 8 == 0 && (c2 == 0 || c1 % a.cpg == 0) && (long)HW * (a.cpg / 8) <= 256L * GS_IT) {
-    hipLaunchKernelGGL(gn_small_kernel, dim3(groups, B), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(gn_small_kernel<false>, dim3(groups, B), dim3(256), 0, s, a);
     return af_check_launch("af_groupnorm(small)");
   }
   static const bool no_pair = getenv("AF_GN_NO_PAIR") != nullptr;        // A/B switch
@@ -598,9 +772,9 @@ extern "C" int af_groupnorm_stats(const void* x1, const void* x2, int c1, int c2
     const int b8 = (B + 7) / 8 * 8;
     const long nu = ((long)HW * (a.cpg / 2) + 1023) / 1024;
     dim3 gp(b8 * groups), bp(1024);
-    if (nu <= 4) hipLaunchKernelGGL(gn_pair_kernel<4>, gp, bp, 0, s, a);
-    else if (nu <= 8) hipLaunchKernelGGL(gn_pair_kernel<8>, gp, bp, 0, s, a);
-    else hipLaunchKernelGGL(gn_pair_kernel<12>, gp, bp, 0, s, a);
+    if (nu <= 4) hipLaunchKernelGGL((gn_pair_kernel<4, false>), gp, bp, 0, s, a);
+    else if (nu <= 8) hipLaunchKernelGGL((gn_pair_kernel<8, false>), gp, bp, 0, s, a);
+    else hipLaunchKernelGGL((gn_pair_kernel<12, false>), gp, bp, 0, s, a);
     return af_check_launch("af_groupnorm(pair)");
   }
   // enough workgroups to keep >= 4 per CU streaming (B * nblk >= 1024 when the tensor is large enough), each thread with
@@ -626,6 +800,69 @@ extern "C" int af_groupnorm_stats(const void* x1, const void* x2, int c1, int c2
     return af_fail(AF_E_UNSUPPORTED, "af_groupnorm: C > 4096");
   }
   return af_check_launch("af_groupnorm");
+}
+
+// scope of the slab-fed one-launch forms: 1 = gn_small_kernel (16-byte chunks), 2 = gn_pair_kernel (4-byte pairs), 0 = neither
+static int gn_splitk_form(int HW, int C, int groups) {
+  if (groups <= 0 || groups > GN_MAXG || C % groups != 0 || C % 8 != 0 || C > 4096 || HW <= 0) return 0;
+  const int cpg = C / groups;
+  if (cpg % 8 == 0 && (long)HW * (cpg / 8) <= 256L * GS_IT) return 1;
+  if (cpg % 2 == 0 && (long)HW * (cpg / 2) <= 1024L * 12) return 2;
+  return 0;
+}
+
+extern "C" int af_groupnorm_splitk_ok(int B, int HW, int C, int groups) { return B > 0 && gn_splitk_form(HW, C, groups) != 0 ? 1 : 0; }
+
+extern "C" int af_groupnorm_splitk(const void* slabs, int splits, const void* bias, const void* rowbias, int ld_rowbias, const void* residual, void* x_out,
+                                   int C, const void* gamma, const void* beta, void* y, void* stats, int B, int HW, int groups, float eps, int silu,
+                                   void* stream) {
+  AF_REQUIRE(slabs && x_out && gamma && beta && y, "af_groupnorm_splitk: null pointer");
+  AF_REQUIRE(splits >= 1 && B > 0 && HW > 0 && C > 0, "af_groupnorm_splitk: bad sizes");
+  AF_REQUIRE((((uintptr_t)slabs | (uintptr_t)bias | (uintptr_t)rowbias | (uintptr_t)residual | (uintptr_t)x_out | (uintptr_t)y | (uintptr_t)gamma |
+               (uintptr_t)beta) & 15) == 0 && (rowbias == nullptr || (ld_rowbias >= C && ld_rowbias % 8 == 0)),
+             "af_groupnorm_splitk: every pointer must be 16-byte aligned and ld_rowbias a multiple of 8 that covers C");
+  const int form = gn_splitk_form(HW, C, groups);
+  AF_SUPPORTED(form != 0, "af_groupnorm_splitk: outside the one-launch forms' scope (af_groupnorm_splitk_ok)");
+  GnArgs a{};
+  a.x1 = (const half_t*)x_out;                       // never read: the SLAB kernels take their values from the slabs
+  a.c1 = C;
+  a.C = C;
+  a.CP = C / 8;
+  a.gamma = (const float*)gamma;
+  a.beta = (const float*)beta;
+  a.y = (half_t*)y;
+  a.B = B;
+  a.HW = HW;
+  a.groups = groups;
+  a.cpg = C / groups;
+  a.eps = eps;
+  a.silu = silu;
+  a.stats = (float*)stats;
+  a.slab = (const float*)slabs;
+  a.slab_stride = (size_t)B * HW * C;
+  a.splits = splits;
+  a.bias = (const float*)bias;
+  a.rowbias = (const half_t*)rowbias;
+  a.ld_rowbias = ld_rowbias;
+  a.residual = (const half_t*)residual;
+  a.xout = (half_t*)x_out;
+  hipStream_t s = (hipStream_t)stream;
+  AfLaunchScope scope(AF_FAM_GNORM, stream);
+  if (form == 1) {
+    const long nu = ((long)HW * (a.cpg / 8) + 255) / 256;       // items per thread
+    const dim3 g(groups, B), blk(256);
+    if (nu <= 2) hipLaunchKernelGGL((gn_small_kernel<true, 2, 8>), g, blk, 0, s, a);
+    else if (nu <= 5) hipLaunchKernelGGL((gn_small_kernel<true, 5, 4>), g, blk, 0, s, a);
+    else hipLaunchKernelGGL((gn_small_kernel<true, GS_IT, 2>), g, blk, 0, s, a);
+    return af_check_launch("af_groupnorm_splitk(small)");
+  }
+  const int b8 = (B + 7) / 8 * 8;
+  const long nu = ((long)HW * (a.cpg / 2) + 1023) / 1024;
+  dim3 gp(b8 * groups), bp(1024);
+  if (nu <= 4) hipLaunchKernelGGL((gn_pair_kernel<4, true>), gp, bp, 0, s, a);
+  else if (nu <= 8) hipLaunchKernelGGL((gn_pair_kernel<8, true>), gp, bp, 0, s, a);
+  else hipLaunchKernelGGL((gn_pair_kernel<12, true>), gp, bp, 0, s, a);
+  return af_check_launch("af_groupnorm_splitk(pair)");
 }
 
 extern "C" int af_groupnorm_apply(const void* x, int C, const void* gamma, const void* beta, void* y, void* stats, int B, int HW, int groups,

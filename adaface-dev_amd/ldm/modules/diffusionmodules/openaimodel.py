@@ -54,8 +54,13 @@ class EmbPack:
 
 class TimestepEmbedSequential(nn.Sequential, TimestepBlock):
     def hip(self, x, emb, context=None, mask=None):
-        for layer in self:
-            if isinstance(layer, TimestepBlock):
+        n = len(self)
+        for i, layer in enumerate(self):
+            if isinstance(layer, ResBlock):
+                # a ResBlock followed by a SpatialTransformer: the transformer's first launch is its GroupNorm on the block's output, so a split-K
+                # second convolution may leave its reduce pass to it (ops.PendingReduce)
+                x = layer.hip(x, emb, defer_out=i + 1 < n and isinstance(self[i + 1], SpatialTransformer))
+            elif isinstance(layer, TimestepBlock):
                 x = layer.hip(x, emb)
             elif isinstance(layer, SpatialTransformer):
                 x = layer.hip(x, context, mask)
@@ -182,8 +187,9 @@ class ResBlock(TimestepBlock):
             self.skip_connection = conv_nd(dims, channels, self.out_channels, 1)
         self._emb_slice = None  # (offset, width) into EmbPack.all_out, assigned by UNetModel
 
-    def hip(self, x, emb):
-        """x: [B,H,W,C] fp16 or SkipCat((h, skip)); emb: EmbPack or fp16 [B, emb_ch] (raw emb)."""
+    def hip(self, x, emb, defer_out=False):
+        """x: [B,H,W,C] fp16 or SkipCat((h, skip)); emb: EmbPack or fp16 [B, emb_ch] (raw emb).  defer_out: the caller's next launch is a
+        GroupNorm on the returned tensor (TimestepEmbedSequential.hip: a SpatialTransformer follows)."""
         x1, x2 = (x[0], x[1]) if isinstance(x, SkipCat) else (x, None)
         if isinstance(emb, EmbPack) and emb.all_out is not None and self._emb_slice is not None:
             off, width = self._emb_slice
@@ -194,15 +200,16 @@ class ResBlock(TimestepBlock):
         h = self.in_layers[0].hip(x1, silu=True, x2=x2)
         # both convolutions feed a GroupNorm(32) (this block's second norm; the next block's first norm, a transformer's norm or the output
         # norm): they leave the partial statistics of what they store (Conv2d.hip gn_groups)
-        h = self.in_layers[2].hip(h, rowbias=e, gn_groups=32)
+        # ... and when the launch is split-K, the GroupNorm right behind it absorbs the reduce pass (defer_gn: ops.PendingReduce)
+        h = self.in_layers[2].hip(h, rowbias=e, gn_groups=32, defer_gn=True)
         h = self.out_layers[0].hip(h, silu=True)
         if isinstance(self.skip_connection, nn.Identity):
             skip = x1 if x2 is None else torch.cat([x1, x2], dim=-1)
         elif self._skip_fusable(x1, x2):
-            return ops.conv3x3(h, self._packed_conv2_skip(), skip=(x1, x2), gn_cpg=self.out_channels // 32)
+            return ops.conv3x3(h, self._packed_conv2_skip(), skip=(x1, x2), gn_cpg=self.out_channels // 32, defer_gn=defer_out)
         else:
             skip = self.skip_connection.hip(x1, x2=x2)
-        return self.out_layers[3].hip(h, residual=skip, gn_groups=32)
+        return self.out_layers[3].hip(h, residual=skip, gn_groups=32, defer_gn=defer_out)
 
     # ---- out_layers convolution + channel-changing 1x1 skip_connection as ONE K-concatenated implicit GEMM (ops.pack_conv3x3_skip): the block's
     # `skip_connection(x) + h` (openaimodel.py:256-276) costs no launch, no [B,H,W,Cout] round trip and no residual read of its own
@@ -241,7 +248,7 @@ class ResBlock(TimestepBlock):
             ad = lora["conv1"]
             h1, s1 = dora_conv_fwd(self.in_layers[2], ad, a, rowbias=self._emb_out(emb), mask=ad.draw_mask(a.shape, a.device))
         else:
-            h1 = self.in_layers[2].hip(a, rowbias=self._emb_out(emb), gn_groups=32)
+            h1 = self.in_layers[2].hip(a, rowbias=self._emb_out(emb), gn_groups=32, defer_gn=True)    # the GroupNorm below is its next launch
         b, st2 = self.out_layers[0].hip_train(h1, silu=True)
         fuse = "conv2" not in lora and "conv_shortcut" not in lora and not isinstance(self.skip_connection, nn.Identity) and self._skip_fusable(x1, x2)
         if fuse:

@@ -96,13 +96,16 @@ class Conv2d(nn.Conv2d):
 
         return self._cache.get((self.weight, self.bias), build)
 
-    def hip(self, x, x2=None, upsample=False, rowbias=None, residual=None, gn_groups=0):
+    def hip(self, x, x2=None, upsample=False, rowbias=None, residual=None, gn_groups=0, defer_gn=False):
         """x [B,H,W,C1] (+x2 [B,H,W,C2]) fp16 -> [B,Ho,Wo,Cout] fp16.  gn_groups > 0: the output feeds a GroupNorm of that many groups -- where
-        the launch can, it leaves the partial statistics with the tensor (ops.GnPartials) and the GroupNorm skips its statistics pass."""
+        the launch can, it leaves the partial statistics with the tensor (ops.GnPartials) and the GroupNorm skips its statistics pass.
+        defer_gn (3x3 only): the caller's NEXT launch is that GroupNorm on the returned tensor -- a split-K launch then leaves its reduce pass to
+        it (ops.PendingReduce: the tensor is not written until then)."""
         pw = self.packed()
         cpg = self.out_channels // gn_groups if gn_groups and self.out_channels % gn_groups == 0 else 0
         if self.kernel_size == (3, 3):
-            return ops.conv3x3(x, pw, x2=x2, stride=self.stride[0], upsample=upsample, rowbias=rowbias, residual=residual, gn_cpg=cpg)
+            return ops.conv3x3(x, pw, x2=x2, stride=self.stride[0], upsample=upsample, rowbias=rowbias, residual=residual, gn_cpg=cpg,
+                               defer_gn=defer_gn and cpg > 0)
         B, H, W, c1 = x.shape
         a2 = None if x2 is None else x2.reshape(B * H * W, x2.shape[-1])
         res = None if residual is None else residual.reshape(B * H * W, -1)

@@ -48,6 +48,14 @@ def _p(t: Optional[torch.Tensor]):
 
 
 def _chk_f16(t: torch.Tensor, name: str):
+    if _pending:                                  # a split-K output whose reduce pass was left to its GroupNorm is about to be read by something else
+        pr = _pending.get(t.device)
+        if pr is not None and pr.ptr == t.data_ptr():
+            flush_pending(t.device)
+    _chk_f16_raw(t, name)
+
+
+def _chk_f16_raw(t: torch.Tensor, name: str):
     if t.dtype != F16 or not t.is_cuda or not t.is_contiguous():
         raise RuntimeError(f"{name}: expected a contiguous fp16 device tensor, got {t.dtype} {t.device} contiguous={t.is_contiguous()}")
 
@@ -263,6 +271,48 @@ def partials_of(x: torch.Tensor) -> Optional["GnPartials"]:
     return gn
 
 
+# ---- split-K reduction left to the consuming GroupNorm (round 6; af_gemm_desc.defer_reduce / af_groupnorm_splitk) ---------------------------------
+# Every ResBlock convolution of the 32 x 32 / 16 x 16 / 8 x 8 levels is a split-K launch, and what reads its output first is a GroupNorm(32): the
+# chip-wide reduce pass (fp32 slabs -> fp16 tensor) followed by the GroupNorm's own read of that tensor are one launch and one round trip too many.
+# A caller that KNOWS its output's next reader is `groupnorm` / `groupnorm_train` on the same tensor asks for `defer_gn=True`: the split launch leaves its
+# slabs in the shared workspace, the returned tensor is NOT written yet, and one PendingReduce per device remembers what is owed.  `groupnorm(x)` on that
+# tensor then runs af_groupnorm_splitk -- slabs -> (bias, row bias, residual) -> x stored AND normalised, one launch, x bit-identical to the reduce
+# pass.  Safety net: any other wrapper that is handed the tensor (`_chk_f16` compares storage addresses: views included) and any further GEMM launch
+# (it may reuse the slab workspace) first materialises it with the plain reduce pass (af_splitk_reduce).  A torch op reading the tensor directly
+# would see unwritten memory: only call sites whose next launch is the GroupNorm may ask (ResBlock.hip / hip_train).
+DEFER_GN_REDUCE = _os.environ.get("AF_DEFER_GN_REDUCE", "0") != "0"      # OFF by default: bit-identical and a TIE in the step (profiles/r06c_defer_gn_ab.txt)
+
+
+class PendingReduce:
+    __slots__ = ("slabs", "splits", "bias", "rowbias", "ld_rowbias", "rpb", "residual", "out", "ptr", "M", "N")
+
+
+_pending = {}          # device -> PendingReduce (at most one: the slabs live in the per-device split-K workspace)
+pending_stats = {"deferred": 0, "fused": 0, "flushed": 0}
+
+
+def flush_pending(device=None):
+    """Materialise the tensor(s) whose split-K reduce pass is still owed (af_splitk_reduce: the pass af_gemm would have run)."""
+    for dev in ([device] if device is not None else list(_pending)):
+        pr = _pending.pop(dev, None)
+        if pr is not None:
+            pending_stats["flushed"] += 1
+            rc = _lib.lib().af_splitk_reduce(pr.slabs, pr.splits, _p(pr.bias), _p(pr.rowbias), pr.ld_rowbias, pr.rpb, _p(pr.residual), pr.ptr, pr.M, pr.N, _stream())
+            _lib.check(rc, "af_splitk_reduce")
+
+
+def _take_pending(x: torch.Tensor, B: int, hw: int, c: int) -> Optional["PendingReduce"]:
+    """The reduce owed on x, if x is that tensor and has the shape the producer wrote; anything else pending on the device is materialised."""
+    pr = _pending.get(x.device)
+    if pr is None:
+        return None
+    if pr.ptr == x.data_ptr() and pr.M == B * hw and pr.N == c and x.is_contiguous() and pr.rpb == hw:
+        del _pending[x.device]
+        return pr
+    flush_pending(x.device)
+    return None
+
+
 class WeightPrefetcher:
     """Weight prefetch on a SECOND stream inside a captured step (round 5 experiment; bench.py --prefetch-stream).
 
@@ -326,10 +376,13 @@ def _pf_note(*weights):
             _weight_prefetcher.note(w.data_ptr(), w.numel() * w.element_size())
 
 
-def _launch_gemm(d: "GemmDesc", device, what: str, tile: int = 0, splits: int = 0, gn_cpg: int = 0):
+def _launch_gemm(d: "GemmDesc", device, what: str, tile: int = 0, splits: int = 0, gn_cpg: int = 0, defer_gn=None):
     """Pick (tile, splits) -- explicit args > recorder (autotune) > table > heuristic -- and launch.  gn_cpg > 0: the caller's output feeds a
     GroupNorm with groups of gn_cpg channels; when the chosen launch can (af_gemm_gn_stats_ok) it also writes the partial statistics and a
-    GnPartials is returned (None otherwise)."""
+    GnPartials is returned (None otherwise).  defer_gn = (out tensor, bias, rowbias, residual) from a caller whose output's NEXT reader is that
+    GroupNorm: a split launch then leaves its reduce pass to it (PendingReduce above)."""
+    if _pending:
+        flush_pending(device)                       # the slab workspace is about to be reused / the owed tensor may be an operand
     if tile == 0 and splits == 0:
         key = f"{d.taps},{d.M},{d.N},{d.K},{d.act},{d.out_mode},{d.stride},{d.upsample}"
         if d.ln_colsum:
@@ -378,7 +431,21 @@ def _launch_gemm(d: "GemmDesc", device, what: str, tile: int = 0, splits: int = 
             gn = GnPartials(ws, rpb // 128, gn_cpg, nb, rpb, d.N)
     if _weight_prefetcher is not None and _weight_prefetcher.mode is not None:
         _weight_prefetcher.note(int(d.wt), int(d.kpad) * round_up(int(d.N), 128) * 2)
+    left = None
+    if (defer_gn is not None and DEFER_GN_REDUCE and d.splits > 1 and not d.splitk_fused and gn_cpg and _tune_recorder is None and d.act == AF_ACT_NONE
+            and d.out_mode == AF_OUT_NORMAL and d.ld_out in (0, d.N) and d.N % gn_cpg == 0):
+        rpb = d.rows_per_batch if d.rows_per_batch > 0 else d.M
+        if d.M % rpb == 0 and _lib.lib().af_groupnorm_splitk_ok(d.M // rpb, rpb, d.N, d.N // gn_cpg) == 1:
+            left = C.c_int32(0)
+            d.defer_reduce = C.pointer(left)
     _lib.check(_lib.lib().af_gemm(C.byref(d), _stream()), what)
+    if left is not None and left.value > 1:
+        pr = PendingReduce()
+        out, bias, rowbias, residual = defer_gn
+        pr.slabs, pr.splits, pr.bias, pr.rowbias, pr.residual, pr.out = int(d.workspace), left.value, bias, rowbias, residual, out
+        pr.ld_rowbias, pr.rpb, pr.ptr, pr.M, pr.N = int(d.ld_rowbias), (d.rows_per_batch if d.rows_per_batch > 0 else d.M), out.data_ptr(), int(d.M), int(d.N)
+        _pending[device] = pr
+        pending_stats["deferred"] += 1
     return gn
 
 
@@ -445,7 +512,7 @@ def conv3x3_skip_tile(M: int, N: int, cin: int, ktail: int):
 
 def conv3x3(x: torch.Tensor, pw: PackedWeight, *, x2: Optional[torch.Tensor] = None, stride: int = 1, upsample: bool = False,
             rowbias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, tile: int = 0,
-            splits: int = 0, out_hw=None, tap_shift: int = 0, skip=None, gn_cpg: int = 0) -> torch.Tensor:
+            splits: int = 0, out_hw=None, tap_shift: int = 0, skip=None, gn_cpg: int = 0, defer_gn: bool = False) -> torch.Tensor:
     """3x3 / pad 1 convolution as implicit GEMM (tap_shift=1: padding (0, 1, 0, 1) instead, the VAE encoder's Downsample).  x [B,H,W,C1] (+ x2 [B,H,W,C2] channel-concat)
     -> [B,Ho,Wo,Cout].  rowbias [B, >=Cout] is added per batch item (time-embedding), residual
     [B,Ho,Wo,Cout] after it."""
@@ -491,7 +558,8 @@ def conv3x3(x: torch.Tensor, pw: PackedWeight, *, x2: Optional[torch.Tensor] = N
         d.a3, d.a4, d.c3, d.c4, d.lda3, d.lda4 = _p(s1), _p(s2), c3, c4, c3, c4
         if tile == 0 and splits == 0 and _tune_recorder is None:
             tile, splits = conv3x3_skip_tile(d.M, d.N, c1 + c2, pw.k_tail)
-    gn = _launch_gemm(d, x.device, "af_gemm(conv3x3)", tile, splits, gn_cpg=gn_cpg)
+    gn = _launch_gemm(d, x.device, "af_gemm(conv3x3)", tile, splits, gn_cpg=gn_cpg,
+                      defer_gn=(out, pw.bias, rowbias, residual) if defer_gn else None)
     if gn is not None:
         gn.attach(out)
     return out
@@ -555,10 +623,24 @@ def _gn_workspace(device, B: int) -> torch.Tensor:
     return _grow_scratch(_gn_ws, device, _lib.lib().af_groupnorm_ws_floats(max(B, 16)), torch.float32)
 
 
+def _groupnorm_splitk(pr, x, gamma, beta, y, stats, B, hw, c, groups, eps, silu) -> bool:
+    """x's producer left its split-K slabs (PendingReduce): finish x AND normalise it in one launch.  False (after materialising x the plain way)
+    when the GroupNorm is outside the one-launch forms' scope."""
+    if _lib.lib().af_groupnorm_splitk_ok(B, hw, c, groups) != 1 or gamma.data_ptr() % 16 or beta.data_ptr() % 16:
+        _pending[x.device] = pr
+        flush_pending(x.device)
+        return False
+    rc = _lib.lib().af_groupnorm_splitk(pr.slabs, pr.splits, _p(pr.bias), _p(pr.rowbias), pr.ld_rowbias, _p(pr.residual), _p(x), c, _p(gamma), _p(beta), _p(y),
+                                        _p(stats), B, hw, groups, float(eps), int(silu), _stream())
+    _lib.check(rc, "af_groupnorm_splitk")
+    pending_stats["fused"] += 1
+    return True
+
+
 def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, silu: bool, *,
               x2: Optional[torch.Tensor] = None, groups: int = 32) -> torch.Tensor:
     """x [B, ..., C1] (+ x2 [B, ..., C2]) -> [B, ..., C1+C2] fp16; gamma/beta fp32 [C1+C2]."""
-    _chk_f16(x, "groupnorm.x")
+    _chk_f16_raw(x, "groupnorm.x")               # (not _chk_f16: x may be the tensor whose reduce pass this GroupNorm is about to absorb)
     B, c1 = x.shape[0], x.shape[-1]
     hw = x.numel() // (B * c1)
     c2 = 0
@@ -566,6 +648,10 @@ def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
         _chk_f16(x2, "groupnorm.x2")
         c2 = x2.shape[-1]
     y = torch.empty(tuple(x.shape[:-1]) + (c1 + c2,), dtype=F16, device=x.device)
+    if _pending:
+        pr = _take_pending(x, B, hw, c1) if x2 is None else flush_pending(x.device)
+        if pr is not None and _groupnorm_splitk(pr, x, gamma, beta, y, None, B, hw, c1, groups, eps, silu):
+            return y
     gn = partials_of(x) if x2 is None else None
     if gn is not None and gn.B == B and gn.hw == hw and gn.C == c1 and gn.cpg * groups == c1 and x.is_contiguous():
         # the launch that produced x left its partial statistics: normalise in one pass, no statistics pass (af_groupnorm_apply)
@@ -783,12 +869,16 @@ def q_sample(x0: torch.Tensor, noise: torch.Tensor, sa: torch.Tensor, sb: torch.
 # ----------------------------------------------------------------------------- backward ops
 def groupnorm_train(x, gamma, beta, eps, silu, *, x2=None, groups=32):
     """groupnorm() that also returns the (mean, rstd) statistics fp32 [B, groups, 2] for the backward."""
-    _chk_f16(x, "groupnorm.x")
+    _chk_f16_raw(x, "groupnorm.x")
     B, c1 = x.shape[0], x.shape[-1]
     hw = x.numel() // (B * c1)
     c2 = 0 if x2 is None else x2.shape[-1]
     y = torch.empty(tuple(x.shape[:-1]) + (c1 + c2,), dtype=F16, device=x.device)
     stats = torch.empty((B, groups, 2), dtype=torch.float32, device=x.device)
+    if _pending:
+        pr = _take_pending(x, B, hw, c1) if x2 is None else flush_pending(x.device)
+        if pr is not None and _groupnorm_splitk(pr, x, gamma, beta, y, stats, B, hw, c1, groups, eps, silu):
+            return y, stats
     gn = partials_of(x) if x2 is None else None
     if gn is not None and gn.B == B and gn.hw == hw and gn.C == c1 and gn.cpg * groups == c1 and x.is_contiguous():
         rc = _lib.lib().af_groupnorm_apply(_p(x), c1, _p(gamma), _p(beta), _p(y), _p(stats), B, hw, groups, float(eps), int(silu), _p(gn.ws), gn.nblk, _stream())

@@ -175,11 +175,24 @@ typedef struct af_gemm_desc {
    * anything else is AF_E_UNSUPPORTED (callers check af_gemm_gn_stats_ok first). */
   void* gn_partials;
   int32_t gn_cpg;
+  /* Split-K reduction left to the CONSUMER (round 6; NULL otherwise).  A split launch normally ends with a chip-wide reduce pass (fp32 slabs ->
+   * bias / row bias / activation / residual -> fp16).  Where the output's first reader is a GroupNorm (every ResBlock convolution:
+   * openaimodel.py:256-276, util.py:195-212) that pass and the GroupNorm's own read of its result are one launch too many: with defer_reduce != NULL
+   * a launch that WOULD run the separate reduce pass skips it, leaves its `*defer_reduce` = splits slabs [splits][M][N] fp32 at the start of
+   * `workspace`, and writes nothing to `out`; af_groupnorm_splitk (or af_splitk_reduce) then finishes the tensor.  *defer_reduce = 0 when the launch
+   * stored `out` itself (unsplit, or reduced in-launch).  Standard epilogue without activation only (AF_E_BADARG otherwise). */
+  int32_t* defer_reduce;
 } af_gemm_desc;
 #define AF_SPLITK_MAX_TILES 4096
 #define AF_SPLITK_COUNTER_BYTES (AF_SPLITK_MAX_TILES * 4)
 
 int af_gemm(const af_gemm_desc* d, void* stream);
+
+/* The reduce pass of a split-K launch on its own (what af_gemm runs after a split launch unless af_gemm_desc.defer_reduce held it back):
+ * out[m][n] = fp16( sum_sp slabs[sp][m][n] + bias[n] + rowbias[m / rows_per_batch][n] + residual[m][n] ), summed in slice order.  bias fp32 [N],
+ * rowbias fp16 rows of ld_rowbias, residual fp16 [M][N] -- each may be NULL.  N % 4 == 0. */
+int af_splitk_reduce(const void* slabs, int splits, const void* bias, const void* rowbias, int ld_rowbias, int rows_per_batch, const void* residual,
+                     void* out, int M, int N, void* stream);
 
 /* ---- fused feed-forward of a transformer block at C = 320 ------------------------------------------------
  * Replaces, in ONE launch, BasicTransformerBlock's  x + ff(norm3(x))  (attention.py:31-58 FeedForward / GEGLU, :242-252) at the
@@ -225,6 +238,15 @@ int af_groupnorm_ws_floats(int B);
  * af_groupnorm_stats. */
 int af_groupnorm_apply(const void* x, int C, const void* gamma, const void* beta, void* y, void* stats, int B, int HW, int groups, float eps,
                        int silu, const void* partials, int nblk, void* stream);
+/* GroupNorm(32) [+ SiLU] fed by the fp32 slabs of a split-K launch (af_gemm_desc.defer_reduce) in ONE launch: the value at (row, c) is
+ * fp16( sum_sp slabs[sp][row][c] + bias[c] + rowbias[b][c] + residual[row][c] ) -- the same arithmetic in the same order as af_splitk_reduce, so the
+ * stored tensor x_out is bit-identical to the two-launch form -- which is written to x_out (the convolution's output: later readers need it) AND
+ * normalised into y with the one-launch in-register forms of af_groupnorm (a workgroup per (batch item, group)); stats as af_groupnorm_stats.
+ * Replaces af_splitk_reduce_kernel + gn_small / gn_pair behind every split ResBlock convolution (openaimodel.py:256-276).  Scope =
+ * af_groupnorm_splitk_ok(B, HW, C, groups) == 1 (the in-register forms: HW * C / groups small enough); AF_E_UNSUPPORTED otherwise. */
+int af_groupnorm_splitk_ok(int B, int HW, int C, int groups);
+int af_groupnorm_splitk(const void* slabs, int splits, const void* bias, const void* rowbias, int ld_rowbias, const void* residual, void* x_out, int C,
+                        const void* gamma, const void* beta, void* y, void* stats, int B, int HW, int groups, float eps, int silu, void* stream);
 /* 1 when af_gemm with this (tile, splits) takes gn_partials for an output of N channels in groups of cpg and rows_per_batch rows per batch item */
 int af_gemm_gn_stats_ok(int tile, int splits, int taps, int act, int out_mode, int N, int cpg, int rows_per_batch);
 int af_groupnorm(const void* x1, const void* x2, int c1, int c2, const void* gamma, const void* beta,

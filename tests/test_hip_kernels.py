@@ -765,6 +765,105 @@ def test_groupnorm_with_opposite_signed_outliers_near_the_fp16_maximum(dev, B, H
     assert rel_l2(out.numpy(), ref.numpy()) < TOL
 
 
+@pytest.mark.parametrize("B,H,cin,cin2,cout,tile,splits,form", [
+    (2, 16, 1280, 0, 1280, 7, 4, "small"), (8, 16, 640, 0, 1280, 14, 4, "small"), (3, 8, 1280, 1280, 1280, 1, 12, "small"),
+    (2, 32, 640, 0, 640, 14, 2, "pair"), (8, 32, 320, 0, 640, 7, 2, "pair"), (2, 32, 640, 320, 640, 11, 3, "pair"), (1, 16, 320, 0, 320, 2, 5, "pair"),
+    (1, 8, 128, 0, 64, 2, 3, "pair"),
+])
+@pytest.mark.parametrize("silu", [True, False])
+def test_groupnorm_absorbs_the_split_k_reduce_bit_identically(dev, B, H, cin, cin2, cout, tile, splits, form, silu, monkeypatch):
+    """Round 6: a split-K convolution whose next reader is a GroupNorm leaves its reduce pass to it (af_gemm_desc.defer_reduce ->
+    af_groupnorm_splitk: slabs -> bias / time-embedding row bias / residual -> the convolution's fp16 output stored AND normalised, one launch).
+    Against the two-launch form (af_splitk_reduce_kernel, then gn_small / gn_pair) on the same launches: the stored convolution output, the
+    normalised tensor and the (mean, rstd) statistics of the training form must be BIT-IDENTICAL (same summation order, same statistics
+    arithmetic); and against fp32 torch within the ordinary tolerance.  Both one-launch forms, every epilogue input, one / two sources, the
+    K-concatenated shortcut, register-staged and LDS-DMA tiles."""
+    from adaface_dev_amd import ops, rng
+    W = H
+    tag = f"dg{B}.{H}.{cin}.{cin2}.{cout}"
+    x = rng.synth_input(tag + ".x", (B, H, W, cin), seed=31).half().to(dev)
+    x2 = rng.synth_input(tag + ".x2", (B, H, W, cin2), seed=31).half().to(dev) if cin2 else None
+    w = rng.synth_input(tag + ".w", (cout, cin + cin2, 3, 3), seed=31) * ((cin + cin2) * 9) ** -0.5
+    bias = rng.synth_input(tag + ".b", (cout,), seed=31)
+    pw = ops.pack_conv3x3(w, bias, dev)
+    rowb = rng.synth_input(tag + ".rb", (B, cout + 8), seed=31).half().to(dev)[:, :cout]          # a strided view, as the batched emb_layers output
+    res = rng.synth_input(tag + ".res", (B, H, W, cout), seed=31).half().to(dev)
+    gam = (rng.synth_input(tag + ".g", (cout,), seed=31) * 0.2 + 1).to(dev)
+    bet = (rng.synth_input(tag + ".bt", (cout,), seed=31) * 0.2).to(dev)
+    cpg = cout // 32
+
+    def run(defer, train):
+        monkeypatch.setattr(ops, "DEFER_GN_REDUCE", defer)
+        h = ops.conv3x3(x, pw, x2=x2, rowbias=rowb, residual=res, tile=tile, splits=splits, gn_cpg=cpg, defer_gn=True)
+        if train:
+            y, st = ops.groupnorm_train(h, gam, bet, 1e-5, silu)
+        else:
+            y, st = ops.groupnorm(h, gam, bet, 1e-5, silu), None
+        return h, y, st
+
+    for train in (False, True):
+        before = dict(ops.pending_stats)
+        h0, y0, st0 = run(False, train)
+        assert ops.pending_stats == before, "the switch is off: nothing may be deferred"
+        h1, y1, st1 = run(True, train)
+        assert ops.pending_stats["deferred"] == before["deferred"] + 1 and ops.pending_stats["fused"] == before["fused"] + 1, \
+            f"the launch was expected to defer its reduce pass and the GroupNorm to absorb it ({ops.pending_stats} vs {before})"
+        assert not ops._pending
+        assert torch.equal(h0, h1), "convolution output"
+        assert torch.equal(y0, y1), "normalised output"
+        if train:
+            assert torch.equal(st0, st1), "statistics"
+    xin = x if x2 is None else torch.cat([x, x2], -1)
+    ref_h = F.conv2d(xin.float().cpu().permute(0, 3, 1, 2), w.half().float(), bias, padding=1) + rowb.float().cpu()[:, :, None, None] \
+        + res.float().cpu().permute(0, 3, 1, 2)
+    assert rel_l2(h1.float().cpu().permute(0, 3, 1, 2).numpy(), ref_h.numpy()) < TOL
+    ref_y = F.group_norm(h1.float().cpu().permute(0, 3, 1, 2), 32, gam.cpu(), bet.cpu(), 1e-5)
+    ref_y = F.silu(ref_y) if silu else ref_y
+    assert rel_l2(y1.float().cpu().permute(0, 3, 1, 2).numpy(), ref_y.numpy()) < TOL
+
+
+def test_deferred_split_k_reduce_is_materialised_for_any_other_reader(dev, monkeypatch):
+    """The safety net of ops.PendingReduce: a tensor whose reduce pass was left to "the next GroupNorm" but is read by something else first -- another
+    wrapper (through a VIEW), a further GEMM launch (which reuses the slab workspace), a GroupNorm outside the one-launch scope or over two sources --
+    is finished by the plain reduce pass (af_splitk_reduce) before that reader runs.  Every path must give the bits of the never-deferred run."""
+    from adaface_dev_amd import ops, rng
+    B, H, C = 2, 16, 640
+    x = rng.synth_input("dm.x", (B, H, H, C), seed=32).half().to(dev)
+    pw = ops.pack_conv3x3(rng.synth_input("dm.w", (C, C, 3, 3), seed=32) * (C * 9) ** -0.5, rng.synth_input("dm.b", (C,), seed=32), dev)
+    pw1 = ops.pack_matrix(rng.synth_input("dm.w1", (C, C), seed=32) * C ** -0.5, None, dev)
+    gam, bet = torch.ones(2 * C, device=dev), torch.zeros(2 * C, device=dev)
+    monkeypatch.setattr(ops, "DEFER_GN_REDUCE", False)
+    want = ops.conv3x3(x, pw, tile=7, splits=3, gn_cpg=C // 32, defer_gn=True)
+    want_g = ops.gemm(want.reshape(-1, C), pw1, tile=2, splits=2)
+    want_gn2 = ops.groupnorm(want, gam, bet, 1e-5, True, x2=x)
+    monkeypatch.setattr(ops, "DEFER_GN_REDUCE", True)
+
+    def owed():
+        h = ops.conv3x3(x, pw, tile=7, splits=3, gn_cpg=C // 32, defer_gn=True)
+        assert ops._pending, "expected the reduce pass to be owed"
+        return h
+    h = owed()
+    assert torch.equal(ops.add(h.reshape(B * H, H, C), h.reshape(B * H, H, C)), ops.add(want, want).reshape(B * H, H, C)) and not ops._pending     # a wrapper, through a view
+    assert torch.equal(h, want)
+    h = owed()
+    assert torch.equal(ops.gemm(h.reshape(-1, C), pw1, tile=2, splits=2), want_g) and not ops._pending and torch.equal(h, want)      # operand of a split GEMM
+    h = owed()
+    assert torch.equal(ops.groupnorm(h, gam, bet, 1e-5, True, x2=x), want_gn2) and not ops._pending and torch.equal(h, want)            # two-source GroupNorm
+    h = owed()
+    other = ops.conv3x3(x, pw, tile=7, splits=2)                                                                                       # an unrelated launch
+    assert not ops._pending and torch.equal(h, want)
+    h = owed()
+    ops.flush_pending()
+    assert torch.equal(h, want)
+    # a GroupNorm outside the one-launch forms (64 x 64 x 320: the two-launch statistics path) never defers
+    xb = rng.synth_input("dm.xb", (2, 64, 64, 320), seed=32).half().to(dev)
+    pwb = ops.pack_conv3x3(rng.synth_input("dm.wb", (320, 320, 3, 3), seed=32) * (320 * 9) ** -0.5, None, dev)
+    hb = ops.conv3x3(xb, pwb, tile=7, splits=2, gn_cpg=10, defer_gn=True)
+    assert not ops._pending
+    monkeypatch.setattr(ops, "DEFER_GN_REDUCE", False)
+    assert torch.equal(hb, ops.conv3x3(xb, pwb, tile=7, splits=2, gn_cpg=10, defer_gn=True))
+
+
 @pytest.mark.parametrize("rows,C", [(77, 320), (1000, 640), (513, 1280), (64, 32), (10, 2048)])
 def test_layernorm(dev, rows, C):
     from adaface_dev_amd import ops
