@@ -650,6 +650,7 @@ int af_gemm3_try_launch(const af_gemm_desc* d, int splits, int wide, hipStream_t
 int af_gemm3_effective_splits(const af_gemm_desc* d, int splits, int wide);
 
 extern "C" int af_gemm_gn_stats_ok(int tile, int splits, int taps, int act, int out_mode, int N, int cpg, int rows_per_batch) {
+  if (tile == 19) tile = 14;                         // the round-5 loop of the halo-resident kernel: same tile, same epilogue
   const int bn = tile == 7 ? 320 : ((tile == 11 || tile == 13 || tile == 14) ? 160 : 0);
   if (bn == 0 || splits > 1 || (taps != 1 && taps != 9) || act == AF_ACT_GEGLU || out_mode != AF_OUT_NORMAL) return 0;
   if (tile == 14 && (taps != 9 || rows_per_batch % 256 != 0)) return 0;      // the halo-resident kernel's tile is 256 rows of one image
@@ -777,7 +778,7 @@ extern "C" int af_gemm(const af_gemm_desc* d, void* stream) {
     const long t128 = (long)((d->M + 127) / 128) * ((d->N + 127) / 128);
     tile = (t128 >= 192 && d->N >= 96) ? 1 : 2;
   }
-  AF_REQUIRE(tile >= 1 && tile <= 18, "af_gemm: tile must be 0 .. 18");
+  AF_REQUIRE(tile >= 1 && tile <= 19, "af_gemm: tile must be 0 .. 19");
 
   AfLaunchScope scope(AF_FAM_GEMM, stream);
   hipStream_t s = (hipStream_t)stream;

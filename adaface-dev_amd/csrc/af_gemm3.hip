@@ -77,6 +77,32 @@ __device__ __forceinline__ void glds16_nowait(const half_t* src, char* lds_dst) 
 }
 #pragma clang diagnostic pop
 
+// LDS-DMA with a SCALAR base pointer and a 32-bit per-lane byte offset (round 6): what is per-lane about a piece's source is computed once, the
+// per-stage part (K offset, tap) is scalar arithmetic.  lds_dst wave-uniform.
+__device__ __forceinline__ void glds16_sbase(const half_t* sbase, unsigned voff, char* lds_dst) {
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"((unsigned)(size_t)lds_dst) : "memory", "m0");
+#pragma clang diagnostic pop
+}
+// the same with the lanes whose `pix` is negative switched off (no LDS write for them)
+__device__ __forceinline__ void glds16_sbase_masked(const half_t* sbase, unsigned voff, int pix, char* lds_dst) {
+  unsigned long long keep;
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+  asm volatile(
+      "v_cmp_lt_i32 vcc, -1, %2\n\t"
+      "s_and_saveexec_b64 %0, vcc\n\t"
+      "s_mov_b32 m0, %4\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %3\n\t"
+      "s_mov_b64 exec, %0"
+      : "=&s"(keep)
+      : "v"(voff), "v"(pix), "s"(sbase), "s"((unsigned)(size_t)lds_dst)
+      : "memory", "m0", "vcc");
+#pragma clang diagnostic pop
+}
+
 // Tile shape: NWM x NWN waves, each wave 64 (M) x 16*TN (N).  Two instantiations:
 //   <2, 2, 4>: 128 x 128, 4 waves, 2 workgroups per CU             (64 FLOP per operand byte)
 //   <2, 4, 5>: 128 x 320, 8 waves, 1 workgroup per CU              (91 FLOP per operand byte)
@@ -790,11 +816,76 @@ __global__ __launch_bounds__(64 * NWM * NWN, (NWM * NWN == 4 && NSLOT == 2) ? 2 
     wok[j] = n < p.npad;
     wptr[j] = p.wt + (size_t)(wok[j] ? n : 0) * p.kpad + (slot ^ ((row >> 1) & 7)) * 8;
   }
+  // Round 6 (vector-instruction diet, see af_conv3hd_kernel): everything per-lane about a piece's address is computed ONCE --
+  //   * weight pieces and plain-row A pieces (taps 1, the K tail) use the scalar-base LDS-DMA form: a 32-bit per-lane byte offset here + a scalar
+  //     pointer per stage.  Rows past M / past the packed weight are CLAMPED to a valid row instead of being pointed at the zero page: their
+  //     products only reach output rows / columns the epilogue drops (m >= M, n >= N);
+  //   * 3x3 taps keep a per-lane 64-bit pixel pointer per source; a stage adds the tap's scalar offset and selects the zero page for taps that
+  //     fall outside the image (the nearest-x2 gather keeps the per-stage arithmetic: its tap offset depends on the lane's pixel parity).
+  // Byte offsets are 32-bit: the host routes tensors of 2 GB and more to the register-staged kernel.
+  unsigned w_off[WPW];
+#pragma unroll
+  for (int j = 0; j < WPW; ++j) {
+    const int row = (wave * WPW + j) * 8 + prow;
+    const int n = min(tile_n * BN + row, p.npad - 1);
+    w_off[j] = ((unsigned)n * (unsigned)p.kpad + (unsigned)((slot ^ ((row >> 1) & 7)) * 8)) * 2u;
+  }
+  unsigned a_off1[APW], a_off2[APW];                  // plain rows: taps 1 (sources 1 / 2) or the K tail of a 3x3 launch (a3 / a4)
+  const half_t* a_px1[APW];                           // 3x3: the centre pixel's chunk in source 1 / 2
+  const half_t* a_px2[APW];
+#pragma unroll
+  for (int j = 0; j < APW; ++j) {
+    const int row = (wave * APW + j) * 8 + prow;
+    const int mc = min(tile_m * BM + row, p.M - 1);
+    const unsigned ch = (unsigned)(a_lc[j] * 8);
+    if (TAPS == 9) {
+      a_off1[j] = ((unsigned)mc * (unsigned)p.lda3 + ch) * 2u;
+      a_off2[j] = ((unsigned)mc * (unsigned)p.lda4 + ch) * 2u;
+      a_px1[j] = p.a1 + (size_t)a_base[j] * p.c1 + ch;
+      a_px2[j] = p.a2 + (size_t)a_base[j] * p.c2 + ch;
+    } else {
+      a_off1[j] = ((unsigned)mc * (unsigned)p.lda1 + ch) * 2u;
+      a_off2[j] = ((unsigned)mc * (unsigned)p.lda2 + ch) * 2u;
+      a_px1[j] = a_px2[j] = nullptr;
+    }
+  }
+  const bool diet = (p.ablate & 512) == 0;            // AF_GEMM3_ABLATE bit 512: the round-5 per-stage address arithmetic (A/B arm)
 
   auto issue_stage = [&](int kt, int sl) {
     char* As = af_smem + sl * STAGE;
     char* Ws = As + BM * 128;
     const int k0 = kt * BKW;
+    if (diet && !(TAPS == 9 && p.upsample)) {
+      if (TAPS == 9 && p.c3 > 0 && k0 >= 9 * Cin) {
+        const int kt0 = k0 - 9 * Cin;                // the K tail: plain rows of a3 | a4 (64 | c3, c4: no K padding behind it)
+        const bool first = kt0 < p.c3;
+        const half_t* sb = first ? p.a3 + kt0 : p.a4 + (kt0 - p.c3);
+#pragma unroll
+        for (int j = 0; j < APW; ++j) glds16_sbase(sb, first ? a_off1[j] : a_off2[j], As + (wave * APW + j) * 1024);
+      } else if (TAPS == 9) {
+        const int tp = k0 / Cin;                     // workgroup-uniform (64 | c1, c2)
+        const int c0 = k0 - tp * Cin;
+        const bool first = c0 < p.c1;
+        const int cs = first ? p.c1 : p.c2;
+        const int ty = tp / 3, tx = tp - ty * 3;
+        const long soff = (long)((ty - 1) * p.W + (tx - 1)) * cs + (first ? c0 : c0 - p.c1);    // elements from the centre pixel's chunk: scalar
+#pragma unroll
+        for (int j = 0; j < APW; ++j) {
+          const bool ok = (a_mask[j] >> tp) & 1u;
+          const half_t* g = ok ? (first ? a_px1[j] : a_px2[j]) + soff : p.zeros;
+          glds16(g, As + (wave * APW + j) * 1024);
+        }
+      } else {
+        const bool first = k0 < p.c1;                // uniform: 64 | c1
+        const half_t* sb = first ? p.a1 + k0 : p.a2 + (k0 - p.c1);
+#pragma unroll
+        for (int j = 0; j < APW; ++j) glds16_sbase(sb, first ? a_off1[j] : a_off2[j], As + (wave * APW + j) * 1024);
+      }
+      const half_t* wb = p.wt + k0;
+#pragma unroll
+      for (int j = 0; j < WPW; ++j) glds16_sbase(wb, w_off[j], Ws + (wave * WPW + j) * 1024);
+      return;
+    }
     if (TAPS == 9 && p.c3 > 0 && k0 >= 9 * Cin) {
       // K tail: a 1x1 convolution of a second image on the output grid (stride 1: the tile row's pixel index IS its output row), c3 | c4 columns
       const int kt0 = k0 - 9 * Cin;
@@ -1286,6 +1377,252 @@ __global__ __launch_bounds__(512) void af_conv3h_kernel(const Gemm3Dev p) {
   gemm3_epilogue<E3_STD, NWM, NWN, TN, CH_LDS>(p, acc, af_smem, tile_m, tile_n, wm, wn, fr, fq, tid);
 }
 
+// ---- Round 6: the same kernel on a vector-instruction diet ("d").  The counters of the kernel above (profiles/r05b_gemm_pmc.txt) read 2.5 vector
+// instructions per MFMA in the main loop: per stage and wave ~50 for the 18 fragment-read addresses (tap offset + XOR swizzle recomputed from the
+// pixel index every stage), ~8 per LDS-DMA piece (a 64-bit per-lane address, a zero-page select) -- ~80 against 40 MFMAs, and while the SIMD partner
+// owns the matrix pipe an MFMA leaves 8 of every 16 cycles to vector issue: the L part (reads + address arithmetic + DMA issue) was pinned at about
+// the length of the partner's M part by instruction COUNT alone.  Here nothing of that is left in the loop:
+//   * the nine taps are unrolled and every (tap, 16-row group) fragment address is a register computed once (36 VGPRs); the second K half is that
+//     address XOR 64; a chunk change adds +-(one halo buffer) to them (36 adds per nine stages);
+//   * weight fragments: nine taps x three ring slots = the slot of a tap is tap % 3 at compile time, so the reads are two base registers + immediates;
+//   * LDS-DMA pieces use the scalar-base form (global_load_lds v_offset, s[base]): a weight piece is a per-lane 32-bit offset computed once + a
+//     scalar pointer per stage; a halo piece is one multiply-add (pixel x row pitch of the chunk's source) and lanes outside the image are switched
+//     off in EXEC instead of being pointed at the zero page -- their 16 bytes of both halo buffers are zeroed once in the prologue and never written.
+// Same stages, same hazards, same MFMA order as the kernel above: bit-identical results (tests compare the two).
+__global__ __launch_bounds__(512) void af_conv3hd_kernel(const Gemm3Dev p) {
+  constexpr int NWM = 4, NWN = 2, TN = 5, TM = 4, NW = 8, BM = CH_BM, BN = CH_BN;
+  constexpr int APW = (CH_NP_MAX + NW - 1) / NW;                 // 7 halo pieces per wave at most
+  constexpr int WPW = (BN / 8 + NW - 1) / NW;                    // 3 weight pieces per wave at most (20 pieces)
+  constexpr int WBASE = 2 * CH_ASZ;                              // the weight ring behind the two halo buffers
+  extern __shared__ __attribute__((aligned(16))) char af_smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave % NWM, wn = wave / NWM;
+  int tile_m, tile_n;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    if (p.n_major) {
+      tile_n = lid / p.tiles_m;
+      tile_m = lid - tile_n * p.tiles_m;
+    } else {
+      tile_m = lid / p.tiles_n;
+      tile_n = lid - tile_m * p.tiles_n;
+    }
+  }
+  const int Wd = p.Wo, Hd = p.Ho, Wh = Wd + 2, R = BM / Wd;
+  const int Hi = min(R, Hd), nimg = R / Hi, blk_px = (Hi + 2) * Wh;
+  const int halo_px = nimg * blk_px, NP = (halo_px + 7) >> 3;
+  const int m0 = tile_m * BM;
+  const int bimg = m0 / p.HoWo;
+  const int y0 = (m0 - bimg * p.HoWo) / Wd;
+  const int prow = lane >> 3, slot = lane & 7;
+  const int nc1 = p.c1 >> 6;
+  const int cb = blockIdx.y * p.kt_per_split;
+  const int ce = min((p.c1 + p.c2) >> 6, cb + p.kt_per_split);
+
+  // ---- loaders.  Halo piece j of this wave = piece wave + 8 j: lane (prow, slot) fills physical chunk `slot` of halo pixel hp = piece * 8 + prow with the
+  // pixel's logical chunk slot ^ (hp & 7) = slot ^ prow -- the same for every piece.  a_pix: the source pixel, -1 outside the image / the halo.
+  int a_pix[APW];
+#pragma unroll
+  for (int j = 0; j < APW; ++j) {
+    const int hp = (wave + NW * j) * 8 + prow;
+    const int im = hp / blk_px, hq = hp - im * blk_px;
+    const int hy = hq / Wh, hx = hq - hy * Wh;
+    const int iy = y0 - 1 + hy, ix = hx - 1;
+    const bool ok = hp < halo_px && (unsigned)iy < (unsigned)Hd && (unsigned)ix < (unsigned)Wd;
+    const int sy = p.upsample ? iy >> 1 : iy, sx = p.upsample ? ix >> 1 : ix;
+    a_pix[j] = ok ? ((bimg + im) * p.H + sy) * p.W + sx : -1;
+  }
+  const unsigned chunk16 = (unsigned)((slot ^ prow) * 16);
+  // weight piece j = rows (wave + 8 j) * 8 + prow of the tile; the row's physical chunk `slot` takes logical chunk slot ^ ((row >> 1) & 7), and
+  // (row >> 1) & 7 does not depend on j: a per-lane byte offset from the stage's scalar pointer wt + k0
+  unsigned w_off[WPW];
+#pragma unroll
+  for (int j = 0; j < WPW; ++j) {
+    const int row = (wave + NW * j) * 8 + prow;
+    const int n = min(tile_n * BN + row, p.npad - 1);
+    w_off[j] = ((unsigned)n * (unsigned)p.kpad + (unsigned)((slot ^ ((row >> 1) & 7)) * 8)) * 2u;
+  }
+  // kernel arguments the loop uses, as opaque scalar registers (left as kernarg loads they are re-loaded inside the loop, and every scalar load is
+  // waited for with lgkmcnt(0), behind the fragment reads)
+  const half_t *a1r = p.a1, *a2r = p.a2, *wtr = p.wt;
+  int c1r = p.c1, c2r = p.c2;
+  asm volatile("" : "+s"(a1r), "+s"(a2r), "+s"(wtr), "+s"(c1r), "+s"(c2r));
+  const int Cin = c1r + c2r;
+  auto chunk_src = [&](int u, const half_t*& src, int& ld2) {        // workgroup-uniform: a chunk lies in one source; ld2 = row pitch in bytes
+    const bool first = u < nc1;
+    src = first ? a1r + u * 64 : a2r + (u - nc1) * 64;
+    ld2 = (first ? c1r : c2r) * 2;
+  };
+  auto issue_halo_piece = [&](int j, const half_t* src, int ld2, int buf_off) {
+    if (wave + NW * j < NP)
+      glds16_sbase_masked(src, (unsigned)a_pix[j] * (unsigned)ld2 + chunk16, a_pix[j], af_smem + buf_off + (wave + NW * j) * 1024);
+  };
+  auto issue_w = [&](int u, int tap, int sl) {                       // this wave's weight pieces of the stage at (chunk u, tap), ring slot sl
+    const half_t* wb = wtr + (size_t)(tap * Cin + u * 64);
+    char* Ws = af_smem + WBASE + sl * CH_WSZ;
+#pragma unroll
+    for (int j = 0; j < WPW; ++j)
+      if (wave + NW * j < BN / 8) glds16_sbase(wb, w_off[j], Ws + (wave + NW * j) * 1024);
+  };
+
+  floatx4 acc[TN][TM];
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) acc[tn][tm] = floatx4{0.f, 0.f, 0.f, 0.f};
+  const int fr = lane & 15, fq = lane >> 4;
+  // fragment addresses (bytes from af_smem), first K half; second half = address ^ 64 (chunk 4 + fq instead of fq under the XOR swizzle)
+  const int wr0 = WBASE + (wn * TN * 16) * 128 + fr * 128 + ((fq ^ (fr >> 1)) * 16);
+  int fa[9][TM];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    const int q = wm * 64 + tm * 16 + fr;
+    const int r = q / Wd, im = r / Hi;
+    const int hpb = im * blk_px + (r - im * Hi) * Wh + (q - r * Wd);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int hp = hpb + (tap / 3) * Wh + (tap % 3);
+      fa[tap][tm] = hp * 128 + ((fq ^ (hp & 7)) * 16);
+    }
+  }
+
+  if (p.wpf > 0 && p.splits == 1)
+    // (the dump goes to weight slot 2, which nothing fills before the first barrier: every wave's dump loads have landed by then -- its own vmcnt(0) --
+    // while a dump in halo buffer 1, as in the kernel above, could land on a pad position AFTER another wave has zeroed it)
+    af_prefetch_weight_tile(p.wt, p.kpad, p.npad, tile_n * BN, BN, 0, p.kpad >> 6, p.wpf_coop, tile_m % p.wpf_coop, p.wpf, NW, wave, lane, af_smem + WBASE + 2 * CH_WSZ);
+
+  const int grp = wave >> 2;
+  half8_t wf[TN], xf[TM], wf1[TN], xf1[TM];
+  auto mfmas = [&]() {
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+        acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[tn], xf[tm], acc[tn][tm], 0, 0, 0);
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+        acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf1[tn], xf1[tm], acc[tn][tm], 0, 0, 0);
+  };
+#define CHD_READ_FRAGS(TAP)                                                                                                      \
+  {                                                                                                                              \
+    constexpr int wsl_ = ((TAP) % 3) * CH_WSZ;                                                                                   \
+    _Pragma("unroll") for (int tn = 0; tn < TN; ++tn) wf[tn] = *reinterpret_cast<const half8_t*>(af_smem + wr0 + wsl_ + tn * 2048);               \
+    _Pragma("unroll") for (int tm = 0; tm < TM; ++tm) xf[tm] = *reinterpret_cast<const half8_t*>(af_smem + fa[TAP][tm]);                            \
+    _Pragma("unroll") for (int tn = 0; tn < TN; ++tn) wf1[tn] = *reinterpret_cast<const half8_t*>(af_smem + (wr0 ^ 64) + wsl_ + tn * 2048);         \
+    _Pragma("unroll") for (int tm = 0; tm < TM; ++tm) xf1[tm] = *reinterpret_cast<const half8_t*>(af_smem + (fa[TAP][tm] ^ 64));                    \
+  }
+
+  __builtin_amdgcn_s_setprio(1);
+  const int nchunks = ce - cb;
+  if (nchunks > 0) {
+    const half_t* src;
+    int ld2;
+    chunk_src(cb, src, ld2);
+#pragma unroll
+    for (int j = 0; j < APW; ++j) issue_halo_piece(j, src, ld2, 0);
+    issue_w(cb, 0, 0);
+    issue_w(cb, 1, 1);                                               // stage 1: every wave's pieces
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // the halo's out-of-image positions: zero in BOTH buffers, once (no DMA ever writes them)
+#pragma unroll
+  for (int j = 0; j < APW; ++j)
+    if (wave + NW * j < NP && a_pix[j] < 0) {
+      char* z = af_smem + (wave + NW * j) * 1024 + lane * 16;
+      *reinterpret_cast<uintx4_t*>(z) = uintx4_t{0u, 0u, 0u, 0u};
+      *reinterpret_cast<uintx4_t*>(z + CH_ASZ) = uintx4_t{0u, 0u, 0u, 0u};
+    }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+
+  if (grp == 0) {
+#pragma nounroll
+    for (int u = cb; u < ce; ++u) {
+      const bool first = u == cb, last = u + 1 == ce;
+      const half_t* hsrc = a1r;
+      int hld2 = 0;
+      if (!last) chunk_src(u + 1, hsrc, hld2);
+      const int nbuf = ((u + 1 - cb) & 1) * CH_ASZ;
+#define CHD_STAGE0(TAP)                                                                                                          \
+      {                                                                                                                          \
+        CHD_READ_FRAGS(TAP)                                                                                                      \
+        if (!(first && (TAP) == 0) && !(last && (TAP) == 8)) issue_w((TAP) < 8 ? u : u + 1, ((TAP) + 1) % 9, ((TAP) + 1) % 3);   \
+        if (!last && (TAP) < APW) issue_halo_piece((TAP) < APW ? (TAP) : 0, hsrc, hld2, nbuf);                                   \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                                       \
+        __builtin_amdgcn_s_barrier();                                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                                       \
+        __builtin_amdgcn_s_setprio(0);                                                                                           \
+        mfmas();                                                                                                                 \
+        __builtin_amdgcn_s_setprio(1);                                                                                           \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                                       \
+        __builtin_amdgcn_s_barrier();                                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                                       \
+      }
+      CHD_STAGE0(0) CHD_STAGE0(1) CHD_STAGE0(2) CHD_STAGE0(3) CHD_STAGE0(4) CHD_STAGE0(5) CHD_STAGE0(6) CHD_STAGE0(7) CHD_STAGE0(8)
+#undef CHD_STAGE0
+      const int d = ((u - cb) & 1) ? -CH_ASZ : CH_ASZ;               // the next chunk's halo lies in the other buffer
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) fa[tap][tm] += d;
+    }
+    __builtin_amdgcn_s_barrier();                                    // group 1's last interval
+  } else {
+#pragma nounroll
+    for (int u = cb; u < ce; ++u) {
+      const bool first = u == cb, last = u + 1 == ce;
+      const half_t* hsrc = a1r;
+      int hld2 = 0;
+      if (!last) chunk_src(u + 1, hsrc, hld2);
+      const int nbuf = ((u + 1 - cb) & 1) * CH_ASZ;
+#define CHD_STAGE1(TAP)                                                                                                          \
+      {                                                                                                                          \
+        if (!(first && (TAP) == 0)) {                                                                                            \
+          __builtin_amdgcn_s_setprio(0);                                                                                         \
+          mfmas();                                                                                                               \
+          __builtin_amdgcn_s_setprio(1);                                                                                         \
+        }                                                                                                                        \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                                       \
+        __builtin_amdgcn_s_barrier();                                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                                       \
+        CHD_READ_FRAGS(TAP)                                                                                                      \
+        if (!(last && (TAP) >= 7)) issue_w((TAP) < 7 ? u : u + 1, ((TAP) + 2) % 9, ((TAP) + 2) % 3);                             \
+        if (!last && (TAP) < APW) issue_halo_piece((TAP) < APW ? (TAP) : 0, hsrc, hld2, nbuf);                                   \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                                       \
+        __builtin_amdgcn_s_barrier();                                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                                       \
+      }
+      CHD_STAGE1(0) CHD_STAGE1(1) CHD_STAGE1(2) CHD_STAGE1(3) CHD_STAGE1(4) CHD_STAGE1(5) CHD_STAGE1(6) CHD_STAGE1(7) CHD_STAGE1(8)
+#undef CHD_STAGE1
+      const int d = ((u - cb) & 1) ? -CH_ASZ : CH_ASZ;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) fa[tap][tm] += d;
+    }
+    if (nchunks > 0) {                                               // M(last stage)
+      __builtin_amdgcn_s_setprio(0);
+      mfmas();
+      __builtin_amdgcn_s_setprio(1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+#undef CHD_READ_FRAGS
+  __builtin_amdgcn_s_setprio(0);
+  gemm3_epilogue<E3_STD, NWM, NWN, TN, CH_LDS>(p, acc, af_smem, tile_m, tile_n, wm, wn, fr, fq, tid);
+}
+
 // scope of the halo-resident kernel
 static bool conv3h_eligible(const af_gemm_desc* d) {
   if (d->taps != 9 || (d->upsample != 0 && d->upsample != 1) || d->tap_shift || d->c1 % 64 != 0 || d->c2 % 64 != 0 || d->c3 != 0 || d->c4 != 0 || d->N % CH_BN != 0) return false;
@@ -1301,7 +1638,7 @@ static bool conv3h_eligible(const af_gemm_desc* d) {
 
 static int conv3h_chunks(const af_gemm_desc* d) { return (d->c1 + d->c2) / 64; }
 
-static bool launch_conv3h(const Gemm3Dev& p0, hipStream_t stream) {
+static bool launch_conv3h(const Gemm3Dev& p0, hipStream_t stream, bool r5_loop) {
   Gemm3Dev p = p0;
   p.tiles_n = p.N / CH_BN;
   p.tiles_m = p.M / CH_BM;
@@ -1319,6 +1656,15 @@ static bool launch_conv3h(const Gemm3Dev& p0, hipStream_t stream) {
     if (af_allow_dyn_lds(reinterpret_cast<const void*>(&af_conv3h_kernel<A>), CH_LDS, set_, "af_gemm"))                                       \
       hipLaunchKernelGGL(af_conv3h_kernel<A>, grid, block, CH_LDS, stream, p);                                                                \
     break;                                                                                                                                    \
+  }
+  static const bool diet_env = !(getenv("AF_CONV3H_DIET") && atoi(getenv("AF_CONV3H_DIET")) == 0);    // A/B switch: 0 = the round-5 loop
+  static const bool diet_dynamic = getenv("AF_GEMM3_ABLATE_DYNAMIC") != nullptr;
+  const bool diet = diet_dynamic ? !(getenv("AF_CONV3H_DIET") && atoi(getenv("AF_CONV3H_DIET")) == 0) : diet_env;
+  if (diet && !r5_loop && (p.ablate & 63) == 0) {
+    static bool set_d = false;
+    if (af_allow_dyn_lds(reinterpret_cast<const void*>(&af_conv3hd_kernel), CH_LDS, set_d, "af_gemm"))
+      hipLaunchKernelGGL(af_conv3hd_kernel, grid, block, CH_LDS, stream, p);
+    return p.counters != nullptr;
   }
   switch (p.ablate & 63) {
 #ifdef AF_CONV3H_ABLATIONS                                         // timing experiments only (tools/probes/r05s_conv3hp_ablate.sh builds with this)
@@ -1556,6 +1902,8 @@ int af_gemm3_try_launch(const af_gemm_desc* d, int splits, int wide, hipStream_t
   // 4 = 128 x 320 (GEGLU 128 x 256), 5 = 128 x 128, 6 = GEGLU 256 x 320, 7 = GEGLU 256 x 256, 8 = 128 x 160 (4 waves, 2 workgroups per CU),
   // 9 / 10 = 128 x 128 / 128 x 160 with a four-slot ring (three stages in flight, one workgroup per CU)
   const bool geglu = d->act == AF_ACT_GEGLU, split_t = d->out_mode == AF_OUT_SPLIT_T;
+  const bool halo_r5 = wide == 16;                              // tile 19: tile 14 with the round-5 main loop (A/B arm and bit-identity reference of tile 14)
+  if (halo_r5) wide = 11;
   if (wide == 11 && !conv3h_eligible(d)) return 1;              // halo-resident 3x3 kernel (tile 14)
   if (d->upsample && !((wide == 4 || wide == 5 || (wide >= 8 && wide <= 12)) && d->upsample == 1 && d->taps == 9)) return 1;   // nearest x2: whole-line kernel only
   if (d->c1 % BK3 != 0 || d->c2 % BK3 != 0 || d->zeros == nullptr) return 1;
@@ -1650,7 +1998,7 @@ int af_gemm3_try_launch(const af_gemm_desc* d, int splits, int wide, hipStream_t
     if (p.splits > nchunk) p.splits = nchunk;
     p.kt_per_split = (nchunk + p.splits - 1) / p.splits;
     p.splits = (nchunk + p.kt_per_split - 1) / p.kt_per_split;
-    fused = launch_conv3h(p, stream);
+    fused = launch_conv3h(p, stream, halo_r5);
     return (p.splits > 1 && !fused) ? 2 : 0;
   }
   if (wide >= 4) {
@@ -1707,6 +2055,7 @@ int af_gemm3_try_launch(const af_gemm_desc* d, int splits, int wide, hipStream_t
 }
 
 int af_gemm3_effective_splits(const af_gemm_desc* d, int splits, int wide) {
+  if (wide == 16) wide = 11;                                     // tile 19 = tile 14's scope
   const int nk = (wide == 11 && conv3h_eligible(d)) ? conv3h_chunks(d) : d->kpad / (wide >= 4 ? 64 : BK3);
   int s = splits > 1 ? splits : 1;
   if (s > nk) s = nk;

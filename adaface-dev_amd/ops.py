@@ -423,7 +423,7 @@ def _launch_gemm(d: "GemmDesc", device, what: str, tile: int = 0, splits: int = 
         rpb = d.rows_per_batch if d.rows_per_batch > 0 else d.M
         # the table's key carries no image geometry: tile 14 (halo-resident 3x3) on a latent outside its scope (W not 16 / 32 / 64, ragged rows)
         # falls back to a tap-by-tap tile INSIDE the library, which leaves no statistics -- ask for them only where tile 14 will really run
-        if (d.tile != 14 or conv_halo_eligible(d)) and d.M % rpb == 0 and d.ld_out in (0, d.N) \
+        if (d.tile not in (14, 19) or conv_halo_eligible(d)) and d.M % rpb == 0 and d.ld_out in (0, d.N) \
                 and _lib.lib().af_gemm_gn_stats_ok(d.tile, d.splits, d.taps, d.act, d.out_mode, d.N, gn_cpg, rpb) == 1:
             nb = d.M // rpb
             ws = torch.empty((nb, 128, 32, 2), dtype=torch.float32, device=device)

@@ -127,7 +127,10 @@ typedef struct af_gemm_desc {
                            (stride 1, pad 1, c1 % 64 == 0, c2 % 64 == 0 -- one or two channel-concatenated sources --, no K tail, N % 160 == 0,
                            Wo in {8, 16, 32, 64}, a tile = 256 / Wo whole rows of one image or whole images (the 8 x 8 level), upsample 0 / 1; split-K over 64-channel chunks of c1 + c2).  Main loop: ping-pong between the two
                            waves of a SIMD (one group issues a stage's 40 MFMAs while the other reads its fragments and issues its LDS-DMA
-                           pieces; 160 KB of LDS).  Outside that scope it falls back to tile 1 */
+                           pieces; 160 KB of LDS).  Round 6: every per-stage address (fragment reads per tap, LDS-DMA pieces) is a register or a scalar +
+                           immediate computed outside the loop, out-of-image halo lanes are EXEC-masked instead of reading a zero page (~10 instead of
+                           ~80 vector instructions per 40-MFMA stage).  Outside that scope it falls back to tile 1 */
+                        /* 19 = tile 14 with its round-5 main loop (addresses recomputed per stage): the A/B arm; bit-identical results */
                         /* 15 = whole-line kernel, 256 x 128 tile of eight waves (4 x 2; N % 128 == 0; standard epilogue, taps 1 / 9, nearest x2): 85 instead of
                            64 FLOP per operand byte for narrow outputs over many rows (the VAE decoder's 128- / 256-channel convolutions at 256^2 / 512^2) */
                         /* 16 / 17 = whole-line kernel, 64 x 128 / 128 x 64 tile of four waves (1 x 4 / 2 x 2; N % 128 / 64 == 0; standard and transposed-V-split epilogues, folded

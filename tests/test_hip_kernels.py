@@ -149,6 +149,10 @@ def test_conv3x3_tile14_halo_resident(dev, B, H, W, cin, cout, splits, extras):
     out7 = ops.conv3x3(x.to(dev), ops.pack_conv3x3(w, bias, dev), rowbias=None if rowb is None else rowb.to(dev),
                        residual=None if res is None else res.to(dev), tile=8, splits=1)
     assert rel_l2(out.float().cpu().numpy(), out7.float().cpu().numpy()) < 2e-3
+    # round 6: the loop with its address arithmetic hoisted (tile 14) against the round-5 loop (tile 19): same stages, same MFMA order -> same bits
+    out19 = ops.conv3x3(x.to(dev), ops.pack_conv3x3(w, bias, dev), rowbias=None if rowb is None else rowb.to(dev),
+                        residual=None if res is None else res.to(dev), tile=19, splits=splits)
+    assert torch.equal(out, out19)
 
 
 @pytest.mark.parametrize("B,H,W,cin,cs1,cs2,cout,tile,splits", [
@@ -199,11 +203,12 @@ def test_conv3x3_tile14_two_sources(dev, B, H, W, c1, c2, cout, splits):
     rowb, res = rnd((B, cout), 5), rnd((B, H, W, cout), 6)
     ref = F.conv2d(torch.cat([x1, x2], -1).float().permute(0, 3, 1, 2), w.float(), bias, padding=1) + rowb.float()[:, :, None, None] + res.float().permute(0, 3, 1, 2)
     pw = ops.pack_conv3x3(w, bias, dev)
-    run = lambda: ops.conv3x3(x1.to(dev), pw, x2=x2.to(dev), rowbias=rowb.to(dev), residual=res.to(dev), tile=14, splits=splits)
+    run = lambda tile=14: ops.conv3x3(x1.to(dev), pw, x2=x2.to(dev), rowbias=rowb.to(dev), residual=res.to(dev), tile=tile, splits=splits)
     out = run()
     assert rel_l2(out.float().cpu().permute(0, 3, 1, 2).numpy(), ref.numpy()) < TOL
     for _ in range(10):
         assert torch.equal(run(), out)
+    assert torch.equal(run(19), out)               # the round-5 loop (tile 19): bit-identical
 
 
 @pytest.mark.parametrize("B,H,W,c1,c2,cout,splits", [(1, 32, 32, 640, 0, 640, 1), (2, 16, 16, 1280, 0, 320, 2), (2, 8, 8, 128, 64, 160, 3), (1, 8, 32, 64, 0, 160, 1)])
@@ -225,6 +230,7 @@ def test_conv3x3_tile14_nearest_x2_upsample(dev, B, H, W, c1, c2, cout, splits):
     assert rel_l2(out.float().cpu().numpy(), run(8, 1).float().cpu().numpy()) < 2e-3
     for _ in range(5):
         assert torch.equal(run(14, splits), out)
+    assert torch.equal(run(19, splits), out)       # the round-5 loop (tile 19): bit-identical
 
 
 @pytest.mark.parametrize("kind,B,H,W,cin,cout,tile", [("conv", 2, 16, 16, 128, 320, 7), ("conv", 1, 64, 64, 320, 320, 7), ("conv", 2, 32, 32, 64, 640, 7),
