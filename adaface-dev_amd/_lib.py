@@ -9,7 +9,9 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libadaface_hip.so")
+# AF_LIB: another build of the SAME sources to load instead (measurement only: tools/ab_lib.sh compares two builds of the library, e.g. one compiled
+# with -DAF_GEMM3W_DIET=0, in alternating runs on one box).  Unset in every judged run; a missing file fails as loudly as the default path.
+LIB_PATH = os.environ.get("AF_LIB") or os.path.join(CSRC, "libadaface_hip.so")
 
 AF_OK, AF_E_BADARG, AF_E_UNSUPPORTED, AF_E_HIP = 0, -1, -2, -3
 AF_ACT_NONE, AF_ACT_SILU, AF_ACT_GEGLU, AF_ACT_QUICKGELU = 0, 1, 2, 3

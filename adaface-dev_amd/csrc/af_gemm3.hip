@@ -17,6 +17,8 @@
 // 3x3 taps with channel counts that are multiples of 32 and no upsampling.  Everything else stays on af_gemm.hip.
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "af_common.h"
 
 int af_gemm_n_major(int M, int N, int K, int cin);   // af_gemm.hip
@@ -112,6 +114,9 @@ __device__ __forceinline__ void glds16_sbase_masked(const half_t* sbase, unsigne
 // Every wave issues exactly 4 LDS-DMA pieces per stage in both shapes (2 A + 2 W, or 1 A + 3 W with the W pieces
 // padded from 20 to 24; padding pieces fetch the zero page), so the counted waits are the same constants.
 enum { E3_STD = 0, E3_GEGLU = 1, E3_SPLIT_T = 2 };
+#ifndef AF_GEMM3W_DIET
+#define AF_GEMM3W_DIET 1
+#endif
 
 // Epilogue shared by the ring kernel and the whole-line kernel: split-K partial tiles, or bias / row bias / activation / residual
 // (identical arithmetic to af_gemm.hip's standard epilogue), GEGLU, transposed-V split.  LDSB = bytes of LDS the main loop owned.
@@ -849,7 +854,10 @@ __global__ __launch_bounds__(64 * NWM * NWN, (NWM * NWN == 4 && NSLOT == 2) ? 2 
       a_px1[j] = a_px2[j] = nullptr;
     }
   }
-  const bool diet = (p.ablate & 512) == 0;            // AF_GEMM3_ABLATE bit 512: the round-5 per-stage address arithmetic (A/B arm)
+  // A/B arms: 3x3 launches keep the round-5 per-stage arithmetic behind AF_GEMM3_ABLATE bit 512 (their nearest-x2 path needs its state anyway);
+  // plain-row launches have it behind the compile-time AF_GEMM3W_DIET=0 only (a runtime switch would keep both sets of loader registers alive:
+  // the 256 x 320 GEGLU tile then spills)
+  const bool diet = TAPS == 9 ? (p.ablate & 512) == 0 : (AF_GEMM3W_DIET != 0);
 
   auto issue_stage = [&](int kt, int sl) {
     char* As = af_smem + sl * STAGE;
@@ -860,8 +868,15 @@ __global__ __launch_bounds__(64 * NWM * NWN, (NWM * NWN == 4 && NSLOT == 2) ? 2 
         const int kt0 = k0 - 9 * Cin;                // the K tail: plain rows of a3 | a4 (64 | c3, c4: no K padding behind it)
         const bool first = kt0 < p.c3;
         const half_t* sb = first ? p.a3 + kt0 : p.a4 + (kt0 - p.c3);
+        // (a scalar branch, not `first ? a_off1[j] : a_off2[j]`: hipcc turns a select between two register arrays into a load from a selected
+        // ADDRESS, i.e. both arrays go to scratch)
+        if (first) {
 #pragma unroll
-        for (int j = 0; j < APW; ++j) glds16_sbase(sb, first ? a_off1[j] : a_off2[j], As + (wave * APW + j) * 1024);
+          for (int j = 0; j < APW; ++j) glds16_sbase(sb, a_off1[j], As + (wave * APW + j) * 1024);
+        } else {
+#pragma unroll
+          for (int j = 0; j < APW; ++j) glds16_sbase(sb, a_off2[j], As + (wave * APW + j) * 1024);
+        }
       } else if (TAPS == 9) {
         const int tp = k0 / Cin;                     // workgroup-uniform (64 | c1, c2)
         const int c0 = k0 - tp * Cin;
@@ -872,14 +887,21 @@ __global__ __launch_bounds__(64 * NWM * NWN, (NWM * NWN == 4 && NSLOT == 2) ? 2 
 #pragma unroll
         for (int j = 0; j < APW; ++j) {
           const bool ok = (a_mask[j] >> tp) & 1u;
-          const half_t* g = ok ? (first ? a_px1[j] : a_px2[j]) + soff : p.zeros;
+          const half_t* px = a_px1[j];
+          if (!first) px = a_px2[j];
+          const half_t* g = ok ? px + soff : p.zeros;
           glds16(g, As + (wave * APW + j) * 1024);
         }
       } else {
         const bool first = k0 < p.c1;                // uniform: 64 | c1
         const half_t* sb = first ? p.a1 + k0 : p.a2 + (k0 - p.c1);
+        if (first) {
 #pragma unroll
-        for (int j = 0; j < APW; ++j) glds16_sbase(sb, first ? a_off1[j] : a_off2[j], As + (wave * APW + j) * 1024);
+          for (int j = 0; j < APW; ++j) glds16_sbase(sb, a_off1[j], As + (wave * APW + j) * 1024);
+        } else {
+#pragma unroll
+          for (int j = 0; j < APW; ++j) glds16_sbase(sb, a_off2[j], As + (wave * APW + j) * 1024);
+        }
       }
       const half_t* wb = p.wt + k0;
 #pragma unroll
@@ -1988,6 +2010,11 @@ int af_gemm3_try_launch(const af_gemm_desc* d, int splits, int wide, hipStream_t
   static const int ablate = getenv("AF_GEMM3_ABLATE") ? atoi(getenv("AF_GEMM3_ABLATE")) : 0;
   static const bool ablate_dynamic = getenv("AF_GEMM3_ABLATE_DYNAMIC") != nullptr;   // experiments: re-read per call (in-process A/B)
   p.ablate = ablate_dynamic ? (getenv("AF_GEMM3_ABLATE") ? atoi(getenv("AF_GEMM3_ABLATE")) : 0) : ablate;
+  {
+    // the whole-line kernel's loaders hold 32-bit byte offsets into the row-addressed operands (round 6): anything larger goes to the register-staged kernel
+    const long ldmax = std::max(std::max((long)(d->lda1 ? d->lda1 : d->c1), (long)(d->lda2 ? d->lda2 : d->c2)), std::max((long)(d->lda3 ? d->lda3 : d->c3), (long)(d->lda4 ? d->lda4 : d->c4)));
+    if (wide >= 4 && wide != 11 && (long)d->M * ldmax * 2 >= (1L << 32)) return 1;
+  }
   {
     const int ncols = geglu ? d->N / 2 : d->N;
     p.stage_ok = ncols % 8 == 0 && p.ld_out % 8 == 0 && (reinterpret_cast<uintptr_t>(p.out) & 15) == 0;
