@@ -27,6 +27,10 @@
 
 #include "af_common.h"
 
+#ifndef AF_ATTN_NW_DEFAULT
+#define AF_ATTN_NW_DEFAULT 4
+#endif
+
 namespace {
 
 struct AttnArgs {
@@ -367,21 +371,28 @@ __global__ __launch_bounds__(256) void af_attn_kernel(AttnArgs a) {
 // the Q fragment holds -m as fp16 (any per-query constant cancels in the normalisation as long as every key sees the same one) -- so the S^T
 // accumulators start from the inline constant 0 instead of 32 v_mov of -m per chain and stage; the half-wave maximum is exchanged by
 // v_permlane32_swap instead of a ds_bpermute round trip.
-template <int DS, bool ONES, bool SLOT = false>
-__global__ __launch_bounds__(256) void af_attn2_kernel(AttnArgs a) {
+// NW (round 6): waves per workgroup.  4 = rounds 2 - 5: 256 queries per workgroup, two workgroups per CU, so the two waves of a SIMD belong to DIFFERENT
+// workgroups and nothing orders them -- they settle into lock step (both want the matrix pipe for their S^T / P.V batches, then both issue their exp2
+// blocks), and a stage costs the SUM of its matrix and vector cycles (profiles/r04c).  8 = one workgroup of 512 queries per CU whose waves w and w + 4
+// share a SIMD, the upper half at a STATIC raised priority (s_setprio 1 once, no flips: MI355X_MICROARCH.md, two waves per SIMD, item 4): when both
+// partners want the matrix pipe the upper wave takes it and the lower one gets it while the upper one is in its exp2 block, so the partners run out of
+// phase by construction; K / V^T tiles are staged once per 512 queries.  Same arithmetic per chain in the same order: bit-identical results.
+template <int DS, bool ONES, bool SLOT = false, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void af_attn2_kernel(AttnArgs a) {
+  constexpr int NT = 64 * NW;
   constexpr int DP = 16 * DS, DT = (DS + 1) / 2, DV = 32 * DT;
   constexpr int KST = DP + 8, KBUF = KB * KST, VBUF = 2 * DV * VST, STAGE = KBUF + VBUF;
-  constexpr int KCH = KB * (DP / 8), NKC = (KCH + 255) / 256, VCH = DV * 8, NVC = (VCH + 255) / 256;
+  constexpr int KCH = KB * (DP / 8), NKC = (KCH + NT - 1) / NT, VCH = DV * 8, NVC = (VCH + NT - 1) / NT;
   extern __shared__ __attribute__((aligned(16))) char af_smem[];
   half_t* lds = reinterpret_cast<half_t*>(af_smem);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, hh = lane >> 5;
-  const int qblocks = (a.Nq + 255) / 256;
+  const int qblocks = (a.Nq + NT - 1) / NT;
   const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
   const int bh = (idx / qblocks) * 8 + xcd;
   if (bh >= a.B * a.heads) return;
   const int b = bh / a.heads, h = bh - b * a.heads;
-  const int q0 = (idx % qblocks) * 256 + wave * 64 + r;          // chain c handles query q0 + 32 c
+  const int q0 = (idx % qblocks) * NT + wave * 64 + r;          // chain c handles query q0 + 32 c
   const half8_t zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 
   half8_t qf[2][DS];
@@ -404,7 +415,7 @@ __global__ __launch_bounds__(256) void af_attn2_kernel(AttnArgs a) {
   bool kok[NKC], kone[NKC];
 #pragma unroll
   for (int j = 0; j < NKC; ++j) {
-    const int i = tid + 256 * j;
+    const int i = tid + NT * j;
     const int row = i / (DP / 8), ch = i - row * (DP / 8);
     kok[j] = i < KCH && ch * 8 < a.d;
     kone[j] = SLOT && i < KCH && ch * 8 == a.d;      // K column d = 1.0: multiplies the -m slot of Q
@@ -415,7 +426,7 @@ __global__ __launch_bounds__(256) void af_attn2_kernel(AttnArgs a) {
   bool vok[NVC], vones[NVC];
 #pragma unroll
   for (int j = 0; j < NVC; ++j) {
-    const int i = tid + 256 * j;
+    const int i = tid + NT * j;
     const int row = i >> 3, ch = i & 7;
     vok[j] = i < VCH && row < a.d;
     vones[j] = ONES && i < VCH && row == DV - 1;
@@ -433,7 +444,7 @@ __global__ __launch_bounds__(256) void af_attn2_kernel(AttnArgs a) {
     half_t* Vs = Ks + KBUF;
 #pragma unroll
     for (int j = 0; j < NKC; ++j) {
-      const int i = tid + 256 * j;
+      const int i = tid + NT * j;
       if (i < KCH) {
         const int row = i / (DP / 8), ch = i - row * (DP / 8);
         *reinterpret_cast<half8_t*>(Ks + row * KST + ch * 8) = rk[j];
@@ -441,7 +452,7 @@ __global__ __launch_bounds__(256) void af_attn2_kernel(AttnArgs a) {
     }
 #pragma unroll
     for (int j = 0; j < NVC; ++j) {
-      const int i = tid + 256 * j;
+      const int i = tid + NT * j;
       if (i < VCH) {
         const int row = i >> 3, ch = i & 7;
         half_t* dst = Vs + ((ch >> 2) * DV + row) * VST + (ch & 3) * 8;
@@ -516,6 +527,7 @@ __global__ __launch_bounds__(256) void af_attn2_kernel(AttnArgs a) {
   load_stage(0);
   store_stage(0);
   __syncthreads();
+  if (NW == 8 && __builtin_amdgcn_readfirstlane(wave) >= 4) __builtin_amdgcn_s_setprio(1);      // the SIMD partners of waves 0 - 3: static priority
   for (int st = 0; st < nstage; ++st) {
     const bool more = st + 1 < nstage;
     if (more) load_stage((st + 1) * KB);
@@ -617,9 +629,19 @@ template <int DS, bool ONES, bool SLOT = false>
 int launch_attn2chain(const AttnArgs& a, hipStream_t stream) {
   constexpr int DP = 16 * DS, DT = (DS + 1) / 2, DV = 32 * DT;
   constexpr size_t lds = (size_t)2 * (KB * (DP + 8) + 2 * DV * VST) * sizeof(half_t);
+  const int bh8 = (a.B * a.heads + 7) / 8 * 8;
+  // AF_ATTN_NW (read per call: the tests compare both forms in one process): 8 = one 512-query workgroup per CU with the static-priority SIMD partners
+  const char* nw_s = getenv("AF_ATTN_NW");
+  const int nw = nw_s ? atoi(nw_s) : AF_ATTN_NW_DEFAULT;
+  if (nw == 8 && SLOT && a.Nq % 512 == 0) {          // (the SLOT instantiations fit 256 registers at 512 threads; the others would spill)
+    static bool attr8 = false;
+    if (!af_allow_dyn_lds(reinterpret_cast<const void*>(&af_attn2_kernel<DS, ONES, SLOT, 8>), lds, attr8, "af_attention")) return af_check_launch("af_attention");
+    hipLaunchKernelGGL((af_attn2_kernel<DS, ONES, SLOT, 8>), dim3((a.Nq / 512) * bh8), dim3(512), lds, stream, a);
+    return af_check_launch("af_attention(two-chain, 8 waves)");
+  }
   static bool attr_set = false;  // benign race: idempotent attribute
   if (!af_allow_dyn_lds(reinterpret_cast<const void*>(&af_attn2_kernel<DS, ONES, SLOT>), lds, attr_set, "af_attention")) return af_check_launch("af_attention");
-  const int qblocks = (a.Nq + 255) / 256, bh8 = (a.B * a.heads + 7) / 8 * 8;
+  const int qblocks = (a.Nq + 255) / 256;
   hipLaunchKernelGGL((af_attn2_kernel<DS, ONES, SLOT>), dim3(qblocks * bh8), dim3(256), lds, stream, a);
   return af_check_launch("af_attention(two-chain)");
 }

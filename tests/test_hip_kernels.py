@@ -1169,6 +1169,31 @@ def test_attention_online_softmax_rescale_branch(dev, N):
     assert rel_l2(o.float().cpu().reshape(B, N, C).numpy(), ref.numpy()) < TOL
 
 
+@pytest.mark.parametrize("B,N,L,heads,d", [(1, 4096, 4096, 2, 40), (2, 1024, 1024, 8, 40), (3, 512, 320, 4, 40), (1, 1536, 256, 3, 40)])
+def test_self_attention_eight_wave_workgroups_bit_identical(dev, B, N, L, heads, d, monkeypatch):
+    """Round 6: the two-chain self-attention kernel with 8-wave workgroups (512 queries, one workgroup per CU, the SIMD partners at a static
+    raised priority so that they run out of phase: AF_ATTN_NW=8) against the 4-wave form on the same inputs: the same per-chain arithmetic in the
+    same order -> bit-identical outputs and log-sum-exps, incl. the lazy-reference rescale branch (a spiked key in the last stage) -- and repeated
+    launches stay identical (the partners share K / V^T tiles through LDS behind one barrier per stage, as before)."""
+    from adaface_dev_amd import ops
+    C = heads * d
+    q, k, v = rnd((B, N, C), 1), rnd((B, L, C), 2, 0.5), rnd((B, L, C), 3)
+    k[0, L - 3] = (q[0, 5] * 4).half()
+    k[0, 130] = (q[0, 40] * 4).half()
+    vt = v.permute(0, 2, 1).contiguous()
+    run = lambda: ops.attention(q.reshape(B * N, C).to(dev), k.reshape(B * L, C).to(dev), vt.to(dev), B=B, Nq=N, L=L, heads=heads, d=d, ldq=C, ldk=C,
+                                want_lse=True)
+    monkeypatch.setenv("AF_ATTN_NW", "4")
+    o4, l4 = run()
+    monkeypatch.setenv("AF_ATTN_NW", "8")
+    o8, l8 = run()
+    assert torch.equal(o4, o8) and torch.equal(l4, l8)
+    for _ in range(5):
+        o, l = run()
+        assert torch.equal(o, o8) and torch.equal(l, l8)
+    assert rel_l2(o8.float().cpu().reshape(B, N, C).numpy(), _attn_ref(q, k, v, heads).numpy()) < TOL
+
+
 def test_attention_scores_capture(dev):
     from adaface_dev_amd import ops
     B, N, L, heads, d = 2, 100, 77, 8, 40
