@@ -46,6 +46,8 @@ GEMM_GFLOP_PER_SAMPLE = 400.33 + 233.28 + 43.62   # SURVEY.md 8d / BASELINE.md s
 ATTN_GFLOP_PER_SAMPLE = 122.49 + 3.56
 UNET_GFLOP_PER_SAMPLE = 803.27
 MFMA_PEAK_TFLOPS = 2500.0                          # dense fp16/bf16, MI355X_MICROARCH.md
+VAE_DEC_TFLOP = 2.51                               # SD-1.5 KL-f8 decoder, one 64 x 64 latent -> 512 x 512 image, forward (conv / matmul FLOPs of the reference Decoder)
+FACE_TFLOP = 0.0034                                # ResNetFace-18 IR-SE on one 128 x 128 crop, forward
 HBM_PEAK_GBS = 8000.0
 # cross-attention core algorithmic bytes per U-Net sample (fp16): 2 B * (q + o: 2 N C, k + v: 2 T C) per layer,
 # layers: 5 x (N 4096, C 320), 5 x (1024, 640), 5 x (256, 1280), 1 x (64, 1280); T = 77
@@ -153,6 +155,8 @@ def build_train(args, ctx, dev, stage=1):
         ldm.cache_uncond_in_step = False
         ldm.skip_unread_cls_priming = False
         ldm.batch_no_grad_instances = False
+        ldm.share_no_grad_trunk = False          # (round 5's pass batching too: every gradient-free instance pass walks its own trunk,
+        ldm.batch_cond_with_uncond = False       #  prompt rows and null-prompt rows are separate U-Net calls, as the reference makes them)
     tr = DistillTrainer(ldm, id2ada.to(dev), text_enc.to(dev), batch_size=B, accumulate_grad_batches=2, prompt_len=97, stage=stage,
                         use_graphs=not args.no_train_graphs)
     if getattr(args, "reference_pass_structure", False):
@@ -189,6 +193,27 @@ def run_train(args, ctx, dev, stage=1):
     import torch.distributed as dist
     from adaface_dev_amd import _lib, ops
     tr, batches, step_kw, B, n_train, ldm, teacher, id2ada, text_enc = build_train(args, ctx, dev, stage)
+    # what the leg runs besides U-Net passes, counted as it runs (the FLOP count of the leg's roofline fraction below): images through the VAE decoder
+    # (forward; and those decoded WITH an input gradient, i.e. whose backward runs too) and face crops through ResNetFace-18
+    extra = {"vae_fwd_images": 0, "vae_grad_images": 0, "face_fwd_images": 0, "face_grad_images": 0}
+    if getattr(ldm, "first_stage_model", None) is not None:
+        _dec = ldm.first_stage_model.decode
+
+        def counting_decode(z, *a, **k):
+            extra["vae_fwd_images"] += int(z.shape[0])
+            if torch.is_grad_enabled() and z.requires_grad:
+                extra["vae_grad_images"] += int(z.shape[0])
+            return _dec(z, *a, **k)
+        ldm.first_stage_model.decode = counting_decode
+    if getattr(ldm, "arcface", None) is not None:
+        _face = ldm.arcface.arcface.forward
+
+        def counting_face(x, *a, **k):
+            extra["face_fwd_images"] += int(x.shape[0])
+            if torch.is_grad_enabled() and x.requires_grad:
+                extra["face_grad_images"] += int(x.shape[0])
+            return _face(x, *a, **k)
+        ldm.arcface.arcface.forward = counting_face
     steps = args.train_steps + (args.train_steps % 2)            # whole accumulation windows
     warm = max(2, args.train_warmup + (args.train_warmup % 2))
     losses = []
@@ -226,6 +251,8 @@ def run_train(args, ctx, dev, stage=1):
             _slack = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             del _slack
     seg0 = torch.cuda.memory_stats(dev).get("segment.all.allocated", 0)
+    for k in extra:
+        extra[k] = 0
     t0 = time.perf_counter()
     host_ms, seg_allocs = [], []
     for i in range(steps):
@@ -242,6 +269,7 @@ def run_train(args, ctx, dev, stage=1):
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    extra_timed = dict(extra)                         # counts of the timed region only
     gc.enable()
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -317,6 +345,16 @@ def run_train(args, ctx, dev, stage=1):
                         "priming U-Net 3-4 CFG steps + student 4 subject-compos steps x 4 prompts with capture of layers 22-24 + guidance passes + re-denoising of the subject-single instance, "
                         "x0 of the subject-single block decoded per step (the blocks the loss reads; image logging is out of scope), VAE decoder + ResNetFace-18 with input gradients, "
                         f"attention + FFN DoRA adapters, {n_train} trainable fp32 params, accumulate_grad_batches=2, CAdamW")
+        # + the VAE decoder and ResNetFace-18 passes the micro-batches ran (counted above): VAE_DEC_TFLOP per decoded 512 x 512 image forward (the
+        # reference Decoder under FLOP hooks), as much again where the input gradient is taken (dgrad convolutions only: the VAE is
+        # frozen); ResNetFace-18 IR-SE at 128 x 128: FACE_TFLOP per crop and direction
+        unet_tflop = train_tflop
+        vae_tflop = VAE_DEC_TFLOP * (extra_timed["vae_fwd_images"] + extra_timed["vae_grad_images"]) / steps
+        face_tflop = FACE_TFLOP * (extra_timed["face_fwd_images"] + extra_timed["face_grad_images"]) / steps
+        train_tflop = unet_tflop + vae_tflop + face_tflop
+        what += (f"; + {vae_tflop:.2f} TFLOP of VAE decoding ({extra_timed['vae_fwd_images'] / steps:.2f} images forward, {extra_timed['vae_grad_images'] / steps:.2f} with the "
+                 f"input-gradient backward, per micro-batch; {VAE_DEC_TFLOP} TFLOP per image and direction) + {face_tflop:.3f} TFLOP of ResNetFace-18 "
+                 f"({extra_timed['face_fwd_images'] / steps:.2f} crops forward per micro-batch) = {train_tflop:.2f} TFLOP per micro-batch: the fraction below is of the whole leg")
         out = {"metric": metric, "value": round(world * B * steps / elapsed, 3),
                "unit": "images/s", "n_gpus": world, "steps": steps, "warmup": warm, "ms_per_step": round(ms, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
@@ -333,6 +371,7 @@ def run_train(args, ctx, dev, stage=1):
                           "allocator_segments_per_micro_batch_in_timed_region": seg_allocs},
                "roofline": {"bound": "mfma", "achieved": round(train_tflop / (ms * 1e-3), 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                             "frac": round(train_tflop / (ms * 1e-3) / MFMA_PEAK_TFLOPS, 4), **train_traffic(stage, args),
+                            "tflop_per_micro_batch": {"unet": round(unet_tflop, 3), "vae_decoder": round(vae_tflop, 3), "resnetface18": round(face_tflop, 4)},
                             "what": what},
                "families_per_micro_batch": fam}
     del tr, ldm, teacher, id2ada, text_enc
@@ -567,8 +606,20 @@ def run_denoise(args, ctx, dev):
                 traffic = round(tj["gemm"]["bytes_per_step"] / g_n, 1)   # per af_gemm call, like `achieved`
                 traffic_src = os.path.basename(tpath)
                 break
+        # the same fraction from the kernels that produced ms_per_step: the rocprofv3 --kernel-trace summary of the GRAPH-REPLAYED leg (this pass is eager
+        # and instrumented, and runs the C = 320 cross-attention blocks as three launches: it reads ~5 % slower).  Counters / traces cannot be taken
+        # in-process: the committed measurement (tools/profile_round.sh -> tools/rocprof_frac.py) is reported while its sources hash matches this build
+        rocprof = None
+        for rpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_rocprof_frac.json")), reverse=True):
+            with open(rpath) as f:
+                rj = json.load(f)
+            if rj.get("sources_sha") == _lib.sources_sha():
+                rocprof = {k: rj[k] for k in ("file", "gemm_family_ms_per_step", "kernel_ms_per_step", "achieved_tflops", "frac", "what")}
+                rocprof["json"] = os.path.basename(rpath)
+                break
         roofline = {
-            "kernel": "af_gemm family: af_gemm3w_kernel / af_gemm3_kernel / af_gemm_kernel (conv3x3 implicit GEMM + linear + conv1x1)",
+            "kernel": "af_gemm family: af_conv3hd_kernel / af_gemm3w_kernel / af_gemm3_kernel / af_gemm_kernel (conv3x3 implicit GEMM + linear + conv1x1)",
+            "rocprof": rocprof,
             "bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
             "flops_per_launch": flops_step / g_n if g_n else None,
@@ -681,6 +732,7 @@ def main():
     ap.add_argument("--reference-pass-structure", action="store_true",
                     help="train legs: run every pass the reference runs (duplicate null-prompt pass, class-prompt pass on priming steps, SS / SR as separate "
                          "calls, all 16 x0 predictions decoded): the like-for-like run against BASELINE configs[2..4]; the default legs skip that work")
+    ap.add_argument("--no-reference-leg", action="store_true", help="train legs: do not also time the --reference-pass-structure form (the default line carries both)")
     ap.add_argument("--no-train-graphs", action="store_true", help="train leg: launch every kernel from Python instead of replaying captured segments")
     ap.add_argument("--sync-debug", default=None, metavar="FILE", help="train legs: write the Python stack of every host<->device synchronisation "
                     "of the timed micro-batches to FILE (torch.cuda.set_sync_debug_mode); the timing of such a run is not a result")
@@ -714,8 +766,8 @@ def main():
         done = threading.Event()
 
         def watchdog():
-            if not done.wait(900.0) and rank == 0:
-                res = dict(out or {}, train={"error": "train leg exceeded 900 s"})
+            if not done.wait(1200.0) and rank == 0:
+                res = dict(out or {}, train={"error": "train legs exceeded 1200 s"})
                 print(json.dumps(res), flush=True)
                 os._exit(3)
         threading.Thread(target=watchdog, daemon=True).start()
@@ -730,6 +782,24 @@ def main():
         lap("train leg")
         tr2 = leg(2) if args.mode in ("all", "train2") else None
         lap("train_stage2 leg")
+        if not args.reference_pass_structure and not args.no_reference_leg and not args.distill_only and not args.sync_debug:
+            # the like-for-like number beside the default one, in the same line (round-5 review): the same legs with every pass the reference runs,
+            # a shorter timed region, no instrumented pass
+            import copy
+            ref_args = copy.copy(args)
+            ref_args.reference_pass_structure, ref_args.no_roofline, ref_args.train_steps = True, True, min(args.train_steps, 8)
+            for res, stage in ((tr, 1), (tr2, 2)):
+                if isinstance(res, dict) and "error" not in res:
+                    try:
+                        r = run_train(ref_args, ctx, dev, stage=stage)
+                    except Exception as e:              # noqa: BLE001  (reported, not swallowed)
+                        r = {"error": f"{type(e).__name__}: {e}"}
+                    if rank == 0:
+                        res["reference_pass_structure"] = r if "error" in (r or {}) else {
+                            k: r[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup")} | {
+                            "pass_structure": r["config"]["pass_structure"], "per_iteration_type": r["config"]["per_iteration_type"],
+                            "tflop_per_micro_batch": r["roofline"]["tflop_per_micro_batch"], "frac": r["roofline"]["frac"]}
+                    lap(f"reference-pass-structure leg (stage {stage})")
         done.set()
         if args.mode == "train":
             out = tr

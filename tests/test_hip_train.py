@@ -851,6 +851,27 @@ def test_full_size_distill_loss_gradient_of_bs4_equals_its_bs1_slices(dev):
         assert e < 1.6e-2          # two fp16 passes against each other: each is within GRAD_TOL = 8e-3 of exact (tests/test_hip_unet.py)
         wsum = w1 if wsum is None else {k: wsum[k] + w1[k] for k in w1}
     assert abs(l4 - float(np.mean(l1s))) < 2e-3 * abs(l4)
+    # round 6: an ORACLE-side value at full size too (the round-5 review: the full-size training tests were property checks only).  The loss of sample 0
+    # run alone -- one student pass with the FFN adapters + one teacher pass of the full SD-1.5 U-Net in fp32 on the CPU (oracle/train_oracle.py
+    # unet_distill_loss over oracle/unet_oracle.py; ~10 s) -- against the bs-1 HIP value above.  Chained fp16 U-Nets: 5e-3 as at reduced width.
+    from oracle import diffusion_oracle as D
+    from oracle import train_oracle as T
+    from oracle import unet_oracle as O
+    with torch.no_grad():
+        sd_s = {k: v.detach().float().cpu() for k, v in ld.model.diffusion_model.state_dict().items()}
+        sd_t = {k: v.detach().float().cpu() for k, v in teacher.state_dict().items()}
+        ffn = {}
+        for bi, ads in lora.active("unet_distill").items():
+            ffn[f"output_blocks.{bi}.0."] = {key: (ad.lora_A.detach().float().cpu(), ad.lora_B.detach().float().cpu(), ad.lora_magnitude_vector.detach().float().cpu(),
+                                                   ad.scaling, None) for key, ad in ads.items()}
+        tabs = D.register_schedule(D.make_beta_schedule_linear())
+        c = lambda v: v[0:1].detach().float().cpu()
+        ref = T.unet_distill_loss(lambda x, tt, cc: O.unet_forward(sd_s, SD15_UNET_CONFIG, x, tt, cc, {"res_hidden_states_gradscale": 0.5, "ffn_lora": ffn}),
+                                  lambda x, tt, cc: O.unet_forward(sd_t, SD15_UNET_CONFIG, x, tt, cc, {}),
+                                  tabs, c(x0), c(noise), t[0:1].cpu(), c(sctx), c(tctx), c(fg), 1, [])
+    el = abs(l1s[0] - float(ref)) / abs(float(ref))
+    print(f"full size, sample 0: distillation loss {l1s[0]:.5f} (HIP) vs {float(ref):.5f} (CPU oracle), rel {el:.2e}")
+    assert el < 5e-3
     for k in w4:                                                      # adapter weight gradients add over the samples
         e = rel_l2(w4[k].float().cpu().numpy(), (wsum[k] / 4).float().cpu().numpy())
         assert e < 1.5e-2, (k, e)

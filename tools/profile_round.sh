@@ -23,6 +23,7 @@ print((idx[-1] - idx[-2]) * 10)
 PY
 )
 { echo "# rocprofv3 --kernel-trace --stats -- python3 bench.py --mode denoise --steps 20 --warmup 3 --no-cpu-baseline --no-roofline   (last 10 steps = $N dispatches)"; python3 tools/rocpd_summary.py $DB --last $N; } > $OUT/${TAG}_bench_kernel_stats.txt
+python3 tools/rocprof_frac.py $OUT/${TAG}_bench_kernel_stats.txt --json $OUT/${TAG}_rocprof_frac.json > $OUT/${TAG}_rocprof_frac.txt 2>&1
 # train legs: the last 3 optimizer steps (= 6 micro-batches, two 2,3,4-step cycles), delimited by the CAdamW kernels (one launch per arena)
 for LEG in train train2; do
   rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_ttrace -- python3 bench.py --mode $LEG --train-steps 12 --train-warmup 12 --no-cpu-baseline --no-roofline > $OUT/${TAG}_${LEG}_trace.log 2>&1
