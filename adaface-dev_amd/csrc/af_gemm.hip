@@ -674,7 +674,7 @@ extern "C" int af_gemm(const af_gemm_desc* d, void* stream) {
     AF_REQUIRE(d->c3 % 64 == 0 && d->c4 % 64 == 0, "af_gemm: c3 / c4 must be multiples of 64");
     AF_REQUIRE((d->lda3 == 0 || (d->lda3 >= d->c3 && d->lda3 % 8 == 0)) && (d->lda4 == 0 || (d->lda4 >= d->c4 && d->lda4 % 8 == 0)), "af_gemm: bad lda3 / lda4");
     AF_REQUIRE((d->stride == 0 || d->stride == 1) && d->upsample == 0 && d->tap_shift == 0, "af_gemm: the K tail needs stride 1, no upsample, no tap_shift");
-    AF_SUPPORTED((d->tile >= 7 && d->tile <= 13) || d->tile == 15, "af_gemm: the K tail runs on the whole-line tiles 7 .. 13 and 15 only");
+    AF_SUPPORTED((d->tile >= 7 && d->tile <= 15), "af_gemm: the K tail runs on the whole-line tiles 7 .. 13, 15 and the halo-resident tile 14 only");
   }
   AF_REQUIRE(d->K == d->taps * (d->c1 + d->c2) + d->c3 + d->c4, "af_gemm: K != taps*(c1+c2) (+ c3 + c4)");
   g_defer_reduce = nullptr;

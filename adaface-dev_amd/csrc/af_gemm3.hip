@@ -1411,6 +1411,7 @@ __global__ __launch_bounds__(512) void af_conv3h_kernel(const Gemm3Dev p) {
 //     scalar pointer per stage; a halo piece is one multiply-add (pixel x row pitch of the chunk's source) and lanes outside the image are switched
 //     off in EXEC instead of being pointed at the zero page -- their 16 bytes of both halo buffers are zeroed once in the prologue and never written.
 // Same stages, same hazards, same MFMA order as the kernel above: bit-identical results (tests compare the two).
+template <bool TAIL>                                              // TAIL: the K-concatenated 1x1 shortcut behind the chunks (its own instantiation: the plain kernel keeps its registers)
 __global__ __launch_bounds__(512) void af_conv3hd_kernel(const Gemm3Dev p) {
   constexpr int NWM = 4, NWN = 2, TN = 5, TM = 4, NW = 8, BM = CH_BM, BN = CH_BN;
   constexpr int APW = (CH_NP_MAX + NW - 1) / NW;                 // 7 halo pieces per wave at most
@@ -1441,8 +1442,20 @@ __global__ __launch_bounds__(512) void af_conv3hd_kernel(const Gemm3Dev p) {
   const int y0 = (m0 - bimg * p.HoWo) / Wd;
   const int prow = lane >> 3, slot = lane & 7;
   const int nc1 = p.c1 >> 6;
-  const int cb = blockIdx.y * p.kt_per_split;
-  const int ce = min((p.c1 + p.c2) >> 6, cb + p.kt_per_split);
+  // K tail (round 6: the ResBlock's 1x1 shortcut K-concatenated behind the nine tap blocks, af_gemm_desc.a3 / a4): ntail 64-column stages of plain rows
+  // (the tile's own 256 output pixels) behind the chunks.  They run in the LAST K split, and the chunk boundaries of the splits are placed so that every
+  // split has about the same number of stages (9 per chunk + the tail's).
+  const int nmain = (p.c1 + p.c2) >> 6, ntail = TAIL ? (p.c3 + p.c4) >> 6 : 0;
+  int cb, ce;
+  if (ntail == 0) {
+    cb = blockIdx.y * p.kt_per_split;
+    ce = min(nmain, cb + p.kt_per_split);
+  } else {
+    const int S = 9 * nmain + ntail, den = 9 * p.splits;
+    cb = blockIdx.y == 0 ? 0 : min(nmain, ((int)blockIdx.y * S + den / 2) / den);
+    ce = (int)blockIdx.y + 1 == p.splits ? nmain : min(nmain, (((int)blockIdx.y + 1) * S + den / 2) / den);
+  }
+  const bool tail_here = ntail > 0 && (int)blockIdx.y + 1 == p.splits;
 
   // ---- loaders.  Halo piece j of this wave = piece wave + 8 j: lane (prow, slot) fills physical chunk `slot` of halo pixel hp = piece * 8 + prow with the
   // pixel's logical chunk slot ^ (hp & 7) = slot ^ prow -- the same for every piece.  a_pix: the source pixel, -1 outside the image / the halo.
@@ -1460,13 +1473,17 @@ __global__ __launch_bounds__(512) void af_conv3hd_kernel(const Gemm3Dev p) {
   const unsigned chunk16 = (unsigned)((slot ^ prow) * 16);
   // weight piece j = rows (wave + 8 j) * 8 + prow of the tile; the row's physical chunk `slot` takes logical chunk slot ^ ((row >> 1) & 7), and
   // (row >> 1) & 7 does not depend on j: a per-lane byte offset from the stage's scalar pointer wt + k0
-  unsigned w_off[WPW];
+  // (piece j + 1 lies 64 rows behind piece j: the same per-lane offset from a scalar pointer 64 rows further on -- one register instead of three; the
+  // tile's rows exist in the packed weight: N % 160 == 0)
+  // TAIL instantiation only (it needs the two registers): the plain kernel keeps one offset per piece
+  unsigned w_off[TAIL ? 1 : WPW];
 #pragma unroll
-  for (int j = 0; j < WPW; ++j) {
+  for (int j = 0; j < (TAIL ? 1 : WPW); ++j) {
     const int row = (wave + NW * j) * 8 + prow;
-    const int n = min(tile_n * BN + row, p.npad - 1);
-    w_off[j] = ((unsigned)n * (unsigned)p.kpad + (unsigned)((slot ^ ((row >> 1) & 7)) * 8)) * 2u;
+    w_off[j] = ((unsigned)min(tile_n * BN + row, p.npad - 1) * (unsigned)p.kpad + (unsigned)((slot ^ ((row >> 1) & 7)) * 8)) * 2u;
   }
+  int kpad64 = p.kpad * 64;
+  if constexpr (TAIL) asm volatile("" : "+s"(kpad64));
   // kernel arguments the loop uses, as opaque scalar registers (left as kernarg loads they are re-loaded inside the loop, and every scalar load is
   // waited for with lgkmcnt(0), behind the fragment reads)
   const half_t *a1r = p.a1, *a2r = p.a2, *wtr = p.wt;
@@ -1480,14 +1497,29 @@ __global__ __launch_bounds__(512) void af_conv3hd_kernel(const Gemm3Dev p) {
   };
   auto issue_halo_piece = [&](int j, const half_t* src, int ld2, int buf_off) {
     if (wave + NW * j < NP)
-      glds16_sbase_masked(src, (unsigned)a_pix[j] * (unsigned)ld2 + chunk16, a_pix[j], af_smem + buf_off + (wave + NW * j) * 1024);
+      glds16_sbase_masked(src, (TAIL ? __umul24((unsigned)a_pix[j], (unsigned)ld2) : (unsigned)a_pix[j] * (unsigned)ld2) + chunk16, a_pix[j],
+                          af_smem + buf_off + (wave + NW * j) * 1024);   // (TAIL: pixel index, row pitch < 2^24)
   };
-  auto issue_w = [&](int u, int tap, int sl) {                       // this wave's weight pieces of the stage at (chunk u, tap), ring slot sl
-    const half_t* wb = wtr + (size_t)(tap * Cin + u * 64);
+  auto issue_wk = [&](int k0, int sl) {                              // this wave's weight pieces of the stage whose first weight column is k0, ring slot sl
+    const half_t* wb = wtr + (size_t)k0;
     char* Ws = af_smem + WBASE + sl * CH_WSZ;
 #pragma unroll
     for (int j = 0; j < WPW; ++j)
-      if (wave + NW * j < BN / 8) glds16_sbase(wb, w_off[j], Ws + (wave + NW * j) * 1024);
+      if (wave + NW * j < BN / 8) {
+        if constexpr (TAIL) glds16_sbase(wb + (size_t)j * kpad64, w_off[0], Ws + (wave + NW * j) * 1024);
+        else glds16_sbase(wb, w_off[j], Ws + (wave + NW * j) * 1024);
+      }
+  };
+  auto issue_w = [&](int u, int tap, int sl) { issue_wk(tap * Cin + u * 64, sl); };     // ... of the stage at (chunk u, tap)
+  // K-tail stage t: the tile's 256 rows x 64 columns of a3 | a4 as 32 pieces of 8 rows (wave w: pieces w + 8 j, j < 4), row q at q * 128 of the buffer,
+  // chunk index XOR (q & 7) = XOR prow: the same per-lane chunk as the halo pieces.  Every row is a valid output pixel (M % 256 == 0): no masking.
+  // (kernel arguments read where they are used, behind the main loop: nothing of the tail is live inside it -- the loop has no register to spare)
+  auto issue_tail_piece = [&](int j, int t, int buf_off) {
+    const bool first = t * 64 < p.c3;
+    const half_t* src = first ? p.a3 + t * 64 : p.a4 + (t * 64 - p.c3);
+    const unsigned ld2 = (unsigned)(first ? p.lda3 : p.lda4) * 2u;
+    const int pc = wave + NW * j;
+    glds16_sbase(src, (unsigned)(m0 + pc * 8 + prow) * ld2 + chunk16, af_smem + buf_off + pc * 1024);
   };
 
   floatx4 acc[TN][TM];
@@ -1641,13 +1673,56 @@ __global__ __launch_bounds__(512) void af_conv3hd_kernel(const Gemm3Dev p) {
     __builtin_amdgcn_s_barrier();
   }
 #undef CHD_READ_FRAGS
+  if (TAIL && tail_here) {
+    // ---- the K tail, lock step (every wave: wait, barrier, issue the next stage, 18 fragment reads, 40 MFMAs): a tail stage moves a whole 32 KB A tile
+    // + 20 KB of weights, the tap-by-tap tile's traffic, and one stage of look-ahead is all the three-slot ring and the two halo buffers allow.
+    // Stage 0's operands are requested here (every read and LDS-DMA of the main loop has retired behind its last barrier): one exposed round trip
+    // per launch; prefetching them under the last chunk would cost the main loop registers it does not have (it sits at 256).
+    int tb = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) issue_tail_piece(j, 0, tb);
+    issue_wk(9 * Cin, 0);
+    int ft[TM];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) ft[tm] = (wm * 64 + tm * 16 + fr) * 128 + ((fq ^ (fr & 7)) * 16);
+#pragma nounroll
+    for (int t = 0; t < ntail; ++t) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      const int tn_ = tb == 0 ? CH_ASZ : 0;
+      if (t + 1 < ntail) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) issue_tail_piece(j, t + 1, tn_);
+        issue_wk(9 * Cin + (t + 1) * 64, (t + 1) % 3);
+      }
+      const int ws = (t % 3) * CH_WSZ;
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) wf[tn] = *reinterpret_cast<const half8_t*>(af_smem + wr0 + ws + tn * 2048);
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) xf[tm] = *reinterpret_cast<const half8_t*>(af_smem + tb + ft[tm]);
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) wf1[tn] = *reinterpret_cast<const half8_t*>(af_smem + (wr0 ^ 64) + ws + tn * 2048);
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) xf1[tm] = *reinterpret_cast<const half8_t*>(af_smem + tb + (ft[tm] ^ 64));
+      __builtin_amdgcn_s_setprio(0);
+      mfmas();
+      __builtin_amdgcn_s_setprio(1);
+      tb = tn_;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                    // the staged epilogue reuses the LDS
+  }
   __builtin_amdgcn_s_setprio(0);
   gemm3_epilogue<E3_STD, NWM, NWN, TN, CH_LDS>(p, acc, af_smem, tile_m, tile_n, wm, wn, fr, fq, tid);
 }
 
 // scope of the halo-resident kernel
 static bool conv3h_eligible(const af_gemm_desc* d) {
-  if (d->taps != 9 || (d->upsample != 0 && d->upsample != 1) || d->tap_shift || d->c1 % 64 != 0 || d->c2 % 64 != 0 || d->c3 != 0 || d->c4 != 0 || d->N % CH_BN != 0) return false;
+  if (d->taps != 9 || (d->upsample != 0 && d->upsample != 1) || d->tap_shift || d->c1 % 64 != 0 || d->c2 % 64 != 0 || d->N % CH_BN != 0) return false;
+  if (d->c3 || d->c4) {                                            // K tail (round 6): plain rows of a3 | a4 on the output grid, whole 64-column stages
+    if (d->c3 <= 0 || d->c3 % 64 != 0 || d->c4 < 0 || d->c4 % 64 != 0 || d->a3 == nullptr || (d->c4 > 0 && d->a4 == nullptr) || d->upsample) return false;
+    if ((long)d->M * std::max(d->lda3 ? d->lda3 : d->c3, d->lda4 ? d->lda4 : d->c4) * 2 >= (1L << 32)) return false;
+  }
   const int up = d->upsample ? 2 : 1;                              // nearest x2 folded into the halo gather
   if ((d->stride ? d->stride : 1) != 1 || d->Ho != up * d->H || d->Wo != up * d->W) return false;
   if (d->Wo != 8 && d->Wo != 16 && d->Wo != 32 && d->Wo != 64) return false;
@@ -1682,10 +1757,14 @@ static bool launch_conv3h(const Gemm3Dev& p0, hipStream_t stream, bool r5_loop) 
   static const bool diet_env = !(getenv("AF_CONV3H_DIET") && atoi(getenv("AF_CONV3H_DIET")) == 0);    // A/B switch: 0 = the round-5 loop
   static const bool diet_dynamic = getenv("AF_GEMM3_ABLATE_DYNAMIC") != nullptr;
   const bool diet = diet_dynamic ? !(getenv("AF_CONV3H_DIET") && atoi(getenv("AF_CONV3H_DIET")) == 0) : diet_env;
-  if (diet && !r5_loop && (p.ablate & 63) == 0) {
-    static bool set_d = false;
-    if (af_allow_dyn_lds(reinterpret_cast<const void*>(&af_conv3hd_kernel), CH_LDS, set_d, "af_gemm"))
-      hipLaunchKernelGGL(af_conv3hd_kernel, grid, block, CH_LDS, stream, p);
+  if ((diet || p.c3 > 0) && !r5_loop && (p.ablate & 63) == 0) {
+    static bool set_d = false, set_t = false;
+    if (p.c3 > 0) {
+      if (af_allow_dyn_lds(reinterpret_cast<const void*>(&af_conv3hd_kernel<true>), CH_LDS, set_t, "af_gemm"))
+        hipLaunchKernelGGL(af_conv3hd_kernel<true>, grid, block, CH_LDS, stream, p);
+    } else if (af_allow_dyn_lds(reinterpret_cast<const void*>(&af_conv3hd_kernel<false>), CH_LDS, set_d, "af_gemm")) {
+      hipLaunchKernelGGL(af_conv3hd_kernel<false>, grid, block, CH_LDS, stream, p);
+    }
     return p.counters != nullptr;
   }
   switch (p.ablate & 63) {
@@ -1927,9 +2006,10 @@ int af_gemm3_try_launch(const af_gemm_desc* d, int splits, int wide, hipStream_t
   const bool halo_r5 = wide == 16;                              // tile 19: tile 14 with the round-5 main loop (A/B arm and bit-identity reference of tile 14)
   if (halo_r5) wide = 11;
   if (wide == 11 && !conv3h_eligible(d)) return 1;              // halo-resident 3x3 kernel (tile 14)
+  if (halo_r5 && d->c3 > 0) return 1;                           // (the K tail exists in the round-6 loop only)
   if (d->upsample && !((wide == 4 || wide == 5 || (wide >= 8 && wide <= 12)) && d->upsample == 1 && d->taps == 9)) return 1;   // nearest x2: whole-line kernel only
   if (d->c1 % BK3 != 0 || d->c2 % BK3 != 0 || d->zeros == nullptr) return 1;
-  if (d->c3 > 0 && (wide < 4 || (wide > 10 && wide != 12) || d->taps != 9 || d->upsample || (d->stride != 0 && d->stride != 1))) return 1;   // K tail: whole-line tap-by-tap tiles
+  if (d->c3 > 0 && (wide < 4 || (wide > 10 && wide != 12 && wide != 11) || d->taps != 9 || d->upsample || (d->stride != 0 && d->stride != 1))) return 1;   // K tail: whole-line tap-by-tap tiles + the halo-resident kernel
   if ((geglu || split_t) && (d->taps != 1 || splits > 1)) return 1;
   if (geglu && (!wide || d->N % (wide == 5 ? 128 : 256) != 0)) return 1;   // GEGLU: 128 x 256 tile, the 256-row tiles, or 128 x 128 whole-line
   if (!geglu && wide == 1 && d->N % 320 != 0) return 1;

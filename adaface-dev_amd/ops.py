@@ -171,8 +171,9 @@ def conv_halo_eligible(d) -> bool:
     """The scope of af_gemm tile 14, the halo-resident 3x3 kernel (include/adaface_hip.h); tools/autotune_gemm.py times it against the
     tap-by-tap tiles wherever this holds."""
     up = 2 if d.upsample else 1
-    return (d.taps == 9 and d.stride in (0, 1) and d.upsample in (0, 1) and not d.tap_shift and d.c1 % 64 == 0 and d.c2 % 64 == 0 and d.c3 == 0
-            and d.c4 == 0 and d.N % 160 == 0 and d.Wo in (8, 16, 32, 64) and _halo_rows_ok(d.Ho, d.Wo) and d.M % 256 == 0 and d.Ho == up * d.H
+    tail_ok = (d.c3 == 0 and d.c4 == 0) or (d.c3 > 0 and d.c3 % 64 == 0 and d.c4 % 64 == 0 and not d.upsample)     # round 6: the K-concatenated 1x1 shortcut
+    return (d.taps == 9 and d.stride in (0, 1) and d.upsample in (0, 1) and not d.tap_shift and d.c1 % 64 == 0 and d.c2 % 64 == 0 and tail_ok
+            and d.N % 160 == 0 and d.Wo in (8, 16, 32, 64) and _halo_rows_ok(d.Ho, d.Wo) and d.M % 256 == 0 and d.Ho == up * d.H
             and d.Wo == up * d.W and d.act != AF_ACT_GEGLU and d.out_mode == AF_OUT_NORMAL)
 
 
@@ -505,7 +506,7 @@ def conv3x3_skip_tile(M: int, N: int, cin: int, ktail: int):
     else what the table says for the plain convolution of the same shape (the tail only lengthens K), else a whole-line default."""
     for K in (9 * cin + ktail, 9 * cin):
         t = tune_table().get(f"9,{M},{N},{K},0,0,1,0")
-        if t is not None and 7 <= t[0] <= 13:
+        if t is not None and 7 <= t[0] <= 14:          # (14: the halo-resident kernel takes the tail since round 6; conv3x3 falls back inside the library outside its scope)
             return t
     return (7 if (N % 320 == 0 and M >= 8192) else (11 if N % 160 == 0 else 8)), 1
 
@@ -558,6 +559,10 @@ def conv3x3(x: torch.Tensor, pw: PackedWeight, *, x2: Optional[torch.Tensor] = N
         d.a3, d.a4, d.c3, d.c4, d.lda3, d.lda4 = _p(s1), _p(s2), c3, c4, c3, c4
         if tile == 0 and splits == 0 and _tune_recorder is None:
             tile, splits = conv3x3_skip_tile(d.M, d.N, c1 + c2, pw.k_tail)
+            if tile == 14 and not conv_halo_eligible(d):
+                # the table's key has no image geometry: tile 14 on a latent outside its scope (W not 8 / 16 / 32 / 64, ragged rows) would fall back to
+                # the register-staged kernel inside the library, which has no K tail -- take a whole-line tap-by-tap tile instead
+                tile, splits = (7 if (d.N % 320 == 0 and d.M >= 8192) else (11 if d.N % 160 == 0 else 8)), 1
     gn = _launch_gemm(d, x.device, "af_gemm(conv3x3)", tile, splits, gn_cpg=gn_cpg,
                       defer_gn=(out, pw.bias, rowbias, residual) if defer_gn else None)
     if gn is not None:

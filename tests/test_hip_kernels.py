@@ -158,7 +158,11 @@ def test_conv3x3_tile14_halo_resident(dev, B, H, W, cin, cout, splits, extras):
 @pytest.mark.parametrize("B,H,W,cin,cs1,cs2,cout,tile,splits", [
     (1, 64, 64, 320, 640, 320, 320, 7, 1), (2, 32, 32, 640, 640, 640, 640, 7, 2), (2, 16, 16, 1280, 1280, 1280, 1280, 7, 4), (2, 32, 32, 640, 320, 0, 640, 8, 1),
     (2, 16, 16, 128, 64, 64, 160, 11, 1), (1, 12, 20, 64, 128, 0, 128, 8, 3), (2, 16, 16, 128, 64, 64, 160, 13, 2), (2, 8, 8, 192, 64, 0, 128, 12, 1),
-    (3, 8, 8, 1280, 1280, 1280, 1280, 8, 4)])
+    (3, 8, 8, 1280, 1280, 1280, 1280, 8, 4),
+    # round 6: the halo-resident kernel (tile 14) takes the K tail too -- its 3x3 part on the ping-pong loop, the tail as lock-step stages behind it, in the
+    # last K split; chunk boundaries balanced over the splits (incl. a split that holds the tail only)
+    (1, 64, 64, 320, 640, 320, 320, 14, 1), (2, 32, 32, 640, 640, 640, 640, 14, 2), (2, 16, 16, 1280, 1280, 1280, 1280, 14, 4), (4, 8, 8, 1280, 1280, 1280, 1280, 14, 4),
+    (2, 16, 16, 128, 64, 64, 160, 14, 1), (2, 32, 32, 640, 320, 0, 640, 14, 3), (1, 16, 16, 64, 640, 640, 160, 14, 3), (1, 64, 64, 64, 64, 0, 160, 14, 1)])
 def test_conv3x3_with_k_concatenated_1x1_skip(dev, B, H, W, cin, cs1, cs2, cout, tile, splits):
     """out = conv3x3(h) + conv1x1(cat(x1, x2)) as ONE launch (af_gemm_desc.a3 / a4: the ResBlock's second convolution with its channel-changing
     skip_connection K-concatenated behind the nine tap blocks, openaimodel.py:256-276) against torch in fp32 and against the two-launch form;
@@ -185,6 +189,8 @@ def test_conv3x3_with_k_concatenated_1x1_skip(dev, B, H, W, cin, cs1, cs2, cout,
                   a2=None if x2 is None else x2d.reshape(B * H * W, cs2))
     out2 = ops.conv3x3(h.to(dev), ops.pack_conv3x3(w3, b3, dev), residual=sk.reshape(B, H, W, cout), tile=8)
     assert rel_l2(out.float().cpu().numpy(), out2.float().cpu().numpy()) < 2e-3
+    for _ in range(5):                                   # repeated launches: bit-stable (the hand-offs between the loops are ordered by barriers)
+        assert torch.equal(ops.conv3x3(h.to(dev), pw, skip=(x1.to(dev), x2d), tile=tile, splits=splits), out)
     # outside the whole-line tiles the descriptor is refused, never silently mis-computed
     with pytest.raises(RuntimeError, match="K tail"):
         ops.conv3x3(h.to(dev), pw, skip=(x1.to(dev), x2d), tile=2)
@@ -330,6 +336,30 @@ def test_conv3x3_statistics_request_on_a_geometry_outside_tile14(dev):
     out = ops.groupnorm(y, torch.ones(c, device=dev), torch.zeros(c, device=dev), 1e-5, True)
     gref = F.silu(F.group_norm(y[:1].float().cpu().permute(0, 3, 1, 2), 32, None, None, 1e-5)).permute(0, 2, 3, 1)
     assert rel_l2(out[:1].float().cpu().numpy(), gref.numpy()) < TOL
+
+
+def test_conv3x3_with_skip_on_a_geometry_outside_tile14_takes_a_tap_by_tap_tile(dev):
+    """Round 6: the table gives the conv2 + shortcut launches of the 64 x 64 level to the halo-resident kernel (tile 14, key `9,32768,320,3520`: no image
+    geometry in it).  The same key at a latent tile 14 cannot take (8 x 32 x 128: W = 128) must not reach the library's register-staged fallback, which has
+    no K tail: ops.conv3x3 picks a whole-line tap-by-tap tile there."""
+    from adaface_dev_amd import ops
+    B, H, W, cin, cs, cout = 8, 32, 128, 320, 640, 320
+    assert ops.tune_table().get(f"9,{B * H * W},{cout},{9 * cin + cs},0,0,1,0", (0, 1))[0] == 14, "this test is about the table's tile-14 entry for the tail key"
+    h, x1 = rnd((B, H, W, cin), 1), rnd((B, H, W, cs), 2)
+    w3, w1 = rnd((cout, cin, 3, 3), 3, (9 * cin) ** -0.5), rnd((cout, cs, 1, 1), 4, cs ** -0.5)
+    pw = ops.pack_conv3x3_skip(w3, None, w1, None, dev)
+    out = ops.conv3x3(h.to(dev), pw, skip=(x1.to(dev), None), gn_cpg=cout // 32)
+    ref = F.conv2d(h.float().permute(0, 3, 1, 2)[:1], w3.float(), None, padding=1) + F.conv2d(x1.float().permute(0, 3, 1, 2)[:1], w1.float())
+    assert rel_l2(out[:1].float().cpu().permute(0, 3, 1, 2).numpy(), ref.numpy()) < TOL
+    # and on the geometry tile 14 takes, the table's choice runs there and leaves the GroupNorm statistics
+    h2, x2 = rnd((8, 64, 64, cin), 5), rnd((8, 64, 64, cs), 6)
+    out2 = ops.conv3x3(h2.to(dev), pw, skip=(x2.to(dev), None), gn_cpg=cout // 32)
+    assert ops.partials_of(out2) is not None
+    ref2 = F.conv2d(h2.float().permute(0, 3, 1, 2)[:1], w3.float(), None, padding=1) + F.conv2d(x2.float().permute(0, 3, 1, 2)[:1], w1.float())
+    assert rel_l2(out2[:1].float().cpu().permute(0, 3, 1, 2).numpy(), ref2.numpy()) < TOL
+    gn = ops.groupnorm(out2, torch.ones(cout, device=dev), torch.zeros(cout, device=dev), 1e-5, True)
+    gref = F.silu(F.group_norm(out2[:1].float().cpu().permute(0, 3, 1, 2), 32, None, None, 1e-5)).permute(0, 2, 3, 1)
+    assert rel_l2(gn[:1].float().cpu().numpy(), gref.numpy()) < TOL
 
 
 @pytest.mark.parametrize("B,H,W,with_bias", [(2, 16, 16, True), (1, 64, 64, True), (3, 16, 8, False), (8, 32, 32, True)])

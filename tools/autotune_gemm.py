@@ -47,8 +47,8 @@ def candidate_ok(d, tile, splits, _lib, ops):
         return False
     if tile in (5, 6) and (d.taps != 1 or d.out_mode != 0 or d.M * d.N < 256 * 256 * 128 or splits > 1):
         return False                        # 256-row ring tiles: plain / GEGLU 1x1 GEMMs with at least ~128 tiles
-    if (d.c3 or d.c4) and not (7 <= tile <= 13 or tile == 15):
-        return False                        # the K-concatenated 1x1 tail lives in the whole-line tiles
+    if (d.c3 or d.c4) and not (7 <= tile <= 15):
+        return False                        # the K-concatenated 1x1 tail lives in the whole-line tiles and (round 6) the halo-resident kernel
     if d.ln_colsum and (tile < 7 or tile in (14, 15) or splits > 1 or (tile in (9, 10) and not geglu)):
         return False                        # folded LayerNorm: whole-line tiles, unsplit
     f32 = d.out_mode == _lib.AF_OUT_F32     # weight gradients: fp32 from the reduce pass, or unsplit from tiles 1 / 2
