@@ -1459,12 +1459,18 @@ __global__ __launch_bounds__(512) void af_conv3hd_kernel(const Gemm3Dev p) {
 
   // ---- loaders.  Halo piece j of this wave = piece wave + 8 j: lane (prow, slot) fills physical chunk `slot` of halo pixel hp = piece * 8 + prow with the
   // pixel's logical chunk slot ^ (hp & 7) = slot ^ prow -- the same for every piece.  a_pix: the source pixel, -1 outside the image / the halo.
+  // (index divisions by the float reciprocal: floor((x + 0.5) / d) is exact for these ranges -- x < 4096, and (2 x + 1) / (2 d) is at least 1 / (2 d) away
+  // from an integer while the product's error is below (x + 0.5) * 2e-7 / d -- at 4 vector instructions instead of the ~25 of an integer division; the
+  // kernel's prologue was ~900 of them, a fifth of a short launch: profiles/r06j)
+  const float inv_blk = __builtin_amdgcn_rcpf((float)blk_px), inv_wh = __builtin_amdgcn_rcpf((float)Wh), inv_wd = __builtin_amdgcn_rcpf((float)Wd),
+              inv_hi = __builtin_amdgcn_rcpf((float)Hi);
+  auto fdiv = [](int x, float inv) { return (int)(((float)x + 0.5f) * inv); };
   int a_pix[APW];
 #pragma unroll
   for (int j = 0; j < APW; ++j) {
     const int hp = (wave + NW * j) * 8 + prow;
-    const int im = hp / blk_px, hq = hp - im * blk_px;
-    const int hy = hq / Wh, hx = hq - hy * Wh;
+    const int im = fdiv(hp, inv_blk), hq = hp - im * blk_px;
+    const int hy = fdiv(hq, inv_wh), hx = hq - hy * Wh;
     const int iy = y0 - 1 + hy, ix = hx - 1;
     const bool ok = hp < halo_px && (unsigned)iy < (unsigned)Hd && (unsigned)ix < (unsigned)Wd;
     const int sy = p.upsample ? iy >> 1 : iy, sx = p.upsample ? ix >> 1 : ix;
@@ -1534,7 +1540,7 @@ __global__ __launch_bounds__(512) void af_conv3hd_kernel(const Gemm3Dev p) {
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
     const int q = wm * 64 + tm * 16 + fr;
-    const int r = q / Wd, im = r / Hi;
+    const int r = fdiv(q, inv_wd), im = fdiv(r, inv_hi);
     const int hpb = im * blk_px + (r - im * Hi) * Wh + (q - r * Wd);
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
