@@ -32,7 +32,7 @@ EXPORTS = (
     "af_layernorm_param_grads", "af_transpose_tokens_pair", "af_ff_fused", "af_xattn_fused",
     "af_softmax_rows_bwd", "af_affine_prelu_bwd", "af_maxpool2x2_bwd", "af_se_gate_grad", "af_se_residual_prelu_bwd",
     "af_groupnorm_apply", "af_gemm_gn_stats_ok", "af_gn_proj_fused",
-    "af_splitk_reduce", "af_groupnorm_splitk_ok", "af_groupnorm_splitk",
+    "af_splitk_reduce", "af_groupnorm_splitk_ok", "af_groupnorm_splitk", "af_xattn_chain",
 )
 
 
@@ -187,6 +187,7 @@ def lib() -> C.CDLL:
     L.af_cadamw_step.argtypes = [vp, vp, vp, vp, vp, i32, vp, f32, f32, f32, f32, f32, i32, i32, vp]
     L.af_ff_fused.argtypes = [vp, vp, vp, vp, f32, i32, vp, vp, i32, vp, vp, i32, i32, i32, vp, vp]
     L.af_xattn_fused.argtypes = [vp, vp, vp, vp, f32, i32, vp, i32, vp, i64, i32, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, f32, vp, vp]
+    L.af_xattn_chain.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp, vp, f32, i32, vp, i32, vp, i64, i32, vp, vp, i32, vp, i32, i32, i32, i32, i32, f32, vp, vp]
     for name in EXPORTS:
         if name != "af_last_error":
             getattr(L, name).restype = C.c_int

@@ -640,9 +640,11 @@ int launch_attn2chain(const AttnArgs& a, hipStream_t stream) {
     return af_check_launch("af_attention(two-chain, 8 waves)");
   }
   static bool attr_set = false;  // benign race: idempotent attribute
-  if (!af_allow_dyn_lds(reinterpret_cast<const void*>(&af_attn2_kernel<DS, ONES, SLOT>), lds, attr_set, "af_attention")) return af_check_launch("af_attention");
+  // AF_ATTN_LDS_PAD (experiments only): extra dynamic LDS per workgroup, e.g. 90000 leaves room for ONE 4-wave workgroup per CU (one wave per SIMD)
+  static const size_t pad = getenv("AF_ATTN_LDS_PAD") ? (size_t)atol(getenv("AF_ATTN_LDS_PAD")) : 0;
+  if (!af_allow_dyn_lds(reinterpret_cast<const void*>(&af_attn2_kernel<DS, ONES, SLOT>), lds + pad, attr_set, "af_attention")) return af_check_launch("af_attention");
   const int qblocks = (a.Nq + 255) / 256;
-  hipLaunchKernelGGL((af_attn2_kernel<DS, ONES, SLOT>), dim3(qblocks * bh8), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL((af_attn2_kernel<DS, ONES, SLOT>), dim3(qblocks * bh8), dim3(256), lds + pad, stream, a);
   return af_check_launch("af_attention(two-chain)");
 }
 

@@ -52,6 +52,14 @@ struct XaDev {
   int M, N, L, kpad_q, kpad_o, ldk, ldv, ln_on;
   long vbs;
   float ln_eps, scale_log2e;
+  // chained form (af_xattn_chain, round 6): the self-attention's output projection runs in FRONT of this block, x = ao W_1^T + b_1 + x0, so `x` is an OUTPUT
+  // (the tile's rows are stored there and read back by the same lanes as the final residual); nullptr / 0 otherwise
+  const half_t* ao;        // [M][320] self-attention output (the A operand of phase 0)
+  const half_t* w1;        // packed [>= 320][kpad_1]: attn1.to_out
+  const float* b1;         // [320] or nullptr
+  const half_t* x0;        // [M][320]: the transformer block's input (phase 0's residual)
+  half_t* x1;              // [M][320]: phase 0's result (scratch the caller owns)
+  int kpad_1;
 };
 
 __global__ __launch_bounds__(512, 1) void af_xattn320_kernel(const XaDev p) {
@@ -345,7 +353,11 @@ __device__ __forceinline__ floatx4 mfma_k16(const half4_t& a, const half4_t& b, 
 #endif
 }
 
-template <int NT>
+// PRE (round 6): the self-attention's to_out + residual as phase 0 in front (attention.py:242-252: x = attn1(norm1(x)) + x, then attn2 ...): the tile R first
+// holds the self-attention output, a 2 x 4 wave GEMM over it on the weight ring (W_1, five stages) gives x1 = ao W_1^T + b_1 + x0, which is stored to
+// memory (the final residual: every lane reads back exactly the elements it stored, phase C has the same wave -> tile mapping) AND into R in the swizzled
+// fp16 layout phase A reads -- one launch of `1,32768,320,320` (25 us, a 21 MB write and two 21 MB reads) less per transformer block of the 64 x 64 level.
+template <int NT, bool PRE = false>
 __global__ __launch_bounds__(512, 1) void af_xattn320t_kernel(const XaDev p) {
   constexpr int NW = 8;
   extern __shared__ __attribute__((aligned(16))) char af_smem[];
@@ -380,12 +392,77 @@ __global__ __launch_bounds__(512, 1) void af_xattn320t_kernel(const XaDev p) {
       glds16(w + (size_t)row * kpad + st * 64 + lc * 8, dst + pc * 1024);
     }
   };
-  issue_x();
-  issue_w(p.wq, p.kpad_q, 0, 0);
-  issue_w(p.wq, p.kpad_q, 1, 1);
-
   // fragment offsets inside a [rows x 128 B] block whose 16-row groups start at EVEN rows ((row >> 1) & 7 == ((row0 >> 1) + (fr >> 1)) & 7)
   auto frag_off = [&](int row0, int kk) { return (row0 + fr) * 128 + (((kk * 4 + fq) ^ (((row0 + fr) >> 1) & 7)) * 16); };
+  if constexpr (PRE) {
+    // ================= phase 0: x1 [128 x 320] = ao W_1^T + b_1 + x0, 2 x 4 waves of 64 x 80 (the layout of phase C)
+#pragma unroll
+    for (int j = 0; j < 10; ++j) {                      // the self-attention output tile -> R (as issue_x)
+      const int pc = wave + NW * j, c = pc >> 4, row = (pc & 15) * 8 + prow;
+      const int lc = slot ^ ((row >> 1) & 7);
+      const int m = m0 + row;
+      glds16(m < p.M ? p.ao + (size_t)m * XA_C + c * 64 + lc * 8 : p.zeros, R + c * (XA_BM * 128) + (pc & 15) * 1024);
+    }
+    issue_w(p.w1, p.kpad_1, 0, 0);
+    issue_w(p.w1, p.kpad_1, 1, 1);
+    const int wm0 = wave & 1, wn0 = wave >> 1;
+    floatx4 a0[5][4];
+#pragma unroll
+    for (int tn = 0; tn < 5; ++tn)
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm) a0[tn][tm] = zf;
+#pragma nounroll
+    for (int st = 0; st < 5; ++st) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (st >= 1 && st + 1 < 5) issue_w(p.w1, p.kpad_1, st + 1, (st + 1) & 1);
+      const char* Ws = RING + (st & 1) * XT_STAGE;
+      const char* As = R + st * (XA_BM * 128);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        half8_t wf[5], xf[4];
+#pragma unroll
+        for (int tn = 0; tn < 5; ++tn) wf[tn] = *reinterpret_cast<const half8_t*>(Ws + frag_off(wn0 * 80 + tn * 16, kk));
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm) xf[tm] = *reinterpret_cast<const half8_t*>(As + frag_off(wm0 * 64 + tm * 16, kk));
+#pragma unroll
+        for (int tn = 0; tn < 5; ++tn)
+#pragma unroll
+          for (int tm = 0; tm < 4; ++tm) a0[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[tn], xf[tm], a0[tn][tm], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_s_barrier();                       // every wave has read the last of ao and of W_1: R may take x1, the ring W_q
+    issue_w(p.wq, p.kpad_q, 0, 0);                      // ... whose first two stages arrive under the epilogue below
+    issue_w(p.wq, p.kpad_q, 1, 1);
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm) {
+      const int row = wm0 * 64 + tm * 16 + fr, m = m0 + row;
+#pragma unroll
+      for (int tn = 0; tn < 5; ++tn) {
+        const int c = wn0 * 80 + tn * 16 + 4 * fq;
+        floatx4 v = a0[tn][tm];
+        half4_t o = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+        if (m < p.M) {
+          if (p.b1) {
+            const floatx4 b = *reinterpret_cast<const floatx4*>(p.b1 + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += b[e];
+          }
+          const half4_t rr = *reinterpret_cast<const half4_t*>(p.x0 + (size_t)m * XA_C + c);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += (float)rr[e];
+          o = half4_t{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+          *reinterpret_cast<half4_t*>(p.x1 + (size_t)m * XA_C + c) = o;
+        }
+        *reinterpret_cast<half4_t*>(R + (c >> 6) * (XA_BM * 128) + row * 128 + ((((c & 63) >> 3) ^ ((row >> 1) & 7)) * 16) + ((c >> 2) & 1) * 8) = o;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's part of x1 is in R before the barrier at the top of phase A
+  } else {
+    issue_x();
+    issue_w(p.wq, p.kpad_q, 0, 0);
+    issue_w(p.wq, p.kpad_q, 1, 1);
+  }
 
   // ================= phase A: Q_h^T [48 x 128] = W_q,h x^T
   floatx4 qa[3][8];
@@ -630,8 +707,9 @@ __global__ __launch_bounds__(512, 1) void af_xattn320t_kernel(const XaDev p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] += b[e];
       }
-      if (p.residual) {
-        const half4_t rr = *reinterpret_cast<const half4_t*>(p.residual + (size_t)m * XA_C + c);
+      const half_t* res = PRE ? p.x1 : p.residual;      // PRE: what this very lane stored in phase 0
+      if (res) {
+        const half4_t rr = *reinterpret_cast<const half4_t*>(res + (size_t)m * XA_C + c);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] += (float)rr[e];
       }
@@ -812,7 +890,7 @@ extern "C" int af_xattn_fused(const void* x, const void* wq, const void* bq, con
   AF_SUPPORTED(L > 0 && L <= 80, "af_xattn_fused: at most 80 keys");
   AF_REQUIRE(kpad_q >= C && kpad_q % 64 == 0 && kpad_o >= C && kpad_o % 64 == 0, "af_xattn_fused: weight row strides must be 64-multiples covering C");
   AF_REQUIRE(ldk >= C && ldk % 8 == 0 && ldv >= L && ldv % 8 == 0 && vt_batch_stride % 8 == 0, "af_xattn_fused: K / V^T strides must keep 16-byte alignment");
-  XaDev p;
+  XaDev p{};
   p.x = (const half_t*)x;
   p.wq = (const half_t*)wq;
   p.bq = (const float*)bq;
@@ -850,6 +928,57 @@ extern "C" int af_xattn_fused(const void* x, const void* wq, const void* bq, con
   }
   hipLaunchKernelGGL(af_xattn320_kernel, dim3(p.M / XA_BM), dim3(512), XA_LDS, (hipStream_t)stream, p);
   return af_check_launch("af_xattn_fused");
+}
+
+// The chained form: the self-attention's output projection + residual in front of the block (af_xattn320t_kernel<2, true>).  ao = the self-attention
+// core's output, w1 / b1 = attn1.to_out, x0 = the transformer block's input; x1 = ao W_1^T + b_1 + x0 is written to the caller's scratch `x1` and is both
+// the cross-attention's input and its residual.  The other arguments as af_xattn_fused (which has no residual argument here: it is x1).
+extern "C" int af_xattn_chain(const void* ao, const void* w1, const void* b1, int kpad_1, const void* x0, void* x1, const void* wq, const void* bq,
+                              const void* ln_colsum, float ln_eps, int kpad_q, const void* k, int ldk, const void* vt, int64_t vt_batch_stride, int ldv,
+                              const void* wo, const void* bo, int kpad_o, void* out, int B, int N, int L, int C, int heads, float scale, const void* zeros,
+                              void* stream) {
+  AF_REQUIRE(ao && w1 && x0 && x1 && wq && k && vt && wo && out && zeros, "af_xattn_chain: null pointer");
+  AF_SUPPORTED(C == XA_C && heads == XA_H, "af_xattn_chain: built for C = 320, 8 heads (the 64 x 64 level of SD-1.5)");
+  AF_REQUIRE(B > 0 && N > 0 && N % XA_BM == 0, "af_xattn_chain: tokens per image must be a positive multiple of 128");
+  AF_SUPPORTED(L > 0 && L <= 80, "af_xattn_chain: at most 80 keys");
+  AF_REQUIRE(kpad_1 >= C && kpad_1 % 64 == 0 && kpad_q >= C && kpad_q % 64 == 0 && kpad_o >= C && kpad_o % 64 == 0, "af_xattn_chain: weight row strides must be 64-multiples covering C");
+  AF_REQUIRE(ldk >= C && ldk % 8 == 0 && ldv >= L && ldv % 8 == 0 && vt_batch_stride % 8 == 0, "af_xattn_chain: K / V^T strides must keep 16-byte alignment");
+  AF_REQUIRE((((uintptr_t)ao | (uintptr_t)x0 | (uintptr_t)x1 | (uintptr_t)out | (uintptr_t)b1) & 15) == 0 && x1 != out && x1 != x0 && x1 != ao,
+             "af_xattn_chain: ao / x0 / x1 / out / b1 must be 16-byte aligned and x1 a buffer of its own");
+  XaDev p{};
+  p.ao = (const half_t*)ao;
+  p.w1 = (const half_t*)w1;
+  p.b1 = (const float*)b1;
+  p.kpad_1 = kpad_1;
+  p.x0 = (const half_t*)x0;
+  p.x1 = (half_t*)x1;
+  p.x = (const half_t*)x1;
+  p.wq = (const half_t*)wq;
+  p.bq = (const float*)bq;
+  p.cs = (const float*)ln_colsum;
+  p.ln_on = ln_colsum != nullptr;
+  p.k = (const half_t*)k;
+  p.vt = (const half_t*)vt;
+  p.wo = (const half_t*)wo;
+  p.bo = (const float*)bo;
+  p.residual = (const half_t*)x1;
+  p.out = (half_t*)out;
+  p.zeros = (const half_t*)zeros;
+  p.M = B * N;
+  p.N = N;
+  p.L = L;
+  p.kpad_q = kpad_q;
+  p.kpad_o = kpad_o;
+  p.ldk = ldk;
+  p.ldv = ldv;
+  p.vbs = (long)vt_batch_stride;
+  p.ln_eps = ln_eps;
+  p.scale_log2e = scale * 1.4426950408889634f;
+  static bool attr_t = false;
+  if (!af_allow_dyn_lds(reinterpret_cast<const void*>(&af_xattn320t_kernel<2, true>), XT_LDS, attr_t, "af_xattn_chain")) return af_check_launch("af_xattn_chain");
+  AfLaunchScope scope(AF_FAM_XATTN, stream);
+  hipLaunchKernelGGL((af_xattn320t_kernel<2, true>), dim3(p.M / XA_BM), dim3(512), XT_LDS, (hipStream_t)stream, p);
+  return af_check_launch("af_xattn_chain");
 }
 
 // GroupNorm(32) of a single-source tensor whose partial statistics exist (af_gemm_desc.gn_partials) + the 1x1 convolution / Linear behind it at

@@ -32,6 +32,7 @@ from .diffusionmodules.util import (Conv2d, GroupNorm32, LayerNorm, Linear, _Pac
 # LayerNorm -> Linear pairs of the inference pass run as ONE GEMM (ops.pack_matrix_ln); AF_FOLD_LAYERNORM=0 keeps the separate kernels (A/B runs)
 FOLD_LAYERNORM = _os.environ.get("AF_FOLD_LAYERNORM", "1") != "0"
 FUSE_GN_PROJ = _os.environ.get("AF_FUSE_GN_PROJ", "1") != "0"      # SpatialTransformer: GroupNorm's normalising pass + proj_in in one launch at C = 320 (af_gn_proj_fused)
+CHAIN_XATTN = _os.environ.get("AF_CHAIN_XATTN", "1") != "0"    # round 6: the self-attention's to_out + residual as phase 0 of the one-launch C = 320 cross-attention block (af_xattn_chain)
 XATTN_FUSE_MIN_TOKENS = int(_os.environ.get("AF_XATTN_FUSE_MIN_TOKENS", "8192"))   # U-Net batch x tokens from which the one-launch block is used
 FUSE_XATTN = _os.environ.get("AF_FUSE_XATTN", "1") != "0"      # the C = 320 cross-attention block as ONE launch (af_xattn_fused): on par with the
                                                                 # three launches alone, -0.03 ms per denoise step (csrc/af_xattn_fused.hip); 0 = three launches
@@ -184,7 +185,12 @@ class CrossAttention(nn.Module):
         return self._q_cache_ln.get((self.to_q.weight, ln.weight, ln.bias), lambda: ops.pack_matrix_ln(
             self.to_q.weight, None, ln.weight, ln.bias, ln.eps, self.to_q.weight.device))
 
-    def hip(self, x2d, B, N, context=None, keybias=None, residual=None, ln=None):
+    def xattn_fusable(self, C, B, N, L, ln) -> bool:
+        """Whether this (cross-attention) layer runs as the one-launch C = 320 block (af_xattn_fused / af_xattn_chain)."""
+        return bool(FUSE_XATTN and ln is not None and self.inner_dim == 320 and C == 320 and self.heads == 8 and not self.save_cross_attn_vars
+                    and N % 128 == 0 and L <= 80 and B * N >= XATTN_FUSE_MIN_TOKENS)
+
+    def hip(self, x2d, B, N, context=None, keybias=None, residual=None, ln=None, defer_out=False, pre=None):
         """x2d [B*N, C] fp16; context [B, L, Cc] fp16 or None (self-attention); keybias fp32
         [B, roundup(L,64)] or None; residual [B*N, C] added after to_out.  ``ln``: the LayerNorm whose output this layer's query
         (and, for self-attention, key / value) projection consumes -- x2d is then the UN-normalised input and the normalisation is
@@ -203,8 +209,12 @@ class CrossAttention(nn.Module):
                 k, vt, ldk = self._kv_pre
             else:
                 k, vt = ops.gemm(context.reshape(B * L, context.shape[-1]), self._packed_kv(), rows_per_batch=L, split_col=Ci)
-            if (FUSE_XATTN and ln is not None and Ci == 320 and x2d.shape[1] == 320 and h == 8 and keybias is None and not self.save_cross_attn_vars
-                    and N % 128 == 0 and L <= 80 and B * N >= XATTN_FUSE_MIN_TOKENS):
+            if pre is not None:
+                # round 6: the self-attention's output projection + residual chained in front (BasicTransformerBlock.hip decided with xattn_fusable):
+                # pre = (self-attention core output, attn1.to_out pack, the block's input)
+                ao, pw_o1, x0 = pre
+                return ops.xattn_chain(ao, pw_o1, x0, self._packed_q_ln(ln), k, vt, self.to_out[0].packed(), B=B, N=N, L=L, heads=h, scale=self.scale, ldk=ldk)
+            if keybias is None and self.xattn_fusable(x2d.shape[1], B, N, L, ln):
                 # the 64 x 64 level: q projection (norm2 folded in), the 77-key core, to_out and the residual as ONE launch over 128-token tiles
                 # that stay in LDS (af_xattn_fused, tiled form); worth it once the 128-token workgroups cover enough of the chip
                 return ops.xattn_fused(x2d, self._packed_q_ln(ln), k, vt, self.to_out[0].packed(), B=B, N=N, L=L, heads=h, scale=self.scale,
@@ -232,6 +242,8 @@ class CrossAttention(nn.Module):
             }
             if residual is None:
                 return out_plain
+        if defer_out and not self.save_cross_attn_vars:
+            return o, self.to_out[0].packed(), residual          # the consumer (the chained cross-attention block) runs to_out + residual itself
         return self.to_out[0].hip(o, residual=residual)
 
     # ---- training mode: row-major q|k|v kept for the flash backward
@@ -313,6 +325,12 @@ class BasicTransformerBlock(nn.Module):
             # 8 x 8 level) the q | k | v and to_q GEMMs sit on the register-staged 64 x 64 tile, which has no fold, and a 3.8 us LayerNorm
             # is cheaper than moving them to a whole-line tile (profiles/r03d_lnfold_runtime_flag.txt: +2.5 .. +4.0 us folded)
             small = x2d.shape[0] < 1024
+            if (CHAIN_XATTN and not small and context is not None and not self.attn1.save_cross_attn_vars 
+                    and self.attn2.xattn_fusable(x2d.shape[1], B, N, context.shape[1], self.norm2)):
+                # the 64 x 64 level: attn1's to_out + residual run as phase 0 of the one-launch cross-attention block (af_xattn_chain)
+                pre = self.attn1.hip(x2d, B, N, None, keybias, residual=x2d, ln=self.norm1, defer_out=True)
+                x2 = self.attn2.hip(None, B, N, context, None, residual=None, ln=self.norm2, pre=pre)
+                return self.ff.hip(x2, residual=x2, ln=self.norm3)
             x1 = self.attn1.hip(self.norm1.hip(x2d) if small else x2d, B, N, None, keybias, residual=x2d, ln=None if small else self.norm1)
             x2 = self.attn2.hip(self.norm2.hip(x1) if small else x1, B, N, context, None, residual=x1, ln=None if small else self.norm2)
             return self.ff.hip(x2, residual=x2, ln=self.norm3)

@@ -611,6 +611,25 @@ def xattn_fused(x2d: torch.Tensor, pw_q: PackedWeight, k: torch.Tensor, vt: torc
     return out
 
 
+def xattn_chain(ao: torch.Tensor, pw_o1: PackedWeight, x0: torch.Tensor, pw_q: PackedWeight, k: torch.Tensor, vt: torch.Tensor, pw_o: PackedWeight, *,
+                B: int, N: int, L: int, heads: int, scale: float, ldk: int) -> torch.Tensor:
+    """af_xattn_chain: the self-attention's output projection + residual (ao, pw_o1, x0) in front of the C = 320 cross-attention block, one launch.
+    Returns the block's output; the intermediate x1 = ao W1^T + b1 + x0 lives in a scratch tensor of this call."""
+    _chk_f16(ao, "xattn_chain.ao")
+    _chk_f16(x0, "xattn_chain.x0")
+    M, Cn = ao.shape
+    assert M == B * N and x0.shape == ao.shape and pw_o1.N == Cn and pw_o1.K == Cn and pw_q.N == Cn and pw_o.N == Cn and pw_o.K == Cn
+    assert vt.stride(2) == 1 and k.stride(1) == 1 and pw_o1.ln_cs is None
+    x1 = torch.empty_like(ao)
+    out = torch.empty_like(ao)
+    _pf_note(pw_o1.wt, pw_q.wt, pw_o.wt)
+    rc = _lib.lib().af_xattn_chain(_p(ao), _p(pw_o1.wt), _p(pw_o1.bias), pw_o1.kpad, _p(x0), _p(x1), _p(pw_q.wt), _p(pw_q.bias), _p(pw_q.ln_cs), float(pw_q.ln_eps),
+                                   pw_q.kpad, _p(k), int(ldk), _p(vt), int(vt.stride(0)), int(vt.stride(1)), _p(pw_o.wt), _p(pw_o.bias), pw_o.kpad, _p(out), B, N, L, Cn,
+                                   heads, float(scale), _zero_page(ao.device).data_ptr(), _stream())
+    _lib.check(rc, "af_xattn_chain")
+    return out
+
+
 def _grow_scratch(cache: dict, device, need: int, dtype, floor: int = 0) -> torch.Tensor:
     """Per-device scratch that grows on demand.  A hipGraph bakes in the address of whatever buffer a captured launch was given, and
     growing the cached buffer frees the old one -- so while the current stream is CAPTURING the scratch comes from the capturing graph's

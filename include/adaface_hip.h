@@ -216,6 +216,16 @@ int af_xattn_fused(const void* x, const void* wq, const void* bq, const void* ln
                    const void* vt, int64_t vt_batch_stride, int ldv, const void* wo, const void* bo, int kpad_o, const void* residual,
                    void* out, int B, int N, int L, int C, int heads, float scale, const void* zeros, void* stream);
 
+/* The same block with the SELF-attention's output projection chained in front (round 6; attention.py:242-252: x = attn1(norm1(x)) + x; x = attn2(norm2(x),
+ * context) + x): x1 = ao W1^T + b1 + x0 is formed by the launch itself -- ao [B * N][C] the self-attention core's output, w1 / b1 attn1.to_out packed as for
+ * af_gemm, x0 the transformer block's input -- written to the caller's scratch x1 [B * N][C] (a buffer of its own) and used as the cross-attention's
+ * input AND residual; out = x1 + bo + Wo . attention(LN(x1) Wq^T, K, V).  One `[B * N, 320] x [320, 320]` launch and three passes over that tensor
+ * less per transformer block.  The other arguments as af_xattn_fused. */
+int af_xattn_chain(const void* ao, const void* w1, const void* b1, int kpad_1, const void* x0, void* x1, const void* wq, const void* bq,
+                   const void* ln_colsum, float ln_eps, int kpad_q, const void* k, int ldk, const void* vt, int64_t vt_batch_stride, int ldv,
+                   const void* wo, const void* bo, int kpad_o, void* out, int B, int N, int L, int C, int heads, float scale, const void* zeros,
+                   void* stream);
+
 /* PADDED LEADING DIMENSIONS -- the contract for every entry point that takes an ld larger than the logical extent (k / q rows wider than heads*d,
  * vt rows of ldv >= L keys, keybias rows of ldb >= L, out2 rows of ld_out2 >= rows_per_batch): a consumer NEVER lets bytes outside the logical
  * extent reach a result -- they may be uninitialised memory (NaN, Inf) -- and a producer that owns a padded output row (af_gemm's AF_OUT_SPLIT_T

@@ -1199,6 +1199,65 @@ def test_attention_online_softmax_rescale_branch(dev, N):
     assert rel_l2(o.float().cpu().reshape(B, N, C).numpy(), ref.numpy()) < TOL
 
 
+@pytest.mark.parametrize("B,N,L", [(2, 4096, 77), (8, 1024, 77), (1, 8192, 80), (3, 3072, 50)])
+def test_xattn_chain_c320_transformer_block(dev, B, N, L, monkeypatch):
+    """Round 6, af_xattn_chain: the self-attention's output projection + residual as phase 0 of the one-launch C = 320 cross-attention block.  A whole
+    BasicTransformerBlock.hip (attention.py:242-252: LayerNorm-folded q | k | v, self-attention, to_out + x, cross-attention on 77 keys + x, GEGLU
+    feed-forward + x) with the chain against the same block without it (one more GEMM launch, x1 through memory) and against fp32 torch; ragged key
+    counts; B * N from one 128-token tile per CU downwards; repeated launches bit-stable."""
+    from adaface_dev_amd.ldm.modules import attention as A
+    C, Cc = 320, 768
+    blk = A.BasicTransformerBlock(C, 8, 40, context_dim=Cc).to(dev)
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        for n, p in blk.named_parameters():
+            if p.dim() == 2:
+                p.copy_(torch.randn(p.shape, generator=g) * p.shape[1] ** -0.5)
+            elif "norm" in n and n.endswith("weight"):
+                p.copy_(torch.randn(p.shape, generator=g) * 0.2 + 1)
+            else:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.1)
+    x, _, _ = _ln_inputs(B * N, C, seed=11)
+    ctx = rnd((B, L, Cc), 12)
+    monkeypatch.setattr(A, "XATTN_FUSE_MIN_TOKENS", 0)
+
+    def run(chain):
+        monkeypatch.setattr(A, "CHAIN_XATTN", chain)
+        return blk.hip(x.to(dev), B, N, ctx.to(dev), None)
+    y0 = run(False)
+    calls = {"n": 0}
+    from adaface_dev_amd import ops
+    real = ops.xattn_chain
+
+    def spy(*a, **k):
+        calls["n"] += 1
+        return real(*a, **k)
+    monkeypatch.setattr(ops, "xattn_chain", spy)
+    y1 = run(True)
+    assert calls["n"] == 1, "the chained launch was expected to run"
+    for _ in range(3):
+        assert torch.equal(run(True), y1)
+    assert rel_l2(y1.float().cpu().numpy(), y0.float().cpu().numpy()) < TOL
+    # fp32 reference of the block
+    P = {n: p.detach().float().cpu() for n, p in blk.named_parameters()}
+    xf = x.float()
+
+    def attn(xq, kv, pre):
+        q = (xq @ P[pre + "to_q.weight"].t()).reshape(B, -1, 8, 40).permute(0, 2, 1, 3)
+        kk = (kv @ P[pre + "to_k.weight"].t()).reshape(B, -1, 8, 40).permute(0, 2, 1, 3)
+        vv = (kv @ P[pre + "to_v.weight"].t()).reshape(B, -1, 8, 40).permute(0, 2, 1, 3)
+        o = torch.softmax(q @ kk.transpose(-1, -2) * 40 ** -0.5, dim=-1) @ vv
+        return o.permute(0, 2, 1, 3).reshape(-1, C) @ P[pre + "to_out.0.weight"].t() + P[pre + "to_out.0.bias"]
+    ln = lambda v, n: F.layer_norm(v, (C,), P[n + ".weight"], P[n + ".bias"], 1e-5)
+    h = ln(xf, "norm1").reshape(B, N, C)
+    x1 = attn(h, h, "attn1.") + xf
+    x2 = attn(ln(x1, "norm2").reshape(B, N, C), ctx.float(), "attn2.") + x1
+    hp = ln(x2, "norm3") @ P["ff.net.0.proj.weight"].t() + P["ff.net.0.proj.bias"]
+    a, gte = hp.chunk(2, dim=-1)
+    ref = (a * F.gelu(gte)) @ P["ff.net.2.weight"].t() + P["ff.net.2.bias"] + x2
+    assert rel_l2(y1.float().cpu().numpy(), ref.numpy()) < 2 * TOL      # three chained fp16 sub-blocks
+
+
 @pytest.mark.parametrize("B,N,L,heads,d", [(1, 4096, 4096, 2, 40), (2, 1024, 1024, 8, 40), (3, 512, 320, 4, 40), (1, 1536, 256, 3, 40)])
 def test_self_attention_eight_wave_workgroups_bit_identical(dev, B, N, L, heads, d, monkeypatch):
     """Round 6: the two-chain self-attention kernel with 8-wave workgroups (512 queries, one workgroup per CU, the SIMD partners at a static
