@@ -28,7 +28,7 @@
 #include "af_common.h"
 
 #ifndef AF_ATTN_NW_DEFAULT
-#define AF_ATTN_NW_DEFAULT 4
+#define AF_ATTN_NW_DEFAULT 8
 #endif
 
 namespace {

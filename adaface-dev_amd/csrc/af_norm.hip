@@ -455,6 +455,24 @@ __global__ __launch_bounds__(256) void gn_small_kernel(GnArgs a) {
     s *= 2.f;                                           // the sums were taken over (x - p) / 2
     q *= 4.f;
   }
+  // gamma / beta of this thread's chunks: requested BEFORE the reduction (they do not depend on the statistics; loaded behind it they were one more
+  // dependent memory round trip in a launch that is nothing but a chain of them).  A thread's chunk index cycles with period cpb / gcd(dr, cpb): every
+  // item's own registers when the launch needs few items (the slab-fed forms, IT <= 5), the first chunk's otherwise re-loaded per item as before
+  constexpr bool kHoist = GS_IT <= 5;
+  floatx4 hg0[kHoist ? GS_IT : 1], hg1[kHoist ? GS_IT : 1], hb0[kHoist ? GS_IT : 1], hb1[kHoist ? GS_IT : 1];
+  if constexpr (kHoist) {
+    int ch = ch0;
+#pragma unroll
+    for (int u = 0; u < GS_IT; ++u) {
+      const int c = c0 + ch * 8;
+      hg0[u] = *reinterpret_cast<const floatx4*>(a.gamma + c);
+      hg1[u] = *reinterpret_cast<const floatx4*>(a.gamma + c + 4);
+      hb0[u] = *reinterpret_cast<const floatx4*>(a.beta + c);
+      hb1[u] = *reinterpret_cast<const floatx4*>(a.beta + c + 4);
+      ch += dr;
+      if (ch >= cpb) ch -= cpb;
+    }
+  }
   s = af_wave_sum(s);
   q = af_wave_sum(q);
   if (lane == 0) {
@@ -477,8 +495,13 @@ __global__ __launch_bounds__(256) void gn_small_kernel(GnArgs a) {
   for (int u = 0; u < GS_IT; ++u) {
     if (t + 256 * u < items) {
       const int c = c0 + ch * 8;
-      const floatx4 g0 = *reinterpret_cast<const floatx4*>(a.gamma + c), g1 = *reinterpret_cast<const floatx4*>(a.gamma + c + 4);
-      const floatx4 b0 = *reinterpret_cast<const floatx4*>(a.beta + c), b1 = *reinterpret_cast<const floatx4*>(a.beta + c + 4);
+      floatx4 g0, g1, b0, b1;
+      if constexpr (kHoist) {
+        g0 = hg0[u], g1 = hg1[u], b0 = hb0[u], b1 = hb1[u];
+      } else {
+        g0 = *reinterpret_cast<const floatx4*>(a.gamma + c), g1 = *reinterpret_cast<const floatx4*>(a.gamma + c + 4);
+        b0 = *reinterpret_cast<const floatx4*>(a.beta + c), b1 = *reinterpret_cast<const floatx4*>(a.beta + c + 4);
+      }
       half8_t o;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -763,7 +786,10 @@ extern "C" int af_groupnorm_stats(const void* x1, const void* x2, int c1, int c2
   // small tensors: one launch, one workgroup per (batch item, group)
   static const bool no_small = getenv("AF_GN_NO_SMALL") != nullptr;      // A/B switch
   if (!no_small && a.cpg % 8 == 0 && (c2 == 0 || c1 % a.cpg == 0) && (long)HW * (a.cpg / 8) <= 256L * GS_IT) {
-    hipLaunchKernelGGL(gn_small_kernel<false>, dim3(groups, B), dim3(256), 0, s, a);
+    const long nu = ((long)HW * (a.cpg / 8) + 255) / 256;     // items per thread: the instantiation with that many registers' worth of gamma / beta hoisted
+    if (nu <= 2) hipLaunchKernelGGL((gn_small_kernel<false, 2>), dim3(groups, B), dim3(256), 0, s, a);
+    else if (nu <= 5) hipLaunchKernelGGL((gn_small_kernel<false, 5>), dim3(groups, B), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((gn_small_kernel<false>), dim3(groups, B), dim3(256), 0, s, a);
     return af_check_launch("af_groupnorm(small)");
   }
   static const bool no_pair = getenv("AF_GN_NO_PAIR") != nullptr;        // A/B switch
