@@ -31,7 +31,7 @@ EXPORTS = (
     "af_xattn_scores", "af_xattn_softmax_pv", "af_xattn_softmax_pv_bwd", "af_xattn_rowmix", "af_xattn_colmix_ws_bytes", "af_xattn_colmix",
     "af_layernorm_param_grads", "af_transpose_tokens_pair", "af_ff_fused", "af_xattn_fused",
     "af_softmax_rows_bwd", "af_affine_prelu_bwd", "af_maxpool2x2_bwd", "af_se_gate_grad", "af_se_residual_prelu_bwd",
-    "af_groupnorm_apply", "af_gemm_gn_stats_ok", "af_gn_proj_fused",
+    "af_groupnorm_apply", "af_gemm_gn_stats_ok", "af_gemm_halo_variant", "af_gn_proj_fused",
     "af_splitk_reduce", "af_groupnorm_splitk_ok", "af_groupnorm_splitk", "af_xattn_chain",
 )
 
@@ -127,6 +127,7 @@ def lib() -> C.CDLL:
     L.af_groupnorm.argtypes = [vp, vp, i32, i32, vp, vp, vp, i32, i32, i32, f32, i32, vp, vp]
     L.af_groupnorm_apply.argtypes = [vp, i32, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp, i32, vp]
     L.af_gemm_gn_stats_ok.argtypes = [i32, i32, i32, i32, i32, i32, i32, i32]
+    L.af_gemm_halo_variant.argtypes = [C.POINTER(GemmDesc)]
     L.af_splitk_reduce.argtypes = [vp, i32, vp, vp, i32, i32, vp, vp, i32, i32, vp]
     L.af_groupnorm_splitk_ok.argtypes = [i32, i32, i32, i32]
     L.af_groupnorm_splitk.argtypes = [vp, i32, vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp]

@@ -651,7 +651,7 @@ int af_gemm3_effective_splits(const af_gemm_desc* d, int splits, int wide);
 
 extern "C" int af_gemm_gn_stats_ok(int tile, int splits, int taps, int act, int out_mode, int N, int cpg, int rows_per_batch) {
   if (tile == 19) tile = 14;                         // the round-5 loop of the halo-resident kernel: same tile, same epilogue
-  const int bn = tile == 7 ? 320 : ((tile == 11 || tile == 13 || tile == 14) ? 160 : 0);
+  const int bn = tile == 7 ? 320 : ((tile == 11 || tile == 13) ? 160 : (tile == 14 ? (N % 160 == 0 ? 160 : 128) : 0));   // (tile 14: 256 x 160, or 256 x 128 where N is no 160-multiple)
   if (bn == 0 || splits > 1 || (taps != 1 && taps != 9) || act == AF_ACT_GEGLU || out_mode != AF_OUT_NORMAL) return 0;
   if (tile == 14 && (taps != 9 || rows_per_batch % 256 != 0)) return 0;      // the halo-resident kernel's tile is 256 rows of one image
   if (cpg <= 0 || cpg % 2 != 0 || bn % cpg != 0 || N % cpg != 0 || N / cpg > 32 || N % bn != 0 || N % 8 != 0) return 0;

@@ -56,6 +56,8 @@ struct Gemm3Dev {
   int gn_cpg;
   int wpf;              // whole-line kernel: weight-tile L2 prefetch at kernel start, wave instructions per wave (0 = off; AF_GEMM3_WPREFETCH)
   int wpf_coop;         // workgroups that share one weight tile and split its prefetch (min(tiles_m, 32))
+  int patch_tx;         // halo-resident kernel, PATCH form (images wider than 64 pixels): 16 x 16-pixel tiles, patch_tx of them per image row, patch_tpi per image
+  int patch_tpi;
 };
 
 constexpr int BK3 = 32;
@@ -120,10 +122,19 @@ enum { E3_STD = 0, E3_GEGLU = 1, E3_SPLIT_T = 2 };
 
 // Epilogue shared by the ring kernel and the whole-line kernel: split-K partial tiles, or bias / row bias / activation / residual
 // (identical arithmetic to af_gemm.hip's standard epilogue), GEGLU, transposed-V split.  LDSB = bytes of LDS the main loop owned.
-template <int EPI, int NWM, int NWN, int TN, int LDSB>
+template <int EPI, int NWM, int NWN, int TN, int LDSB, bool PATCH = false>
 __device__ __forceinline__ void gemm3_epilogue(const Gemm3Dev& p, floatx4 (&acc)[TN][4], char* af_smem, int tile_m, int tile_n, int wm, int wn,
                                                int fr, int fq, int tid, const float* lnst = nullptr) {
   constexpr int TM = 4, NW = NWM * NWN, BM = NWM * 64, BN = NWN * TN * 16;
+  // PATCH (halo-resident kernel on images wider than 64 pixels): the tile's 256 rows are a 16 x 16-pixel patch of one image, local row q = pixel
+  // (q >> 4, q & 15) of the patch; staged standard epilogue without split-K only (the host guarantees it)
+  int patch_m0 = 0;
+  if constexpr (PATCH) {
+    const int im = tile_m / p.patch_tpi, t = tile_m - im * p.patch_tpi;
+    const int py = t / p.patch_tx, px = t - py * p.patch_tx;
+    patch_m0 = (im * p.Ho + py * 16) * p.Wo + px * 16;
+  }
+  auto tile_row = [&](int row) { return PATCH ? patch_m0 + (row >> 4) * p.Wo + (row & 15) : tile_m * BM + row; };
   if (lnst != nullptr) {
     // LayerNorm folded into this GEMM: acc = x . (gamma W)^T of the UN-normalised rows; LN(x) W^T = rstd * (acc - mean * colsum) (+ b + W beta,
     // which is the packed bias).  lnst[row] = (mean, rstd) of the tile's rows, written by the main loop's statistics waves.
@@ -232,13 +243,13 @@ __device__ __forceinline__ void gemm3_epilogue(const Gemm3Dev& p, floatx4 (&acc)
   constexpr int BNO = EPI == E3_GEGLU ? BN / 2 : BN;          // output columns of the tile
   constexpr int TS = BNO + 8;                                  // staging row stride (halves): 16 bytes of padding
   constexpr bool kCanStage = (EPI == E3_STD || EPI == E3_GEGLU) && (size_t)BM * TS * 2 <= (size_t)LDSB;
-  if (kCanStage && p.stage_ok && !(p.ablate & 32)) {
+  if (kCanStage && (PATCH || (p.stage_ok && !(p.ablate & 32)))) {
     __syncthreads();                                           // every wave is done reading the last ring slot
     half_t* T = reinterpret_cast<half_t*>(af_smem);
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
       const int row = wm * 64 + tm * 16 + fr;
-      const int m = tile_m * BM + row;
+      const int m = tile_row(row);
       const bool mok = m < p.M;
       const int bidx = (p.rowbias && mok) ? m / p.rows_per_batch : 0;
       if (EPI == E3_GEGLU) {
@@ -355,7 +366,7 @@ __device__ __forceinline__ void gemm3_epilogue(const Gemm3Dev& p, floatx4 (&acc)
     const int ncols = EPI == E3_GEGLU ? (p.N >> 1) : p.N;
     for (int c = tid; c < BM * CPR; c += 64 * NW) {
       const int row = c / CPR, cc = c - row * CPR;
-      const int m = tile_m * BM + row, n = tile_n * BNO + cc * 8;
+      const int m = tile_row(row), n = tile_n * BNO + cc * 8;
       if (m < p.M && n < ncols)
         *reinterpret_cast<half8_t*>(p.out + (size_t)m * p.ld_out + n) = *reinterpret_cast<const half8_t*>(T + row * TS + cc * 8);
     }
@@ -1411,11 +1422,16 @@ __global__ __launch_bounds__(512) void af_conv3h_kernel(const Gemm3Dev p) {
 //     scalar pointer per stage; a halo piece is one multiply-add (pixel x row pitch of the chunk's source) and lanes outside the image are switched
 //     off in EXEC instead of being pointed at the zero page -- their 16 bytes of both halo buffers are zeroed once in the prologue and never written.
 // Same stages, same hazards, same MFMA order as the kernel above: bit-identical results (tests compare the two).
-template <bool TAIL>                                              // TAIL: the K-concatenated 1x1 shortcut behind the chunks (its own instantiation: the plain kernel keeps its registers)
+// TN_ = 4 (round 6, the VAE's channel counts: 128-multiples that are no 160-multiples): a 256 x 128 tile, 16 KB weight stages.  PATCH (images wider than 64
+// pixels: the VAE decoder's 128 / 256 / 512 levels): the tile is a 16 x 16-pixel patch of one image (halo 18 x 18 = 324 pixels, 41 pieces) instead of whole
+// image rows; everything else -- stages, hazards, MFMA order per output element -- as before.
+template <bool TAIL, int TN_ = 5, bool PATCH = false>             // TAIL: the K-concatenated 1x1 shortcut behind the chunks (its own instantiation: the plain kernel keeps its registers)
 __global__ __launch_bounds__(512) void af_conv3hd_kernel(const Gemm3Dev p) {
-  constexpr int NWM = 4, NWN = 2, TN = 5, TM = 4, NW = 8, BM = CH_BM, BN = CH_BN;
+  constexpr int NWM = 4, NWN = 2, TN = TN_, TM = 4, NW = 8, BM = CH_BM, BN = NWN * TN * 16;
+  constexpr int WSZ = BN * 128;                                  // one weight stage (CH_WSZ at TN = 5)
+  static_assert(!(TAIL && (PATCH || TN_ != 5)), "the K tail exists in the 256 x 160 whole-rows form only");
   constexpr int APW = (CH_NP_MAX + NW - 1) / NW;                 // 7 halo pieces per wave at most
-  constexpr int WPW = (BN / 8 + NW - 1) / NW;                    // 3 weight pieces per wave at most (20 pieces)
+  constexpr int WPW = (BN / 8 + NW - 1) / NW;                    // 3 weight pieces per wave at most (20 pieces; 2 of 16 at TN = 4)
   constexpr int WBASE = 2 * CH_ASZ;                              // the weight ring behind the two halo buffers
   extern __shared__ __attribute__((aligned(16))) char af_smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1434,12 +1450,21 @@ __global__ __launch_bounds__(512) void af_conv3hd_kernel(const Gemm3Dev p) {
       tile_n = lid - tile_m * p.tiles_n;
     }
   }
-  const int Wd = p.Wo, Hd = p.Ho, Wh = Wd + 2, R = BM / Wd;
-  const int Hi = min(R, Hd), nimg = R / Hi, blk_px = (Hi + 2) * Wh;
+  // whole-rows form: the tile = R whole rows of one image (or R / Ho whole images); Wd = the tile's width in pixels.  PATCH: a 16 x 16 patch at (y0, x0)
+  const int Wd = PATCH ? 16 : p.Wo, Hd = p.Ho, Wh = Wd + 2, R = BM / Wd;
+  const int Hi = PATCH ? 16 : min(R, Hd), nimg = R / Hi, blk_px = (Hi + 2) * Wh;
   const int halo_px = nimg * blk_px, NP = (halo_px + 7) >> 3;
   const int m0 = tile_m * BM;
-  const int bimg = m0 / p.HoWo;
-  const int y0 = (m0 - bimg * p.HoWo) / Wd;
+  int bimg, y0, x0 = 0;
+  if constexpr (PATCH) {
+    bimg = tile_m / p.patch_tpi;
+    const int t = tile_m - bimg * p.patch_tpi, py = t / p.patch_tx;
+    y0 = py * 16;
+    x0 = (t - py * p.patch_tx) * 16;
+  } else {
+    bimg = m0 / p.HoWo;
+    y0 = (m0 - bimg * p.HoWo) / Wd;
+  }
   const int prow = lane >> 3, slot = lane & 7;
   const int nc1 = p.c1 >> 6;
   // K tail (round 6: the ResBlock's 1x1 shortcut K-concatenated behind the nine tap blocks, af_gemm_desc.a3 / a4): ntail 64-column stages of plain rows
@@ -1471,8 +1496,8 @@ __global__ __launch_bounds__(512) void af_conv3hd_kernel(const Gemm3Dev p) {
     const int hp = (wave + NW * j) * 8 + prow;
     const int im = fdiv(hp, inv_blk), hq = hp - im * blk_px;
     const int hy = fdiv(hq, inv_wh), hx = hq - hy * Wh;
-    const int iy = y0 - 1 + hy, ix = hx - 1;
-    const bool ok = hp < halo_px && (unsigned)iy < (unsigned)Hd && (unsigned)ix < (unsigned)Wd;
+    const int iy = y0 - 1 + hy, ix = x0 + hx - 1;
+    const bool ok = hp < halo_px && (unsigned)iy < (unsigned)Hd && (unsigned)ix < (unsigned)p.Wo;
     const int sy = p.upsample ? iy >> 1 : iy, sx = p.upsample ? ix >> 1 : ix;
     a_pix[j] = ok ? ((bimg + im) * p.H + sy) * p.W + sx : -1;
   }
@@ -1508,7 +1533,7 @@ __global__ __launch_bounds__(512) void af_conv3hd_kernel(const Gemm3Dev p) {
   };
   auto issue_wk = [&](int k0, int sl) {                              // this wave's weight pieces of the stage whose first weight column is k0, ring slot sl
     const half_t* wb = wtr + (size_t)k0;
-    char* Ws = af_smem + WBASE + sl * CH_WSZ;
+    char* Ws = af_smem + WBASE + sl * WSZ;
 #pragma unroll
     for (int j = 0; j < WPW; ++j)
       if (wave + NW * j < BN / 8) {
@@ -1552,7 +1577,7 @@ __global__ __launch_bounds__(512) void af_conv3hd_kernel(const Gemm3Dev p) {
   if (p.wpf > 0 && p.splits == 1)
     // (the dump goes to weight slot 2, which nothing fills before the first barrier: every wave's dump loads have landed by then -- its own vmcnt(0) --
     // while a dump in halo buffer 1, as in the kernel above, could land on a pad position AFTER another wave has zeroed it)
-    af_prefetch_weight_tile(p.wt, p.kpad, p.npad, tile_n * BN, BN, 0, p.kpad >> 6, p.wpf_coop, tile_m % p.wpf_coop, p.wpf, NW, wave, lane, af_smem + WBASE + 2 * CH_WSZ);
+    af_prefetch_weight_tile(p.wt, p.kpad, p.npad, tile_n * BN, BN, 0, p.kpad >> 6, p.wpf_coop, tile_m % p.wpf_coop, p.wpf, NW, wave, lane, af_smem + WBASE + 2 * WSZ);
 
   const int grp = wave >> 2;
   half8_t wf[TN], xf[TM], wf1[TN], xf1[TM];
@@ -1570,7 +1595,7 @@ __global__ __launch_bounds__(512) void af_conv3hd_kernel(const Gemm3Dev p) {
   };
 #define CHD_READ_FRAGS(TAP)                                                                                                      \
   {                                                                                                                              \
-    constexpr int wsl_ = ((TAP) % 3) * CH_WSZ;                                                                                   \
+    constexpr int wsl_ = ((TAP) % 3) * WSZ;                                                                                   \
     _Pragma("unroll") for (int tn = 0; tn < TN; ++tn) wf[tn] = *reinterpret_cast<const half8_t*>(af_smem + wr0 + wsl_ + tn * 2048);               \
     _Pragma("unroll") for (int tm = 0; tm < TM; ++tm) xf[tm] = *reinterpret_cast<const half8_t*>(af_smem + fa[TAP][tm]);                            \
     _Pragma("unroll") for (int tn = 0; tn < TN; ++tn) wf1[tn] = *reinterpret_cast<const half8_t*>(af_smem + (wr0 ^ 64) + wsl_ + tn * 2048);         \
@@ -1701,7 +1726,7 @@ __global__ __launch_bounds__(512) void af_conv3hd_kernel(const Gemm3Dev p) {
         for (int j = 0; j < 4; ++j) issue_tail_piece(j, t + 1, tn_);
         issue_wk(9 * Cin + (t + 1) * 64, (t + 1) % 3);
       }
-      const int ws = (t % 3) * CH_WSZ;
+      const int ws = (t % 3) * WSZ;
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn) wf[tn] = *reinterpret_cast<const half8_t*>(af_smem + wr0 + ws + tn * 2048);
 #pragma unroll
@@ -1719,32 +1744,45 @@ __global__ __launch_bounds__(512) void af_conv3hd_kernel(const Gemm3Dev p) {
     __builtin_amdgcn_s_barrier();                                    // the staged epilogue reuses the LDS
   }
   __builtin_amdgcn_s_setprio(0);
-  gemm3_epilogue<E3_STD, NWM, NWN, TN, CH_LDS>(p, acc, af_smem, tile_m, tile_n, wm, wn, fr, fq, tid);
+  gemm3_epilogue<E3_STD, NWM, NWN, TN, CH_LDS, PATCH>(p, acc, af_smem, tile_m, tile_n, wm, wn, fr, fq, tid);
 }
 
 // scope of the halo-resident kernel
-static bool conv3h_eligible(const af_gemm_desc* d) {
-  if (d->taps != 9 || (d->upsample != 0 && d->upsample != 1) || d->tap_shift || d->c1 % 64 != 0 || d->c2 % 64 != 0 || d->N % CH_BN != 0) return false;
+// 0 = outside; 1 = the 256 x 160 tile on whole image rows (the U-Net's levels); 2 = the 256 x 128 tile on whole image rows; 3 = the 256 x 128 tile on
+// 16 x 16-pixel patches (images wider than 64 pixels: the VAE decoder's 128 / 256 / 512 levels)
+static int conv3h_variant(const af_gemm_desc* d) {
+  if (d->taps != 9 || (d->upsample != 0 && d->upsample != 1) || d->tap_shift || d->c1 % 64 != 0 || d->c2 % 64 != 0) return 0;
+  const bool n160 = d->N % CH_BN == 0;
+  if (!n160 && d->N % 128 != 0) return 0;
   if (d->c3 || d->c4) {                                            // K tail (round 6): plain rows of a3 | a4 on the output grid, whole 64-column stages
-    if (d->c3 <= 0 || d->c3 % 64 != 0 || d->c4 < 0 || d->c4 % 64 != 0 || d->a3 == nullptr || (d->c4 > 0 && d->a4 == nullptr) || d->upsample) return false;
-    if ((long)d->M * std::max(d->lda3 ? d->lda3 : d->c3, d->lda4 ? d->lda4 : d->c4) * 2 >= (1L << 32)) return false;
+    if (!n160 || d->c3 <= 0 || d->c3 % 64 != 0 || d->c4 < 0 || d->c4 % 64 != 0 || d->a3 == nullptr || (d->c4 > 0 && d->a4 == nullptr) || d->upsample) return 0;
+    if ((long)d->M * std::max(d->lda3 ? d->lda3 : d->c3, d->lda4 ? d->lda4 : d->c4) * 2 >= (1L << 32)) return 0;
   }
   const int up = d->upsample ? 2 : 1;                              // nearest x2 folded into the halo gather
-  if ((d->stride ? d->stride : 1) != 1 || d->Ho != up * d->H || d->Wo != up * d->W) return false;
-  if (d->Wo != 8 && d->Wo != 16 && d->Wo != 32 && d->Wo != 64) return false;
+  if ((d->stride ? d->stride : 1) != 1 || d->Ho != up * d->H || d->Wo != up * d->W) return 0;
+  if (d->M % CH_BM != 0 || d->M != d->B * d->Ho * d->Wo) return 0;
+  if (d->act == AF_ACT_GEGLU || d->out_mode == AF_OUT_SPLIT_T || d->ln_colsum != nullptr || d->kpad % 64 != 0) return 0;
+  if ((long)d->B * d->H * d->W * std::max(d->c1, d->c2) * 2 >= (1L << 32)) return 0;      // the halo gather's 32-bit byte offsets
+  if (d->Wo > 64) {                                                // patches: no K tail, no split-K (the caller checks), no 160-wide form
+    if (n160 || d->Wo % 16 != 0 || d->Ho % 16 != 0 || d->c3 || d->c4) return 0;
+    return 3;
+  }
+  if (d->Wo != 8 && d->Wo != 16 && d->Wo != 32 && d->Wo != 64) return 0;
   const int rows = CH_BM / d->Wo;                                   // a tile: `rows` whole rows of one image, or rows / Ho whole images
-  if ((d->Ho % rows != 0 && rows % d->Ho != 0) || d->M % CH_BM != 0 || d->M != d->B * d->Ho * d->Wo) return false;
-  if (d->Ho < rows && (rows / d->Ho) * (d->Ho + 2) * (d->Wo + 2) > CH_NP_MAX * 8) return false;     // the images' halo blocks must fit one halo buffer
-  if (d->act == AF_ACT_GEGLU || d->out_mode == AF_OUT_SPLIT_T || d->ln_colsum != nullptr) return false;
-  return d->kpad % 64 == 0;
+  if (d->Ho % rows != 0 && rows % d->Ho != 0) return 0;
+  if (d->Ho < rows && (rows / d->Ho) * (d->Ho + 2) * (d->Wo + 2) > CH_NP_MAX * 8) return 0;     // the images' halo blocks must fit one halo buffer
+  return n160 ? 1 : 2;
 }
+static bool conv3h_eligible(const af_gemm_desc* d) { return conv3h_variant(d) != 0; }
 
 static int conv3h_chunks(const af_gemm_desc* d) { return (d->c1 + d->c2) / 64; }
 
-static bool launch_conv3h(const Gemm3Dev& p0, hipStream_t stream, bool r5_loop) {
+static bool launch_conv3h(const Gemm3Dev& p0, hipStream_t stream, bool r5_loop, int variant) {
   Gemm3Dev p = p0;
-  p.tiles_n = p.N / CH_BN;
+  p.tiles_n = p.N / (variant == 1 ? CH_BN : 128);
   p.tiles_m = p.M / CH_BM;
+  p.patch_tx = p.Wo / 16;
+  p.patch_tpi = p.patch_tx * (p.Ho / 16);
   {
     static const int coop_env = getenv("AF_GEMM3_WPF_COOP") ? atoi(getenv("AF_GEMM3_WPF_COOP")) : 32;
     p.wpf_coop = p.tiles_m < coop_env ? p.tiles_m : coop_env;
@@ -1753,6 +1791,16 @@ static bool launch_conv3h(const Gemm3Dev& p0, hipStream_t stream, bool r5_loop) 
   if (p.counters && (p.splits <= 1 || p.splits > 4 || p.tiles_m * p.tiles_n > AF_SPLITK_MAX_TILES)) p.counters = nullptr;
   p.n_major = af_gemm_n_major(p.M, p.N, p.K, p.c1 + p.c2);
   dim3 grid(p.tiles_m * p.tiles_n, p.splits), block(512);
+  if (variant >= 2) {                                              // 256 x 128 tile (round 6): the diet loop only
+    static bool set_2 = false, set_3 = false;
+    if (variant == 2) {
+      if (af_allow_dyn_lds(reinterpret_cast<const void*>(&af_conv3hd_kernel<false, 4, false>), CH_LDS, set_2, "af_gemm"))
+        hipLaunchKernelGGL((af_conv3hd_kernel<false, 4, false>), grid, block, CH_LDS, stream, p);
+    } else if (af_allow_dyn_lds(reinterpret_cast<const void*>(&af_conv3hd_kernel<false, 4, true>), CH_LDS, set_3, "af_gemm")) {
+      hipLaunchKernelGGL((af_conv3hd_kernel<false, 4, true>), grid, block, CH_LDS, stream, p);
+    }
+    return p.counters != nullptr;
+  }
 #define AF_CONV3H_CASE(A)                                                                                                                     \
   case A: {                                                                                                                                   \
     static bool set_ = false;                                                                                                                 \
@@ -2002,6 +2050,9 @@ __global__ __launch_bounds__(512, 1) void af_ff320_kernel(FfDev p) {
 
 }  // namespace
 
+// Which form of the halo-resident kernel (tile 14) a descriptor would run (include/adaface_hip.h)
+extern "C" int af_gemm_halo_variant(const af_gemm_desc* d) { return d != nullptr ? conv3h_variant(d) : 0; }
+
 // Called by af_gemm (af_gemm.hip) for tile == 3 after the common argument validation.  Returns 1 if the shape is
 // outside this kernel's scope (caller falls back), 0 after a launch.
 int af_gemm3_try_launch(const af_gemm_desc* d, int splits, int wide, hipStream_t stream) {
@@ -2011,8 +2062,10 @@ int af_gemm3_try_launch(const af_gemm_desc* d, int splits, int wide, hipStream_t
   const bool geglu = d->act == AF_ACT_GEGLU, split_t = d->out_mode == AF_OUT_SPLIT_T;
   const bool halo_r5 = wide == 16;                              // tile 19: tile 14 with the round-5 main loop (A/B arm and bit-identity reference of tile 14)
   if (halo_r5) wide = 11;
-  if (wide == 11 && !conv3h_eligible(d)) return 1;              // halo-resident 3x3 kernel (tile 14)
-  if (halo_r5 && d->c3 > 0) return 1;                           // (the K tail exists in the round-6 loop only)
+  const int halo_variant = wide == 11 ? conv3h_variant(d) : 0;
+  if (wide == 11 && halo_variant == 0) return 1;                // halo-resident 3x3 kernel (tile 14)
+  if (halo_r5 && (d->c3 > 0 || halo_variant != 1)) return 1;    // (the K tail and the 256 x 128 forms exist in the round-6 loop only)
+  if (halo_variant == 3 && splits > 1) return 1;                // (patches: never split)
   if (d->upsample && !((wide == 4 || wide == 5 || (wide >= 8 && wide <= 12)) && d->upsample == 1 && d->taps == 9)) return 1;   // nearest x2: whole-line kernel only
   if (d->c1 % BK3 != 0 || d->c2 % BK3 != 0 || d->zeros == nullptr) return 1;
   if (d->c3 > 0 && (wide < 4 || (wide > 10 && wide != 12 && wide != 11) || d->taps != 9 || d->upsample || (d->stride != 0 && d->stride != 1))) return 1;   // K tail: whole-line tap-by-tap tiles + the halo-resident kernel
@@ -2111,7 +2164,11 @@ int af_gemm3_try_launch(const af_gemm_desc* d, int splits, int wide, hipStream_t
     if (p.splits > nchunk) p.splits = nchunk;
     p.kt_per_split = (nchunk + p.splits - 1) / p.splits;
     p.splits = (nchunk + p.kt_per_split - 1) / p.kt_per_split;
-    fused = launch_conv3h(p, stream, halo_r5);
+    if (halo_variant == 3) {
+      if (!p.stage_ok) return 1;                                 // (the patch form leaves through the staged epilogue only)
+      p.splits = 1;
+    }
+    fused = launch_conv3h(p, stream, halo_r5, halo_variant);
     return (p.splits > 1 && !fused) ? 2 : 0;
   }
   if (wide >= 4) {

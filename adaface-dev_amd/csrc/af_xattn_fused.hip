@@ -720,6 +720,333 @@ __global__ __launch_bounds__(512, 1) void af_xattn320t_kernel(const XaDev p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// The same block at C = 640 (8 heads of 80; the 32 x 32 level), ONE launch (round 6; the form the round-5 review prescribed: 64-token tiles, an 80 KB
+// row tile + the 80 KB two-slot weight ring, 128 workgroups at M = 8192):
+//   * R = the workgroup's 64 x 640 fp16 tile (ten 64-channel blocks of [64 rows x 128 B], swizzled as above): x, then O in place;
+//   * a 640-row weight goes through the ring of af_xattn320t_kernel as 2 row halves x 10 K stages of [320 rows x 64 K] (40 KB) -- 20 stages per projection;
+//   * phase A: row half nh holds heads 4 nh .. 4 nh + 3; wave w computes Q^T [80 x 32] of head 4 nh + (w & 3) for the token half w >> 2, so over the two
+//     halves a wave OWNS TWO HEADS x 32 TOKENS (80 accumulator registers); LayerNorm statistics from the token fragments of the first half's ten stages;
+//   * phase B: per owned head the K_h / V_h^T fragments (d = 80 = two 32-deep k steps + a 16-deep tail; 80 keys likewise) come from global memory into 100
+//     registers, the two 16-token tiles run as two independent chains;
+//   * phase C: out [64 x 640] as 2 x 4 waves of 32 x 80 per row half (acc [2][5][2]).
+// Every workgroup streams BOTH whole weights (1.6 MB) through its ring -- what the three-launch form's 2-D tiling avoids; measured: see DESIGN.md 8.0.
+constexpr int X6_C = 640, X6_D = 80, X6_BM = 64;
+constexpr int X6_BLK = X6_BM * 128;                    // 8,192: one 64-channel block of R
+constexpr int X6_R = (X6_C / 64) * X6_BLK;             // 81,920
+constexpr int X6_LDS = X6_R + 2 * XT_STAGE;            // 163,840
+
+template <int NT>
+__global__ __launch_bounds__(512, 1) void af_xattn640t_kernel(const XaDev p) {
+  constexpr int NW = 8, NS = 20;                       // NS: stages per projection
+  static_assert(NT == 2, "a wave owns two 16-token tiles per head");
+  extern __shared__ __attribute__((aligned(16))) char af_smem[];
+  char* R = af_smem;
+  char* RING = af_smem + X6_R;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int prow = lane >> 3, slot = lane & 7;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int m0 = blockIdx.x * X6_BM;
+  const int bimg = m0 / p.N;
+  const floatx4 zf = {0.f, 0.f, 0.f, 0.f};
+
+  auto issue_x = [&]() {                                // 80 pieces: block c (64 channels) x 8 row groups
+#pragma unroll
+    for (int j = 0; j < 10; ++j) {
+      const int pc = wave + NW * j, c = pc >> 3, row = (pc & 7) * 8 + prow;
+      const int lc = slot ^ ((row >> 1) & 7);
+      const int m = m0 + row;
+      glds16(m < p.M ? p.x + (size_t)m * X6_C + c * 64 + lc * 8 : p.zeros, R + c * X6_BLK + (pc & 7) * 1024);
+    }
+  };
+  auto issue_w = [&](const half_t* w, int kpad, int s, int sl) {   // stage s = (row half s / 10, K stage s % 10) of a packed [>= 640][kpad] weight: 40 pieces
+    char* dst = RING + sl * XT_STAGE;
+    const int nh = s >= 10 ? 1 : 0, st = s - 10 * nh;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const int pc = wave + NW * j, row = pc * 8 + prow;
+      const int lc = slot ^ ((row >> 1) & 7);
+      glds16(w + (size_t)(nh * 320 + row) * kpad + st * 64 + lc * 8, dst + pc * 1024);
+    }
+  };
+  auto frag_off = [&](int row0, int kk) { return (row0 + fr) * 128 + (((kk * 4 + fq) ^ (((row0 + fr) >> 1) & 7)) * 16); };
+
+  issue_x();
+  issue_w(p.wq, p.kpad_q, 0, 0);
+  issue_w(p.wq, p.kpad_q, 1, 1);
+
+  // ================= phase A: Q_h^T [80 x 32] per row half
+  const int hh = wave & 3, th = wave >> 2;
+  floatx4 qa[2][5][2];
+#pragma unroll
+  for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+    for (int t = 0; t < 5; ++t)
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) qa[nh][t][tt] = zf;
+  float ls[2] = {0.f, 0.f}, lq[2] = {0.f, 0.f};
+  const half2_t one2 = {(half_t)1.0f, (half_t)1.0f};
+#pragma unroll
+  for (int nh = 0; nh < 2; ++nh) {
+#pragma nounroll
+    for (int st = 0; st < 10; ++st) {
+      const int s = nh * 10 + st;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (s >= 1 && s + 1 < NS) issue_w(p.wq, p.kpad_q, s + 1, (s + 1) & 1);
+      const char* Ws = RING + (s & 1) * XT_STAGE;
+      const char* Xs = R + st * X6_BLK;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        half8_t wf[5], xf[2];
+#pragma unroll
+        for (int t = 0; t < 5; ++t) wf[t] = *reinterpret_cast<const half8_t*>(Ws + frag_off(hh * X6_D + t * 16, kk));
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) xf[tt] = *reinterpret_cast<const half8_t*>(Xs + frag_off(th * 32 + tt * 16, kk));
+        if (nh == 0 && p.ln_on) {
+#pragma unroll
+          for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+              const half2_t a = {xf[tt][e], xf[tt][e + 1]};
+              ls[tt] = __builtin_amdgcn_fdot2(a, one2, ls[tt], false);
+              lq[tt] = __builtin_amdgcn_fdot2(a, a, lq[tt], false);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 5; ++t)
+#pragma unroll
+          for (int tt = 0; tt < 2; ++tt) qa[nh][t][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[t], xf[tt], qa[nh][t][tt], 0, 0, 0);
+      }
+    }
+  }
+  __builtin_amdgcn_s_barrier();                           // every wave is done with x and with the W_q ring: R may take O, the ring W_o
+  issue_w(p.wo, p.kpad_o, 0, 0);
+  issue_w(p.wo, p.kpad_o, 1, 1);
+  // folded LayerNorm, shift, softmax scale (log2 units); packed as the B operands of S^T (k slot 8 fq + j <-> head dimension 16 a + 4 fq + j, j < 4; 16 b + 4 fq + j - 4)
+  float mean[2], rstd[2];
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt) {
+    mean[tt] = 0.f;
+    rstd[tt] = 1.f;
+    if (p.ln_on) {
+      float s = ls[tt], q = lq[tt];
+      s += __shfl_xor(s, 16, 64);
+      q += __shfl_xor(q, 16, 64);
+      s += __shfl_xor(s, 32, 64);
+      q += __shfl_xor(q, 32, 64);
+      mean[tt] = s * (1.0f / X6_C);
+      rstd[tt] = rsqrtf(fmaxf(q * (1.0f / X6_C) - mean[tt] * mean[tt], 0.f) + p.ln_eps);
+    }
+  }
+  half8_t q0[2][2][2];
+  half4_t q1[2][2];
+#pragma unroll
+  for (int nh = 0; nh < 2; ++nh) {
+    const int h = nh * 4 + hh;
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+      const int n = h * X6_D + t * 16 + 4 * fq;
+      const floatx4 csv = p.ln_on ? *reinterpret_cast<const floatx4*>(p.cs + n) : zf;
+      const floatx4 bqv = p.bq ? *reinterpret_cast<const floatx4*>(p.bq + n) : zf;
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) qa[nh][t][tt][e] = (rstd[tt] * (qa[nh][t][tt][e] - mean[tt] * csv[e]) + bqv[e]) * p.scale_log2e;
+    }
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+        q0[nh][s2][tt] = half8_t{(half_t)qa[nh][2 * s2][tt][0],     (half_t)qa[nh][2 * s2][tt][1],     (half_t)qa[nh][2 * s2][tt][2],     (half_t)qa[nh][2 * s2][tt][3],
+                                 (half_t)qa[nh][2 * s2 + 1][tt][0], (half_t)qa[nh][2 * s2 + 1][tt][1], (half_t)qa[nh][2 * s2 + 1][tt][2], (half_t)qa[nh][2 * s2 + 1][tt][3]};
+      q1[nh][tt] = half4_t{(half_t)qa[nh][4][tt][0], (half_t)qa[nh][4][tt][1], (half_t)qa[nh][4][tt][2], (half_t)qa[nh][4][tt][3]};
+    }
+  }
+
+  // ================= phase B: the 77-key core of the wave's two heads x two 16-token tiles
+  typedef unsigned long long u64;
+  auto ld8 = [](const half_t* ptr) { return *reinterpret_cast<const u64*>(ptr); };
+  auto live_mask = [&](int first) {                    // keys first .. first + 3: bits of those < L
+    const int live = p.L - first;
+    return live >= 4 ? ~0ull : (live <= 0 ? 0ull : ((1ull << (16 * live)) - 1ull));
+  };
+#pragma unroll
+  for (int nh = 0; nh < 2; ++nh) {
+    const int h = nh * 4 + hh;
+    half8_t kA32[5][2], vA32[5][2];
+    half4_t kA16[5], vA16[5];
+    {
+      // unconditional loads from in-range addresses, masked afterwards (a select in front of a load becomes an exec-masked branch with its own wait)
+      u64 klo[5][2], khi[5][2], kt8[5];
+#pragma unroll
+      for (int kt = 0; kt < 5; ++kt) {
+        const int key = kt * 16 + fr;
+        const half_t* kp = p.k + ((size_t)bimg * p.L + (key < p.L ? key : 0)) * p.ldk + h * X6_D;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          klo[kt][s2] = ld8(kp + 32 * s2 + 4 * fq);
+          khi[kt][s2] = ld8(kp + 32 * s2 + 16 + 4 * fq);
+        }
+        kt8[kt] = ld8(kp + 64 + 4 * fq);
+      }
+      u64 vlo[5][2], vhi[5][2], vt8[5];
+#pragma unroll
+      for (int t = 0; t < 5; ++t) {
+        const half_t* vp = p.vt + (size_t)bimg * p.vbs + (size_t)(h * X6_D + t * 16 + fr) * p.ldv;
+        auto at = [&](int key0) { return vp + (key0 + 4 <= p.ldv ? key0 : 0); };     // key0 % 4 == 0 and ldv % 8 == 0: the 8 bytes stay inside the row
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          vlo[t][s2] = ld8(at(32 * s2 + 4 * fq));
+          vhi[t][s2] = ld8(at(32 * s2 + 16 + 4 * fq));
+        }
+        vt8[t] = ld8(at(64 + 4 * fq));
+      }
+#pragma unroll
+      for (int kt = 0; kt < 5; ++kt) {
+        const u64 km = (kt * 16 + fr) < p.L ? ~0ull : 0ull;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const half4_t lo = __builtin_bit_cast(half4_t, klo[kt][s2] & km), hi = __builtin_bit_cast(half4_t, khi[kt][s2] & km);
+          kA32[kt][s2] = half8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+        kA16[kt] = __builtin_bit_cast(half4_t, kt8[kt] & km);
+      }
+#pragma unroll
+      for (int t = 0; t < 5; ++t) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const half4_t lo = __builtin_bit_cast(half4_t, vlo[t][s2] & live_mask(32 * s2 + 4 * fq));
+          const half4_t hi = __builtin_bit_cast(half4_t, vhi[t][s2] & live_mask(32 * s2 + 16 + 4 * fq));
+          vA32[t][s2] = half8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+        vA16[t] = __builtin_bit_cast(half4_t, vt8[t] & live_mask(64 + 4 * fq));
+      }
+    }
+    floatx4 sa[5][NT];
+#pragma unroll
+    for (int kt = 0; kt < 5; ++kt)
+#pragma unroll
+      for (int u = 0; u < NT; ++u) sa[kt][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kA32[kt][0], q0[nh][0][u], zf, 0, 0, 0);
+#pragma unroll
+    for (int kt = 0; kt < 5; ++kt)
+#pragma unroll
+      for (int u = 0; u < NT; ++u) sa[kt][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kA32[kt][1], q0[nh][1][u], sa[kt][u], 0, 0, 0);
+#pragma unroll
+    for (int kt = 0; kt < 5; ++kt)
+#pragma unroll
+      for (int u = 0; u < NT; ++u) sa[kt][u] = mfma_k16(kA16[kt], q1[nh][u], sa[kt][u]);
+    float inv[NT];
+    half8_t p0[NT], p1[NT];
+    half4_t p2[NT];
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+      float mx = -3.0e38f;
+#pragma unroll
+      for (int kt = 0; kt < 5; ++kt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (kt * 16 + 4 * fq + e >= p.L) sa[kt][u][e] = -3.0e38f;
+          mx = fmaxf(mx, sa[kt][u][e]);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      float sum = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 5; ++kt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          sa[kt][u][e] = __builtin_amdgcn_exp2f(sa[kt][u][e] - mx);
+          sum += sa[kt][u][e];
+        }
+      sum += __shfl_xor(sum, 16, 64);
+      sum += __shfl_xor(sum, 32, 64);
+      inv[u] = __builtin_amdgcn_rcpf(sum);
+      p0[u] = half8_t{(half_t)sa[0][u][0], (half_t)sa[0][u][1], (half_t)sa[0][u][2], (half_t)sa[0][u][3],
+                      (half_t)sa[1][u][0], (half_t)sa[1][u][1], (half_t)sa[1][u][2], (half_t)sa[1][u][3]};
+      p1[u] = half8_t{(half_t)sa[2][u][0], (half_t)sa[2][u][1], (half_t)sa[2][u][2], (half_t)sa[2][u][3],
+                      (half_t)sa[3][u][0], (half_t)sa[3][u][1], (half_t)sa[3][u][2], (half_t)sa[3][u][3]};
+      p2[u] = half4_t{(half_t)sa[4][u][0], (half_t)sa[4][u][1], (half_t)sa[4][u][2], (half_t)sa[4][u][3]};
+    }
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+      floatx4 o[NT];
+#pragma unroll
+      for (int u = 0; u < NT; ++u) o[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vA32[t][0], p0[u], zf, 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < NT; ++u) o[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vA32[t][1], p1[u], o[u], 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < NT; ++u) o[u] = mfma_k16(vA16[t], p2[u], o[u]);
+      const int c = h * X6_D + t * 16 + 4 * fq;         // channel: block c >> 6, 16-byte chunk (c & 63) >> 3, 8-byte half (c >> 2) & 1
+#pragma unroll
+      for (int u = 0; u < NT; ++u) {
+        const int row = th * 32 + u * 16 + fr;
+        const half4_t o4 = {(half_t)(o[u][0] * inv[u]), (half_t)(o[u][1] * inv[u]), (half_t)(o[u][2] * inv[u]), (half_t)(o[u][3] * inv[u])};
+        *reinterpret_cast<half4_t*>(R + (c >> 6) * X6_BLK + row * 128 + ((((c & 63) >> 3) ^ ((row >> 1) & 7)) * 16) + ((c >> 2) & 1) * 8) = o4;
+      }
+    }
+  }
+
+  // ================= phase C: out = O W_o^T + b_o + residual, 2 x 4 waves of 32 x 80 per row half
+  const int wm = wave & 1, wn = wave >> 1;
+  floatx4 acc[2][5][2];
+#pragma unroll
+  for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+    for (int tn = 0; tn < 5; ++tn)
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm) acc[nh][tn][tm] = zf;
+#pragma unroll
+  for (int nh = 0; nh < 2; ++nh) {
+#pragma nounroll
+    for (int st = 0; st < 10; ++st) {
+      const int s = nh * 10 + st;
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // W_o stage s has landed; (first pass) this wave's O stores are in LDS
+      __builtin_amdgcn_s_barrier();
+      if (s >= 1 && s + 1 < NS) issue_w(p.wo, p.kpad_o, s + 1, (s + 1) & 1);
+      const char* Ws = RING + (s & 1) * XT_STAGE;
+      const char* Os = R + st * X6_BLK;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        half8_t wf[5], xf[2];
+#pragma unroll
+        for (int tn = 0; tn < 5; ++tn) wf[tn] = *reinterpret_cast<const half8_t*>(Ws + frag_off(wn * 80 + tn * 16, kk));
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm) xf[tm] = *reinterpret_cast<const half8_t*>(Os + frag_off(wm * 32 + tm * 16, kk));
+#pragma unroll
+        for (int tn = 0; tn < 5; ++tn)
+#pragma unroll
+          for (int tm = 0; tm < 2; ++tm) acc[nh][tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[tn], xf[tm], acc[nh][tn][tm], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm) {
+    const int m = m0 + wm * 32 + tm * 16 + fr;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+      for (int tn = 0; tn < 5; ++tn) {
+        const int c = nh * 320 + wn * 80 + tn * 16 + 4 * fq;
+        floatx4 v = acc[nh][tn][tm];
+        if (p.bo) {
+          const floatx4 b = *reinterpret_cast<const floatx4*>(p.bo + c);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += b[e];
+        }
+        if (p.residual) {
+          const half4_t rr = *reinterpret_cast<const half4_t*>(p.residual + (size_t)m * X6_C + c);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += (float)rr[e];
+        }
+        const half4_t o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+        *reinterpret_cast<half4_t*>(p.out + (size_t)m * X6_C + c) = o;
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // GroupNorm's normalising pass + the 1x1 convolution behind it at C = 320, ONE launch (af_gn_proj_fused; round 4): the SpatialTransformer's
 // `proj_in(norm(x))` (attention.py:283-291).  Unfused: af_groupnorm_apply writes the normalised [M, 320] tensor (42 MB of traffic at U-Net
 // batch 8, 14 us) and a 16.6 us GEMM reads it back.  Here a workgroup normalises its 128-token tile straight into the LDS tile R (the layout of
@@ -885,8 +1212,8 @@ extern "C" int af_xattn_fused(const void* x, const void* wq, const void* bq, con
                               const void* vt, int64_t vt_batch_stride, int ldv, const void* wo, const void* bo, int kpad_o, const void* residual,
                               void* out, int B, int N, int L, int C, int heads, float scale, const void* zeros, void* stream) {
   AF_REQUIRE(x && wq && k && vt && wo && out && zeros, "af_xattn_fused: null pointer");
-  AF_SUPPORTED(C == XA_C && heads == XA_H, "af_xattn_fused: built for C = 320, 8 heads (the 64 x 64 level of SD-1.5)");
-  AF_REQUIRE(B > 0 && N > 0 && N % XA_BM == 0, "af_xattn_fused: tokens per image must be a positive multiple of 128");
+  AF_SUPPORTED((C == XA_C || C == X6_C) && heads == XA_H, "af_xattn_fused: built for C = 320 / 640, 8 heads (the 64 x 64 and 32 x 32 levels of SD-1.5)");
+  AF_REQUIRE(B > 0 && N > 0 && N % (C == XA_C ? XA_BM : X6_BM) == 0, "af_xattn_fused: tokens per image must be a positive multiple of 128 (C = 320) / 64 (C = 640)");
   AF_SUPPORTED(L > 0 && L <= 80, "af_xattn_fused: at most 80 keys");
   AF_REQUIRE(kpad_q >= C && kpad_q % 64 == 0 && kpad_o >= C && kpad_o % 64 == 0, "af_xattn_fused: weight row strides must be 64-multiples covering C");
   AF_REQUIRE(ldk >= C && ldk % 8 == 0 && ldv >= L && ldv % 8 == 0 && vt_batch_stride % 8 == 0, "af_xattn_fused: K / V^T strides must keep 16-byte alignment");
@@ -913,6 +1240,15 @@ extern "C" int af_xattn_fused(const void* x, const void* wq, const void* bq, con
   p.vbs = (long)vt_batch_stride;
   p.ln_eps = ln_eps;
   p.scale_log2e = scale * 1.4426950408889634f;
+  if (C == X6_C) {
+    AF_REQUIRE((((uintptr_t)x | (uintptr_t)out | (uintptr_t)residual | (uintptr_t)bo | (uintptr_t)bq | (uintptr_t)ln_colsum) & 15) == 0,
+               "af_xattn_fused: x / out / residual / bo / bq / ln_colsum must be 16-byte aligned");
+    static bool attr6 = false;
+    if (!af_allow_dyn_lds(reinterpret_cast<const void*>(&af_xattn640t_kernel<2>), X6_LDS, attr6, "af_xattn_fused")) return af_check_launch("af_xattn_fused");
+    AfLaunchScope scope6(AF_FAM_XATTN, stream);
+    hipLaunchKernelGGL(af_xattn640t_kernel<2>, dim3(p.M / X6_BM), dim3(512), X6_LDS, (hipStream_t)stream, p);
+    return af_check_launch("af_xattn_fused(C = 640)");
+  }
   static bool attr_set = false;
   if (!af_allow_dyn_lds(reinterpret_cast<const void*>(&af_xattn320_kernel), XA_LDS, attr_set, "af_xattn_fused")) return af_check_launch("af_xattn_fused");
   AfLaunchScope scope(AF_FAM_XATTN, stream);

@@ -34,6 +34,8 @@ FOLD_LAYERNORM = _os.environ.get("AF_FOLD_LAYERNORM", "1") != "0"
 FUSE_GN_PROJ = _os.environ.get("AF_FUSE_GN_PROJ", "1") != "0"      # SpatialTransformer: GroupNorm's normalising pass + proj_in in one launch at C = 320 (af_gn_proj_fused)
 CHAIN_XATTN = _os.environ.get("AF_CHAIN_XATTN", "1") != "0"    # round 6: the self-attention's to_out + residual as phase 0 of the one-launch C = 320 cross-attention block (af_xattn_chain)
 XATTN_FUSE_MIN_TOKENS = int(_os.environ.get("AF_XATTN_FUSE_MIN_TOKENS", "8192"))   # U-Net batch x tokens from which the one-launch block is used
+FUSE_XATTN640 = _os.environ.get("AF_FUSE_XATTN640", "0") != "0"  # the C = 640 blocks as one launch too (af_xattn640t_kernel, round 6): measured, see DESIGN.md 8.0
+XATTN640_FUSE_MIN_TOKENS = 4096                                   # 64-token workgroups: 64 of them at least
 FUSE_XATTN = _os.environ.get("AF_FUSE_XATTN", "1") != "0"      # the C = 320 cross-attention block as ONE launch (af_xattn_fused): on par with the
                                                                 # three launches alone, -0.03 ms per denoise step (csrc/af_xattn_fused.hip); 0 = three launches
 FUSE_FF = _os.environ.get("AF_FUSE_FF", "1") != "0"          # the C = 320 feed-forward as one launch (af_ff_fused); 0 = the two GEMMs (A/B runs)
@@ -185,10 +187,13 @@ class CrossAttention(nn.Module):
         return self._q_cache_ln.get((self.to_q.weight, ln.weight, ln.bias), lambda: ops.pack_matrix_ln(
             self.to_q.weight, None, ln.weight, ln.bias, ln.eps, self.to_q.weight.device))
 
-    def xattn_fusable(self, C, B, N, L, ln) -> bool:
-        """Whether this (cross-attention) layer runs as the one-launch C = 320 block (af_xattn_fused / af_xattn_chain)."""
-        return bool(FUSE_XATTN and ln is not None and self.inner_dim == 320 and C == 320 and self.heads == 8 and not self.save_cross_attn_vars
-                    and N % 128 == 0 and L <= 80 and B * N >= XATTN_FUSE_MIN_TOKENS)
+    def xattn_fusable(self, C, B, N, L, ln, chain=False) -> bool:
+        """Whether this (cross-attention) layer runs as the one-launch block (af_xattn_fused; ``chain``: af_xattn_chain, C = 320 only)."""
+        if not (FUSE_XATTN and ln is not None and self.heads == 8 and not self.save_cross_attn_vars and L <= 80 and self.inner_dim == C):
+            return False
+        if C == 320:
+            return N % 128 == 0 and B * N >= XATTN_FUSE_MIN_TOKENS
+        return bool(FUSE_XATTN640 and not chain and C == 640 and N % 64 == 0 and B * N >= XATTN640_FUSE_MIN_TOKENS)
 
     def hip(self, x2d, B, N, context=None, keybias=None, residual=None, ln=None, defer_out=False, pre=None):
         """x2d [B*N, C] fp16; context [B, L, Cc] fp16 or None (self-attention); keybias fp32
@@ -326,7 +331,7 @@ class BasicTransformerBlock(nn.Module):
             # is cheaper than moving them to a whole-line tile (profiles/r03d_lnfold_runtime_flag.txt: +2.5 .. +4.0 us folded)
             small = x2d.shape[0] < 1024
             if (CHAIN_XATTN and not small and context is not None and not self.attn1.save_cross_attn_vars 
-                    and self.attn2.xattn_fusable(x2d.shape[1], B, N, context.shape[1], self.norm2)):
+                    and self.attn2.xattn_fusable(x2d.shape[1], B, N, context.shape[1], self.norm2, chain=True)):
                 # the 64 x 64 level: attn1's to_out + residual run as phase 0 of the one-launch cross-attention block (af_xattn_chain)
                 pre = self.attn1.hip(x2d, B, N, None, keybias, residual=x2d, ln=self.norm1, defer_out=True)
                 x2 = self.attn2.hip(None, B, N, context, None, residual=None, ln=self.norm2, pre=pre)

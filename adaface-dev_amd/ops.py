@@ -169,12 +169,21 @@ _TUNE_PATH = _os.environ.get("AF_TUNE_TABLE") or _os.path.join(_os.path.dirname(
 _tune_table = None
 def conv_halo_eligible(d) -> bool:
     """The scope of af_gemm tile 14, the halo-resident 3x3 kernel (include/adaface_hip.h); tools/autotune_gemm.py times it against the
-    tap-by-tap tiles wherever this holds."""
+    tap-by-tap tiles wherever this holds.  Three forms (csrc/af_gemm3.hip::conv3h_variant): 256 x 160 tiles on whole image rows (the U-Net's levels,
+    with the K-concatenated shortcut since round 6), 256 x 128 tiles on whole rows, and 256 x 128 tiles on 16 x 16-pixel patches of images wider
+    than 64 pixels (the VAE's 128 / 256 / 512 levels)."""
     up = 2 if d.upsample else 1
-    tail_ok = (d.c3 == 0 and d.c4 == 0) or (d.c3 > 0 and d.c3 % 64 == 0 and d.c4 % 64 == 0 and not d.upsample)     # round 6: the K-concatenated 1x1 shortcut
-    return (d.taps == 9 and d.stride in (0, 1) and d.upsample in (0, 1) and not d.tap_shift and d.c1 % 64 == 0 and d.c2 % 64 == 0 and tail_ok
-            and d.N % 160 == 0 and d.Wo in (8, 16, 32, 64) and _halo_rows_ok(d.Ho, d.Wo) and d.M % 256 == 0 and d.Ho == up * d.H
-            and d.Wo == up * d.W and d.act != AF_ACT_GEGLU and d.out_mode == AF_OUT_NORMAL)
+    tail = d.c3 > 0 or d.c4 > 0
+    n160 = d.N % 160 == 0
+    if not (d.taps == 9 and d.stride in (0, 1) and d.upsample in (0, 1) and not d.tap_shift and d.c1 % 64 == 0 and d.c2 % 64 == 0
+            and (n160 or d.N % 128 == 0) and d.M % 256 == 0 and d.Ho == up * d.H and d.Wo == up * d.W and d.act != AF_ACT_GEGLU
+            and d.out_mode == AF_OUT_NORMAL):
+        return False
+    if tail and not (n160 and d.c3 > 0 and d.c3 % 64 == 0 and d.c4 % 64 == 0 and not d.upsample):     # round 6: the K-concatenated 1x1 shortcut
+        return False
+    if d.Wo > 64:
+        return not n160 and not tail and d.Wo % 16 == 0 and d.Ho % 16 == 0 and d.splits <= 1
+    return d.Wo in (8, 16, 32, 64) and _halo_rows_ok(d.Ho, d.Wo)
 
 
 def _halo_rows_ok(Ho: int, Wo: int) -> bool:
@@ -229,6 +238,7 @@ def _splitk_workspace(device) -> torch.Tensor:
 # 78.3 us -- the one reducer workgroup per tile reads its slabs at a dependent-latency rate while the separate pass spreads them
 # over all CUs and the launch boundary costs only ~1.5 us under graph replay), so the default is 0 = never; the path stays
 # available (bit-identical results, tests/test_hip_kernels.py) for callers whose launch boundaries are expensive.
+VAE_HALO_DEFAULT = _os.environ.get("AF_VAE_HALO_DEFAULT", "1") != "0"     # untabled VAE-kind 3x3 shapes go to the halo-resident kernel (see _launch_gemm)
 SPLITK_FUSED_MAX = int(_os.environ.get("AF_SPLITK_FUSED_MAX", "0"))
 
 
@@ -394,6 +404,10 @@ def _launch_gemm(d: "GemmDesc", device, what: str, tile: int = 0, splits: int = 
             tile, splits = tune_table().get(key, (0, 1))
             if d.ln_colsum and tile == 0:
                 tile, splits = tune_table().get(key[:-3], (0, 1))
+            if VAE_HALO_DEFAULT and tile == 0 and d.taps == 9 and d.N % 160 != 0 and d.M >= 16384 and conv_halo_eligible(d):
+                # a 3x3 convolution of the VAE's kind (128-multiples of channels over many pixels) at a batch size the table has not met: the halo-resident
+                # kernel's 256 x 128 forms win every such shape the table holds by 20 - 40 % (profiles/r06t_try14.log)
+                tile, splits = 14, 1
     if (SMALL_GEMM_MAX_M and tile in (0, 2) and d.taps == 1 and d.M <= SMALL_GEMM_MAX_M and d.K <= SMALL_GEMM_MAX_K and not d.a2 and not d.ln_colsum
             and d.act != AF_ACT_GEGLU and d.out_mode != AF_OUT_SPLIT_T and d.K % 8 == 0 and _tune_recorder is None
             and (tile == 2 or (d.M * d.N <= (1 << 21)))):

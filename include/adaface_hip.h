@@ -129,7 +129,10 @@ typedef struct af_gemm_desc {
                            waves of a SIMD (one group issues a stage's 40 MFMAs while the other reads its fragments and issues its LDS-DMA
                            pieces; 160 KB of LDS).  Round 6: every per-stage address (fragment reads per tap, LDS-DMA pieces) is a register or a scalar +
                            immediate computed outside the loop, out-of-image halo lanes are EXEC-masked instead of reading a zero page (~10 instead of
-                           ~80 vector instructions per 40-MFMA stage).  Outside that scope it falls back to tile 1 */
+                           ~80 vector instructions per 40-MFMA stage).  Also round 6, for the VAE's channel counts and image sizes (model.py:136-175, 536-567): where N is
+                           a 128-multiple but no 160-multiple the tile is 256 x 128 (no K tail), and on images wider than 64 pixels (Wo % 16 == 0, Ho % 16 == 0; never
+                           split) a tile is a 16 x 16-pixel PATCH of one image (18 x 18 halo) instead of whole rows.  af_gemm_halo_variant tells which form a
+                           descriptor gets.  Outside that scope it falls back to tile 1 */
                         /* 19 = tile 14 with its round-5 main loop (addresses recomputed per stage): the A/B arm; bit-identical results */
                         /* 15 = whole-line kernel, 256 x 128 tile of eight waves (4 x 2; N % 128 == 0; standard epilogue, taps 1 / 9, nearest x2): 85 instead of
                            64 FLOP per operand byte for narrow outputs over many rows (the VAE decoder's 128- / 256-channel convolutions at 256^2 / 512^2) */
@@ -211,7 +214,9 @@ int af_ff_fused(const void* x, const void* w1, const void* b1, const void* ln_co
  * attention.py:168-222 + the norm2 of :242-252): out = residual + bo + Wo . concat_h(softmax(q_h K_h^T scale) V_h), q = LN(x) Wq^T.
  * wq / bq / ln_colsum: the q projection packed with the LayerNorm folded in (as af_gemm_desc.ln_colsum takes it; ln_colsum NULL = x is
  * used as it is, bq NULL = no shift).  k [B * L][ldk] and vt [B][C][ldv] (batch stride vt_batch_stride; the row pad, keys L .. ldv-1, may hold ANYTHING: masked keys contribute nothing) are this
- * layer's slices of the context projection (head h at columns / rows 40 h ..).  N (tokens per image) % 128 == 0, L <= 80. */
+ * layer's slices of the context projection (head h at columns / rows 40 h ..).  N (tokens per image) % 128 == 0, L <= 80.
+ * Round 6: C = 640 (8 heads of 80, the 32 x 32 level; N % 64 == 0) is taken too -- 64-token workgroups that stream both 640 x 640 weights; measured slower than
+ * three launches there, so the module keeps it behind AF_FUSE_XATTN640.  Any other C: AF_E_UNSUPPORTED. */
 int af_xattn_fused(const void* x, const void* wq, const void* bq, const void* ln_colsum, float ln_eps, int kpad_q, const void* k, int ldk,
                    const void* vt, int64_t vt_batch_stride, int ldv, const void* wo, const void* bo, int kpad_o, const void* residual,
                    void* out, int B, int N, int L, int C, int heads, float scale, const void* zeros, void* stream);
@@ -262,6 +267,10 @@ int af_groupnorm_splitk(const void* slabs, int splits, const void* bias, const v
                         const void* gamma, const void* beta, void* y, void* stats, int B, int HW, int groups, float eps, int silu, void* stream);
 /* 1 when af_gemm with this (tile, splits) takes gn_partials for an output of N channels in groups of cpg and rows_per_batch rows per batch item */
 int af_gemm_gn_stats_ok(int tile, int splits, int taps, int act, int out_mode, int N, int cpg, int rows_per_batch);
+/* Which form of the halo-resident 3x3 kernel (tile 14) this descriptor would run: 0 = outside its scope (af_gemm falls back to a tap-by-tap tile),
+ * 1 = 256 x 160 tiles on whole image rows, 2 = 256 x 128 tiles on whole image rows, 3 = 256 x 128 tiles on 16 x 16-pixel patches.  Reads the geometry
+ * fields only (taps, c1 .. c4, N, B, H, W, Ho, Wo, stride, upsample, tap_shift, act, out_mode, kpad, M); no launch. */
+int af_gemm_halo_variant(const af_gemm_desc* d);
 int af_groupnorm(const void* x1, const void* x2, int c1, int c2, const void* gamma, const void* beta,
                  void* y, int B, int HW, int groups, float eps, int silu, void* workspace, void* stream);
 

@@ -1031,19 +1031,22 @@ def test_ff_fused_c320(dev, M, with_ln, with_res):
         assert torch.equal(y, out)
 
 
+@pytest.mark.parametrize("C", [320, 640])
 @pytest.mark.parametrize("B,N,L,with_ln,with_res,ld_extra", [(2, 256, 77, True, True, 0), (1, 128, 77, False, False, 0), (3, 384, 80, True, False, 0),
                                                              (2, 128, 40, True, True, 0), (2, 128, 37, True, True, 0), (2, 256, 77, True, True, 16),
-                                                             (1, 128, 5, False, True, 8), (2, 128, 64, True, False, 8)])
-def test_xattn_fused_c320(dev, B, N, L, with_ln, with_res, ld_extra):
-    """af_xattn_fused (the whole C = 320 cross-attention block in one launch: LayerNorm-folded q projection, 77-key softmax attention on
+                                                             (1, 128, 5, False, True, 8), (2, 128, 64, True, False, 8), (3, 64, 77, True, True, 8)])
+def test_xattn_fused_c320(dev, B, N, L, with_ln, with_res, ld_extra, C):
+    """af_xattn_fused (the whole C = 320 / C = 640 cross-attention block in one launch: LayerNorm-folded q projection, 77-key softmax attention on
     the context projection's K / V^T slices, to_out, bias, residual) against fp32 torch AND against the three-launch path of
     CrossAttention.hip on the same weights; K / V^T handed over exactly as the U-Net does (column / row slices of a wider batched
     projection, so the strides are not the layer's own)."""
     from adaface_dev_amd import ops
     from adaface_dev_amd.ldm.modules import attention as A
     from adaface_dev_amd.ldm.modules.diffusionmodules.util import LayerNorm
-    C, Cc, heads = 320, 768, 8
-    m = A.CrossAttention(C, Cc, heads=heads, dim_head=40).to(dev)
+    if C == 320 and N % 128:
+        pytest.skip("C = 320: 128-token workgroups")
+    Cc, heads, dh = 768, 8, C // 8
+    m = A.CrossAttention(C, Cc, heads=heads, dim_head=dh).to(dev)
     ln = LayerNorm(C).to(dev)
     with torch.no_grad():
         for i, w in enumerate((m.to_q.weight, m.to_k.weight, m.to_v.weight, m.to_out[0].weight)):
@@ -1058,10 +1061,10 @@ def test_xattn_fused_c320(dev, B, N, L, with_ln, with_res, ld_extra):
     xf = x.float()
     xn = F.layer_norm(xf, (C,), ln.weight.detach().float().cpu(), ln.bias.detach().float().cpu(), 1e-5) if with_ln else xf
     W = [w.detach().float().cpu() for w in (m.to_q.weight, m.to_k.weight, m.to_v.weight, m.to_out[0].weight)]
-    q = (xn @ W[0].t()).reshape(B, N, heads, 40).permute(0, 2, 1, 3)
-    kk = (ctx.float() @ W[1].t()).reshape(B, L, heads, 40).permute(0, 2, 1, 3)
-    vv = (ctx.float() @ W[2].t()).reshape(B, L, heads, 40).permute(0, 2, 1, 3)
-    o = torch.softmax(q @ kk.transpose(-1, -2) * 40 ** -0.5, dim=-1) @ vv
+    q = (xn @ W[0].t()).reshape(B, N, heads, dh).permute(0, 2, 1, 3)
+    kk = (ctx.float() @ W[1].t()).reshape(B, L, heads, dh).permute(0, 2, 1, 3)
+    vv = (ctx.float() @ W[2].t()).reshape(B, L, heads, dh).permute(0, 2, 1, 3)
+    o = torch.softmax(q @ kk.transpose(-1, -2) * dh ** -0.5, dim=-1) @ vv
     ref = o.permute(0, 2, 1, 3).reshape(B * N, C) @ W[3].t() + m.to_out[0].bias.detach().float().cpu()
     if with_res:
         ref = ref + res.float()
@@ -1074,14 +1077,23 @@ def test_xattn_fused_c320(dev, B, N, L, with_ln, with_res, ld_extra):
     k_all, vt_all = ops.gemm(ctx.to(dev).reshape(B * L, Cc), pack, rows_per_batch=L, split_col=wk.shape[0], ld_out2=ldv)
     # the projection's transposed output owns its row pad: zero, although the buffer came from a (NaN-poisoned, see conftest) torch.empty
     assert vt_all.shape[-1] == ldv and torch.isfinite(vt_all).all() and (vt_all[..., L:] == 0).all()
-    k, vt = k_all[:, 640:960], vt_all[:, 640:960, :]
+    k, vt = k_all[:, 640:640 + C], vt_all[:, 640:640 + C, :]
     pq = m._packed_q_ln(ln) if with_ln else m.to_q.packed()
-    out = ops.xattn_fused(x.to(dev), pq, k, vt, m.to_out[0].packed(), B=B, N=N, L=L, heads=heads, scale=40 ** -0.5, ldk=wk.shape[0],
+    out = ops.xattn_fused(x.to(dev), pq, k, vt, m.to_out[0].packed(), B=B, N=N, L=L, heads=heads, scale=dh ** -0.5, ldk=wk.shape[0],
                           residual=None if res is None else res.to(dev))
     assert rel_l2(out.float().cpu().numpy(), ref.numpy()) < TOL
     # the three-launch path of the module on the same operands
     m._kv_pre = (k, vt, wk.shape[0])
     old = A.FUSE_XATTN
+    if C == 640:                                        # and the module takes the one-launch form when its switch is on
+        old640, A.FUSE_XATTN640, min640, A.XATTN640_FUSE_MIN_TOKENS = A.FUSE_XATTN640, True, A.XATTN640_FUSE_MIN_TOKENS, 64
+        try:
+            if with_ln and A.FUSE_XATTN:
+                assert m.xattn_fusable(C, B, N, L, ln) and not m.xattn_fusable(C, B, N, L, ln, chain=True)
+                out1 = m.hip(x.to(dev), B, N, context=ctx.to(dev), residual=None if res is None else res.to(dev), ln=ln)
+                assert torch.equal(out1, out)
+        finally:
+            A.FUSE_XATTN640, A.XATTN640_FUSE_MIN_TOKENS = old640, min640
     A.FUSE_XATTN = False
     try:
         out3 = m.hip(x.to(dev), B, N, context=ctx.to(dev), residual=None if res is None else res.to(dev), ln=ln if with_ln else None)
@@ -1095,11 +1107,11 @@ def test_xattn_fused_c320(dev, B, N, L, with_ln, with_res, ld_extra):
         for bad in (float("nan"), float("inf"), -65504.0):
             vt_h = vt_all.clone()
             vt_h[..., L:] = bad
-            out_h = ops.xattn_fused(x.to(dev), pq, k, vt_h[:, 640:960, :], m.to_out[0].packed(), B=B, N=N, L=L, heads=heads, scale=40 ** -0.5,
+            out_h = ops.xattn_fused(x.to(dev), pq, k, vt_h[:, 640:640 + C, :], m.to_out[0].packed(), B=B, N=N, L=L, heads=heads, scale=dh ** -0.5,
                                     ldk=wk.shape[0], residual=None if res is None else res.to(dev))
             assert torch.isfinite(out_h).all(), f"pad = {bad}"
             assert torch.equal(out_h, out), f"pad = {bad}"
-            m._kv_pre = (k, vt_h[:, 640:960, :], wk.shape[0])
+            m._kv_pre = (k, vt_h[:, 640:640 + C, :], wk.shape[0])
             A.FUSE_XATTN = False
             try:
                 out3_h = m.hip(x.to(dev), B, N, context=ctx.to(dev), residual=None if res is None else res.to(dev), ln=ln if with_ln else None)
@@ -1414,3 +1426,46 @@ def test_split_k_in_kernel_reduction_is_bit_identical_and_repeatable(dev, tile, 
     monkeypatch.setattr(ops, "SPLITK_FUSED_MAX", 4)
     for rep in range(5):
         assert torch.equal(ops.conv3x3(x, pc, x2=x2, tile=tile, splits=3), wc), rep
+
+
+@pytest.mark.parametrize("B,H,W,c1,c2,cout,up,splits,extras,variant", [
+    (1, 64, 64, 128, 0, 128, False, 1, True, 2), (2, 32, 32, 64, 0, 256, False, 1, False, 2), (1, 16, 16, 128, 0, 128, False, 2, True, 2), (4, 8, 8, 128, 64, 128, False, 1, True, 2),
+    (1, 128, 128, 64, 0, 128, False, 1, True, 3), (2, 128, 128, 128, 0, 256, False, 1, False, 3), (1, 256, 256, 64, 0, 128, False, 1, True, 3),
+    (1, 64, 64, 128, 0, 128, True, 1, False, 3), (1, 144, 176, 64, 0, 128, False, 1, True, 3), (1, 128, 128, 64, 64, 512, False, 1, True, 3),
+    (2, 64, 32, 64, 0, 128, True, 1, True, 2)])
+def test_conv3x3_tile14_256x128_tile_and_patches(dev, B, H, W, c1, c2, cout, up, splits, extras, variant):
+    """Round 6: the halo-resident kernel on the VAE's channel counts and image sizes (model.py:136-175, 536-567) -- a 256 x 128 tile where N is no
+    160-multiple (af_gemm_halo_variant 2), and 16 x 16-pixel patches on images wider than 64 pixels (variant 3: borders on all four sides of a patch,
+    nearest-x2 sources, two sources, non-square images) -- against torch conv2d in fp32 and the tap-by-tap tile."""
+    from adaface_dev_amd import ops, _lib
+    import ctypes as C
+    x1 = rnd((B, H, W, c1), 1)
+    x2 = rnd((B, H, W, c2), 2) if c2 else None
+    cin = c1 + c2
+    w = rnd((cout, cin, 3, 3), 3, (9 * cin) ** -0.5)
+    bias = torch.randn(cout, generator=torch.Generator().manual_seed(4))
+    xin = (x1 if x2 is None else torch.cat([x1, x2], -1)).float().permute(0, 3, 1, 2)
+    if up:
+        xin = F.interpolate(xin, scale_factor=2, mode="nearest")
+    ref = F.conv2d(xin, w.float(), bias, padding=1)
+    Ho, Wo = ref.shape[2:]
+    rowb = res = None
+    if extras:
+        rowb = rnd((B, cout), 5)
+        res = rnd((B, Ho, Wo, cout), 6)
+        ref = ref + rowb.float()[:, :, None, None] + res.float().permute(0, 3, 1, 2)
+    d = _lib.GemmDesc()
+    d.taps, d.c1, d.c2, d.N, d.B, d.H, d.W, d.Ho, d.Wo, d.M, d.upsample, d.stride = 9, c1, c2, cout, B, H, W, Ho, Wo, B * Ho * Wo, int(up), 1
+    d.K, d.kpad = 9 * cin, 9 * cin
+    assert _lib.lib().af_gemm_halo_variant(C.byref(d)) == variant
+    d.splits = splits
+    assert ops.conv_halo_eligible(d)
+    pw = ops.pack_conv3x3(w, bias, dev)
+    kw = dict(x2=None if x2 is None else x2.to(dev), upsample=up, rowbias=None if rowb is None else rowb.to(dev), residual=None if res is None else res.to(dev))
+    out = ops.conv3x3(x1.to(dev), pw, tile=14, splits=splits, **kw)
+    assert rel_l2(out.float().cpu().permute(0, 3, 1, 2).numpy(), ref.numpy()) < TOL
+    out8 = ops.conv3x3(x1.to(dev), pw, tile=8, splits=1, **kw)
+    assert rel_l2(out.float().cpu().numpy(), out8.float().cpu().numpy()) < 2e-3
+    assert (out.float() - out8.float()).abs().max().item() < 0.05 * max(1.0, out8.float().abs().max().item())      # no misplaced patch / row anywhere
+    for _ in range(3):
+        assert torch.equal(ops.conv3x3(x1.to(dev), pw, tile=14, splits=splits, **kw), out)

@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--tiles", default="", help="comma-separated tile ids to time (default: all)")
     ap.add_argument("--trace", action="store_true", help="print every configuration before it is launched (to find one that faults)")
     ap.add_argument("--try-tile", type=int, default=0, help="for every shape this run meets that is ALREADY in the table: time the table's choice against this tile (splits 1, 2) and take the tile only where it is > 2 %% faster")
+    ap.add_argument("--new-halo-forms", action="store_true", help="with --try-tile 14: only the shapes that the kernel's round-6 forms took into its scope (256 x 128 tile, 16 x 16-pixel patches: the VAE's shapes)")
     ap.add_argument("--retune-halo", action="store_true", help="re-time only the 3x3 shapes in the scope of the halo-resident kernel (tile 14)")
     ap.add_argument("--protect", default="", help="comma-separated logs of tools/autotune_instep.py: the shapes they decided inside a step are left alone")
     args = ap.parse_args()
@@ -151,6 +152,8 @@ def main():
             tl = args.try_tile
             ok = not (tl == 15 and (d.act == _lib.AF_ACT_GEGLU or d.out_mode != 0 or d.N % 128 != 0 or d.M < 16384 or d.c1 % 64 or d.c2 % 64 or d.upsample not in (0, 1)))
             ok = ok and candidate_ok(d, tl, 1, _lib, ops)           # (outside its scope the library falls back to another tile silently)
+            if args.new_halo_forms:
+                ok = ok and tl == 14 and L.af_gemm_halo_variant(C.byref(d)) in (2, 3)
             if ok:
                 cur = table[key]
                 t_cur = timed(d, device, cur[0], cur[1])

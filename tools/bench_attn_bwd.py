@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Attention backward (af_attention_bwd: three transposes + delta + dQ kernel + dK/dV kernel) timed per kernel with rocprofv3-free
 HIP events on the shapes of the U-Net: self-attention of the 64x64 / 32x32 / 16x16 levels and the 97-key cross-attention.
-    python tools/bench_attn_bwd.py [batch]"""
+    python tools/bench_attn_bwd.py [batch] [substring of the shape's name: only that one]"""
 import os
 import sys
 
@@ -13,10 +13,13 @@ import torch  # noqa: E402
 def main():
     from adaface_dev_amd import ops
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+    only = sys.argv[2] if len(sys.argv) > 2 else ""
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(0)
     for name, N, L, heads, d in (("self 64x64", 4096, 4096, 8, 40), ("self 32x32", 1024, 1024, 8, 80), ("self 16x16", 256, 256, 8, 160),
                                  ("cross 64x64", 4096, 97, 8, 40), ("cross 32x32", 1024, 97, 8, 80)):
+        if only not in name:
+            continue
         C = heads * d
         q = torch.randn(B * N, C, generator=g).half().to(dev)
         k = torch.randn(B * L, C, generator=g).half().to(dev)
