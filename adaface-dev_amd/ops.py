@@ -224,12 +224,25 @@ def _zero_page(device) -> torch.Tensor:
 def _splitk_workspace(device) -> torch.Tensor:
     """fp32 partial slabs + (last AF_SPLITK_COUNTER_BYTES) the per-tile arrival counters of the in-kernel reduction, which must be
     zero between launches: zeroed here once, every launch restores them."""
-    ws = _splitk_ws.get(device)
+    key = device if _ws_lane == 0 else (device, _ws_lane)
+    ws = _splitk_ws.get(key)
     if ws is None:
         ws = torch.empty((SPLITK_WS_BYTES // 4,), dtype=torch.float32, device=device)
         ws[-(_lib.AF_SPLITK_COUNTER_BYTES // 4):].zero_()
-        _splitk_ws[device] = ws
+        _splitk_ws[key] = ws
     return ws
+
+
+_ws_lane = 0
+
+
+def set_workspace_lane(lane: int) -> int:
+    """Launches issued from now on use split-K workspace number ``lane`` (0 = the default one).  The slab workspace is the one piece of scratch every
+    launch of a device shares; a caller that runs two independent passes CONCURRENTLY on two streams (tools/probes/r06w_two_streams.py) gives each stream
+    its own lane while it issues that stream's launches.  Returns the previous lane."""
+    global _ws_lane
+    prev, _ws_lane = _ws_lane, int(lane)
+    return prev
 
 
 # split-K with at most this many slices is reduced inside the GEMM launch by the last-arriving workgroup of each tile (one launch

@@ -719,6 +719,7 @@ def test_groupnorm(dev, B, HW, c1, c2, eps, silu):
     (2, 1024, 640, "pair"), (3, 256, 960, "pair"),            # ... 4-byte pairs in registers
     (2, 4096, 320, "two-launch"), (1, 16384, 256, "two-launch"), (2, 4000, 640, "two-launch"),   # partial blocks + normalise
     (2, 4096, 320, "producer"), (1, 1024, 640, "producer"), (2, 4096, 320, "producer14"),         # partials from the producing GEMM's epilogue
+    (1, 16384, 256, "producer14"), (2, 4096, 512, "producer14"),                                   # ... of the halo-resident kernel's 256 x 128 forms (patches / whole rows)
 ])
 def test_groupnorm_with_group_mean_far_above_its_spread(dev, B, HW, C, path, ratio):
     """GroupNorm statistics when |mean| / sigma of a group is 10, 100, 1000 (outlier channels of real SD-1.5 checkpoints): a one-pass
@@ -758,7 +759,7 @@ def test_groupnorm_with_group_mean_far_above_its_spread(dev, B, HW, C, path, rat
 
 @pytest.mark.parametrize("B,HW,C,path", [
     (2, 64, 1280, "small"), (2, 1024, 640, "pair"), (2, 4096, 320, "two-launch"), (2, 4096, 320, "producer"), (1, 1024, 640, "producer"),
-    (2, 4096, 320, "producer14"),
+    (2, 4096, 320, "producer14"), (1, 16384, 128, "producer14"),
 ])
 def test_groupnorm_with_opposite_signed_outliers_near_the_fp16_maximum(dev, B, HW, C, path):
     """Groups that hold +6e4 and -6e4 (the SD fp16 VAE / decoder trunk carries activations in the 1e4 range): |x - pivot| reaches 1.2e5, past
