@@ -1433,7 +1433,7 @@ def test_split_k_in_kernel_reduction_is_bit_identical_and_repeatable(dev, tile, 
     (1, 64, 64, 128, 0, 128, False, 1, True, 2), (2, 32, 32, 64, 0, 256, False, 1, False, 2), (1, 16, 16, 128, 0, 128, False, 2, True, 2), (4, 8, 8, 128, 64, 128, False, 1, True, 2),
     (1, 128, 128, 64, 0, 128, False, 1, True, 3), (2, 128, 128, 128, 0, 256, False, 1, False, 3), (1, 256, 256, 64, 0, 128, False, 1, True, 3),
     (1, 64, 64, 128, 0, 128, True, 1, False, 3), (1, 144, 176, 64, 0, 128, False, 1, True, 3), (1, 128, 128, 64, 64, 512, False, 1, True, 3),
-    (2, 64, 32, 64, 0, 128, True, 1, True, 2)])
+    (2, 64, 32, 64, 0, 128, True, 1, True, 2), (3, 128, 144, 64, 0, 128, False, 1, True, 3)])
 def test_conv3x3_tile14_256x128_tile_and_patches(dev, B, H, W, c1, c2, cout, up, splits, extras, variant):
     """Round 6: the halo-resident kernel on the VAE's channel counts and image sizes (model.py:136-175, 536-567) -- a 256 x 128 tile where N is no
     160-multiple (af_gemm_halo_variant 2), and 16 x 16-pixel patches on images wider than 64 pixels (variant 3: borders on all four sides of a patch,
