@@ -1553,6 +1553,31 @@ __global__ __launch_bounds__(512) void af_conv3hd_kernel(const Gemm3Dev p) {
     glds16_sbase(src, (unsigned)(m0 + pc * 8 + prow) * ld2 + chunk16, af_smem + buf_off + pc * 1024);
   };
 
+#ifdef AF_CONV3H_GN_PROBE
+  // TIMING PROBE ONLY (-DAF_CONV3H_GN_PROBE, tools/probes/r06ab_gn_in_conv_probe.sh; results are NOT a convolution of the input): what the round-5 review's
+  // item 1.ii -- GroupNorm-apply + SiLU inside this kernel -- would add to the loop.  Halo piece j of chunk u, 16 bytes per lane, is read back from LDS once
+  // it has landed, turned into silu(x * g[c] * r + s) with per-channel factors from memory and written back (pad positions stay zero), one piece per
+  // stage in the L part of the stage after the one that requested it: the best schedule the loop offers.
+  const float probe_r = 1.0f + p.ln_eps, probe_s = p.ln_eps;
+  auto gn_probe_piece = [&](int j, int buf_off, int u) {
+    if (wave + NW * j < NP) {
+      char* q = af_smem + buf_off + (wave + NW * j) * 1024 + lane * 16;
+      const half8_t v = *reinterpret_cast<const half8_t*>(q);
+      const int ch = ((u * 64) & 255) + (int)(chunk16 >> 1);
+      const floatx4 g0 = *reinterpret_cast<const floatx4*>(p.bias + ch), g1 = *reinterpret_cast<const floatx4*>(p.bias + ch + 4);
+      half8_t o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float y = af_silu(fmaf((float)v[e] * (e < 4 ? g0[e] : g1[e - 4]), probe_r, probe_s));
+        o[e] = a_pix[j] >= 0 ? (half_t)y : (half_t)0.f;
+      }
+      *reinterpret_cast<half8_t*>(q) = o;
+    }
+  };
+#define CHD_GN_PROBE(TAP) if (!last && (TAP) >= 1 && (TAP) - 1 < APW) gn_probe_piece((TAP) >= 1 ? (TAP) - 1 : 0, nbuf, u + 1);
+#else
+#define CHD_GN_PROBE(TAP)
+#endif
   floatx4 acc[TN][TM];
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn)
@@ -1614,6 +1639,12 @@ __global__ __launch_bounds__(512) void af_conv3hd_kernel(const Gemm3Dev p) {
     issue_w(cb, 1, 1);                                               // stage 1: every wave's pieces
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef AF_CONV3H_GN_PROBE
+  if (nchunks > 0) {
+#pragma unroll
+    for (int j = 0; j < APW; ++j) gn_probe_piece(j, 0, cb);
+  }
+#endif
   // the halo's out-of-image positions: zero in BOTH buffers, once (no DMA ever writes them)
 #pragma unroll
   for (int j = 0; j < APW; ++j)
@@ -1639,6 +1670,7 @@ __global__ __launch_bounds__(512) void af_conv3hd_kernel(const Gemm3Dev p) {
         CHD_READ_FRAGS(TAP)                                                                                                      \
         if (!(first && (TAP) == 0) && !(last && (TAP) == 8)) issue_w((TAP) < 8 ? u : u + 1, ((TAP) + 1) % 9, ((TAP) + 1) % 3);   \
         if (!last && (TAP) < APW) issue_halo_piece((TAP) < APW ? (TAP) : 0, hsrc, hld2, nbuf);                                   \
+        CHD_GN_PROBE(TAP)                                                                                                        \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                       \
         __builtin_amdgcn_sched_barrier(0);                                                                                       \
         __builtin_amdgcn_s_barrier();                                                                                            \
@@ -1682,6 +1714,7 @@ __global__ __launch_bounds__(512) void af_conv3hd_kernel(const Gemm3Dev p) {
         CHD_READ_FRAGS(TAP)                                                                                                      \
         if (!(last && (TAP) >= 7)) issue_w((TAP) < 7 ? u : u + 1, ((TAP) + 2) % 9, ((TAP) + 2) % 3);                             \
         if (!last && (TAP) < APW) issue_halo_piece((TAP) < APW ? (TAP) : 0, hsrc, hld2, nbuf);                                   \
+        CHD_GN_PROBE(TAP)                                                                                                        \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                       \
         __builtin_amdgcn_sched_barrier(0);                                                                                       \
         __builtin_amdgcn_s_barrier();                                                                                            \
@@ -1704,6 +1737,7 @@ __global__ __launch_bounds__(512) void af_conv3hd_kernel(const Gemm3Dev p) {
     __builtin_amdgcn_s_barrier();
   }
 #undef CHD_READ_FRAGS
+#undef CHD_GN_PROBE
   if (TAIL && tail_here) {
     // ---- the K tail, lock step (every wave: wait, barrier, issue the next stage, 18 fragment reads, 40 MFMAs): a tail stage moves a whole 32 KB A tile
     // + 20 KB of weights, the tap-by-tap tile's traffic, and one stage of look-ahead is all the three-slot ring and the two halo buffers allow.
