@@ -29,7 +29,7 @@ EXPORTS = (
     "af_transpose_tokens", "af_cadamw_step", "af_attention_ex", "af_colsum", "af_quickgelu_fwd", "af_quickgelu_bwd",
     "af_scale_f32", "af_affine_prelu", "af_maxpool2x2", "af_global_avgpool", "af_se_residual_prelu", "af_axpy_f16", "af_dora_combine", "af_mul_f16", "af_im2col3x3", "af_colsum_tall", "af_softmax_rows", "af_attention_strided", "af_clamp_f32", "af_mask_pairs", "af_prefetch", "af_prefetch_ex",
     "af_xattn_scores", "af_xattn_softmax_pv", "af_xattn_softmax_pv_bwd", "af_xattn_rowmix", "af_xattn_colmix_ws_bytes", "af_xattn_colmix",
-    "af_layernorm_param_grads", "af_transpose_tokens_pair", "af_ff_fused", "af_xattn_fused",
+    "af_layernorm_param_grads", "af_transpose_tokens_pair", "af_ff_fused", "af_ff_chain", "af_xattn_fused",
     "af_softmax_rows_bwd", "af_affine_prelu_bwd", "af_maxpool2x2_bwd", "af_se_gate_grad", "af_se_residual_prelu_bwd",
     "af_groupnorm_apply", "af_gemm_gn_stats_ok", "af_gemm_halo_variant", "af_gn_proj_fused",
     "af_splitk_reduce", "af_groupnorm_splitk_ok", "af_groupnorm_splitk", "af_xattn_chain",
@@ -187,6 +187,7 @@ def lib() -> C.CDLL:
     L.af_transpose_tokens_pair.argtypes = [vp, vp, i32, i32, vp, vp, i32, i32, i32, i32, i32, vp]
     L.af_cadamw_step.argtypes = [vp, vp, vp, vp, vp, i32, vp, f32, f32, f32, f32, f32, i32, i32, vp]
     L.af_ff_fused.argtypes = [vp, vp, vp, vp, f32, i32, vp, vp, i32, vp, vp, i32, i32, i32, vp, vp]
+    L.af_ff_chain.argtypes = [vp, vp, vp, vp, f32, i32, vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]
     L.af_xattn_fused.argtypes = [vp, vp, vp, vp, f32, i32, vp, i32, vp, i64, i32, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, f32, vp, vp]
     L.af_xattn_chain.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp, vp, f32, i32, vp, i32, vp, i64, i32, vp, vp, i32, vp, i32, i32, i32, i32, i32, f32, vp, vp]
     for name in EXPORTS:

@@ -1895,8 +1895,17 @@ struct FfDev {
   int M, inner, kpad1, kpad2;
   float ln_eps;
   Gemm3Dev epi;          // what the final (standard, staged) epilogue reads: bias = b2, residual, out, M, N = 320, ld_out
+  // TAILP (af_ff_chain, round 6): the SpatialTransformer's proj_out + residual behind the feed-forward (attention.py:287-304): out = x_in + b_p + W_p x3 with
+  // x3 = the feed-forward's own result (epi: b2 + residual, never written to memory); nullptr / unused otherwise
+  const half_t* wp;      // packed [>= 320][kpad_p]
+  int kpad_p;
+  Gemm3Dev epi_p;        // the tail's epilogue: bias = b_p, residual = x_in, out, GroupNorm partials of the block's output
 };
 
+// TAILP: x3 = OUT + b2 + residual goes into the X tile's LDS (the swizzled fp16 layout GEMM1 read x from) instead of memory, and a third GEMM, 128 x 320 x 320 with
+// W_p, runs over it: W_p streams as 2 row halves x 5 K stages of [160 rows x 64 K] (20 KB) through a three-slot ring in the W1 / W2 area (72 KB); the waves keep
+// their 64 x 80 output tiles, so a row half is computed by the four waves that own its columns (a 26 MFLOP GEMM: the MFMA time is not what it costs).
+template <bool TAILP>
 __global__ __launch_bounds__(512, 1) void af_ff320_kernel(FfDev p) {
   constexpr int NW = 8, NWM = 2, TM = 4;
   extern __shared__ __attribute__((aligned(16))) char af_smem[];
@@ -2079,7 +2088,86 @@ __global__ __launch_bounds__(512, 1) void af_ff320_kernel(FfDev p) {
       }
     }
   }
-  gemm3_epilogue<E3_STD, 2, 4, 5, FF_XS + 2 * FF_W1S + FF_W2B>(p.epi, acc2, af_smem, tile_m, 0, wm, wn, fr, fq, tid, nullptr);
+  if constexpr (!TAILP) {
+    gemm3_epilogue<E3_STD, 2, 4, 5, FF_XS + 2 * FF_W1S + FF_W2B>(p.epi, acc2, af_smem, tile_m, 0, wm, wn, fr, fq, tid, nullptr);
+  } else {
+    constexpr int PST = 160 * 128;                                 // one W_p stage: 160 rows x 64 K
+    static_assert(3 * PST <= 2 * FF_W1S + FF_W2B, "the three-slot W_p ring lives in the W1 ring + W2 tile area");
+    auto issue_wp = [&](int sidx) {                                // stage sidx = (row half sidx / 5, K chunk sidx % 5): 20 pieces of 8 rows, wave w takes w, w + 8, (w + 16)
+      const int nh = sidx >= 5 ? 1 : 0, kc = sidx - 5 * nh;
+      char* dst = W1r + (sidx % 3) * PST;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int pc = wave + NW * j;
+        if (pc < 20) {
+          const int row = pc * 8 + prow;
+          const int lc = slot ^ ((row >> 1) & 7);
+          glds16(p.wp + (size_t)(nh * 160 + row) * p.kpad_p + kc * 64 + lc * 8, dst + pc * 1024);
+        }
+      }
+    };
+    __syncthreads();                                               // every wave is done with x, G and the W2 tile
+    issue_wp(0);
+    issue_wp(1);
+    // x3 = OUT + b2 + residual (the arithmetic and order of the standard epilogue) -> fp16 -> the X tile
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      const int row = wm * 64 + tm * 16 + fr, m = tile_m * FF_BM + row;
+#pragma unroll
+      for (int tn = 0; tn < 5; ++tn) {
+        const int c = wn * 80 + tn * 16 + 4 * fq;
+        floatx4 v = acc2[tn][tm];
+        half4_t o = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+        if (m < p.M) {
+          if (p.epi.bias) {
+            const floatx4 bv = *reinterpret_cast<const floatx4*>(p.epi.bias + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += bv[e];
+          }
+          if (p.epi.residual) {
+            const half4_t rv = *reinterpret_cast<const half4_t*>(p.epi.residual + (size_t)m * FF_C + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
+          }
+          o = half4_t{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+        }
+        *reinterpret_cast<half4_t*>(Xs + (c >> 6) * (FF_BM * 128) + row * 128 + ((((c & 63) >> 3) ^ ((row >> 1) & 7)) * 16) + ((c >> 2) & 1) * 8) = o;
+      }
+    }
+    floatx4 acc3[5][TM];
+#pragma unroll
+    for (int tn = 0; tn < 5; ++tn)
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) acc3[tn][tm] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma nounroll
+    for (int sidx = 0; sidx < 10; ++sidx) {
+      // stage sidx must have landed; the stage behind it (this wave's 3 / 2 pieces, issued one iteration ago) may still fly
+      if (sidx == 9) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      else if (wave < 4) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                                // ... for every wave (first pass: the x3 tile is complete); the slot refilled next is free
+      if (sidx + 2 < 10) issue_wp(sidx + 2);
+      const int nh = sidx >= 5 ? 1 : 0, kc = sidx - 5 * nh;
+      if ((wn >> 1) == nh) {
+        const char* Ws = W1r + (sidx % 3) * PST;
+        const char* As = Xs + kc * (FF_BM * 128);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          const int rd = kk ? rd1 : rd0;
+          half8_t wf[5], xf[TM];
+#pragma unroll
+          for (int tn = 0; tn < 5; ++tn) wf[tn] = *reinterpret_cast<const half8_t*>(Ws + ((wn & 1) * 80 + tn * 16) * 128 + rd);
+#pragma unroll
+          for (int tm = 0; tm < TM; ++tm) xf[tm] = *reinterpret_cast<const half8_t*>(As + (wm * 64 + tm * 16) * 128 + rd);
+#pragma unroll
+          for (int tn = 0; tn < 5; ++tn)
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) acc3[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[tn], xf[tm], acc3[tn][tm], 0, 0, 0);
+        }
+      }
+    }
+    gemm3_epilogue<E3_STD, 2, 4, 5, FF_XS + 2 * FF_W1S + FF_W2B>(p.epi_p, acc3, af_smem, tile_m, 0, wm, wn, fr, fq, tid, nullptr);
+  }
 }
 
 }  // namespace
@@ -2276,7 +2364,7 @@ extern "C" int af_ff_fused(const void* x, const void* w1, const void* b1, const 
   AF_SUPPORTED(C == FF_C, "af_ff_fused: built for C = 320 (the 64 x 64 level of SD-1.5)");
   AF_REQUIRE(M > 0 && inner > 0 && inner % FF_HC == 0, "af_ff_fused: inner must be a positive multiple of 64");
   AF_REQUIRE(kpad1 >= C && kpad1 % 64 == 0 && kpad2 >= inner && kpad2 % 64 == 0, "af_ff_fused: weight row strides must be 64-multiples covering K");
-  FfDev p;
+  FfDev p{};
   p.x = (const half_t*)x;
   p.w1 = (const half_t*)w1;
   p.b1 = (const float*)b1;
@@ -2303,7 +2391,63 @@ extern "C" int af_ff_fused(const void* x, const void* w1, const void* b1, const 
   e.stage_ok = (reinterpret_cast<uintptr_t>(out) & 15) == 0;
   AfLaunchScope scope(AF_FAM_GEMM, stream);
   static bool attr_set = false;
-  const bool lds_ok = af_allow_dyn_lds(reinterpret_cast<const void*>(&af_ff320_kernel), FF_LDS + AF_WPF_DUMP_BYTES, attr_set, "af_gemm");
-  if (lds_ok) hipLaunchKernelGGL(af_ff320_kernel, dim3((M + FF_BM - 1) / FF_BM), dim3(512), FF_LDS + AF_WPF_DUMP_BYTES, (hipStream_t)stream, p);
+  const bool lds_ok = af_allow_dyn_lds(reinterpret_cast<const void*>(&af_ff320_kernel<false>), FF_LDS + AF_WPF_DUMP_BYTES, attr_set, "af_gemm");
+  if (lds_ok) hipLaunchKernelGGL(af_ff320_kernel<false>, dim3((M + FF_BM - 1) / FF_BM), dim3(512), FF_LDS + AF_WPF_DUMP_BYTES, (hipStream_t)stream, p);
   return af_check_launch("af_ff_fused");
+}
+
+// The feed-forward with the SpatialTransformer's proj_out + residual behind it (af_ff320_kernel<true>; attention.py:287-304: x = proj_out(blocks(proj_in(norm(x)))) + x_in):
+//     x3 = residual + b2 + W2 (v * gelu(g))      (what af_ff_fused writes; here it stays in LDS)
+//     out = x_in + b_p + W_p x3
+// gn_partials / gn_cpg / rows_per_batch: GroupNorm partial statistics of `out` as af_gemm_desc.gn_partials leaves them ([M / rows_per_batch][128][32][2] floats; NULL = none).
+extern "C" int af_ff_chain(const void* x, const void* w1, const void* b1, const void* ln_colsum, float ln_eps, int kpad1, const void* w2, const void* b2, int kpad2,
+                           const void* residual, const void* wp, const void* bp, int kpad_p, const void* x_in, void* out, void* gn_partials, int gn_cpg,
+                           int rows_per_batch, int M, int C, int inner, const void* zeros, void* stream) {
+  AF_REQUIRE(x && w1 && b1 && w2 && wp && out && zeros, "af_ff_chain: null pointer");
+  AF_SUPPORTED(C == FF_C, "af_ff_chain: built for C = 320 (the 64 x 64 level of SD-1.5)");
+  AF_REQUIRE(M > 0 && inner > 0 && inner % FF_HC == 0, "af_ff_chain: inner must be a positive multiple of 64");
+  AF_REQUIRE(kpad1 >= C && kpad1 % 64 == 0 && kpad2 >= inner && kpad2 % 64 == 0 && kpad_p >= C && kpad_p % 64 == 0, "af_ff_chain: weight row strides must be 64-multiples covering K");
+  AF_REQUIRE((((uintptr_t)out | (uintptr_t)residual | (uintptr_t)x_in | (uintptr_t)b2 | (uintptr_t)bp) & 15) == 0, "af_ff_chain: out / residual / x_in / b2 / bp must be 16-byte aligned");
+  if (gn_partials != nullptr) {
+    AF_REQUIRE(gn_cpg > 0 && gn_cpg % 2 == 0 && C % gn_cpg == 0 && C / gn_cpg <= 32 && rows_per_batch > 0 && rows_per_batch % FF_BM == 0 && M % rows_per_batch == 0 &&
+                   rows_per_batch / 128 <= 128,
+               "af_ff_chain: gn_partials needs an even gn_cpg dividing C into at most 32 groups and whole 128-row blocks per batch item (at most 128)");
+  }
+  FfDev p{};
+  p.x = (const half_t*)x;
+  p.w1 = (const half_t*)w1;
+  p.b1 = (const float*)b1;
+  p.cs1 = ln_colsum ? (const float*)ln_colsum : (const float*)b1;
+  p.ln_on = ln_colsum != nullptr;
+  p.w2 = (const half_t*)w2;
+  p.zeros = (const half_t*)zeros;
+  p.M = M;
+  p.inner = inner;
+  p.kpad1 = kpad1;
+  p.kpad2 = kpad2;
+  p.ln_eps = ln_eps;
+  p.wp = (const half_t*)wp;
+  p.kpad_p = kpad_p;
+  p.epi = Gemm3Dev{};
+  p.epi.bias = (const float*)b2;
+  p.epi.residual = (const half_t*)residual;
+  Gemm3Dev& e = p.epi_p;
+  e = Gemm3Dev{};
+  e.bias = (const float*)bp;
+  e.residual = (const half_t*)x_in;
+  e.out = (half_t*)out;
+  e.M = M;
+  e.N = C;
+  e.K = C;
+  e.ld_out = C;
+  e.splits = 1;
+  e.rows_per_batch = gn_partials ? rows_per_batch : M;
+  e.stage_ok = 1;
+  e.gn_ws = (float*)gn_partials;
+  e.gn_cpg = gn_cpg;
+  AfLaunchScope scope(AF_FAM_GEMM, stream);
+  static bool attr_set = false;
+  const bool lds_ok = af_allow_dyn_lds(reinterpret_cast<const void*>(&af_ff320_kernel<true>), FF_LDS + AF_WPF_DUMP_BYTES, attr_set, "af_gemm");
+  if (lds_ok) hipLaunchKernelGGL(af_ff320_kernel<true>, dim3((M + FF_BM - 1) / FF_BM), dim3(512), FF_LDS + AF_WPF_DUMP_BYTES, (hipStream_t)stream, p);
+  return af_check_launch("af_ff_chain");
 }

@@ -34,6 +34,7 @@ FOLD_LAYERNORM = _os.environ.get("AF_FOLD_LAYERNORM", "1") != "0"
 FUSE_GN_PROJ = _os.environ.get("AF_FUSE_GN_PROJ", "1") != "0"      # SpatialTransformer: GroupNorm's normalising pass + proj_in in one launch at C = 320 (af_gn_proj_fused)
 CHAIN_XATTN = _os.environ.get("AF_CHAIN_XATTN", "1") != "0"    # round 6: the self-attention's to_out + residual as phase 0 of the one-launch C = 320 cross-attention block (af_xattn_chain)
 XATTN_FUSE_MIN_TOKENS = int(_os.environ.get("AF_XATTN_FUSE_MIN_TOKENS", "8192"))   # U-Net batch x tokens from which the one-launch block is used
+CHAIN_PROJ_OUT = _os.environ.get("AF_CHAIN_PROJ_OUT", "1") != "0"   # the SpatialTransformer's proj_out + residual as the tail of the one-launch feed-forward at C = 320 (af_ff_chain, round 6)
 FUSE_XATTN640 = _os.environ.get("AF_FUSE_XATTN640", "0") != "0"  # the C = 640 blocks as one launch too (af_xattn640t_kernel, round 6): measured, see DESIGN.md 8.0
 XATTN640_FUSE_MIN_TOKENS = 4096                                   # 64-token workgroups: 64 of them at least
 FUSE_XATTN = _os.environ.get("AF_FUSE_XATTN", "1") != "0"      # the C = 320 cross-attention block as ONE launch (af_xattn_fused): on par with the
@@ -122,7 +123,15 @@ class FeedForward(nn.Module):
             raise NotImplementedError("dropout > 0 is not supported (SD-1.5 uses 0)")
         self.net = nn.Sequential(GEGLU(dim, inner_dim), nn.Dropout(dropout), Linear(inner_dim, dim_out))
 
-    def hip(self, x2d, residual=None, ln=None):
+    def ff_fusable(self, M, C, ln) -> bool:
+        """Whether this feed-forward runs as the one-launch C = 320 kernel (af_ff_fused / af_ff_chain)."""
+        return bool(FUSE_FF and ln is not None and C == 320 and M >= 24576)
+
+    def hip(self, x2d, residual=None, ln=None, post=None):
+        """post = (proj_out pack, x_in 2-D, rows per image, gn_cpg): the SpatialTransformer's proj_out + residual chained behind (af_ff_chain; the caller checked ff_fusable)."""
+        if post is not None:
+            pw_p, x_in, rpb, cpg = post
+            return ops.ff_chain(x2d, self.net[0].packed_ln(ln), self.net[2].packed(), residual, pw_p, x_in, rows_per_batch=rpb, gn_cpg=cpg)
         if FUSE_FF and ln is not None and x2d.shape[1] == 320 and x2d.shape[0] >= 24576:
             # the 64 x 64 level: LayerNorm, GEGLU projection, output projection and residual as ONE launch (af_ff_fused): the
             # [tokens, 1280] intermediate never leaves the compute unit.  One workgroup per 128 tokens: worth it once they fill the chip
@@ -323,8 +332,10 @@ class BasicTransformerBlock(nn.Module):
         self.norm3 = LayerNorm(dim)
         self.checkpoint = checkpoint
 
-    def hip(self, x2d, B, N, context=None, keybias=None):
-        """attention.py:242-252 with the three residual adds fused into GEMM epilogues."""
+    def hip(self, x2d, B, N, context=None, keybias=None, post=None):
+        """attention.py:242-252 with the three residual adds fused into GEMM epilogues.  post (SpatialTransformer.hip, its LAST block only) = (proj_out pack, x_in 2-D,
+        rows per image, gn_cpg): proj_out + residual run as the tail of the one-launch feed-forward where that runs (af_ff_chain) -- the return value is then the
+        SpatialTransformer's output and ``post_done(...)`` says so."""
         if FOLD_LAYERNORM and x2d.shape[1] % 64 == 0:
             # the LayerNorms do not run as kernels: each is folded into the projection GEMM that consumes it.  Below ~1,000 rows (the
             # 8 x 8 level) the q | k | v and to_q GEMMs sit on the register-staged 64 x 64 tile, which has no fold, and a 3.8 us LayerNorm
@@ -335,13 +346,17 @@ class BasicTransformerBlock(nn.Module):
                 # the 64 x 64 level: attn1's to_out + residual run as phase 0 of the one-launch cross-attention block (af_xattn_chain)
                 pre = self.attn1.hip(x2d, B, N, None, keybias, residual=x2d, ln=self.norm1, defer_out=True)
                 x2 = self.attn2.hip(None, B, N, context, None, residual=None, ln=self.norm2, pre=pre)
-                return self.ff.hip(x2, residual=x2, ln=self.norm3)
+                return self.ff.hip(x2, residual=x2, ln=self.norm3, post=post if self.post_done(x2d.shape[0], x2d.shape[1], post) else None)
             x1 = self.attn1.hip(self.norm1.hip(x2d) if small else x2d, B, N, None, keybias, residual=x2d, ln=None if small else self.norm1)
             x2 = self.attn2.hip(self.norm2.hip(x1) if small else x1, B, N, context, None, residual=x1, ln=None if small else self.norm2)
-            return self.ff.hip(x2, residual=x2, ln=self.norm3)
+            return self.ff.hip(x2, residual=x2, ln=self.norm3, post=post if self.post_done(x2d.shape[0], x2d.shape[1], post) else None)
         x1 = self.attn1.hip(self.norm1.hip(x2d), B, N, None, keybias, residual=x2d)
         x2 = self.attn2.hip(self.norm2.hip(x1), B, N, context, None, residual=x1)
         return self.ff.hip(self.norm3.hip(x2), residual=x2)
+
+    def post_done(self, M, C, post) -> bool:
+        """Whether ``hip(..., post=post)`` on [M, C] rows runs the caller's proj_out + residual itself (the one-launch feed-forward with its tail, af_ff_chain)."""
+        return bool(post is not None and CHAIN_PROJ_OUT and FOLD_LAYERNORM and C % 64 == 0 and self.ff.ff_fusable(M, C, self.norm3))
 
     def hip_train(self, x2d, B, N, context=None, keybias=None):
         if FOLD_LAYERNORM and x2d.shape[1] % 64 == 0 and x2d.shape[0] >= 1024:
@@ -416,12 +431,20 @@ class SpatialTransformer(nn.Module):
         kb = None
         if mask is not None:
             kb = self._keybias(mask, B, H, W)
-        for block in self.transformer_blocks:
-            block.attn2.infeat_size = (H, W)
-            y = block.hip(y, B, N, context, kb)
         # the block's output feeds the next GroupNorm(32) (a ResBlock's first norm or the output norm) when it is not concatenated first: leave
         # the partial statistics with it (ops.GnPartials)
-        out = ops.gemm(y, self.proj_out.packed(), residual=x.reshape(B * N, Cn), rows_per_batch=N, gn_cpg=Cn // 32 if Cn % 32 == 0 else 0)
+        cpg = Cn // 32 if Cn % 32 == 0 else 0
+        last = len(self.transformer_blocks) - 1
+        post = (self.proj_out.packed(), x.reshape(B * N, Cn), N, cpg)
+        chained = False
+        for i, block in enumerate(self.transformer_blocks):
+            block.attn2.infeat_size = (H, W)
+            if i == last and block.post_done(B * N, y.shape[1], post):
+                # round 6: proj_out + residual as the tail of the last block's one-launch feed-forward (C = 320, the 64 x 64 level: af_ff_chain)
+                y, chained = block.hip(y, B, N, context, kb, post=post), True
+            else:
+                y = block.hip(y, B, N, context, kb)
+        out = y if chained else ops.gemm(y, self.proj_out.packed(), residual=x.reshape(B * N, Cn), rows_per_batch=N, gn_cpg=cpg)
         out4 = out.reshape(B, H, W, Cn)
         if hasattr(out, "_gn_partials"):
             out4._gn_partials = out._gn_partials      # a view: same storage address and version counter (ops.partials_of)

@@ -614,6 +614,32 @@ def ff_fused(x2d: torch.Tensor, pw1: PackedWeight, pw2: PackedWeight, residual: 
     return out
 
 
+def ff_chain(x2d: torch.Tensor, pw1: PackedWeight, pw2: PackedWeight, residual: torch.Tensor, pw_p: PackedWeight, x_in: torch.Tensor, *, rows_per_batch: int,
+             gn_cpg: int = 0) -> torch.Tensor:
+    """af_ff_chain: `ff_fused` with the SpatialTransformer's proj_out + residual behind it, one launch -- out = x_in + b_p + W_p (residual + b2 + W2 (v * gelu(g))).
+    gn_cpg > 0: `out` feeds a GroupNorm with groups of gn_cpg channels; where the shape allows, the launch leaves the partial statistics with it (GnPartials)."""
+    _chk_f16(x2d, "ff_chain.x")
+    _chk_f16(residual, "ff_chain.residual")
+    _chk_f16(x_in, "ff_chain.x_in")
+    M, Cn = x2d.shape
+    assert pw1.K == Cn and pw2.N == Cn and pw2.K * 2 == pw1.N and pw1.bias is not None and pw_p.N == Cn and pw_p.K == Cn and pw_p.ln_cs is None
+    assert residual.shape == x2d.shape and x_in.shape == x2d.shape and M % rows_per_batch == 0
+    out = torch.empty((M, Cn), dtype=F16, device=x2d.device)
+    gn, gnp = None, None
+    if gn_cpg and GN_FROM_PRODUCER and gn_cpg % 2 == 0 and Cn % gn_cpg == 0 and Cn // gn_cpg <= 32 and rows_per_batch % 128 == 0 and rows_per_batch // 128 <= 128:
+        nb = M // rows_per_batch
+        ws = torch.empty((nb, 128, 32, 2), dtype=torch.float32, device=x2d.device)
+        gn, gnp = GnPartials(ws, rows_per_batch // 128, gn_cpg, nb, rows_per_batch, Cn), ws.data_ptr()
+    _pf_note(pw1.wt, pw2.wt, pw_p.wt)
+    rc = _lib.lib().af_ff_chain(_p(x2d), _p(pw1.wt), _p(pw1.bias), _p(pw1.ln_cs), float(pw1.ln_eps), pw1.kpad, _p(pw2.wt), _p(pw2.bias), pw2.kpad, _p(residual),
+                                _p(pw_p.wt), _p(pw_p.bias), pw_p.kpad, _p(x_in), _p(out), gnp, int(gn_cpg if gn is not None else 0), int(rows_per_batch), M, Cn, pw2.K,
+                                _p(_zero_page(x2d.device)), _stream())
+    _lib.check(rc, "af_ff_chain")
+    if gn is not None:
+        gn.attach(out)
+    return out
+
+
 # ----------------------------------------------------------------------------- norms
 _gn_ws = {}
 

@@ -209,6 +209,15 @@ int af_splitk_reduce(const void* slabs, int splits, const void* bias, const void
  * zeros as af_gemm_desc.zeros.  AF_E_UNSUPPORTED for any other C.                                                              */
 int af_ff_fused(const void* x, const void* w1, const void* b1, const void* ln_colsum, float ln_eps, int kpad1, const void* w2, const void* b2,
                 int kpad2, const void* residual, void* out, int M, int C, int inner, const void* zeros, void* stream);
+/* The same feed-forward with the SpatialTransformer's proj_out + residual behind it (round 6; attention.py:287-304: x = proj_out(blocks(...)) + x_in), one launch:
+ *     x3  = residual + b2 + W2 (v * gelu_erf(g))        (af_ff_fused's result: here it never leaves the compute unit)
+ *     out = x_in + bp + Wp x3
+ * wp: fp16 packed [>= C rows][kpad_p], bp fp32 [C] (may be NULL), x_in fp16 [M, C].  gn_partials (may be NULL): the GroupNorm partial statistics of `out` as
+ * af_gemm_desc.gn_partials leaves them, [M / rows_per_batch][128][32][2] floats, groups of gn_cpg channels, rows_per_batch a multiple of 128 (at most 128 blocks).
+ * C = 320 only (AF_E_UNSUPPORTED otherwise); out / residual / x_in / b2 / bp 16-byte aligned. */
+int af_ff_chain(const void* x, const void* w1, const void* b1, const void* ln_colsum, float ln_eps, int kpad1, const void* w2, const void* b2, int kpad2,
+                const void* residual, const void* wp, const void* bp, int kpad_p, const void* x_in, void* out, void* gn_partials, int gn_cpg,
+                int rows_per_batch, int M, int C, int inner, const void* zeros, void* stream);
 
 /* Whole cross-attention block of a transformer layer at C = 320, 8 heads (the 64 x 64 level of SD-1.5) in ONE launch (replaces
  * attention.py:168-222 + the norm2 of :242-252): out = residual + bo + Wo . concat_h(softmax(q_h K_h^T scale) V_h), q = LN(x) Wq^T.

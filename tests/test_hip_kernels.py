@@ -1032,6 +1032,53 @@ def test_ff_fused_c320(dev, M, with_ln, with_res):
         assert torch.equal(y, out)
 
 
+@pytest.mark.parametrize("B,N,with_gn", [(2, 256, True), (1, 384, False), (3, 128, True), (8, 4096, True)])
+def test_ff_chain_c320_proj_out_tail(dev, B, N, with_gn):
+    """af_ff_chain: the one-launch C = 320 feed-forward with the SpatialTransformer's proj_out + residual as its tail (attention.py:287-304) against the same chain
+    in fp32, and BIT FOR BIT against the two launches it replaces (af_ff_fused, then the proj_out GEMM with x_in as residual: the intermediate takes the same fp16
+    rounding in LDS as in memory); the GroupNorm partials it leaves give the same GroupNorm as the tensor's own statistics.  The 8 x 4096 case is what the
+    SpatialTransformer of the 64 x 64 level launches."""
+    from adaface_dev_amd import ops
+    from adaface_dev_amd.ldm.modules import attention as A
+    from adaface_dev_amd.ldm.modules.diffusionmodules.util import LayerNorm
+    C, M = 320, B * N
+    x, g, b = _ln_inputs(M, C)
+    x_in = rnd((M, C), 21)
+    ff, ln = A.FeedForward(C, glu=True).to(dev), LayerNorm(C).to(dev)
+    wp, bp = rnd((C, C), 22, C ** -0.5), torch.randn(C, generator=torch.Generator().manual_seed(23)) * 0.1
+    with torch.no_grad():
+        ff.net[0].proj.weight.copy_(rnd((8 * C, C), 2, C ** -0.5).float())
+        ff.net[0].proj.bias.copy_(torch.randn(8 * C, generator=torch.Generator().manual_seed(3)) * 0.1)
+        ff.net[2].weight.copy_(rnd((C, 4 * C), 4, (4 * C) ** -0.5).float())
+        ff.net[2].bias.copy_(torch.randn(C, generator=torch.Generator().manual_seed(5)) * 0.1)
+        ln.weight.copy_(g)
+        ln.bias.copy_(b)
+    pw1, pw2, pwp = ff.net[0].packed_ln(ln), ff.net[2].packed(), ops.pack_matrix(wp, bp, dev)
+    out = ops.ff_chain(x.to(dev), pw1, pw2, x.to(dev), pwp, x_in.to(dev), rows_per_batch=N, gn_cpg=10 if with_gn else 0)
+    # two launches
+    x3 = ops.ff_fused(x.to(dev), pw1, pw2, residual=x.to(dev))
+    out2 = ops.gemm(x3, pwp, residual=x_in.to(dev), tile=7)
+    assert torch.equal(out, out2) or rel_l2(out.float().cpu().numpy(), out2.float().cpu().numpy()) < 2e-4      # (same products; the GEMM's K order may differ by tile)
+    # fp32
+    if M <= 4096:
+        h = F.layer_norm(x.float(), (C,), g, b, 1e-5) @ ff.net[0].proj.weight.detach().float().cpu().t() + ff.net[0].proj.bias.detach().float().cpu()
+        xv, gv = h.chunk(2, dim=-1)
+        r3 = (xv * F.gelu(gv)) @ ff.net[2].weight.detach().float().cpu().t() + ff.net[2].bias.detach().float().cpu() + x.float()
+        ref = r3 @ wp.float().t() + bp + x_in.float()
+        assert rel_l2(out.float().cpu().numpy(), ref.numpy()) < TOL
+    if with_gn:
+        gn = ops.partials_of(out)
+        assert gn is not None and gn.cpg == 10
+        gam, bet = torch.randn(C, generator=torch.Generator().manual_seed(7)) * 0.2 + 1, torch.randn(C, generator=torch.Generator().manual_seed(8)) * 0.2
+        y_p = ops.groupnorm(out.reshape(B, N, C), gam.to(dev), bet.to(dev), 1e-5, True)            # from the partials
+        y_s = ops.groupnorm(out.clone().reshape(B, N, C), gam.to(dev), bet.to(dev), 1e-5, True)    # its own statistics pass
+        assert rel_l2(y_p.float().cpu().numpy(), y_s.float().cpu().numpy()) < 1e-3
+    else:
+        assert ops.partials_of(out) is None
+    for _ in range(3):
+        assert torch.equal(ops.ff_chain(x.to(dev), pw1, pw2, x.to(dev), pwp, x_in.to(dev), rows_per_batch=N, gn_cpg=0), out)
+
+
 @pytest.mark.parametrize("C", [320, 640])
 @pytest.mark.parametrize("B,N,L,with_ln,with_res,ld_extra", [(2, 256, 77, True, True, 0), (1, 128, 77, False, False, 0), (3, 384, 80, True, False, 0),
                                                              (2, 128, 40, True, True, 0), (2, 128, 37, True, True, 0), (2, 256, 77, True, True, 16),
